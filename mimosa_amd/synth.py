@@ -1,0 +1,230 @@
+"""Synthetic "rooms" world + Ouster OS0-128 scan generator.
+
+Test / bench tooling only — deterministic, counter-based RNG (splitmix64(seed ^ index)) so the
+same world can be regenerated on the GPU box without shipping data.  Nothing here is on the
+product path; the product consumes plain float32 arrays through the C ABI.
+
+World: closed axis-aligned box rooms, interior 74 x 55 x 18 m, tiled on a grid with 1 m walls;
+surfaces sampled on a 0.16 m jittered grid (+-0.005 m in-plane) with Gaussian normal noise
+sigma = 0.02 m (a perfectly planar map is rejected wholesale by the reference:
+geometric_factor.hpp:202-206).  One room ~ 0.5 M points.
+
+Scan: OS0-128 model, 128 beams (+45.9 .. -45.9 deg, uniform — the real table in
+config/enwide/os_enwide.json is near-uniform), 1024 columns, column c fired at c * 97_656 ns,
+beam origin 27.67 mm off the axis, range noise sigma = 0.02 m; row-major point order
+(idx = row * 1024 + col), exactly 131 072 points (every ray hits the room).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ROOM = np.array([74.0, 55.0, 18.0])
+WALL = 1.0
+GRID = 0.16
+JITTER = 0.005
+SIGMA_N = 0.02
+SENSOR_LOCAL = np.array([35.3, 26.1, 1.7])
+SENSOR_YAW = 0.3
+BASE_SEED = 0x6D696D6F7361  # "mimosa"
+COL_NS = 97_656
+N_COLS = 1024
+BEAM_ORIGIN_M = 0.02767
+
+POINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"),
+     ("t", "<u4"), ("idx", "<u4"), ("range", "<f4")]
+)
+assert POINT_DTYPE.itemsize == 32  # lidar::Point, include/mimosa/lidar/point.hpp:18-39
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (x.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _uniform(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    """U[0,1) for counter idx on (seed, stream)."""
+    with np.errstate(over="ignore"):
+        key = splitmix64(np.array([seed ^ (stream * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)], dtype=np.uint64))[0]
+        z = splitmix64(idx.astype(np.uint64) ^ key)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _normal(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    u1 = _uniform(seed, 2 * stream, idx)
+    u2 = _uniform(seed, 2 * stream + 1, idx)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# World origin offset: keeps every wall ~6 sigma away from a 0.5 m voxel boundary (walls sitting
+# exactly on a boundary would split each surface over two voxel layers and halve the bucket fill).
+WORLD_OFFSET = np.array([0.13, 0.21, 0.17])
+
+
+def room_origin(rx: int, ry: int) -> np.ndarray:
+    return WORLD_OFFSET + np.array([rx * (ROOM[0] + WALL), ry * (ROOM[1] + WALL), 0.0])
+
+
+def make_room(seed: int, rx: int, ry: int, grid: float = GRID, room=ROOM) -> np.ndarray:
+    """float32 (n,3) surface samples of one room, face by face."""
+    room = np.asarray(room, dtype=np.float64)
+    out = []
+    org = room_origin(rx, ry)
+    face_id = 0
+    counter0 = (rx * 1000 + ry) * 16
+    for axis in range(3):
+        u_ax, v_ax = [a for a in range(3) if a != axis]
+        nu, nv = int(room[u_ax] / grid), int(room[v_ax] / grid)
+        for side in (0.0, room[axis]):
+            n = nu * nv
+            idx = np.arange(n, dtype=np.uint64)
+            st = counter0 + face_id
+            ju = (2.0 * _uniform(seed, 10 * st + 1, idx) - 1.0) * JITTER
+            jv = (2.0 * _uniform(seed, 10 * st + 2, idx) - 1.0) * JITTER
+            nn = _normal(seed, 10 * st + 3, idx) * SIGMA_N
+            iu, iv = np.divmod(np.arange(n), nv)
+            p = np.empty((n, 3))
+            p[:, u_ax] = (iu + 0.5) * grid + ju
+            p[:, v_ax] = (iv + 0.5) * grid + jv
+            p[:, axis] = side + nn
+            out.append(p + org)
+            face_id += 1
+    return np.concatenate(out).astype(np.float32)
+
+
+def make_map_rooms(n_rx: int, n_ry: int, seed: int = BASE_SEED):
+    """Yield (rx, ry, float32 (n,3)) per room — one iVox insert() call per room."""
+    for rx in range(n_rx):
+        for ry in range(n_ry):
+            yield rx, ry, make_room(seed, rx, ry)
+
+
+def rot_z(a: float) -> np.ndarray:
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def so3_exp(w: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+def sensor_pose_gt() -> tuple[np.ndarray, np.ndarray]:
+    """Ground-truth T_W_L at scan end: (R, t)."""
+    return rot_z(SENSOR_YAW), room_origin(0, 0) + SENSOR_LOCAL
+
+
+def query_pose(R=None, t=None) -> tuple[np.ndarray, np.ndarray]:
+    """Pose handed to linearize: ground truth composed with a small perturbation (§8(d))."""
+    if R is None or t is None:
+        R, t = sensor_pose_gt()
+    dR = so3_exp(np.deg2rad(np.array([0.5, -0.3, 0.8])))
+    dt = np.array([0.05, -0.03, 0.02])
+    return R @ dR, t + R @ dt
+
+
+def _raycast_box(o: np.ndarray, d: np.ndarray, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tpos = np.where(d > 0, (hi - o) / d, np.where(d < 0, (lo - o) / d, np.inf))
+    return tpos.min(axis=1)
+
+
+def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
+              v=(2.0, 0.3, 0.0), w=(0.0, 0.0, 0.5), n_cols: int = N_COLS, room=ROOM,
+              sensor_local=SENSOR_LOCAL):
+    """Return (points[POINT_DTYPE] in the sensor frame, aux dict).
+
+    skew=False: every ray is cast from the scan-end pose (an already-deskewed cloud).
+    skew=True : column c is cast from the pose the sensor had at its firing time under constant
+                (v, w) ego motion (body-frame twist); aux['Rt12'] holds the exact T_Le_Lt per unique
+                timestamp (float32 R|t, 12 per group) and aux['unique_ns'] the sorted timestamps, i.e.
+                the inputs of Manager::deskewPoints' hot loop (src/lidar/manager.cpp:496-509).
+    """
+    room = np.asarray(room, dtype=np.float64)
+    R_end, t_end = rot_z(SENSOR_YAW), room_origin(0, 0) + np.asarray(sensor_local)
+    full = np.linspace(45.9, -45.9, 128)
+    alt = np.deg2rad(full[:: 128 // n_rows][:n_rows])
+    az = -2.0 * np.pi * (np.arange(n_cols) / n_cols)  # Ouster spins clockwise seen from above
+    t_ns = (np.arange(n_cols) * COL_NS * (N_COLS // n_cols)).astype(np.uint32)
+    t_end_ns = float(t_ns[-1])
+
+    rows, cols = np.meshgrid(np.arange(n_rows), np.arange(n_cols), indexing="ij")
+    rows, cols = rows.ravel(), cols.ravel()
+    ca, sa = np.cos(alt[rows]), np.sin(alt[rows])
+    cz, sz = np.cos(az[cols]), np.sin(az[cols])
+    d_s = np.stack([ca * cz, ca * sz, sa], axis=1)  # beam direction, sensor frame
+    o_s = np.stack([BEAM_ORIGIN_M * cz, BEAM_ORIGIN_M * sz, np.zeros_like(cz)], axis=1)
+
+    # per-column sensor pose in the world
+    Rc = np.empty((n_cols, 3, 3))
+    tc = np.empty((n_cols, 3))
+    Rt12 = np.empty((n_cols, 12), dtype=np.float32)
+    v, w = np.asarray(v, dtype=np.float64), np.asarray(w, dtype=np.float64)
+    for c in range(n_cols):
+        if skew:
+            dt = (t_end_ns - float(t_ns[c])) * 1e-9  # time until scan end
+            # T_Le_Lt = exp(-twist * dt): sensor at time t expressed in the scan-end frame
+            R_rel = so3_exp(-w * dt)
+            t_rel = -v * dt  # constant body velocity, first order in the rotation coupling
+            Rc[c] = R_end @ R_rel
+            tc[c] = t_end + R_end @ t_rel
+            Rt12[c, :9] = R_rel.astype(np.float32).ravel()
+            Rt12[c, 9:] = t_rel.astype(np.float32)
+        else:
+            Rc[c], tc[c] = R_end, t_end
+            Rt12[c, :9] = np.eye(3, dtype=np.float32).ravel()
+            Rt12[c, 9:] = 0
+    d_w = np.einsum("nij,nj->ni", Rc[cols], d_s)
+    o_w = tc[cols] + np.einsum("nij,nj->ni", Rc[cols], o_s)
+    lo = room_origin(0, 0)
+    rng = _raycast_box(o_w, d_w, lo, lo + room)
+    n = rows.size
+    rng = rng + _normal(seed, 7, np.arange(n, dtype=np.uint64)) * SIGMA_N
+    p_s = o_s + rng[:, None] * d_s
+
+    pts = np.zeros(n, dtype=POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = p_s[:, 0], p_s[:, 1], p_s[:, 2]
+    pts["intensity"] = 100.0
+    pts["t"] = t_ns[cols]
+    pts["idx"] = (rows * n_cols + cols).astype(np.uint32)
+    pts["range"] = np.sqrt(pts["x"] ** 2 + pts["y"] ** 2 + pts["z"] ** 2)
+    aux = {"unique_ns": t_ns.copy(), "Rt12": Rt12, "R_W_L": R_end, "t_W_L": t_end}
+    return pts, aux
+
+
+def points_xyz(pts: np.ndarray) -> np.ndarray:
+    return np.stack([pts["x"], pts["y"], pts["z"]], axis=1)
+
+
+def enwide_config() -> dict:
+    """scan_to_map block of config/enwide/params.yaml:85-100 (+ neighbor_voxel_mode :85)."""
+    return dict(
+        source_voxel_grid_filter_leaf_size=0.5, source_voxel_grid_min_dist_in_voxel=0.15,
+        target_ivox_map_leaf_size=0.5, target_ivox_map_min_dist_in_voxel=0.15,
+        num_corres_points=5, max_corres_distance=1.0, plane_validity_distance=0.07,
+        lidar_point_noise_std_dev=0.07, use_huber=1, huber_threshold=1.345, reg_4_dof=0,
+        project_on_degneneracy=0, degen_thresh_rot=0.0, degen_thresh_trans=40.0,
+    )
+
+
+ENWIDE_NEIGHBOR_MODE = 19
+ENWIDE_LRU_HORIZON = 1000
+MAX_PTS_PER_VOXEL = 20
+
+
+def small_world(seed: int = 1234, room=(6.0, 5.0, 3.0), n_rows: int = 16, n_cols: int = 64,
+                grid: float = 0.16):
+    """A tiny single-room world for fixtures / fast parity tests: ~5 k map points, 1 k scan points."""
+    room = np.asarray(room, dtype=np.float64)
+    m = make_room(seed, 0, 0, grid=grid, room=room)
+    pts, aux = make_scan(n_rows=n_rows, seed=seed + 1, n_cols=n_cols, room=room,
+                         sensor_local=np.array([2.3, 2.6, 1.2]))
+    return m, pts, aux
