@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — ICP correspondence + residual throughput (M points/s) of the HIP hot path.
+
+Metric (BASELINE.json): "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU".
+Workload at N=1 = BASELINE.json configs[1]: Ouster OS0-128 131 072-pt scan vs a ~5 M-pt local map
+(10 synthetic rooms), k=5 point-to-plane, ENWIDE parameters.
+
+A "step" = one COLD ICPFactor::linearize of the whole scan (fresh data-association state: every
+point runs the voxel-map k-NN, plane fit, residual, Jacobian; the 6x6 Hessian + localizabilities
+come back to the host).  Scan and map are resident in HBM before the timed region.  Steps are
+enqueued back-to-back on the context stream (up to 32 in flight, every result still lands in host
+memory); the synchronous per-call latency is reported alongside.
+
+One JSON line on rank 0; see the task contract for the fields.  `roofline.achieved` uses the
+ALGORITHMIC gather-model bytes of SURVEY.md §8(d): B_pt = 384 + 16 * mean(C_q) bytes per point.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+INFLIGHT = 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rooms", type=str, default="2x5", help="map size in rooms (2x5 ~ 5 M points)")
+    ap.add_argument("--rows", type=int, default=128, help="scan rows (128 -> 131 072 points)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=8)
+    return ap.parse_args()
+
+
+def build_world(rank: int, rooms: str, rows: int):
+    from mimosa_amd import synth
+
+    nx, ny = (int(v) for v in rooms.lower().split("x"))
+    room_clouds = [xyz for _, _, xyz in synth.make_map_rooms(nx, ny)]
+    # every rank scans the same room geometry with its own range-noise seed (independent scans)
+    pts, aux = synth.make_scan(rows, seed=synth.BASE_SEED + 1 + rank)
+    R, t = synth.query_pose()
+    return room_clouds, pts, R, t
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mimosa_amd import capi, synth
+
+    ctx = capi.Context(local_rank)  # raises if the HIP extension or the GPU is missing
+
+    room_clouds, pts, R, t = build_world(rank, args.rooms, args.rows)
+    cfgd = synth.enwide_config()
+    t0 = time.time()
+    gmap = capi.VoxelMap(ctx, leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
+                         max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
+                         lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    for xyz in room_clouds:
+        gmap.insert(xyz)
+    factor = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
+    n_pts = len(pts)
+    first = factor.linearize(R, t)  # uploads the map, first cold pass
+    stats = gmap.stats()
+    setup_s = time.time() - t0
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_steps(k, collect=None):
+        done = 0
+        while done < k:
+            nb = min(INFLIGHT, k - done)
+            outs = []
+            for _ in range(nb):
+                factor.reset()
+                outs.append(factor.linearize_async(R, t))
+            factor.wait()
+            if collect is not None:
+                collect.extend(outs)
+            done += nb
+
+    # ---- warmup, then the timed region (per-kernel HIP events on the launch stream are on) ----
+    ctx.set_profiling(True)
+    run_steps(args.warmup)
+    outs = []
+    barrier()
+    t_start = time.perf_counter()
+    run_steps(args.steps, outs)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    k3_ms = np.array([o.gpu_ms_linearize for o in outs], dtype=np.float64)
+    k4_ms = np.array([o.gpu_ms_localizability for o in outs], dtype=np.float64)
+    last = outs[-1].as_dict()
+    assert np.array_equal(last["H_ss"], first["H_ss"]), "cold linearize is not reproducible"
+
+    # synchronous per-call latency (result on the host before the next call), events off
+    ctx.set_profiling(False)
+    lat = []
+    for _ in range(min(50, max(10, args.steps // 4))):
+        factor.reset()
+        ctx.synchronize()
+        a = time.perf_counter()
+        factor.linearize(R, t)
+        lat.append(time.perf_counter() - a)
+    lat_ms = float(np.median(lat) * 1e3)
+
+    # untimed-by-events pipelined pass (how much the event records cost)
+    barrier()
+    a = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed_noev = time.perf_counter() - a
+
+    total_pts = n_pts * args.steps * world
+    value = total_pts / elapsed / 1e6
+    mean_cq = float(last["mean_candidates"])
+    b_pt = 384.0 + 16.0 * mean_cq
+    k3_avg_s = float(k3_ms.mean()) * 1e-3
+    achieved_gbs = n_pts * b_pt / k3_avg_s / 1e9
+
+    line = {
+        "metric": "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU",
+        "value": round(value, 3),
+        "unit": "Mpts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: OS0-128 {n_pts}-pt scan vs {stats['n_points']}-pt local map "
+                        f"({stats['n_voxels']} voxels, {args.rooms} rooms), k=5 point-to-plane, ENWIDE params, "
+                        f"cold linearize per step",
+            "mode": f"pipelined, <= {INFLIGHT} linearize calls in flight, every result copied to the host",
+            "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
+            "status_hist": [int(v) for v in last["status_hist"]],
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "icp_linearize_kernel<5,false>",
+            "achieved": round(achieved_gbs, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy_peak": round(achieved_gbs / HBM_COPY_GBS, 4),
+            "traffic": None,
+            "bytes_per_point": round(b_pt, 1),
+            "mean_candidates_per_query": round(mean_cq, 2),
+            "kernel_ms_avg": round(float(k3_ms.mean()), 5),
+            "kernel_ms_p95": round(float(np.percentile(k3_ms, 95)), 5),
+            "localizability_kernel_ms_avg": round(float(k4_ms.mean()), 5),
+        },
+        "sync_latency_ms": round(lat_ms, 4),
+        "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
+        "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
+        "setup_s": round(setup_s, 2),
+    }
+
+    # ---- CPU baseline: the oracle ("port") on the host cores, rank 0, N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_cpu
+
+        rmap = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
+                           max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
+                           lru_horizon=synth.ENWIDE_LRU_HORIZON)
+        for xyz in room_clouds:
+            rmap.insert(xyz)
+        rcfg = ref_cpu.make_config(**cfgd)
+        ncores = os.cpu_count() or 1
+        secs4, res4 = ref_cpu.time_cold(rmap, pts, rcfg, R, t, n_threads=4, iters=args.cpu_iters + 2)
+        secs_all, _ = ref_cpu.time_cold(rmap, pts, rcfg, R, t, n_threads=ncores, iters=args.cpu_iters + 2)
+        med4 = float(np.median(secs4[2:]))
+        med_all = float(np.median(secs_all[2:]))
+        from tests.parity import rel  # noqa: E402  (checker only)
+        line["cpu_baseline"] = {
+            "value": round(n_pts / med4 / 1e6, 3),
+            "unit": "Mpts/s",
+            "cores": 4,
+            "kind": "port",
+            "sample": f"the full workload ({n_pts}-pt scan vs the same map), median of {args.cpu_iters} cold "
+                      f"linearizes after 2 warm-ups, 4 OpenMP threads as hard-coded in the reference "
+                      f"(geometric_factor.hpp:261)",
+            "all_cores_value": round(n_pts / med_all / 1e6, 3),
+            "all_cores": ncores,
+        }
+        line["parity_vs_oracle"] = {
+            "H_rel": rel(last["H_ss"], res4["H_ss"]), "b_rel": rel(last["b_s"], res4["b_s"]),
+            "f_rel": abs(last["f"] - res4["f"]) / abs(res4["f"]),
+            "status_hist_equal": bool(np.array_equal(last["status_hist"], res4["status_hist"])),
+        }
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    factor.destroy()
+    gmap.release()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * mimosa_hip.h — C ABI of libmimosa_hip.so: the MI355X-native (gfx950, HIP) implementation of the
+ * LiDAR geometric-factor hot path of ntnu-arl/mimosa.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch / GTSAM
+ * types.  Every entry point names the reference interface it replaces (paths relative to the
+ * reference's mimosa/ package).  The C++ host layer in mimosa_amd/host/ (ICPFactor, Geometric,
+ * IncrementalVoxelMap, Manager) is a thin mirror of the reference classes over this ABI.
+ *
+ * Conventions
+ *  - every function returns an mh_status (0 = MH_OK); nothing throws across the boundary; per-point
+ *    failures are RejectStatus values (same enum values 0..8 as geometric_factor.hpp:35-46), never
+ *    errors.
+ *  - matrices are row-major doubles; poses are (R[9], t[3]).
+ *  - caller-owned host buffers are only read/written for the duration of the call; device memory is
+ *    owned by the library behind opaque handles.
+ *  - handles are not individually thread-safe; different handles may be used from different host
+ *    threads (the library sets the device per call; one HIP stream per context).
+ */
+#ifndef MIMOSA_HIP_H
+#define MIMOSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ABI_VERSION 1
+
+typedef enum mh_status {
+  MH_OK = 0,
+  MH_ERR_INVALID_ARG = 1,
+  MH_ERR_HIP = 2,        /* a HIP runtime call failed; see mh_last_error() */
+  MH_ERR_NO_DEVICE = 3,  /* no usable gfx950 device (the library never falls back to the CPU) */
+  MH_ERR_OOM = 4,
+  MH_ERR_UNSUPPORTED = 5
+} mh_status;
+
+/* ICPFactor::RejectStatus, include/mimosa/lidar/geometric_factor.hpp:35-46 */
+typedef enum mh_reject_status {
+  MH_UNPROCESSED = 0,
+  MH_INSUFFICIENT_CORRES_POINTS = 1,
+  MH_CORRES_MAX_DIST = 2,
+  MH_EIGEN_SOLVER_FAIL = 3,
+  MH_MIN_EIGEN_VALUE_LOW = 4,
+  MH_LINE = 5,
+  MH_CORRES_PLANE_INVALID = 6,
+  MH_MAX_ERROR = 7,
+  MH_VALID = 8
+} mh_reject_status;
+
+/* lidar::Point, include/mimosa/lidar/point.hpp:18-39 (32 bytes, 16-byte aligned) */
+typedef struct mh_point32 {
+  float x, y, z, pad;
+  float intensity;
+  uint32_t t;   /* ns since the beginning of the scan */
+  uint32_t idx; /* index in the original cloud */
+  float range;
+} mh_point32;
+
+/* lidar::RegistrationConfig, include/mimosa/lidar/geometric_config.hpp:17-33 (same field order) */
+typedef struct mh_reg_config {
+  float source_voxel_grid_filter_leaf_size;
+  float source_voxel_grid_min_dist_in_voxel;
+  float target_ivox_map_leaf_size;
+  float target_ivox_map_min_dist_in_voxel;
+  uint64_t num_corres_points; /* 2..8 supported */
+  float max_corres_distance;
+  float plane_validity_distance;
+  float lidar_point_noise_std_dev;
+  int32_t use_huber;
+  float huber_threshold;
+  int32_t reg_4_dof;
+  int32_t project_on_degneneracy; /* (sic) spelling follows the reference */
+  float degen_thresh_rot;
+  float degen_thresh_trans;
+} mh_reg_config;
+
+/* gtsam_points::iVox settings as configured by Geometric's constructor, src/lidar/geometric.cpp:23-28 */
+typedef struct mh_map_config {
+  double leaf_size;            /* scan_to_map.target_ivox_map_leaf_size */
+  double min_dist_in_cell;     /* scan_to_map.target_ivox_map_min_dist_in_voxel */
+  int32_t max_points_in_cell;  /* FlatContainer default 20 (<= 20 supported) */
+  int32_t neighbor_voxel_mode; /* 1, 7, 19 or 27 */
+  int64_t lru_horizon;         /* GeometricConfig::lru_horizon */
+  int32_t lru_clear_cycle;     /* iVox default 10 */
+  int32_t reserved;
+} mh_map_config;
+
+typedef struct mh_map_stats {
+  int64_t n_voxels;
+  int64_t n_points;
+  int64_t n_blocks;          /* 4x4x4-voxel blocks in the device block table */
+  int64_t device_bytes;      /* HBM held by this map */
+  int64_t uploads;           /* number of host->device synchronisations so far */
+  int64_t upload_bytes;      /* total bytes pushed host->device */
+} mh_map_stats;
+
+/*
+ * What gtsam::HessianFactor(key[, key2], G11, [G12,] g1, [G22, g2,] f) receives from
+ * ICPFactor::linearize (geometric_factor.hpp:459-462, 559-560) plus every getter-visible side
+ * output (getLocalizabilities :52-62, getDegenInfo :64-70, getLinearizeCount :72) and the status
+ * histogram Geometric::getFactors builds (src/lidar/geometric.cpp:280-323).
+ * The Hessian factor is HessianFactor(key, H_ss, -b_s, f).
+ */
+typedef struct mh_icp_result {
+  double H_ss[36]; /* J_s^T J_s, row-major 6x6, rotation block first (GTSAM Pose3 tangent order) */
+  double H_st[36]; /* binary factor only */
+  double H_tt[36]; /* binary factor only */
+  double b_s[6];   /* J_s^T e */
+  double b_t[6];   /* binary factor only */
+  double f;        /* sum e^2 */
+  double loc_trans_comp[3], loc_rot_comp[3], loc_trans_final[3], loc_rot_final[3];
+  double eigvec_trans[9], eigvec_rot[9]; /* eigenvectors in columns, row-major storage */
+  double degen_rot[3], degen_trans[3], degen_eigvec_rot[9], degen_eigvec_trans[9];
+  int32_t status_hist[9];
+  int32_t linearize_count;
+  double mean_candidates; /* mean number of map points scanned per query that ran k-NN */
+  int64_t n_knn;          /* queries that ran k-NN in this call (the rest hit the DA cache) */
+  /* device-side timing of this call, ms; filled only when profiling is on (mh_set_profiling) */
+  float gpu_ms_linearize; /* icp_linearize kernel (K3) */
+  float gpu_ms_localizability; /* component-localizability kernel (K4) */
+} mh_icp_result;
+
+typedef struct mh_ctx mh_ctx;
+typedef struct mh_map mh_map;
+typedef struct mh_icp mh_icp;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int mh_abi_version(void);
+/* Binds a context to HIP device `device` and creates its stream.  MH_ERR_NO_DEVICE if there is no
+ * GPU: there is no CPU fallback. */
+int mh_init(int device, mh_ctx ** out);
+void mh_shutdown(mh_ctx * ctx);
+/* Last error text for this context (or the calling thread when ctx == NULL). */
+const char * mh_last_error(const mh_ctx * ctx);
+/* Per-kernel HIP-event timing inside mh_icp_linearize / mh_icp_linearize_async (off by default). */
+int mh_set_profiling(mh_ctx * ctx, int on);
+/* hipStream_t of the context, for callers that want to order their own work / events on it. */
+void * mh_stream(mh_ctx * ctx);
+int mh_synchronize(mh_ctx * ctx);
+/* Event pair on the context stream: begin/end bracket, returns elapsed ms (synchronises). */
+int mh_timer_begin(mh_ctx * ctx);
+int mh_timer_end(mh_ctx * ctx, float * ms);
+
+/* ---- target map: IncrementalVoxelMapPCL / gtsam_points::iVox --------------------------------
+ * replaces include/mimosa/lidar/incremental_voxel_map.hpp:22-54, src/lidar/incremental_voxel_map.cpp:14-62 */
+int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out); /* ctor, geometric.cpp:23-28 */
+/* IncrementalVoxelMapPCL::insert (incremental_voxel_map.cpp:19-24): greedy first-come-first-kept
+ * insertion in input order (min-distance rule, per-voxel cap, LRU purge) then device sync of the
+ * touched buckets.  xyz: n points, `stride_floats` floats apart (3 for packed xyz, 8 for mh_point32). */
+int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_floats);
+/* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by
+ * Geometric::updateMap's copy-then-insert (geometric.cpp:494). */
+int mh_map_copy(const mh_map * map, mh_map ** out);
+/* shared_ptr semantics: factors retain the map they were built with. */
+int mh_map_retain(mh_map * map);
+void mh_map_release(mh_map * map);
+int mh_map_get_stats(const mh_map * map, mh_map_stats * out);
+/* IncrementalVoxelMapPCL::getCloud (incremental_voxel_map.cpp:34-38): all points in voxel order.
+ * xyz may be NULL to query the size; returns the number of points through n_out. */
+int mh_map_get_cloud(const mh_map * map, float * xyz, size_t capacity_points, size_t * n_out);
+/* IncrementalVoxelMapPCL::knn_search (incremental_voxel_map.cpp:26-32) for a batch of fp64 queries,
+ * run on the device.  point_xyz (n*k*3 doubles) receives the neighbour coordinates
+ * (ivox->point(id), geometric_factor.hpp:184), sq_dists n*k ascending, found[n] = number found
+ * (the reference returns found == k). */
+int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * point_xyz,
+               double * sq_dists, int32_t * found);
+
+/* ---- ICPFactor ------------------------------------------------------------------------------
+ * replaces include/mimosa/lidar/geometric_factor.hpp:25-563 */
+/* ctor (:119-156): copies the source cloud to the device, retains the map, allocates the per-point
+ * data-association state zero-initialised. */
+int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n,
+                  const mh_reg_config * cfg, int is_binary, mh_icp ** out);
+/* clone() (:160-164): deep-copies the per-point state, shares the map. */
+int mh_icp_clone(const mh_icp * icp, mh_icp ** out);
+void mh_icp_destroy(mh_icp * icp);
+/* linearize(Values) (:231-562).  T_src = Values[keys[0]]; (R_tgt, t_tgt) = Values[keys[1]] for a
+ * binary factor, NULL for unary; g_unit = Values[G(0)].unitVector() (read unconditionally, :257).
+ * Blocks until the result is on the host. */
+int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3],
+                     const double * R_tgt, const double * t_tgt, const double g_unit[3],
+                     mh_icp_result * out);
+/* Same work enqueued on the context stream without waiting; the result is written to *out (which
+ * must stay valid) when mh_icp_wait / mh_synchronize returns. Up to 64 calls may be in flight. */
+int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3],
+                           const double * R_tgt, const double * t_tgt, const double g_unit[3],
+                           mh_icp_result * out);
+int mh_icp_wait(mh_icp * icp);
+/* getStatuses / getCorresMeansTarget / getCorresNormalsTarget (:48-50); any pointer may be NULL. */
+int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals);
+/* Forget all data associations (== a freshly constructed factor): enqueued, no host sync. */
+int mh_icp_reset(mh_icp * icp);
+size_t mh_icp_size(const mh_icp * icp);
+
+/* ---- deskew / rigid transforms ----------------------------------------------------------------
+ * Manager::deskewPoints hot loop (src/lidar/manager.cpp:496-509): every point whose t equals
+ * unique_ns[g] gets p <- R_g p + t_g in float (no FMA, Eigen's evaluation order).  Rt12 = n_groups x
+ * {R row-major 9 floats, t 3 floats}.  If R_B_L != NULL the Geometric::preprocess body transform
+ * (src/lidar/geometric.cpp:154-161) is applied afterwards in the same kernel. In place, host buffers. */
+int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns,
+              const float * Rt12, size_t n_groups, const float * R_B_L, const float * t_B_L);
+/* p <- R p + t in float for a whole cloud (body transform geometric.cpp:154-161, world transform
+ * geometric.cpp:483-490). In place, host buffers. */
+int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMOSA_HIP_H */

@@ -1,0 +1,69 @@
+"""Build libmimosa_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the snapshot
+(git-ignored, not gpurun-ignored).  `python -m mimosa_amd.build` rebuilds.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmimosa_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  deskew_kernels.hip must not contract a*b+c into FMA: the reference's f32
+# transforms are plain mul/add (baseline x86-64 build) and the results feed voxel hashing.
+SOURCES = [
+    ("icp_kernels.hip", []),
+    ("deskew_kernels.hip", ["-ffp-contract=off"]),
+    ("mh_api.hip", []),
+]
+HEADERS = ["icp_device.hpp", "math3.hpp", "voxel_map.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
+                   "-Wno-unused-parameter", *extra, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

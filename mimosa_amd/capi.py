@@ -1,0 +1,345 @@
+"""ctypes binding over libmimosa_hip.so (include/mimosa_hip.h) — test / bench tooling.
+
+Thin and literal: one Python method per C entry point, numpy arrays for the plain buffers.  There is
+no fallback of any kind: if the library is missing, or no GPU is present, these raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+
+MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSUPPORTED = range(6)
+
+# every symbol include/mimosa_hip.h declares
+EXPORTS = [
+    "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
+    "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
+    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_get_stats",
+    "mh_map_get_cloud", "mh_map_knn",
+    "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
+    "mh_icp_wait", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
+    "mh_deskew", "mh_transform_f32",
+]
+
+
+class MhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mimosa_hip error {code}: {msg}")
+        self.code = code
+
+
+class RegConfig(C.Structure):
+    _fields_ = [
+        ("source_voxel_grid_filter_leaf_size", C.c_float),
+        ("source_voxel_grid_min_dist_in_voxel", C.c_float),
+        ("target_ivox_map_leaf_size", C.c_float),
+        ("target_ivox_map_min_dist_in_voxel", C.c_float),
+        ("num_corres_points", C.c_uint64),
+        ("max_corres_distance", C.c_float),
+        ("plane_validity_distance", C.c_float),
+        ("lidar_point_noise_std_dev", C.c_float),
+        ("use_huber", C.c_int32),
+        ("huber_threshold", C.c_float),
+        ("reg_4_dof", C.c_int32),
+        ("project_on_degneneracy", C.c_int32),
+        ("degen_thresh_rot", C.c_float),
+        ("degen_thresh_trans", C.c_float),
+    ]
+
+
+class MapConfig(C.Structure):
+    _fields_ = [
+        ("leaf_size", C.c_double), ("min_dist_in_cell", C.c_double), ("max_points_in_cell", C.c_int32),
+        ("neighbor_voxel_mode", C.c_int32), ("lru_horizon", C.c_int64), ("lru_clear_cycle", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class MapStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_voxels", "n_points", "n_blocks", "device_bytes", "uploads", "upload_bytes")]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("H_ss", C.c_double * 36), ("H_st", C.c_double * 36), ("H_tt", C.c_double * 36),
+        ("b_s", C.c_double * 6), ("b_t", C.c_double * 6), ("f", C.c_double),
+        ("loc_trans_comp", C.c_double * 3), ("loc_rot_comp", C.c_double * 3),
+        ("loc_trans_final", C.c_double * 3), ("loc_rot_final", C.c_double * 3),
+        ("eigvec_trans", C.c_double * 9), ("eigvec_rot", C.c_double * 9),
+        ("degen_rot", C.c_double * 3), ("degen_trans", C.c_double * 3),
+        ("degen_eigvec_rot", C.c_double * 9), ("degen_eigvec_trans", C.c_double * 9),
+        ("status_hist", C.c_int32 * 9), ("linearize_count", C.c_int32),
+        ("mean_candidates", C.c_double), ("n_knn", C.c_int64),
+        ("gpu_ms_linearize", C.c_float), ("gpu_ms_localizability", C.c_float),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = np.array(v) if hasattr(v, "__len__") else v
+        for k in ("H_ss", "H_st", "H_tt"):
+            d[k] = d[k].reshape(6, 6)
+        for k in ("eigvec_trans", "eigvec_rot", "degen_eigvec_rot", "degen_eigvec_trans"):
+            d[k] = d[k].reshape(3, 3)
+        return d
+
+
+def make_reg_config(**kw) -> RegConfig:
+    c = RegConfig()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libmimosa_hip.so.  Raises if it cannot be built / found — never substitutes anything."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise FileNotFoundError(path)
+        _build.build()
+    L = C.CDLL(path)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    pvp = C.POINTER(C.c_void_p)
+    L.mh_abi_version.restype = i32
+    L.mh_init.argtypes = [i32, pvp]
+    L.mh_shutdown.argtypes = [vp]
+    L.mh_shutdown.restype = None
+    L.mh_last_error.argtypes = [vp]
+    L.mh_last_error.restype = C.c_char_p
+    L.mh_set_profiling.argtypes = [vp, i32]
+    L.mh_stream.argtypes = [vp]
+    L.mh_stream.restype = vp
+    L.mh_synchronize.argtypes = [vp]
+    L.mh_timer_begin.argtypes = [vp]
+    L.mh_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mh_map_create.argtypes = [vp, C.POINTER(MapConfig), pvp]
+    L.mh_map_insert.argtypes = [vp, vp, sz, sz]
+    L.mh_map_copy.argtypes = [vp, pvp]
+    L.mh_map_retain.argtypes = [vp]
+    L.mh_map_release.argtypes = [vp]
+    L.mh_map_release.restype = None
+    L.mh_map_get_stats.argtypes = [vp, C.POINTER(MapStats)]
+    L.mh_map_get_cloud.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.mh_map_knn.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.mh_icp_create.argtypes = [vp, vp, vp, sz, C.POINTER(RegConfig), i32, pvp]
+    L.mh_icp_clone.argtypes = [vp, pvp]
+    L.mh_icp_destroy.argtypes = [vp]
+    L.mh_icp_destroy.restype = None
+    L.mh_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_icp_wait.argtypes = [vp]
+    L.mh_icp_get_state.argtypes = [vp, vp, vp, vp]
+    L.mh_icp_reset.argtypes = [vp]
+    L.mh_icp_size.argtypes = [vp]
+    L.mh_icp_size.restype = sz
+    L.mh_deskew.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    L.mh_transform_f32.argtypes = [vp, vp, sz, vp, vp]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.mh_init(device, C.byref(h))
+        if rc != MH_OK:
+            raise MhError(rc, (self.L.mh_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+        self._children = 0
+        self._closing = False
+
+    def _child_released(self):
+        self._children -= 1
+        if self._closing and self._children == 0:
+            self.close()
+
+    def check(self, rc):
+        if rc != MH_OK:
+            raise MhError(rc, (self.L.mh_last_error(self.h) or b"").decode())
+
+    def set_profiling(self, on: bool):
+        self.check(self.L.mh_set_profiling(self.h, int(on)))
+
+    def synchronize(self):
+        self.check(self.L.mh_synchronize(self.h))
+
+    def timer_begin(self):
+        self.check(self.L.mh_timer_begin(self.h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        self.check(self.L.mh_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def deskew(self, pts, unique_ns, Rt12, R_B_L=None, t_B_L=None):
+        pts = np.ascontiguousarray(pts).copy()
+        u = np.ascontiguousarray(unique_ns, dtype=np.uint32)
+        P = np.ascontiguousarray(Rt12, dtype=np.float32)
+        Rb = np.ascontiguousarray(R_B_L, dtype=np.float32) if R_B_L is not None else None
+        tb = np.ascontiguousarray(t_B_L, dtype=np.float32) if t_B_L is not None else None
+        self.check(self.L.mh_deskew(self.h, _p(pts), len(pts), _p(u), _p(P), len(u), _p(Rb), _p(tb)))
+        return pts
+
+    def transform_f32(self, pts, R, t):
+        pts = np.ascontiguousarray(pts).copy()
+        R = np.ascontiguousarray(R, dtype=np.float32)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        self.check(self.L.mh_transform_f32(self.h, _p(pts), len(pts), _p(R), _p(t)))
+        return pts
+
+    def close(self):
+        """Shut the context down; deferred until every map / factor created on it is released."""
+        if getattr(self, "h", None):
+            if self._children > 0:
+                self._closing = True
+                return
+            self.L.mh_shutdown(self.h)
+            self.h = None
+
+
+class VoxelMap:
+    """IncrementalVoxelMapPCL counterpart (include/mimosa/lidar/incremental_voxel_map.hpp:22-54)."""
+
+    def __init__(self, ctx: Context, leaf=0.5, min_dist=0.15, max_pts=20, mode=19, lru_horizon=1000,
+                 lru_clear_cycle=10, _h=None):
+        self.ctx, self.L = ctx, ctx.L
+        ctx._children += 1
+        if _h is not None:
+            self.h = _h
+            return
+        cfg = MapConfig(leaf, min_dist, max_pts, mode, lru_horizon, lru_clear_cycle, 0)
+        h = C.c_void_p()
+        ctx.check(self.L.mh_map_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def insert(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self.ctx.check(self.L.mh_map_insert(self.h, _p(xyz), xyz.shape[0], 3))
+
+    def copy(self):
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_map_copy(self.h, C.byref(h)))
+        return VoxelMap(self.ctx, _h=h)
+
+    def stats(self) -> dict:
+        s = MapStats()
+        self.ctx.check(self.L.mh_map_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def get_cloud(self):
+        n = C.c_size_t()
+        self.ctx.check(self.L.mh_map_get_cloud(self.h, None, 0, C.byref(n)))
+        xyz = np.empty((n.value, 3), np.float32)
+        self.ctx.check(self.L.mh_map_get_cloud(self.h, _p(xyz), n.value, C.byref(n)))
+        return xyz
+
+    def knn(self, q, k=5):
+        q = _f64(q).reshape(-1, 3)
+        n = q.shape[0]
+        pts = np.empty((n, k, 3))
+        sq = np.empty((n, k))
+        found = np.empty(n, np.int32)
+        self.ctx.check(self.L.mh_map_knn(self.h, _p(q), n, k, _p(pts), _p(sq), _p(found)))
+        return pts, sq, found
+
+    def release(self):
+        if getattr(self, "h", None):
+            self.L.mh_map_release(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class ICPFactor:
+    """lidar::ICPFactor counterpart (include/mimosa/lidar/geometric_factor.hpp:25-563)."""
+
+    def __init__(self, ctx: Context, map_: VoxelMap, pts, cfg: RegConfig, binary=False, _h=None, _n=None):
+        self.ctx, self.L, self.map = ctx, ctx.L, map_
+        ctx._children += 1
+        if _h is not None:
+            self.h, self.n = _h, _n
+            return
+        pts = np.ascontiguousarray(pts)
+        assert pts.dtype.itemsize == 32
+        h = C.c_void_p()
+        ctx.check(self.L.mh_icp_create(ctx.h, map_.h, _p(pts), len(pts), C.byref(cfg), int(binary), C.byref(h)))
+        self.h, self.n = h, len(pts)
+        self._keep = []
+
+    def clone(self):
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_icp_clone(self.h, C.byref(h)))
+        c = ICPFactor(self.ctx, self.map, None, None, _h=h, _n=self.n)
+        c._keep = []
+        return c
+
+    def linearize(self, R, t, g_unit=(0.0, 0.0, -1.0), R_tgt=None, t_tgt=None) -> dict:
+        out = IcpResult()
+        R, t, g = _f64(R), _f64(t), _f64(g_unit)
+        Rt = _f64(R_tgt) if R_tgt is not None else None
+        tt = _f64(t_tgt) if t_tgt is not None else None
+        self.ctx.check(self.L.mh_icp_linearize(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
+        return out.as_dict()
+
+    def linearize_async(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> IcpResult:
+        out = IcpResult()
+        R, t, g = _f64(R), _f64(t), _f64(g_unit)
+        self._keep.append((out, R, t, g))
+        self.ctx.check(self.L.mh_icp_linearize_async(self.h, _p(R), _p(t), None, None, _p(g), C.byref(out)))
+        return out
+
+    def wait(self):
+        self.ctx.check(self.L.mh_icp_wait(self.h))
+        self._keep = []
+
+    def reset(self):
+        self.ctx.check(self.L.mh_icp_reset(self.h))
+
+    def state(self):
+        st = np.empty(self.n, np.int32)
+        means = np.empty((self.n, 3))
+        normals = np.empty((self.n, 3))
+        self.ctx.check(self.L.mh_icp_get_state(self.h, _p(st), _p(means), _p(normals)))
+        return st, means, normals
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.mh_icp_destroy(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

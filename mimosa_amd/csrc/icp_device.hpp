@@ -1,0 +1,81 @@
+// Kernel argument / device-result structs shared by the HIP kernels and the C-ABI implementation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "voxel_map.hpp"
+
+namespace mh
+{
+constexpr int kPartialStride = 96;  // >= 91 sums of the binary factor + 2 counters
+
+// Read-only view of the device-resident voxel map (see voxel_map.hpp for the layout).
+struct MapView
+{
+  const int4 * table;
+  const uint32_t * cells;
+  const float4 * buckets;
+  double inv_leaf;
+  uint32_t mask;
+  int n_off;
+  int8_t off[27][3];  // neighbour offsets in generation order
+};
+
+// Everything linearize() returns from the device in one small D2H copy.
+struct DeviceResult
+{
+  double sums[kPartialStride];  // upper triangle of sum v v^T, v = [J_s(6) (,J_t(6)), e]
+  double loc_rot_final[3], eig_rot[9], loc_trans_final[3], eig_trans[9];
+  double loc_comp[6];     // trans xyz, rot xyz
+  unsigned long long n_knn, n_cand;
+  unsigned int status_hist[9];
+  unsigned int pad;
+};
+
+struct IcpArgs
+{
+  MapView map;
+  const float4 * src;  // source cloud xyz (w unused), 16 B / point
+  int n;
+  int k;
+  int cold;       // 1: treat the per-point state as freshly constructed (all zero)
+  int use_huber;
+  double R[9], t[3];  // delta pose  T_tgt^-1 * T_src
+  double da_thresh, max_d2, plane_valid, sigma, huber;
+  double * q_da;
+  double * mean;
+  double * normal;
+  int32_t * status;
+  double * partials;
+  unsigned int * ticket;
+  DeviceResult * result;
+};
+
+struct LocArgs
+{
+  const float4 * src;
+  int n;
+  double R[9];
+  const double * normal;
+  const int32_t * status;
+  double * partials;
+  unsigned int * ticket;
+  DeviceResult * result;
+};
+
+int linearize_grid(int n);
+int localizability_grid(int n);
+hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream);
+hipError_t launch_localizability(const LocArgs & a, hipStream_t stream);
+hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
+                          int32_t * found, hipStream_t stream);
+
+// deskew_kernels.hip
+hipError_t launch_deskew(mh_point32 * pts, int n, const uint32_t * unique_ns, const float * Rt12, int n_groups,
+                         const float * body_Rt12, hipStream_t stream);
+hipError_t launch_transform(mh_point32 * pts, int n, const float * Rt12, hipStream_t stream);
+hipError_t launch_pack_xyz(const mh_point32 * pts, int n, float4 * xyz, hipStream_t stream);
+
+}  // namespace mh

@@ -1,0 +1,765 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for ICPFactor::linearize.
+//
+// Reference: include/mimosa/lidar/geometric_factor.hpp:231-562 (linearize), :176-229
+// (estimatePlane), src/lidar/incremental_voxel_map.cpp:26-32 -> gtsam_points::iVox::knn_search.
+// SURVEY.md Appendix A is the arithmetic spec; kernels K3 / K4 of SURVEY.md §2.3.
+//
+//   K3  icp_linearize_kernel   one thread per source point, 512-thread workgroups (one per CU at
+//       131 072 points), fused:
+//         pose transform (fp64) -> data-association cache test
+//         A. neighbourhood lookup: 8 block-table probes + all neighbour-cell loads issued together,
+//            occupied voxels compacted into a per-lane list in LDS
+//         B. flattened scan of the listed 320-byte buckets (the wave runs max-over-lanes of the
+//            TOTAL candidate count, ~100, instead of offsets x slots, ~300), fp64 distances in the
+//            reference's exact operation order, branch-free top-(k+1) by v_min/v_max_f64 on keys
+//            whose low 10 mantissa bits carry (list slot, bucket slot); a lane whose kept keys
+//            collide after truncation re-runs an exact insertion scan, so the selection is always
+//            bit-identical to KnnResult::push
+//         C. mean / covariance / closed-form symmetric 3x3 eigen / plane gates -> residual, Huber
+//            weight, Jacobian row
+//         D. LDS tile of rows -> every thread owns one (entry, point-segment) of the 28 (unary) or
+//            91 (binary) sums of v v^T -> per-block partial row (write-through) -> ticket -> the
+//            last-arriving block folds all rows in a fixed order and eigen-decomposes H_rr, H_tt.
+//   K4  icp_localizability_kernel   second pass: component localizabilities in that eigenbasis
+//       (geometric_factor.hpp:434-457) + status histogram (src/lidar/geometric.cpp:280-323).
+//
+// Gather / scan / reduce work bound by the memory system and VALU issue, not a dense contraction:
+// no MFMA.  Measured on MI355X (round 1): cooperating sub-groups of 2/4/8 lanes per query with
+// shuffle-min merges were 1.4x/2.5x/4.9x SLOWER than one lane per query (the kernel is issue-bound,
+// and neighbouring scan points share buckets through L1/L2 anyway), so the wave-level cooperation
+// lives in the reductions, not in the k-NN.
+#include <hip/hip_runtime.h>
+
+#include "icp_device.hpp"
+#include "math3.hpp"
+
+namespace mh
+{
+namespace
+{
+constexpr int kThreads = 512;
+constexpr int kMaxOff = 27;
+constexpr double kDblMax = 1.7976931348623157e308;
+constexpr uint64_t kPayloadMask = 0x3FFull;  // 5 bits list slot, 5 bits bucket slot
+
+// Squared distance exactly as the reference's CPU build evaluates it: no FMA contraction (baseline
+// x86-64), Eigen's SSE2 Vector4d reduction order (dx2 + dz2) + (dy2 + 0).  Keeps the k-NN selection
+// bit-identical to gtsam_points::FlatContainer::knn_search, including near-ties.
+__device__ __forceinline__ double sq_dist3(double dx, double dy, double dz)
+{
+#pragma clang fp contract(off)
+  const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + zz) + yy;
+}
+
+__device__ __forceinline__ int probe_block(const int4 * table, uint32_t mask, int bx, int by, int bz)
+{
+  uint32_t h = block_hash(bx, by, bz) & mask;
+  for (;;) {
+    const int4 s = table[h];
+    if (s.w < 0) return -1;
+    if (s.x == bx && s.y == by && s.z == bz) return s.w;
+    h = (h + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+
+// Exact fallback: KnnResult::push verbatim (ascending, strict '<': the earlier-traversed candidate
+// wins ties) over the same compacted voxel list.  Only runs for lanes whose truncated keys collided.
+template <int K>
+__device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * list, int list_stride, int n_list,
+                                       const double q0, const double q1, const double q2, double (&bd)[K],
+                                       uint32_t (&bi)[K])
+{
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    bd[j] = kDblMax;
+    bi[j] = 0xFFFFFFFFu;
+  }
+  for (int j = 0; j < n_list; ++j) {
+    const uint32_t e = list[j * list_stride];
+    const uint32_t base = (e >> 5) * kBucketStride, cnt = e & 31u;
+    for (uint32_t s = 0; s < cnt; ++s) {
+      const float4 c = buckets[base + s];
+      const double d = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1,
+                                static_cast<double>(c.z) - q2);
+      if (!(d < bd[K - 1])) continue;
+      bd[K - 1] = d;
+      bi[K - 1] = base + s;
+#pragma unroll
+      for (int i = K - 1; i > 0; --i) {
+        if (bd[i] < bd[i - 1]) {
+          const double td = bd[i];
+          bd[i] = bd[i - 1];
+          bd[i - 1] = td;
+          const uint32_t ti = bi[i];
+          bi[i] = bi[i - 1];
+          bi[i - 1] = ti;
+        }
+      }
+    }
+  }
+}
+
+// k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
+// bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
+// dk = squared distance of the k-th.  `list` / `blk` are this lane's columns of LDS arrays
+// [kMaxOff][stride] / [8][stride].
+template <int K>
+__device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
+                                              int k, uint32_t * list, int * blk, int lds_stride,
+                                              uint32_t (&bi)[K], double & dk)
+{
+  // ---- A. neighbourhood lookup ------------------------------------------------------------------
+  const int cx = fast_floor(q0 * map.inv_leaf), cy = fast_floor(q1 * map.inv_leaf), cz = fast_floor(q2 * map.inv_leaf);
+  // offsets are in {-1,0,1}: the neighbourhood touches block coordinates {b0, b0+1} per axis
+  const int bx0 = (cx - 1) >> kBlockLog2, by0 = (cy - 1) >> kBlockLog2, bz0 = (cz - 1) >> kBlockLog2;
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    blk[s * lds_stride] = probe_block(map.table, map.mask, bx0 + (s >> 2), by0 + ((s >> 1) & 1), bz0 + (s & 1));
+  constexpr int m = kBlockDim - 1;
+  uint32_t cell[kMaxOff];
+#pragma unroll
+  for (int o = 0; o < kMaxOff; ++o) {
+    cell[o] = kEmptyCell;
+    if (o < map.n_off) {
+      const int vx = cx + map.off[o][0], vy = cy + map.off[o][1], vz = cz + map.off[o][2];
+      const int slot = (((vx >> kBlockLog2) - bx0) << 2) | (((vy >> kBlockLog2) - by0) << 1) | ((vz >> kBlockLog2) - bz0);
+      const int b = blk[slot * lds_stride];
+      if (b >= 0)
+        cell[o] = map.cells[static_cast<size_t>(b) * kCellsPerBlock +
+                            (((vx & m) << (2 * kBlockLog2)) | ((vy & m) << kBlockLog2) | (vz & m))];
+    }
+  }
+  int n_list = 0;
+  uint32_t total = 0;
+#pragma unroll
+  for (int o = 0; o < kMaxOff; ++o) {
+    if (cell[o] != kEmptyCell) {  // traversal (offset-generation) order is preserved
+      list[n_list * lds_stride] = cell[o];
+      ++n_list;
+      total += cell[o] & 31u;
+    }
+  }
+
+  // ---- B. flattened candidate scan, branch-free top-(K+1) on payload-carrying keys --------------
+  double key[K + 1];
+#pragma unroll
+  for (int j = 0; j <= K; ++j) key[j] = kDblMax;
+  {
+    int j = -1;
+    uint32_t base = 0, cnt = 0, s = 0;
+    for (uint32_t it = 0; it < total; ++it) {
+      if (s == cnt) {  // next listed voxel (every listed voxel holds >= 1 point)
+        ++j;
+        const uint32_t e = list[j * lds_stride];
+        base = (e >> 5) * kBucketStride;
+        cnt = e & 31u;
+        s = 0;
+      }
+      const float4 c = map.buckets[base + s];
+      const double d = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1,
+                                static_cast<double>(c.z) - q2);
+      const uint64_t kb = (static_cast<uint64_t>(__double_as_longlong(d)) & ~kPayloadMask) |
+                          static_cast<uint64_t>((static_cast<uint32_t>(j) << 5) | s);
+      double t = __longlong_as_double(static_cast<long long>(kb));
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const double lo = dmin(key[i], t);
+        t = dmax(key[i], t);
+        key[i] = lo;
+      }
+      key[K] = dmin(key[K], t);
+      ++s;
+    }
+  }
+  // Truncation is monotone, so distinct truncated keys order exactly like the distances.  Equal
+  // truncated distances among the kept keys (relative gap < 2^-42) -> exact path for this lane.
+  bool ambiguous = false;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const uint64_t a = static_cast<uint64_t>(__double_as_longlong(key[i]));
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(key[i + 1]));
+    if (i < k && key[i] < kDblMax && ((a ^ b) >> 10) == 0) ambiguous = true;
+  }
+  if (ambiguous) {
+    double bd[K];
+    knn_exact<K>(map.buckets, list, lds_stride, n_list, q0, q1, q2, bd, bi);
+    dk = kDblMax;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (i == k - 1) dk = bd[i];
+    return total;
+  }
+  dk = kDblMax;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    bi[i] = 0xFFFFFFFFu;
+    if (i < k && key[i] < kDblMax) {
+      const uint32_t p = static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(key[i])) & kPayloadMask);
+      const uint32_t e = list[(p >> 5) * lds_stride];
+      bi[i] = (e >> 5) * kBucketStride + (p & 31u);
+      if (i == k - 1) {  // exact (untruncated) k-th distance for the max-distance gate
+        const float4 c = map.buckets[bi[i]];
+        dk = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1, static_cast<double>(c.z) - q2);
+      }
+    }
+  }
+  return total;
+}
+
+// Closed-form eigen-decomposition of a symmetric PSD 3x3 (covariance of k points): eigenvalues
+// ascending by the trigonometric method, unit eigenvector of the smallest one from the best-
+// conditioned cross product of two rows of (A - w0 I).  fp64 throughout: |dw| ~ eps * |A|, far inside
+// the 1e-5 parity bar and the plane gates' margins.  Replaces the Eigen::SelfAdjointEigenSolver
+// call of estimatePlane (geometric_factor.hpp:196), which only consumes the three eigenvalues and
+// eigenvector 0 (:202-215).
+__device__ __forceinline__ void plane_eigen(const double a00, const double a01, const double a02, const double a11,
+                                            const double a12, const double a22, double (&w)[3], double (&v)[3])
+{
+  const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+  if (!(p2 > 0.0)) {  // isotropic (or NaN): eigenvalues all q
+    w[0] = w[1] = w[2] = q;
+    v[0] = 1.0;
+    v[1] = 0.0;
+    v[2] = 0.0;
+    return;
+  }
+  const double p = sqrt(p2 * (1.0 / 6.0));
+  const double ip = 1.0 / p;
+  const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+  double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+  r = fmin(1.0, fmax(-1.0, r));
+  const double phi = acos(r) * (1.0 / 3.0);
+  const double w2 = q + 2.0 * p * cos(phi);
+  const double w0 = q + 2.0 * p * cos(phi + 2.0943951023931954923);  // + 2 pi / 3
+  w[0] = w0;
+  w[2] = w2;
+  w[1] = 3.0 * q - w0 - w2;
+  // eigenvector of w0: rows of M = A - w0 I are orthogonal to it
+  const double m00 = a00 - w0, m11 = a11 - w0, m22 = a22 - w0;
+  const double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;  // r0 x r1
+  const double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;  // r0 x r2
+  const double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;  // r1 x r2
+  const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+  double vx = x0, vy = y0, vz = z0, nn = n0;
+  if (n1 > nn) {
+    vx = x1;
+    vy = y1;
+    vz = z1;
+    nn = n1;
+  }
+  if (n2 > nn) {
+    vx = x2;
+    vy = y2;
+    vz = z2;
+    nn = n2;
+  }
+  if (nn > 0.0) {
+    const double inv = 1.0 / sqrt(nn);
+    v[0] = vx * inv;
+    v[1] = vy * inv;
+    v[2] = vz * inv;
+  } else {
+    v[0] = 1.0;
+    v[1] = 0.0;
+    v[2] = 0.0;
+  }
+}
+
+// Inter-workgroup hand-off of the per-block partial rows (cdna_hip_programming.md §6 G16,
+// MI355X_MICROARCH.md "valid forms"): 8-byte agent-scope atomics on BOTH sides — write-through (sc1)
+// producer stores drained with s_waitcnt vmcnt(0) before the ticket; the last arriver reads with
+// agent-scope loads.  No release fence (a per-block buffer_wbl2 costs microseconds).
+__device__ __forceinline__ void store_partial(double * p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_partial(const double * p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool arrive_is_last(unsigned int * ticket, unsigned int n_blocks, bool * s_last)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (prev == n_blocks - 1);
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    *s_last = last;
+  }
+  __syncthreads();
+  return *s_last;
+}
+
+// Deterministic parallel fold of the per-block partial rows by the last-arriving block: thread
+// (entry, lane-segment) sums blocks seg, seg+NSEG, ... with four independent accumulators (loads
+// stay in flight), segments are then combined in index order.  Result in s_out[0..n_ent).
+template <int EW>  // entries rounded up: 32 (unary / K4) or 96 (binary)
+__device__ __forceinline__ void fold_rows(const double * partials, int n_blocks, int n_ent, double * s_seg,
+                                          double * s_out)
+{
+  constexpr int NSEG = kThreads / EW;
+  const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
+  if (seg < NSEG && ent < n_ent) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = seg;
+    for (; b + 3 * NSEG < n_blocks; b += 4 * NSEG) {
+      const double v0 = load_partial(partials + static_cast<size_t>(b) * kPartialStride + ent);
+      const double v1 = load_partial(partials + static_cast<size_t>(b + NSEG) * kPartialStride + ent);
+      const double v2 = load_partial(partials + static_cast<size_t>(b + 2 * NSEG) * kPartialStride + ent);
+      const double v3 = load_partial(partials + static_cast<size_t>(b + 3 * NSEG) * kPartialStride + ent);
+      a0 += v0;
+      a1 += v1;
+      a2 += v2;
+      a3 += v3;
+    }
+    for (; b < n_blocks; b += NSEG) a0 += load_partial(partials + static_cast<size_t>(b) * kPartialStride + ent);
+    s_seg[seg * EW + ent] = (a0 + a1) + (a2 + a3);
+  } else if (seg < NSEG) {
+    s_seg[seg * EW + ent] = 0.0;
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < n_ent) {
+    double s = 0.0;
+    for (int g = 0; g < NSEG; ++g) s += s_seg[g * EW + threadIdx.x];
+    s_out[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// K3
+// ------------------------------------------------------------------------------------------------
+template <int K, bool BINARY>
+__global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a)
+{
+  constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
+  constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
+  constexpr int SEGS = kThreads / NENT;         // 18 / 5 point segments reduced in parallel
+  constexpr int PPS = (kThreads + SEGS - 1) / SEGS;
+  constexpr int EW = BINARY ? 96 : 32;
+  constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
+  // One LDS arena, reused: [k-NN] per-lane voxel list + 8 block ids; [reduce] rows, segment sums.
+  constexpr int kListWords = (kMaxOff + 8) * kThreads;
+  constexpr int kRowWords = kThreads * ROWW * 2;
+  constexpr int kSegWords = SEGS * NENT * 2;
+  constexpr int kFoldWords = (kThreads / EW) * EW * 2 + EW * 2;
+  constexpr int kReduceWords = kRowWords + (kSegWords > kFoldWords ? kSegWords : kFoldWords);
+  constexpr int kArenaWords = kListWords > kReduceWords ? kListWords : kReduceWords;
+  __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
+  __shared__ unsigned int s_cnt[2];  // n_knn, n_cand of this block
+  __shared__ bool s_last;
+
+  uint32_t * s_list = s_arena + threadIdx.x;                                          // [kMaxOff][kThreads]
+  int * s_blk = reinterpret_cast<int *>(s_arena + kMaxOff * kThreads + threadIdx.x);  // [8][kThreads]
+  double * s_rows = reinterpret_cast<double *>(s_arena);                              // [kThreads][ROWW]
+  double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
+
+  const int qi = blockIdx.x * kThreads + threadIdx.x;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+
+  double row[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) row[j] = 0.0;
+
+  const int k = a.k;
+  if (qi < a.n) {
+    const float4 sp = a.src[qi];
+    const double px = sp.x, py = sp.y, pz = sp.z;
+    // 1. q = R p + t (geometric_factor.hpp:276-277)
+    const double q0 = (a.R[0] * px + (a.R[1] * py + a.R[2] * pz)) + a.t[0];
+    const double q1 = (a.R[3] * px + (a.R[4] * py + a.R[5] * pz)) + a.t[1];
+    const double q2 = (a.R[6] * px + (a.R[7] * py + a.R[8] * pz)) + a.t[2];
+
+    // 2. data-association cache (:279-287).  cold == a freshly constructed factor: cached state
+    //    reads as zero without touching memory.
+    double qd0 = 0.0, qd1 = 0.0, qd2 = 0.0;
+    int st = MH_UNPROCESSED;
+    if (!a.cold) {
+      qd0 = a.q_da[3 * qi + 0];
+      qd1 = a.q_da[3 * qi + 1];
+      qd2 = a.q_da[3 * qi + 2];
+      st = a.status[qi];
+    }
+    const double ddx = q0 - qd0, ddy = q1 - qd1, ddz = q2 - qd2;
+    const bool update = sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
+
+    double mean[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
+    bool go = false;
+    if (update) {
+      st = MH_UNPROCESSED;
+      a.q_da[3 * qi + 0] = q0;
+      a.q_da[3 * qi + 1] = q1;
+      a.q_da[3 * qi + 2] = q2;
+      // 3. k-NN (:292-302)
+      uint32_t bi[K];
+      double dk;
+      const uint32_t n_cand = knn_query<K>(a.map, q0, q1, q2, k, s_list, s_blk, kThreads, bi, dk);
+      atomicAdd(&s_cnt[0], 1u);
+      atomicAdd(&s_cnt[1], n_cand);
+      if (!(dk < kDblMax)) {
+        st = MH_INSUFFICIENT_CORRES_POINTS;  // found != k
+      } else if (dk > a.max_d2) {
+        st = MH_CORRES_MAX_DIST;
+      } else {
+        // 4. estimatePlane (:176-229)
+        double X[K][3];
+        double sx = 0, sy = 0, sz = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          X[j][0] = X[j][1] = X[j][2] = 0.0;
+          if (j < k) {
+            const float4 c = a.map.buckets[bi[j]];
+            X[j][0] = c.x;
+            X[j][1] = c.y;
+            X[j][2] = c.z;
+            sx += X[j][0];
+            sy += X[j][1];
+            sz += X[j][2];
+          }
+        }
+        const double kd = static_cast<double>(k);
+        mean[0] = sx / kd;
+        mean[1] = sy / kd;
+        mean[2] = sz / kd;
+        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          if (j < k) {
+            X[j][0] -= mean[0];
+            X[j][1] -= mean[1];
+            X[j][2] -= mean[2];
+            c00 += X[j][0] * X[j][0];
+            c01 += X[j][0] * X[j][1];
+            c02 += X[j][0] * X[j][2];
+            c11 += X[j][1] * X[j][1];
+            c12 += X[j][1] * X[j][2];
+            c22 += X[j][2] * X[j][2];
+          }
+        }
+        const double ikm1 = 1.0 / (kd - 1.0);
+        // the mean is cached before the gates (:191)
+        a.mean[3 * qi + 0] = mean[0];
+        a.mean[3 * qi + 1] = mean[1];
+        a.mean[3 * qi + 2] = mean[2];
+        double w[3], v0[3];
+        plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
+        if (!(w[0] == w[0]) || !(w[2] == w[2])) {
+          st = MH_EIGEN_SOLVER_FAIL;  // NaN input: Eigen would report NoConvergence (:197)
+        } else if (w[0] < 1e-6) {
+          st = MH_MIN_EIGEN_VALUE_LOW;
+        } else if (w[2] > 3.0 * w[1]) {
+          st = MH_LINE;
+        } else {
+          nrm[0] = v0[0];
+          nrm[1] = v0[1];
+          nrm[2] = v0[2];
+          // normal faces the sensor origin o = t (:217-220)
+          const double dp =
+            nrm[0] * (a.t[0] - mean[0]) + (nrm[1] * (a.t[1] - mean[1]) + nrm[2] * (a.t[2] - mean[2]));
+          if (dp < 0) {
+            nrm[0] = -nrm[0];
+            nrm[1] = -nrm[1];
+            nrm[2] = -nrm[2];
+          }
+          a.normal[3 * qi + 0] = nrm[0];
+          a.normal[3 * qi + 1] = nrm[1];
+          a.normal[3 * qi + 2] = nrm[2];
+          bool plane_ok = true;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            if (j < k) {
+              const double dj = X[j][0] * nrm[0] + (X[j][1] * nrm[1] + X[j][2] * nrm[2]);
+              if (fabs(dj) > a.plane_valid) plane_ok = false;
+            }
+          }
+          if (plane_ok)
+            go = true;
+          else
+            st = MH_CORRES_PLANE_INVALID;
+        }
+      }
+      if (a.cold) {
+        // a fresh factor has zero mean / normal wherever this pass did not write them
+        if (st == MH_INSUFFICIENT_CORRES_POINTS || st == MH_CORRES_MAX_DIST)
+          a.mean[3 * qi + 0] = a.mean[3 * qi + 1] = a.mean[3 * qi + 2] = 0.0;
+        if (st >= MH_INSUFFICIENT_CORRES_POINTS && st <= MH_LINE)
+          a.normal[3 * qi + 0] = a.normal[3 * qi + 1] = a.normal[3 * qi + 2] = 0.0;
+      }
+    } else {
+      // :308-317 — reuse the cached plane only if the previous pass got past the plane gates
+      if (st > MH_CORRES_PLANE_INVALID) {
+        mean[0] = a.mean[3 * qi + 0];
+        mean[1] = a.mean[3 * qi + 1];
+        mean[2] = a.mean[3 * qi + 2];
+        nrm[0] = a.normal[3 * qi + 0];
+        nrm[1] = a.normal[3 * qi + 1];
+        nrm[2] = a.normal[3 * qi + 2];
+        go = true;
+      } else if (a.cold) {
+        // lazily materialise the zero state of a fresh factor for points that never associate
+        a.q_da[3 * qi + 0] = a.q_da[3 * qi + 1] = a.q_da[3 * qi + 2] = 0.0;
+        a.mean[3 * qi + 0] = a.mean[3 * qi + 1] = a.mean[3 * qi + 2] = 0.0;
+        a.normal[3 * qi + 0] = a.normal[3 * qi + 1] = a.normal[3 * qi + 2] = 0.0;
+      }
+    }
+
+    if (go) {
+      // 5. residual + max-error gate (:319-328)
+      double e = nrm[0] * (mean[0] - q0) + (nrm[1] * (mean[1] - q1) + nrm[2] * (mean[2] - q2));
+      const double range = sqrt(px * px + (py * py + pz * pz));
+      const double s = 1.0 - 0.9 * fabs(e) / sqrt(range);
+      if (s < 0.9) {
+        st = MH_MAX_ERROR;
+      } else {
+        // 6. Huber (:330-339)
+        double sw = 1.0;
+        if (a.use_huber) {
+          const double we = e / a.sigma;
+          if (fabs(we) > a.huber) sw = sqrt(a.huber / fabs(we));
+        }
+        const double wgt = sw / a.sigma;
+        e *= wgt;
+        // 7. Jacobian (:341-355): n_s = R^T n, J = [(n_s x p)^T, -n_s^T]
+        const double ns0 = a.R[0] * nrm[0] + (a.R[3] * nrm[1] + a.R[6] * nrm[2]);
+        const double ns1 = a.R[1] * nrm[0] + (a.R[4] * nrm[1] + a.R[7] * nrm[2]);
+        const double ns2 = a.R[2] * nrm[0] + (a.R[5] * nrm[1] + a.R[8] * nrm[2]);
+        row[0] = (ns1 * pz - ns2 * py) * wgt;
+        row[1] = (ns2 * px - ns0 * pz) * wgt;
+        row[2] = (ns0 * py - ns1 * px) * wgt;
+        row[3] = -ns0 * wgt;
+        row[4] = -ns1 * wgt;
+        row[5] = -ns2 * wgt;
+        if constexpr (BINARY) {
+          // :368-376  J_t = [(q x n)^T, n^T]
+          row[6] = (q1 * nrm[2] - q2 * nrm[1]) * wgt;
+          row[7] = (q2 * nrm[0] - q0 * nrm[2]) * wgt;
+          row[8] = (q0 * nrm[1] - q1 * nrm[0]) * wgt;
+          row[9] = nrm[0] * wgt;
+          row[10] = nrm[1] * wgt;
+          row[11] = nrm[2] * wgt;
+        }
+        row[NV - 1] = e;
+        st = MH_VALID;
+      }
+    }
+    a.status[qi] = st;
+  }
+
+  // 8. H += J^T J, b += J^T e, f += e^2 (:363-382) — LDS tile of rows (the k-NN arena is dead now),
+  //    then every thread owns one (entry, segment) pair of the upper triangle of sum v v^T.
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
+  __syncthreads();
+  {
+    const int ent = threadIdx.x % NENT, seg = threadIdx.x / NENT;
+    if (seg < SEGS) {
+      int r = 0, rem = ent;  // ent -> (r, c), r <= c, row-major upper triangle
+      while (rem >= NV - r) {
+        rem -= NV - r;
+        ++r;
+      }
+      const int c = r + rem;
+      double s = 0.0;
+      const int p0 = seg * PPS, p1 = min(kThreads, p0 + PPS);
+      for (int p = p0; p < p1; ++p) s += s_rows[p * ROWW + r] * s_rows[p * ROWW + c];
+      s_aux[seg * NENT + ent] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NENT) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < SEGS; ++g) s += s_aux[g * NENT + threadIdx.x];
+    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + threadIdx.x], s);
+  }
+  // the block's k-NN counters ride along as two more partial entries (exact in fp64): same-line
+  // global atomics from every block would serialise at L2
+  if (threadIdx.x >= 128 && threadIdx.x < 130)
+    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + NENT + (threadIdx.x - 128)],
+                  static_cast<double>(s_cnt[threadIdx.x - 128]));
+
+  if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
+
+  // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
+  double * s_sum = s_aux + (kThreads / EW) * EW;
+  fold_rows<EW>(a.partials, gridDim.x, NENT + 2, s_aux, s_sum);
+  if (threadIdx.x < NENT) a.result->sums[threadIdx.x] = s_sum[threadIdx.x];
+  if (threadIdx.x == NENT) a.result->n_knn = static_cast<unsigned long long>(s_sum[NENT]);
+  if (threadIdx.x == NENT + 1) a.result->n_cand = static_cast<unsigned long long>(s_sum[NENT + 1]);
+  if (threadIdx.x == 0 || threadIdx.x == 64) {
+    // computeLocalizability on the rot / trans 3x3 blocks of J_s^T J_s (:405-411), one wave each
+    auto ent_of = [](int r, int c) { return r * NV - r * (r - 1) / 2 + (c - r); };  // r <= c
+    const int o = threadIdx.x ? 3 : 0;
+    double Hb[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const int rr = r < c ? r : c, cc = r < c ? c : r;
+        Hb[3 * r + c] = s_sum[ent_of(rr + o, cc + o)];
+      }
+    double loc[3], E[9];
+    compute_localizability(Hb, loc, E);
+    double * dl = o ? a.result->loc_trans_final : a.result->loc_rot_final;
+    double * de = o ? a.result->eig_trans : a.result->eig_rot;
+    for (int i = 0; i < 3; ++i) dl[i] = loc[i];
+    for (int i = 0; i < 9; ++i) de[i] = E[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: component localizabilities (geometric_factor.hpp:434-457) + status histogram
+// (src/lidar/geometric.cpp:280-323).  Recomputes the unwhitened Jacobian directions from the cached
+// normal instead of storing two more per-point vectors.  6 sums by wave shuffles, 9 counts by
+// ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocArgs a)
+{
+  constexpr int NW = kThreads / 64;
+  __shared__ double s_w[NW][16];
+  __shared__ double s_seg[(kThreads / 32) * 32 + 32];
+  __shared__ bool s_last;
+
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  int st = -1;
+  if (i < a.n) {
+    st = a.status[i];
+    if (st == MH_VALID) {
+      const float4 sp = a.src[i];
+      const double px = sp.x, py = sp.y, pz = sp.z;
+      const double n0 = a.normal[3 * i], n1 = a.normal[3 * i + 1], n2 = a.normal[3 * i + 2];
+      const double ns0 = a.R[0] * n0 + (a.R[3] * n1 + a.R[6] * n2);
+      const double ns1 = a.R[1] * n0 + (a.R[4] * n1 + a.R[7] * n2);
+      const double ns2 = a.R[2] * n0 + (a.R[5] * n1 + a.R[8] * n2);
+      double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
+      const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
+      if (nr2 > 0.0) {  // Eigen normalized(): unchanged when the squared norm is zero
+        const double inv = 1.0 / sqrt(nr2);
+        r0 *= inv;
+        r1 *= inv;
+        r2 *= inv;
+      }
+      const double * Er = a.result->eig_rot;
+      const double * Et = a.result->eig_trans;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double tc = fabs((-ns0) * Et[c] + ((-ns1) * Et[3 + c] + (-ns2) * Et[6 + c]));
+        const double rc = fabs(r0 * Er[c] + (r1 * Er[3 + c] + r2 * Er[6 + c]));
+        v[c] = tc >= 0.5 ? tc : 0.0;      // trans components
+        v[3 + c] = rc >= 0.5 ? rc : 0.0;  // rot components
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = v[j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) s_w[wv][j] = s;
+  }
+#pragma unroll
+  for (int h = 0; h < 9; ++h) {
+    const unsigned long long b = __ballot(st == h);
+    if (lane == 0) s_w[wv][6 + h] = static_cast<double>(__popcll(b));
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) {
+    double s = 0.0;
+    for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
+    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + threadIdx.x], s);
+  }
+  if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
+  double * s_sum = s_seg + (kThreads / 32) * 32;
+  fold_rows<32>(a.partials, gridDim.x, 15, s_seg, s_sum);
+  if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
+  if (threadIdx.x >= 6 && threadIdx.x < 15)
+    a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched k-NN (IncrementalVoxelMapPCL::knn_search for n queries) — parity / tooling entry point.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, const double * q, int n, int k,
+                                                           double * pts, double * sq, int32_t * found)
+{
+  constexpr int K = 8;
+  __shared__ uint32_t s_list[(kMaxOff + 8) * kThreads];
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
+  uint32_t bi[K];
+  double dk;
+  knn_query<K>(map, q0, q1, q2, k, s_list + threadIdx.x,
+               reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk);
+  int f = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < k) {
+      const size_t o = static_cast<size_t>(i) * k + j;
+      if (bi[j] != 0xFFFFFFFFu) {
+        ++f;
+        const float4 c = map.buckets[bi[j]];
+        pts[o * 3 + 0] = c.x;
+        pts[o * 3 + 1] = c.y;
+        pts[o * 3 + 2] = c.z;
+        sq[o] = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1, static_cast<double>(c.z) - q2);
+      } else {
+        pts[o * 3 + 0] = pts[o * 3 + 1] = pts[o * 3 + 2] = 0.0;
+        sq[o] = kDblMax;
+      }
+    }
+  }
+  found[i] = f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+int linearize_grid(int n) { return (n + kThreads - 1) / kThreads; }
+int localizability_grid(int n) { return (n + kThreads - 1) / kThreads; }
+
+hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
+{
+  const dim3 grid(linearize_grid(a.n)), block(kThreads);
+  if (a.k == 5) {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_kernel<5, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_linearize_kernel<5, false>), grid, block, 0, stream, a);
+  } else {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_kernel<8, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_linearize_kernel<8, false>), grid, block, 0, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_localizability(const LocArgs & a, hipStream_t stream)
+{
+  hipLaunchKernelGGL(icp_localizability_kernel, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
+                          int32_t * found, hipStream_t stream)
+{
+  const int grid = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(map_knn_kernel, dim3(grid), dim3(kThreads), 0, stream, map, q, n, k, pts, sq, found);
+  return hipGetLastError();
+}
+
+}  // namespace mh

@@ -1,0 +1,805 @@
+// C ABI of libmimosa_hip.so (include/mimosa_hip.h): contexts, the device-resident voxel map, the
+// ICP factor handle and the deskew entry points.  Host-side epilogue of linearize()
+// (geometric_factor.hpp:405-428, 459-561) lives here; the per-point work is in icp_kernels.hip.
+//
+// There is deliberately no CPU fallback: without a HIP device every entry point fails with
+// MH_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mimosa_hip.h"
+#include "icp_device.hpp"
+#include "math3.hpp"
+#include "voxel_map.hpp"
+
+namespace
+{
+thread_local std::string g_err;
+constexpr int kMaxPending = 64;
+}  // namespace
+
+struct mh_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  hipEvent_t timer[2] = {nullptr, nullptr};
+};
+
+namespace
+{
+int fail(const mh_ctx * ctx, int code, const std::string & msg)
+{
+  g_err = msg;
+  if (ctx) const_cast<mh_ctx *>(ctx)->err = msg;
+  return code;
+}
+int hip_fail(const mh_ctx * ctx, hipError_t e, const char * what)
+{
+  const int code = (e == hipErrorOutOfMemory) ? MH_ERR_OOM : (e == hipErrorNoDevice ? MH_ERR_NO_DEVICE : MH_ERR_HIP);
+  return fail(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define MH_HIP(ctx, call)                                   \
+  do {                                                      \
+    const hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
+  } while (0)
+
+// Growable device buffer
+struct DevBuf
+{
+  void * p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes, hipStream_t stream, bool keep)
+  {
+    if (bytes <= cap) return hipSuccess;
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < bytes) ncap += ncap / 2 + 4096;
+    void * np = nullptr;
+    hipError_t e = hipMalloc(&np, ncap);
+    if (e != hipSuccess) return e;
+    if (keep && p && cap) {
+      e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) return e;
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+}  // namespace
+
+struct mh_map
+{
+  mh_ctx * ctx;
+  std::atomic<int> refs{1};
+  mh::HostVoxelMap host;
+  DevBuf d_table, d_cells, d_buckets;
+  bool device_stale = true;
+  int64_t uploads = 0, upload_bytes = 0;
+  int n_off = 0;
+  int8_t off[27][3];
+  explicit mh_map(mh_ctx * c, const mh_map_config & cfg) : ctx(c), host(cfg)
+  {
+    n_off = mh::neighbor_offsets(cfg.neighbor_voxel_mode, off);
+  }
+};
+
+struct PendingCall
+{
+  mh_icp_result * out;
+  double R[9];     // delta rotation (for reg_4_dof's local_z)
+  double gz[3];    // global_z = -g_unit
+  int parity;
+  int linearize_count;
+  hipEvent_t ev[3];
+};
+
+struct mh_icp
+{
+  mh_ctx * ctx;
+  mh_map * map;
+  size_t n;
+  mh_reg_config cfg;
+  bool binary;
+  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result;
+  mh::DeviceResult * h_results = nullptr;  // pinned ring
+  PendingCall pending[kMaxPending];
+  int n_pending = 0;
+  int parity = 0;
+  bool cold = true;
+  int linearize_count = 0;
+  hipEvent_t events[kMaxPending][3];
+  bool events_ready = false;
+};
+
+namespace
+{
+int map_sync_device(mh_map * m)
+{
+  if (!m->device_stale) return MH_OK;
+  mh_ctx * ctx = m->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const auto & H = m->host;
+  const size_t tb = H.table().size() * sizeof(mh::Int4);
+  const size_t cb = H.cells().size() * sizeof(uint32_t);
+  const size_t bb = H.buckets().size() * sizeof(mh::Float4);
+  // Factors on this context may still be reading the old buffers: drain before (re)allocating.
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
+  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : 4, ctx->stream, false));
+  MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, false));
+  MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
+  if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
+  if (bb) MH_HIP(ctx, hipMemcpyAsync(m->d_buckets.p, H.buckets().data(), bb, hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  m->host.clear_dirty();
+  m->host.take_full_rebuild();
+  m->device_stale = false;
+  m->uploads++;
+  m->upload_bytes += static_cast<int64_t>(tb + cb + bb);
+  return MH_OK;
+}
+
+mh::MapView map_view(const mh_map * m)
+{
+  mh::MapView v;
+  v.table = static_cast<const int4 *>(m->d_table.p);
+  v.cells = static_cast<const uint32_t *>(m->d_cells.p);
+  v.buckets = static_cast<const float4 *>(m->d_buckets.p);
+  v.inv_leaf = m->host.inv_leaf();
+  v.mask = m->host.table_mask();
+  v.n_off = m->n_off;
+  std::memcpy(v.off, m->off, sizeof(v.off));
+  return v;
+}
+
+void pose_inverse_compose(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t)
+{
+  // delta = T_tgt^-1 * T_src (geometric_factor.hpp:251); unary: T_tgt = identity
+  if (!Rt || !tt) {
+    std::memcpy(R, Rs, sizeof(double) * 9);
+    std::memcpy(t, ts, sizeof(double) * 3);
+    return;
+  }
+  double Rinv[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rinv[3 * i + j] = Rt[3 * j + i];
+  double tinv[3];
+  for (int i = 0; i < 3; ++i) tinv[i] = -(Rinv[3 * i] * tt[0] + (Rinv[3 * i + 1] * tt[1] + Rinv[3 * i + 2] * tt[2]));
+  mh::mat3_mul(Rinv, Rs, R);
+  for (int i = 0; i < 3; ++i) t[i] = tinv[i] + (Rinv[3 * i] * ts[0] + (Rinv[3 * i + 1] * ts[1] + Rinv[3 * i + 2] * ts[2]));
+}
+
+// include/mimosa/lidar/utils.hpp:191-213
+bool projection_matrix(const double loc[3], double thresh, const double E[9], double P[9])
+{
+  if (loc[0] > thresh && loc[1] > thresh && loc[2] > thresh) {
+    for (int i = 0; i < 9; ++i) P[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return false;
+  }
+  for (int i = 0; i < 9; ++i) P[i] = 0.0;
+  for (int i = 0; i < 3; ++i)
+    if (loc[i] > thresh)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) P[3 * r + c] += E[3 * r + i] * E[3 * c + i];
+  return true;
+}
+
+// Host epilogue of linearize(): unpack the device sums into the HessianFactor blocks, Schur
+// degeneracy info (:413-428), 4-DoF projection (:464-475), degeneracy projection quirk (:477-557).
+void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const PendingCall & pc, mh_icp_result * out)
+{
+  std::memset(out, 0, sizeof(*out));
+  const int NV = icp->binary ? 13 : 7;
+  auto ent = [NV](int r, int c) {
+    if (r > c) std::swap(r, c);
+    return r * NV - r * (r - 1) / 2 + (c - r);
+  };
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c < 6; ++c) out->H_ss[6 * r + c] = d.sums[ent(r, c)];
+    out->b_s[r] = d.sums[ent(r, NV - 1)];
+  }
+  out->f = d.sums[ent(NV - 1, NV - 1)];
+  if (icp->binary) {
+    for (int r = 0; r < 6; ++r) {
+      for (int c = 0; c < 6; ++c) {
+        out->H_st[6 * r + c] = d.sums[ent(r, 6 + c)];
+        out->H_tt[6 * r + c] = d.sums[ent(6 + r, 6 + c)];
+      }
+      out->b_t[r] = d.sums[ent(6 + r, 12)];
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    out->loc_rot_final[i] = d.loc_rot_final[i];
+    out->loc_trans_final[i] = d.loc_trans_final[i];
+    out->loc_trans_comp[i] = d.loc_comp[i];
+    out->loc_rot_comp[i] = d.loc_comp[3 + i];
+  }
+  std::memcpy(out->eigvec_rot, d.eig_rot, sizeof(double) * 9);
+  std::memcpy(out->eigvec_trans, d.eig_trans, sizeof(double) * 9);
+
+  double Hrr[9], Hrt[9], Htr[9], Htt[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      Hrr[3 * r + c] = out->H_ss[6 * r + c];
+      Hrt[3 * r + c] = out->H_ss[6 * r + 3 + c];
+      Htr[3 * r + c] = out->H_ss[6 * (3 + r) + c];
+      Htt[3 * r + c] = out->H_ss[6 * (3 + r) + 3 + c];
+    }
+  {
+    double inv[9], tmp[9], tmp2[9], S[9], Sigma[9];
+    mh::mat3_inv(Htt, inv);
+    mh::mat3_mul(Hrt, inv, tmp);
+    mh::mat3_mul(tmp, Htr, tmp2);
+    for (int i = 0; i < 9; ++i) S[i] = Hrr[i] - tmp2[i];
+    mh::mat3_inv(S, Sigma);
+    mh::compute_localizability(Sigma, out->degen_rot, out->degen_eigvec_rot);
+    for (int i = 0; i < 3; ++i) out->degen_rot[i] *= 180.0 / M_PI;
+    mh::mat3_inv(Hrr, inv);
+    mh::mat3_mul(Htr, inv, tmp);
+    mh::mat3_mul(tmp, Hrt, tmp2);
+    for (int i = 0; i < 9; ++i) S[i] = Htt[i] - tmp2[i];
+    mh::mat3_inv(S, Sigma);
+    mh::compute_localizability(Sigma, out->degen_trans, out->degen_eigvec_trans);
+  }
+
+  if (!icp->binary) {
+    if (icp->cfg.reg_4_dof) {
+      // local_z = R^T global_z; Pi = local_z local_z^T  (:257-259, :464-475)
+      double lz[3];
+      for (int i = 0; i < 3; ++i) lz[i] = pc.R[i] * pc.gz[0] + (pc.R[3 + i] * pc.gz[1] + pc.R[6 + i] * pc.gz[2]);
+      double Pi[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Pi[3 * r + c] = lz[r] * lz[c];
+      double a[9], b[9], c9[9], tmp[9];
+      mh::mat3_mul(Pi, Hrr, tmp);
+      mh::mat3_mul(tmp, Pi, a);
+      mh::mat3_mul(Pi, Hrt, b);
+      mh::mat3_mul(Htr, Pi, c9);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          out->H_ss[6 * r + c] = a[3 * r + c];
+          out->H_ss[6 * r + 3 + c] = b[3 * r + c];
+          out->H_ss[6 * (3 + r) + c] = c9[3 * r + c];
+        }
+      double br[3];
+      for (int i = 0; i < 3; ++i) br[i] = Pi[3 * i] * out->b_s[0] + (Pi[3 * i + 1] * out->b_s[1] + Pi[3 * i + 2] * out->b_s[2]);
+      for (int i = 0; i < 3; ++i) out->b_s[i] = br[i];
+    }
+    if (icp->cfg.project_on_degneneracy) {
+      double P[9];
+      const bool rot_degen = projection_matrix(out->loc_rot_final, icp->cfg.degen_thresh_rot, out->eigvec_rot, P);
+      const bool trans_degen = projection_matrix(out->loc_trans_final, icp->cfg.degen_thresh_trans, out->eigvec_trans, P);
+      if (rot_degen || trans_degen) {
+        // Reference behaviour: H and b are rebuilt from two per-point arrays that
+        // are allocated zero and never written (geometric_factor.hpp:270-271, 496-532), so the
+        // rebuilt H and b are exactly zero and the localizabilities are recomputed from zero.
+        std::memset(out->H_ss, 0, sizeof(out->H_ss));
+        std::memset(out->b_s, 0, sizeof(out->b_s));
+        const double Z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        mh::compute_localizability(Z, out->loc_rot_final, out->eigvec_rot);
+        mh::compute_localizability(Z, out->loc_trans_final, out->eigvec_trans);
+      }
+    }
+  }
+  for (int i = 0; i < 9; ++i) out->status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
+  out->n_knn = static_cast<int64_t>(d.n_knn);
+  out->mean_candidates = d.n_knn ? static_cast<double>(d.n_cand) / static_cast<double>(d.n_knn) : 0.0;
+  out->linearize_count = pc.linearize_count;
+}
+}  // namespace
+
+extern "C" {
+
+int mh_abi_version(void) { return MH_ABI_VERSION; }
+
+const char * mh_last_error(const mh_ctx * ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int mh_init(int device, mh_ctx ** out)
+{
+  if (!out) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, MH_ERR_NO_DEVICE, "mh_init: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init: device index out of range");
+  MH_HIP(nullptr, hipSetDevice(device));
+  mh_ctx * ctx = new (std::nothrow) mh_ctx;
+  if (!ctx) return fail(nullptr, MH_ERR_OOM, "mh_init: host allocation failed");
+  ctx->device = device;
+  MH_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MH_HIP(nullptr, hipEventCreate(&ctx->timer[0]));
+  MH_HIP(nullptr, hipEventCreate(&ctx->timer[1]));
+  *out = ctx;
+  return MH_OK;
+}
+
+void mh_shutdown(mh_ctx * ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  if (ctx->timer[0]) (void)hipEventDestroy(ctx->timer[0]);
+  if (ctx->timer[1]) (void)hipEventDestroy(ctx->timer[1]);
+  delete ctx;
+}
+
+int mh_set_profiling(mh_ctx * ctx, int on)
+{
+  if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_set_profiling: ctx is NULL");
+  ctx->profiling = on != 0;
+  return MH_OK;
+}
+
+void * mh_stream(mh_ctx * ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+int mh_synchronize(mh_ctx * ctx)
+{
+  if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_synchronize: ctx is NULL");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_timer_begin(mh_ctx * ctx)
+{
+  if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_timer_begin: ctx is NULL");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipEventRecord(ctx->timer[0], ctx->stream));
+  return MH_OK;
+}
+
+int mh_timer_end(mh_ctx * ctx, float * ms)
+{
+  if (!ctx || !ms) return fail(ctx, MH_ERR_INVALID_ARG, "mh_timer_end: NULL argument");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipEventRecord(ctx->timer[1], ctx->stream));
+  MH_HIP(ctx, hipEventSynchronize(ctx->timer[1]));
+  MH_HIP(ctx, hipEventElapsedTime(ms, ctx->timer[0], ctx->timer[1]));
+  return MH_OK;
+}
+
+// ---- map ---------------------------------------------------------------------------------------
+int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out)
+{
+  if (!ctx || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: NULL argument");
+  *out = nullptr;
+  if (!(cfg->leaf_size > 0)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: leaf_size must be > 0");
+  if (cfg->max_points_in_cell < 1 || cfg->max_points_in_cell > mh::kBucketStride)
+    return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_create: max_points_in_cell must be in 1..20");
+  const int m = cfg->neighbor_voxel_mode;
+  if (m != 1 && m != 7 && m != 19 && m != 27)
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: neighbor_voxel_mode must be 1, 7, 19 or 27");
+  if (cfg->lru_clear_cycle < 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_clear_cycle must be >= 1");
+  mh_map * map = new (std::nothrow) mh_map(ctx, *cfg);
+  if (!map) return fail(ctx, MH_ERR_OOM, "mh_map_create: host allocation failed");
+  *out = map;
+  return MH_OK;
+}
+
+int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_floats)
+{
+  if (!map || (!xyz && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert: NULL argument");
+  if (stride_floats < 3) return fail(map->ctx, MH_ERR_INVALID_ARG, "mh_map_insert: stride_floats must be >= 3");
+  map->host.insert(xyz, n, stride_floats);
+  map->device_stale = true;
+  return MH_OK;
+}
+
+int mh_map_copy(const mh_map * src, mh_map ** out)
+{
+  if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_copy: NULL argument");
+  *out = nullptr;
+  mh_map * map = new (std::nothrow) mh_map(src->ctx, src->host.config());
+  if (!map) return fail(src->ctx, MH_ERR_OOM, "mh_map_copy: host allocation failed");
+  map->host = src->host;  // deep copy of the flat arrays
+  map->device_stale = true;
+  *out = map;
+  return MH_OK;
+}
+
+int mh_map_retain(mh_map * map)
+{
+  if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_retain: map is NULL");
+  map->refs.fetch_add(1);
+  return MH_OK;
+}
+
+void mh_map_release(mh_map * map)
+{
+  if (!map) return;
+  if (map->refs.fetch_sub(1) == 1) {
+    (void)hipSetDevice(map->ctx->device);
+    (void)hipStreamSynchronize(map->ctx->stream);
+    map->d_table.release();
+    map->d_cells.release();
+    map->d_buckets.release();
+    delete map;
+  }
+}
+
+int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
+{
+  if (!map || !out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_stats: NULL argument");
+  out->n_voxels = static_cast<int64_t>(map->host.n_voxels());
+  out->n_points = static_cast<int64_t>(map->host.n_points());
+  out->n_blocks = static_cast<int64_t>(map->host.n_blocks());
+  out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap);
+  out->uploads = map->uploads;
+  out->upload_bytes = map->upload_bytes;
+  return MH_OK;
+}
+
+int mh_map_get_cloud(const mh_map * map, float * xyz, size_t capacity_points, size_t * n_out)
+{
+  if (!map || !n_out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_cloud: NULL argument");
+  *n_out = map->host.get_cloud(xyz, capacity_points);
+  return MH_OK;
+}
+
+int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * point_xyz, double * sq_dists,
+               int32_t * found)
+{
+  if (!map || !queries || !point_xyz || !sq_dists || !found)
+    return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_knn: NULL argument");
+  if (k < 1 || k > 8) return fail(map->ctx, MH_ERR_UNSUPPORTED, "mh_map_knn: k must be in 1..8");
+  mh_ctx * ctx = map->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc = map_sync_device(map);
+  if (rc != MH_OK) return rc;
+  if (n == 0) return MH_OK;
+  double *d_q = nullptr, *d_p = nullptr, *d_s = nullptr;
+  int32_t * d_f = nullptr;
+  MH_HIP(ctx, hipMalloc(&d_q, n * 3 * sizeof(double)));
+  MH_HIP(ctx, hipMalloc(&d_p, n * k * 3 * sizeof(double)));
+  MH_HIP(ctx, hipMalloc(&d_s, n * k * sizeof(double)));
+  MH_HIP(ctx, hipMalloc(&d_f, n * sizeof(int32_t)));
+  MH_HIP(ctx, hipMemcpyAsync(d_q, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, mh::launch_map_knn(map_view(map), d_q, static_cast<int>(n), k, d_p, d_s, d_f, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(point_xyz, d_p, n * k * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(sq_dists, d_s, n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(found, d_f, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_q);
+  (void)hipFree(d_p);
+  (void)hipFree(d_s);
+  (void)hipFree(d_f);
+  return MH_OK;
+}
+
+// ---- factor ------------------------------------------------------------------------------------
+static int icp_alloc(mh_icp * icp)
+{
+  mh_ctx * ctx = icp->ctx;
+  const size_t n = icp->n ? icp->n : 1;
+  MH_HIP(ctx, icp->d_src.reserve(n * sizeof(float4), ctx->stream, false));
+  MH_HIP(ctx, icp->d_qda.reserve(n * 3 * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, icp->d_mean.reserve(n * 3 * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, icp->d_normal.reserve(n * 3 * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, icp->d_status.reserve(n * sizeof(int32_t), ctx->stream, false));
+  const size_t max_grid = static_cast<size_t>(mh::linearize_grid(static_cast<int>(n)));
+  MH_HIP(ctx, icp->d_partials.reserve(max_grid * mh::kPartialStride * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, icp->d_ticket.reserve(2 * sizeof(unsigned int), ctx->stream, false));
+  MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
+  MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending,
+                            hipHostMallocDefault));
+  return MH_OK;
+}
+
+int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
+                  int is_binary, mh_icp ** out)
+{
+  if (!ctx || !map || !cfg || !out || (!source && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: NULL argument");
+  *out = nullptr;
+  if (map->ctx != ctx) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: map belongs to another context");
+  if (cfg->num_corres_points < 2 || cfg->num_corres_points > 8)
+    return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: num_corres_points must be in 2..8");
+  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: cloud too large");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_icp * icp = new (std::nothrow) mh_icp;
+  if (!icp) return fail(ctx, MH_ERR_OOM, "mh_icp_create: host allocation failed");
+  icp->ctx = ctx;
+  icp->map = map;
+  mh_map_retain(map);
+  icp->n = n;
+  icp->cfg = *cfg;
+  icp->binary = is_binary != 0;
+  int rc = icp_alloc(icp);
+  if (rc != MH_OK) {
+    mh_icp_destroy(icp);
+    return rc;
+  }
+  // source cloud: upload the 32-byte records, pack xyz into the 16-byte layout the kernel reads
+  if (n) {
+    mh_point32 * d_pts = nullptr;
+    MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
+    MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, mh::launch_pack_xyz(d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p), ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_pts);
+  }
+  MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
+  // commonConstructor(): all per-point state zero (geometric_factor.hpp:144-156).  Materialised
+  // lazily by the first (cold) linearize; zero here so getters before any linearize read zeros.
+  MH_HIP(ctx, hipMemsetAsync(icp->d_qda.p, 0, icp->d_qda.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_mean.p, 0, icp->d_mean.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_normal.p, 0, icp->d_normal.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_status.p, 0, icp->d_status.cap, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  icp->cold = true;
+  *out = icp;
+  return MH_OK;
+}
+
+int mh_icp_clone(const mh_icp * src, mh_icp ** out)
+{
+  if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_clone: NULL argument");
+  *out = nullptr;
+  mh_ctx * ctx = src->ctx;
+  if (src->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_clone: source has linearize calls in flight");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_icp * icp = new (std::nothrow) mh_icp;
+  if (!icp) return fail(ctx, MH_ERR_OOM, "mh_icp_clone: host allocation failed");
+  icp->ctx = ctx;
+  icp->map = src->map;
+  mh_map_retain(icp->map);
+  icp->n = src->n;
+  icp->cfg = src->cfg;
+  icp->binary = src->binary;
+  int rc = icp_alloc(icp);
+  if (rc != MH_OK) {
+    mh_icp_destroy(icp);
+    return rc;
+  }
+  const size_t n = src->n;
+  auto cp = [&](const DevBuf & a, DevBuf & b, size_t bytes) {
+    return bytes ? hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
+  };
+  MH_HIP(ctx, cp(src->d_src, icp->d_src, n * sizeof(float4)));
+  MH_HIP(ctx, cp(src->d_qda, icp->d_qda, n * 3 * sizeof(double)));
+  MH_HIP(ctx, cp(src->d_mean, icp->d_mean, n * 3 * sizeof(double)));
+  MH_HIP(ctx, cp(src->d_normal, icp->d_normal, n * 3 * sizeof(double)));
+  MH_HIP(ctx, cp(src->d_status, icp->d_status, n * sizeof(int32_t)));
+  MH_HIP(ctx, cp(src->d_result, icp->d_result, sizeof(mh::DeviceResult)));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  icp->cold = src->cold;
+  icp->linearize_count = src->linearize_count;
+  *out = icp;
+  return MH_OK;
+}
+
+void mh_icp_destroy(mh_icp * icp)
+{
+  if (!icp) return;
+  (void)hipSetDevice(icp->ctx->device);
+  (void)hipStreamSynchronize(icp->ctx->stream);
+  icp->d_src.release();
+  icp->d_qda.release();
+  icp->d_mean.release();
+  icp->d_normal.release();
+  icp->d_status.release();
+  icp->d_partials.release();
+  icp->d_ticket.release();
+  icp->d_result.release();
+  if (icp->h_results) (void)hipHostFree(icp->h_results);
+  if (icp->events_ready)
+    for (auto & ev : icp->events)
+      for (auto & e : ev) (void)hipEventDestroy(e);
+  if (icp->map) mh_map_release(icp->map);
+  delete icp;
+}
+
+size_t mh_icp_size(const mh_icp * icp) { return icp ? icp->n : 0; }
+
+int mh_icp_reset(mh_icp * icp)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_reset: icp is NULL");
+  icp->cold = true;  // the next linearize treats the cached state as all-zero (no memset needed)
+  return MH_OK;
+}
+
+int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+{
+  if (!icp || !R_src || !t_src || !g_unit || !out)
+    return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (icp->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize: binary factor needs the target pose");
+  if (icp->n_pending >= kMaxPending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_async: too many calls in flight");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_sync_device(icp->map);
+  if (rc != MH_OK) return rc;
+  if (ctx->profiling && !icp->events_ready) {
+    for (auto & ev : icp->events)
+      for (auto & e : ev) MH_HIP(ctx, hipEventCreate(&e));
+    icp->events_ready = true;
+  }
+
+  mh::IcpArgs a;
+  a.map = map_view(icp->map);
+  a.src = static_cast<const float4 *>(icp->d_src.p);
+  a.n = static_cast<int>(icp->n);
+  a.k = static_cast<int>(icp->cfg.num_corres_points);
+  a.cold = icp->cold ? 1 : 0;
+  a.use_huber = icp->cfg.use_huber;
+  pose_inverse_compose(R_src, t_src, icp->binary ? R_tgt : nullptr, icp->binary ? t_tgt : nullptr, a.R, a.t);
+  // config floats are promoted to double in the reference's expressions (geometric_config.hpp:17-33)
+  a.da_thresh = static_cast<double>(icp->cfg.target_ivox_map_min_dist_in_voxel / 4);
+  a.max_d2 = static_cast<double>(icp->cfg.max_corres_distance * icp->cfg.max_corres_distance);
+  a.plane_valid = static_cast<double>(icp->cfg.plane_validity_distance);
+  a.sigma = static_cast<double>(icp->cfg.lidar_point_noise_std_dev);
+  a.huber = static_cast<double>(icp->cfg.huber_threshold);
+  a.q_da = static_cast<double *>(icp->d_qda.p);
+  a.mean = static_cast<double *>(icp->d_mean.p);
+  a.normal = static_cast<double *>(icp->d_normal.p);
+  a.status = static_cast<int32_t *>(icp->d_status.p);
+  a.partials = static_cast<double *>(icp->d_partials.p);
+  a.ticket = static_cast<unsigned int *>(icp->d_ticket.p);
+  a.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
+
+  mh::LocArgs l;
+  l.src = a.src;
+  l.n = a.n;
+  std::memcpy(l.R, a.R, sizeof(l.R));
+  l.normal = a.normal;
+  l.status = a.status;
+  l.partials = a.partials;
+  l.ticket = a.ticket + 1;
+  l.result = a.result;
+
+  const int slot = icp->n_pending;
+  PendingCall & pc = icp->pending[slot];
+  pc.out = out;
+  std::memcpy(pc.R, a.R, sizeof(pc.R));
+  for (int i = 0; i < 3; ++i) pc.gz[i] = -g_unit[i];
+  pc.linearize_count = ++icp->linearize_count;
+  if (ctx->profiling) {
+    for (int i = 0; i < 3; ++i) pc.ev[i] = icp->events[slot][i];
+    MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
+  } else {
+    pc.ev[0] = pc.ev[1] = pc.ev[2] = nullptr;
+  }
+  if (a.n > 0) {
+    MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
+    if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+    if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+  } else if (ctx->profiling) {
+    MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+    MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+  }
+  MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  icp->n_pending++;
+  icp->cold = false;
+  return MH_OK;
+}
+
+int mh_icp_wait(mh_icp * icp)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
+  mh_ctx * ctx = icp->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < icp->n_pending; ++s) {
+    const PendingCall & pc = icp->pending[s];
+    finish_result(icp, icp->h_results[s], pc, pc.out);
+    if (pc.ev[0]) {
+      (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
+      (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
+    }
+  }
+  icp->n_pending = 0;
+  return MH_OK;
+}
+
+int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                     const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+{
+  const int rc = mh_icp_linearize_async(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out);
+  if (rc != MH_OK) return rc;
+  return mh_icp_wait(icp);
+}
+
+int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_get_state: icp is NULL");
+  mh_ctx * ctx = icp->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = icp->n;
+  if (n == 0) return MH_OK;
+  if (status) MH_HIP(ctx, hipMemcpyAsync(status, icp->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (means) MH_HIP(ctx, hipMemcpyAsync(means, icp->d_mean.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (normals)
+    MH_HIP(ctx, hipMemcpyAsync(normals, icp->d_normal.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+// ---- deskew / transforms -----------------------------------------------------------------------
+int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns, const float * Rt12, size_t n_groups,
+              const float * R_B_L, const float * t_B_L)
+{
+  if (!ctx || (!pts && n) || (!unique_ns && n_groups) || (!Rt12 && n_groups))
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_deskew: NULL argument");
+  if ((R_B_L == nullptr) != (t_B_L == nullptr)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_deskew: R_B_L and t_B_L go together");
+  if (n == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_point32 * d_pts = nullptr;
+  uint32_t * d_ns = nullptr;
+  float *d_rt = nullptr, *d_body = nullptr;
+  MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
+  MH_HIP(ctx, hipMalloc(&d_ns, (n_groups ? n_groups : 1) * sizeof(uint32_t)));
+  MH_HIP(ctx, hipMalloc(&d_rt, (n_groups ? n_groups : 1) * 12 * sizeof(float)));
+  MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+  if (n_groups) {
+    MH_HIP(ctx, hipMemcpyAsync(d_ns, unique_ns, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(d_rt, Rt12, n_groups * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (R_B_L) {
+    float body[12];
+    std::memcpy(body, R_B_L, 9 * sizeof(float));
+    std::memcpy(body + 9, t_B_L, 3 * sizeof(float));
+    MH_HIP(ctx, hipMalloc(&d_body, sizeof(body)));
+    MH_HIP(ctx, hipMemcpyAsync(d_body, body, sizeof(body), hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `body` is a stack buffer
+  }
+  MH_HIP(ctx, mh::launch_deskew(d_pts, static_cast<int>(n), d_ns, d_rt, static_cast<int>(n_groups), d_body, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_pts);
+  (void)hipFree(d_ns);
+  (void)hipFree(d_rt);
+  if (d_body) (void)hipFree(d_body);
+  return MH_OK;
+}
+
+int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
+{
+  if (!ctx || (!pts && n) || !R || !t) return fail(ctx, MH_ERR_INVALID_ARG, "mh_transform_f32: NULL argument");
+  if (n == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_point32 * d_pts = nullptr;
+  float * d_rt = nullptr;
+  float rt[12];
+  std::memcpy(rt, R, 9 * sizeof(float));
+  std::memcpy(rt + 9, t, 3 * sizeof(float));
+  MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
+  MH_HIP(ctx, hipMalloc(&d_rt, sizeof(rt)));
+  MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(d_rt, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MH_HIP(ctx, mh::launch_transform(d_pts, static_cast<int>(n), d_rt, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_pts);
+  (void)hipFree(d_rt);
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+// Host side of the device-resident incremental voxel map (the iVox counterpart).
+//
+// Replaces gtsam_points::iVox as used through IncrementalVoxelMapPCL
+// (reference: include/mimosa/lidar/incremental_voxel_map.hpp:22-54,
+// src/lidar/incremental_voxel_map.cpp:14-62; configuration src/lidar/geometric.cpp:23-28).
+//
+// Same observable semantics — greedy first-come-first-kept insertion in input order with a
+// min-distance rule and a per-voxel cap, voxels numbered in creation order, LRU purge every
+// lru_clear_cycle inserts, neighbour traversal in offset-generation order — but laid out for HBM,
+// not for pointer chasing:
+//
+//   buckets : float4[n_voxels * 20]        one 320-byte bucket per voxel, points in insertion order
+//   cells   : uint32[n_blocks * 64]        4x4x4-voxel blocks; entry = voxel_id << 5 | count, ~0u = empty
+//   table   : int4[capacity]               open-addressing hash of BLOCK coords -> block id (w), -1 empty
+//
+// A 19/27-voxel neighbourhood touches at most 8 blocks (usually 1-2), so a query costs 1-2 hash
+// probes plus cell reads that share 256-byte block rows, instead of 19 independent hash probes.
+// Map points are float32-valued in the reference too (PointCloudCPU is built from Vector3f,
+// incremental_voxel_map.cpp:40-48), so float4 storage is lossless; all distance arithmetic is fp64.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mimosa_hip.h"
+
+namespace mh
+{
+constexpr int kBlockLog2 = 2;                       // 4x4x4 voxels per block
+constexpr int kBlockDim = 1 << kBlockLog2;
+constexpr int kCellsPerBlock = kBlockDim * kBlockDim * kBlockDim;
+constexpr int kBucketStride = 20;                   // FlatContainer max_num_points_in_cell
+constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
+
+struct Int4
+{
+  int32_t x, y, z, w;
+};
+struct Float4
+{
+  float x, y, z, w;
+};
+
+// include/mimosa/lidar/utils.hpp:218-222 (same helper in gtsam_points/util/fast_floor.hpp)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int fast_floor(double v)
+{
+  const int n = static_cast<int>(v);
+  return n - (v < static_cast<double>(n) ? 1 : 0);
+}
+
+// Hash of a block coordinate.  Internal to the table (not observable), so the 32-bit Teschner
+// primes + a finaliser are used instead of the 64-bit XORVector3iHash multiplies
+// (include/mimosa/lidar/utils.hpp:228-238): 3 v_mul_lo_u32 on the device instead of 3 64-bit muls.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t block_hash(int bx, int by, int bz)
+{
+  uint32_t h = (static_cast<uint32_t>(bx) * 73856093u) ^ (static_cast<uint32_t>(by) * 19349663u) ^
+               (static_cast<uint32_t>(bz) * 83492791u);
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h;
+}
+
+inline int neighbor_offsets(int mode, int8_t out[27][3])
+{
+  // gtsam_points neighbor_offsets(): generation order is observable through tie-breaking
+  int n = 0;
+  auto push = [&](int i, int j, int k) {
+    out[n][0] = static_cast<int8_t>(i);
+    out[n][1] = static_cast<int8_t>(j);
+    out[n][2] = static_cast<int8_t>(k);
+    ++n;
+  };
+  if (mode == 1) {
+    push(0, 0, 0);
+  } else if (mode == 7) {
+    push(0, 0, 0);
+    push(1, 0, 0);
+    push(-1, 0, 0);
+    push(0, 1, 0);
+    push(0, -1, 0);
+    push(0, 0, 1);
+    push(0, 0, -1);
+  } else if (mode == 19 || mode == 27) {
+    for (int i = -1; i <= 1; ++i)
+      for (int j = -1; j <= 1; ++j)
+        for (int k = -1; k <= 1; ++k) {
+          if (mode == 19 && (i != 0) && (j != 0) && (k != 0)) continue;
+          push(i, j, k);
+        }
+  }
+  return n;
+}
+
+class HostVoxelMap
+{
+public:
+  explicit HostVoxelMap(const mh_map_config & cfg)
+  : cfg_(cfg), inv_leaf_(1.0 / cfg.leaf_size), min_sq_(cfg.min_dist_in_cell * cfg.min_dist_in_cell)
+  {
+    rehash_blocks(1024);
+  }
+
+  const mh_map_config & config() const { return cfg_; }
+  double inv_leaf() const { return inv_leaf_; }
+  size_t n_voxels() const { return vox_count_.size(); }
+  size_t n_blocks() const { return n_blocks_; }
+  size_t n_points() const { return n_points_; }
+  uint32_t table_mask() const { return table_mask_; }
+  const std::vector<Int4> & table() const { return table_; }
+  const std::vector<uint32_t> & cells() const { return cells_; }
+  const std::vector<Float4> & buckets() const { return buckets_; }
+  const std::vector<uint8_t> & counts() const { return vox_count_; }
+
+  // Dirty tracking for the device mirror.
+  bool structure_changed() const { return structure_changed_; }
+  const std::vector<uint32_t> & dirty_voxels() const { return dirty_; }
+  void clear_dirty()
+  {
+    for (uint32_t v : dirty_) dirty_flag_[v] = 0;
+    dirty_.clear();
+    structure_changed_ = false;
+  }
+
+  // iVox::insert: in input order; LRU bookkeeping after the batch.
+  void insert(const float * xyz, size_t n, size_t stride)
+  {
+    const size_t max_pts = static_cast<size_t>(cfg_.max_points_in_cell);
+    for (size_t i = 0; i < n; ++i) {
+      const float fx = xyz[i * stride + 0], fy = xyz[i * stride + 1], fz = xyz[i * stride + 2];
+      const double px = fx, py = fy, pz = fz;
+      const int cx = fast_floor(px * inv_leaf_), cy = fast_floor(py * inv_leaf_), cz = fast_floor(pz * inv_leaf_);
+      const uint32_t vid = find_or_create_voxel(cx, cy, cz);
+      vox_lru_[vid] = lru_counter_;
+      const size_t cnt = vox_count_[vid];
+      if (cnt >= max_pts) continue;
+      Float4 * b = &buckets_[static_cast<size_t>(vid) * kBucketStride];
+      bool close = false;
+      for (size_t j = 0; j < cnt; ++j) {
+        const double dx = static_cast<double>(b[j].x) - px, dy = static_cast<double>(b[j].y) - py,
+                     dz = static_cast<double>(b[j].z) - pz;
+        // Eigen SSE2 Vector4d squaredNorm order: (dx2 + dz2) + (dy2 + dw2), dw = 0
+        if ((dx * dx + dz * dz) + (dy * dy + 0.0) < min_sq_) {
+          close = true;
+          break;
+        }
+      }
+      if (close) continue;
+      b[cnt] = Float4{fx, fy, fz, 1.0f};
+      vox_count_[vid] = static_cast<uint8_t>(cnt + 1);
+      cells_[vox_cell_[vid]] = (vid << 5) | static_cast<uint32_t>(cnt + 1);
+      ++n_points_;
+      mark_dirty(vid);
+    }
+    if ((++lru_counter_) % static_cast<uint64_t>(cfg_.lru_clear_cycle) == 0) purge_lru();
+  }
+
+  // voxel_data(): all points in voxel (creation) order
+  size_t get_cloud(float * xyz, size_t capacity) const
+  {
+    size_t n = 0;
+    for (size_t v = 0; v < vox_count_.size(); ++v)
+      for (size_t j = 0; j < vox_count_[v]; ++j) {
+        if (xyz && n < capacity) {
+          const Float4 & p = buckets_[v * kBucketStride + j];
+          xyz[3 * n + 0] = p.x;
+          xyz[3 * n + 1] = p.y;
+          xyz[3 * n + 2] = p.z;
+        }
+        ++n;
+      }
+    return n;
+  }
+
+private:
+  int find_block(int bx, int by, int bz) const
+  {
+    uint32_t h = block_hash(bx, by, bz) & table_mask_;
+    for (;;) {
+      const Int4 & s = table_[h];
+      if (s.w < 0) return -1;
+      if (s.x == bx && s.y == by && s.z == bz) return s.w;
+      h = (h + 1) & table_mask_;
+    }
+  }
+  void table_put(int bx, int by, int bz, int id)
+  {
+    uint32_t h = block_hash(bx, by, bz) & table_mask_;
+    while (table_[h].w >= 0) h = (h + 1) & table_mask_;
+    table_[h] = Int4{bx, by, bz, id};
+  }
+  void rehash_blocks(size_t capacity)
+  {
+    table_.assign(capacity, Int4{0, 0, 0, -1});
+    table_mask_ = static_cast<uint32_t>(capacity - 1);
+    for (size_t b = 0; b < n_blocks_; ++b)
+      table_put(block_coord_[3 * b], block_coord_[3 * b + 1], block_coord_[3 * b + 2], static_cast<int>(b));
+    structure_changed_ = true;
+  }
+  uint32_t find_or_create_voxel(int cx, int cy, int cz)
+  {
+    const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
+    int blk;
+    if (last_block_ >= 0 && bx == last_b_[0] && by == last_b_[1] && bz == last_b_[2]) {
+      blk = last_block_;
+    } else {
+      blk = find_block(bx, by, bz);
+      if (blk < 0) {
+        if ((n_blocks_ + 1) * 2 > table_.size()) rehash_blocks(table_.size() * 2);
+        blk = static_cast<int>(n_blocks_++);
+        block_coord_.insert(block_coord_.end(), {bx, by, bz});
+        cells_.resize(n_blocks_ * kCellsPerBlock, kEmptyCell);
+        table_put(bx, by, bz, blk);
+        structure_changed_ = true;
+      }
+      last_block_ = blk;
+      last_b_[0] = bx;
+      last_b_[1] = by;
+      last_b_[2] = bz;
+    }
+    const int m = kBlockDim - 1;
+    const size_t cell = static_cast<size_t>(blk) * kCellsPerBlock +
+                        (((cx & m) << (2 * kBlockLog2)) | ((cy & m) << kBlockLog2) | (cz & m));
+    uint32_t e = cells_[cell];
+    if (e != kEmptyCell) return e >> 5;
+    const uint32_t vid = static_cast<uint32_t>(vox_count_.size());
+    vox_count_.push_back(0);
+    vox_lru_.push_back(lru_counter_);
+    vox_cell_.push_back(static_cast<uint32_t>(cell));
+    vox_coord_.insert(vox_coord_.end(), {cx, cy, cz});
+    buckets_.resize(static_cast<size_t>(vid + 1) * kBucketStride, Float4{0, 0, 0, 0});
+    dirty_flag_.push_back(0);
+    cells_[cell] = vid << 5;
+    mark_dirty(vid);
+    return vid;
+  }
+  void mark_dirty(uint32_t vid)
+  {
+    if (!dirty_flag_[vid]) {
+      dirty_flag_[vid] = 1;
+      dirty_.push_back(vid);
+    }
+  }
+  // Remove voxels with lru + horizon < counter, keep creation order, renumber, rebuild the blocks.
+  void purge_lru()
+  {
+    const uint64_t horizon = static_cast<uint64_t>(cfg_.lru_horizon);
+    size_t keep = 0;
+    bool any = false;
+    for (size_t v = 0; v < vox_count_.size(); ++v)
+      if (vox_lru_[v] + horizon < lru_counter_) {
+        any = true;
+        break;
+      }
+    if (!any) return;
+    std::vector<int32_t> coord;
+    std::vector<uint8_t> count;
+    std::vector<uint64_t> lru;
+    std::vector<Float4> buckets;
+    for (size_t v = 0; v < vox_count_.size(); ++v) {
+      if (vox_lru_[v] + horizon < lru_counter_) continue;
+      coord.insert(coord.end(), {vox_coord_[3 * v], vox_coord_[3 * v + 1], vox_coord_[3 * v + 2]});
+      count.push_back(vox_count_[v]);
+      lru.push_back(vox_lru_[v]);
+      buckets.insert(
+        buckets.end(), buckets_.begin() + v * kBucketStride, buckets_.begin() + (v + 1) * kBucketStride);
+      ++keep;
+    }
+    vox_coord_.swap(coord);
+    vox_count_.swap(count);
+    vox_lru_.swap(lru);
+    buckets_.swap(buckets);
+    vox_cell_.assign(keep, 0);
+    dirty_flag_.assign(keep, 0);
+    dirty_.clear();
+    n_blocks_ = 0;
+    block_coord_.clear();
+    cells_.clear();
+    last_block_ = -1;
+    size_t cap = 1024;
+    while (cap < keep) cap *= 2;  // blocks <= voxels
+    table_.assign(cap, Int4{0, 0, 0, -1});
+    table_mask_ = static_cast<uint32_t>(cap - 1);
+    n_points_ = 0;
+    for (size_t v = 0; v < keep; ++v) {
+      const int cx = vox_coord_[3 * v], cy = vox_coord_[3 * v + 1], cz = vox_coord_[3 * v + 2];
+      const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
+      int blk = find_block(bx, by, bz);
+      if (blk < 0) {
+        blk = static_cast<int>(n_blocks_++);
+        block_coord_.insert(block_coord_.end(), {bx, by, bz});
+        cells_.resize(n_blocks_ * kCellsPerBlock, kEmptyCell);
+        table_put(bx, by, bz, blk);
+      }
+      const int m = kBlockDim - 1;
+      const size_t cell = static_cast<size_t>(blk) * kCellsPerBlock +
+                          (((cx & m) << (2 * kBlockLog2)) | ((cy & m) << kBlockLog2) | (cz & m));
+      vox_cell_[v] = static_cast<uint32_t>(cell);
+      cells_[cell] = (static_cast<uint32_t>(v) << 5) | vox_count_[v];
+      n_points_ += vox_count_[v];
+    }
+    structure_changed_ = true;
+    full_rebuild_ = true;
+  }
+
+public:
+  bool take_full_rebuild()
+  {
+    const bool r = full_rebuild_;
+    full_rebuild_ = false;
+    return r;
+  }
+
+private:
+  mh_map_config cfg_;
+  double inv_leaf_, min_sq_;
+  uint64_t lru_counter_ = 0;
+  size_t n_points_ = 0;
+  // per voxel (creation order == iVox flat_voxels order)
+  std::vector<int32_t> vox_coord_;
+  std::vector<uint8_t> vox_count_;
+  std::vector<uint64_t> vox_lru_;
+  std::vector<uint32_t> vox_cell_;
+  std::vector<Float4> buckets_;
+  // blocks
+  size_t n_blocks_ = 0;
+  std::vector<int32_t> block_coord_;
+  std::vector<uint32_t> cells_;
+  std::vector<Int4> table_;
+  uint32_t table_mask_ = 0;
+  int last_block_ = -1;
+  int last_b_[3] = {0, 0, 0};
+  // device mirror bookkeeping
+  std::vector<uint8_t> dirty_flag_;
+  std::vector<uint32_t> dirty_;
+  bool structure_changed_ = true;
+  bool full_rebuild_ = false;
+};
+
+}  // namespace mh

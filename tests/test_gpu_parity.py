@@ -1,0 +1,226 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs."""
+import numpy as np
+import pytest
+
+from parity import assert_result_parity, assert_state_parity, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(ctx, world, binary=False, mode=19, cfg_over=None, k=None):
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    cfg = dict(world["cfg"])
+    if cfg_over:
+        cfg.update(cfg_over)
+    if k is not None:
+        cfg["num_corres_points"] = k
+    gm = capi.VoxelMap(ctx, mode=mode)
+    gm.insert(world["map_xyz"])
+    rm = ref_cpu.Map(mode=mode)
+    rm.insert(world["map_xyz"])
+    gf = capi.ICPFactor(ctx, gm, world["pts"], capi.make_reg_config(**cfg), binary=binary)
+    rf = ref_cpu.ICP(rm, world["pts"], ref_cpu.make_config(**cfg), binary=binary)
+    return gm, rm, gf, rf
+
+
+def test_map_matches_oracle(ctx, small_world):
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm = capi.VoxelMap(ctx)
+    rm = ref_cpu.Map()
+    for chunk in np.array_split(small_world["map_xyz"], 3):
+        gm.insert(chunk)
+        rm.insert(chunk)
+    s = gm.stats()
+    assert s["n_voxels"] == rm.num_voxels and s["n_points"] == rm.num_points
+    _, _, xyz = rm.export()
+    assert np.array_equal(gm.get_cloud(), xyz)  # same voxel creation order, same kept points (bit-exact)
+
+
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_knn_matches_oracle(ctx, small_world, k):
+    gm, rm, gf, rf = _mk(ctx, small_world)
+    rng = np.random.default_rng(5)
+    q = small_world["map_xyz"][rng.integers(0, len(small_world["map_xyz"]), 700)].astype(np.float64)
+    q += rng.normal(0, 0.2, q.shape)
+    q = np.concatenate([q, [[1e3, 1e3, 1e3], [-50.2, 3.3, 9.1]]])  # far away: nothing found
+    pts, sq, found = gm.knn(q, k)
+    idx, sq_r, found_r, _ = rm.knn(q, k)
+    assert np.array_equal(found, found_r)
+    for i in range(len(q)):
+        f = found[i]
+        assert np.array_equal(sq[i, :f], sq_r[i, :f]), (  # fp64 distances bit-exact, same order
+            i, q[i].tolist(), (sq[i, :f] - sq_r[i, :f]).tolist(), sq[i, :f].view(np.int64) - sq_r[i, :f].view(np.int64))
+        for j in range(f):
+            assert np.array_equal(pts[i, j], rm.point(idx[i, j]))
+
+
+def test_linearize_cold_and_relinearize(ctx, small_world):
+    from mimosa_amd import synth
+    gm, rm, gf, rf = _mk(ctx, small_world)
+    R, t = small_world["R"], small_world["t"]
+    g = gf.linearize(R, t)
+    r = rf.linearize(R, t)
+    assert_result_parity(g, r)
+    assert_state_parity(gf.state(), rf.state())
+    assert g["status_hist"][8] > 300  # a healthy share of valid correspondences
+    # small move: everything hits the data-association cache (no k-NN)
+    t2 = t + np.array([0.004, 0.003, -0.002])
+    g2, r2 = gf.linearize(R, t2), rf.linearize(R, t2)
+    assert g2["n_knn"] == 0
+    assert_result_parity(g2, r2)
+    # small rotation: far points move more than min_dist/4 and re-associate, near ones do not
+    R3 = R @ synth.so3_exp(np.array([0.0, 0.0, 0.015]))
+    g3, r3 = gf.linearize(R3, t2), rf.linearize(R3, t2)
+    assert 0 < g3["n_knn"] < len(small_world["pts"])
+    assert_result_parity(g3, r3)
+    assert_state_parity(gf.state(), rf.state())
+
+
+def test_reset_equals_fresh_factor(ctx, small_world):
+    gm, rm, gf, rf = _mk(ctx, small_world)
+    R, t = small_world["R"], small_world["t"]
+    first = gf.linearize(R, t)
+    gf.linearize(R, t + 0.05)
+    gf.reset()
+    again = gf.linearize(R, t)
+    for k in ("H_ss", "b_s", "f", "status_hist", "loc_trans_comp"):
+        assert np.array_equal(first[k], again[k]), k  # deterministic reduction order: bit-identical
+    from oracle import ref_cpu
+    rf2 = ref_cpu.ICP(rm, small_world["pts"], ref_cpu.make_config(**small_world["cfg"]))
+    rf2.linearize(R, t)
+    assert_state_parity(gf.state(), rf2.state())
+
+
+def test_clone_is_deep(ctx, small_world):
+    gm, rm, gf, rf = _mk(ctx, small_world)
+    R, t = small_world["R"], small_world["t"]
+    gf.linearize(R, t)
+    rf.linearize(R, t)
+    gc, rc = gf.clone(), rf.clone()
+    t2 = t + np.array([0.03, -0.02, 0.01])
+    assert_result_parity(gc.linearize(R, t2), rc.linearize(R, t2))
+    # the original still holds its own association state
+    t3 = t + np.array([0.001, 0.0, 0.0])
+    assert_result_parity(gf.linearize(R, t3), rf.linearize(R, t3))
+
+
+def test_binary_factor(ctx, small_world):
+    gm, rm, gf, rf = _mk(ctx, small_world, binary=True)
+    R, t = small_world["R"], small_world["t"]
+    from mimosa_amd import synth
+    Rt = synth.so3_exp(np.array([0.01, -0.02, 0.015]))
+    tt = np.array([0.02, -0.01, 0.03])
+    Rs, ts = Rt @ R, Rt @ t + tt  # so that delta = T_tgt^-1 T_src equals the unary query pose
+    g = gf.linearize(Rs, ts, R_tgt=Rt, t_tgt=tt)
+    r = rf.linearize(Rs, ts, R_tgt=Rt, t_tgt=tt)
+    assert_result_parity(g, r, binary=True)
+
+
+@pytest.mark.parametrize("mode", [1, 7, 27])
+def test_neighbor_modes(ctx, small_world, mode):
+    gm, rm, gf, rf = _mk(ctx, small_world, mode=mode)
+    assert_result_parity(gf.linearize(small_world["R"], small_world["t"]), rf.linearize(small_world["R"], small_world["t"]))
+
+
+@pytest.mark.parametrize("k", [3, 4, 6, 8])
+def test_num_corres_points(ctx, small_world, k):
+    gm, rm, gf, rf = _mk(ctx, small_world, k=k)
+    assert_result_parity(gf.linearize(small_world["R"], small_world["t"]), rf.linearize(small_world["R"], small_world["t"]))
+
+
+def test_reg_4_dof_and_degeneracy_projection(ctx, small_world):
+    R, t = small_world["R"], small_world["t"]
+    g_unit = np.array([0.05, -0.02, -1.0])
+    g_unit /= np.linalg.norm(g_unit)
+    gm, rm, gf, rf = _mk(ctx, small_world, cfg_over=dict(reg_4_dof=1))
+    assert_result_parity(gf.linearize(R, t, g_unit), rf.linearize(R, t, g_unit))
+    # struct-default thresholds trigger the reference's degeneracy branch (H, b rebuilt as zero: F10)
+    gm, rm, gf, rf = _mk(ctx, small_world, cfg_over=dict(project_on_degneneracy=1, degen_thresh_trans=1e9))
+    g, r = gf.linearize(R, t), rf.linearize(R, t)
+    assert not g["H_ss"].any() and not r["H_ss"].any()
+    assert_result_parity(g, r, check_eigvec=False)
+
+
+def test_empty_and_far_inputs(ctx, small_world):
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+    cfg = small_world["cfg"]
+    gm = capi.VoxelMap(ctx)
+    # empty map: every point InsufficientCorresPoints
+    gf = capi.ICPFactor(ctx, gm, small_world["pts"][:100], capi.make_reg_config(**cfg))
+    g = gf.linearize(small_world["R"], small_world["t"])
+    assert g["status_hist"][1] == 100 and g["f"] == 0.0
+    # empty cloud
+    gm.insert(small_world["map_xyz"])
+    gf0 = capi.ICPFactor(ctx, gm, np.zeros(0, synth.POINT_DTYPE), capi.make_reg_config(**cfg))
+    g0 = gf0.linearize(small_world["R"], small_world["t"])
+    assert g0["status_hist"].sum() == 0 and not g0["H_ss"].any()
+    # cloud transformed far outside the map
+    gf2 = capi.ICPFactor(ctx, gm, small_world["pts"], capi.make_reg_config(**cfg))
+    rm = ref_cpu.Map(); rm.insert(small_world["map_xyz"])
+    rf2 = ref_cpu.ICP(rm, small_world["pts"], ref_cpu.make_config(**cfg))
+    tf = small_world["t"] + 500.0
+    assert np.array_equal(gf2.linearize(small_world["R"], tf)["status_hist"], rf2.linearize(small_world["R"], tf)["status_hist"])
+
+
+def test_room_scale_parity(ctx, room_world):
+    """config[0] size: 65 536-pt scan vs ~0.5 M-pt map."""
+    gm, rm, gf, rf = _mk(ctx, room_world)
+    R, t = room_world["R"], room_world["t"]
+    r = rf.linearize(R, t)
+    g = gf.linearize(R, t)
+    assert_result_parity(g, r)
+    assert_state_parity(gf.state(), rf.state())
+    # per-point whitened residual / Jacobian rows on points valid in both (§8(d) parity check)
+    e_r, J_r, valid = rf.point_rows(R, t)
+    st, mean, nrm = gf.state()
+    P = np.stack([room_world["pts"]["x"], room_world["pts"]["y"], room_world["pts"]["z"]], 1).astype(np.float64)
+    v = (st == 8) & (valid == 1)
+    q = P[v] @ R.T + t
+    e = np.einsum("ij,ij->i", nrm[v], mean[v] - q)
+    sigma = float(np.float32(room_world["cfg"]["lidar_point_noise_std_dev"]))
+    hub = float(np.float32(room_world["cfg"]["huber_threshold"]))
+    w = np.abs(e / sigma)
+    sw = np.where(w > hub, np.sqrt(hub / np.maximum(w, 1e-300)), 1.0)
+    assert rel(e * sw / sigma, e_r[v]) <= 1e-5
+
+
+def test_deskew_bit_exact(ctx):
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+    pts, aux = synth.make_scan(32, skew=True)
+    R_B_L = synth.so3_exp(np.array([0.01, 0.02, -0.03])).astype(np.float32)
+    t_B_L = np.array([0.1, -0.05, 0.2], np.float32)
+    got = ctx.deskew(pts, aux["unique_ns"], aux["Rt12"])
+    ref = ref_cpu.deskew(pts, aux["unique_ns"], aux["Rt12"])
+    assert got.tobytes() == ref.tobytes()
+    got2 = ctx.deskew(pts, aux["unique_ns"], aux["Rt12"], R_B_L, t_B_L)
+    ref2 = ref_cpu.transform_f32(ref, R_B_L, t_B_L)
+    assert got2.tobytes() == ref2.tobytes()
+    got3 = ctx.transform_f32(pts, R_B_L, t_B_L)
+    assert got3.tobytes() == ref_cpu.transform_f32(pts, R_B_L, t_B_L).tobytes()
+    # timestamps missing from the table are left untouched
+    sub = aux["unique_ns"][::2]
+    got4 = ctx.deskew(pts, sub, aux["Rt12"][::2])
+    assert got4.tobytes() == ref_cpu.deskew(pts, sub, aux["Rt12"][::2]).tobytes()
+
+
+def test_async_pipeline_matches_sync(ctx, small_world):
+    gm, rm, gf, rf = _mk(ctx, small_world)
+    R, t = small_world["R"], small_world["t"]
+    sync = []
+    for i in range(4):
+        gf.reset()
+        sync.append(gf.linearize(R, t + 0.001 * i))
+    outs = []
+    for i in range(4):
+        gf.reset()
+        outs.append(gf.linearize_async(R, t + 0.001 * i))
+    gf.wait()
+    for a, b in zip(sync, outs):
+        b = b.as_dict()
+        assert np.array_equal(a["H_ss"], b["H_ss"]) and np.array_equal(a["status_hist"], b["status_hist"])
