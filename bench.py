@@ -171,6 +171,8 @@ def main():
             "mode": f"pipelined, <= {INFLIGHT} linearize calls in flight, every result copied to the host",
             "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
             "status_hist": [int(v) for v in last["status_hist"]],
+            "exact_fallback_queries": int(last["n_exact_fallback"]),
+            "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2),
         },
         "roofline": {
             "bound": "hbm",

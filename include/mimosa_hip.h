@@ -117,8 +117,11 @@ typedef struct mh_icp_result {
   double degen_rot[3], degen_trans[3], degen_eigvec_rot[9], degen_eigvec_trans[9];
   int32_t status_hist[9];
   int32_t linearize_count;
-  double mean_candidates; /* mean number of map points scanned per query that ran k-NN */
+  double mean_candidates; /* mean number of map points in the occupied neighbour voxels of a query that ran k-NN
+                             (what the reference scans; SURVEY.md §8(d)'s C_q) */
+  double mean_scanned;    /* mean number the device actually scanned after exact box-distance pruning */
   int64_t n_knn;          /* queries that ran k-NN in this call (the rest hit the DA cache) */
+  int64_t n_exact_fallback; /* of those, queries whose coarse f32 scan could not be proven exact and were redone in fp64 */
   /* device-side timing of this call, ms; filled only when profiling is on (mh_set_profiling) */
   float gpu_ms_linearize; /* icp_linearize kernel (K3) */
   float gpu_ms_localizability; /* component-localizability kernel (K4) */

@@ -21,6 +21,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("icp_kernels.hip", []),
     ("deskew_kernels.hip", ["-ffp-contract=off"]),
+    ("order_kernels.hip", []),
     ("mh_api.hip", []),
 ]
 HEADERS = ["icp_device.hpp", "math3.hpp", "voxel_map.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
@@ -40,9 +41,11 @@ def _stale(out: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
+    """timeline=True builds the diagnostic variant libmimosa_hip_timeline.so (-DMH_TIMELINE:
+    per-wave s_memtime stamps + mh_icp_timeline); never loaded by the product path."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_timeline" if timeline else "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -53,17 +56,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
-                   "-Wno-unused-parameter", *extra, "-c", s, "-o", o]
+                   "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] if timeline else []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    lib = LIB.replace(".so", "_timeline.so") if timeline else LIB
+    if force or _stale(lib, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

@@ -75,7 +75,7 @@ class IcpResult(C.Structure):
         ("degen_rot", C.c_double * 3), ("degen_trans", C.c_double * 3),
         ("degen_eigvec_rot", C.c_double * 9), ("degen_eigvec_trans", C.c_double * 9),
         ("status_hist", C.c_int32 * 9), ("linearize_count", C.c_int32),
-        ("mean_candidates", C.c_double), ("n_knn", C.c_int64),
+        ("mean_candidates", C.c_double), ("mean_scanned", C.c_double), ("n_knn", C.c_int64), ("n_exact_fallback", C.c_int64),
         ("gpu_ms_linearize", C.c_float), ("gpu_ms_localizability", C.c_float),
     ]
 

@@ -9,7 +9,7 @@
 
 namespace mh
 {
-constexpr int kPartialStride = 96;  // >= 91 sums of the binary factor + 2 counters
+constexpr int kPartialStride = 96;  // >= 91 sums of the binary factor + 4 counters
 
 // Read-only view of the device-resident voxel map (see voxel_map.hpp for the layout).
 struct MapView
@@ -19,8 +19,10 @@ struct MapView
   const float4 * buckets;
   double inv_leaf;
   uint32_t mask;
-  int n_off;
-  int8_t off[27][3];  // neighbour offsets in generation order
+  int n_off;     // 1, 7, 19 or 27
+  int mode_idx;  // row of the constant neighbour-offset table (0..3).  NOTE: no arrays in kernel-argument
+                 // structs — a loop-indexed array member makes the compiler spill the whole by-value
+                 // kernarg block to scratch and serialise every access behind s_waitcnt vmcnt(0).
 };
 
 // Everything linearize() returns from the device in one small D2H copy.
@@ -29,7 +31,7 @@ struct DeviceResult
   double sums[kPartialStride];  // upper triangle of sum v v^T, v = [J_s(6) (,J_t(6)), e]
   double loc_rot_final[3], eig_rot[9], loc_trans_final[3], eig_trans[9];
   double loc_comp[6];     // trans xyz, rot xyz
-  unsigned long long n_knn, n_cand;
+  unsigned long long n_knn, n_cand, n_fallback, n_scanned;
   unsigned int status_hist[9];
   unsigned int pad;
 };
@@ -51,6 +53,8 @@ struct IcpArgs
   double * partials;
   unsigned int * ticket;
   DeviceResult * result;
+  unsigned long long * dbg;  // MH_TIMELINE diagnostic build only, else null
+  int reps;                  // MH_TIMELINE only: repeat the per-point section (warm-cache experiment)
 };
 
 struct LocArgs
@@ -71,6 +75,14 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream);
 hipError_t launch_localizability(const LocArgs & a, hipStream_t stream);
 hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
                           int32_t * found, hipStream_t stream);
+
+// order_kernels.hip
+size_t order_temp_bytes(int n);
+hipError_t launch_spatial_order(const float4 * xyz_in, int n, float cell, uint32_t * keys2, uint32_t * vals, void * temp,
+                                size_t temp_bytes, uint32_t * perm, float4 * xyz_out, hipStream_t stream);
+hipError_t launch_unpermute_state(const uint32_t * perm, int n, const int32_t * st_in, const double * mean_in,
+                                  const double * nrm_in, int32_t * st_out, double * mean_out, double * nrm_out,
+                                  hipStream_t stream);
 
 // deskew_kernels.hip
 hipError_t launch_deskew(mh_point32 * pts, int n, const uint32_t * unique_ns, const float * Rt12, int n_groups,

@@ -40,7 +40,22 @@ namespace
 constexpr int kThreads = 512;
 constexpr int kMaxOff = 27;
 constexpr double kDblMax = 1.7976931348623157e308;
-constexpr uint64_t kPayloadMask = 0x3FFull;  // 5 bits list slot, 5 bits bucket slot
+
+// Neighbour-voxel offsets in gtsam_points' generation order (mh::neighbor_offsets in voxel_map.hpp is
+// the host twin), one packed word per offset: (i+1) | (j+1) << 2 | (k+1) << 4.  Rows: mode 1, 7, 19, 27.
+// Lives in constant memory and is read with wave-uniform scalar loads.
+#define MH_O(i, j, k) (((i) + 1) | (((j) + 1) << 2) | (((k) + 1) << 4))
+__constant__ uint32_t kNeighborOffsets[4][kMaxOff] = {
+  {MH_O(0, 0, 0)},
+  {MH_O(0, 0, 0), MH_O(1, 0, 0), MH_O(-1, 0, 0), MH_O(0, 1, 0), MH_O(0, -1, 0), MH_O(0, 0, 1), MH_O(0, 0, -1)},
+  {MH_O(-1, -1, 0), MH_O(-1, 0, -1), MH_O(-1, 0, 0), MH_O(-1, 0, 1), MH_O(-1, 1, 0), MH_O(0, -1, -1), MH_O(0, -1, 0),
+   MH_O(0, -1, 1), MH_O(0, 0, -1), MH_O(0, 0, 0), MH_O(0, 0, 1), MH_O(0, 1, -1), MH_O(0, 1, 0), MH_O(0, 1, 1),
+   MH_O(1, -1, 0), MH_O(1, 0, -1), MH_O(1, 0, 0), MH_O(1, 0, 1), MH_O(1, 1, 0)},
+  {MH_O(-1, -1, -1), MH_O(-1, -1, 0), MH_O(-1, -1, 1), MH_O(-1, 0, -1), MH_O(-1, 0, 0), MH_O(-1, 0, 1), MH_O(-1, 1, -1),
+   MH_O(-1, 1, 0), MH_O(-1, 1, 1), MH_O(0, -1, -1), MH_O(0, -1, 0), MH_O(0, -1, 1), MH_O(0, 0, -1), MH_O(0, 0, 0),
+   MH_O(0, 0, 1), MH_O(0, 1, -1), MH_O(0, 1, 0), MH_O(0, 1, 1), MH_O(1, -1, -1), MH_O(1, -1, 0), MH_O(1, -1, 1),
+   MH_O(1, 0, -1), MH_O(1, 0, 0), MH_O(1, 0, 1), MH_O(1, 1, -1), MH_O(1, 1, 0), MH_O(1, 1, 1)}};
+#undef MH_O
 
 // Squared distance exactly as the reference's CPU build evaluates it: no FMA contraction (baseline
 // x86-64), Eigen's SSE2 Vector4d reduction order (dx2 + dz2) + (dy2 + 0).  Keeps the k-NN selection
@@ -52,19 +67,28 @@ __device__ __forceinline__ double sq_dist3(double dx, double dy, double dz)
   return (xx + zz) + yy;
 }
 
-__device__ __forceinline__ int probe_block(const int4 * table, uint32_t mask, int bx, int by, int bz)
+// XCD-aware blockIdx -> chunk mapping (cdna_hip_programming.md T1): workgroup b runs on XCD b % 8, so
+// XCD x takes the contiguous chunk range [x * cpx, (x + 1) * cpx).  Consecutive chunks of a scan (or
+// of a voxel-ordered down-sampled cloud) are spatial neighbours that read the same buckets: they now
+// share one 4 MiB L2 instead of pulling the same lines into all eight.  The grid is padded to a
+// multiple of 8; chunks past the cloud simply find qi >= n.  Placement is a speed matter only.
+__device__ __forceinline__ int xcd_chunk(int b, int n_blocks)
 {
-  uint32_t h = block_hash(bx, by, bz) & mask;
-  for (;;) {
-    const int4 s = table[h];
-    if (s.w < 0) return -1;
-    if (s.x == bx && s.y == by && s.z == bz) return s.w;
-    h = (h + 1) & mask;
-  }
+  const int cpx = n_blocks >> 3;  // launchers round the grid up to a multiple of 8
+  return (b & 7) * cpx + (b >> 3);
 }
 
-__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+// Diagnostic build only (-DMH_TIMELINE): per-wave s_memtime stamps at phase boundaries.
+#ifdef MH_TIMELINE
+#define MH_STAMP(ptr, i)                                                                       \
+  do {                                                                                         \
+    if ((ptr) && (threadIdx.x & 63) == 0)                                                      \
+      (ptr)[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 8 + (i)] = \
+        __builtin_amdgcn_s_memtime();                                                          \
+  } while (0)
+#else
+#define MH_STAMP(ptr, i) do { } while (0)
+#endif
 
 // Exact fallback: KnnResult::push verbatim (ascending, strict '<': the earlier-traversed candidate
 // wins ties) over the same compacted voxel list.  Only runs for lanes whose truncated keys collided.
@@ -78,8 +102,9 @@ __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * 
     bd[j] = kDblMax;
     bi[j] = 0xFFFFFFFFu;
   }
-  for (int j = 0; j < n_list; ++j) {
+  for (int j = 0; j < n_list; ++j) {  // slots in traversal (offset-generation) order, empty ones skipped
     const uint32_t e = list[j * list_stride];
+    if (e == kEmptyCell) continue;
     const uint32_t base = (e >> 5) * kBucketStride, cnt = e & 31u;
     for (uint32_t s = 0; s < cnt; ++s) {
       const float4 c = buckets[base + s];
@@ -106,141 +131,341 @@ __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * 
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
 // dk = squared distance of the k-th.  `list` / `blk` are this lane's columns of LDS arrays
-// [kMaxOff][stride] / [8][stride].
-template <int K>
+// [kMaxOff][stride] / [8][stride].  Returns the number of points in all occupied neighbour voxels
+// (what the reference scans); n_scanned = what was actually scanned.
+//
+// In-kernel timeline + counters (MH_TIMELINE build, round 1): the scan is bound by dependent-issue
+// latency with only ~2 waves/SIMD — not by memory (making every scan load hit one address changed
+// nothing) — so the scan does less work per point, in three exact steps:
+//   prune   the centre voxel is scanned first; a neighbour voxel whose BOX is farther from q than a
+//           proven upper bound of the current k-th distance cannot hold a top-k point and is skipped
+//           (strictly farther, so not even ties are affected): ~83 -> ~35 candidates per query
+//   coarse  every scanned candidate: f32 squared distance (6 VALU ops) -> 32-bit key whose low 10
+//           bits carry (neighbour offset index, bucket slot) -> branch-free top-KK by v_min/max_u32
+//   exact   the KK survivors: fp64 distance in the reference's operation order, ordered by
+//           (distance, traversal rank) exactly like KnnResult::push
+// plus a proof check: every scanned non-survivor's key is >= the KK-th key, so if that bound (minus
+// the f32 error budget) exceeds the exact k-th distance no non-survivor can belong to the answer;
+// otherwise the lane re-runs the exact insertion scan over all voxels (counted in
+// n_exact_fallback).  Either way the selection is bit-identical to the reference.
+template <int K, int NOFF>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int * blk, int lds_stride,
-                                              uint32_t (&bi)[K], double & dk)
+                                              uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
+                                              unsigned long long * dbg = nullptr)
 {
+  (void)dbg;
+  fell_back = false;
+  constexpr int KK = K + 3 + (K > 5 ? 1 : 0);  // survivors: 8 for k = 5, 12 for the generic k <= 8 path
+  constexpr int kCenter = NOFF == 7 ? 0 : (NOFF == 19 ? 9 : 13);  // offset (0,0,0) in kNeighborOffsets
   // ---- A. neighbourhood lookup ------------------------------------------------------------------
   const int cx = fast_floor(q0 * map.inv_leaf), cy = fast_floor(q1 * map.inv_leaf), cz = fast_floor(q2 * map.inv_leaf);
   // offsets are in {-1,0,1}: the neighbourhood touches block coordinates {b0, b0+1} per axis
   const int bx0 = (cx - 1) >> kBlockLog2, by0 = (cy - 1) >> kBlockLog2, bz0 = (cz - 1) >> kBlockLog2;
+  {
+    // all eight first probes are issued before any is inspected: one memory round trip, not eight
+    int4 first[8];
+    uint32_t h[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s)
-    blk[s * lds_stride] = probe_block(map.table, map.mask, bx0 + (s >> 2), by0 + ((s >> 1) & 1), bz0 + (s & 1));
-  constexpr int m = kBlockDim - 1;
-  uint32_t cell[kMaxOff];
+    for (int s = 0; s < 8; ++s) {
+      h[s] = block_hash(bx0 + (s >> 2), by0 + ((s >> 1) & 1), bz0 + (s & 1)) & map.mask;
+      first[s] = map.table[h[s]];
+    }
 #pragma unroll
-  for (int o = 0; o < kMaxOff; ++o) {
-    cell[o] = kEmptyCell;
-    if (o < map.n_off) {
-      const int vx = cx + map.off[o][0], vy = cy + map.off[o][1], vz = cz + map.off[o][2];
-      const int slot = (((vx >> kBlockLog2) - bx0) << 2) | (((vy >> kBlockLog2) - by0) << 1) | ((vz >> kBlockLog2) - bz0);
-      const int b = blk[slot * lds_stride];
-      if (b >= 0)
-        cell[o] = map.cells[static_cast<size_t>(b) * kCellsPerBlock +
-                            (((vx & m) << (2 * kBlockLog2)) | ((vy & m) << kBlockLog2) | (vz & m))];
+    for (int s = 0; s < 8; ++s) {
+      const int bx = bx0 + (s >> 2), by = by0 + ((s >> 1) & 1), bz = bz0 + (s & 1);
+      int id = first[s].w;
+      if (id >= 0 && !(first[s].x == bx && first[s].y == by && first[s].z == bz)) {
+        // collision: continue the linear probe (load factor <= 0.5 keeps this rare and short)
+        uint32_t hh = (h[s] + 1) & map.mask;
+        for (;;) {
+          const int4 e = map.table[hh];
+          if (e.w < 0 || (e.x == bx && e.y == by && e.z == bz)) {
+            id = e.w;
+            break;
+          }
+          hh = (hh + 1) & map.mask;
+        }
+      }
+      blk[s * lds_stride] = id;
     }
   }
-  int n_list = 0;
-  uint32_t total = 0;
+  constexpr int m = kBlockDim - 1;
+  // NOFF (7 / 19 / 27) is a template parameter and nothing below branches: every lookup of the
+  // neighbourhood is straight-line code, so the block-id LDS reads and then all cell loads are
+  // issued back to back behind ONE wait each.
+  uint32_t cell[NOFF];
+  {
+    int cblk[NOFF];
+    uint32_t cidx[NOFF];
 #pragma unroll
-  for (int o = 0; o < kMaxOff; ++o) {
-    if (cell[o] != kEmptyCell) {  // traversal (offset-generation) order is preserved
-      list[n_list * lds_stride] = cell[o];
-      ++n_list;
-      total += cell[o] & 31u;
+    for (int o = 0; o < NOFF; ++o) {
+      const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
+      const int vx = cx + static_cast<int>(ow & 3u) - 1, vy = cy + static_cast<int>((ow >> 2) & 3u) - 1,
+                vz = cz + static_cast<int>((ow >> 4) & 3u) - 1;
+      const int slot = (((vx >> kBlockLog2) - bx0) << 2) | (((vy >> kBlockLog2) - by0) << 1) | ((vz >> kBlockLog2) - bz0);
+      cblk[o] = blk[slot * lds_stride];
+      cidx[o] = static_cast<uint32_t>(((vx & m) << (2 * kBlockLog2)) | ((vy & m) << kBlockLog2) | (vz & m));
+    }
+#pragma unroll
+    for (int o = 0; o < NOFF; ++o) {
+      // unconditional load (block 0 when absent; the cells array always holds >= 1 block) + select
+      const uint32_t cv = map.cells[static_cast<size_t>(cblk[o] < 0 ? 0 : cblk[o]) * kCellsPerBlock + cidx[o]];
+      cell[o] = (cblk[o] >= 0 && o < map.n_off) ? cv : kEmptyCell;
+    }
+  }
+  // Every cell word goes to LDS slot o (no compaction); which voxels get scanned is a bit mask, and
+  // their point counts are packed into registers (5 bits each, 12 per word) so the scan cursor never
+  // reads memory.
+  uint32_t amask = 0u, total_ref = 0u;
+  uint64_t cw0 = 0, cw1 = 0, cw2 = 0;
+#pragma unroll
+  for (int o = 0; o < NOFF; ++o) {
+    list[o * lds_stride] = cell[o];
+    const uint32_t c = cell[o] != kEmptyCell ? (cell[o] & 31u) : 0u;
+    amask |= (c ? 1u : 0u) << o;
+    total_ref += c;
+    if (o < 12)
+      cw0 |= static_cast<uint64_t>(c) << (5 * o);
+    else if (o < 24)
+      cw1 |= static_cast<uint64_t>(c) << (5 * (o - 12));
+    else
+      cw2 |= static_cast<uint64_t>(c) << (5 * (o - 24));
+  }
+  MH_STAMP(dbg, 1);
+
+  const float qf0 = static_cast<float>(q0), qf1 = static_cast<float>(q1), qf2 = static_cast<float>(q2);
+  const double mag = fmax(fmax(fabs(q0), fabs(q1)), fmax(fabs(q2), 1.0));
+  const double eps_abs = mag * 2.4e-7;  // 2 ulp_f32 of the largest coordinate: rounding q and the differences
+  uint32_t ck[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
+#define MH_COARSE_UPDATE(cxv, cyv, czv, payload, valid)                           \
+  do {                                                                            \
+    const float dx_ = (cxv) - qf0, dy_ = (cyv) - qf1, dz_ = (czv) - qf2;          \
+    const float d_ = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;                           \
+    uint32_t t_ = (__float_as_uint(d_) & ~0x3FFu) | (payload);                    \
+    t_ = (valid) ? t_ : 0xFFFFFFFFu;                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < KK - 1; ++i_)                         \
+    {                                                                             \
+      const uint32_t lo_ = min(ck[i_], t_);                                       \
+      t_ = max(ck[i_], t_);                                                       \
+      ck[i_] = lo_;                                                               \
+    }                                                                             \
+    ck[KK - 1] = min(ck[KK - 1], t_);                                             \
+  } while (0)
+
+  // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
+  n_scanned = 0;
+  if (amask & (1u << kCenter)) {
+    const uint32_t cc = cell[kCenter] & 31u;
+    const float4 * b = map.buckets + static_cast<size_t>(cell[kCenter] >> 5) * kBucketStride;
+    n_scanned += cc;
+    for (uint32_t s0 = 0; s0 < cc; s0 += 4) {
+      float4 c4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c4[u] = b[s0 + u < cc ? s0 + u : 0u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) MH_COARSE_UPDATE(c4[u].x, c4[u].y, c4[u].z, (kCenter << 5) | (s0 + u), s0 + u < cc);
+    }
+    amask &= ~(1u << kCenter);
+  }
+  // ---- prune: drop neighbour voxels that provably hold no top-k point ----------------------------
+  {
+    uint32_t kth = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (i == k - 1) kth = ck[i];
+    if (kth != 0xFFFFFFFFu) {
+      // upper bound of the TRUE k-th distance so far: undo the 10-bit truncation (<= 2^-13 relative),
+      // then the f32 evaluation error
+      const float kv = __uint_as_float(kth & ~0x3FFu) * (1.0f + 2.5e-4f);
+      const float r_up = sqrtf(kv) * (1.0f + 2e-6f) + 2.0f * static_cast<float>(eps_abs);
+      const float b_up = r_up * r_up;
+      const float leaf = static_cast<float>(1.0 / map.inv_leaf);
+      // position of q inside its centre voxel, shrunk by a margin that also covers voxel-assignment
+      // rounding (a stored point may sit ~1 ulp outside its nominal box)
+      const float marg = static_cast<float>(eps_abs) + 1e-6f * leaf;
+      const float ux = static_cast<float>(q0 - static_cast<double>(cx) / map.inv_leaf);
+      const float uy = static_cast<float>(q1 - static_cast<double>(cy) / map.inv_leaf);
+      const float uz = static_cast<float>(q2 - static_cast<double>(cz) / map.inv_leaf);
+      const float gxm = fmaxf(ux - marg, 0.f), gxp = fmaxf(leaf - ux - marg, 0.f);
+      const float gym = fmaxf(uy - marg, 0.f), gyp = fmaxf(leaf - uy - marg, 0.f);
+      const float gzm = fmaxf(uz - marg, 0.f), gzp = fmaxf(leaf - uz - marg, 0.f);
+#pragma unroll
+      for (int o = 0; o < NOFF; ++o) {
+        const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
+        const int ox = static_cast<int>(ow & 3u) - 1, oy = static_cast<int>((ow >> 2) & 3u) - 1,
+                  oz = static_cast<int>((ow >> 4) & 3u) - 1;
+        const float gx = ox < 0 ? gxm : (ox > 0 ? gxp : 0.f);
+        const float gy = oy < 0 ? gym : (oy > 0 ? gyp : 0.f);
+        const float gz = oz < 0 ? gzm : (oz > 0 ? gzp : 0.f);
+        if (gx * gx + gy * gy + gz * gz > b_up) amask &= ~(1u << o);
+      }
     }
   }
 
-  // ---- B. flattened candidate scan, branch-free top-(K+1) on payload-carrying keys --------------
-  double key[K + 1];
-#pragma unroll
-  for (int j = 0; j <= K; ++j) key[j] = kDblMax;
+  // ---- B2. remaining voxels: flattened, software-pipelined coarse scan ---------------------------
+  // The (voxel, slot) cursor walks the active-bit mask in registers kPipe candidates ahead of the
+  // arithmetic; every load is unconditional (index 0 past the end), validity is a select on the key.
   {
-    int j = -1;
-    uint32_t base = 0, cnt = 0, s = 0;
-    for (uint32_t it = 0; it < total; ++it) {
-      if (s == cnt) {  // next listed voxel (every listed voxel holds >= 1 point)
-        ++j;
-        const uint32_t e = list[j * lds_stride];
-        base = (e >> 5) * kBucketStride;
-        cnt = e & 31u;
-        s = 0;
-      }
-      const float4 c = map.buckets[base + s];
-      const double d = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1,
-                                static_cast<double>(c.z) - q2);
-      const uint64_t kb = (static_cast<uint64_t>(__double_as_longlong(d)) & ~kPayloadMask) |
-                          static_cast<uint64_t>((static_cast<uint32_t>(j) << 5) | s);
-      double t = __longlong_as_double(static_cast<long long>(kb));
+    constexpr int kPipe = 8;
+    uint32_t total = 0;
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const double lo = dmin(key[i], t);
-        t = dmax(key[i], t);
-        key[i] = lo;
+    for (int o = 0; o < NOFF; ++o) total += (amask >> o) & 1u ? (cell[o] & 31u) : 0u;
+    n_scanned += total;
+    uint32_t rem = amask;                                  // voxels not yet entered by the cursor
+    int o_cur = rem ? __builtin_ctz(rem) : 0;
+    rem &= rem - 1u;
+    uint32_t s = 0;
+    uint32_t fetched = 0;
+    float px[kPipe], py[kPipe], pz[kPipe];
+    uint32_t pay[kPipe];
+#define MH_PREFETCH(u)                                                                              \
+  do {                                                                                              \
+    const uint64_t w_ = o_cur < 12 ? cw0 : (o_cur < 24 ? cw1 : cw2);                                \
+    const int jj_ = o_cur < 12 ? o_cur : (o_cur < 24 ? o_cur - 12 : o_cur - 24);                    \
+    const uint32_t cj_ = static_cast<uint32_t>(w_ >> (5 * jj_)) & 31u;                              \
+    const bool sw_ = (s == cj_) && rem != 0u; /* next active voxel (each holds >= 1 point) */       \
+    o_cur = sw_ ? __builtin_ctz(rem) : o_cur;                                                       \
+    rem = sw_ ? (rem & (rem - 1u)) : rem;                                                           \
+    s = sw_ ? 0u : s;                                                                               \
+    const uint32_t e_ = list[o_cur * lds_stride]; /* off the cursor's dependency chain */           \
+    const uint32_t idx_ = fetched < total ? (e_ >> 5) * kBucketStride + s : 0u;                     \
+    const float4 c_ = map.buckets[idx_];                                                            \
+    px[u] = c_.x;                                                                                   \
+    py[u] = c_.y;                                                                                   \
+    pz[u] = c_.z;                                                                                   \
+    pay[u] = (static_cast<uint32_t>(o_cur) << 5) | s;                                               \
+    ++s;                                                                                            \
+    ++fetched;                                                                                      \
+  } while (0)
+#pragma unroll
+    for (int u = 0; u < kPipe; ++u) MH_PREFETCH(u);
+    for (uint32_t it = 0; it < total; it += kPipe) {
+#pragma unroll
+      for (int u = 0; u < kPipe; ++u) {
+        const float cxv = px[u], cyv = py[u], czv = pz[u];
+        const uint32_t pl = pay[u];
+        MH_PREFETCH(u);  // refill this stage with candidate it + u + kPipe
+        MH_COARSE_UPDATE(cxv, cyv, czv, pl, it + u < total);
       }
-      key[K] = dmin(key[K], t);
-      ++s;
     }
+#undef MH_PREFETCH
   }
-  // Truncation is monotone, so distinct truncated keys order exactly like the distances.  Equal
-  // truncated distances among the kept keys (relative gap < 2^-42) -> exact path for this lane.
-  bool ambiguous = false;
+#undef MH_COARSE_UPDATE
+  MH_STAMP(dbg, 2);
+
+  // ---- exact tier: re-rank the survivors in fp64 by (distance, traversal rank) -------------------
+  double bd[K];
+  uint32_t br[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const uint64_t a = static_cast<uint64_t>(__double_as_longlong(key[i]));
-    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(key[i + 1]));
-    if (i < k && key[i] < kDblMax && ((a ^ b) >> 10) == 0) ambiguous = true;
+    bd[i] = kDblMax;
+    bi[i] = 0xFFFFFFFFu;
+    br[i] = 0xFFFFFFFFu;
   }
-  if (ambiguous) {
-    double bd[K];
-    knn_exact<K>(map.buckets, list, lds_stride, n_list, q0, q1, q2, bd, bi);
-    dk = kDblMax;
+  {
+    uint32_t sidx[KK];
+    float4 sc[KK];
 #pragma unroll
-    for (int i = 0; i < K; ++i)
-      if (i == k - 1) dk = bd[i];
-    return total;
+    for (int u = 0; u < KK; ++u) {  // all survivor loads issued together (index 0 for empty slots)
+      const uint32_t p = ck[u] & 0x3FFu;
+      const uint32_t e = list[min(static_cast<int>(p >> 5), NOFF - 1) * lds_stride];
+      sidx[u] = ck[u] != 0xFFFFFFFFu ? (e >> 5) * kBucketStride + (p & 31u) : 0u;
+      sc[u] = map.buckets[sidx[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < KK; ++u) {
+      const uint32_t p = ck[u] & 0x3FFu;
+      const double d = sq_dist3(static_cast<double>(sc[u].x) - q0, static_cast<double>(sc[u].y) - q1,
+                                static_cast<double>(sc[u].z) - q2);
+      if (ck[u] != 0xFFFFFFFFu && (d < bd[K - 1] || (d == bd[K - 1] && p < br[K - 1]))) {
+        bd[K - 1] = d;
+        bi[K - 1] = sidx[u];
+        br[K - 1] = p;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+          if (bd[i] < bd[i - 1] || (bd[i] == bd[i - 1] && br[i] < br[i - 1])) {
+            const double td = bd[i];
+            bd[i] = bd[i - 1];
+            bd[i - 1] = td;
+            const uint32_t ti = bi[i];
+            bi[i] = bi[i - 1];
+            bi[i - 1] = ti;
+            const uint32_t tr = br[i];
+            br[i] = br[i - 1];
+            br[i - 1] = tr;
+          }
+        }
+      }
+    }
   }
   dk = kDblMax;
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    bi[i] = 0xFFFFFFFFu;
-    if (i < k && key[i] < kDblMax) {
-      const uint32_t p = static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(key[i])) & kPayloadMask);
-      const uint32_t e = list[(p >> 5) * lds_stride];
-      bi[i] = (e >> 5) * kBucketStride + (p & 31u);
-      if (i == k - 1) {  // exact (untruncated) k-th distance for the max-distance gate
-        const float4 c = map.buckets[bi[i]];
-        dk = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1, static_cast<double>(c.z) - q2);
+  for (int i = 0; i < K; ++i)
+    if (i == k - 1) dk = bd[i];
+  // ---- proof check (only meaningful when there ARE non-survivors: the KK-th slot is filled) ------
+  if (ck[KK - 1] != 0xFFFFFFFFu && dk < kDblMax) {
+    // Scanned non-survivors have f32 keys >= ck[KK-1]; clearing the payload bits only lowers the
+    // bound.  |r_f32 - r| <= sqrt(3) * eps_abs + 4 ulp_f32 * r.  (Pruned voxels are farther than the
+    // k-th distance by construction.)
+    const double c8 = static_cast<double>(__uint_as_float(ck[KK - 1] & ~0x3FFu));
+    const double r_lo = sqrt(c8) * (1.0 - 1e-6) - 2.0 * eps_abs;
+    if (!(r_lo > 0.0 && dk < r_lo * r_lo)) {
+      // separate arrays: anything passed by reference to the out-of-line fallback lives in scratch,
+      // and the main path's bd / bi must stay in registers
+      double ebd[K];
+      uint32_t ebi[K];
+      fell_back = true;
+      knn_exact<K>(map.buckets, list, lds_stride, NOFF, q0, q1, q2, ebd, ebi);
+      dk = kDblMax;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        bi[i] = ebi[i];
+        if (i == k - 1) dk = ebd[i];
       }
     }
   }
-  return total;
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+    if (i >= k) bi[i] = 0xFFFFFFFFu;
+  return total_ref;
 }
 
-// Closed-form eigen-decomposition of a symmetric PSD 3x3 (covariance of k points): eigenvalues
-// ascending by the trigonometric method, unit eigenvector of the smallest one from the best-
-// conditioned cross product of two rows of (A - w0 I).  fp64 throughout: |dw| ~ eps * |A|, far inside
-// the 1e-5 parity bar and the plane gates' margins.  Replaces the Eigen::SelfAdjointEigenSolver
-// call of estimatePlane (geometric_factor.hpp:196), which only consumes the three eigenvalues and
-// eigenvector 0 (:202-215).
+// Eigen-decomposition of a symmetric PSD 3x3 (covariance of k points) for the plane fit:
+// eigenvalues ascending + unit eigenvector of the smallest.  Replaces the
+// Eigen::SelfAdjointEigenSolver call of estimatePlane (geometric_factor.hpp:196), which only consumes
+// the three eigenvalues and eigenvector 0 (:202-215).
+//   w0: Newton on the characteristic cubic p(x) = x^3 - c2 x^2 + c1 x - c0 from x = 0.  For a PSD
+//       matrix p is increasing and concave on [0, w0], so the iterates rise monotonically to the
+//       smallest root with no overshoot; convergence is quadratic (<= 6 steps from 0 in fp64).
+//   w1, w2: the deflated quadratic.  v0: best-conditioned cross product of two rows of A - w0 I.
+// fp64 throughout; |dw| ~ eps |A|, far inside the 1e-5 parity bar and the plane gates' margins.
+// (The trigonometric closed form costs three fp64 transcendental calls per point: 2x this.)
 __device__ __forceinline__ void plane_eigen(const double a00, const double a01, const double a02, const double a11,
                                             const double a12, const double a22, double (&w)[3], double (&v)[3])
 {
-  const double q = (a00 + a11 + a22) * (1.0 / 3.0);
-  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
-  const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
-  if (!(p2 > 0.0)) {  // isotropic (or NaN): eigenvalues all q
-    w[0] = w[1] = w[2] = q;
-    v[0] = 1.0;
-    v[1] = 0.0;
-    v[2] = 0.0;
-    return;
+  const double c2 = a00 + a11 + a22;
+  const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+  const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+  double x = 0.0;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const double p = ((x - c2) * x + c1) * x - c0;
+    const double dp = (3.0 * x - 2.0 * c2) * x + c1;
+    if (!(dp > 0.0)) break;
+    const double step = p / dp;
+    x -= step;
+    if (fabs(step) <= 1e-16 * fabs(x)) break;
   }
-  const double p = sqrt(p2 * (1.0 / 6.0));
-  const double ip = 1.0 / p;
-  const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
-  double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
-  r = fmin(1.0, fmax(-1.0, r));
-  const double phi = acos(r) * (1.0 / 3.0);
-  const double w2 = q + 2.0 * p * cos(phi);
-  const double w0 = q + 2.0 * p * cos(phi + 2.0943951023931954923);  // + 2 pi / 3
+  const double w0 = x;
+  const double S = c2 - w0;               // w1 + w2
+  const double P = c1 - w0 * S;           // w1 * w2
+  const double disc = sqrt(fmax(S * S - 4.0 * P, 0.0));
   w[0] = w0;
-  w[2] = w2;
-  w[1] = 3.0 * q - w0 - w2;
+  w[1] = 0.5 * (S - disc);
+  w[2] = 0.5 * (S + disc);
   // eigenvector of w0: rows of M = A - w0 I are orthogonal to it
   const double m00 = a00 - w0, m11 = a11 - w0, m22 = a22 - w0;
   const double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;  // r0 x r1
@@ -340,7 +565,7 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 // ------------------------------------------------------------------------------------------------
 // K3
 // ------------------------------------------------------------------------------------------------
-template <int K, bool BINARY>
+template <int K, bool BINARY, int NOFF>
 __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a)
 {
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
@@ -357,7 +582,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   constexpr int kReduceWords = kRowWords + (kSegWords > kFoldWords ? kSegWords : kFoldWords);
   constexpr int kArenaWords = kListWords > kReduceWords ? kListWords : kReduceWords;
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
-  __shared__ unsigned int s_cnt[2];  // n_knn, n_cand of this block
+  __shared__ unsigned int s_cnt[4];  // n_knn, n_cand, exact-fallback count, candidates actually scanned
   __shared__ bool s_last;
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [kMaxOff][kThreads]
@@ -365,15 +590,21 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [kThreads][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
-  const int qi = blockIdx.x * kThreads + threadIdx.x;
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+  const int qi = xcd_chunk(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
 
   double row[NV];
+#ifdef MH_TIMELINE
+  // diagnostic: repeat the per-point section (MH_REPS env) so the last pass runs with warm caches
+  for (int rep = 0; rep < a.reps; ++rep) {
+  if (rep > 0 && threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+#endif
+  MH_STAMP(a.dbg, 0);
 #pragma unroll
   for (int j = 0; j < NV; ++j) row[j] = 0.0;
 
-  const int k = a.k;
+  const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
   if (qi < a.n) {
     const float4 sp = a.src[qi];
     const double px = sp.x, py = sp.y, pz = sp.z;
@@ -405,9 +636,13 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       // 3. k-NN (:292-302)
       uint32_t bi[K];
       double dk;
-      const uint32_t n_cand = knn_query<K>(a.map, q0, q1, q2, k, s_list, s_blk, kThreads, bi, dk);
+      bool fell_back;
+      uint32_t n_scanned;
+      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, s_blk, kThreads, bi, dk, fell_back, n_scanned, a.dbg);
       atomicAdd(&s_cnt[0], 1u);
       atomicAdd(&s_cnt[1], n_cand);
+      if (fell_back) atomicAdd(&s_cnt[2], 1u);
+      atomicAdd(&s_cnt[3], n_scanned);
       if (!(dk < kDblMax)) {
         st = MH_INSUFFICIENT_CORRES_POINTS;  // found != k
       } else if (dk > a.max_d2) {
@@ -556,10 +791,15 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
     }
     a.status[qi] = st;
   }
+#ifdef MH_TIMELINE
+  }
+#endif
 
   // 8. H += J^T J, b += J^T e, f += e^2 (:363-382) — LDS tile of rows (the k-NN arena is dead now),
   //    then every thread owns one (entry, segment) pair of the upper triangle of sum v v^T.
+  MH_STAMP(a.dbg, 3);
   __syncthreads();
+  MH_STAMP(a.dbg, 4);
 #pragma unroll
   for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
   __syncthreads();
@@ -587,18 +827,22 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   }
   // the block's k-NN counters ride along as two more partial entries (exact in fp64): same-line
   // global atomics from every block would serialise at L2
-  if (threadIdx.x >= 128 && threadIdx.x < 130)
+  if (threadIdx.x >= 128 && threadIdx.x < 132)
     store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + NENT + (threadIdx.x - 128)],
                   static_cast<double>(s_cnt[threadIdx.x - 128]));
 
+  MH_STAMP(a.dbg, 5);
   if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
+  MH_STAMP(a.dbg, 6);
 
   // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
   double * s_sum = s_aux + (kThreads / EW) * EW;
-  fold_rows<EW>(a.partials, gridDim.x, NENT + 2, s_aux, s_sum);
+  fold_rows<EW>(a.partials, gridDim.x, NENT + 4, s_aux, s_sum);
   if (threadIdx.x < NENT) a.result->sums[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x == NENT) a.result->n_knn = static_cast<unsigned long long>(s_sum[NENT]);
   if (threadIdx.x == NENT + 1) a.result->n_cand = static_cast<unsigned long long>(s_sum[NENT + 1]);
+  if (threadIdx.x == NENT + 2) a.result->n_fallback = static_cast<unsigned long long>(s_sum[NENT + 2]);
+  if (threadIdx.x == NENT + 3) a.result->n_scanned = static_cast<unsigned long long>(s_sum[NENT + 3]);
   if (threadIdx.x == 0 || threadIdx.x == 64) {
     // computeLocalizability on the rot / trans 3x3 blocks of J_s^T J_s (:405-411), one wave each
     auto ent_of = [](int r, int c) { return r * NV - r * (r - 1) / 2 + (c - r); };  // r <= c
@@ -616,6 +860,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
     for (int i = 0; i < 3; ++i) dl[i] = loc[i];
     for (int i = 0; i < 9; ++i) de[i] = E[i];
   }
+  MH_STAMP(a.dbg, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -631,7 +876,7 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
   __shared__ double s_seg[(kThreads / 32) * 32 + 32];
   __shared__ bool s_last;
 
-  const int i = blockIdx.x * kThreads + threadIdx.x;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double v[6] = {0, 0, 0, 0, 0, 0};
   int st = -1;
@@ -702,8 +947,17 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
   const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
   uint32_t bi[K];
   double dk;
-  knn_query<K>(map, q0, q1, q2, k, s_list + threadIdx.x,
-               reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk);
+  bool fell_back;
+  uint32_t n_scanned;
+  if (map.n_off <= 7)
+    knn_query<K, 7>(map, q0, q1, q2, k, s_list + threadIdx.x,
+                    reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
+  else if (map.n_off == 19)
+    knn_query<K, 19>(map, q0, q1, q2, k, s_list + threadIdx.x,
+                     reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
+  else
+    knn_query<K, 27>(map, q0, q1, q2, k, s_list + threadIdx.x,
+                     reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
   int f = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
@@ -728,23 +982,34 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-int linearize_grid(int n) { return (n + kThreads - 1) / kThreads; }
-int localizability_grid(int n) { return (n + kThreads - 1) / kThreads; }
+int linearize_grid(int n) { return (((n + kThreads - 1) / kThreads) + 7) & ~7; }
+int localizability_grid(int n) { return linearize_grid(n); }
 
-hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
+template <int NOFF>
+static void launch_linearize_n(const IcpArgs & a, bool binary, hipStream_t stream)
 {
   const dim3 grid(linearize_grid(a.n)), block(kThreads);
   if (a.k == 5) {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<5, true>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_linearize_kernel<5, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF>), grid, block, 0, stream, a);
   } else {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<8, true>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_linearize_kernel<8, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF>), grid, block, 0, stream, a);
   }
+}
+
+hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
+{
+  if (a.map.n_off <= 7)
+    launch_linearize_n<7>(a, binary, stream);
+  else if (a.map.n_off == 19)
+    launch_linearize_n<19>(a, binary, stream);
+  else
+    launch_linearize_n<27>(a, binary, stream);
   return hipGetLastError();
 }
 

@@ -120,7 +120,8 @@ struct mh_icp
   size_t n;
   mh_reg_config cfg;
   bool binary;
-  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result;
+  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm;
+  bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
   mh::DeviceResult * h_results = nullptr;  // pinned ring
   PendingCall pending[kMaxPending];
   int n_pending = 0;
@@ -145,7 +146,7 @@ int map_sync_device(mh_map * m)
   // Factors on this context may still be reading the old buffers: drain before (re)allocating.
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
-  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : 4, ctx->stream, false));
+  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, false));
   MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, false));
   MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
   if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
@@ -168,7 +169,7 @@ mh::MapView map_view(const mh_map * m)
   v.inv_leaf = m->host.inv_leaf();
   v.mask = m->host.table_mask();
   v.n_off = m->n_off;
-  std::memcpy(v.off, m->off, sizeof(v.off));
+  v.mode_idx = m->n_off == 1 ? 0 : (m->n_off == 7 ? 1 : (m->n_off == 19 ? 2 : 3));
   return v;
 }
 
@@ -303,6 +304,8 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
   }
   for (int i = 0; i < 9; ++i) out->status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
   out->n_knn = static_cast<int64_t>(d.n_knn);
+  out->n_exact_fallback = static_cast<int64_t>(d.n_fallback);
+  out->mean_scanned = d.n_knn ? static_cast<double>(d.n_scanned) / static_cast<double>(d.n_knn) : 0.0;
   out->mean_candidates = d.n_knn ? static_cast<double>(d.n_cand) / static_cast<double>(d.n_knn) : 0.0;
   out->linearize_count = pc.linearize_count;
 }
@@ -504,6 +507,10 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_partials.reserve(max_grid * mh::kPartialStride * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, icp->d_ticket.reserve(2 * sizeof(unsigned int), ctx->stream, false));
   MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
+#ifdef MH_TIMELINE
+  MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 8 * sizeof(unsigned long long), ctx->stream, false));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_dbg.p, 0, icp->d_dbg.cap, ctx->stream));
+#endif
   MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending,
                             hipHostMallocDefault));
   return MH_OK;
@@ -540,6 +547,30 @@ int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t 
     MH_HIP(ctx, mh::launch_pack_xyz(d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p), ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_pts);
+    // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
+    const char * ns = std::getenv("MH_NO_SORT");
+    if (!(ns && ns[0] == '1')) {
+      const int ni = static_cast<int>(n);
+      const size_t tb = mh::order_temp_bytes(ni);
+      float4 * d_tmp_xyz = nullptr;
+      uint32_t *d_keys = nullptr, *d_vals = nullptr;
+      void * d_temp = nullptr;
+      MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, hipMalloc(&d_tmp_xyz, n * sizeof(float4)));
+      MH_HIP(ctx, hipMalloc(&d_keys, 2 * n * sizeof(uint32_t)));
+      MH_HIP(ctx, hipMalloc(&d_vals, n * sizeof(uint32_t)));
+      MH_HIP(ctx, hipMalloc(&d_temp, tb ? tb : 16));
+      MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, 0.25f, d_keys, d_vals, d_temp, tb,
+                                           static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
+                                           ctx->stream));
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(d_tmp_xyz);
+      (void)hipFree(d_keys);
+      (void)hipFree(d_vals);
+      (void)hipFree(d_temp);
+      icp->ordered = true;
+    }
   }
   MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
@@ -585,6 +616,11 @@ int mh_icp_clone(const mh_icp * src, mh_icp ** out)
   MH_HIP(ctx, cp(src->d_normal, icp->d_normal, n * 3 * sizeof(double)));
   MH_HIP(ctx, cp(src->d_status, icp->d_status, n * sizeof(int32_t)));
   MH_HIP(ctx, cp(src->d_result, icp->d_result, sizeof(mh::DeviceResult)));
+  if (src->ordered) {
+    MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
+    MH_HIP(ctx, cp(src->d_perm, icp->d_perm, n * sizeof(uint32_t)));
+    icp->ordered = true;
+  }
   MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   icp->cold = src->cold;
@@ -606,6 +642,8 @@ void mh_icp_destroy(mh_icp * icp)
   icp->d_partials.release();
   icp->d_ticket.release();
   icp->d_result.release();
+  icp->d_dbg.release();
+  icp->d_perm.release();
   if (icp->h_results) (void)hipHostFree(icp->h_results);
   if (icp->events_ready)
     for (auto & ev : icp->events)
@@ -615,6 +653,22 @@ void mh_icp_destroy(mh_icp * icp)
 }
 
 size_t mh_icp_size(const mh_icp * icp) { return icp ? icp->n : 0; }
+
+#ifdef MH_TIMELINE
+// Diagnostic build only: per-wave s_memtime stamps of the last linearize (8 per wave).
+int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_words, size_t * n_words)
+{
+  if (!icp || !out || !n_words) return MH_ERR_INVALID_ARG;
+  mh_ctx * ctx = icp->ctx;
+  const size_t words = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 8;
+  *n_words = words;
+  if (capacity_words < words) return MH_ERR_INVALID_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MH_HIP(ctx, hipMemcpy(out, icp->d_dbg.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+#endif
 
 int mh_icp_reset(mh_icp * icp)
 {
@@ -661,6 +715,11 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   a.partials = static_cast<double *>(icp->d_partials.p);
   a.ticket = static_cast<unsigned int *>(icp->d_ticket.p);
   a.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
+  a.dbg = static_cast<unsigned long long *>(icp->d_dbg.p);
+  {
+    const char * rp = std::getenv("MH_REPS");
+    a.reps = rp ? std::atoi(rp) : 1;
+  }
 
   mh::LocArgs l;
   l.src = a.src;
@@ -733,11 +792,28 @@ int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, doubl
   MH_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = icp->n;
   if (n == 0) return MH_OK;
-  if (status) MH_HIP(ctx, hipMemcpyAsync(status, icp->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (means) MH_HIP(ctx, hipMemcpyAsync(means, icp->d_mean.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (normals)
-    MH_HIP(ctx, hipMemcpyAsync(normals, icp->d_normal.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  const int32_t * d_st = static_cast<const int32_t *>(icp->d_status.p);
+  const double * d_mean = static_cast<const double *>(icp->d_mean.p);
+  const double * d_nrm = static_cast<const double *>(icp->d_normal.p);
+  int32_t * t_st = nullptr;
+  double *t_mean = nullptr, *t_nrm = nullptr;
+  if (icp->ordered) {  // back to the caller's point order
+    if (status) MH_HIP(ctx, hipMalloc(&t_st, n * sizeof(int32_t)));
+    if (means) MH_HIP(ctx, hipMalloc(&t_mean, n * 3 * sizeof(double)));
+    if (normals) MH_HIP(ctx, hipMalloc(&t_nrm, n * 3 * sizeof(double)));
+    MH_HIP(ctx, mh::launch_unpermute_state(static_cast<const uint32_t *>(icp->d_perm.p), static_cast<int>(n), d_st, d_mean,
+                                           d_nrm, t_st, t_mean, t_nrm, ctx->stream));
+    d_st = t_st;
+    d_mean = t_mean;
+    d_nrm = t_nrm;
+  }
+  if (status) MH_HIP(ctx, hipMemcpyAsync(status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (means) MH_HIP(ctx, hipMemcpyAsync(means, d_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (normals) MH_HIP(ctx, hipMemcpyAsync(normals, d_nrm, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (t_st) (void)hipFree(t_st);
+  if (t_mean) (void)hipFree(t_mean);
+  if (t_nrm) (void)hipFree(t_nrm);
   return MH_OK;
 }
 

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave phase timeline of icp_linearize_kernel (needs the -DMH_TIMELINE build).
+
+Stamps (s_memtime, shader-clock... 100 MHz REFCLK on gfx950 — calibrated below against the HIP-event
+kernel time): 0 entry, 1 neighbourhood list built, 2 candidate scan done, 3 per-point work done,
+4 after the block barrier, 5 partial row stored, 6 last block: won the ticket, 7 last block: done.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mimosa_amd import build as hb, capi, synth  # noqa: E402
+
+lib = hb.build(timeline=True)
+capi._build.LIB = lib  # load the diagnostic variant
+ctx = capi.Context(0)
+L = ctx.L
+L.mh_icp_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+rooms = [xyz for _, _, xyz in synth.make_map_rooms(2, 5)]
+pts, aux = synth.make_scan(128)
+R, t = synth.query_pose()
+cfg = synth.enwide_config()
+m = capi.VoxelMap(ctx)
+for xyz in rooms:
+    m.insert(xyz)
+f = capi.ICPFactor(ctx, m, pts, capi.make_reg_config(**cfg))
+ctx.set_profiling(True)
+for _ in range(5):
+    f.reset()
+    r = f.linearize(R, t)
+n = C.c_size_t()
+buf = np.zeros(8 * 8 * 4096, np.uint64)
+rc = L.mh_icp_timeline(f.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n))
+assert rc == 0, rc
+T = buf[: n.value].reshape(-1, 8).astype(np.int64)
+blk = np.arange(len(T)) // 8
+live = T[:, 0] > 0
+T, blk = T[live], blk[live]
+k3_us = r["gpu_ms_linearize"] * 1e3
+print(f"waves {len(T)}  K3 by HIP events {k3_us:.1f} us  (ticks = s_memtime; per-XCD counters, so cross-wave times are per XCD)")
+
+
+def stat(name, x):
+    print(f"{name:40s} mean {x.mean():9.0f}  p50 {np.percentile(x,50):9.0f}  p95 {np.percentile(x,95):9.0f}  max {x.max():9.0f} ticks")
+
+
+stat("A: lookup + list (0->1)", T[:, 1] - T[:, 0])
+stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
+stat("C: plane/residual (2->3)", T[:, 3] - T[:, 2])
+stat("barrier wait (3->4)", T[:, 4] - T[:, 3])
+stat("D: block reduce+store (4->5)", T[:, 5] - T[:, 4])
+stat("wave total (0->5)", T[:, 5] - T[:, 0])
+# per XCD: start skew and end times relative to the XCD's first entry
+skew, endt, spans = [], [], []
+for x in range(8):
+    sel = (blk % 8) == x
+    if not sel.any():
+        continue
+    t0 = T[sel, 0].min()
+    skew.append(T[sel, 0] - t0)
+    endt.append(T[sel, 5] - t0)
+    last = T[sel][T[sel, 7] > 0]
+    spans.append(max(T[sel, 5].max(), last[:, 7].max() if len(last) else 0) - t0)
+stat("start skew within XCD", np.concatenate(skew))
+stat("wave end within XCD (5 - xcd start)", np.concatenate(endt))
+print("per-XCD span (ticks):", spans, " => ticks/us ~", max(spans) / k3_us)
+last = T[T[:, 7] > 0]
+if len(last):
+    stat("last block: ticket wait (5->6)", last[:, 6] - last[:, 5])
+    stat("last block: fold+eigen (6->7)", last[:, 7] - last[:, 6])
