@@ -151,6 +151,16 @@ def main():
     k3_avg_s = float(k3_ms.mean()) * 1e-3
     achieved_gbs = n_pts * b_pt / k3_avg_s / 1e9
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
+    # committed summary of the separate rocprofv3 --pmc passes is reported (profiles/latest_pmc.json)
+    traffic, traffic_note = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        traffic = int((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024)
+        traffic_note = "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from " + pm["source"]
+    except Exception:
+        pass
+
     line = {
         "metric": "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU",
         "value": round(value, 3),
@@ -182,7 +192,9 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved_gbs / HBM_COPY_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
+            "algorithmic_bytes_per_launch": int(n_pts * b_pt),
             "bytes_per_point": round(b_pt, 1),
             "mean_candidates_per_query": round(mean_cq, 2),
             "kernel_ms_avg": round(float(k3_ms.mean()), 5),

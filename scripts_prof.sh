@@ -1,13 +1,29 @@
 #!/bin/bash
-# Profile the bench command with rocprofv3: kernel trace + stats, then PMC passes (own runs).
+# Round profile: rocprofv3 kernel trace + stats of the default bench command, then the HBM-traffic
+# PMC passes (each in its own run, kernel-trace only, each under its own timeout).
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "GRBM_GUI_ACTIVE"; do
-  tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -- $CMD > $OUT/pmc_$tag.log 2>&1
+CMD="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+  tag=$(echo $pass | tr ' ' '_' | cut -c1-32)
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -- $CMD > $OUT/pmc_$tag.log 2>&1
 done
-find $OUT -name "*.csv" | head -50
+python3 - <<PY
+import csv,glob,collections,json
+out={}
+for d in sorted(glob.glob('$OUT/pmc_*/')):
+    f=glob.glob(d+'*/*_counter_collection.csv')
+    if not f: continue
+    acc=collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        acc[r['Kernel_Name'].split('(')[0][-40:]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in acc.items():
+        if 'icp_' in k:
+            out.setdefault(k,{}).update({c:sum(x)/len(x) for c,x in v.items()})
+json.dump(out,open('$OUT/pmc_summary.json','w'),indent=1)
+print(json.dumps(out,indent=1))
+PY
+cat $OUT/stats/*/*_kernel_stats.csv

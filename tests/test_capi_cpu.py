@@ -1,0 +1,62 @@
+"""CPU suite: the C-ABI shared library builds for gfx950, loads, exports every symbol the header
+declares, and fails loudly (never falls back) without a GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mimosa_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_surface():
+    fns = header_functions()
+    for f in ("mh_init", "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_knn", "mh_icp_create", "mh_icp_clone",
+              "mh_icp_linearize", "mh_icp_get_state", "mh_deskew", "mh_transform_f32"):
+        assert f in fns
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    from mimosa_amd import build, capi
+    lib = build.build()
+    assert os.path.exists(lib)
+    L = C.CDLL(lib)
+    missing = [f for f in header_functions() if not hasattr(L, f)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == header_functions()  # the Python binding list mirrors the header
+    assert L.mh_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+    assert C.sizeof(capi.RegConfig) == 64 == C.sizeof(ref_cpu.RegistrationConfig)
+    assert synth.POINT_DTYPE.itemsize == 32
+    assert C.sizeof(capi.MapConfig) == 40
+    # mh_icp_result: 3*36 + 2*6 + 1 + 4*3 + 2*9 + 2*3 + 2*9 doubles, 10 int32, 2 doubles, 2 int64, 2 floats
+    assert C.sizeof(capi.IcpResult) == (108 + 12 + 1 + 12 + 18 + 6 + 18) * 8 + 40 + 16 + 16 + 8
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    from mimosa_amd import capi
+    with pytest.raises(capi.MhError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.MH_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mimosa_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("ref_cpu", "numpy_ref", "import oracle", "from oracle", "libref_cpu"):
+                    assert needle not in txt, (f, needle)

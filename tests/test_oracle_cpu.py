@@ -1,0 +1,171 @@
+"""CPU suite: the C++ oracle (oracle/ref_cpu.hpp) against the independent numpy restatement and the
+committed golden fixtures.  PARITY UNPINNED — the reference has no tests of its own."""
+import numpy as np
+import pytest
+
+from golden_cases import LINEARIZE_CASES, cfg_of, check_linearize, check_state, load, rel
+
+
+@pytest.fixture(scope="module")
+def world():
+    from mimosa_amd import synth
+    m, pts, aux = synth.small_world()
+    return m, pts, aux
+
+
+def test_eigen3_matches_lapack():
+    from oracle import ref_cpu
+    rng = np.random.default_rng(3)
+    for i in range(300):
+        X = rng.normal(size=(5, 3)) * rng.uniform(1e-3, 1.0, size=3)
+        A = np.cov(X.T) if i % 3 else np.diag(rng.uniform(0, 1, 3))  # includes already-diagonal inputs
+        ok, w, V = ref_cpu.eigen3(A)
+        w_ref, V_ref = np.linalg.eigh(A)
+        assert ok
+        assert np.allclose(w, w_ref, rtol=1e-12, atol=1e-15 * max(1.0, np.abs(w_ref).max()))
+        assert np.allclose(A @ V, V * w, atol=1e-13 * max(1.0, np.abs(w_ref).max()))
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
+    ok, w, V = ref_cpu.eigen3(np.zeros((3, 3)))
+    assert ok and not w.any()
+
+
+def test_map_insert_knn_vs_numpy(world):
+    from oracle import numpy_ref, ref_cpu
+    m, pts, aux = world
+    M = ref_cpu.Map()
+    V = numpy_ref.VoxelMap(lru_horizon=1000)
+    for chunk in np.array_split(m, 4):
+        M.insert(chunk)
+        V.insert(chunk)
+    assert M.num_points == V.num_points and M.num_voxels == len(V.order)
+    coords, counts, xyz = M.export()
+    assert [tuple(c) for c in coords] == V.order
+    assert np.array_equal(xyz, np.concatenate([np.array(V.cells[c][0]) for c in V.order]).astype(np.float32))
+    rng = np.random.default_rng(7)
+    q = m[rng.integers(0, len(m), 200)].astype(np.float64) + rng.normal(0, 0.15, (200, 3))
+    idx, sq, found, ncand = M.knn(q, 5)
+    for i in range(len(q)):
+        nb, d2 = V.knn(q[i], 5)
+        assert found[i] == len(nb)
+        assert ncand[i] == len(V.candidates(q[i]))
+        for j in range(found[i]):
+            assert np.array_equal(M.point(idx[i, j]), nb[j])
+        assert np.allclose(sq[i, : found[i]], d2, rtol=1e-14, atol=0)
+
+
+def test_map_lru_golden():
+    from oracle import ref_cpu
+    g = load("map_lru")
+    M = ref_cpu.Map(lru_horizon=2)
+    # the oracle's clear cycle is iVox's default 10; the fixture uses 2 -> go through the numpy twin's
+    # semantics by inserting empty batches would change counters, so compare at cycle 10 separately
+    from oracle import numpy_ref
+    V = numpy_ref.VoxelMap(lru_horizon=2, lru_clear_cycle=2)
+    sizes = []
+    for c in np.array_split(g["chunks"], int(g["n_chunks"])):
+        V.insert(c)
+        sizes.append(V.num_points)
+    assert sizes == list(g["sizes"])
+    cloud = np.concatenate([np.array(V.cells[c][0]) for c in V.order if V.cells[c][0]]).astype(np.float32)
+    assert np.array_equal(cloud, g["cloud"])
+    # C++ oracle with the default cycle: identical to the numpy twin configured the same way
+    V10 = numpy_ref.VoxelMap(lru_horizon=2, lru_clear_cycle=10)
+    for r in range(12):
+        c = (g["chunks"][:200] + np.float32(r) * np.array([3.0, 0, 0], np.float32))
+        M.insert(c)
+        V10.insert(c)
+        assert M.num_points == V10.num_points, r
+    assert M.num_points < 12 * 200  # something was purged at the 10th insert
+
+
+@pytest.mark.parametrize("case", LINEARIZE_CASES)
+def test_linearize_golden(case, world):
+    from oracle import ref_cpu
+    m, pts, aux = world
+    g = load("linearize_" + case)
+    cfg = cfg_of(g)
+    M = ref_cpu.Map(mode=int(g["mode"]))
+    M.insert(m)
+    f = ref_cpu.ICP(M, pts, ref_cpu.make_config(**cfg), binary=bool(int(g["binary"])))
+    kw = dict(R_tgt=g["R_tgt"], t_tgt=g["t_tgt"]) if int(g["binary"]) else {}
+    r1 = f.linearize(g["R1"], g["t1"], g["g_unit"], **kw)
+    check_linearize(g, "a", r1)
+    st, mean, nrm, _ = f.state()
+    check_state(g, 1, st, mean, nrm)
+    r2 = f.linearize(g["R2"], g["t2"], g["g_unit"], **kw)
+    check_linearize(g, "b", r2)
+    st, mean, nrm, _ = f.state()
+    check_state(g, 2, st, mean, nrm)
+    assert r2["linearize_count"] == 2
+    # clone keeps its own state; error() is the reference's constant 0; dim 6
+    c = f.clone()
+    assert np.array_equal(c.state()[0], st)
+
+
+def test_degeneracy_projection_quirk(world):
+    """project_on_degneneracy with a triggering threshold rebuilds H, b as zero."""
+    from mimosa_amd import synth
+    from oracle import numpy_ref, ref_cpu
+    m, pts, aux = world
+    R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    cfg = dict(synth.enwide_config(), project_on_degneneracy=1, degen_thresh_trans=1e9)
+    M = ref_cpu.Map()
+    M.insert(m)
+    r = ref_cpu.ICP(M, pts, ref_cpu.make_config(**cfg)).linearize(R, t)
+    assert not r["H_ss"].any() and not r["b_s"].any() and r["f"] > 0
+    V = numpy_ref.VoxelMap(lru_horizon=1000)
+    V.insert(m)
+    r2, _ = numpy_ref.linearize(V, synth.points_xyz(pts), cfg, R, t)
+    assert not r2["H_ss"].any() and abs(r2["f"] - r["f"]) <= 1e-12 * r["f"]
+
+
+def test_deskew_golden_bit_exact():
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+    g = load("deskew")
+    pts = np.zeros(len(g["xyz"]), synth.POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"], pts["t"] = g["xyz"][:, 0], g["xyz"][:, 1], g["xyz"][:, 2], g["t"]
+    d = ref_cpu.deskew(pts, g["unique_ns"], g["Rt12"])
+    assert np.array_equal(synth.points_xyz(d), g["deskewed"])
+    b = ref_cpu.transform_f32(d, g["R_B_L"], g["t_B_L"])
+    assert np.array_equal(synth.points_xyz(b), g["body"])
+    assert np.array_equal(b["t"], pts["t"]) and np.array_equal(b["idx"], pts["idx"])  # only xyz changes
+
+
+def test_downsample_golden():
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+    g = load("downsample")
+    pts = np.zeros(len(g["cloud"]), synth.POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = g["cloud"][:, 0], g["cloud"][:, 1], g["cloud"][:, 2]
+    assert np.array_equal(ref_cpu.downsample(pts, 0.5, 20, 0.15), g["kept"])
+
+
+def test_projection_matrix():
+    from oracle import ref_cpu
+    E = np.linalg.qr(np.random.default_rng(1).normal(size=(3, 3)))[0]
+    d, P, ax = ref_cpu.projection_matrix([5.0, 20.0, 30.0], 10.0, E)
+    assert d and np.allclose(P, np.outer(E[:, 1], E[:, 1]) + np.outer(E[:, 2], E[:, 2])) and list(ax) == [1, 0, 0]
+    d, P, ax = ref_cpu.projection_matrix([15.0, 20.0, 30.0], 10.0, E)
+    assert not d and np.allclose(P, np.eye(3)) and not ax.any()
+
+
+def test_config0_room_plumbing():
+    """BASELINE configs[0]: 65 536-pt scan vs ~0.5 M-pt planar map through the CPU reference path."""
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+    m = synth.make_room(synth.BASE_SEED, 0, 0)
+    pts, aux = synth.make_scan(64)
+    assert len(pts) == 65536 and 480_000 < len(m) < 520_000
+    M = ref_cpu.Map()
+    M.insert(m)
+    assert 9.0 < M.num_points / M.num_voxels < 10.5
+    R, t = synth.query_pose()
+    r = ref_cpu.ICP(M, pts, ref_cpu.make_config(**synth.enwide_config())).linearize(R, t)
+    assert r["status_hist"].sum() == 65536 and r["status_hist"][8] > 30000
+    assert 70 < r["mean_candidates"] < 95
+    w = np.linalg.eigvalsh(r["H_ss"])
+    assert w[0] > 0  # a closed room constrains all six degrees of freedom
+    # the perturbation is recovered by one Gauss-Newton step to a few mm / mrad
+    dx = np.linalg.solve(r["H_ss"], -r["b_s"])
+    assert np.linalg.norm(dx[3:]) < 0.1 and np.linalg.norm(dx[:3]) < 0.03
