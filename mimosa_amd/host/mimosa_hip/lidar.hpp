@@ -1,0 +1,525 @@
+// C++ host mirror of the reference's LiDAR geometric classes over the C ABI (include/mimosa_hip.h):
+//
+//   IncrementalVoxelMapPCL   include/mimosa/lidar/incremental_voxel_map.hpp:22-54
+//   ICPFactor                include/mimosa/lidar/geometric_factor.hpp:25-563
+//   Geometric                include/mimosa/lidar/geometric.hpp:36-89, src/lidar/geometric.cpp
+//   Manager::deskewPoints    src/lidar/manager.cpp:385-512 (the per-point part, :496-509)
+//
+// Same constructor / method / getter names and argument meaning, same call order, same error
+// behaviour (std::runtime_error for fatal conditions, per-point failures are statuses).  ROS
+// publishers, loggers and config_utilities are replaced by plain structs.  Header-only; link with
+// libmimosa_hip.so.  All arithmetic happens behind the C ABI on the GPU — nothing here computes a
+// residual, and there is no CPU fallback.
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+
+#include "../../../include/mimosa_hip.h"
+#include "types.hpp"
+
+namespace mimosa_hip
+{
+namespace lidar
+{
+using Point = mh_point32;                 // include/mimosa/lidar/point.hpp:18-39
+using PointCloud = std::vector<Point>;    // pcl::PointCloud<Point>
+using RegistrationConfig = mh_reg_config; // include/mimosa/lidar/geometric_config.hpp:17-33
+
+inline RegistrationConfig defaultRegistrationConfig()
+{
+  // struct defaults of geometric_config.hpp:17-33
+  RegistrationConfig c{};
+  c.source_voxel_grid_filter_leaf_size = 0.5f;
+  c.source_voxel_grid_min_dist_in_voxel = 0.1f;
+  c.target_ivox_map_leaf_size = 0.5f;
+  c.target_ivox_map_min_dist_in_voxel = 0.1f;
+  c.num_corres_points = 5;
+  c.max_corres_distance = 2.24f;
+  c.plane_validity_distance = 0.04f;
+  c.lidar_point_noise_std_dev = 0.02f;
+  c.use_huber = 1;
+  c.huber_threshold = 1.345f;
+  c.reg_4_dof = 0;
+  c.project_on_degneneracy = 1;
+  c.degen_thresh_rot = 10;
+  c.degen_thresh_trans = 15;
+  return c;
+}
+
+// GeometricConfig, geometric_config.hpp:37-55 (ROS frame names / log settings dropped)
+struct GeometricConfig
+{
+  bool enabled = true;
+  Pose3 T_B_L = Pose3::Identity();
+  int point_skip_divisor = 1;
+  int ring_skip_divisor = 1;
+  float map_keyframe_trans_thresh = 0.1f;
+  float map_keyframe_rot_thresh_deg = 10;
+  size_t initial_clouds_to_force_map_update = 10;
+  size_t lru_horizon = 100;
+  size_t neighbor_voxel_mode = 7;
+  RegistrationConfig scan_to_map = defaultRegistrationConfig();
+};
+
+// One context per process/device; thrown errors carry mh_last_error().
+class Context
+{
+public:
+  explicit Context(int device = 0)
+  {
+    if (mh_init(device, &ctx_) != MH_OK) throw std::runtime_error(std::string("mh_init: ") + mh_last_error(nullptr));
+  }
+  ~Context() { mh_shutdown(ctx_); }
+  Context(const Context &) = delete;
+  Context & operator=(const Context &) = delete;
+  mh_ctx * get() const { return ctx_; }
+  void check(int rc, const char * what) const
+  {
+    if (rc != MH_OK) throw std::runtime_error(std::string(what) + ": " + mh_last_error(ctx_));
+  }
+
+private:
+  mh_ctx * ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+class IncrementalVoxelMapPCL
+{
+public:
+  using Ptr = std::shared_ptr<IncrementalVoxelMapPCL>;
+
+  IncrementalVoxelMapPCL(const std::shared_ptr<Context> & ctx, const float leaf_size) : ctx_(ctx)
+  {
+    cfg_.leaf_size = leaf_size;  // iVox defaults, overridden by Geometric's ctor (geometric.cpp:23-28)
+    cfg_.min_dist_in_cell = 0.1;
+    cfg_.max_points_in_cell = 20;
+    cfg_.neighbor_voxel_mode = 7;
+    cfg_.lru_horizon = 100;
+    cfg_.lru_clear_cycle = 10;
+  }
+  // Deep copy constructor (incremental_voxel_map.hpp:33-42)
+  IncrementalVoxelMapPCL(const IncrementalVoxelMapPCL & other) : ctx_(other.ctx_), cfg_(other.cfg_)
+  {
+    if (other.map_) ctx_->check(mh_map_copy(other.map_, &map_), "mh_map_copy");
+  }
+  IncrementalVoxelMapPCL & operator=(const IncrementalVoxelMapPCL &) = delete;
+  ~IncrementalVoxelMapPCL() { mh_map_release(map_); }
+
+  // iVox setters used at geometric.cpp:25-28 — must precede the first insert
+  void set_lru_horizon(size_t h) { require_empty(); cfg_.lru_horizon = static_cast<int64_t>(h); }
+  void set_neighbor_voxel_mode(size_t m) { require_empty(); cfg_.neighbor_voxel_mode = static_cast<int32_t>(m); }
+  void set_min_dist_in_cell(double d) { require_empty(); cfg_.min_dist_in_cell = d; }
+
+  void insert(const PointCloud & cloud)  // incremental_voxel_map.cpp:19-24
+  {
+    ensure();
+    if (!cloud.empty())
+      ctx_->check(mh_map_insert(map_, &cloud[0].x, cloud.size(), sizeof(Point) / sizeof(float)), "mh_map_insert");
+  }
+  void insert(const float * xyz, size_t n)
+  {
+    ensure();
+    ctx_->check(mh_map_insert(map_, xyz, n, 3), "mh_map_insert");
+  }
+  // incremental_voxel_map.cpp:26-32: true iff k neighbours were found; coordinates instead of ids
+  bool knn_search(const V3D & point, const size_t k, std::vector<V3D> & neighbours, std::vector<double> & sq_dists)
+  {
+    ensure();
+    neighbours.assign(k, V3D{});
+    sq_dists.assign(k, 0.0);
+    int32_t found = 0;
+    ctx_->check(mh_map_knn(map_, point.data(), 1, static_cast<int>(k), neighbours[0].data(), sq_dists.data(), &found),
+                "mh_map_knn");
+    return static_cast<size_t>(found) == k;
+  }
+  PointCloud getCloud()  // incremental_voxel_map.cpp:34-38
+  {
+    ensure();
+    size_t n = 0;
+    ctx_->check(mh_map_get_cloud(map_, nullptr, 0, &n), "mh_map_get_cloud");
+    std::vector<float> xyz(3 * n);
+    ctx_->check(mh_map_get_cloud(map_, xyz.data(), n, &n), "mh_map_get_cloud");
+    PointCloud out(n, Point{});
+    for (size_t i = 0; i < n; ++i) {
+      out[i].x = xyz[3 * i];
+      out[i].y = xyz[3 * i + 1];
+      out[i].z = xyz[3 * i + 2];
+    }
+    return out;
+  }
+  mh_map * underlying()
+  {
+    ensure();
+    return map_;
+  }
+  const std::shared_ptr<Context> & context() const { return ctx_; }
+
+private:
+  void ensure()
+  {
+    if (!map_) ctx_->check(mh_map_create(ctx_->get(), &cfg_, &map_), "mh_map_create");
+  }
+  void require_empty() const
+  {
+    if (map_) throw std::runtime_error("IncrementalVoxelMapPCL: settings must be applied before the first insert");
+  }
+  std::shared_ptr<Context> ctx_;
+  mh_map_config cfg_{};
+  mh_map * map_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+class ICPFactor : public NonlinearFactor
+{
+public:
+  using Ptr = std::shared_ptr<ICPFactor>;
+  enum class RejectStatus {  // geometric_factor.hpp:35-46
+    Unprocessed = 0,
+    InsufficientCorresPoints,
+    CorresMaxDist,
+    EigenSolverFail,
+    MinEigenValueLow,
+    Line,
+    CorresPlaneInvalid,
+    MaxError,
+    Valid
+  };
+
+  // unary: key_source is T_W_B, the cloud is registered to the map frame (:119-129)
+  ICPFactor(const Key key_source, IncrementalVoxelMapPCL::Ptr ivox_target, const PointCloud & cloud_source,
+            const RegistrationConfig & config)
+  : NonlinearFactor({key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
+  {
+    create(cloud_source, config);
+  }
+  // binary (:131-142)
+  ICPFactor(const Key key_source, const Key key_target, IncrementalVoxelMapPCL::Ptr ivox_target,
+            const PointCloud & cloud_source, const RegistrationConfig & config)
+  : NonlinearFactor({key_source, key_target}), is_binary_(true), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
+  {
+    create(cloud_source, config);
+  }
+  ~ICPFactor() override { mh_icp_destroy(icp_); }
+
+  NonlinearFactor::shared_ptr clone() const override  // :160-164 deep-copies the per-point state
+  {
+    std::shared_ptr<ICPFactor> c(new ICPFactor(*this, CloneTag{}));
+    return c;
+  }
+  size_t dim() const override { return 6; }                  // :166
+  double error(const Values &) const override { return 0.0; }  // :168-174 (the reference prints and returns 0)
+
+  std::shared_ptr<GaussianFactor> linearize(const Values & c) const override  // :231-562
+  {
+    const Pose3 & Ts = c.atPose3(keys()[0]);
+    const Pose3 * Tt = is_binary_ ? &c.atPose3(keys()[1]) : nullptr;
+    mh_icp_result r;
+    ctx().check(mh_icp_linearize(icp_, Ts.R.data(), Ts.t.data(), Tt ? Tt->R.data() : nullptr, Tt ? Tt->t.data() : nullptr,
+                                 c.gravityUnit().data(), &r),
+                "mh_icp_linearize");
+    last_ = r;
+    auto h = std::make_shared<HessianFactor>();
+    h->keys = keys();
+    std::memcpy(h->G11.data(), r.H_ss, sizeof(r.H_ss));
+    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_s[i];  // HessianFactor(key, H, -b, f), :559-560
+    h->f = r.f;
+    if (is_binary_) {  // :460-462
+      std::memcpy(h->G12.data(), r.H_st, sizeof(r.H_st));
+      std::memcpy(h->G22.data(), r.H_tt, sizeof(r.H_tt));
+      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_t[i];
+    }
+    return h;
+  }
+
+  // getters, :48-72
+  std::vector<RejectStatus> getStatuses() const
+  {
+    std::vector<int32_t> s(n_);
+    if (n_) ctx().check(mh_icp_get_state(icp_, s.data(), nullptr, nullptr), "mh_icp_get_state");
+    std::vector<RejectStatus> out(n_);
+    for (size_t i = 0; i < n_; ++i) out[i] = static_cast<RejectStatus>(s[i]);
+    return out;
+  }
+  std::vector<V3D> getCorresMeansTarget() const
+  {
+    std::vector<V3D> m(n_);
+    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, m[0].data(), nullptr), "mh_icp_get_state");
+    return m;
+  }
+  std::vector<V3D> getCorresNormalsTarget() const
+  {
+    std::vector<V3D> m(n_);
+    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, nullptr, m[0].data()), "mh_icp_get_state");
+    return m;
+  }
+  void getLocalizabilities(V3D & trans_comp, V3D & rot_comp, V3D & trans_final, V3D & rot_final, M33 & eigenvectors_trans,
+                           M33 & eigenvectors_rot)
+  {
+    std::memcpy(trans_comp.data(), last_.loc_trans_comp, 24);
+    std::memcpy(rot_comp.data(), last_.loc_rot_comp, 24);
+    std::memcpy(trans_final.data(), last_.loc_trans_final, 24);
+    std::memcpy(rot_final.data(), last_.loc_rot_final, 24);
+    std::memcpy(eigenvectors_trans.data(), last_.eigvec_trans, 72);
+    std::memcpy(eigenvectors_rot.data(), last_.eigvec_rot, 72);
+  }
+  void getDegenInfo(V3D & rot, M33 & eigenvectors_rot, V3D & trans, M33 & eigenvectors_trans)
+  {
+    std::memcpy(rot.data(), last_.degen_rot, 24);
+    std::memcpy(eigenvectors_rot.data(), last_.degen_eigvec_rot, 72);
+    std::memcpy(trans.data(), last_.degen_trans, 24);
+    std::memcpy(eigenvectors_trans.data(), last_.degen_eigvec_trans, 72);
+  }
+  int getLinearizeCount() const { return last_.linearize_count; }
+  const mh_icp_result & lastResult() const { return last_; }  // incl. the status histogram of geometric.cpp:280-323
+
+private:
+  struct CloneTag
+  {
+  };
+  ICPFactor(const ICPFactor & o, CloneTag)
+  : NonlinearFactor(o.keys()), is_binary_(o.is_binary_), ivox_target_(o.ivox_target_), n_(o.n_), last_(o.last_)
+  {
+    ctx().check(mh_icp_clone(o.icp_, &icp_), "mh_icp_clone");
+  }
+  void create(const PointCloud & cloud, const RegistrationConfig & config)
+  {
+    std::memset(&last_, 0, sizeof(last_));
+    ctx().check(mh_icp_create(ctx().get(), ivox_target_->underlying(), cloud.data(), cloud.size(), &config, is_binary_ ? 1 : 0,
+                              &icp_),
+                "mh_icp_create");
+  }
+  const Context & ctx() const { return *ivox_target_->context(); }
+
+  const bool is_binary_;
+  IncrementalVoxelMapPCL::Ptr ivox_target_;
+  size_t n_;
+  mh_icp * icp_ = nullptr;
+  mutable mh_icp_result last_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// mimosa_msgs/msg/LidarGeometricDebug.msg counterpart (plain struct)
+struct GeometricDebug
+{
+  size_t n_points_in = 0, n_points_in_sm_ds = 0;
+  int n_status[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  V3D localizability_trans_comp{}, localizability_rot_comp{}, localizability_trans_final{}, localizability_rot_final{};
+  bool degen_rot_bool[3] = {false, false, false}, degen_trans_bool[3] = {false, false, false};
+  int n_linearize_calls = 0;
+  bool map_updated = false;
+};
+
+class Geometric
+{
+public:
+  const GeometricConfig config;
+
+  Geometric(const std::shared_ptr<Context> & ctx, const GeometricConfig & cfg) : config(cfg), ctx_(ctx)
+  {
+    // geometric.cpp:23-28
+    ivox_map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, config.scan_to_map.target_ivox_map_leaf_size);
+    ivox_map_->set_lru_horizon(config.lru_horizon);
+    ivox_map_->set_neighbor_voxel_mode(config.neighbor_voxel_mode);
+    ivox_map_->set_min_dist_in_cell(config.scan_to_map.target_ivox_map_min_dist_in_voxel);
+    initial_clouds_to_force_map_update_ = config.initial_clouds_to_force_map_update;
+  }
+
+  // geometric.cpp:128-183: subset -> body frame (f32, on the GPU) -> voxel down-sample (host, :55-126)
+  void preprocess(const PointCloud & points_deskewed, const std::vector<size_t> & idxs, const double ts)
+  {
+    if (!config.enabled) return;
+    ts_ = ts;
+    Be_cloud_.clear();
+    Be_cloud_.reserve(idxs.size());
+    for (const size_t idx : idxs) Be_cloud_.push_back(points_deskewed[idx]);
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(config.T_B_L.R[i]);
+    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(config.T_B_L.t[i]);
+    if (!Be_cloud_.empty())
+      ctx_->check(mh_transform_f32(ctx_->get(), Be_cloud_.data(), Be_cloud_.size(), R, t), "mh_transform_f32");
+    downsample(Be_cloud_, sm_Be_cloud_ds_, config.scan_to_map.source_voxel_grid_filter_leaf_size, 20,
+               config.scan_to_map.source_voxel_grid_min_dist_in_voxel);
+    debug_.n_points_in = points_deskewed.size();
+    debug_.n_points_in_sm_ds = sm_Be_cloud_ds_.size();
+  }
+
+  // geometric.cpp:185-328
+  void getFactors(const Key & key, const Values & values, NonlinearFactorGraph & graph, M66 & eigenvectors_block_matrix,
+                  V6D & degen_directions)
+  {
+    if (!config.enabled) return;
+    factor_ = std::make_shared<ICPFactor>(key, ivox_map_, sm_Be_cloud_ds_, config.scan_to_map);
+    auto tmp = factor_->linearize(values);  // linearized right away so localizability is available (:196)
+    (void)tmp;
+    V3D tc, rc, tf, rf;
+    M33 et, er;
+    factor_->getLocalizabilities(tc, rc, tf, rf, et, er);
+    eigenvectors_block_matrix.fill(0.0);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        eigenvectors_block_matrix[6 * r + c] = er[3 * r + c];
+        eigenvectors_block_matrix[6 * (3 + r) + 3 + c] = et[3 * r + c];
+      }
+    for (int i = 0; i < 3; ++i) {  // :218-228
+      degen_directions[i] = rc[i] < config.scan_to_map.degen_thresh_rot;
+      degen_directions[3 + i] = tc[i] < config.scan_to_map.degen_thresh_trans;
+      debug_.degen_rot_bool[i] = degen_directions[i] != 0;
+      debug_.degen_trans_bool[i] = degen_directions[3 + i] != 0;
+    }
+    debug_.localizability_trans_comp = tc;
+    debug_.localizability_rot_comp = rc;
+    debug_.localizability_trans_final = tf;
+    debug_.localizability_rot_final = rf;
+    for (int i = 0; i < 9; ++i) debug_.n_status[i] = factor_->lastResult().status_hist[i];  // :280-323
+    graph.add(factor_);
+  }
+
+  // geometric.cpp:427-513
+  void updateMap(const Key key, const Values & values)
+  {
+    if (!config.enabled) return;
+    if (factor_) debug_.n_linearize_calls = factor_->getLinearizeCount();
+    const Pose3 & T_W_Be = values.atPose3(key);
+    bool update_map = true;
+    if (!map_poses_.empty()) {
+      float min_diff_trans = std::numeric_limits<float>::max();
+      size_t min_diff_index = 0;
+      for (size_t i = 0; i < map_poses_.size(); ++i) {
+        const V3D & a = map_poses_[i].t;
+        const float d = static_cast<float>(std::sqrt((a[0] - T_W_Be.t[0]) * (a[0] - T_W_Be.t[0]) +
+                                                     (a[1] - T_W_Be.t[1]) * (a[1] - T_W_Be.t[1]) +
+                                                     (a[2] - T_W_Be.t[2]) * (a[2] - T_W_Be.t[2])));
+        if (d < min_diff_trans) {
+          min_diff_trans = d;
+          min_diff_index = i;
+        }
+      }
+      // rot_diff = R_B_L^-1 * between(R_kf, R_now) * R_B_L, yaw-pitch-roll magnitudes (:454-458)
+      Pose3 RBL;
+      RBL.R = config.T_B_L.R;
+      Pose3 Rk, Rn;
+      Rk.R = map_poses_[min_diff_index].R;
+      Rn.R = T_W_Be.R;
+      const Pose3 d = RBL.inverse() * (Rk.inverse() * Rn) * RBL;
+      const double yaw = std::atan2(d.R[3], d.R[0]);
+      const double pitch = std::atan2(-d.R[6], std::sqrt(d.R[7] * d.R[7] + d.R[8] * d.R[8]));
+      const double roll = std::atan2(d.R[7], d.R[8]);
+      const double ypr_max = std::max(std::fabs(yaw), std::max(std::fabs(pitch), std::fabs(roll)));
+      if (min_diff_trans > config.map_keyframe_trans_thresh)
+        update_map = true;
+      else if (ypr_max > config.map_keyframe_rot_thresh_deg * M_PI / 180.0)
+        update_map = true;
+      else
+        update_map = false;
+    }
+    if (initial_clouds_to_force_map_update_ > 0) {
+      update_map = true;
+      initial_clouds_to_force_map_update_--;
+    }
+    debug_.map_updated = update_map;
+    if (!update_map) return;
+    // world transform in f32 (:483-490), then copy-then-insert so live factors keep their snapshot (:494-495)
+    PointCloud W = Be_cloud_;
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
+    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
+    if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
+    ivox_map_ = std::make_shared<IncrementalVoxelMapPCL>(*ivox_map_);
+    ivox_map_->insert(W);
+    map_poses_.push_back(T_W_Be);
+  }
+
+  const GeometricDebug & debug() const { return debug_; }
+  const PointCloud & sourceCloud() const { return sm_Be_cloud_ds_; }
+  const IncrementalVoxelMapPCL::Ptr & map() const { return ivox_map_; }
+  const ICPFactor::Ptr & factor() const { return factor_; }
+
+  // Geometric::downsample, geometric.cpp:55-126 with FlatContainerMinimal::add (lidar/utils.hpp:260-278):
+  // greedy, input order; output = voxels in first-seen order, points in acceptance order.
+  static void downsample(const PointCloud & in, PointCloud & out, const double leaf_size, const size_t max_points_per_voxel,
+                         const double min_dist_in_voxel)
+  {
+    struct Key3
+    {
+      int x, y, z;
+      bool operator==(const Key3 & o) const { return x == o.x && y == o.y && z == o.z; }
+    };
+    struct Hash
+    {
+      size_t operator()(const Key3 & k) const
+      {  // XORVector3iHash, lidar/utils.hpp:228-238
+        return static_cast<size_t>((k.x * 9132043225175502913ull) ^ (k.y * 7277549399757405689ull) ^
+                                   (k.z * 6673468629021231217ull));
+      }
+    };
+    auto ffloor = [](double v) {
+      const int n = static_cast<int>(v);
+      return n - (v < static_cast<double>(n) ? 1 : 0);
+    };
+    const double inv = 1.0 / leaf_size, min_sq = min_dist_in_voxel * min_dist_in_voxel;
+    std::unordered_map<Key3, size_t, Hash> voxels;
+    voxels.reserve(in.size() / 2 + 1);
+    std::vector<std::vector<uint32_t>> kept;
+    for (size_t i = 0; i < in.size(); ++i) {
+      const double px = in[i].x, py = in[i].y, pz = in[i].z;
+      const Key3 c{ffloor(px * inv), ffloor(py * inv), ffloor(pz * inv)};
+      auto f = voxels.find(c);
+      if (f == voxels.end()) {
+        f = voxels.emplace(c, kept.size()).first;
+        kept.emplace_back();
+      }
+      auto & cell = kept[f->second];
+      if (cell.size() >= max_points_per_voxel) continue;
+      bool close = false;
+      for (const uint32_t j : cell) {
+        const double dx = in[j].x - px, dy = in[j].y - py, dz = in[j].z - pz;
+        if (dx * dx + (dy * dy + dz * dz) < min_sq) {
+          close = true;
+          break;
+        }
+      }
+      if (!close) cell.push_back(static_cast<uint32_t>(i));
+    }
+    out.clear();
+    for (const auto & cell : kept)
+      for (const uint32_t j : cell) out.push_back(in[j]);
+  }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  PointCloud Be_cloud_, sm_Be_cloud_ds_;
+  ICPFactor::Ptr factor_;
+  IncrementalVoxelMapPCL::Ptr ivox_map_;
+  std::vector<Pose3> map_poses_;
+  size_t initial_clouds_to_force_map_update_ = 0;
+  double ts_ = 0;
+  GeometricDebug debug_;
+};
+
+// Manager::deskewPoints' per-point part (manager.cpp:496-509).  T_Le_Lt[g] is the pose of the sensor at
+// unique timestamp g in the scan-end frame — computed by the caller's IMU propagation (:455-499), which
+// stays on the CPU.  Points are transformed in place on the GPU.
+inline void deskewPoints(const Context & ctx, PointCloud & points_full, const std::vector<uint32_t> & unique_ns,
+                         const std::vector<Pose3> & T_Le_Lt, const Pose3 * T_B_L = nullptr)
+{
+  if (unique_ns.size() != T_Le_Lt.size()) throw std::runtime_error("deskewPoints: one pose per unique timestamp");
+  std::vector<float> Rt12(12 * T_Le_Lt.size());
+  for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
+    for (int i = 0; i < 9; ++i) Rt12[12 * g + i] = static_cast<float>(T_Le_Lt[g].R[i]);
+    for (int i = 0; i < 3; ++i) Rt12[12 * g + 9 + i] = static_cast<float>(T_Le_Lt[g].t[i]);
+  }
+  float Rb[9], tb[3];
+  if (T_B_L) {
+    for (int i = 0; i < 9; ++i) Rb[i] = static_cast<float>(T_B_L->R[i]);
+    for (int i = 0; i < 3; ++i) tb[i] = static_cast<float>(T_B_L->t[i]);
+  }
+  ctx.check(mh_deskew(ctx.get(), points_full.data(), points_full.size(), unique_ns.data(), Rt12.data(), unique_ns.size(),
+                      T_B_L ? Rb : nullptr, T_B_L ? tb : nullptr),
+            "mh_deskew");
+}
+
+}  // namespace lidar
+}  // namespace mimosa_hip

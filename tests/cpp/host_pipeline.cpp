@@ -1,0 +1,125 @@
+// Drives the C++ host mirror (mimosa_amd/host/mimosa_hip/lidar.hpp) through the reference's call order
+//   deskewPoints -> Geometric::preprocess -> getFactors (ctor + first linearize) -> relinearize ->
+//   updateMap (copy + insert) -> getFactors on the new map
+// on inputs written by tests/test_gpu_host_cpp.py, and prints the results as JSON for comparison with
+// the oracle.  Input file: little-endian, see read_* below.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "../../mimosa_amd/host/mimosa_hip/lidar.hpp"
+
+using namespace mimosa_hip;
+using namespace mimosa_hip::lidar;
+
+template <typename T>
+static std::vector<T> read_vec(std::ifstream & f)
+{
+  uint64_t n = 0;
+  f.read(reinterpret_cast<char *>(&n), 8);
+  std::vector<T> v(n);
+  f.read(reinterpret_cast<char *>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
+  return v;
+}
+static Pose3 pose_from(const double * p)
+{
+  Pose3 T;
+  for (int i = 0; i < 9; ++i) T.R[i] = p[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = p[9 + i];
+  return T;
+}
+static void dump(const char * name, const double * v, int n, bool last = false)
+{
+  std::printf("\"%s\": [", name);
+  for (int i = 0; i < n; ++i) std::printf("%.17g%s", v[i], i + 1 < n ? ", " : "");
+  std::printf("]%s\n", last ? "" : ",");
+}
+static void dump_factor(const char * tag, const Geometric & g, const HessianFactor & h, const V6D & degen)
+{
+  std::printf("\"%s\": {\n", tag);
+  dump("H", h.G11.data(), 36);
+  dump("g", h.g1.data(), 6);
+  std::printf("\"f\": %.17g,\n", h.f);
+  std::printf("\"n_ds\": %zu,\n", g.debug().n_points_in_sm_ds);
+  std::printf("\"status_hist\": [");
+  for (int i = 0; i < 9; ++i) std::printf("%d%s", g.debug().n_status[i], i < 8 ? ", " : "");
+  std::printf("],\n");
+  dump("loc_trans_comp", g.debug().localizability_trans_comp.data(), 3);
+  dump("loc_rot_comp", g.debug().localizability_rot_comp.data(), 3);
+  dump("degen_directions", degen.data(), 6, true);
+  std::printf("}");
+}
+
+int main(int argc, char ** argv)
+{
+  if (argc < 2) return 2;
+  std::ifstream f(argv[1], std::ios::binary);
+  auto map_xyz = read_vec<float>(f);        // 3 per point
+  auto scan = read_vec<Point>(f);           // skewed scan, sensor frame
+  auto unique_ns = read_vec<uint32_t>(f);
+  auto poses12 = read_vec<double>(f);       // T_Le_Lt per unique ns: R(9) t(3)
+  auto misc = read_vec<double>(f);          // T_B_L (12), T_W_B query (12), T_W_B second (12)
+  try {
+    auto ctx = std::make_shared<Context>(0);
+    GeometricConfig cfg;  // ENWIDE: config/enwide/params.yaml:76-100
+    cfg.T_B_L = pose_from(&misc[0]);
+    cfg.point_skip_divisor = 4;
+    cfg.map_keyframe_trans_thresh = 2;
+    cfg.map_keyframe_rot_thresh_deg = 30;
+    cfg.initial_clouds_to_force_map_update = 1;
+    cfg.lru_horizon = 1000;
+    cfg.neighbor_voxel_mode = 19;
+    cfg.scan_to_map.source_voxel_grid_min_dist_in_voxel = 0.15f;
+    cfg.scan_to_map.target_ivox_map_min_dist_in_voxel = 0.15f;
+    cfg.scan_to_map.max_corres_distance = 1.0f;
+    cfg.scan_to_map.plane_validity_distance = 0.07f;
+    cfg.scan_to_map.lidar_point_noise_std_dev = 0.07f;
+    cfg.scan_to_map.project_on_degneneracy = 0;
+    cfg.scan_to_map.degen_thresh_trans = 40;
+    cfg.scan_to_map.degen_thresh_rot = 0;
+    Geometric geo(ctx, cfg);
+    geo.map()->insert(map_xyz.data(), map_xyz.size() / 3);  // pre-built local map
+
+    std::vector<Pose3> T_Le_Lt(unique_ns.size());
+    for (size_t g = 0; g < unique_ns.size(); ++g) T_Le_Lt[g] = pose_from(&poses12[12 * g]);
+    deskewPoints(*ctx, scan, unique_ns, T_Le_Lt);  // manager.cpp:496-509
+
+    std::vector<size_t> idxs;  // point_skip_divisor filter, manager.cpp:318
+    for (size_t i = 0; i < scan.size(); ++i)
+      if (scan[i].idx % static_cast<uint32_t>(cfg.point_skip_divisor) == 0) idxs.push_back(i);
+    geo.preprocess(scan, idxs, 0.0);
+
+    const Key X0 = 1;
+    Values values;
+    values.insert(X0, pose_from(&misc[12]));
+    NonlinearFactorGraph graph;
+    M66 evecs;
+    V6D degen;
+    geo.getFactors(X0, values, graph, evecs, degen);
+    std::printf("{\n");
+    auto h1 = std::static_pointer_cast<HessianFactor>(graph.factors[0]->linearize(values));  // relinearize: cache path
+    dump_factor("first", geo, *h1, degen);
+    std::printf(",\n\"linearize_count\": %d,\n", geo.factor()->getLinearizeCount());
+
+    // clone keeps working independently (ISAM2 clones factors)
+    auto cl = graph.factors[0]->clone();
+    auto hc = std::static_pointer_cast<HessianFactor>(cl->linearize(values));
+    std::printf("\"clone_f\": %.17g,\n", hc->f);
+
+    geo.updateMap(X0, values);  // first keyframe is forced; map becomes a copy + this scan
+    std::printf("\"map_updated\": %d,\n", geo.debug().map_updated ? 1 : 0);
+    std::printf("\"map_points_after\": %zu,\n", geo.map()->getCloud().size());
+
+    values.update(X0, pose_from(&misc[24]));
+    NonlinearFactorGraph graph2;
+    geo.getFactors(X0, values, graph2, evecs, degen);
+    auto h2 = std::static_pointer_cast<HessianFactor>(graph2.factors[0]->linearize(values));
+    dump_factor("second", geo, *h2, degen);
+    geo.updateMap(X0, values);  // too close to the first keyframe: no update
+    std::printf(",\n\"map_updated_2\": %d\n}\n", geo.debug().map_updated ? 1 : 0);
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "host_pipeline: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

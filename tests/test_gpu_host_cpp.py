@@ -1,0 +1,102 @@
+"""-m gpu: the C++ host mirror (ICPFactor / Geometric / IncrementalVoxelMapPCL / deskewPoints over the
+C ABI) driven through the reference's call order, compared with the oracle doing the same steps."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from parity import rel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_exe():
+    from mimosa_amd import build
+    lib = build.build()
+    exe = os.path.join(os.path.dirname(lib), "host_pipeline")
+    src = os.path.join(ROOT, "tests", "cpp", "host_pipeline.cpp")
+    hdr = os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", "lidar.hpp")
+    if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lib)) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, src, "-o", exe,
+                               "-L", os.path.dirname(lib), "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
+    return exe
+
+
+def test_host_layer_compiles():
+    """CPU-runnable: the header-only host mirror builds warning-free against the C ABI."""
+    assert os.path.exists(build_exe())
+
+
+def _pose12(R, t):
+    return np.concatenate([np.asarray(R, float).ravel(), np.asarray(t, float)])
+
+
+@pytest.mark.gpu
+def test_host_pipeline_matches_oracle(tmp_path):
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+
+    room = np.array([6.0, 5.0, 3.0])
+    map_xyz = synth.make_room(1234, 0, 0, room=room)
+    scan, aux = synth.make_scan(n_rows=32, seed=77, skew=True, n_cols=256, room=room,
+                                sensor_local=np.array([2.3, 2.6, 1.2]))
+    T_B_L = (synth.so3_exp(np.array([0.01, -0.02, 0.03])), np.array([0.05, 0.02, -0.1]))
+    # body pose: T_W_B = T_W_L * T_B_L^-1, perturbed like the bench query pose
+    R_WL, t_WL = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    R_WB = R_WL @ T_B_L[0].T
+    t_WB = t_WL - R_WB @ T_B_L[1]
+    R_WB2, t_WB2 = R_WB @ synth.so3_exp(np.array([0.0, 0.0, 0.004])), t_WB + np.array([0.05, 0.02, 0.0])
+    poses = np.concatenate([aux["Rt12"][g].astype(np.float64) for g in range(len(aux["unique_ns"]))])
+
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        def w(arr):
+            arr = np.ascontiguousarray(arr)
+            f.write(struct.pack("<Q", arr.size if arr.dtype.itemsize != 32 else len(arr)))
+            f.write(arr.tobytes())
+        w(map_xyz.astype(np.float32).ravel())
+        w(scan)
+        w(aux["unique_ns"].astype(np.uint32))
+        w(poses)
+        w(np.concatenate([_pose12(*T_B_L), _pose12(R_WB, t_WB), _pose12(R_WB2, t_WB2)]))
+    out = subprocess.run([build_exe(), str(inp)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout)
+
+    # ---- the same steps through the oracle --------------------------------------------------------
+    cfg = synth.enwide_config()
+    desk = ref_cpu.deskew(scan, aux["unique_ns"], aux["Rt12"])
+    sub = desk[desk["idx"] % 4 == 0]
+    Be = ref_cpu.transform_f32(sub, T_B_L[0].astype(np.float32), T_B_L[1].astype(np.float32))
+    ds = Be[ref_cpu.downsample(Be, 0.5, 20, 0.15)]
+    rmap = ref_cpu.Map()
+    rmap.insert(map_xyz)
+    fac = ref_cpu.ICP(rmap, ds, ref_cpu.make_config(**cfg))
+    fac.linearize(R_WB, t_WB)
+    r1 = fac.linearize(R_WB, t_WB)  # the driver relinearizes once more before dumping
+    for key, ref in (("first", r1),):
+        g = got[key]
+        assert g["n_ds"] == len(ds)
+        assert g["status_hist"] == [int(v) for v in ref["status_hist"]]
+        assert rel(np.array(g["H"]).reshape(6, 6), ref["H_ss"]) <= 1e-5
+        assert rel(np.array(g["g"]), -ref["b_s"]) <= 1e-5  # HessianFactor gets -J^T e
+        assert abs(g["f"] - ref["f"]) <= 1e-5 * ref["f"]
+        assert rel(g["loc_trans_comp"], ref["loc_trans_comp"]) <= 1e-5
+        want = [float(ref["loc_rot_comp"][i] < cfg["degen_thresh_rot"]) for i in range(3)] + \
+               [float(ref["loc_trans_comp"][i] < cfg["degen_thresh_trans"]) for i in range(3)]
+        assert g["degen_directions"] == want
+    assert got["linearize_count"] == 2 and abs(got["clone_f"] - r1["f"]) <= 1e-5 * r1["f"]
+    assert got["map_updated"] == 1 and got["map_updated_2"] == 0
+    W = ref_cpu.transform_f32(Be, R_WB.astype(np.float32), t_WB.astype(np.float32))
+    rmap2 = rmap.copy()
+    rmap2.insert(np.stack([W["x"], W["y"], W["z"]], 1))
+    assert got["map_points_after"] == rmap2.num_points
+    fac2 = ref_cpu.ICP(rmap2, ds, ref_cpu.make_config(**cfg))
+    fac2.linearize(R_WB2, t_WB2)
+    r2 = fac2.linearize(R_WB2, t_WB2)
+    g = got["second"]
+    assert g["status_hist"] == [int(v) for v in r2["status_hist"]]
+    assert rel(np.array(g["H"]).reshape(6, 6), r2["H_ss"]) <= 1e-5 and abs(g["f"] - r2["f"]) <= 1e-5 * r2["f"]
