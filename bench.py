@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rooms", type=str, default="2x5", help="map size in rooms (2x5 ~ 5 M points)")
     ap.add_argument("--rows", type=int, default=128, help="scan rows (128 -> 131 072 points)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent scans in flight on separate HIP streams (contexts) sharing the map")
+    ap.add_argument("--concurrent-streams", type=int, default=4,
+                    help="size of the extra aggregate-throughput pass reported as value_concurrent (0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
     return ap.parse_args()
@@ -83,31 +87,45 @@ def main():
     factor = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
     n_pts = len(pts)
     first = factor.linearize(R, t)  # uploads the map, first cold pass
+    # additional independent scans (own range-noise seed) on their own HIP streams, same map
+    ctxs, factors = [ctx], [factor]
+    for sidx in range(1, args.streams):
+        c2 = capi.Context(local_rank)
+        p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + rank + 1000 * sidx)
+        f2 = capi.ICPFactor(c2, gmap, p2, capi.make_reg_config(**cfgd))
+        f2.linearize(R, t)
+        ctxs.append(c2)
+        factors.append(f2)
     stats = gmap.stats()
     setup_s = time.time() - t0
 
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         if dist is not None:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
 
     def run_steps(k, collect=None):
+        """k cold linearizes in total, dealt round-robin to the streams, <= INFLIGHT in flight each."""
         done = 0
         while done < k:
-            nb = min(INFLIGHT, k - done)
+            nb = min(INFLIGHT * len(factors), k - done)
             outs = []
-            for _ in range(nb):
-                factor.reset()
-                outs.append(factor.linearize_async(R, t))
-            factor.wait()
+            for i in range(nb):
+                f = factors[i % len(factors)]
+                f.reset()
+                outs.append(f.linearize_async(R, t))
+            for f in factors:
+                f.wait()
             if collect is not None:
                 collect.extend(outs)
             done += nb
 
     # ---- warmup, then the timed region (per-kernel HIP events on the launch stream are on) ----
-    ctx.set_profiling(True)
+    for c in ctxs:
+        c.set_profiling(True)
     run_steps(args.warmup)
     outs = []
     barrier()
@@ -123,11 +141,12 @@ def main():
 
     k3_ms = np.array([o.gpu_ms_linearize for o in outs], dtype=np.float64)
     k4_ms = np.array([o.gpu_ms_localizability for o in outs], dtype=np.float64)
-    last = outs[-1].as_dict()
+    last = outs[(len(outs) - 1) // len(factors) * len(factors)].as_dict()  # a result of stream 0
     assert np.array_equal(last["H_ss"], first["H_ss"]), "cold linearize is not reproducible"
 
     # synchronous per-call latency (result on the host before the next call), events off
-    ctx.set_profiling(False)
+    for c in ctxs:
+        c.set_profiling(False)
     lat = []
     for _ in range(min(50, max(10, args.steps // 4))):
         factor.reset()
@@ -155,6 +174,32 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed_noev = time.perf_counter() - a
+
+    # Aggregate throughput with several independent scans in flight (own HIP streams, shared map): a single
+    # 131 072-point scan can only put 2 waves on a SIMD, concurrent scans fill the machine.
+    conc = None
+    if args.streams == 1 and args.concurrent_streams > 1:
+        for sidx in range(1, args.concurrent_streams):
+            c2 = capi.Context(local_rank)
+            p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + rank + 1000 * sidx)
+            f2 = capi.ICPFactor(c2, gmap, p2, capi.make_reg_config(**cfgd))
+            f2.linearize(R, t)
+            ctxs.append(c2)
+            factors.append(f2)
+        ksteps = args.steps * 2
+        run_steps(args.warmup)
+        barrier()
+        a = time.perf_counter()
+        run_steps(ksteps)
+        barrier()
+        el = time.perf_counter() - a
+        if dist is not None:
+            import torch
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        conc = {"streams": args.concurrent_streams, "steps": ksteps,
+                "value": round(n_pts * ksteps * world / el / 1e6, 2), "ms_per_step": round(el / ksteps * 1e3, 5)}
 
     total_pts = n_pts * args.steps * world
     value = total_pts / elapsed / 1e6
@@ -190,7 +235,9 @@ def main():
             "workload": f"configs[1]: OS0-128 {n_pts}-pt scan vs {stats['n_points']}-pt local map "
                         f"({stats['n_voxels']} voxels, {args.rooms} rooms), k=5 point-to-plane, ENWIDE params, "
                         f"cold linearize per step",
-            "mode": f"pipelined, <= {INFLIGHT} linearize calls in flight, every result copied to the host",
+            "mode": f"{args.streams} independent scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT} "
+                    f"linearize calls in flight per stream, every result copied to the host",
+            "streams": args.streams,
             "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
             "status_hist": [int(v) for v in last["status_hist"]],
             "exact_fallback_queries": int(last["n_exact_fallback"]),
@@ -216,6 +263,7 @@ def main():
         "sync_latency_ms": round(lat_ms, 4),
         "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
         "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
+        "value_concurrent": conc,
         "value_pcie_inclusive": round(n_pts / (create_plus_lin_ms * 1e-3) / 1e6, 2),
         "create_plus_linearize_ms": round(create_plus_lin_ms, 4),
         "setup_s": round(setup_s, 2),
@@ -256,8 +304,11 @@ def main():
 
     if rank == 0:
         print(json.dumps(line), flush=True)
-    factor.destroy()
+    for f in factors:
+        f.destroy()
     gmap.release()
+    for c in ctxs[1:]:
+        c.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

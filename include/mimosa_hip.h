@@ -175,7 +175,9 @@ int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * p
 /* ---- ICPFactor ------------------------------------------------------------------------------
  * replaces include/mimosa/lidar/geometric_factor.hpp:25-563 */
 /* ctor (:119-156): copies the source cloud to the device, retains the map, allocates the per-point
- * data-association state zero-initialised. */
+ * data-association state zero-initialised.  `map` may belong to another context of the same device
+ * (several contexts = several HIP streams sharing one read-only map); while factors of other contexts
+ * are linearizing, do not insert into that map. */
 int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n,
                   const mh_reg_config * cfg, int is_binary, mh_icp ** out);
 /* clone() (:160-164): deep-copies the per-point state, shares the map. */

@@ -17,6 +17,7 @@ struct MapView
   const int4 * table;
   const uint32_t * cells;
   const float4 * buckets;
+  const uint4 * qbuckets;  // 5 x uint4 per voxel: 20 packed 3 x 10-bit points (coarse tier)
   double inv_leaf;
   uint32_t mask;
   int n_off;     // 1, 7, 19 or 27
@@ -59,6 +60,7 @@ struct IcpArgs
 
 struct LocArgs
 {
+  DeviceResult * host_result;  // mapped pinned host slot: the last block publishes the result there (no D2H copy node)
   const float4 * src;
   int n;
   double R[9];

@@ -92,7 +92,7 @@ struct mh_map
   mh_ctx * ctx;
   std::atomic<int> refs{1};
   mh::HostVoxelMap host;
-  DevBuf d_table, d_cells, d_buckets;
+  DevBuf d_table, d_cells, d_buckets, d_qbuckets;
   bool device_stale = true;
   int64_t uploads = 0, upload_bytes = 0;
   int n_off = 0;
@@ -122,7 +122,8 @@ struct mh_icp
   bool binary;
   DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm;
   bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
-  mh::DeviceResult * h_results = nullptr;  // pinned ring
+  mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly
+  mh::DeviceResult * d_h_results = nullptr;  // its device-side address
   PendingCall pending[kMaxPending];
   int n_pending = 0;
   int parity = 0;
@@ -143,20 +144,23 @@ int map_sync_device(mh_map * m)
   const size_t tb = H.table().size() * sizeof(mh::Int4);
   const size_t cb = H.cells().size() * sizeof(uint32_t);
   const size_t bb = H.buckets().size() * sizeof(mh::Float4);
+  const size_t qb = H.qbuckets().size() * sizeof(uint32_t);
   // Factors on this context may still be reading the old buffers: drain before (re)allocating.
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
   MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, false));
   MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, false));
+  MH_HIP(ctx, m->d_qbuckets.reserve(qb ? qb : 80, ctx->stream, false));
   MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
   if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
   if (bb) MH_HIP(ctx, hipMemcpyAsync(m->d_buckets.p, H.buckets().data(), bb, hipMemcpyHostToDevice, ctx->stream));
+  if (qb) MH_HIP(ctx, hipMemcpyAsync(m->d_qbuckets.p, H.qbuckets().data(), qb, hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->host.clear_dirty();
   m->host.take_full_rebuild();
   m->device_stale = false;
   m->uploads++;
-  m->upload_bytes += static_cast<int64_t>(tb + cb + bb);
+  m->upload_bytes += static_cast<int64_t>(tb + cb + bb + qb);
   return MH_OK;
 }
 
@@ -166,6 +170,7 @@ mh::MapView map_view(const mh_map * m)
   v.table = static_cast<const int4 *>(m->d_table.p);
   v.cells = static_cast<const uint32_t *>(m->d_cells.p);
   v.buckets = static_cast<const float4 *>(m->d_buckets.p);
+  v.qbuckets = static_cast<const uint4 *>(m->d_qbuckets.p);
   v.inv_leaf = m->host.inv_leaf();
   v.mask = m->host.table_mask();
   v.n_off = m->n_off;
@@ -440,6 +445,7 @@ void mh_map_release(mh_map * map)
     map->d_table.release();
     map->d_cells.release();
     map->d_buckets.release();
+    map->d_qbuckets.release();
     delete map;
   }
 }
@@ -450,7 +456,7 @@ int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
   out->n_voxels = static_cast<int64_t>(map->host.n_voxels());
   out->n_points = static_cast<int64_t>(map->host.n_points());
   out->n_blocks = static_cast<int64_t>(map->host.n_blocks());
-  out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap);
+  out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap + map->d_qbuckets.cap);
   out->uploads = map->uploads;
   out->upload_bytes = map->upload_bytes;
   return MH_OK;
@@ -512,7 +518,8 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, hipMemsetAsync(icp->d_dbg.p, 0, icp->d_dbg.cap, ctx->stream));
 #endif
   MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending,
-                            hipHostMallocDefault));
+                            hipHostMallocMapped));
+  MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_results), icp->h_results, 0));
   return MH_OK;
 }
 
@@ -521,7 +528,9 @@ int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t 
 {
   if (!ctx || !map || !cfg || !out || (!source && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: NULL argument");
   *out = nullptr;
-  if (map->ctx != ctx) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: map belongs to another context");
+  // A map may be shared read-only by factors of several contexts (= HIP streams) of the SAME device:
+  // uploads are host-synchronised on the map's own stream before any factor kernel is enqueued.
+  if (map->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: map lives on another device");
   if (cfg->num_corres_points < 2 || cfg->num_corres_points > 8)
     return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: num_corres_points must be in 2..8");
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: cloud too large");
@@ -723,6 +732,7 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
 
   mh::LocArgs l;
   l.src = a.src;
+  l.host_result = nullptr;  // set below once the slot is known
   l.n = a.n;
   std::memcpy(l.R, a.R, sizeof(l.R));
   l.normal = a.normal;
@@ -746,14 +756,16 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   if (a.n > 0) {
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+    l.host_result = icp->d_h_results + slot;
     MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
     if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   } else if (ctx->profiling) {
     MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   }
-  MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
-                             ctx->stream));
+  if (a.n == 0)  // nothing was launched: the (zero) device result is copied the plain way
+    MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
+                               ctx->stream));
   icp->n_pending++;
   icp->cold = false;
   return MH_OK;

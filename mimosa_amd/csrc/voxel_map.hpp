@@ -10,6 +10,10 @@
 // not for pointer chasing:
 //
 //   buckets : float4[n_voxels * 20]        one 320-byte bucket per voxel, points in insertion order
+//   qbuckets: uint32[n_voxels * 20]        the same points, 3 x 10-bit voxel-relative fixed point
+//                                          (x | y << 10 | z << 20, cell = leaf / 1024): the coarse k-NN
+//                                          tier reads 4 candidates per 16-byte load; selection is
+//                                          always re-decided on the exact float4 copy
 //   cells   : uint32[n_blocks * 64]        4x4x4-voxel blocks; entry = voxel_id << 5 | count, ~0u = empty
 //   table   : int4[capacity]               open-addressing hash of BLOCK coords -> block id (w), -1 empty
 //
@@ -32,6 +36,7 @@ constexpr int kBlockDim = 1 << kBlockLog2;
 constexpr int kCellsPerBlock = kBlockDim * kBlockDim * kBlockDim;
 constexpr int kBucketStride = 20;                   // FlatContainer max_num_points_in_cell
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
+constexpr int kQuantBits = 10;                     // coarse copy: leaf / 1024 resolution
 
 struct Int4
 {
@@ -117,6 +122,7 @@ public:
   const std::vector<Int4> & table() const { return table_; }
   const std::vector<uint32_t> & cells() const { return cells_; }
   const std::vector<Float4> & buckets() const { return buckets_; }
+  const std::vector<uint32_t> & qbuckets() const { return qbuckets_; }
   const std::vector<uint8_t> & counts() const { return vox_count_; }
 
   // Dirty tracking for the device mirror.
@@ -154,6 +160,14 @@ public:
       }
       if (close) continue;
       b[cnt] = Float4{fx, fy, fz, 1.0f};
+      {  // coarse copy: floor(frac(p * inv_leaf) * 1024) per axis (frac is in [0,1) by construction of c)
+        auto qz = [](double v, int c) {
+          int u = static_cast<int>((v - static_cast<double>(c)) * static_cast<double>(1 << kQuantBits));
+          return static_cast<uint32_t>(u < 0 ? 0 : (u > (1 << kQuantBits) - 1 ? (1 << kQuantBits) - 1 : u));
+        };
+        qbuckets_[static_cast<size_t>(vid) * kBucketStride + cnt] =
+          qz(px * inv_leaf_, cx) | (qz(py * inv_leaf_, cy) << kQuantBits) | (qz(pz * inv_leaf_, cz) << (2 * kQuantBits));
+      }
       vox_count_[vid] = static_cast<uint8_t>(cnt + 1);
       cells_[vox_cell_[vid]] = (vid << 5) | static_cast<uint32_t>(cnt + 1);
       ++n_points_;
@@ -236,6 +250,7 @@ private:
     vox_cell_.push_back(static_cast<uint32_t>(cell));
     vox_coord_.insert(vox_coord_.end(), {cx, cy, cz});
     buckets_.resize(static_cast<size_t>(vid + 1) * kBucketStride, Float4{0, 0, 0, 0});
+    qbuckets_.resize(static_cast<size_t>(vid + 1) * kBucketStride, 0u);
     dirty_flag_.push_back(0);
     cells_[cell] = vid << 5;
     mark_dirty(vid);
@@ -264,6 +279,7 @@ private:
     std::vector<uint8_t> count;
     std::vector<uint64_t> lru;
     std::vector<Float4> buckets;
+    std::vector<uint32_t> qb;
     for (size_t v = 0; v < vox_count_.size(); ++v) {
       if (vox_lru_[v] + horizon < lru_counter_) continue;
       coord.insert(coord.end(), {vox_coord_[3 * v], vox_coord_[3 * v + 1], vox_coord_[3 * v + 2]});
@@ -271,12 +287,14 @@ private:
       lru.push_back(vox_lru_[v]);
       buckets.insert(
         buckets.end(), buckets_.begin() + v * kBucketStride, buckets_.begin() + (v + 1) * kBucketStride);
+      qb.insert(qb.end(), qbuckets_.begin() + v * kBucketStride, qbuckets_.begin() + (v + 1) * kBucketStride);
       ++keep;
     }
     vox_coord_.swap(coord);
     vox_count_.swap(count);
     vox_lru_.swap(lru);
     buckets_.swap(buckets);
+    qbuckets_.swap(qb);
     vox_cell_.assign(keep, 0);
     dirty_flag_.assign(keep, 0);
     dirty_.clear();
@@ -329,6 +347,7 @@ private:
   std::vector<uint64_t> vox_lru_;
   std::vector<uint32_t> vox_cell_;
   std::vector<Float4> buckets_;
+  std::vector<uint32_t> qbuckets_;
   // blocks
   size_t n_blocks_ = 0;
   std::vector<int32_t> block_coord_;
