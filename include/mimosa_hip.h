@@ -195,6 +195,17 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
                            const double * R_tgt, const double * t_tgt, const double g_unit[3],
                            mh_icp_result * out);
 int mh_icp_wait(mh_icp * icp);
+/* Two-phase form for a factor whose map is sharded across GPUs (no reference counterpart; the
+ * reference is single-process).  begin = everything of linearize up to the Hessian sums of THIS shard
+ * (`partial`: H, b, f, counters; its localizability fields are shard-local and must be ignored);
+ * the caller all-reduces H across shards, eigen-decomposes the 3x3 rot / trans blocks and hands the
+ * GLOBAL eigenvectors (columns, row-major) to finish, which runs the component-localizability pass
+ * (geometric_factor.hpp:434-457) over this shard's valid points; the caller sums those across shards. */
+int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3],
+                           const double * R_tgt, const double * t_tgt, const double g_unit[3],
+                           mh_icp_result * partial);
+int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9],
+                            double loc_trans_comp[3], double loc_rot_comp[3], int32_t status_hist[9]);
 /* getStatuses / getCorresMeansTarget / getCorresNormalsTarget (:48-50); any pointer may be NULL. */
 int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals);
 /* Forget all data associations (== a freshly constructed factor): enqueued, no host sync. */

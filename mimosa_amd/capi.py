@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
-    "mh_icp_wait", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
+    "mh_icp_wait", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
 ]
 
@@ -143,6 +143,8 @@ def load(build_if_missing: bool = True):
     L.mh_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_wait.argtypes = [vp]
+    L.mh_icp_linearize_begin.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_icp_linearize_finish.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mh_icp_get_state.argtypes = [vp, vp, vp, vp]
     L.mh_icp_reset.argtypes = [vp]
     L.mh_icp_size.argtypes = [vp]
@@ -310,6 +312,19 @@ class ICPFactor:
         tt = _f64(t_tgt) if t_tgt is not None else None
         self.ctx.check(self.L.mh_icp_linearize(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
         return out.as_dict()
+
+    def linearize_begin(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> dict:
+        out = IcpResult()
+        R, t, g = _f64(R), _f64(t), _f64(g_unit)
+        self.ctx.check(self.L.mh_icp_linearize_begin(self.h, _p(R), _p(t), None, None, _p(g), C.byref(out)))
+        return out.as_dict()
+
+    def linearize_finish(self, eigvec_rot, eigvec_trans):
+        er, et = _f64(eigvec_rot), _f64(eigvec_trans)
+        tc, rc = np.empty(3), np.empty(3)
+        hist = np.empty(9, np.int32)
+        self.ctx.check(self.L.mh_icp_linearize_finish(self.h, _p(er), _p(et), _p(tc), _p(rc), _p(hist)))
+        return tc, rc, hist
 
     def linearize_async(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> IcpResult:
         out = IcpResult()

@@ -61,6 +61,7 @@ struct IcpArgs
 struct LocArgs
 {
   DeviceResult * host_result;  // mapped pinned host slot: the last block publishes the result there (no D2H copy node)
+  const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = use result->eig_* from K3
   const float4 * src;
   int n;
   double R[9];

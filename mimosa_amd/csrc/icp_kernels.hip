@@ -948,8 +948,8 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
         r1 *= inv;
         r2 *= inv;
       }
-      const double * Er = a.result->eig_rot;
-      const double * Et = a.result->eig_trans;
+      const double * Er = a.eig ? a.eig : a.result->eig_rot;
+      const double * Et = a.eig ? a.eig + 9 : a.result->eig_trans;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const double tc = fabs((-ns0) * Et[c] + ((-ns1) * Et[3 + c] + (-ns2) * Et[6 + c]));

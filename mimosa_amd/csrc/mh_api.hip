@@ -120,8 +120,10 @@ struct mh_icp
   size_t n;
   mh_reg_config cfg;
   bool binary;
-  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm;
+  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm, d_eig;
   bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
+  double split_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // delta rotation of an open mh_icp_linearize_begin
+  bool split_open = false;
   mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly
   mh::DeviceResult * d_h_results = nullptr;  // its device-side address
   PendingCall pending[kMaxPending];
@@ -653,6 +655,7 @@ void mh_icp_destroy(mh_icp * icp)
   icp->d_result.release();
   icp->d_dbg.release();
   icp->d_perm.release();
+  icp->d_eig.release();
   if (icp->h_results) (void)hipHostFree(icp->h_results);
   if (icp->events_ready)
     for (auto & ev : icp->events)
@@ -733,6 +736,7 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   mh::LocArgs l;
   l.src = a.src;
   l.host_result = nullptr;  // set below once the slot is known
+  l.eig = nullptr;
   l.n = a.n;
   std::memcpy(l.R, a.R, sizeof(l.R));
   l.normal = a.normal;
@@ -795,6 +799,61 @@ int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3],
   const int rc = mh_icp_linearize_async(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out);
   if (rc != MH_OK) return rc;
   return mh_icp_wait(icp);
+}
+
+// ---- two-phase form for map-sharded factors (mimosa_amd/dist.py): the Hessian sums of all shards are
+// all-reduced between the two phases and the component-localizability pass runs in the GLOBAL eigenbasis.
+int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
+{
+  if (!icp || !partial) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin: NULL argument");
+  if (icp->n_pending) return fail(icp->ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin: calls in flight");
+  const int rc = mh_icp_linearize(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial);
+  if (rc != MH_OK) return rc;
+  std::memcpy(icp->split_R, icp->pending[0].R, sizeof(icp->split_R));
+  icp->split_open = true;
+  return MH_OK;
+}
+
+int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
+                            double loc_rot_comp[3], int32_t status_hist[9])
+{
+  if (!icp || !eigvec_rot || !eigvec_trans || !loc_trans_comp || !loc_rot_comp)
+    return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (!icp->split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish: no mh_icp_linearize_begin before");
+  icp->split_open = false;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < 3; ++i) loc_trans_comp[i] = loc_rot_comp[i] = 0.0;
+  if (status_hist) std::memset(status_hist, 0, 9 * sizeof(int32_t));
+  if (icp->n == 0) return MH_OK;
+  double e18[18];
+  std::memcpy(e18, eigvec_rot, 72);
+  std::memcpy(e18 + 9, eigvec_trans, 72);
+  MH_HIP(ctx, icp->d_eig.reserve(sizeof(e18), ctx->stream, false));
+  MH_HIP(ctx, hipMemcpyAsync(icp->d_eig.p, e18, sizeof(e18), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // e18 is a stack buffer
+  mh::LocArgs l;
+  l.host_result = icp->d_h_results;  // slot 0
+  l.eig = static_cast<const double *>(icp->d_eig.p);
+  l.src = static_cast<const float4 *>(icp->d_src.p);
+  l.n = static_cast<int>(icp->n);
+  std::memcpy(l.R, icp->split_R, sizeof(l.R));
+  l.normal = static_cast<const double *>(icp->d_normal.p);
+  l.status = static_cast<const int32_t *>(icp->d_status.p);
+  l.partials = static_cast<double *>(icp->d_partials.p);
+  l.ticket = static_cast<unsigned int *>(icp->d_ticket.p) + 1;
+  l.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
+  MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const mh::DeviceResult & d = icp->h_results[0];
+  for (int i = 0; i < 3; ++i) {
+    loc_trans_comp[i] = d.loc_comp[i];
+    loc_rot_comp[i] = d.loc_comp[3 + i];
+  }
+  if (status_hist)
+    for (int i = 0; i < 9; ++i) status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
+  return MH_OK;
 }
 
 int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals)

@@ -112,9 +112,12 @@ class ShardedICP:
         return local
 
     def linearize(self, R, t, device=None):
-        """Local linearize + C3 all-reduce of H, b, f, histogram and counters."""
+        """Local linearize + C3 all-reduce of H, b, f, histogram and counters; when the backend offers the
+        two-phase form (mh_icp_linearize_begin / _finish) the component localizabilities are computed in
+        the GLOBAL eigenbasis and all-reduced too."""
         import torch
-        r = self.factor.linearize(R, t)
+        two_phase = hasattr(self.factor, "linearize_begin")
+        r = self.factor.linearize_begin(R, t) if two_phase else self.factor.linearize(R, t)
         n_knn = float(r["n_knn"])
         vec = np.concatenate([np.asarray(r["H_ss"], float).ravel(), np.asarray(r["b_s"], float), [float(r["f"])],
                               np.asarray(r["status_hist"], float), [n_knn, float(r["mean_candidates"]) * n_knn]])
@@ -123,5 +126,19 @@ class ShardedICP:
             tv = tv.to(device)
         self.dist.all_reduce(tv, op=self.dist.ReduceOp.SUM, group=self.comm)
         v = tv.cpu().numpy()
-        return dict(H_ss=v[:36].reshape(6, 6), b_s=v[36:42], f=float(v[42]), status_hist=v[43:52].astype(np.int64),
+        extra = {}
+        if two_phase:
+            H = v[:36].reshape(6, 6)
+            wr, Er = np.linalg.eigh(H[:3, :3])
+            wt, Et = np.linalg.eigh(H[3:, 3:])
+            tc, rc, _ = self.factor.linearize_finish(Er, Et)
+            lv = torch.from_numpy(np.concatenate([tc, rc]))
+            if device is not None:
+                lv = lv.to(device)
+            self.dist.all_reduce(lv, op=self.dist.ReduceOp.SUM, group=self.comm)
+            lv = lv.cpu().numpy()
+            with np.errstate(invalid="ignore"):
+                extra = dict(loc_trans_comp=lv[:3], loc_rot_comp=lv[3:], eigvec_rot=Er, eigvec_trans=Et,
+                             loc_rot_final=np.sqrt(wr), loc_trans_final=np.sqrt(wt))
+        return dict(**extra, H_ss=v[:36].reshape(6, 6), b_s=v[36:42], f=float(v[42]), status_hist=v[43:52].astype(np.int64),
                     n_knn=int(v[52]), mean_candidates=(v[53] / v[52] if v[52] else 0.0), n_local=self.n_local)
