@@ -254,3 +254,79 @@ def test_two_phase_linearize_matches_single_call(ctx, small_world):
     a = np.abs(-ns @ Et); a[a < 0.5] = 0
     b = np.abs(Lrot @ Er); b[b < 0.5] = 0
     assert rel(tc, a.sum(0)) <= 1e-10 and rel(rc, b.sum(0)) <= 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 63, 511, 513, 1000])
+def test_ragged_cloud_sizes(ctx, small_world, n):
+    """Cloud sizes around the 512-thread workgroup / 64-lane wave boundaries."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+    w = dict(small_world, pts=small_world["pts"][:n])
+    gm, rm, gf, rf = _mk(ctx, w)
+    g, r = gf.linearize(w["R"], w["t"]), rf.linearize(w["R"], w["t"])
+    assert np.array_equal(g["status_hist"], r["status_hist"]) and g["status_hist"].sum() == n
+    if r["status_hist"][8] >= 6:
+        assert_result_parity(g, r)
+    assert_state_parity(gf.state(), rf.state())
+
+
+@pytest.mark.parametrize("shift,leaf", [((1000.0, -512.0, 37.0), 0.5), ((-3.3, -7.7, -2.2), 0.5), ((0.0, 0.0, 0.0), 0.3),
+                                        ((250.0, 250.0, -20.0), 0.37)])
+def test_far_origin_negative_coords_and_odd_leaf(ctx, small_world, shift, leaf):
+    """The coarse tier works in voxel-relative grid units, so selection must stay exact 1 km from the
+    origin, across negative coordinates (floor, arithmetic block shifts, hash of negatives) and for leaf
+    sizes whose inverse is not exactly representable."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+    sh = np.array(shift)
+    m = (small_world["map_xyz"].astype(np.float64) + sh).astype(np.float32)
+    cfg = dict(small_world["cfg"], target_ivox_map_leaf_size=leaf)
+    gm = capi.VoxelMap(ctx, leaf=leaf)
+    rm = ref_cpu.Map(leaf=leaf)
+    gm.insert(m)
+    rm.insert(m)
+    assert gm.stats()["n_points"] == rm.num_points and gm.stats()["n_voxels"] == rm.num_voxels
+    gf = capi.ICPFactor(ctx, gm, small_world["pts"], capi.make_reg_config(**cfg))
+    rf = ref_cpu.ICP(rm, small_world["pts"], ref_cpu.make_config(**cfg))
+    R, t = small_world["R"], small_world["t"] + sh
+    g, r = gf.linearize(R, t), rf.linearize(R, t)
+    assert_result_parity(g, r)
+    assert_state_parity(gf.state(), rf.state(), tol=1e-9 * max(1.0, np.abs(sh).max()))
+    # batched k-NN: bit-identical distances and neighbours
+    rng = np.random.default_rng(9)
+    q = m[rng.integers(0, len(m), 300)].astype(np.float64) + rng.normal(0, 0.1, (300, 3))
+    pts, sq, found = gm.knn(q, 5)
+    idx, sq_r, found_r, _ = rm.knn(q, 5)
+    assert np.array_equal(found, found_r)
+    for i in range(len(q)):
+        assert np.array_equal(sq[i, : found[i]], sq_r[i, : found[i]])
+
+
+def test_saturated_voxels_and_duplicates(ctx):
+    """Voxels at the 20-point cap, exact duplicate points (rejected by the min-distance rule) and exact
+    distance ties (two map points symmetric about a query): the earlier-traversed one must win."""
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+    rng = np.random.default_rng(4)
+    dense = rng.uniform(0, 0.5, (400, 3)).astype(np.float32)           # one voxel, far more than 20 candidates
+    dup = np.repeat(np.array([[1.25, 0.25, 0.25]], np.float32), 5, 0)  # duplicates
+    sym = np.array([[2.0, 0.25, 0.25], [2.5, 0.25, 0.25], [2.25, 0.0, 0.25], [2.25, 0.5 - 2**-20, 0.25],
+                    [2.25, 0.25, 0.1], [2.25, 0.25, 0.4]], np.float32)  # +-0.25 pairs around (2.25, 0.25, 0.25)
+    m = np.concatenate([dense, dup, sym])
+    gm = capi.VoxelMap(ctx, min_dist=0.02)
+    rm = ref_cpu.Map(min_dist=0.02)
+    gm.insert(m)
+    rm.insert(m)
+    s = gm.stats()
+    assert s["n_points"] == rm.num_points and s["n_voxels"] == rm.num_voxels
+    _, counts, xyz = rm.export()
+    assert counts.max() == 20 and np.array_equal(gm.get_cloud(), xyz)
+    q = np.array([[2.25, 0.25, 0.25], [0.25, 0.25, 0.25], [1.25, 0.25, 0.25], [2.25, 0.25, 0.2500001]])
+    for k in (1, 2, 5, 8):
+        pts, sq, found = gm.knn(q, k)
+        idx, sq_r, found_r, _ = rm.knn(q, k)
+        assert np.array_equal(found, found_r)
+        for i in range(len(q)):
+            assert np.array_equal(sq[i, : found[i]], sq_r[i, : found[i]])
+            for j in range(found[i]):
+                assert np.array_equal(pts[i, j], rm.point(idx[i, j])), (k, i, j)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel trace + stats of the default bench command, then the HBM-traffic
 # PMC passes (each in its own run, kernel-trace only, each under its own timeout).
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
