@@ -43,6 +43,9 @@ def parse():
                     help="independent scans in flight on separate HIP streams (contexts) sharing the map")
     ap.add_argument("--concurrent-streams", type=int, default=4,
                     help="size of the extra aggregate-throughput pass reported as value_concurrent (0/1 = skip)")
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="only the warm-up and the timed region (what rocprofv3 should see): no latency, "
+                         "re-linearization, PCIe, concurrent or CPU-baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
     return ap.parse_args()
@@ -147,23 +150,26 @@ def main():
     # synchronous per-call latency (result on the host before the next call), events off
     for c in ctxs:
         c.set_profiling(False)
+    if args.profile_mode:
+        args.no_cpu_baseline, args.concurrent_streams = True, 0
     lat = []
-    for _ in range(min(50, max(10, args.steps // 4))):
+    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
         factor.reset()
         ctx.synchronize()
         a = time.perf_counter()
         factor.linearize(R, t)
         lat.append(time.perf_counter() - a)
-    lat_ms = float(np.median(lat) * 1e3)
+    lat_ms = float(np.median(lat) * 1e3) if lat else float("nan")
 
     # The second caller of the path: GTSAM re-linearization (src/graph/manager.cpp:585-588).  The pose moved
     # < min_dist/4, so every point takes the data-association cache branch (geometric_factor.hpp:308-317):
     # no k-NN, cached plane, residual + Jacobian + reduction only.
     ctx.set_profiling(True)
-    factor.reset()
-    factor.linearize(R, t)
     relin_k3, relin_wall = [], []
-    for i in range(30):
+    if not args.profile_mode:
+        factor.reset()
+        factor.linearize(R, t)
+    for i in range(0 if args.profile_mode else 30):
         dt = np.array([1e-3, -5e-4, 2e-4]) * ((i % 3) - 1)
         ctx.synchronize()
         a = time.perf_counter()
@@ -176,21 +182,22 @@ def main():
     # PCIe-inclusive figure: the boundary hands over HOST buffers, so a scan costs a factor creation
     # (4 MiB upload + pack + Morton sort) before its first linearize.  Reported, never the headline.
     cre = []
-    for _ in range(5):
+    for _ in range(0 if args.profile_mode else 5):
         ctx.synchronize()
         a = time.perf_counter()
         f2 = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
         f2.linearize(R, t)
         cre.append(time.perf_counter() - a)
         f2.destroy()
-    create_plus_lin_ms = float(np.median(cre) * 1e3)
+    create_plus_lin_ms = float(np.median(cre) * 1e3) if cre else float("nan")
 
     # untimed-by-events pipelined pass (how much the event records cost)
     barrier()
     a = time.perf_counter()
-    run_steps(args.steps)
+    if not args.profile_mode:
+        run_steps(args.steps)
     barrier()
-    elapsed_noev = time.perf_counter() - a
+    elapsed_noev = max(time.perf_counter() - a, 1e-9)
 
     # Aggregate throughput with several independent scans in flight (own HIP streams, shared map): a single
     # 131 072-point scan can only put 2 waves on a SIMD, concurrent scans fill the machine.
@@ -282,9 +289,9 @@ def main():
         "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
         "value_concurrent": conc,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
-                        "kernel_ms": round(float(np.median(relin_k3)), 5),
-                        "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4),
-                        "value_sync": round(n_pts / float(np.median(relin_wall)) / 1e6, 1)},
+                        "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
+                        "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,
+                        "value_sync": round(n_pts / float(np.median(relin_wall)) / 1e6, 1) if relin_wall else None},
         "value_pcie_inclusive": round(n_pts / (create_plus_lin_ms * 1e-3) / 1e6, 2),
         "create_plus_linearize_ms": round(create_plus_lin_ms, 4),
         "setup_s": round(setup_s, 2),
