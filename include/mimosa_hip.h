@@ -96,6 +96,8 @@ typedef struct mh_map_stats {
   int64_t device_bytes;      /* HBM held by this map */
   int64_t uploads;           /* number of host->device synchronisations so far */
   int64_t upload_bytes;      /* total bytes pushed host->device */
+  int64_t delta_uploads;     /* synchronisations that moved only the touched buckets / cells / new ranges */
+  int64_t full_uploads;      /* synchronisations that re-sent the whole mirror (first one, after an LRU purge, mass edits) */
 } mh_map_stats;
 
 /*
@@ -161,6 +163,9 @@ int mh_map_copy(const mh_map * map, mh_map ** out);
 /* shared_ptr semantics: factors retain the map they were built with. */
 int mh_map_retain(mh_map * map);
 void mh_map_release(mh_map * map);
+/* Pushes pending inserts to the device mirror now (otherwise done lazily by the next linearize / knn):
+ * only the touched buckets, cell words and appended ranges travel unless the voxels were renumbered. */
+int mh_map_sync(mh_map * map);
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out);
 /* IncrementalVoxelMapPCL::getCloud (incremental_voxel_map.cpp:34-38): all points in voxel order.
  * xyz may be NULL to query the size; returns the number of points through n_out. */

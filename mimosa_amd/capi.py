@@ -20,7 +20,7 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 EXPORTS = [
     "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
-    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_get_stats",
+    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
@@ -62,7 +62,8 @@ class MapConfig(C.Structure):
 
 
 class MapStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("n_voxels", "n_points", "n_blocks", "device_bytes", "uploads", "upload_bytes")]
+    _fields_ = [(n, C.c_int64) for n in ("n_voxels", "n_points", "n_blocks", "device_bytes", "uploads", "upload_bytes",
+                                         "delta_uploads", "full_uploads")]
 
 
 class IcpResult(C.Structure):
@@ -133,6 +134,7 @@ def load(build_if_missing: bool = True):
     L.mh_map_retain.argtypes = [vp]
     L.mh_map_release.argtypes = [vp]
     L.mh_map_release.restype = None
+    L.mh_map_sync.argtypes = [vp]
     L.mh_map_get_stats.argtypes = [vp, C.POINTER(MapStats)]
     L.mh_map_get_cloud.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.mh_map_knn.argtypes = [vp, vp, sz, i32, vp, vp, vp]
@@ -247,6 +249,9 @@ class VoxelMap:
         h = C.c_void_p()
         self.ctx.check(self.L.mh_map_copy(self.h, C.byref(h)))
         return VoxelMap(self.ctx, _h=h)
+
+    def sync(self):
+        self.ctx.check(self.L.mh_map_sync(self.h))
 
     def stats(self) -> dict:
         s = MapStats()

@@ -109,7 +109,7 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_blocks)
 #define MH_STAMP(ptr, i)                                                                       \
   do {                                                                                         \
     if ((ptr) && (threadIdx.x & 63) == 0)                                                      \
-      (ptr)[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 8 + (i)] = \
+      (ptr)[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16 + (i)] = \
         __builtin_amdgcn_s_memtime();                                                          \
   } while (0)
 #else
@@ -216,6 +216,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       blk[s * lds_stride] = id;
     }
   }
+  MH_STAMP(dbg, 8);
   constexpr int m = kBlockDim - 1;
   // NOFF (7 / 19 / 27) is a template parameter and nothing below branches: every lookup of the
   // neighbourhood is straight-line code, so the block-id LDS reads and then all cell loads are
@@ -240,6 +241,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       cell[o] = (cblk[o] >= 0 && o < map.n_off) ? cv : kEmptyCell;
     }
   }
+#ifdef MH_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the cell-load latency to this stamp
+#endif
+  MH_STAMP(dbg, 9);
   // Every cell word goes to LDS slot o (no compaction); which voxels get scanned is a bit mask, and
   // their point counts are packed into registers (5 bits each, 12 per word) so the scan cursor never
   // reads memory.
@@ -315,6 +320,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     }
     amask &= ~(1u << kCenter);
   }
+  MH_STAMP(dbg, 10);
   // ---- prune: drop neighbour voxels that provably hold no top-k point ----------------------------
   {
     uint32_t kth = 0xFFFFFFFFu;
@@ -346,6 +352,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     }
   }
 
+  MH_STAMP(dbg, 11);
   // ---- B2. remaining voxels: flattened, software-pipelined coarse scan over QUADS of candidates ---
   // The (voxel, quad) cursor walks the active-bit mask in registers kPipe quads ahead of the
   // arithmetic; every load is unconditional (quad 0 of voxel 0 past the end), validity is a select.
@@ -452,6 +459,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       }
     }
   }
+  MH_STAMP(dbg, 12);
   dk = kDblMax;
 #pragma unroll
   for (int i = 0; i < K; ++i)

@@ -92,7 +92,11 @@ struct mh_map
   mh_ctx * ctx;
   std::atomic<int> refs{1};
   mh::HostVoxelMap host;
-  DevBuf d_table, d_cells, d_buckets, d_qbuckets;
+  DevBuf d_table, d_cells, d_buckets, d_qbuckets, d_stage;
+  // what the device mirror currently holds (delta uploads append / scatter relative to this)
+  bool dev_valid = false;
+  size_t dev_n_voxels = 0, dev_n_blocks = 0, dev_table_cap = 0;
+  int64_t delta_uploads = 0, full_uploads = 0;
   bool device_stale = true;
   int64_t uploads = 0, upload_bytes = 0;
   int n_off = 0;
@@ -142,27 +146,91 @@ int map_sync_device(mh_map * m)
   if (!m->device_stale) return MH_OK;
   mh_ctx * ctx = m->ctx;
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  const auto & H = m->host;
+  auto & H = m->host;
   const size_t tb = H.table().size() * sizeof(mh::Int4);
   const size_t cb = H.cells().size() * sizeof(uint32_t);
   const size_t bb = H.buckets().size() * sizeof(mh::Float4);
   const size_t qb = H.qbuckets().size() * sizeof(uint32_t);
-  // Factors on this context may still be reading the old buffers: drain before (re)allocating.
+  // Factors on this context may still be reading the buffers: drain before touching them.
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const bool rebuilt = H.take_full_rebuild();  // LRU purge renumbered the voxels
+  const size_t n_dirty = H.dirty_voxels().size();
+  const bool delta = m->dev_valid && !rebuilt && n_dirty * 4 < H.n_voxels() + 1024;
+  const bool keep = delta;
   MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
-  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, false));
-  MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, false));
-  MH_HIP(ctx, m->d_qbuckets.reserve(qb ? qb : 80, ctx->stream, false));
-  MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
-  if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
-  if (bb) MH_HIP(ctx, hipMemcpyAsync(m->d_buckets.p, H.buckets().data(), bb, hipMemcpyHostToDevice, ctx->stream));
-  if (qb) MH_HIP(ctx, hipMemcpyAsync(m->d_qbuckets.p, H.qbuckets().data(), qb, hipMemcpyHostToDevice, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  m->host.clear_dirty();
-  m->host.take_full_rebuild();
+  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, keep));
+  MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, keep));
+  MH_HIP(ctx, m->d_qbuckets.reserve(qb ? qb : 80, ctx->stream, keep));
+  int64_t moved = 0;
+  if (!delta) {
+    MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
+    if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
+    if (bb) MH_HIP(ctx, hipMemcpyAsync(m->d_buckets.p, H.buckets().data(), bb, hipMemcpyHostToDevice, ctx->stream));
+    if (qb) MH_HIP(ctx, hipMemcpyAsync(m->d_qbuckets.p, H.qbuckets().data(), qb, hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    moved = static_cast<int64_t>(tb + cb + bb + qb);
+    m->full_uploads++;
+  } else {
+    // (1) block table: only when blocks were added (or it was rehashed)
+    if (H.n_blocks() != m->dev_n_blocks || H.table().size() != m->dev_table_cap) {
+      MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
+      moved += static_cast<int64_t>(tb);
+    }
+    // (2) appended ranges: cells of new blocks, buckets of new voxels
+    if (H.n_blocks() > m->dev_n_blocks) {
+      const size_t o = m->dev_n_blocks * mh::kCellsPerBlock, n = (H.n_blocks() - m->dev_n_blocks) * mh::kCellsPerBlock;
+      MH_HIP(ctx, hipMemcpyAsync(static_cast<uint32_t *>(m->d_cells.p) + o, H.cells().data() + o, n * sizeof(uint32_t),
+                                 hipMemcpyHostToDevice, ctx->stream));
+      moved += static_cast<int64_t>(n * sizeof(uint32_t));
+    }
+    if (H.n_voxels() > m->dev_n_voxels) {
+      const size_t o = m->dev_n_voxels * mh::kBucketStride, n = (H.n_voxels() - m->dev_n_voxels) * mh::kBucketStride;
+      MH_HIP(ctx, hipMemcpyAsync(static_cast<mh::Float4 *>(m->d_buckets.p) + o, H.buckets().data() + o, n * sizeof(mh::Float4),
+                                 hipMemcpyHostToDevice, ctx->stream));
+      MH_HIP(ctx, hipMemcpyAsync(static_cast<uint32_t *>(m->d_qbuckets.p) + o, H.qbuckets().data() + o, n * sizeof(uint32_t),
+                                 hipMemcpyHostToDevice, ctx->stream));
+      moved += static_cast<int64_t>(n * (sizeof(mh::Float4) + sizeof(uint32_t)));
+    }
+    // (3) scatter: buckets of touched OLD voxels, cell words of every touched voxel that lives in an old block
+    std::vector<mh::MapScatterRecord> recs;
+    std::vector<uint2> cellu;
+    for (const uint32_t vid : H.dirty_voxels()) {
+      const uint32_t ci = H.voxel_cell_index(vid);
+      if (ci < m->dev_n_blocks * mh::kCellsPerBlock) cellu.push_back(make_uint2(ci, H.cells()[ci]));
+      if (vid < m->dev_n_voxels) {
+        mh::MapScatterRecord r;
+        r.vid = vid;
+        r.n_pts = H.counts()[vid];
+        r.pad0 = r.pad1 = 0;
+        std::memcpy(r.pts, &H.buckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.pts));
+        std::memcpy(r.q, &H.qbuckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.q));
+        recs.push_back(r);
+      }
+    }
+    if (!recs.empty() || !cellu.empty()) {
+      const size_t rb = recs.size() * sizeof(mh::MapScatterRecord), ub = cellu.size() * sizeof(uint2);
+      const size_t rb_al = (rb + 15) & ~size_t(15);
+      MH_HIP(ctx, m->d_stage.reserve(rb_al + ub + 16, ctx->stream, false));
+      char * st = static_cast<char *>(m->d_stage.p);
+      if (rb) MH_HIP(ctx, hipMemcpyAsync(st, recs.data(), rb, hipMemcpyHostToDevice, ctx->stream));
+      if (ub) MH_HIP(ctx, hipMemcpyAsync(st + rb_al, cellu.data(), ub, hipMemcpyHostToDevice, ctx->stream));
+      MH_HIP(ctx, mh::launch_map_scatter(reinterpret_cast<const mh::MapScatterRecord *>(st), static_cast<int>(recs.size()),
+                                         static_cast<float4 *>(m->d_buckets.p), static_cast<uint32_t *>(m->d_qbuckets.p),
+                                         reinterpret_cast<const uint2 *>(st + rb_al), static_cast<int>(cellu.size()),
+                                         static_cast<uint32_t *>(m->d_cells.p), ctx->stream));
+      moved += static_cast<int64_t>(rb + ub);
+    }
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // recs / cellu are stack-owned
+    m->delta_uploads++;
+  }
+  H.clear_dirty();
   m->device_stale = false;
+  m->dev_valid = true;
+  m->dev_n_voxels = H.n_voxels();
+  m->dev_n_blocks = H.n_blocks();
+  m->dev_table_cap = H.table().size();
   m->uploads++;
-  m->upload_bytes += static_cast<int64_t>(tb + cb + bb + qb);
+  m->upload_bytes += moved;
   return MH_OK;
 }
 
@@ -427,6 +495,28 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
   if (!map) return fail(src->ctx, MH_ERR_OOM, "mh_map_copy: host allocation failed");
   map->host = src->host;  // deep copy of the flat arrays
   map->device_stale = true;
+  if (src->dev_valid) {
+    // the device mirror is copied device-to-device (what it held at the source's last sync); the host
+    // copy carries the source's pending dirty list, so the next sync of the copy is a delta on top
+    mh_ctx * ctx = src->ctx;
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    auto dup = [&](const DevBuf & a, DevBuf & b) -> hipError_t {
+      if (!a.cap) return hipSuccess;
+      hipError_t e = b.reserve(a.cap, ctx->stream, false);
+      if (e != hipSuccess) return e;
+      return hipMemcpyAsync(b.p, a.p, a.cap, hipMemcpyDeviceToDevice, ctx->stream);
+    };
+    MH_HIP(ctx, dup(src->d_table, map->d_table));
+    MH_HIP(ctx, dup(src->d_cells, map->d_cells));
+    MH_HIP(ctx, dup(src->d_buckets, map->d_buckets));
+    MH_HIP(ctx, dup(src->d_qbuckets, map->d_qbuckets));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    map->dev_valid = true;
+    map->dev_n_voxels = src->dev_n_voxels;
+    map->dev_n_blocks = src->dev_n_blocks;
+    map->dev_table_cap = src->dev_table_cap;
+    map->device_stale = src->device_stale;
+  }
   *out = map;
   return MH_OK;
 }
@@ -448,8 +538,15 @@ void mh_map_release(mh_map * map)
     map->d_cells.release();
     map->d_buckets.release();
     map->d_qbuckets.release();
+    map->d_stage.release();
     delete map;
   }
+}
+
+int mh_map_sync(mh_map * map)
+{
+  if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_sync: map is NULL");
+  return map_sync_device(map);
 }
 
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
@@ -461,6 +558,8 @@ int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
   out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap + map->d_qbuckets.cap);
   out->uploads = map->uploads;
   out->upload_bytes = map->upload_bytes;
+  out->delta_uploads = map->delta_uploads;
+  out->full_uploads = map->full_uploads;
   return MH_OK;
 }
 
@@ -516,7 +615,7 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_ticket.reserve(2 * sizeof(unsigned int), ctx->stream, false));
   MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
 #ifdef MH_TIMELINE
-  MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 8 * sizeof(unsigned long long), ctx->stream, false));
+  MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 16 * sizeof(unsigned long long), ctx->stream, false));
   MH_HIP(ctx, hipMemsetAsync(icp->d_dbg.p, 0, icp->d_dbg.cap, ctx->stream));
 #endif
   MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending,
@@ -572,7 +671,9 @@ int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t 
       MH_HIP(ctx, hipMalloc(&d_vals, n * sizeof(uint32_t)));
       MH_HIP(ctx, hipMalloc(&d_temp, tb ? tb : 16));
       MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, 0.25f, d_keys, d_vals, d_temp, tb,
+      float cell = 0.25f;
+      if (const char * cs = std::getenv("MH_SORT_CELL")) cell = static_cast<float>(std::atof(cs));
+      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, cell, d_keys, d_vals, d_temp, tb,
                                            static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
                                            ctx->stream));
       MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -672,7 +773,7 @@ int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_word
 {
   if (!icp || !out || !n_words) return MH_ERR_INVALID_ARG;
   mh_ctx * ctx = icp->ctx;
-  const size_t words = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 8;
+  const size_t words = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 16;
   *n_words = words;
   if (capacity_words < words) return MH_ERR_INVALID_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));

@@ -113,6 +113,16 @@ public:
     rehash_blocks(1024);
   }
 
+  // Copy with growth headroom: a plain vector copy has capacity == size, so the first voxel created in the
+  // copy (Geometric::updateMap inserts right after copying, geometric.cpp:494-495) would reallocate and
+  // move the whole bucket array again.
+  HostVoxelMap(const HostVoxelMap & o) { copy_from(o); }
+  HostVoxelMap & operator=(const HostVoxelMap & o)
+  {
+    if (this != &o) copy_from(o);
+    return *this;
+  }
+
   const mh_map_config & config() const { return cfg_; }
   double inv_leaf() const { return inv_leaf_; }
   size_t n_voxels() const { return vox_count_.size(); }
@@ -124,6 +134,7 @@ public:
   const std::vector<Float4> & buckets() const { return buckets_; }
   const std::vector<uint32_t> & qbuckets() const { return qbuckets_; }
   const std::vector<uint8_t> & counts() const { return vox_count_; }
+  uint32_t voxel_cell_index(uint32_t vid) const { return vox_cell_[vid]; }
 
   // Dirty tracking for the device mirror.
   bool structure_changed() const { return structure_changed_; }
@@ -326,6 +337,39 @@ private:
     }
     structure_changed_ = true;
     full_rebuild_ = true;
+  }
+
+  template <typename T>
+  static void copy_with_headroom(std::vector<T> & dst, const std::vector<T> & src)
+  {
+    std::vector<T> v;
+    v.reserve(src.size() + src.size() / 8 + 4096);
+    v.assign(src.begin(), src.end());
+    dst.swap(v);
+  }
+  void copy_from(const HostVoxelMap & o)
+  {
+    cfg_ = o.cfg_;
+    inv_leaf_ = o.inv_leaf_;
+    min_sq_ = o.min_sq_;
+    lru_counter_ = o.lru_counter_;
+    n_points_ = o.n_points_;
+    copy_with_headroom(vox_coord_, o.vox_coord_);
+    copy_with_headroom(vox_count_, o.vox_count_);
+    copy_with_headroom(vox_lru_, o.vox_lru_);
+    copy_with_headroom(vox_cell_, o.vox_cell_);
+    copy_with_headroom(buckets_, o.buckets_);
+    copy_with_headroom(qbuckets_, o.qbuckets_);
+    n_blocks_ = o.n_blocks_;
+    copy_with_headroom(block_coord_, o.block_coord_);
+    copy_with_headroom(cells_, o.cells_);
+    table_ = o.table_;
+    table_mask_ = o.table_mask_;
+    last_block_ = -1;
+    copy_with_headroom(dirty_flag_, o.dirty_flag_);
+    dirty_ = o.dirty_;
+    structure_changed_ = o.structure_changed_;
+    full_rebuild_ = o.full_rebuild_;
   }
 
 public:

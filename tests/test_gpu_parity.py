@@ -330,3 +330,54 @@ def test_saturated_voxels_and_duplicates(ctx):
             assert np.array_equal(sq[i, : found[i]], sq_r[i, : found[i]])
             for j in range(found[i]):
                 assert np.array_equal(pts[i, j], rm.point(idx[i, j])), (k, i, j)
+
+
+def test_keyframe_update_copy_then_insert_is_a_delta(ctx, small_world):
+    """Geometric::updateMap's copy-then-insert (geometric.cpp:494-495): the copy's mirror is duplicated
+    device-to-device and only the touched buckets / cells / appended ranges are uploaded; the old map (held
+    by live factors) is untouched; contents stay identical to the oracle's."""
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+    m = small_world["map_xyz"]
+    ga, ra = capi.VoxelMap(ctx), ref_cpu.Map()
+    ga.insert(m)
+    ra.insert(m)
+    ga.sync()
+    assert ga.stats()["full_uploads"] == 1
+    rng = np.random.default_rng(12)
+    q = m[rng.integers(0, len(m), 400)].astype(np.float64) + rng.normal(0, 0.1, (400, 3))
+    # keyframe cloud: re-observes part of the room (touches existing voxels) and adds a new region
+    # (new voxels in old blocks, new blocks, a rehash-free table update)
+    kf = np.concatenate([m[::7] + np.float32(0.07), (m[:600] + np.array([7.5, 0.0, 0.0], np.float32))])
+    gb, rb = ga.copy(), ra.copy()
+    gb.insert(kf)
+    rb.insert(kf)
+    before = gb.stats()
+    gb.sync()
+    st = gb.stats()
+    assert st["delta_uploads"] == 1 and st["full_uploads"] == 0
+    assert st["upload_bytes"] - before["upload_bytes"] < 0.6 * st["device_bytes"]
+    assert st["n_points"] == rb.num_points and st["n_voxels"] == rb.num_voxels
+    q2 = np.concatenate([q, kf[-200:].astype(np.float64) + 0.03])
+    for gm_, rm_ in ((gb, rb), (ga, ra)):  # the new map AND the untouched old one
+        pts, sq, found = gm_.knn(q2, 5)
+        idx, sq_r, found_r, _ = rm_.knn(q2, 5)
+        assert np.array_equal(found, found_r)
+        for i in range(len(q2)):
+            assert np.array_equal(sq[i, : found[i]], sq_r[i, : found[i]])
+    assert np.array_equal(gb.get_cloud(), rb.export()[2]) and np.array_equal(ga.get_cloud(), ra.export()[2])
+    # a second, tiny keyframe: a handful of records travel
+    kf2 = m[:50] + np.float32(0.11)
+    gb.insert(kf2)
+    rb.insert(kf2)
+    b0 = gb.stats()["upload_bytes"]
+    gb.sync()
+    assert gb.stats()["upload_bytes"] - b0 < 64 * 1024
+    pts, sq, found = gb.knn(q2, 5)
+    idx, sq_r, found_r, _ = rb.knn(q2, 5)
+    assert np.array_equal(found, found_r) and all(np.array_equal(sq[i, : found[i]], sq_r[i, : found[i]]) for i in range(len(q2)))
+    # linearize on the updated map matches the oracle
+    cfg = small_world["cfg"]
+    gf = capi.ICPFactor(ctx, gb, small_world["pts"], capi.make_reg_config(**cfg))
+    rf = ref_cpu.ICP(rb, small_world["pts"], ref_cpu.make_config(**cfg))
+    assert_result_parity(gf.linearize(small_world["R"], small_world["t"]), rf.linearize(small_world["R"], small_world["t"]))

@@ -33,10 +33,10 @@ for _ in range(5):
     f.reset()
     r = f.linearize(R, t)
 n = C.c_size_t()
-buf = np.zeros(8 * 8 * 4096, np.uint64)
+buf = np.zeros(8 * 16 * 4096, np.uint64)
 rc = L.mh_icp_timeline(f.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n))
 assert rc == 0, rc
-T = buf[: n.value].reshape(-1, 8).astype(np.int64)
+T = buf[: n.value].reshape(-1, 16).astype(np.int64)
 blk = np.arange(len(T)) // 8
 live = T[:, 0] > 0
 T, blk = T[live], blk[live]
@@ -49,6 +49,14 @@ def stat(name, x):
 
 
 stat("A: lookup + list (0->1)", T[:, 1] - T[:, 0])
+stat("   A.1 transform + 8 probes (0->8)", T[:, 8] - T[:, 0])
+stat("   A.2 cell loads arrived (8->9)", T[:, 9] - T[:, 8])
+stat("   A.3 mask/pack/LDS list (9->1)", T[:, 1] - T[:, 9])
+stat("   B.1 centre voxel scan (1->10)", T[:, 10] - T[:, 1])
+stat("   B.2 prune (10->11)", T[:, 11] - T[:, 10])
+stat("   B.3 neighbour scan (11->2)", T[:, 2] - T[:, 11])
+stat("   C.1 exact tier (2->12)", T[:, 12] - T[:, 2])
+stat("   C.2 proof+plane+residual+stores (12->3)", T[:, 3] - T[:, 12])
 stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
 stat("C: plane/residual (2->3)", T[:, 3] - T[:, 2])
 stat("barrier wait (3->4)", T[:, 4] - T[:, 3])
