@@ -64,6 +64,7 @@ struct LocArgs
   const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = use result->eig_* from K3
   const float4 * src;
   int n;
+  int chunks_per_block;  // set by the launcher
   double R[9];
   const double * normal;
   const int32_t * status;

@@ -935,9 +935,13 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
   __shared__ double s_seg[(kThreads / 32) * 32 + 32];
   __shared__ bool s_last;
 
-  const int i = xcd_chunk(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double v[6] = {0, 0, 0, 0, 0, 0};
+  unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
+  // cost is the ticket + fold tail, which scales with the number of partial rows
+  for (int ch = 0; ch < a.chunks_per_block; ++ch) {
+  const int i = (blockIdx.x * a.chunks_per_block + ch) * kThreads + threadIdx.x;
   int st = -1;
   if (i < a.n) {
     st = a.status[i];
@@ -962,10 +966,13 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
       for (int c = 0; c < 3; ++c) {
         const double tc = fabs((-ns0) * Et[c] + ((-ns1) * Et[3 + c] + (-ns2) * Et[6 + c]));
         const double rc = fabs(r0 * Er[c] + (r1 * Er[3 + c] + r2 * Er[6 + c]));
-        v[c] = tc >= 0.5 ? tc : 0.0;      // trans components
-        v[3 + c] = rc >= 0.5 ? rc : 0.0;  // rot components
+        v[c] += tc >= 0.5 ? tc : 0.0;      // trans components
+        v[3 + c] += rc >= 0.5 ? rc : 0.0;  // rot components
       }
     }
+  }
+#pragma unroll
+  for (int h = 0; h < 9; ++h) hist[h] += static_cast<unsigned int>(__popcll(__ballot(st == h)));
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -975,10 +982,8 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
     if (lane == 0) s_w[wv][j] = s;
   }
 #pragma unroll
-  for (int h = 0; h < 9; ++h) {
-    const unsigned long long b = __ballot(st == h);
-    if (lane == 0) s_w[wv][6 + h] = static_cast<double>(__popcll(b));
-  }
+  for (int h = 0; h < 9; ++h)
+    if (lane == 0) s_w[wv][6 + h] = static_cast<double>(hist[h]);
   __syncthreads();
   if (threadIdx.x < 15) {
     double s = 0.0;
@@ -1058,7 +1063,8 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // Launchers
 // ------------------------------------------------------------------------------------------------
 int linearize_grid(int n) { return (((n + kThreads - 1) / kThreads) + 7) & ~7; }
-int localizability_grid(int n) { return linearize_grid(n); }
+constexpr int kLocChunksPerBlock = 1;  // measured: 1 vs 4 chunks per workgroup makes no difference (launch + round-trip bound)
+int localizability_grid(int n) { return (linearize_grid(n) + kLocChunksPerBlock - 1) / kLocChunksPerBlock; }
 
 template <int NOFF>
 static void launch_linearize_n(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -1088,8 +1094,10 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
   return hipGetLastError();
 }
 
-hipError_t launch_localizability(const LocArgs & a, hipStream_t stream)
+hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
+  LocArgs a = a0;
+  a.chunks_per_block = kLocChunksPerBlock;
   hipLaunchKernelGGL(icp_localizability_kernel, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
