@@ -185,61 +185,45 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   constexpr int KK = K + 3 + (K > 5 ? 1 : 0);  // survivors: 8 for k = 5, 12 for the generic k <= 8 path
   constexpr int kCenter = NOFF == 7 ? 0 : (NOFF == 19 ? 9 : 13);  // offset (0,0,0) in kNeighborOffsets
   // ---- A. neighbourhood lookup ------------------------------------------------------------------
+  // Block tables carry a one-voxel halo (voxel_map.hpp): all 27 neighbours of the centre voxel are in
+  // the table of ITS block.  One hash probe, then nine 12-byte loads (the z-triple of each (dx, dy)
+  // column) — 11 per-lane L1 transactions with the source point instead of 28.
   const int cx = fast_floor(q0 * map.inv_leaf), cy = fast_floor(q1 * map.inv_leaf), cz = fast_floor(q2 * map.inv_leaf);
-  // offsets are in {-1,0,1}: the neighbourhood touches block coordinates {b0, b0+1} per axis
-  const int bx0 = (cx - 1) >> kBlockLog2, by0 = (cy - 1) >> kBlockLog2, bz0 = (cz - 1) >> kBlockLog2;
+  constexpr int m = kBlockDim - 1;
+  const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
+  int blk_id;
   {
-    // all eight first probes are issued before any is inspected: one memory round trip, not eight
-    int4 first[8];
-    uint32_t h[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      h[s] = block_hash(bx0 + (s >> 2), by0 + ((s >> 1) & 1), bz0 + (s & 1)) & map.mask;
-      first[s] = map.table[h[s]];
+    uint32_t h = block_hash(bx, by, bz) & map.mask;
+    int4 e = map.table[h];
+    while (e.w >= 0 && !(e.x == bx && e.y == by && e.z == bz)) {  // collision: linear probe (load <= 0.5)
+      h = (h + 1) & map.mask;
+      e = map.table[h];
     }
+    blk_id = e.w;
+  }
+  (void)blk;
+  MH_STAMP(dbg, 8);
+  uint32_t col[9][3];
+  {
+    // centre word of the 3x3x3 neighbourhood inside the halo'd table; block 0 when the block is absent
+    // (the cells array always holds >= 1 table) + select below
+    const uint32_t * tab = map.cells + static_cast<size_t>(blk_id < 0 ? 0 : blk_id) * kCellsPerBlock +
+                           halo_index(cx & m, cy & m, cz & m);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int bx = bx0 + (s >> 2), by = by0 + ((s >> 1) & 1), bz = bz0 + (s & 1);
-      int id = first[s].w;
-      if (id >= 0 && !(first[s].x == bx && first[s].y == by && first[s].z == bz)) {
-        // collision: continue the linear probe (load factor <= 0.5 keeps this rare and short)
-        uint32_t hh = (h[s] + 1) & map.mask;
-        for (;;) {
-          const int4 e = map.table[hh];
-          if (e.w < 0 || (e.x == bx && e.y == by && e.z == bz)) {
-            id = e.w;
-            break;
-          }
-          hh = (hh + 1) & map.mask;
-        }
-      }
-      blk[s * lds_stride] = id;
+    for (int c = 0; c < 9; ++c) {
+      const uint32_t * p = tab + ((c / 3 - 1) * kHaloDim + (c % 3 - 1)) * kHaloDim - 1;  // (dx, dy) column, dz = -1
+      col[c][0] = p[0];
+      col[c][1] = p[1];
+      col[c][2] = p[2];
     }
   }
-  MH_STAMP(dbg, 8);
-  constexpr int m = kBlockDim - 1;
-  // NOFF (7 / 19 / 27) is a template parameter and nothing below branches: every lookup of the
-  // neighbourhood is straight-line code, so the block-id LDS reads and then all cell loads are
-  // issued back to back behind ONE wait each.
   uint32_t cell[NOFF];
-  {
-    int cblk[NOFF];
-    uint32_t cidx[NOFF];
 #pragma unroll
-    for (int o = 0; o < NOFF; ++o) {
-      const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
-      const int vx = cx + static_cast<int>(ow & 3u) - 1, vy = cy + static_cast<int>((ow >> 2) & 3u) - 1,
-                vz = cz + static_cast<int>((ow >> 4) & 3u) - 1;
-      const int slot = (((vx >> kBlockLog2) - bx0) << 2) | (((vy >> kBlockLog2) - by0) << 1) | ((vz >> kBlockLog2) - bz0);
-      cblk[o] = blk[slot * lds_stride];
-      cidx[o] = static_cast<uint32_t>(((vx & m) << (2 * kBlockLog2)) | ((vy & m) << kBlockLog2) | (vz & m));
-    }
-#pragma unroll
-    for (int o = 0; o < NOFF; ++o) {
-      // unconditional load (block 0 when absent; the cells array always holds >= 1 block) + select
-      const uint32_t cv = map.cells[static_cast<size_t>(cblk[o] < 0 ? 0 : cblk[o]) * kCellsPerBlock + cidx[o]];
-      cell[o] = (cblk[o] >= 0 && o < map.n_off) ? cv : kEmptyCell;
-    }
+  for (int o = 0; o < NOFF; ++o) {
+    constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
+    const int ox = static_cast<int>(kOffCode[row][o] & 3u), oy = static_cast<int>((kOffCode[row][o] >> 2) & 3u),
+              oz = static_cast<int>((kOffCode[row][o] >> 4) & 3u);  // each already offset by +1
+    cell[o] = (blk_id >= 0 && o < map.n_off) ? col[ox * 3 + oy][oz] : kEmptyCell;
   }
 #ifdef MH_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the cell-load latency to this stamp

@@ -195,8 +195,10 @@ int map_sync_device(mh_map * m)
     std::vector<mh::MapScatterRecord> recs;
     std::vector<uint2> cellu;
     for (const uint32_t vid : H.dirty_voxels()) {
-      const uint32_t ci = H.voxel_cell_index(vid);
-      if (ci < m->dev_n_blocks * mh::kCellsPerBlock) cellu.push_back(make_uint2(ci, H.cells()[ci]));
+      const uint32_t * pos = nullptr;
+      const int np = H.voxel_cell_positions(vid, &pos);
+      for (int k = 0; k < np; ++k)
+        if (pos[k] < m->dev_n_blocks * mh::kCellsPerBlock) cellu.push_back(make_uint2(pos[k], H.cells()[pos[k]]));
       if (vid < m->dev_n_voxels) {
         mh::MapScatterRecord r;
         r.vid = vid;

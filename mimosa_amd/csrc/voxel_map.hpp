@@ -14,11 +14,15 @@
 //                                          (x | y << 10 | z << 20, cell = leaf / 1024): the coarse k-NN
 //                                          tier reads 4 candidates per 16-byte load; selection is
 //                                          always re-decided on the exact float4 copy
-//   cells   : uint32[n_blocks * 64]        4x4x4-voxel blocks; entry = voxel_id << 5 | count, ~0u = empty
+//   cells   : uint32[n_blocks * 216]       4x4x4-voxel blocks stored WITH A ONE-VOXEL HALO (6x6x6 words,
+//                                          z fastest); entry = voxel_id << 5 | count, ~0u = empty
 //   table   : int4[capacity]               open-addressing hash of BLOCK coords -> block id (w), -1 empty
 //
-// A 19/27-voxel neighbourhood touches at most 8 blocks (usually 1-2), so a query costs 1-2 hash
-// probes plus cell reads that share 256-byte block rows, instead of 19 independent hash probes.
+// Every voxel is written into the table of its home block and into the halo of each adjacent block it
+// touches (<= 8 tables; a table is created as soon as any voxel falls in its halo).  All 27 neighbours
+// of any voxel of a block therefore sit in THAT block's table: a query costs ONE hash probe plus nine
+// 12-byte loads (one z-triple per (dx, dy) column) instead of 19 independent hash probes — the lookup
+// is bound by the number of per-lane L1 transactions, not by bytes.
 // Map points are float32-valued in the reference too (PointCloudCPU is built from Vector3f,
 // incremental_voxel_map.cpp:40-48), so float4 storage is lossless; all distance arithmetic is fp64.
 #pragma once
@@ -33,7 +37,8 @@ namespace mh
 {
 constexpr int kBlockLog2 = 2;                       // 4x4x4 voxels per block
 constexpr int kBlockDim = 1 << kBlockLog2;
-constexpr int kCellsPerBlock = kBlockDim * kBlockDim * kBlockDim;
+constexpr int kHaloDim = kBlockDim + 2;                // block + one-voxel halo
+constexpr int kCellsPerBlock = kHaloDim * kHaloDim * kHaloDim;  // 216 words per block table
 constexpr int kBucketStride = 20;                   // FlatContainer max_num_points_in_cell
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 constexpr int kQuantBits = 10;                     // coarse copy: leaf / 1024 resolution
@@ -55,6 +60,15 @@ inline int fast_floor(double v)
 {
   const int n = static_cast<int>(v);
   return n - (v < static_cast<double>(n) ? 1 : 0);
+}
+
+// Index of the voxel with block-local coordinates l = c - 4 b, each in [-1, 4], inside a halo'd table.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int halo_index(int lx, int ly, int lz)
+{
+  return ((lx + 1) * kHaloDim + (ly + 1)) * kHaloDim + (lz + 1);
 }
 
 // Hash of a block coordinate.  Internal to the table (not observable), so the 32-bit Teschner
@@ -134,7 +148,12 @@ public:
   const std::vector<Float4> & buckets() const { return buckets_; }
   const std::vector<uint32_t> & qbuckets() const { return qbuckets_; }
   const std::vector<uint8_t> & counts() const { return vox_count_; }
-  uint32_t voxel_cell_index(uint32_t vid) const { return vox_cell_[vid]; }
+  // positions (indices into cells()) that hold this voxel's word: home table + adjacent halos
+  int voxel_cell_positions(uint32_t vid, const uint32_t ** pos) const
+  {
+    *pos = &vox_cells_[static_cast<size_t>(vid) * 8];
+    return vox_ncells_[vid];
+  }
 
   // Dirty tracking for the device mirror.
   bool structure_changed() const { return structure_changed_; }
@@ -180,7 +199,7 @@ public:
           qz(px * inv_leaf_, cx) | (qz(py * inv_leaf_, cy) << kQuantBits) | (qz(pz * inv_leaf_, cz) << (2 * kQuantBits));
       }
       vox_count_[vid] = static_cast<uint8_t>(cnt + 1);
-      cells_[vox_cell_[vid]] = (vid << 5) | static_cast<uint32_t>(cnt + 1);
+      write_voxel_word(vid, (vid << 5) | static_cast<uint32_t>(cnt + 1));
       ++n_points_;
       mark_dirty(vid);
     }
@@ -229,6 +248,50 @@ private:
       table_put(block_coord_[3 * b], block_coord_[3 * b + 1], block_coord_[3 * b + 2], static_cast<int>(b));
     structure_changed_ = true;
   }
+  int find_or_create_block(int bx, int by, int bz)
+  {
+    int blk = find_block(bx, by, bz);
+    if (blk < 0) {
+      if ((n_blocks_ + 1) * 2 > table_.size()) rehash_blocks(table_.size() * 2);
+      blk = static_cast<int>(n_blocks_++);
+      block_coord_.insert(block_coord_.end(), {bx, by, bz});
+      cells_.resize(n_blocks_ * kCellsPerBlock, kEmptyCell);
+      table_put(bx, by, bz, blk);
+      structure_changed_ = true;
+    }
+    return blk;
+  }
+  void write_voxel_word(uint32_t vid, uint32_t word)
+  {
+    const uint32_t * pos = &vox_cells_[static_cast<size_t>(vid) * 8];
+    for (int i = 0; i < vox_ncells_[vid]; ++i) cells_[pos[i]] = word;
+  }
+  // Registers voxel `vid` at (cx,cy,cz) in its home table and in the halo of every adjacent block it touches
+  // (creating those tables), remembers the positions, writes `word` there.
+  void place_voxel(uint32_t vid, int cx, int cy, int cz, uint32_t word)
+  {
+    const int m = kBlockDim - 1;
+    int bs[3][2], nb[3];
+    const int c[3] = {cx, cy, cz};
+    for (int a = 0; a < 3; ++a) {
+      bs[a][0] = c[a] >> kBlockLog2;
+      nb[a] = 1;
+      if ((c[a] & m) == 0) bs[a][nb[a]++] = (c[a] >> kBlockLog2) - 1;       // local coordinate 4 in the block below
+      else if ((c[a] & m) == m) bs[a][nb[a]++] = (c[a] >> kBlockLog2) + 1;  // local coordinate -1 in the block above
+    }
+    int n = 0;
+    for (int ix = 0; ix < nb[0]; ++ix)
+      for (int iy = 0; iy < nb[1]; ++iy)
+        for (int iz = 0; iz < nb[2]; ++iz) {
+          const int bx = bs[0][ix], by = bs[1][iy], bz = bs[2][iz];
+          const int blk = find_or_create_block(bx, by, bz);
+          const uint32_t pos = static_cast<uint32_t>(static_cast<size_t>(blk) * kCellsPerBlock +
+                                                     halo_index(cx - bx * kBlockDim, cy - by * kBlockDim, cz - bz * kBlockDim));
+          vox_cells_[static_cast<size_t>(vid) * 8 + n++] = pos;  // the home block comes first (ix = iy = iz = 0)
+          cells_[pos] = word;
+        }
+    vox_ncells_[vid] = static_cast<uint8_t>(n);
+  }
   uint32_t find_or_create_voxel(int cx, int cy, int cz)
   {
     const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
@@ -237,33 +300,27 @@ private:
       blk = last_block_;
     } else {
       blk = find_block(bx, by, bz);
-      if (blk < 0) {
-        if ((n_blocks_ + 1) * 2 > table_.size()) rehash_blocks(table_.size() * 2);
-        blk = static_cast<int>(n_blocks_++);
-        block_coord_.insert(block_coord_.end(), {bx, by, bz});
-        cells_.resize(n_blocks_ * kCellsPerBlock, kEmptyCell);
-        table_put(bx, by, bz, blk);
-        structure_changed_ = true;
-      }
       last_block_ = blk;
       last_b_[0] = bx;
       last_b_[1] = by;
       last_b_[2] = bz;
     }
     const int m = kBlockDim - 1;
-    const size_t cell = static_cast<size_t>(blk) * kCellsPerBlock +
-                        (((cx & m) << (2 * kBlockLog2)) | ((cy & m) << kBlockLog2) | (cz & m));
-    uint32_t e = cells_[cell];
-    if (e != kEmptyCell) return e >> 5;
+    if (blk >= 0) {
+      const uint32_t e = cells_[static_cast<size_t>(blk) * kCellsPerBlock + halo_index(cx & m, cy & m, cz & m)];
+      if (e != kEmptyCell) return e >> 5;
+    }
     const uint32_t vid = static_cast<uint32_t>(vox_count_.size());
     vox_count_.push_back(0);
     vox_lru_.push_back(lru_counter_);
-    vox_cell_.push_back(static_cast<uint32_t>(cell));
+    vox_cells_.resize(static_cast<size_t>(vid + 1) * 8, 0u);
+    vox_ncells_.push_back(0);
     vox_coord_.insert(vox_coord_.end(), {cx, cy, cz});
     buckets_.resize(static_cast<size_t>(vid + 1) * kBucketStride, Float4{0, 0, 0, 0});
     qbuckets_.resize(static_cast<size_t>(vid + 1) * kBucketStride, 0u);
     dirty_flag_.push_back(0);
-    cells_[cell] = vid << 5;
+    place_voxel(vid, cx, cy, cz, vid << 5);
+    last_block_ = -1;  // place_voxel may have created / rehashed blocks
     mark_dirty(vid);
     return vid;
   }
@@ -306,33 +363,20 @@ private:
     vox_lru_.swap(lru);
     buckets_.swap(buckets);
     qbuckets_.swap(qb);
-    vox_cell_.assign(keep, 0);
+    vox_cells_.assign(keep * 8, 0u);
+    vox_ncells_.assign(keep, 0);
     dirty_flag_.assign(keep, 0);
     dirty_.clear();
     n_blocks_ = 0;
     block_coord_.clear();
     cells_.clear();
     last_block_ = -1;
-    size_t cap = 1024;
-    while (cap < keep) cap *= 2;  // blocks <= voxels
-    table_.assign(cap, Int4{0, 0, 0, -1});
-    table_mask_ = static_cast<uint32_t>(cap - 1);
+    table_.assign(1024, Int4{0, 0, 0, -1});
+    table_mask_ = 1023u;
     n_points_ = 0;
     for (size_t v = 0; v < keep; ++v) {
-      const int cx = vox_coord_[3 * v], cy = vox_coord_[3 * v + 1], cz = vox_coord_[3 * v + 2];
-      const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
-      int blk = find_block(bx, by, bz);
-      if (blk < 0) {
-        blk = static_cast<int>(n_blocks_++);
-        block_coord_.insert(block_coord_.end(), {bx, by, bz});
-        cells_.resize(n_blocks_ * kCellsPerBlock, kEmptyCell);
-        table_put(bx, by, bz, blk);
-      }
-      const int m = kBlockDim - 1;
-      const size_t cell = static_cast<size_t>(blk) * kCellsPerBlock +
-                          (((cx & m) << (2 * kBlockLog2)) | ((cy & m) << kBlockLog2) | (cz & m));
-      vox_cell_[v] = static_cast<uint32_t>(cell);
-      cells_[cell] = (static_cast<uint32_t>(v) << 5) | vox_count_[v];
+      place_voxel(static_cast<uint32_t>(v), vox_coord_[3 * v], vox_coord_[3 * v + 1], vox_coord_[3 * v + 2],
+                  (static_cast<uint32_t>(v) << 5) | vox_count_[v]);
       n_points_ += vox_count_[v];
     }
     structure_changed_ = true;
@@ -357,7 +401,8 @@ private:
     copy_with_headroom(vox_coord_, o.vox_coord_);
     copy_with_headroom(vox_count_, o.vox_count_);
     copy_with_headroom(vox_lru_, o.vox_lru_);
-    copy_with_headroom(vox_cell_, o.vox_cell_);
+    copy_with_headroom(vox_cells_, o.vox_cells_);
+    copy_with_headroom(vox_ncells_, o.vox_ncells_);
     copy_with_headroom(buckets_, o.buckets_);
     copy_with_headroom(qbuckets_, o.qbuckets_);
     n_blocks_ = o.n_blocks_;
@@ -389,7 +434,8 @@ private:
   std::vector<int32_t> vox_coord_;
   std::vector<uint8_t> vox_count_;
   std::vector<uint64_t> vox_lru_;
-  std::vector<uint32_t> vox_cell_;
+  std::vector<uint32_t> vox_cells_;   // 8 slots per voxel: indices into cells_ that hold its word (home first)
+  std::vector<uint8_t> vox_ncells_;   // how many of the 8 are used
   std::vector<Float4> buckets_;
   std::vector<uint32_t> qbuckets_;
   // blocks
