@@ -156,8 +156,7 @@ __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * 
 
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
-// dk = squared distance of the k-th.  `list` / `blk` are this lane's columns of LDS arrays
-// [kMaxOff][stride] / [8][stride].  Returns the number of points in all occupied neighbour voxels
+// dk = squared distance of the k-th.  `list` is this lane's column of an LDS array [kMaxOff][stride].  Returns the number of points in all occupied neighbour voxels
 // (what the reference scans); n_scanned = what was actually scanned.
 //
 // In-kernel timeline + counters (MH_TIMELINE build, round 1): the scan is bound by dependent-issue
@@ -176,7 +175,7 @@ __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * 
 // n_exact_fallback).  Either way the selection is bit-identical to the reference.
 template <int K, int NOFF>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
-                                              int k, uint32_t * list, int * blk, int lds_stride,
+                                              int k, uint32_t * list, int lds_stride,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
                                               unsigned long long * dbg = nullptr)
 {
@@ -201,7 +200,6 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     }
     blk_id = e.w;
   }
-  (void)blk;
   MH_STAMP(dbg, 8);
   uint32_t col[9][3];
   {
@@ -577,20 +575,22 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
   constexpr int NSEG = kThreads / EW;
   const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
   if (seg < NSEG && ent < n_ent) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int b = seg;
-    for (; b + 3 * NSEG < n_blocks; b += 4 * NSEG) {
-      const double v0 = load_partial(partials + static_cast<size_t>(b) * kPartialStride + ent);
-      const double v1 = load_partial(partials + static_cast<size_t>(b + NSEG) * kPartialStride + ent);
-      const double v2 = load_partial(partials + static_cast<size_t>(b + 2 * NSEG) * kPartialStride + ent);
-      const double v3 = load_partial(partials + static_cast<size_t>(b + 3 * NSEG) * kPartialStride + ent);
-      a0 += v0;
-      a1 += v1;
-      a2 += v2;
-      a3 += v3;
+    // all of this thread's rows are requested before the first one is consumed: ONE memory round trip for
+    // the usual <= 16 rows per thread (the fold is the serial tail of the kernel; four dependent rounds
+    // of write-through loads cost ~4 us)
+    constexpr int kBatch = 16;
+    double acc = 0.0;
+    for (int b0 = seg; b0 < n_blocks; b0 += kBatch * NSEG) {
+      double v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int b = b0 + u * NSEG;
+        v[u] = load_partial(partials + static_cast<size_t>(b < n_blocks ? b : seg) * kPartialStride + ent);
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) acc += (b0 + u * NSEG < n_blocks) ? v[u] : 0.0;  // fixed order: deterministic
     }
-    for (; b < n_blocks; b += NSEG) a0 += load_partial(partials + static_cast<size_t>(b) * kPartialStride + ent);
-    s_seg[seg * EW + ent] = (a0 + a1) + (a2 + a3);
+    s_seg[seg * EW + ent] = acc;
   } else if (seg < NSEG) {
     s_seg[seg * EW + ent] = 0.0;
   }
@@ -617,8 +617,8 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   constexpr int PPS = (kThreads + SEGS - 1) / SEGS;
   constexpr int EW = BINARY ? 96 : 32;
   constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
-  // One LDS arena, reused: [k-NN] per-lane voxel list + 8 block ids; [reduce] rows, segment sums.
-  constexpr int kListWords = (kMaxOff + 8) * kThreads;
+  // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [reduce] rows, segment sums.
+  constexpr int kListWords = kMaxOff * kThreads;
   constexpr int kRowWords = kThreads * ROWW * 2;
   constexpr int kSegWords = SEGS * NENT * 2;
   constexpr int kFoldWords = (kThreads / EW) * EW * 2 + EW * 2;
@@ -629,7 +629,6 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   __shared__ bool s_last;
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [kMaxOff][kThreads]
-  int * s_blk = reinterpret_cast<int *>(s_arena + kMaxOff * kThreads + threadIdx.x);  // [8][kThreads]
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [kThreads][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
@@ -681,7 +680,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       double dk;
       bool fell_back;
       uint32_t n_scanned;
-      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, s_blk, kThreads, bi, dk, fell_back, n_scanned, a.dbg);
+      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, kThreads, bi, dk, fell_back, n_scanned, a.dbg);
       atomicAdd(&s_cnt[0], 1u);
       atomicAdd(&s_cnt[1], n_cand);
       if (fell_back) atomicAdd(&s_cnt[2], 1u);
@@ -922,17 +921,30 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double v[6] = {0, 0, 0, 0, 0, 0};
   unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // the two eigenbases are requested up front, in the same round trip as the first per-point loads
+  double er[9], et[9];
+  {
+    const double * Er = a.eig ? a.eig : a.result->eig_rot;
+    const double * Et = a.eig ? a.eig + 9 : a.result->eig_trans;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      er[q] = Er[q];
+      et[q] = Et[q];
+    }
+  }
   // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
   // cost is the ticket + fold tail, which scales with the number of partial rows
   for (int ch = 0; ch < a.chunks_per_block; ++ch) {
   const int i = (blockIdx.x * a.chunks_per_block + ch) * kThreads + threadIdx.x;
   int st = -1;
   if (i < a.n) {
+    // status, point and normal are requested together (one memory round trip instead of a dependent chain;
+    // the pass is a handful of round trips long, nothing else)
     st = a.status[i];
+    const float4 sp = a.src[i];
+    const double n0 = a.normal[3 * i], n1 = a.normal[3 * i + 1], n2 = a.normal[3 * i + 2];
     if (st == MH_VALID) {
-      const float4 sp = a.src[i];
       const double px = sp.x, py = sp.y, pz = sp.z;
-      const double n0 = a.normal[3 * i], n1 = a.normal[3 * i + 1], n2 = a.normal[3 * i + 2];
       const double ns0 = a.R[0] * n0 + (a.R[3] * n1 + a.R[6] * n2);
       const double ns1 = a.R[1] * n0 + (a.R[4] * n1 + a.R[7] * n2);
       const double ns2 = a.R[2] * n0 + (a.R[5] * n1 + a.R[8] * n2);
@@ -944,12 +956,10 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
         r1 *= inv;
         r2 *= inv;
       }
-      const double * Er = a.eig ? a.eig : a.result->eig_rot;
-      const double * Et = a.eig ? a.eig + 9 : a.result->eig_trans;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double tc = fabs((-ns0) * Et[c] + ((-ns1) * Et[3 + c] + (-ns2) * Et[6 + c]));
-        const double rc = fabs(r0 * Er[c] + (r1 * Er[3 + c] + r2 * Er[6 + c]));
+        const double tc = fabs((-ns0) * et[c] + ((-ns1) * et[3 + c] + (-ns2) * et[6 + c]));
+        const double rc = fabs(r0 * er[c] + (r1 * er[3 + c] + r2 * er[6 + c]));
         v[c] += tc >= 0.5 ? tc : 0.0;      // trans components
         v[3 + c] += rc >= 0.5 ? rc : 0.0;  // rot components
       }
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
                                                            double * pts, double * sq, int32_t * found)
 {
   constexpr int K = 8;
-  __shared__ uint32_t s_list[(kMaxOff + 8) * kThreads];
+  __shared__ uint32_t s_list[kMaxOff * kThreads];
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
@@ -1014,14 +1024,11 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
   bool fell_back;
   uint32_t n_scanned;
   if (map.n_off <= 7)
-    knn_query<K, 7>(map, q0, q1, q2, k, s_list + threadIdx.x,
-                    reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 7>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
   else if (map.n_off == 19)
-    knn_query<K, 19>(map, q0, q1, q2, k, s_list + threadIdx.x,
-                     reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 19>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
   else
-    knn_query<K, 27>(map, q0, q1, q2, k, s_list + threadIdx.x,
-                     reinterpret_cast<int *>(s_list + kMaxOff * kThreads + threadIdx.x), kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 27>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
   int f = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
