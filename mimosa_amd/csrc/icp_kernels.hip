@@ -104,6 +104,21 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_blocks)
   return (b & 7) * cpx + (b >> 3);
 }
 
+// Wave-wide sum by DPP (all 64 lanes must be active); the total lands in lane 63.  Two quad permutes, two
+// row mirrors, then row_bcast15 / row_bcast31 carry the 16-lane row sums across rows.  (Leaving this to
+// atomicAdd on LDS makes the compiler aggregate with a 64-trip scalar v_readlane loop per counter:
+// ~450 dependent SALU instructions each, 11 k of the wave's 71 k cycles in round 1.)
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
+{
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+  return v;
+}
+
 // Diagnostic build only (-DMH_TIMELINE): per-wave s_memtime stamps at phase boundaries.
 #ifdef MH_TIMELINE
 #define MH_STAMP(ptr, i)                                                                       \
@@ -261,29 +276,58 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint32_t ck[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
-  // one candidate: packed word w_, voxel offset (in grid units) ofx/ofy/ofz, payload, validity
-#define MH_COARSE_UPDATE(w_, ofx, ofy, ofz, payload, valid)                                            \
+  // Key of one candidate (no insertion): packed word w_, voxel offsets in grid units, payload, validity.
+  // y is decoded by OR-ing its bit field (bits 10-19) into the mantissa of 2^13 (whose mantissa bit 10 weighs
+  // 1, ulp 2^-10): one v_and_or + one v_sub instead of extract + convert + add; the 2^13 is folded into the
+  // per-voxel offset by the caller (rounding <= 2^-11 grid units, inside kErrG's slack).  The same trick on x
+  // (bits 0-9) would need 2^23, whose ulp of one whole grid unit would destroy the sub-grid offset.
+#define MH_COARSE_KEY(key_, w_, ofx, mfy, ofz, payload, valid)                                        \
   do {                                                                                                 \
     const float dx_ = static_cast<float>((w_) & 1023u) + (ofx);                                        \
-    const float dy_ = static_cast<float>(((w_) >> 10) & 1023u) + (ofy);                                \
+    const float dy_ = __uint_as_float(((w_) & 0xFFC00u) | 0x46000000u) - (mfy);                        \
     const float dz_ = static_cast<float>(((w_) >> 20) & 1023u) + (ofz);                                \
     const float d_ = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;                                                \
-    uint32_t t_ = (__float_as_uint(d_) & ~0x3FFu) | (payload);                                         \
-    t_ = (valid) ? t_ : 0xFFFFFFFFu;                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < KK - 1; ++i_)                                              \
-    {                                                                                                  \
-      const uint32_t lo_ = min(ck[i_], t_);                                                            \
-      t_ = max(ck[i_], t_);                                                                            \
-      ck[i_] = lo_;                                                                                    \
-    }                                                                                                  \
-    ck[KK - 1] = min(ck[KK - 1], t_);                                                                  \
+    const uint32_t t_ = (__float_as_uint(d_) & ~0x3FFu) | (payload);                                   \
+    (key_) = (valid) ? t_ : 0xFFFFFFFFu;                                                               \
   } while (0)
+#define MH_CE(a_, b_)                        \
+  do {                                       \
+    const uint32_t lo_ = min((a_), (b_));    \
+    (b_) = max((a_), (b_));                  \
+    (a_) = lo_;                              \
+  } while (0)
+  // Four candidates at once.  KK == 8: sort the quad (5 compare-exchanges), half-clean it against the upper
+  // half of the sorted top-8 (C[i] = min(ck[4+i], q[3-i]) keeps the 8 smallest of the 12 as a bitonic
+  // sequence), bitonic-merge the 8 (12 compare-exchanges): 38 min/max ops instead of 4 x 15 for four serial
+  // insertions.  Other KK (generic k <= 8 path): serial insertion.
 #define MH_COARSE_QUAD(qw, ofx, ofy, ofz, o_, s0_, cnt_)                                               \
   do {                                                                                                 \
-    MH_COARSE_UPDATE((qw).x, ofx, ofy, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 0u), (s0_) + 0u < (cnt_)); \
-    MH_COARSE_UPDATE((qw).y, ofx, ofy, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 1u), (s0_) + 1u < (cnt_)); \
-    MH_COARSE_UPDATE((qw).z, ofx, ofy, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 2u), (s0_) + 2u < (cnt_)); \
-    MH_COARSE_UPDATE((qw).w, ofx, ofy, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 3u), (s0_) + 3u < (cnt_)); \
+    const float mfy_ = 8192.0f - (ofy);                                                                \
+    uint32_t k0_, k1_, k2_, k3_;                                                                       \
+    MH_COARSE_KEY(k0_, (qw).x, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 0u), (s0_) + 0u < (cnt_)); \
+    MH_COARSE_KEY(k1_, (qw).y, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 1u), (s0_) + 1u < (cnt_)); \
+    MH_COARSE_KEY(k2_, (qw).z, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 2u), (s0_) + 2u < (cnt_)); \
+    MH_COARSE_KEY(k3_, (qw).w, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 3u), (s0_) + 3u < (cnt_)); \
+    if constexpr (KK == 8) {                                                                           \
+      MH_CE(k0_, k1_); MH_CE(k2_, k3_); MH_CE(k0_, k2_); MH_CE(k1_, k3_); MH_CE(k1_, k2_);             \
+      ck[4] = min(ck[4], k3_); ck[5] = min(ck[5], k2_); ck[6] = min(ck[6], k1_); ck[7] = min(ck[7], k0_); \
+      MH_CE(ck[0], ck[4]); MH_CE(ck[1], ck[5]); MH_CE(ck[2], ck[6]); MH_CE(ck[3], ck[7]);              \
+      MH_CE(ck[0], ck[2]); MH_CE(ck[1], ck[3]); MH_CE(ck[4], ck[6]); MH_CE(ck[5], ck[7]);              \
+      MH_CE(ck[0], ck[1]); MH_CE(ck[2], ck[3]); MH_CE(ck[4], ck[5]); MH_CE(ck[6], ck[7]);              \
+    } else {                                                                                           \
+      uint32_t kq_[4] = {k0_, k1_, k2_, k3_};                                                          \
+      _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                 \
+      {                                                                                                \
+        uint32_t t_ = kq_[c_];                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < KK - 1; ++i_)                                          \
+        {                                                                                              \
+          const uint32_t lo_ = min(ck[i_], t_);                                                        \
+          t_ = max(ck[i_], t_);                                                                        \
+          ck[i_] = lo_;                                                                                \
+        }                                                                                              \
+        ck[KK - 1] = min(ck[KK - 1], t_);                                                              \
+      }                                                                                                \
+    }                                                                                                  \
   } while (0)
 
   // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
@@ -303,6 +347,9 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     amask &= ~(1u << kCenter);
   }
   MH_STAMP(dbg, 10);
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+  const uint32_t amask_unpruned = amask;
+#endif
   // ---- prune: drop neighbour voxels that provably hold no top-k point ----------------------------
   {
     uint32_t kth = 0xFFFFFFFFu;
@@ -348,6 +395,20 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       total_q += (c + 3u) >> 2;
     }
     n_scanned += total;
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+    if (dbg) {  // lane balance of the neighbour scan: wave sum / max of per-lane quad counts (slots 13, 14)
+      uint32_t sq = total_q, mq = total_q;
+      for (int d = 32; d > 0; d >>= 1) {
+        sq += __shfl_xor(sq, d);
+        mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
+        w_[13] = sq;
+        w_[14] = mq;
+      }
+    }
+#endif
     uint32_t rem = amask;  // voxels not yet entered by the cursor
     int o_cur = rem ? __builtin_ctz(rem) : 0;
     rem &= rem - 1u;
@@ -393,7 +454,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #undef MH_PREFETCH
   }
 #undef MH_COARSE_QUAD
-#undef MH_COARSE_UPDATE
+#undef MH_COARSE_KEY
+#undef MH_CE
   MH_STAMP(dbg, 2);
 
   // ---- exact tier: re-rank the survivors in fp64 by (distance, traversal rank) -------------------
@@ -446,6 +508,27 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #pragma unroll
   for (int i = 0; i < K; ++i)
     if (i == k - 1) dk = bd[i];
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+  if (dbg) {  // ideal pruning: quads in neighbour voxels whose box is nearer than the FINAL k-th distance (slot 15)
+    const float dkg = dk < kDblMax ? static_cast<float>(dk / (g_d * g_d)) : 3.0e38f;
+    uint32_t iq = 0;
+    for (int o = 0; o < NOFF; ++o) {
+      const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
+      const int ox = static_cast<int>(ow & 3u) - 1, oy = static_cast<int>((ow >> 2) & 3u) - 1, oz = static_cast<int>((ow >> 4) & 3u) - 1;
+      const float gx = ox < 0 ? qg0 : (ox > 0 ? kQ - qg0 : 0.f), gy = oy < 0 ? qg1 : (oy > 0 ? kQ - qg1 : 0.f),
+                  gz = oz < 0 ? qg2 : (oz > 0 ? kQ - qg2 : 0.f);
+      if (((amask_unpruned >> o) & 1u) && gx * gx + gy * gy + gz * gz <= dkg) iq += ((cell[o] & 31u) + 3u) >> 2;
+    }
+    uint32_t sq = iq, mq = iq;
+    for (int d = 32; d > 0; d >>= 1) {
+      sq += __shfl_xor(sq, d);
+      mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
+    }
+    if ((threadIdx.x & 63) == 0)
+      dbg[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16 + 15] =
+        static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
+  }
+#endif
   // ---- proof check (only meaningful when there ARE non-survivors: the KK-th slot is filled) ------
   if (ck[KK - 1] != 0xFFFFFFFFu && dk < kDblMax) {
     // Scanned non-survivors have coarse keys >= ck[KK-1]; clearing the payload bits only lowers the
@@ -637,6 +720,8 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   __syncthreads();
 
   double row[NV];
+  uint32_t cnt_pack = 0u;  // this lane's k-NN counters, reduced per wave after the per-point section
+  bool did_knn = false, did_fall = false;
 #ifdef MH_TIMELINE
   // diagnostic: repeat the per-point section (MH_REPS env) so the last pass runs with warm caches
   for (int rep = 0; rep < a.reps; ++rep) {
@@ -681,10 +766,9 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       bool fell_back;
       uint32_t n_scanned;
       const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, kThreads, bi, dk, fell_back, n_scanned, a.dbg);
-      atomicAdd(&s_cnt[0], 1u);
-      atomicAdd(&s_cnt[1], n_cand);
-      if (fell_back) atomicAdd(&s_cnt[2], 1u);
-      atomicAdd(&s_cnt[3], n_scanned);
+      cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
+      did_knn = true;
+      did_fall = fell_back;
       if (!(dk < kDblMax)) {
         st = MH_INSUFFICIENT_CORRES_POINTS;  // found != k
       } else if (dk > a.max_d2) {
@@ -706,6 +790,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
             sz += X[j][2];
           }
         }
+        MH_STAMP(a.dbg, 13);
         const double kd = static_cast<double>(k);
         mean[0] = sx / kd;
         mean[1] = sy / kd;
@@ -731,7 +816,9 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
         a.mean[3 * qi + 1] = mean[1];
         a.mean[3 * qi + 2] = mean[2];
         double w[3], v0[3];
+        MH_STAMP(a.dbg, 14);
         plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
+        MH_STAMP(a.dbg, 15);
         if (!(w[0] == w[0]) || !(w[2] == w[2])) {
           st = MH_EIGEN_SOLVER_FAIL;  // NaN input: Eigen would report NoConvergence (:197)
         } else if (w[0] < 1e-6) {
@@ -832,6 +919,19 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       }
     }
     a.status[qi] = st;
+  }
+  {
+    // k-NN counters: one LDS atomic per wave and counter (uniform control flow: every lane is active here)
+    const uint32_t packed = wave_sum_to_lane63(cnt_pack);
+    const unsigned long long mk = __ballot(did_knn), mf = __ballot(did_fall);
+    if ((threadIdx.x & 63) == 63) {
+      atomicAdd(&s_cnt[0], static_cast<unsigned int>(__popcll(mk)));
+      atomicAdd(&s_cnt[1], packed & 0xFFFFu);
+      atomicAdd(&s_cnt[2], static_cast<unsigned int>(__popcll(mf)));
+      atomicAdd(&s_cnt[3], packed >> 16);
+    }
+    cnt_pack = 0u;
+    did_knn = did_fall = false;
   }
 #ifdef MH_TIMELINE
   }

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mimosa_amd import build as hb, capi, synth  # noqa: E402
 
-lib = hb.build(timeline=True)
+lib = hb.build(timeline=True)  # add -DMH_BALANCE by hand for the lane-balance counters (MH_BALANCE=1 here)
 capi._build.LIB = lib  # load the diagnostic variant
 ctx = capi.Context(0)
 L = ctx.L
@@ -58,6 +58,19 @@ stat("   B.3 neighbour scan (11->2)", T[:, 2] - T[:, 11])
 stat("   C.1 exact tier (2->12)", T[:, 12] - T[:, 2])
 stat("   C.2 proof+plane+residual+stores (12->3)", T[:, 3] - T[:, 12])
 stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
+if os.environ.get("MH_BALANCE"):
+  q_sum, q_max = T[:, 13].astype(float), T[:, 14].astype(float)
+  print(f"neighbour-scan lane balance: mean quads/lane {q_sum.mean()/64:.2f}, mean per-wave max {q_max.mean():.2f} "
+        f"(padded to x4: {(np.ceil(q_max/4)*4).mean():.2f}), SIMT efficiency {q_sum.sum()/(64*q_max.sum()):.2f}")
+  i_sum, i_max = (T[:, 15] & 0xFFFFFFFF).astype(float), (T[:, 15] >> 32).astype(float)
+  print(f"ideal pruning (box nearer than the final k-th distance): mean quads/lane {i_sum.mean()/64:.2f}, "
+        f"mean per-wave max {i_max.mean():.2f}")
+else:
+  ok = T[:, 13] > 0
+  stat("   C.2a proof check + 5 bucket loads (12->13)", (T[:, 13] - T[:, 12])[ok])
+  stat("   C.2b mean + covariance (13->14)", (T[:, 14] - T[:, 13])[ok])
+  stat("   C.2c plane_eigen (14->15)", (T[:, 15] - T[:, 14])[ok])
+  stat("   C.2d gates + residual + Jacobian + stores (15->3)", (T[:, 3] - T[:, 15])[ok])
 stat("C: plane/residual (2->3)", T[:, 3] - T[:, 2])
 stat("barrier wait (3->4)", T[:, 4] - T[:, 3])
 stat("D: block reduce+store (4->5)", T[:, 5] - T[:, 4])
