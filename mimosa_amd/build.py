@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
-                   "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] if timeline else []), "-c", s, "-o", o]
+                   "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] + (["-DMH_BALANCE"] if os.environ.get("MH_BALANCE") else []) if timeline else []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

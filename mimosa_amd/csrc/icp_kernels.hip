@@ -41,46 +41,58 @@ constexpr int kThreads = 512;
 constexpr int kMaxOff = 27;
 constexpr double kDblMax = 1.7976931348623157e308;
 
-// Neighbour-voxel offsets in gtsam_points' generation order (mh::neighbor_offsets in voxel_map.hpp is
-// the host twin), one packed word per offset: (i+1) | (j+1) << 2 | (k+1) << 4.  Rows: mode 1, 7, 19, 27.
-// Lives in constant memory and is read with wave-uniform scalar loads.
-#define MH_O(i, j, k) (((i) + 1) | (((j) + 1) << 2) | (((k) + 1) << 4))
-__constant__ uint32_t kNeighborOffsets[4][kMaxOff] = {
-  {MH_O(0, 0, 0)},
-  {MH_O(0, 0, 0), MH_O(1, 0, 0), MH_O(-1, 0, 0), MH_O(0, 1, 0), MH_O(0, -1, 0), MH_O(0, 0, 1), MH_O(0, 0, -1)},
-  {MH_O(-1, -1, 0), MH_O(-1, 0, -1), MH_O(-1, 0, 0), MH_O(-1, 0, 1), MH_O(-1, 1, 0), MH_O(0, -1, -1), MH_O(0, -1, 0),
-   MH_O(0, -1, 1), MH_O(0, 0, -1), MH_O(0, 0, 0), MH_O(0, 0, 1), MH_O(0, 1, -1), MH_O(0, 1, 0), MH_O(0, 1, 1),
-   MH_O(1, -1, 0), MH_O(1, 0, -1), MH_O(1, 0, 0), MH_O(1, 0, 1), MH_O(1, 1, 0)},
-  {MH_O(-1, -1, -1), MH_O(-1, -1, 0), MH_O(-1, -1, 1), MH_O(-1, 0, -1), MH_O(-1, 0, 0), MH_O(-1, 0, 1), MH_O(-1, 1, -1),
-   MH_O(-1, 1, 0), MH_O(-1, 1, 1), MH_O(0, -1, -1), MH_O(0, -1, 0), MH_O(0, -1, 1), MH_O(0, 0, -1), MH_O(0, 0, 0),
-   MH_O(0, 0, 1), MH_O(0, 1, -1), MH_O(0, 1, 0), MH_O(0, 1, 1), MH_O(1, -1, -1), MH_O(1, -1, 0), MH_O(1, -1, 1),
-   MH_O(1, 0, -1), MH_O(1, 0, 0), MH_O(1, 0, 1), MH_O(1, 1, -1), MH_O(1, 1, 0), MH_O(1, 1, 1)}};
-#undef MH_O
-
-// The same offsets as compile-time packed words (6 bits per offset, 10 per 64-bit word) for code that
-// indexes them with a per-lane value: register shifts instead of a memory request.
+// Neighbour-voxel offsets in gtsam_points' generation order (mh::neighbor_offsets in voxel_map.hpp is the
+// host twin) as compile-time packed codes (i+1) | (j+1) << 2 | (k+1) << 4.  Rows: mode 1, 7, 19, 27.
 constexpr uint32_t kOffCode[4][kMaxOff] = {
   {21},
   {21, 22, 20, 25, 17, 37, 5},
   {16, 4, 20, 36, 24, 1, 17, 33, 5, 21, 37, 9, 25, 41, 18, 6, 22, 38, 26},
   {0, 16, 32, 4, 20, 36, 8, 24, 40, 1, 17, 33, 5, 21, 37, 9, 25, 41, 2, 18, 34, 6, 22, 38, 10, 26, 42}};
-constexpr uint64_t off_lut_word(int row, int w)
+// Scan order of the neighbour voxels: centre, then the 6 faces, the 12 edges, the 8 corners (each class
+// in generation order).  The coarse tier is order-independent (it keeps a SET of survivors), so it visits
+// the voxels most likely to tighten the pruning bound first; the traversal rank o that KnnResult::push's
+// tie rule needs is recovered per survivor.  ent[row][b] = offset code | o << 6 of scan position b,
+// pos[row][o] = scan position of traversal rank o.
+struct ScanTab
 {
-  uint64_t r = 0;
-  for (int i = 0; i < 10; ++i) {
-    const int o = 10 * w + i;
-    if (o < kMaxOff) r |= static_cast<uint64_t>(kOffCode[row][o] & 63u) << (6 * i);
+  uint32_t ent[4][kMaxOff];
+  uint32_t pos[4][kMaxOff];
+};
+constexpr int kRowN[4] = {1, 7, 19, 27};
+constexpr ScanTab make_scan_tab()
+{
+  ScanTab t{};
+  for (int r = 0; r < 4; ++r) {
+    int b = 0;
+    for (int cls = 0; cls <= 3; ++cls)
+      for (int o = 0; o < kRowN[r]; ++o) {
+        const uint32_t c = kOffCode[r][o];
+        const int nz = ((c & 3u) != 1u ? 1 : 0) + (((c >> 2) & 3u) != 1u ? 1 : 0) + (((c >> 4) & 3u) != 1u ? 1 : 0);
+        if (nz == cls) {
+          t.ent[r][b] = c | (static_cast<uint32_t>(o) << 6);
+          t.pos[r][o] = static_cast<uint32_t>(b);
+          ++b;
+        }
+      }
+    for (; b < kMaxOff; ++b) t.ent[r][b] = 21u;
   }
-  return r;
+  return t;
 }
+constexpr ScanTab kScan = make_scan_tab();
+__constant__ ScanTab kScanDev = make_scan_tab();
+constexpr int kScanLutWords = 64;  // LDS copy of one row: [b] = offset code, [32 + b] = traversal rank o
+
+// Every block copies its mode's row into LDS once: the scan cursor indexes it with a per-lane value (one
+// ds_read instead of a 12-instruction register LUT or a scattered constant-memory load).
 template <int NOFF>
-__device__ __forceinline__ uint32_t off_code(int o)
+__device__ __forceinline__ void fill_scan_lut(uint32_t * lut)
 {
   constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
-  constexpr uint64_t L0 = off_lut_word(row, 0), L1 = off_lut_word(row, 1), L2 = off_lut_word(row, 2);
-  const uint64_t w = o < 10 ? L0 : (o < 20 ? L1 : L2);
-  const int j = o < 10 ? o : (o < 20 ? o - 10 : o - 20);
-  return static_cast<uint32_t>(w >> (6 * j)) & 63u;
+  if (threadIdx.x < kMaxOff) {
+    const uint32_t e = kScanDev.ent[row][threadIdx.x];
+    lut[threadIdx.x] = e & 63u;
+    lut[32 + threadIdx.x] = e >> 6;
+  }
 }
 
 // Squared distance exactly as the reference's CPU build evaluates it: no FMA contraction (baseline
@@ -130,42 +142,62 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
 #else
 #define MH_STAMP(ptr, i) do { } while (0)
 #endif
+#ifdef MH_BALANCE  // slots 13-15 carry the lane-balance counters instead of the C2 sub-phase stamps
+#define MH_STAMP_C2(ptr, i) do { } while (0)
+#else
+#define MH_STAMP_C2(ptr, i) MH_STAMP(ptr, i)
+#endif
 
 // Exact fallback: KnnResult::push verbatim (ascending, strict '<': the earlier-traversed candidate
 // wins ties) over the same compacted voxel list.  Only runs for lanes whose truncated keys collided.
 template <int K>
 __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * list, int list_stride, int n_list,
-                                       const double q0, const double q1, const double q2, double (&bd)[K],
-                                       uint32_t (&bi)[K])
+                                       const uint32_t * pos, const double q0, const double q1, const double q2,
+                                       double (&out_d)[K], uint32_t (&out_i)[K])
 {
+  // The by-reference outputs live in scratch (out-of-line call): the running top-k stays in LOCAL arrays
+  // (registers) and is copied out once — an insertion sort through scratch cost ~50 k cycles per call and,
+  // because a kernel ends with its slowest wave, set the duration of every scan that had one fallback.
+  double bd[K];
+  uint32_t bi[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     bd[j] = kDblMax;
     bi[j] = 0xFFFFFFFFu;
   }
-  for (int j = 0; j < n_list; ++j) {  // slots in traversal (offset-generation) order, empty ones skipped
-    const uint32_t e = list[j * list_stride];
+  for (int j = 0; j < n_list; ++j) {  // traversal (offset-generation) order; the LDS list is in scan order
+    const uint32_t e = list[pos[j] * list_stride];
     if (e == kEmptyCell) continue;
     const uint32_t base = (e >> 5) * kBucketStride, cnt = e & 31u;
-    for (uint32_t s = 0; s < cnt; ++s) {
-      const float4 c = buckets[base + s];
-      const double d = sq_dist3(static_cast<double>(c.x) - q0, static_cast<double>(c.y) - q1,
-                                static_cast<double>(c.z) - q2);
-      if (!(d < bd[K - 1])) continue;
-      bd[K - 1] = d;
-      bi[K - 1] = base + s;
+    for (uint32_t s0 = 0; s0 < cnt; s0 += 4) {
+      float4 c[4];
 #pragma unroll
-      for (int i = K - 1; i > 0; --i) {
-        if (bd[i] < bd[i - 1]) {
-          const double td = bd[i];
-          bd[i] = bd[i - 1];
-          bd[i - 1] = td;
-          const uint32_t ti = bi[i];
-          bi[i] = bi[i - 1];
-          bi[i - 1] = ti;
+      for (uint32_t u = 0; u < 4; ++u) c[u] = buckets[base + min(s0 + u, cnt - 1u)];  // four loads in flight
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const double d = sq_dist3(static_cast<double>(c[u].x) - q0, static_cast<double>(c[u].y) - q1,
+                                  static_cast<double>(c[u].z) - q2);
+        if (s0 + u >= cnt || !(d < bd[K - 1])) continue;
+        bd[K - 1] = d;
+        bi[K - 1] = base + s0 + u;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+          if (bd[i] < bd[i - 1]) {
+            const double td = bd[i];
+            bd[i] = bd[i - 1];
+            bd[i - 1] = td;
+            const uint32_t ti = bi[i];
+            bi[i] = bi[i - 1];
+            bi[i - 1] = ti;
+          }
         }
       }
     }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    out_d[j] = bd[j];
+    out_i[j] = bi[j];
   }
 }
 
@@ -190,14 +222,14 @@ __device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * 
 // n_exact_fallback).  Either way the selection is bit-identical to the reference.
 template <int K, int NOFF>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
-                                              int k, uint32_t * list, int lds_stride,
+                                              int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
                                               unsigned long long * dbg = nullptr)
 {
   (void)dbg;
   fell_back = false;
   constexpr int KK = K + 3 + (K > 5 ? 1 : 0);  // survivors: 8 for k = 5, 12 for the generic k <= 8 path
-  constexpr int kCenter = NOFF == 7 ? 0 : (NOFF == 19 ? 9 : 13);  // offset (0,0,0) in kNeighborOffsets
+  constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
   // ---- A. neighbourhood lookup ------------------------------------------------------------------
   // Block tables carry a one-voxel halo (voxel_map.hpp): all 27 neighbours of the centre voxel are in
   // the table of ITS block.  One hash probe, then nine 12-byte loads (the z-triple of each (dx, dy)
@@ -230,13 +262,12 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       col[c][2] = p[2];
     }
   }
-  uint32_t cell[NOFF];
+  uint32_t cell[NOFF];  // scan order: cell[0] is the centre voxel
 #pragma unroll
-  for (int o = 0; o < NOFF; ++o) {
-    constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
-    const int ox = static_cast<int>(kOffCode[row][o] & 3u), oy = static_cast<int>((kOffCode[row][o] >> 2) & 3u),
-              oz = static_cast<int>((kOffCode[row][o] >> 4) & 3u);  // each already offset by +1
-    cell[o] = (blk_id >= 0 && o < map.n_off) ? col[ox * 3 + oy][oz] : kEmptyCell;
+  for (int b = 0; b < NOFF; ++b) {
+    const uint32_t ent = kScan.ent[row][b];
+    const int ox = static_cast<int>(ent & 3u), oy = static_cast<int>((ent >> 2) & 3u), oz = static_cast<int>((ent >> 4) & 3u);
+    cell[b] = (blk_id >= 0 && static_cast<int>(ent >> 6) < map.n_off) ? col[ox * 3 + oy][oz] : kEmptyCell;
   }
 #ifdef MH_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the cell-load latency to this stamp
@@ -332,9 +363,9 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 
   // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
   n_scanned = 0;
-  if (amask & (1u << kCenter)) {
-    const uint32_t cc = cell[kCenter] & 31u;
-    const uint4 * b = map.qbuckets + static_cast<size_t>(cell[kCenter] >> 5) * (kBucketStride / 4);
+  if (amask & 1u) {
+    const uint32_t cc = cell[0] & 31u;
+    const uint4 * b = map.qbuckets + static_cast<size_t>(cell[0] >> 5) * (kBucketStride / 4);
     n_scanned += cc;
     const float ofx = 0.5f - qg0, ofy = 0.5f - qg1, ofz = 0.5f - qg2;  // centre voxel: offset (0,0,0)
     uint4 qw[kBucketStride / 4];
@@ -342,117 +373,108 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     for (int u = 0; u < kBucketStride / 4; ++u) qw[u] = b[static_cast<uint32_t>(4 * u) < cc ? u : 0];  // all issued together
 #pragma unroll
     for (int u = 0; u < kBucketStride / 4; ++u) {
-      if (static_cast<uint32_t>(4 * u) < cc) MH_COARSE_QUAD(qw[u], ofx, ofy, ofz, kCenter, static_cast<uint32_t>(4 * u), cc);
+      if (static_cast<uint32_t>(4 * u) < cc) MH_COARSE_QUAD(qw[u], ofx, ofy, ofz, 0u, static_cast<uint32_t>(4 * u), cc);
     }
-    amask &= ~(1u << kCenter);
   }
   MH_STAMP(dbg, 10);
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-  const uint32_t amask_unpruned = amask;
-#endif
-  // ---- prune: drop neighbour voxels that provably hold no top-k point ----------------------------
+  // ---- prune: a neighbour voxel whose BOX is farther from q than a proven upper bound of the current
+  // k-th distance cannot hold a top-k point (strictly farther, so not even ties are affected).  The
+  // squared box distances stay in registers: the scan re-applies the test as its bound tightens.
+  float boxd[NOFF];
   {
-    uint32_t kth = 0xFFFFFFFFu;
+    // gaps from q to the faces of its centre voxel, shrunk by a margin that also covers a stored
+    // point sitting ~1 ulp outside its nominal box
+    const float marg = 1e-2f;
+    const float gxm = fmaxf(qg0 - marg, 0.f), gxp = fmaxf(kQ - qg0 - marg, 0.f);
+    const float gym = fmaxf(qg1 - marg, 0.f), gyp = fmaxf(kQ - qg1 - marg, 0.f);
+    const float gzm = fmaxf(qg2 - marg, 0.f), gzp = fmaxf(kQ - qg2 - marg, 0.f);
+    const float g2x[3] = {gxm * gxm, 0.f, gxp * gxp}, g2y[3] = {gym * gym, 0.f, gyp * gyp}, g2z[3] = {gzm * gzm, 0.f, gzp * gzp};
 #pragma unroll
-    for (int i = 0; i < K; ++i)
-      if (i == k - 1) kth = ck[i];
-    if (kth != 0xFFFFFFFFu) {
-      // upper bound (grid units) of the TRUE k-th distance so far: undo the 10-bit key truncation
-      // (<= 2^-13 relative on d^2), then the coarse error
-      const float kv = __uint_as_float(kth & ~0x3FFu) * (1.0f + 2.5e-4f);
-      const float r_up = sqrtf(kv) * (1.0f + 2e-6f) + kErrG;
-      const float b_up = r_up * r_up;
-      // gaps from q to the faces of its centre voxel, shrunk by a margin that also covers a stored
-      // point sitting ~1 ulp outside its nominal box
-      const float marg = 1e-2f;
-      const float gxm = fmaxf(qg0 - marg, 0.f), gxp = fmaxf(kQ - qg0 - marg, 0.f);
-      const float gym = fmaxf(qg1 - marg, 0.f), gyp = fmaxf(kQ - qg1 - marg, 0.f);
-      const float gzm = fmaxf(qg2 - marg, 0.f), gzp = fmaxf(kQ - qg2 - marg, 0.f);
-#pragma unroll
-      for (int o = 0; o < NOFF; ++o) {
-        const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
-        const int ox = static_cast<int>(ow & 3u) - 1, oy = static_cast<int>((ow >> 2) & 3u) - 1,
-                  oz = static_cast<int>((ow >> 4) & 3u) - 1;
-        const float gx = ox < 0 ? gxm : (ox > 0 ? gxp : 0.f);
-        const float gy = oy < 0 ? gym : (oy > 0 ? gyp : 0.f);
-        const float gz = oz < 0 ? gzm : (oz > 0 ? gzp : 0.f);
-        if (gx * gx + gy * gy + gz * gz > b_up) amask &= ~(1u << o);
-      }
+    for (int b = 0; b < NOFF; ++b) {
+      const uint32_t ent = kScan.ent[row][b];
+      boxd[b] = g2x[ent & 3u] + g2y[(ent >> 2) & 3u] + g2z[(ent >> 4) & 3u];
     }
   }
+  // mask_ &= ~(voxels provably too far given the current k-th key)
+#define MH_PRUNE(mask_)                                                                              \
+  do {                                                                                               \
+    uint32_t kth_ = 0xFFFFFFFFu;                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < K; ++i_) if (i_ == k - 1) kth_ = ck[i_];                 \
+    /* upper bound (grid units) of the TRUE k-th distance so far: undo the 10-bit key truncation */  \
+    /* (<= 2^-13 relative on d^2), then the coarse error */                                          \
+    const float kv_ = __uint_as_float(kth_ & ~0x3FFu) * (1.0f + 2.5e-4f);                            \
+    const float r_up_ = sqrtf(kv_) * (1.0f + 2e-6f) + kErrG;                                         \
+    const float b_up_ = kth_ != 0xFFFFFFFFu ? r_up_ * r_up_ : 3.0e38f;                               \
+    _Pragma("unroll") for (int b_ = 1; b_ < NOFF; ++b_) (mask_) &= boxd[b_] > b_up_ ? ~(1u << b_) : ~0u; \
+  } while (0)
+  uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
+  MH_PRUNE(rem);
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+  const uint32_t amask_unpruned = amask & ~1u;
+#endif
 
   MH_STAMP(dbg, 11);
   // ---- B2. remaining voxels: flattened, software-pipelined coarse scan over QUADS of candidates ---
-  // The (voxel, quad) cursor walks the active-bit mask in registers kPipe quads ahead of the
-  // arithmetic; every load is unconditional (quad 0 of voxel 0 past the end), validity is a select.
+  // The (voxel, quad) cursor walks the not-yet-entered mask in registers kPipe quads ahead of the
+  // arithmetic; every load is unconditional (quad 0 of voxel 0 past the end), validity is a select.  The
+  // wave loops while any lane still has a live quad in flight; after the first and second trip the
+  // tightened bound prunes the voxels not entered yet (what matters for lanes whose centre voxel held
+  // fewer than k points: their first bound is infinite).
   {
     constexpr int kPipe = 4;
-    uint32_t total = 0, total_q = 0;
-#pragma unroll
-    for (int o = 0; o < NOFF; ++o) {
-      const uint32_t c = (amask >> o) & 1u ? (cell[o] & 31u) : 0u;
-      total += c;
-      total_q += (c + 3u) >> 2;
-    }
-    n_scanned += total;
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-    if (dbg) {  // lane balance of the neighbour scan: wave sum / max of per-lane quad counts (slots 13, 14)
-      uint32_t sq = total_q, mq = total_q;
-      for (int d = 32; d > 0; d >>= 1) {
-        sq += __shfl_xor(sq, d);
-        mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
-      }
-      if ((threadIdx.x & 63) == 0) {
-        unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
-        w_[13] = sq;
-        w_[14] = mq;
-      }
-    }
-#endif
-    uint32_t rem = amask;  // voxels not yet entered by the cursor
-    int o_cur = rem ? __builtin_ctz(rem) : 0;
-    rem &= rem - 1u;
-    uint32_t qd = 0;       // quad index inside the current voxel
-    uint32_t fetched = 0;
+    int o_cur = 0;
+    uint32_t qd = 8u, cnt_cur = 0u;  // "exhausted": the first prefetch enters the first listed voxel
     uint4 pw[kPipe];
-    uint32_t pmeta[kPipe];  // o << 8 | cnt << 3 | quad
+    uint32_t pmeta[kPipe];  // offset code | b << 6 | live count << 11 | quad << 16
 #define MH_PREFETCH(u)                                                                              \
   do {                                                                                              \
-    const uint64_t w_ = o_cur < 12 ? cw0 : (o_cur < 24 ? cw1 : cw2);                                \
-    const int jj_ = o_cur < 12 ? o_cur : (o_cur < 24 ? o_cur - 12 : o_cur - 24);                    \
-    const uint32_t cj_ = static_cast<uint32_t>(w_ >> (5 * jj_)) & 31u;                              \
-    const bool sw_ = (4u * qd >= cj_) && rem != 0u; /* next active voxel (each holds >= 1 point) */ \
+    const bool sw_ = (4u * qd >= cnt_cur) && rem != 0u; /* next listed voxel (each holds >= 1 point) */ \
     o_cur = sw_ ? __builtin_ctz(rem) : o_cur;                                                       \
     rem = sw_ ? (rem & (rem - 1u)) : rem;                                                           \
     qd = sw_ ? 0u : qd;                                                                             \
     const uint64_t w2_ = o_cur < 12 ? cw0 : (o_cur < 24 ? cw1 : cw2);                               \
     const int j2_ = o_cur < 12 ? o_cur : (o_cur < 24 ? o_cur - 12 : o_cur - 24);                    \
-    const uint32_t c2_ = static_cast<uint32_t>(w2_ >> (5 * j2_)) & 31u;                             \
+    cnt_cur = static_cast<uint32_t>(w2_ >> (5 * j2_)) & 31u;                                        \
+    n_scanned += sw_ ? cnt_cur : 0u;                                                                \
+    const bool live_ = 4u * qd < cnt_cur;                                                           \
     const uint32_t e_ = list[o_cur * lds_stride]; /* off the cursor's dependency chain */           \
-    const uint32_t idx_ = fetched < total_q ? (e_ >> 5) * (kBucketStride / 4) + qd : 0u;            \
+    const uint32_t idx_ = live_ ? (e_ >> 5) * (kBucketStride / 4) + qd : 0u;                        \
     pw[u] = map.qbuckets[idx_];                                                                     \
-    pmeta[u] = (static_cast<uint32_t>(o_cur) << 8) | (c2_ << 3) | qd;                               \
+    pmeta[u] = scan_lut[o_cur] | (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? cnt_cur : 0u) << 11) | (qd << 16); \
     ++qd;                                                                                           \
-    ++fetched;                                                                                      \
   } while (0)
 #pragma unroll
     for (int u = 0; u < kPipe; ++u) MH_PREFETCH(u);
-    for (uint32_t it = 0; it < total_q; it += kPipe) {
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+    uint32_t trips = 0;
+#endif
+    for (int trip = 0;; ++trip) {
+      if (!__any(static_cast<int>((pmeta[0] >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
+      if (trip == 1 || trip == 2) MH_PRUNE(rem);
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+      ++trips;
+#endif
 #pragma unroll
       for (int u = 0; u < kPipe; ++u) {
         const uint4 qw = pw[u];
         const uint32_t meta = pmeta[u];
-        MH_PREFETCH(u);  // refill this stage with quad it + u + kPipe
-        const uint32_t o_ = meta >> 8, cnt_ = (it + u < total_q) ? ((meta >> 3) & 31u) : 0u, s0_ = (meta & 7u) * 4u;
-        const uint32_t ow = off_code<NOFF>(static_cast<int>(o_));  // per-lane index: register LUT, no memory request
-        const float ofx = static_cast<float>(static_cast<int>(ow & 3u) - 1) * kQ + 0.5f - qg0;
-        const float ofy = static_cast<float>(static_cast<int>((ow >> 2) & 3u) - 1) * kQ + 0.5f - qg1;
-        const float ofz = static_cast<float>(static_cast<int>((ow >> 4) & 3u) - 1) * kQ + 0.5f - qg2;
-        MH_COARSE_QUAD(qw, ofx, ofy, ofz, o_, s0_, cnt_);
+        MH_PREFETCH(u);  // refill this stage
+        const uint32_t b_ = (meta >> 6) & 31u, cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
+        const float ofx = static_cast<float>(meta & 3u) * kQ + (0.5f - kQ - qg0);
+        const float ofy = static_cast<float>((meta >> 2) & 3u) * kQ + (0.5f - kQ - qg1);
+        const float ofz = static_cast<float>((meta >> 4) & 3u) * kQ + (0.5f - kQ - qg2);
+        MH_COARSE_QUAD(qw, ofx, ofy, ofz, b_, s0_, cnt_);
       }
     }
 #undef MH_PREFETCH
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+    if (dbg && (threadIdx.x & 63) == 0) {
+      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
+      w_[14] = 4u * trips;  // quad steps the wave executed
+    }
+#endif
   }
+#undef MH_PRUNE
 #undef MH_COARSE_QUAD
 #undef MH_COARSE_KEY
 #undef MH_CE
@@ -468,18 +490,20 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     br[i] = 0xFFFFFFFFu;
   }
   {
-    uint32_t sidx[KK];
+    uint32_t sidx[KK], srank[KK];
     float4 sc[KK];
 #pragma unroll
     for (int u = 0; u < KK; ++u) {  // all survivor loads issued together (index 0 for empty slots)
       const uint32_t p = ck[u] & 0x3FFu;
-      const uint32_t e = list[min(static_cast<int>(p >> 5), NOFF - 1) * lds_stride];
+      const int b = min(static_cast<int>(p >> 5), NOFF - 1);  // scan position
+      const uint32_t e = list[b * lds_stride];
       sidx[u] = ck[u] != 0xFFFFFFFFu ? (e >> 5) * kBucketStride + (p & 31u) : 0u;
       sc[u] = map.buckets[sidx[u]];
+      srank[u] = (scan_lut[32 + b] << 5) | (p & 31u);  // (traversal rank of the voxel, slot): the order push() sees
     }
 #pragma unroll
     for (int u = 0; u < KK; ++u) {
-      const uint32_t p = ck[u] & 0x3FFu;
+      const uint32_t p = srank[u];
       const double d = sq_dist3(static_cast<double>(sc[u].x) - q0, static_cast<double>(sc[u].y) - q1,
                                 static_cast<double>(sc[u].z) - q2);
       if (ck[u] != 0xFFFFFFFFu && (d < bd[K - 1] || (d == bd[K - 1] && p < br[K - 1]))) {
@@ -512,21 +536,20 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   if (dbg) {  // ideal pruning: quads in neighbour voxels whose box is nearer than the FINAL k-th distance (slot 15)
     const float dkg = dk < kDblMax ? static_cast<float>(dk / (g_d * g_d)) : 3.0e38f;
     uint32_t iq = 0;
-    for (int o = 0; o < NOFF; ++o) {
-      const uint32_t ow = kNeighborOffsets[map.mode_idx][o];
-      const int ox = static_cast<int>(ow & 3u) - 1, oy = static_cast<int>((ow >> 2) & 3u) - 1, oz = static_cast<int>((ow >> 4) & 3u) - 1;
-      const float gx = ox < 0 ? qg0 : (ox > 0 ? kQ - qg0 : 0.f), gy = oy < 0 ? qg1 : (oy > 0 ? kQ - qg1 : 0.f),
-                  gz = oz < 0 ? qg2 : (oz > 0 ? kQ - qg2 : 0.f);
-      if (((amask_unpruned >> o) & 1u) && gx * gx + gy * gy + gz * gz <= dkg) iq += ((cell[o] & 31u) + 3u) >> 2;
-    }
-    uint32_t sq = iq, mq = iq;
+#pragma unroll
+    for (int b = 1; b < NOFF; ++b)
+      if (((amask_unpruned >> b) & 1u) && boxd[b] <= dkg) iq += ((cell[b] & 31u) + 3u) >> 2;
+    uint32_t sq = iq, mq = iq, sn = (n_scanned + 3u) >> 2;
     for (int d = 32; d > 0; d >>= 1) {
       sq += __shfl_xor(sq, d);
+      sn += __shfl_xor(sn, d);
       mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
     }
-    if ((threadIdx.x & 63) == 0)
-      dbg[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16 + 15] =
-        static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
+      w_[13] = sn;  // ~quads scanned by the wave's lanes (centre included)
+      w_[15] = static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
+    }
   }
 #endif
   // ---- proof check (only meaningful when there ARE non-survivors: the KK-th slot is filled) ------
@@ -542,7 +565,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       double ebd[K];
       uint32_t ebi[K];
       fell_back = true;
-      knn_exact<K>(map.buckets, list, lds_stride, NOFF, q0, q1, q2, ebd, ebi);
+      knn_exact<K>(map.buckets, list, lds_stride, NOFF, kScanDev.pos[row], q0, q1, q2, ebd, ebi);
       dk = kDblMax;
 #pragma unroll
       for (int i = 0; i < K; ++i) {
@@ -709,6 +732,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   constexpr int kArenaWords = kListWords > kReduceWords ? kListWords : kReduceWords;
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
   __shared__ unsigned int s_cnt[4];  // n_knn, n_cand, exact-fallback count, candidates actually scanned
+  __shared__ uint32_t s_scan[kScanLutWords];
   __shared__ bool s_last;
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [kMaxOff][kThreads]
@@ -717,6 +741,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
 
   const int qi = xcd_chunk(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  fill_scan_lut<NOFF>(s_scan);
   __syncthreads();
 
   double row[NV];
@@ -765,7 +790,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       double dk;
       bool fell_back;
       uint32_t n_scanned;
-      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, kThreads, bi, dk, fell_back, n_scanned, a.dbg);
+      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, kThreads, s_scan, bi, dk, fell_back, n_scanned, a.dbg);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
       did_fall = fell_back;
@@ -790,7 +815,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
             sz += X[j][2];
           }
         }
-        MH_STAMP(a.dbg, 13);
+        MH_STAMP_C2(a.dbg, 13);
         const double kd = static_cast<double>(k);
         mean[0] = sx / kd;
         mean[1] = sy / kd;
@@ -816,9 +841,9 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
         a.mean[3 * qi + 1] = mean[1];
         a.mean[3 * qi + 2] = mean[2];
         double w[3], v0[3];
-        MH_STAMP(a.dbg, 14);
+        MH_STAMP_C2(a.dbg, 14);
         plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
-        MH_STAMP(a.dbg, 15);
+        MH_STAMP_C2(a.dbg, 15);
         if (!(w[0] == w[0]) || !(w[2] == w[2])) {
           st = MH_EIGEN_SOLVER_FAIL;  // NaN input: Eigen would report NoConvergence (:197)
         } else if (w[0] < 1e-6) {
@@ -1116,6 +1141,14 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 {
   constexpr int K = 8;
   __shared__ uint32_t s_list[kMaxOff * kThreads];
+  __shared__ uint32_t s_scan[kScanLutWords];
+  if (map.n_off <= 7)
+    fill_scan_lut<7>(s_scan);
+  else if (map.n_off == 19)
+    fill_scan_lut<19>(s_scan);
+  else
+    fill_scan_lut<27>(s_scan);
+  __syncthreads();
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
@@ -1124,11 +1157,11 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
   bool fell_back;
   uint32_t n_scanned;
   if (map.n_off <= 7)
-    knn_query<K, 7>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 7>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, s_scan, bi, dk, fell_back, n_scanned);
   else if (map.n_off == 19)
-    knn_query<K, 19>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 19>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, s_scan, bi, dk, fell_back, n_scanned);
   else
-    knn_query<K, 27>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, bi, dk, fell_back, n_scanned);
+    knn_query<K, 27>(map, q0, q1, q2, k, s_list + threadIdx.x, kThreads, s_scan, bi, dk, fell_back, n_scanned);
   int f = 0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {

@@ -58,13 +58,13 @@ stat("   B.3 neighbour scan (11->2)", T[:, 2] - T[:, 11])
 stat("   C.1 exact tier (2->12)", T[:, 12] - T[:, 2])
 stat("   C.2 proof+plane+residual+stores (12->3)", T[:, 3] - T[:, 12])
 stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
-if os.environ.get("MH_BALANCE"):
-  q_sum, q_max = T[:, 13].astype(float), T[:, 14].astype(float)
-  print(f"neighbour-scan lane balance: mean quads/lane {q_sum.mean()/64:.2f}, mean per-wave max {q_max.mean():.2f} "
-        f"(padded to x4: {(np.ceil(q_max/4)*4).mean():.2f}), SIMT efficiency {q_sum.sum()/(64*q_max.sum()):.2f}")
+if os.environ.get("MH_BALANCE"):  # build with MH_BALANCE=1 python -m mimosa_amd.build --timeline --force
+  q_sum, steps = T[:, 13].astype(float), T[:, 14].astype(float)
+  print(f"scan lane balance: mean quads/lane (centre incl.) {q_sum.mean()/64:.2f}, mean neighbour quad steps per wave {steps.mean():.2f}, "
+        f"p95 {np.percentile(steps,95):.0f}, max {steps.max():.0f}")
   i_sum, i_max = (T[:, 15] & 0xFFFFFFFF).astype(float), (T[:, 15] >> 32).astype(float)
-  print(f"ideal pruning (box nearer than the final k-th distance): mean quads/lane {i_sum.mean()/64:.2f}, "
-        f"mean per-wave max {i_max.mean():.2f}")
+  print(f"ideal pruning (box nearer than the final k-th distance): mean neighbour quads/lane {i_sum.mean()/64:.2f}, "
+        f"mean per-wave max {i_max.mean():.2f}, p95 {np.percentile(i_max,95):.0f}, max {i_max.max():.0f}")
 else:
   ok = T[:, 13] > 0
   stat("   C.2a proof check + 5 bucket loads (12->13)", (T[:, 13] - T[:, 12])[ok])
@@ -93,3 +93,15 @@ last = T[T[:, 7] > 0]
 if len(last):
     stat("last block: ticket wait (5->6)", last[:, 6] - last[:, 5])
     stat("last block: fold+eigen (6->7)", last[:, 7] - last[:, 6])
+
+# the kernel ends with its slowest wave: show the tail
+tot = T[:, 5] - T[:, 0]
+order = np.argsort(-tot)[:12]
+print("slowest waves: total | A  B1  prune  B3  exact  C2  barrier  D")
+for i in order:
+    t = T[i]
+    print(f"  {tot[i]:7d} | {t[1]-t[0]:6d} {t[10]-t[1]:6d} {t[11]-t[10]:6d} {t[2]-t[11]:6d} {t[12]-t[2]:6d} {t[3]-t[12]:6d} {t[4]-t[3]:6d} {t[5]-t[4]:6d}")
+work = T[:, 3] - T[:, 0]
+print(f"per-wave work before the barrier (0->3): mean {work.mean():.0f} p50 {np.percentile(work,50):.0f} p95 {np.percentile(work,95):.0f} p99 {np.percentile(work,99):.0f} max {work.max()}")
+bw = np.array([work[blk == b].max() for b in np.unique(blk)])
+print(f"per-block slowest wave: mean {bw.mean():.0f} p95 {np.percentile(bw,95):.0f} max {bw.max()}")
