@@ -131,6 +131,17 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
   return v;
 }
 
+// Broadcast of one lane's value to the wave (l must be wave-uniform): v_readlane_b32 -> SGPR.
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int l)
+{
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+}
+__device__ __forceinline__ double lane_get(double v, int l)
+{
+  return __hiloint2double(static_cast<int>(lane_get(static_cast<uint32_t>(__double2hiint(v)), l)),
+                          static_cast<int>(lane_get(static_cast<uint32_t>(__double2loint(v)), l)));
+}
+
 // Diagnostic build only (-DMH_TIMELINE): per-wave s_memtime stamps at phase boundaries.
 #ifdef MH_TIMELINE
 #define MH_STAMP(ptr, i)                                                                       \
@@ -147,59 +158,6 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
 #else
 #define MH_STAMP_C2(ptr, i) MH_STAMP(ptr, i)
 #endif
-
-// Exact fallback: KnnResult::push verbatim (ascending, strict '<': the earlier-traversed candidate
-// wins ties) over the same compacted voxel list.  Only runs for lanes whose truncated keys collided.
-template <int K>
-__device__ __noinline__ void knn_exact(const float4 * buckets, const uint32_t * list, int list_stride, int n_list,
-                                       const uint32_t * pos, const double q0, const double q1, const double q2,
-                                       double (&out_d)[K], uint32_t (&out_i)[K])
-{
-  // The by-reference outputs live in scratch (out-of-line call): the running top-k stays in LOCAL arrays
-  // (registers) and is copied out once — an insertion sort through scratch cost ~50 k cycles per call and,
-  // because a kernel ends with its slowest wave, set the duration of every scan that had one fallback.
-  double bd[K];
-  uint32_t bi[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    bd[j] = kDblMax;
-    bi[j] = 0xFFFFFFFFu;
-  }
-  for (int j = 0; j < n_list; ++j) {  // traversal (offset-generation) order; the LDS list is in scan order
-    const uint32_t e = list[pos[j] * list_stride];
-    if (e == kEmptyCell) continue;
-    const uint32_t base = (e >> 5) * kBucketStride, cnt = e & 31u;
-    for (uint32_t s0 = 0; s0 < cnt; s0 += 4) {
-      float4 c[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) c[u] = buckets[base + min(s0 + u, cnt - 1u)];  // four loads in flight
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const double d = sq_dist3(static_cast<double>(c[u].x) - q0, static_cast<double>(c[u].y) - q1,
-                                  static_cast<double>(c[u].z) - q2);
-        if (s0 + u >= cnt || !(d < bd[K - 1])) continue;
-        bd[K - 1] = d;
-        bi[K - 1] = base + s0 + u;
-#pragma unroll
-        for (int i = K - 1; i > 0; --i) {
-          if (bd[i] < bd[i - 1]) {
-            const double td = bd[i];
-            bd[i] = bd[i - 1];
-            bd[i - 1] = td;
-            const uint32_t ti = bi[i];
-            bi[i] = bi[i - 1];
-            bi[i - 1] = ti;
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    out_d[j] = bd[j];
-    out_i[j] = bi[j];
-  }
-}
 
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
@@ -277,19 +235,18 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // their point counts are packed into registers (5 bits each, 12 per word) so the scan cursor never
   // reads memory.
   uint32_t amask = 0u, total_ref = 0u;
-  uint64_t cw0 = 0, cw1 = 0, cw2 = 0;
+  uint64_t qc0 = 0, qc1 = 0;  // quads per voxel, 3 bits each: scan positions 0..20 | 21..26
 #pragma unroll
   for (int o = 0; o < NOFF; ++o) {
-    list[o * lds_stride] = cell[o];
+    list[o * lds_stride] = cell[o] != kEmptyCell ? cell[o] : 0u;  // empty = (voxel 0, count 0): always a mapped index
     const uint32_t c = cell[o] != kEmptyCell ? (cell[o] & 31u) : 0u;
     amask |= (c ? 1u : 0u) << o;
     total_ref += c;
-    if (o < 12)
-      cw0 |= static_cast<uint64_t>(c) << (5 * o);
-    else if (o < 24)
-      cw1 |= static_cast<uint64_t>(c) << (5 * (o - 12));
+    const uint64_t nq = (c + 3u) >> 2;
+    if (o < 21)
+      qc0 |= nq << (3 * o);
     else
-      cw2 |= static_cast<uint64_t>(c) << (5 * (o - 24));
+      qc1 |= nq << (3 * (o - 21));
   }
   MH_STAMP(dbg, 1);
 
@@ -395,8 +352,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       boxd[b] = g2x[ent & 3u] + g2y[(ent >> 2) & 3u] + g2z[(ent >> 4) & 3u];
     }
   }
-  // mask_ &= ~(voxels provably too far given the current k-th key)
-#define MH_PRUNE(mask_)                                                                              \
+  // keep_ = mask of the voxels that may still hold a top-k point given the current k-th key
+#define MH_PRUNE(keep_)                                                                              \
   do {                                                                                               \
     uint32_t kth_ = 0xFFFFFFFFu;                                                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < K; ++i_) if (i_ == k - 1) kth_ = ck[i_];                 \
@@ -405,10 +362,16 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     const float kv_ = __uint_as_float(kth_ & ~0x3FFu) * (1.0f + 2.5e-4f);                            \
     const float r_up_ = sqrtf(kv_) * (1.0f + 2e-6f) + kErrG;                                         \
     const float b_up_ = kth_ != 0xFFFFFFFFu ? r_up_ * r_up_ : 3.0e38f;                               \
-    _Pragma("unroll") for (int b_ = 1; b_ < NOFF; ++b_) (mask_) &= boxd[b_] > b_up_ ? ~(1u << b_) : ~0u; \
+    (keep_) = ~0u;                                                                                   \
+    _Pragma("unroll") for (int b_ = 1; b_ < NOFF; ++b_) (keep_) &= boxd[b_] > b_up_ ? ~(1u << b_) : ~0u; \
   } while (0)
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
-  MH_PRUNE(rem);
+  {
+    uint32_t keep;
+    MH_PRUNE(keep);
+    rem &= keep;
+  }
+  uint32_t alive = rem;  // neighbour voxels never pruned: alive & ~rem (after the scan) = the voxels scanned
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
   const uint32_t amask_unpruned = amask & ~1u;
 #endif
@@ -423,24 +386,28 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   {
     constexpr int kPipe = 4;
     int o_cur = 0;
-    uint32_t qd = 8u, cnt_cur = 0u;  // "exhausted": the first prefetch enters the first listed voxel
+    uint32_t qd = 8u, nq_cur = 0u;  // "exhausted": the first prefetch enters the first listed voxel
     uint4 pw[kPipe];
-    uint32_t pmeta[kPipe];  // offset code | b << 6 | live count << 11 | quad << 16
+    uint32_t pmeta[kPipe];  // offset code | b << 6 | live point count << 11 | quad << 16
+    // No select on the load index: a `live ? index : 0` makes the compiler sink the LDS read of the cell word
+    // into a branch (four dependent LDS round trips behind s_waitcnt lgkmcnt(0) per trip).  Every list entry
+    // names a mapped voxel and the quad index is clamped, so a dead stage just loads a quad it never uses.
 #define MH_PREFETCH(u)                                                                              \
   do {                                                                                              \
-    const bool sw_ = (4u * qd >= cnt_cur) && rem != 0u; /* next listed voxel (each holds >= 1 point) */ \
+    const bool sw_ = (qd >= nq_cur) && rem != 0u; /* next listed voxel (each holds >= 1 point) */   \
     o_cur = sw_ ? __builtin_ctz(rem) : o_cur;                                                       \
     rem = sw_ ? (rem & (rem - 1u)) : rem;                                                           \
     qd = sw_ ? 0u : qd;                                                                             \
-    const uint64_t w2_ = o_cur < 12 ? cw0 : (o_cur < 24 ? cw1 : cw2);                               \
-    const int j2_ = o_cur < 12 ? o_cur : (o_cur < 24 ? o_cur - 12 : o_cur - 24);                    \
-    cnt_cur = static_cast<uint32_t>(w2_ >> (5 * j2_)) & 31u;                                        \
-    n_scanned += sw_ ? cnt_cur : 0u;                                                                \
-    const bool live_ = 4u * qd < cnt_cur;                                                           \
+    if constexpr (NOFF <= 21)                                                                       \
+      nq_cur = static_cast<uint32_t>(qc0 >> (3 * o_cur)) & 7u;                                      \
+    else                                                                                            \
+      nq_cur = static_cast<uint32_t>((o_cur < 21 ? qc0 : qc1) >> (3 * (o_cur < 21 ? o_cur : o_cur - 21))) & 7u; \
+    const bool live_ = qd < nq_cur;                                                                 \
     const uint32_t e_ = list[o_cur * lds_stride]; /* off the cursor's dependency chain */           \
-    const uint32_t idx_ = live_ ? (e_ >> 5) * (kBucketStride / 4) + qd : 0u;                        \
+    const uint32_t code_ = scan_lut[o_cur];                                                         \
+    const uint32_t idx_ = (e_ >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1)); \
     pw[u] = map.qbuckets[idx_];                                                                     \
-    pmeta[u] = scan_lut[o_cur] | (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? cnt_cur : 0u) << 11) | (qd << 16); \
+    pmeta[u] = code_ | (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? (e_ & 31u) : 0u) << 11) | (qd << 16); \
     ++qd;                                                                                           \
   } while (0)
 #pragma unroll
@@ -450,7 +417,12 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #endif
     for (int trip = 0;; ++trip) {
       if (!__any(static_cast<int>((pmeta[0] >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
-      if (trip == 1 || trip == 2) MH_PRUNE(rem);
+      if (trip == 1 || trip == 2) {
+        uint32_t keep;
+        MH_PRUNE(keep);
+        rem &= keep;
+        alive &= keep;
+      }
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
       ++trips;
 #endif
@@ -460,6 +432,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
         const uint32_t meta = pmeta[u];
         MH_PREFETCH(u);  // refill this stage
         const uint32_t b_ = (meta >> 6) & 31u, cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
+        n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
         const float ofx = static_cast<float>(meta & 3u) * kQ + (0.5f - kQ - qg0);
         const float ofy = static_cast<float>((meta >> 2) & 3u) * kQ + (0.5f - kQ - qg1);
         const float ofz = static_cast<float>((meta >> 4) & 3u) * kQ + (0.5f - kQ - qg2);
@@ -474,7 +447,15 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     }
 #endif
   }
+  // (Measured, round 1: capping the per-lane scan at 16 quads and letting the 64 lanes scan the leftover
+  // voxels together, one candidate per lane, was 2x SLOWER — each (lane, voxel) step is a dependent LDS ->
+  // HBM -> ballot chain with nothing to overlap it.  The per-lane pipelined cursor stays.)
 #undef MH_PRUNE
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t act = __ballot(1);
+  const uint32_t nact = static_cast<uint32_t>(__popcll(act));
+  const uint32_t rank = static_cast<uint32_t>(__popcll(act & ((1ull << lane) - 1ull)));
+  const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem);  // centre + every neighbour voxel the cursor entered
 #undef MH_COARSE_QUAD
 #undef MH_COARSE_KEY
 #undef MH_CE
@@ -497,7 +478,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       const uint32_t p = ck[u] & 0x3FFu;
       const int b = min(static_cast<int>(p >> 5), NOFF - 1);  // scan position
       const uint32_t e = list[b * lds_stride];
-      sidx[u] = ck[u] != 0xFFFFFFFFu ? (e >> 5) * kBucketStride + (p & 31u) : 0u;
+      sidx[u] = (e >> 5) * kBucketStride + (p & 31u);  // empty survivor slot: slot 31 of a listed voxel (mapped, unused)
       sc[u] = map.buckets[sidx[u]];
       srank[u] = (scan_lut[32 + b] << 5) | (p & 31u);  // (traversal rank of the voxel, slot): the order push() sees
     }
@@ -553,24 +534,79 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   }
 #endif
   // ---- proof check (only meaningful when there ARE non-survivors: the KK-th slot is filled) ------
+  bool need_exact = false;
   if (ck[KK - 1] != 0xFFFFFFFFu && dk < kDblMax) {
     // Scanned non-survivors have coarse keys >= ck[KK-1]; clearing the payload bits only lowers the
     // bound; |r_coarse - r| <= kErrG grid units.  (Pruned voxels are farther than the k-th distance
     // by construction.)
     const double c8 = static_cast<double>(__uint_as_float(ck[KK - 1] & ~0x3FFu));  // grid units^2
     const double r_lo = (sqrt(c8) * (1.0 - 1e-6) - static_cast<double>(kErrG)) * g_d;  // metres
-    if (!(r_lo > 0.0 && dk < r_lo * r_lo)) {
-      // separate arrays: anything passed by reference to the out-of-line fallback lives in scratch,
-      // and the main path's bd / bi must stay in registers
-      double ebd[K];
-      uint32_t ebi[K];
-      fell_back = true;
-      knn_exact<K>(map.buckets, list, lds_stride, NOFF, kScanDev.pos[row], q0, q1, q2, ebd, ebi);
+    need_exact = !(r_lo > 0.0 && dk < r_lo * r_lo);
+  }
+  // ---- exact fallback, wave-cooperative: KnnResult::push verbatim for lane L — the scanned voxels in
+  // traversal (offset-generation) order, slots in order, strict '<' so the earlier candidate wins ties —
+  // with the 64 lanes computing one fp64 distance each and L inserting the few that beat its k-th.
+  // (Pruned voxels are provably farther than the k-th distance, so skipping them changes nothing.)
+  fell_back = need_exact;
+  uint64_t fb = __ballot(need_exact);
+  while (fb) {
+    const int L = __builtin_ctzll(fb);
+    fb &= fb - 1ull;
+    const uint32_t mL = lane_get(scanned_mask, L);
+    const double y0 = lane_get(q0, L), y1 = lane_get(q1, L), y2 = lane_get(q2, L);
+    const int dl = L - static_cast<int>(lane);
+    double ed[K];
+    uint32_t ei[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      ed[i] = kDblMax;
+      ei[i] = 0xFFFFFFFFu;
+    }
+    double dlast = kDblMax;  // L's current k-th distance, wave-uniform
+    for (int o = 0; o < NOFF; ++o) {
+      const int b = static_cast<int>(kScanDev.pos[row][o]);
+      if (!((mL >> b) & 1u)) continue;
+      const uint32_t e = list[b * lds_stride + dl];
+      const uint32_t cnt = e & 31u, vbase = (e >> 5) * kBucketStride;
+      for (uint32_t j0 = 0; j0 < cnt; j0 += nact) {
+        const uint32_t j = j0 + rank;
+        const float4 c = map.buckets[vbase + min(j, static_cast<uint32_t>(kBucketStride - 1))];
+        const double d = sq_dist3(static_cast<double>(c.x) - y0, static_cast<double>(c.y) - y1, static_cast<double>(c.z) - y2);
+        uint64_t hm = __ballot(j < cnt && d < dlast);
+        while (hm) {  // ascending lane = ascending slot: the order push() sees
+          const int src = __builtin_ctzll(hm);
+          hm &= hm - 1ull;
+          const double ds = lane_get(d, src);
+          const uint32_t is = vbase + lane_get(j, src);
+          if (static_cast<int>(lane) == L && ds < ed[K - 1]) {
+            ed[K - 1] = ds;
+            ei[K - 1] = is;
+#pragma unroll
+            for (int i = K - 1; i > 0; --i) {
+              if (ed[i] < ed[i - 1]) {
+                const double td = ed[i];
+                ed[i] = ed[i - 1];
+                ed[i - 1] = td;
+                const uint32_t ti = ei[i];
+                ei[i] = ei[i - 1];
+                ei[i - 1] = ti;
+              }
+            }
+          }
+        }
+        double kth = kDblMax;  // found < k keeps the bound open, like an unfilled KnnResult
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          if (i == k - 1) kth = ed[i];
+        dlast = lane_get(kth, L);
+      }
+    }
+    if (static_cast<int>(lane) == L) {
       dk = kDblMax;
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        bi[i] = ebi[i];
-        if (i == k - 1) dk = ebd[i];
+        bi[i] = ei[i];
+        if (i == k - 1) dk = ed[i];
       }
     }
   }
@@ -725,7 +761,8 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
   // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [reduce] rows, segment sums.
   constexpr int kListWords = kMaxOff * kThreads;
-  constexpr int kRowWords = kThreads * ROWW * 2;
+  constexpr int kTileRows = SEGS * PPS;          // >= kThreads; rows past the block's points are zero
+  constexpr int kRowWords = kTileRows * ROWW * 2;
   constexpr int kSegWords = SEGS * NENT * 2;
   constexpr int kFoldWords = (kThreads / EW) * EW * 2 + EW * 2;
   constexpr int kReduceWords = kRowWords + (kSegWords > kFoldWords ? kSegWords : kFoldWords);
@@ -969,6 +1006,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   MH_STAMP(a.dbg, 4);
 #pragma unroll
   for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
+  if (static_cast<int>(threadIdx.x) < (kTileRows - kThreads) * ROWW) s_rows[kThreads * ROWW + threadIdx.x] = 0.0;
   __syncthreads();
   {
     const int ent = threadIdx.x % NENT, seg = threadIdx.x / NENT;
@@ -979,10 +1017,20 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
         ++r;
       }
       const int c = r + rem;
-      double s = 0.0;
-      const int p0 = seg * PPS, p1 = min(kThreads, p0 + PPS);
-      for (int p = p0; p < p1; ++p) s += s_rows[p * ROWW + r] * s_rows[p * ROWW + c];
-      s_aux[seg * NENT + ent] = s;
+      // fixed trip count (the tile is padded with zero rows) and four independent accumulators: the LDS reads
+      // of a whole batch are in flight together instead of one dependent read -> FMA per point
+      const double * pr = s_rows + seg * PPS * ROWW;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int p = 0; p + 3 < PPS; p += 4) {
+        s0 += pr[(p + 0) * ROWW + r] * pr[(p + 0) * ROWW + c];
+        s1 += pr[(p + 1) * ROWW + r] * pr[(p + 1) * ROWW + c];
+        s2 += pr[(p + 2) * ROWW + r] * pr[(p + 2) * ROWW + c];
+        s3 += pr[(p + 3) * ROWW + r] * pr[(p + 3) * ROWW + c];
+      }
+#pragma unroll
+      for (int p = PPS - PPS % 4; p < PPS; ++p) s0 += pr[p * ROWW + r] * pr[p * ROWW + c];
+      s_aux[seg * NENT + ent] = (s0 + s1) + (s2 + s3);
     }
   }
   __syncthreads();

@@ -159,8 +159,10 @@ int map_sync_device(mh_map * m)
   const bool keep = delta;
   MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
   MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, keep));
-  MH_HIP(ctx, m->d_buckets.reserve(bb ? bb : 16, ctx->stream, keep));
-  MH_HIP(ctx, m->d_qbuckets.reserve(qb ? qb : 80, ctx->stream, keep));
+  // one bucket of slack after the last voxel: the kernels' branch-free loads of "no survivor" / "past the end
+  // of this lane's work" slots may touch up to slot 31 of the last voxel (values unused, address must be mapped)
+  MH_HIP(ctx, m->d_buckets.reserve(bb + mh::kBucketStride * sizeof(mh::Float4), ctx->stream, keep));
+  MH_HIP(ctx, m->d_qbuckets.reserve(qb + mh::kBucketStride * sizeof(uint32_t), ctx->stream, keep));
   int64_t moved = 0;
   if (!delta) {
     MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
