@@ -124,7 +124,7 @@ typedef struct mh_icp_result {
   double mean_scanned;    /* mean number the device actually scanned after exact box-distance pruning */
   int64_t n_knn;          /* queries that ran k-NN in this call (the rest hit the DA cache) */
   int64_t n_exact_fallback; /* of those, queries whose coarse f32 scan could not be proven exact and were redone in fp64 */
-  /* device-side timing of this call, ms; filled only when profiling is on (mh_set_profiling) */
+  /* device-side timing of this call, ms; -1 unless this call was timed (mh_set_profiling) */
   float gpu_ms_linearize; /* icp_linearize kernel (K3) */
   float gpu_ms_localizability; /* component-localizability kernel (K4) */
 } mh_icp_result;
@@ -141,8 +141,10 @@ int mh_init(int device, mh_ctx ** out);
 void mh_shutdown(mh_ctx * ctx);
 /* Last error text for this context (or the calling thread when ctx == NULL). */
 const char * mh_last_error(const mh_ctx * ctx);
-/* Per-kernel HIP-event timing inside mh_icp_linearize / mh_icp_linearize_async (off by default). */
-int mh_set_profiling(mh_ctx * ctx, int on);
+/* Per-kernel HIP-event timing inside mh_icp_linearize / mh_icp_linearize_async: 0 = off (default), n >= 1 =
+ * bracket the kernels of every n-th linearize call of a factor (each event record costs ~4 us of stream time,
+ * so a throughput measurement samples).  Untimed calls report gpu_ms_* = -1. */
+int mh_set_profiling(mh_ctx * ctx, int every);
 /* hipStream_t of the context, for callers that want to order their own work / events on it. */
 void * mh_stream(mh_ctx * ctx);
 int mh_synchronize(mh_ctx * ctx);

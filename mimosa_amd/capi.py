@@ -186,8 +186,9 @@ class Context:
         if rc != MH_OK:
             raise MhError(rc, (self.L.mh_last_error(self.h) or b"").decode())
 
-    def set_profiling(self, on: bool):
-        self.check(self.L.mh_set_profiling(self.h, int(on)))
+    def set_profiling(self, every):
+        """0/False = off, n = HIP events around the kernels of every n-th linearize call (True = every call)."""
+        self.check(self.L.mh_set_profiling(self.h, int(every)))
 
     def synchronize(self):
         self.check(self.L.mh_synchronize(self.h))

@@ -54,13 +54,14 @@ struct IcpArgs
   double * partials;
   unsigned int * ticket;
   DeviceResult * result;
+  DeviceResult * host_result;  // mapped pinned host slot (may be null): the last block writes its part there too
   unsigned long long * dbg;  // MH_TIMELINE diagnostic build only, else null
   int reps;                  // MH_TIMELINE only: repeat the per-point section (warm-cache experiment)
 };
 
 struct LocArgs
 {
-  DeviceResult * host_result;  // mapped pinned host slot: the last block publishes the result there (no D2H copy node)
+  DeviceResult * host_result;  // mapped pinned host slot: the last block writes loc_comp / status_hist there (no D2H copy node)
   const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = use result->eig_* from K3
   const float4 * src;
   int n;

@@ -1053,11 +1053,18 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
   double * s_sum = s_aux + (kThreads / EW) * EW;
   fold_rows<EW>(a.partials, gridDim.x, NENT + 4, s_aux, s_sum);
-  if (threadIdx.x < NENT) a.result->sums[threadIdx.x] = s_sum[threadIdx.x];
-  if (threadIdx.x == NENT) a.result->n_knn = static_cast<unsigned long long>(s_sum[NENT]);
-  if (threadIdx.x == NENT + 1) a.result->n_cand = static_cast<unsigned long long>(s_sum[NENT + 1]);
-  if (threadIdx.x == NENT + 2) a.result->n_fallback = static_cast<unsigned long long>(s_sum[NENT + 2]);
-  if (threadIdx.x == NENT + 3) a.result->n_scanned = static_cast<unsigned long long>(s_sum[NENT + 3]);
+  // Results go to the device struct (K4 reads the eigenbases there) AND straight to the caller's mapped
+  // pinned host slot: no D2H copy node, and K4's tail does not have to relay them.
+#define MH_PUT(field, val)                          \
+  do {                                              \
+    a.result->field = (val);                        \
+    if (a.host_result) a.host_result->field = (val); \
+  } while (0)
+  if (threadIdx.x < NENT) MH_PUT(sums[threadIdx.x], s_sum[threadIdx.x]);
+  if (threadIdx.x == NENT) MH_PUT(n_knn, static_cast<unsigned long long>(s_sum[NENT]));
+  if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
+  if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
+  if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
   if (threadIdx.x == 0 || threadIdx.x == 64) {
     // computeLocalizability on the rot / trans 3x3 blocks of J_s^T J_s (:405-411), one wave each
     auto ent_of = [](int r, int c) { return r * NV - r * (r - 1) / 2 + (c - r); };  // r <= c
@@ -1070,11 +1077,20 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       }
     double loc[3], E[9];
     compute_localizability(Hb, loc, E);
-    double * dl = o ? a.result->loc_trans_final : a.result->loc_rot_final;
-    double * de = o ? a.result->eig_trans : a.result->eig_rot;
-    for (int i = 0; i < 3; ++i) dl[i] = loc[i];
-    for (int i = 0; i < 9; ++i) de[i] = E[i];
+    for (int i = 0; i < 3; ++i) {
+      if (o)
+        MH_PUT(loc_trans_final[i], loc[i]);
+      else
+        MH_PUT(loc_rot_final[i], loc[i]);
+    }
+    for (int i = 0; i < 9; ++i) {
+      if (o)
+        MH_PUT(eig_trans[i], E[i]);
+      else
+        MH_PUT(eig_rot[i], E[i]);
+    }
   }
+#undef MH_PUT
   MH_STAMP(a.dbg, 7);
 }
 
@@ -1163,21 +1179,12 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
-  // publish the complete result into the caller's mapped pinned host slot: one 8-byte store per
-  // thread instead of a separate D2H copy node behind the kernel (saves ~4.5 us per linearize)
-  __syncthreads();
+  // this kernel's outputs also go to the caller's mapped pinned host slot, straight from the LDS sums (K3's
+  // last block already wrote its part there); the end of the kernel makes them visible to the host
   if (a.host_result) {
-    constexpr int kWords = static_cast<int>(sizeof(DeviceResult) / 8);
-    static_assert(sizeof(DeviceResult) % 8 == 0, "DeviceResult is copied as 8-byte words");
-    const unsigned long long * src = reinterpret_cast<const unsigned long long *>(a.result);
-    unsigned long long * dst = reinterpret_cast<unsigned long long *>(a.host_result);
-    for (int w = threadIdx.x; w < kWords; w += kThreads) dst[w] = src[w];  // K3's part (previous kernel)
-    __syncthreads();
-    // this kernel's own outputs go to the host slot straight from the registers that hold them
     if (threadIdx.x < 6) a.host_result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
     if (threadIdx.x >= 6 && threadIdx.x < 15)
       a.host_result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
-    __threadfence_system();
   }
 }
 

@@ -31,7 +31,7 @@ struct mh_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  bool profiling = false;
+  int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
   hipEvent_t timer[2] = {nullptr, nullptr};
 };
 
@@ -432,7 +432,7 @@ void mh_shutdown(mh_ctx * ctx)
 int mh_set_profiling(mh_ctx * ctx, int on)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_set_profiling: ctx is NULL");
-  ctx->profiling = on != 0;
+  ctx->profiling = on < 0 ? 0 : on;
   return MH_OK;
 }
 
@@ -832,6 +832,7 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   a.partials = static_cast<double *>(icp->d_partials.p);
   a.ticket = static_cast<unsigned int *>(icp->d_ticket.p);
   a.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
+  a.host_result = nullptr;  // set below once the slot is known
   a.dbg = static_cast<unsigned long long *>(icp->d_dbg.p);
   {
     const char * rp = std::getenv("MH_REPS");
@@ -856,19 +857,22 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   std::memcpy(pc.R, a.R, sizeof(pc.R));
   for (int i = 0; i < 3; ++i) pc.gz[i] = -g_unit[i];
   pc.linearize_count = ++icp->linearize_count;
-  if (ctx->profiling) {
+  // each event record is a barrier + signal packet on the stream (~4 us): sampled calls only
+  const bool timed = ctx->profiling > 0 && (pc.linearize_count % ctx->profiling) == 0;
+  if (timed) {
     for (int i = 0; i < 3; ++i) pc.ev[i] = icp->events[slot][i];
     MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
   } else {
     pc.ev[0] = pc.ev[1] = pc.ev[2] = nullptr;
   }
   if (a.n > 0) {
+    a.host_result = icp->d_h_results + slot;
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
-    if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     l.host_result = icp->d_h_results + slot;
     MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
-    if (ctx->profiling) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
-  } else if (ctx->profiling) {
+    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+  } else if (timed) {
     MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   }
@@ -892,6 +896,8 @@ int mh_icp_wait(mh_icp * icp)
     if (pc.ev[0]) {
       (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
       (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
+    } else {
+      pc.out->gpu_ms_linearize = pc.out->gpu_ms_localizability = -1.0f;  // this call was not timed
     }
   }
   icp->n_pending = 0;
