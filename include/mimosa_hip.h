@@ -60,6 +60,40 @@ typedef struct mh_point32 {
   float range;
 } mh_point32;
 
+/* lidar::PointOuster, include/mimosa/lidar/point.hpp:42-50 (32 bytes, 16-byte aligned): what
+ * Manager::prepareInput<PointOuster> reads from the sensor_msgs::PointCloud2 (lidar/manager.cpp:155-157) */
+typedef struct mh_ouster_point {
+  float x, y, z, pad;
+  float intensity;
+  uint32_t t; /* ns since the beginning of the scan */
+  uint16_t reflectivity;
+  uint16_t ring;
+  uint32_t pad2;
+} mh_ouster_point;
+
+/* The fields of lidar::ManagerConfig (include/mimosa/lidar/manager.hpp:24-41) and GeometricConfig
+ * (geometric_config.hpp:43-44) that Manager::prepareInput reads. */
+typedef struct mh_input_config {
+  float range_min, range_max;         /* metres; compared as squares in float (manager.cpp:19-20, :281-282) */
+  float intensity_min, intensity_max; /* manager.cpp:272-276 */
+  float ns_max;                       /* manager.cpp:306 */
+  float z_offset;                     /* -lidar_to_sensor_transform[11] / 1000 (manager.cpp:18, :313) */
+  int32_t create_full_res_pointcloud; /* loop stride 1 instead of point_skip_divisor (manager.cpp:244-246) */
+  int32_t point_skip_divisor;         /* geometric subset: raw index % divisor == 0 (manager.cpp:318) */
+  int32_t ring_skip_divisor;          /* geometric subset: ring % divisor == 0 (manager.cpp:331) */
+} mh_input_config;
+
+typedef struct mh_scan_info {
+  uint64_t n_in;          /* raw points given to mh_scan_prepare_input */
+  uint64_t n_full;        /* points_full_: points that passed the filters */
+  uint64_t n_geometric;   /* geometric_point_idxs_ */
+  uint64_t n_unique_ns;   /* unique_ns_ */
+  uint64_t n_body;        /* Be_cloud_ (after mh_scan_preprocess_geometric) */
+  uint64_t n_downsampled; /* sm_Be_cloud_ds_ */
+  uint32_t last_point_ns; /* corrected_ts_ = header_ts + last_point_ns * 1e-9 (manager.cpp:336) */
+  uint32_t pad;
+} mh_scan_info;
+
 /* lidar::RegistrationConfig, include/mimosa/lidar/geometric_config.hpp:17-33 (same field order) */
 typedef struct mh_reg_config {
   float source_voxel_grid_filter_leaf_size;
@@ -132,6 +166,7 @@ typedef struct mh_icp_result {
 typedef struct mh_ctx mh_ctx;
 typedef struct mh_map mh_map;
 typedef struct mh_icp mh_icp;
+typedef struct mh_scan mh_scan;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int mh_abi_version(void);
@@ -229,6 +264,37 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
 /* p <- R p + t in float for a whole cloud (body transform geometric.cpp:154-161, world transform
  * geometric.cpp:483-490). In place, host buffers. */
 int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3]);
+
+
+/* ---- device-resident scan front end ------------------------------------------------------------
+ * The raw cloud is uploaded once; input filter, deskew, body-frame subset and voxel down-sampler run on
+ * the device and the ICP factor takes its source cloud from there (no host round trip between
+ * Manager::prepareInput and the first linearize).  Every stage reproduces the reference's sequential
+ * result exactly, including output order.  Call order: prepare_input -> (caller propagates the IMU over
+ * unique_ns) -> deskew -> preprocess_geometric -> mh_icp_create_from_scan. */
+int mh_scan_create(mh_ctx * ctx, mh_scan ** out);
+void mh_scan_destroy(mh_scan * scan);
+/* Manager::prepareInput<PointOuster> (lidar/manager.cpp:149-383): NaN / intensity / range / ns_max filters,
+ * z offset, points_full_ (order preserved), geometric subset indices, distinct timestamps (ascending). */
+int mh_scan_prepare_input(mh_scan * scan, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg,
+                          mh_scan_info * info);
+/* unique_ns_ (lidar/manager.cpp:344-368), ascending; the caller's IMU propagation needs them on the host. */
+int mh_scan_get_unique_ns(const mh_scan * scan, uint32_t * out, size_t capacity, size_t * n_out);
+/* Manager::deskewPoints' per-point part (lidar/manager.cpp:496-509) on points_full_, in place:
+ * Rt12[g] = pose (row-major R, then t, float) of the group with timestamp unique_ns[g]. */
+int mh_scan_deskew(mh_scan * scan, const float * Rt12, size_t n_groups);
+/* Geometric::preprocess (geometric.cpp:128-183): Be_cloud_ = R_B_L * points_full_[geometric idx] + t_B_L
+ * (f32), then Geometric::downsample (geometric.cpp:55-126) into sm_Be_cloud_ds_.  max_points_per_voxel <= 20
+ * (the reference passes the literal 20). */
+int mh_scan_preprocess_geometric(mh_scan * scan, const float R_B_L[9], const float t_B_L[3], double leaf_size,
+                                 int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info);
+/* Copies a stage's cloud to the host.  which: 0 points_full_, 1 Be_cloud_, 2 sm_Be_cloud_ds_. */
+int mh_scan_get_points(const mh_scan * scan, int which, mh_point32 * out, size_t capacity, size_t * n_out);
+/* geometric_point_idxs_ (indices into points_full_) / the indices into Be_cloud_ that the down-sampler kept. */
+int mh_scan_get_indices(const mh_scan * scan, int which, uint32_t * out, size_t capacity, size_t * n_out);
+/* ICPFactor ctor (geometric_factor.hpp:119-142) with sm_Be_cloud_ds_ taken from the device. */
+int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * scan, const mh_reg_config * cfg,
+                            int is_binary, mh_icp ** out);
 
 #ifdef __cplusplus
 }

@@ -22,9 +22,10 @@ SOURCES = [
     ("icp_kernels.hip", []),
     ("deskew_kernels.hip", ["-ffp-contract=off"]),
     ("order_kernels.hip", []),
+    ("scan_kernels.hip", ["-ffp-contract=off"]),
     ("mh_api.hip", []),
 ]
-HEADERS = ["icp_device.hpp", "math3.hpp", "voxel_map.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
+HEADERS = ["icp_device.hpp", "scan_device.hpp", "math3.hpp", "voxel_map.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
 
 
 def _hipcc() -> str:

@@ -25,6 +25,8 @@ EXPORTS = [
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
+    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_get_unique_ns", "mh_scan_deskew",
+    "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
 ]
 
 
@@ -92,6 +94,36 @@ class IcpResult(C.Structure):
         return d
 
 
+class InputConfig(C.Structure):
+    """mh_input_config: the ManagerConfig / GeometricConfig fields Manager::prepareInput reads."""
+    _fields_ = [
+        ("range_min", C.c_float), ("range_max", C.c_float), ("intensity_min", C.c_float), ("intensity_max", C.c_float),
+        ("ns_max", C.c_float), ("z_offset", C.c_float), ("create_full_res_pointcloud", C.c_int32),
+        ("point_skip_divisor", C.c_int32), ("ring_skip_divisor", C.c_int32),
+    ]
+
+
+class ScanInfo(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_uint64), ("n_full", C.c_uint64), ("n_geometric", C.c_uint64), ("n_unique_ns", C.c_uint64),
+        ("n_body", C.c_uint64), ("n_downsampled", C.c_uint64), ("last_point_ns", C.c_uint32), ("pad", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "pad"}
+
+
+def make_input_config(**kw) -> InputConfig:
+    """ENWIDE manager block (config/enwide/params.yaml:66-72) + geometric skip divisors (:79-80) by default."""
+    d = dict(range_min=0.2, range_max=100.0, intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9, z_offset=0.0,
+             create_full_res_pointcloud=1, point_skip_divisor=4, ring_skip_divisor=1)
+    d.update(kw)
+    c = InputConfig()
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
 def make_reg_config(**kw) -> RegConfig:
     c = RegConfig()
     for k, v in kw.items():
@@ -153,6 +185,16 @@ def load(build_if_missing: bool = True):
     L.mh_icp_size.restype = sz
     L.mh_deskew.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
     L.mh_transform_f32.argtypes = [vp, vp, sz, vp, vp]
+    L.mh_scan_create.argtypes = [vp, pvp]
+    L.mh_scan_destroy.argtypes = [vp]
+    L.mh_scan_destroy.restype = None
+    L.mh_scan_prepare_input.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
+    L.mh_scan_get_unique_ns.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.mh_scan_deskew.argtypes = [vp, vp, sz]
+    L.mh_scan_preprocess_geometric.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.POINTER(ScanInfo)]
+    L.mh_scan_get_points.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
+    L.mh_scan_get_indices.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
+    L.mh_icp_create_from_scan.argtypes = [vp, vp, vp, C.POINTER(RegConfig), i32, pvp]
     _LIB = L
     return L
 
@@ -284,6 +326,80 @@ class VoxelMap:
     def __del__(self):
         try:
             self.release()
+        except Exception:
+            pass
+
+
+class Scan:
+    """Device-resident scan front end: Manager::prepareInput -> deskewPoints -> Geometric::preprocess
+    (src/lidar/manager.cpp:149-512, src/lidar/geometric.cpp:55-183) with the cloud staying on the GPU."""
+    FULL, BODY, DOWNSAMPLED = 0, 1, 2
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.L = ctx, ctx.L
+        ctx._children += 1
+        h = C.c_void_p()
+        ctx.check(self.L.mh_scan_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def prepare_input(self, raw, cfg: InputConfig) -> dict:
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype.itemsize == 32
+        info = ScanInfo()
+        self.ctx.check(self.L.mh_scan_prepare_input(self.h, _p(raw), len(raw), C.byref(cfg), C.byref(info)))
+        return info.as_dict()
+
+    def unique_ns(self):
+        n = C.c_size_t()
+        self.ctx.check(self.L.mh_scan_get_unique_ns(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        self.ctx.check(self.L.mh_scan_get_unique_ns(self.h, _p(out), out.size, C.byref(n)))
+        return out
+
+    def deskew(self, Rt12):
+        P = np.ascontiguousarray(Rt12, dtype=np.float32).reshape(-1, 12)
+        self.ctx.check(self.L.mh_scan_deskew(self.h, _p(P), len(P)))
+
+    def preprocess_geometric(self, R_B_L, t_B_L, leaf=0.5, max_pts=20, min_dist=0.15) -> dict:
+        R = np.ascontiguousarray(R_B_L, dtype=np.float32)
+        t = np.ascontiguousarray(t_B_L, dtype=np.float32)
+        info = ScanInfo()
+        self.ctx.check(self.L.mh_scan_preprocess_geometric(self.h, _p(R), _p(t), float(leaf), int(max_pts), float(min_dist),
+                                                           C.byref(info)))
+        return info.as_dict()
+
+    def points(self, which):
+        from .synth import POINT_DTYPE
+        n = C.c_size_t()
+        self.ctx.check(self.L.mh_scan_get_points(self.h, which, None, 0, C.byref(n)))
+        out = np.zeros(n.value, POINT_DTYPE)
+        self.ctx.check(self.L.mh_scan_get_points(self.h, which, _p(out), out.size, C.byref(n)))
+        return out
+
+    def indices(self, which):
+        n = C.c_size_t()
+        self.ctx.check(self.L.mh_scan_get_indices(self.h, which, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        self.ctx.check(self.L.mh_scan_get_indices(self.h, which, _p(out), out.size, C.byref(n)))
+        return out
+
+    def make_factor(self, map_, cfg: RegConfig, binary=False):
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_icp_create_from_scan(self.ctx.h, map_.h, self.h, C.byref(cfg), int(binary), C.byref(h)))
+        n = int(self.L.mh_icp_size(h))
+        f = ICPFactor(self.ctx, map_, None, None, _h=h, _n=n)
+        f._keep = []
+        return f
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.mh_scan_destroy(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.destroy()
         except Exception:
             pass
 

@@ -80,7 +80,7 @@ constexpr ScanTab make_scan_tab()
 }
 constexpr ScanTab kScan = make_scan_tab();
 __constant__ ScanTab kScanDev = make_scan_tab();
-constexpr int kScanLutWords = 64;  // LDS copy of one row: [b] = offset code, [32 + b] = traversal rank o
+constexpr int kScanLutWords = 4 * 32;  // LDS copy of one row, 16 B per scan position: voxel offset in grid units (3 x f32), traversal rank o
 
 // Every block copies its mode's row into LDS once: the scan cursor indexes it with a per-lane value (one
 // ds_read instead of a 12-instruction register LUT or a scattered constant-memory load).
@@ -90,8 +90,11 @@ __device__ __forceinline__ void fill_scan_lut(uint32_t * lut)
   constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
   if (threadIdx.x < kMaxOff) {
     const uint32_t e = kScanDev.ent[row][threadIdx.x];
-    lut[threadIdx.x] = e & 63u;
-    lut[32 + threadIdx.x] = e >> 6;
+    const float q = static_cast<float>(1 << kQuantBits);
+    lut[4 * threadIdx.x + 0] = __float_as_uint((static_cast<float>(e & 3u) - 1.f) * q);
+    lut[4 * threadIdx.x + 1] = __float_as_uint((static_cast<float>((e >> 2) & 3u) - 1.f) * q);
+    lut[4 * threadIdx.x + 2] = __float_as_uint((static_cast<float>((e >> 4) & 3u) - 1.f) * q);
+    lut[4 * threadIdx.x + 3] = e >> 6;
   }
 }
 
@@ -264,6 +267,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint32_t ck[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
+  // 32-bit literals used per candidate live in VGPRs: (a & lit) | lit needs two instructions with literal
+  // operands (one literal per VOP3), one v_and_or_b32 with register operands
+  uint32_t c_ymask = 0xFFC00u, c_ymagic = 0x46000000u, c_kmask = ~0x3FFu;
+  asm volatile("" : "+v"(c_ymask), "+v"(c_ymagic), "+v"(c_kmask));
   // Key of one candidate (no insertion): packed word w_, voxel offsets in grid units, payload, validity.
   // y is decoded by OR-ing its bit field (bits 10-19) into the mantissa of 2^13 (whose mantissa bit 10 weighs
   // 1, ulp 2^-10): one v_and_or + one v_sub instead of extract + convert + add; the 2^13 is folded into the
@@ -272,10 +279,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #define MH_COARSE_KEY(key_, w_, ofx, mfy, ofz, payload, valid)                                        \
   do {                                                                                                 \
     const float dx_ = static_cast<float>((w_) & 1023u) + (ofx);                                        \
-    const float dy_ = __uint_as_float(((w_) & 0xFFC00u) | 0x46000000u) - (mfy);                        \
+    const float dy_ = __uint_as_float(((w_) & c_ymask) | c_ymagic) - (mfy);                            \
     const float dz_ = static_cast<float>(((w_) >> 20) & 1023u) + (ofz);                                \
     const float d_ = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;                                                \
-    const uint32_t t_ = (__float_as_uint(d_) & ~0x3FFu) | (payload);                                   \
+    const uint32_t t_ = (__float_as_uint(d_) & c_kmask) | (payload);                                   \
     (key_) = (valid) ? t_ : 0xFFFFFFFFu;                                                               \
   } while (0)
 #define MH_CE(a_, b_)                        \
@@ -289,13 +296,15 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // sequence), bitonic-merge the 8 (12 compare-exchanges): 38 min/max ops instead of 4 x 15 for four serial
   // insertions.  Other KK (generic k <= 8 path): serial insertion.
 #define MH_COARSE_QUAD(qw, ofx, ofy, ofz, o_, s0_, cnt_)                                               \
+  MH_COARSE_QUAD_M(qw, ofx, 8192.0f - (ofy), ofz, (static_cast<uint32_t>(o_) << 5) | (s0_), s0_, cnt_)
+  // core: y offset already folded with the 2^13 magic, pb_ = payload of the quad's slot 0
+#define MH_COARSE_QUAD_M(qw, ofx, mfy_, ofz, pb_, s0_, cnt_)                                           \
   do {                                                                                                 \
-    const float mfy_ = 8192.0f - (ofy);                                                                \
     uint32_t k0_, k1_, k2_, k3_;                                                                       \
-    MH_COARSE_KEY(k0_, (qw).x, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 0u), (s0_) + 0u < (cnt_)); \
-    MH_COARSE_KEY(k1_, (qw).y, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 1u), (s0_) + 1u < (cnt_)); \
-    MH_COARSE_KEY(k2_, (qw).z, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 2u), (s0_) + 2u < (cnt_)); \
-    MH_COARSE_KEY(k3_, (qw).w, ofx, mfy_, ofz, (static_cast<uint32_t>(o_) << 5) | ((s0_) + 3u), (s0_) + 3u < (cnt_)); \
+    MH_COARSE_KEY(k0_, (qw).x, ofx, mfy_, ofz, (pb_), (s0_) + 0u < (cnt_));                            \
+    MH_COARSE_KEY(k1_, (qw).y, ofx, mfy_, ofz, (pb_) | 1u, (s0_) + 1u < (cnt_));                       \
+    MH_COARSE_KEY(k2_, (qw).z, ofx, mfy_, ofz, (pb_) | 2u, (s0_) + 2u < (cnt_));                       \
+    MH_COARSE_KEY(k3_, (qw).w, ofx, mfy_, ofz, (pb_) | 3u, (s0_) + 3u < (cnt_));                       \
     if constexpr (KK == 8) {                                                                           \
       MH_CE(k0_, k1_); MH_CE(k2_, k3_); MH_CE(k0_, k2_); MH_CE(k1_, k3_); MH_CE(k1_, k2_);             \
       ck[4] = min(ck[4], k3_); ck[5] = min(ck[5], k2_); ck[6] = min(ck[6], k1_); ck[7] = min(ck[7], k0_); \
@@ -388,7 +397,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     int o_cur = 0;
     uint32_t qd = 8u, nq_cur = 0u;  // "exhausted": the first prefetch enters the first listed voxel
     uint4 pw[kPipe];
-    uint32_t pmeta[kPipe];  // offset code | b << 6 | live point count << 11 | quad << 16
+    float4 pofs[kPipe];     // voxel offset in grid units (x, y, z) of the staged quad's voxel
+    uint32_t pmeta[kPipe];  // b << 6 | live point count << 11 | quad << 16
+    const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
+    const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
     // No select on the load index: a `live ? index : 0` makes the compiler sink the LDS read of the cell word
     // into a branch (four dependent LDS round trips behind s_waitcnt lgkmcnt(0) per trip).  Every list entry
     // names a mapped voxel and the quad index is clamped, so a dead stage just loads a quad it never uses.
@@ -404,10 +416,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       nq_cur = static_cast<uint32_t>((o_cur < 21 ? qc0 : qc1) >> (3 * (o_cur < 21 ? o_cur : o_cur - 21))) & 7u; \
     const bool live_ = qd < nq_cur;                                                                 \
     const uint32_t e_ = list[o_cur * lds_stride]; /* off the cursor's dependency chain */           \
-    const uint32_t code_ = scan_lut[o_cur];                                                         \
+    pofs[u] = lut4[o_cur];                                                                          \
     const uint32_t idx_ = (e_ >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1)); \
     pw[u] = map.qbuckets[idx_];                                                                     \
-    pmeta[u] = code_ | (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? (e_ & 31u) : 0u) << 11) | (qd << 16); \
+    pmeta[u] = (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? (e_ & 31u) : 0u) << 11) | (qd << 16); \
     ++qd;                                                                                           \
   } while (0)
 #pragma unroll
@@ -430,13 +442,11 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       for (int u = 0; u < kPipe; ++u) {
         const uint4 qw = pw[u];
         const uint32_t meta = pmeta[u];
+        const float4 vo = pofs[u];
         MH_PREFETCH(u);  // refill this stage
-        const uint32_t b_ = (meta >> 6) & 31u, cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
+        const uint32_t cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
         n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
-        const float ofx = static_cast<float>(meta & 3u) * kQ + (0.5f - kQ - qg0);
-        const float ofy = static_cast<float>((meta >> 2) & 3u) * kQ + (0.5f - kQ - qg1);
-        const float ofz = static_cast<float>((meta >> 4) & 3u) * kQ + (0.5f - kQ - qg2);
-        MH_COARSE_QUAD(qw, ofx, ofy, ofz, b_, s0_, cnt_);
+        MH_COARSE_QUAD_M(qw, vo.x + cx0, cy1 - vo.y, vo.z + cz2, ((meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
       }
     }
 #undef MH_PREFETCH
@@ -457,6 +467,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   const uint32_t rank = static_cast<uint32_t>(__popcll(act & ((1ull << lane) - 1ull)));
   const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem);  // centre + every neighbour voxel the cursor entered
 #undef MH_COARSE_QUAD
+#undef MH_COARSE_QUAD_M
 #undef MH_COARSE_KEY
 #undef MH_CE
   MH_STAMP(dbg, 2);
@@ -480,7 +491,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       const uint32_t e = list[b * lds_stride];
       sidx[u] = (e >> 5) * kBucketStride + (p & 31u);  // empty survivor slot: slot 31 of a listed voxel (mapped, unused)
       sc[u] = map.buckets[sidx[u]];
-      srank[u] = (scan_lut[32 + b] << 5) | (p & 31u);  // (traversal rank of the voxel, slot): the order push() sees
+      srank[u] = (scan_lut[4 * b + 3] << 5) | (p & 31u);  // (traversal rank of the voxel, slot): the order push() sees
     }
 #pragma unroll
     for (int u = 0; u < KK; ++u) {

@@ -18,6 +18,7 @@
 #include "../../include/mimosa_hip.h"
 #include "icp_device.hpp"
 #include "math3.hpp"
+#include "scan_device.hpp"
 #include "voxel_map.hpp"
 
 namespace
@@ -628,10 +629,10 @@ static int icp_alloc(mh_icp * icp)
   return MH_OK;
 }
 
-int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
-                  int is_binary, mh_icp ** out)
+// source: host cloud (d_source == nullptr) or a cloud already on the device (source == nullptr)
+static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_point32 * d_source, size_t n,
+                             const mh_reg_config * cfg, int is_binary, mh_icp ** out)
 {
-  if (!ctx || !map || !cfg || !out || (!source && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: NULL argument");
   *out = nullptr;
   // A map may be shared read-only by factors of several contexts (= HIP streams) of the SAME device:
   // uploads are host-synchronised on the map's own stream before any factor kernel is enqueued.
@@ -656,11 +657,14 @@ int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t 
   // source cloud: upload the 32-byte records, pack xyz into the 16-byte layout the kernel reads
   if (n) {
     mh_point32 * d_pts = nullptr;
-    MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
-    MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, mh::launch_pack_xyz(d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p), ctx->stream));
+    if (!d_source) {
+      MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
+      MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+    }
+    MH_HIP(ctx, mh::launch_pack_xyz(d_source ? d_source : d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p),
+                                    ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_pts);
+    if (d_pts) (void)hipFree(d_pts);
     // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
     const char * ns = std::getenv("MH_NO_SORT");
     if (!(ns && ns[0] == '1')) {
@@ -700,6 +704,13 @@ int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t 
   icp->cold = true;
   *out = icp;
   return MH_OK;
+}
+
+int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
+                  int is_binary, mh_icp ** out)
+{
+  if (!ctx || !map || !cfg || !out || (!source && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: NULL argument");
+  return icp_create_common(ctx, map, source, nullptr, n, cfg, is_binary, out);
 }
 
 int mh_icp_clone(const mh_icp * src, mh_icp ** out)
@@ -1058,6 +1069,225 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
   (void)hipFree(d_pts);
   (void)hipFree(d_rt);
   return MH_OK;
+}
+
+}  // extern "C"
+
+// ---- device-resident scan front end (scan_kernels.hip) ------------------------------------------
+struct mh_scan
+{
+  mh_ctx * ctx;
+  DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_temp, d_rt;
+  DevBuf d_u32[4];  // flag / pos scratch (prepare_input), keys / flags / pos (unique, down-sampler)
+  DevBuf d_u64[2], d_seg, d_first;
+  mh::ScanCounters c{};
+  size_t n_in = 0, n_body = 0;
+  bool prepared = false, preprocessed = false;
+};
+
+namespace
+{
+int scan_fetch_counters(mh_scan * s)
+{
+  mh_ctx * ctx = s->ctx;
+  MH_HIP(ctx, hipMemcpyAsync(&s->c, s->d_counters.p, sizeof(s->c), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+void scan_fill_info(const mh_scan * s, mh_scan_info * info)
+{
+  if (!info) return;
+  std::memset(info, 0, sizeof(*info));
+  info->n_in = s->n_in;
+  info->n_full = s->c.n_full;
+  info->n_geometric = s->c.n_geometric;
+  info->n_unique_ns = s->c.n_unique_ns;
+  info->n_body = s->n_body;
+  info->n_downsampled = s->preprocessed ? s->c.n_downsampled : 0;
+  info->last_point_ns = s->c.last_point_ns;
+}
+}  // namespace
+
+extern "C" {
+
+int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
+{
+  if (!ctx || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_create: NULL argument");
+  *out = nullptr;
+  mh_scan * s = new (std::nothrow) mh_scan;
+  if (!s) return fail(ctx, MH_ERR_OOM, "mh_scan_create: host allocation failed");
+  s->ctx = ctx;
+  *out = s;
+  return MH_OK;
+}
+
+void mh_scan_destroy(mh_scan * s)
+{
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
+                     &s->d_temp, &s->d_rt, &s->d_u32[0], &s->d_u32[1], &s->d_u32[2], &s->d_u32[3], &s->d_u64[0], &s->d_u64[1],
+                     &s->d_seg, &s->d_first})
+    b->release();
+  delete s;
+}
+
+int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
+{
+  if (!s || !cfg || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_prepare_input: cloud too large");
+  if (cfg->point_skip_divisor < 1 || cfg->ring_skip_divisor < 1)
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: skip divisors must be >= 1");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  s->prepared = s->preprocessed = false;
+  s->n_in = n;
+  s->n_body = 0;
+  const size_t m = n ? n : 1;
+  MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));
+  MH_HIP(ctx, s->d_full.reserve(m * sizeof(mh_point32), ctx->stream, false));
+  MH_HIP(ctx, s->d_geo_idx.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_unique.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_counters.reserve(sizeof(mh::ScanCounters), ctx->stream, false));
+  for (auto & b : s->d_u32) MH_HIP(ctx, b.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_temp.reserve(mh::scan_temp_bytes(m), ctx->stream, false));
+  if (n) MH_HIP(ctx, hipMemcpyAsync(s->d_raw.p, raw, n * sizeof(mh_ouster_point), hipMemcpyHostToDevice, ctx->stream));
+  auto * cnt = static_cast<mh::ScanCounters *>(s->d_counters.p);
+  uint32_t * u[4];
+  for (int i = 0; i < 4; ++i) u[i] = static_cast<uint32_t *>(s->d_u32[i].p);
+  MH_HIP(ctx, mh::launch_input_filter(static_cast<const mh_ouster_point *>(s->d_raw.p), static_cast<uint32_t>(n), *cfg, u[0],
+                                      u[1], u[2], u[3], static_cast<mh_point32 *>(s->d_full.p),
+                                      static_cast<uint32_t *>(s->d_geo_idx.p), cnt, s->d_temp.p, s->d_temp.cap, ctx->stream));
+  MH_HIP(ctx, mh::launch_unique_ns(static_cast<const mh_point32 *>(s->d_full.p), cnt, static_cast<uint32_t>(n), u[0], u[1],
+                                   u[2], u[3], static_cast<uint32_t *>(s->d_unique.p), cnt, s->d_temp.p, s->d_temp.cap,
+                                   ctx->stream));
+  const int rc = scan_fetch_counters(s);
+  if (rc != MH_OK) return rc;
+  s->prepared = true;
+  scan_fill_info(s, info);
+  return MH_OK;
+}
+
+int mh_scan_get_unique_ns(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
+{
+  if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_unique_ns: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (!s->prepared) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_unique_ns: no mh_scan_prepare_input before");
+  *n_out = s->c.n_unique_ns;
+  if (!out) return MH_OK;
+  if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_unique_ns: buffer too small");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, s->d_unique.p, *n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
+{
+  if (!s || (!Rt12 && n_groups)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_deskew: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (!s->prepared) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_deskew: no mh_scan_prepare_input before");
+  if (n_groups != s->c.n_unique_ns) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_deskew: one pose per unique timestamp");
+  if (s->c.n_full == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, s->d_rt.reserve((n_groups + 1) * 12 * sizeof(float), ctx->stream, false));
+  MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, Rt12, n_groups * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, mh::launch_deskew(static_cast<mh_point32 *>(s->d_full.p), static_cast<int>(s->c.n_full),
+                                static_cast<const uint32_t *>(s->d_unique.p), static_cast<const float *>(s->d_rt.p),
+                                static_cast<int>(n_groups), nullptr, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // Rt12 is the caller's buffer
+  s->preprocessed = false;
+  return MH_OK;
+}
+
+int mh_scan_preprocess_geometric(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
+                                 int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info)
+{
+  if (!s || !R_B_L || !t_B_L) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_preprocess_geometric: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (!s->prepared) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_preprocess_geometric: no mh_scan_prepare_input before");
+  if (!(leaf_size > 0.0)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_preprocess_geometric: leaf_size must be > 0");
+  if (max_points_per_voxel < 1 || max_points_per_voxel > mh::kBucketStride)
+    return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_preprocess_geometric: max_points_per_voxel must be in 1..20");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = s->c.n_geometric, m = n ? n : 1;
+  s->n_body = n;
+  MH_HIP(ctx, s->d_body.reserve(m * sizeof(mh_point32), ctx->stream, false));
+  MH_HIP(ctx, s->d_ds.reserve(m * sizeof(mh_point32), ctx->stream, false));
+  MH_HIP(ctx, s->d_kept_idx.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  for (auto & b : s->d_u64) MH_HIP(ctx, b.reserve(m * sizeof(uint64_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_seg.reserve((m + 1) * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_first.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_rt.reserve(12 * sizeof(float), ctx->stream, false));
+  float rt[12];
+  std::memcpy(rt, R_B_L, 9 * sizeof(float));
+  std::memcpy(rt + 9, t_B_L, 3 * sizeof(float));
+  MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rt is a stack buffer
+  auto * cnt = static_cast<mh::ScanCounters *>(s->d_counters.p);
+  MH_HIP(ctx, mh::launch_gather_transform(static_cast<const mh_point32 *>(s->d_full.p),
+                                          static_cast<const uint32_t *>(s->d_geo_idx.p), static_cast<uint32_t>(n),
+                                          static_cast<const float *>(s->d_rt.p), static_cast<mh_point32 *>(s->d_body.p),
+                                          ctx->stream));
+  MH_HIP(ctx, mh::launch_downsample(static_cast<const mh_point32 *>(s->d_body.p), static_cast<uint32_t>(n), leaf_size,
+                                    static_cast<uint32_t>(max_points_per_voxel), min_dist_in_voxel,
+                                    static_cast<uint64_t *>(s->d_u64[0].p), static_cast<uint64_t *>(s->d_u64[1].p),
+                                    static_cast<uint32_t *>(s->d_u32[0].p), static_cast<uint32_t *>(s->d_u32[1].p),
+                                    static_cast<uint32_t *>(s->d_u32[2].p), static_cast<uint32_t *>(s->d_u32[3].p),
+                                    static_cast<uint32_t *>(s->d_seg.p), static_cast<uint32_t *>(s->d_first.p),
+                                    static_cast<uint32_t *>(s->d_kept_idx.p), static_cast<mh_point32 *>(s->d_ds.p), cnt,
+                                    s->d_temp.p, s->d_temp.cap, ctx->stream));
+  const int rc = scan_fetch_counters(s);
+  if (rc != MH_OK) return rc;
+  if (n == 0) s->c.n_downsampled = 0;
+  if (s->c.bad_coord) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_preprocess_geometric: a voxel coordinate exceeds +-2^20");
+  s->preprocessed = true;
+  scan_fill_info(s, info);
+  return MH_OK;
+}
+
+int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
+{
+  if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_points: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (!s->prepared || (which != 0 && !s->preprocessed) || which < 0 || which > 2)
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_points: that stage has not run");
+  const DevBuf & b = which == 0 ? s->d_full : (which == 1 ? s->d_body : s->d_ds);
+  *n_out = which == 0 ? s->c.n_full : (which == 1 ? s->n_body : s->c.n_downsampled);
+  if (!out) return MH_OK;
+  if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_points: buffer too small");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, b.p, *n_out * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_scan_get_indices(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
+{
+  if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_indices: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (!s->prepared || (which == 1 && !s->preprocessed) || which < 0 || which > 1)
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_indices: that stage has not run");
+  const DevBuf & b = which == 0 ? s->d_geo_idx : s->d_kept_idx;
+  *n_out = which == 0 ? s->c.n_geometric : s->c.n_downsampled;
+  if (!out) return MH_OK;
+  if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_indices: buffer too small");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, b.p, *n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
+                            mh_icp ** out)
+{
+  if (!ctx || !map || !s || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: NULL argument");
+  if (!s->preprocessed) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: no mh_scan_preprocess_geometric before");
+  if (s->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: scan lives on another device");
+  // the scan's stream has been synchronised by mh_scan_preprocess_geometric: its buffers are complete
+  return icp_create_common(ctx, map, nullptr, static_cast<const mh_point32 *>(s->d_ds.p), s->c.n_downsampled, cfg, is_binary,
+                           out);
 }
 
 }  // extern "C"

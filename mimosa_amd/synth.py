@@ -200,6 +200,42 @@ def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
     return pts, aux
 
 
+# PointOuster (include/mimosa/lidar/point.hpp:42-50), 32 bytes: what Manager::prepareInput<PointOuster> reads
+OUSTER_DTYPE = np.dtype({
+    "names": ["x", "y", "z", "pad", "intensity", "t", "reflectivity", "ring", "pad2"],
+    "formats": ["<f4", "<f4", "<f4", "<f4", "<f4", "<u4", "<u2", "<u2", "<u4"],
+    "offsets": [0, 4, 8, 12, 16, 20, 24, 26, 28], "itemsize": 32})
+
+
+def make_raw_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, n_cols: int = N_COLS, room=ROOM,
+                  sensor_local=SENSOR_LOCAL, dropouts: bool = True):
+    """A raw (skewed) Ouster cloud as the driver publishes it: row-major (ring, column), with the defects
+    Manager::prepareInput filters (src/lidar/manager.cpp:253-306): NaN returns, NaN / out-of-range
+    intensities, returns inside range_min, timestamps past ns_max.  Returns (raw[OUSTER_DTYPE], aux of
+    make_scan(skew=True))."""
+    pts, aux = make_scan(n_rows, seed, skew=True, n_cols=n_cols, room=room, sensor_local=sensor_local)
+    n = len(pts)
+    raw = np.zeros(n, dtype=OUSTER_DTYPE)
+    raw["x"], raw["y"], raw["z"] = pts["x"], pts["y"], pts["z"]
+    raw["pad"] = 1.0
+    i = np.arange(n, dtype=np.uint64)
+    raw["intensity"] = np.floor(_uniform(seed, 21, i) * 2048.0).astype(np.float32)
+    raw["t"] = pts["t"]
+    raw["reflectivity"] = (_uniform(seed, 22, i) * 255.0).astype(np.uint16)
+    raw["ring"] = (pts["idx"] // n_cols).astype(np.uint16)
+    if dropouts:
+        u = _uniform(seed, 23, i)
+        nanret = u < 0.01                      # no return: the driver publishes NaN xyz
+        raw["x"][nanret] = np.nan
+        raw["y"][(u >= 0.01) & (u < 0.012)] = np.nan
+        raw["intensity"][(u >= 0.02) & (u < 0.025)] = np.nan
+        near = (u >= 0.03) & (u < 0.035)       # a return off the robot itself, inside range_min
+        for k in ("x", "y", "z"):
+            raw[k][near] *= np.float32(0.004)
+        raw["t"][(u >= 0.04) & (u < 0.041)] = np.uint32(2_000_000_000)  # corrupt timestamp > ns_max
+    return raw, aux
+
+
 def points_xyz(pts: np.ndarray) -> np.ndarray:
     return np.stack([pts["x"], pts["y"], pts["z"]], axis=1)
 

@@ -286,3 +286,37 @@ def downsample(xyz_f32, leaf=0.5, max_pts=20, min_dist=0.15):
             continue
         pts.append(p); idx.append(i)
     return np.array([i for c in order for i in cells[c][1]], dtype=np.uint32)
+
+
+def prepare_input(raw, range_min=0.2, range_max=100.0, intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9,
+                  z_offset=0.0, create_full_res_pointcloud=True, point_skip_divisor=4, ring_skip_divisor=1):
+    """Manager::prepareInput<PointOuster> (src/lidar/manager.cpp:244-368), vectorised: boolean masks instead of
+    the reference's sequential `continue` chain, numpy float32 arithmetic for the range test.
+    raw: structured array with x, y, z, intensity (f4), t (u4), ring (u2).  Returns points_full fields as a
+    dict of arrays, geometric indices (into points_full), unique_ns, groups, last_point_ns."""
+    n = len(raw)
+    i = np.arange(n)
+    x, y, z = raw["x"].astype(np.float32), raw["y"].astype(np.float32), raw["z"].astype(np.float32)
+    inten = raw["intensity"].astype(np.float32)
+    stride = 1 if create_full_res_pointcloud else point_skip_divisor
+    with np.errstate(invalid="ignore"):
+        keep = (i % stride) == 0
+        keep &= ~(np.isnan(x) | np.isnan(y) | np.isnan(z))                                            # :253
+        keep &= ~(np.isnan(inten) | (inten < np.float32(intensity_min)) | (inten > np.float32(intensity_max)))  # :272-276
+        r2 = (x * x + y * y) + z * z                                                                    # :281, f32, left to right
+        rmin2 = np.float32(range_min) * np.float32(range_min)
+        rmax2 = np.float32(range_max) * np.float32(range_max)
+        keep &= ~((r2 < rmin2) | (r2 > rmax2))                                                          # :282
+        keep &= ~(raw["t"].astype(np.float32) > np.float32(ns_max))                                     # :306
+    sel = np.nonzero(keep)[0]
+    full = {
+        "x": x[sel], "y": y[sel], "z": z[sel] + np.float32(z_offset), "intensity": inten[sel], "t": raw["t"][sel],
+        "idx": sel.astype(np.uint32), "range": np.sqrt(r2[sel]),
+    }
+    geo_mask = ((sel % point_skip_divisor) == 0) & ((raw["ring"][sel] % ring_skip_divisor) == 0)     # :318, :331
+    geo = np.nonzero(geo_mask)[0]
+    t_kept = raw["t"][sel]
+    unique_ns = np.unique(t_kept)                                                                       # :340-368
+    groups = [np.nonzero(t_kept == u)[0] for u in unique_ns]
+    last = int(t_kept.max()) if len(sel) else 0
+    return {"points_full": full, "geometric_idxs": geo, "unique_ns": unique_ns, "groups": groups, "last_point_ns": last}

@@ -987,6 +987,78 @@ inline void transform_f32(const float R[9], const float t[3], float & x, float &
   z = (R[6] * px + (R[7] * py + R[8] * pz)) + t[2];
 }
 
+// PointOuster (include/mimosa/lidar/point.hpp:42-50) and the configuration fields prepareInput reads
+// (include/mimosa/lidar/manager.hpp:24-41, geometric_config.hpp:43-44).
+struct PointOusterIn
+{
+  float x, y, z, pad;
+  float intensity;
+  uint32_t t;
+  uint16_t reflectivity, ring;
+  uint32_t pad2;
+};
+struct InputConfig
+{
+  float range_min, range_max, intensity_min, intensity_max, ns_max, z_offset;
+  int32_t create_full_res_pointcloud, point_skip_divisor, ring_skip_divisor;
+};
+struct PreparedInput
+{
+  std::vector<Point32> points_full;                  // manager.cpp:312-313
+  std::vector<uint64_t> geometric_point_idxs;        // :334
+  std::vector<uint32_t> unique_ns;                   // :344-368
+  std::vector<std::vector<uint64_t>> idxs_at_unique_ns;
+  uint32_t last_point_ns = 0;                        // :310, corrected_ts_ = header + last * 1e-9 (:336)
+};
+
+// Manager::prepareInput<PointOuster> (src/lidar/manager.cpp:149-383) without the ROS / PCL conversion,
+// the transpose / organise branches (other sensors) and the debug timers.
+inline void prepare_input(const PointOusterIn * in, size_t n, const InputConfig & cfg, PreparedInput & out)
+{
+  out = PreparedInput();
+  const float range_min_sq = cfg.range_min * cfg.range_min;  // manager.cpp:19-20
+  const float range_max_sq = cfg.range_max * cfg.range_max;
+  const size_t point_skip = static_cast<size_t>(cfg.point_skip_divisor);
+  const size_t skip_divisor = cfg.create_full_res_pointcloud ? 1 : point_skip;  // :244-245
+  std::vector<std::pair<uint32_t, uint64_t>> ns_idx_pairs;
+  uint32_t last_point_ns = 0;
+  for (size_t i = 0; i < n; i = i + skip_divisor) {
+    const PointOusterIn & pin = in[i];
+    if (std::isnan(pin.x) || std::isnan(pin.y) || std::isnan(pin.z)) continue;  // :253
+    if (std::isnan(pin.intensity) || pin.intensity < cfg.intensity_min || pin.intensity > cfg.intensity_max) continue;  // :272-276
+    const float range_sq = pin.x * pin.x + pin.y * pin.y + pin.z * pin.z;  // :281
+    if (range_sq < range_min_sq || range_sq > range_max_sq) continue;      // :282
+    const uint32_t t_ns = pin.t;                                           // :289
+    if (t_ns > cfg.ns_max) continue;                                       // :306 (uint32 -> float comparison)
+    last_point_ns = std::max(last_point_ns, t_ns);
+    Point32 p{};
+    p.x = pin.x;
+    p.y = pin.y;
+    p.z = pin.z + cfg.z_offset;
+    p.intensity = pin.intensity;
+    p.t = t_ns;
+    p.idx = static_cast<uint32_t>(i);
+    p.range = std::sqrt(range_sq);
+    out.points_full.push_back(p);
+    const uint64_t new_idx = out.points_full.size() - 1;
+    ns_idx_pairs.emplace_back(t_ns, new_idx);
+    if (i % point_skip != 0) continue;                                                  // :318
+    if (pin.ring % static_cast<uint16_t>(cfg.ring_skip_divisor) != 0) continue;          // :331
+    out.geometric_point_idxs.push_back(new_idx);
+  }
+  out.last_point_ns = last_point_ns;
+  // :340-342 std::sort on the timestamp only: the order inside one timestamp is unspecified there; a stable
+  // sort is one admissible outcome (only the membership of each group is consumed, :504-508)
+  std::stable_sort(ns_idx_pairs.begin(), ns_idx_pairs.end(), [](const auto & a, const auto & b) { return a.first < b.first; });
+  for (size_t i = 0; i < ns_idx_pairs.size(); ++i) {
+    if (i == 0 || ns_idx_pairs[i].first != ns_idx_pairs[i - 1].first) {
+      out.unique_ns.push_back(ns_idx_pairs[i].first);
+      out.idxs_at_unique_ns.emplace_back();
+    }
+    out.idxs_at_unique_ns.back().push_back(ns_idx_pairs[i].second);
+  }
+}
+
 // deskewPoints (iii): every point whose t equals unique_ns[g] gets pose g.  Rt12 = per group
 // row-major R (9 floats) then t (3 floats), already cast from fp64 (manager.cpp:502-503).
 inline void deskew(

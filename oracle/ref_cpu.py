@@ -258,6 +258,45 @@ def transform_f32(pts, R, t):
     return pts
 
 
+class InputConfig(C.Structure):
+    _fields_ = [
+        ("range_min", C.c_float), ("range_max", C.c_float), ("intensity_min", C.c_float), ("intensity_max", C.c_float),
+        ("ns_max", C.c_float), ("z_offset", C.c_float), ("create_full_res_pointcloud", C.c_int32),
+        ("point_skip_divisor", C.c_int32), ("ring_skip_divisor", C.c_int32),
+    ]
+
+
+def make_input_config(**kw) -> InputConfig:
+    d = dict(range_min=0.2, range_max=100.0, intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9, z_offset=0.0,
+             create_full_res_pointcloud=1, point_skip_divisor=4, ring_skip_divisor=1)
+    d.update(kw)
+    c = InputConfig()
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+def prepare_input(raw, cfg: InputConfig):
+    """Manager::prepareInput<PointOuster> (src/lidar/manager.cpp:149-383).  Returns a dict: points_full
+    (32-byte records), geometric_idxs, unique_ns, groups (list of index arrays), last_point_ns."""
+    L = lib()
+    raw = np.ascontiguousarray(raw)
+    assert raw.dtype.itemsize == 32
+    n = len(raw)
+    full = np.zeros(max(n, 1), dtype=np.dtype((np.void, 32)))
+    geo = np.zeros(max(n, 1), np.uint64)
+    uniq = np.zeros(max(n, 1), np.uint32)
+    goff = np.zeros(n + 2, np.uint64)
+    gidx = np.zeros(max(n, 1), np.uint64)
+    counts = np.zeros(4, np.uint64)
+    L.ref_prepare_input.restype = C.c_int64
+    L.ref_prepare_input(_p(raw), C.c_int64(n), C.byref(cfg), _p(full), _p(geo), _p(uniq), _p(goff), _p(gidx), _p(counts))
+    nf, ng, nu = int(counts[0]), int(counts[1]), int(counts[2])
+    groups = [gidx[int(goff[g]):int(goff[g + 1])].copy() for g in range(nu)]
+    return {"points_full": full[:nf].copy(), "geometric_idxs": geo[:ng].copy(), "unique_ns": uniq[:nu].copy(),
+            "groups": groups, "last_point_ns": int(counts[3])}
+
+
 def downsample(pts, leaf=0.5, max_pts=20, min_dist=0.15):
     pts = np.ascontiguousarray(pts)
     kept = np.empty(len(pts), np.uint32)

@@ -175,6 +175,29 @@ void ref_transform_f32(Point32 * pts, int64_t n, const float * R, const float * 
 {
   for (int64_t i = 0; i < n; ++i) transform_f32(R, t, pts[i].x, pts[i].y, pts[i].z);
 }
+// Manager::prepareInput.  Outputs sized by the caller for n points; returns n_full.  counts[0..3] = n_full,
+// n_geometric, n_unique_ns, last_point_ns.  group_offsets has n_unique_ns + 1 entries into group_idxs.
+int64_t ref_prepare_input(
+  const PointOusterIn * in, int64_t n, const InputConfig * cfg, Point32 * points_full, uint64_t * geometric_idxs,
+  uint32_t * unique_ns, uint64_t * group_offsets, uint64_t * group_idxs, uint64_t * counts)
+{
+  PreparedInput o;
+  prepare_input(in, static_cast<size_t>(n), *cfg, o);
+  std::memcpy(points_full, o.points_full.data(), o.points_full.size() * sizeof(Point32));
+  std::memcpy(geometric_idxs, o.geometric_point_idxs.data(), o.geometric_point_idxs.size() * sizeof(uint64_t));
+  std::memcpy(unique_ns, o.unique_ns.data(), o.unique_ns.size() * sizeof(uint32_t));
+  uint64_t off = 0;
+  for (size_t g = 0; g < o.idxs_at_unique_ns.size(); ++g) {
+    group_offsets[g] = off;
+    for (const uint64_t j : o.idxs_at_unique_ns[g]) group_idxs[off++] = j;
+  }
+  group_offsets[o.idxs_at_unique_ns.size()] = off;
+  counts[0] = o.points_full.size();
+  counts[1] = o.geometric_point_idxs.size();
+  counts[2] = o.unique_ns.size();
+  counts[3] = o.last_point_ns;
+  return static_cast<int64_t>(o.points_full.size());
+}
 int64_t ref_downsample(
   const Point32 * pts, int64_t n, double leaf, int max_pts, double min_dist, uint32_t * kept)
 {
