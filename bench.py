@@ -205,6 +205,65 @@ def main():
                     "delta": bool(s1["delta_uploads"] > s0["delta_uploads"]), "mirror_bytes": int(s1["device_bytes"])}
         gmap2.release()
 
+    # Scan front end (rows a2-a5 / f-3): raw 128 x 1024 Ouster cloud -> prepareInput -> deskew -> body subset ->
+    # voxel down-sampler, on the device (one 4 MiB upload) vs the oracle's sequential CPU code on this host.
+    fe_stats = None
+    if not args.profile_mode:
+        raw, raux = synth.make_raw_scan(args.rows, seed=synth.BASE_SEED + 1 + rank)
+        icfg = capi.make_input_config()
+        I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+        sc = capi.Scan(ctx)
+        col_of = {int(tt_): c for c, tt_ in enumerate(raux["unique_ns"])}
+        tg = {"prepare_input_ms": [], "deskew_ms": [], "preprocess_geometric_ms": [], "factor_create_ms": []}
+        for it in range(6):
+            ctx.synchronize()
+            a0 = time.perf_counter()
+            finfo = sc.prepare_input(raw, icfg)
+            a1 = time.perf_counter()
+            uns = sc.unique_ns()
+            Rt12 = np.stack([raux["Rt12"][col_of[int(u)]] for u in uns])
+            a1b = time.perf_counter()
+            sc.deskew(Rt12)
+            a2 = time.perf_counter()
+            finfo = sc.preprocess_geometric(I3, z3, cfgd["source_voxel_grid_filter_leaf_size"], 20,
+                                            cfgd["source_voxel_grid_min_dist_in_voxel"])
+            a3 = time.perf_counter()
+            f3 = sc.make_factor(gmap, capi.make_reg_config(**cfgd))
+            a4 = time.perf_counter()
+            f3.destroy()
+            if it:  # first pass allocates
+                tg["prepare_input_ms"].append(a1 - a0)
+                tg["deskew_ms"].append(a2 - a1b)
+                tg["preprocess_geometric_ms"].append(a3 - a2)
+                tg["factor_create_ms"].append(a4 - a3)
+        fe_stats = {k: round(float(np.median(v)) * 1e3, 3) for k, v in tg.items()}
+        fe_stats.update({"raw_points": int(len(raw)), "points_full": finfo["n_full"], "geometric_subset": finfo["n_geometric"],
+                         "downsampled": finfo["n_downsampled"], "unique_timestamps": finfo["n_unique_ns"]})
+        sc.destroy()
+        if not args.no_cpu_baseline:
+            from oracle import ref_cpu as _rc
+            ocfg = _rc.make_input_config()
+            tc = {"prepare_input_ms": [], "deskew_ms": [], "preprocess_geometric_ms": []}
+            for it in range(3):
+                b0 = time.perf_counter()
+                o = _rc.prepare_input(raw, ocfg)
+                b1 = time.perf_counter()
+                full = np.frombuffer(o["points_full"].tobytes(), dtype=synth.POINT_DTYPE).copy()
+                Rt12 = np.stack([raux["Rt12"][col_of[int(u)]] for u in o["unique_ns"]])
+                b1b = time.perf_counter()
+                desk = _rc.deskew(full, o["unique_ns"], Rt12)
+                b2 = time.perf_counter()
+                body = _rc.transform_f32(desk[o["geometric_idxs"].astype(np.int64)], I3, z3)
+                kept = _rc.downsample(body, cfgd["source_voxel_grid_filter_leaf_size"], 20,
+                                      cfgd["source_voxel_grid_min_dist_in_voxel"])
+                b3 = time.perf_counter()
+                tc["prepare_input_ms"].append(b1 - b0)
+                tc["deskew_ms"].append(b2 - b1b)
+                tc["preprocess_geometric_ms"].append(b3 - b2)
+            fe_stats["cpu_oracle"] = {k: round(float(np.median(v)) * 1e3, 3) for k, v in tc.items()}
+            fe_stats["cpu_oracle"]["note"] = "oracle/ref_cpu (sequential restatement, one core, incl. ctypes marshalling)"
+            assert len(kept) == fe_stats["downsampled"], "device and oracle down-samplers disagree"
+
     # PCIe-inclusive figure: the boundary hands over HOST buffers, so a scan costs a factor creation
     # (4 MiB upload + pack + Morton sort) before its first linearize.  Reported, never the headline.
     cre = []
@@ -317,6 +376,7 @@ def main():
         "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
         "value_concurrent": conc,
         "keyframe_map_update": kf_stats,
+        "scan_frontend": fe_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
                         "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,

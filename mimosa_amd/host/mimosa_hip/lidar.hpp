@@ -172,6 +172,86 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Device-resident scan front end: the part of lidar::Manager between the PointCloud2 callback and the
+// geometric factor (prepareInput lidar/manager.cpp:149-383, deskewPoints' per-point loop :496-509),
+// with the cloud uploaded once and kept on the GPU.  Geometric::preprocess / getFactors below consume it.
+using PointOuster = mh_ouster_point;  // include/mimosa/lidar/point.hpp:42-50
+using ManagerInputConfig = mh_input_config;
+
+inline ManagerInputConfig defaultManagerInputConfig()
+{
+  // struct defaults of lidar/manager.hpp:24-41 (+ GeometricConfig skip divisors)
+  ManagerInputConfig c{};
+  c.range_min = 0.0f;
+  c.range_max = 100.0f;
+  c.intensity_min = 0.0f;
+  c.intensity_max = 1e10f;
+  c.ns_max = 1e9f;
+  c.z_offset = 0.0f;
+  c.create_full_res_pointcloud = 0;
+  c.point_skip_divisor = 1;
+  c.ring_skip_divisor = 1;
+  return c;
+}
+
+class ScanFrontEnd
+{
+public:
+  explicit ScanFrontEnd(const std::shared_ptr<Context> & ctx) : ctx_(ctx)
+  {
+    ctx_->check(mh_scan_create(ctx_->get(), &scan_), "mh_scan_create");
+  }
+  ~ScanFrontEnd() { mh_scan_destroy(scan_); }
+  ScanFrontEnd(const ScanFrontEnd &) = delete;
+  ScanFrontEnd & operator=(const ScanFrontEnd &) = delete;
+
+  // Manager::prepareInput<PointOuster>: filters, points_full_, geometric subset, unique_ns_.
+  // corrected_ts_ = header_ts + last_point_ns * 1e-9 (manager.cpp:336).
+  void prepareInput(const PointOuster * raw, size_t n, const ManagerInputConfig & cfg, const double header_ts)
+  {
+    ctx_->check(mh_scan_prepare_input(scan_, raw, n, &cfg, &info_), "mh_scan_prepare_input");
+    corrected_ts_ = header_ts + info_.last_point_ns * 1.0e-9;
+    unique_ns_.resize(info_.n_unique_ns);
+    size_t m = 0;
+    ctx_->check(mh_scan_get_unique_ns(scan_, unique_ns_.data(), unique_ns_.size(), &m), "mh_scan_get_unique_ns");
+  }
+  const std::vector<uint32_t> & uniqueNs() const { return unique_ns_; }  // the IMU propagation runs over these
+  double correctedTs() const { return corrected_ts_; }
+  const mh_scan_info & info() const { return info_; }
+
+  // Manager::deskewPoints, per-point part: T_Le_Lt[g] belongs to uniqueNs()[g] (manager.cpp:496-509)
+  void deskewPoints(const std::vector<Pose3> & T_Le_Lt)
+  {
+    if (T_Le_Lt.size() != unique_ns_.size()) throw std::runtime_error("deskewPoints: one pose per unique timestamp");
+    std::vector<float> Rt12(12 * T_Le_Lt.size());
+    for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
+      for (int i = 0; i < 9; ++i) Rt12[12 * g + i] = static_cast<float>(T_Le_Lt[g].R[i]);
+      for (int i = 0; i < 3; ++i) Rt12[12 * g + 9 + i] = static_cast<float>(T_Le_Lt[g].t[i]);
+    }
+    ctx_->check(mh_scan_deskew(scan_, Rt12.data(), T_Le_Lt.size()), "mh_scan_deskew");
+  }
+  // which: 0 points_full_, 1 Be_cloud_, 2 sm_Be_cloud_ds_
+  PointCloud download(int which) const
+  {
+    size_t n = 0;
+    ctx_->check(mh_scan_get_points(scan_, which, nullptr, 0, &n), "mh_scan_get_points");
+    PointCloud out(n);
+    ctx_->check(mh_scan_get_points(scan_, which, out.data(), out.size(), &n), "mh_scan_get_points");
+    return out;
+  }
+  mh_scan * underlying() { return scan_; }
+  const std::shared_ptr<Context> & context() const { return ctx_; }
+  mh_scan_info & mutableInfo() { return info_; }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  mh_scan * scan_ = nullptr;
+  mh_scan_info info_{};
+  std::vector<uint32_t> unique_ns_;
+  double corrected_ts_ = 0;
+};
+
 class ICPFactor : public NonlinearFactor
 {
 public:
@@ -201,6 +281,14 @@ public:
   : NonlinearFactor({key_source, key_target}), is_binary_(true), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
   {
     create(cloud_source, config);
+  }
+  // unary, source cloud = the scan front end's sm_Be_cloud_ds_, taken from device memory
+  ICPFactor(const Key key_source, IncrementalVoxelMapPCL::Ptr ivox_target, ScanFrontEnd & scan, const RegistrationConfig & config)
+  : NonlinearFactor({key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(scan.info().n_downsampled)
+  {
+    std::memset(&last_, 0, sizeof(last_));
+    ctx().check(mh_icp_create_from_scan(ctx().get(), ivox_target_->underlying(), scan.underlying(), &config, 0, &icp_),
+                "mh_icp_create_from_scan");
   }
   ~ICPFactor() override { mh_icp_destroy(icp_); }
 
@@ -342,8 +430,28 @@ public:
       ctx_->check(mh_transform_f32(ctx_->get(), Be_cloud_.data(), Be_cloud_.size(), R, t), "mh_transform_f32");
     downsample(Be_cloud_, sm_Be_cloud_ds_, config.scan_to_map.source_voxel_grid_filter_leaf_size, 20,
                config.scan_to_map.source_voxel_grid_min_dist_in_voxel);
+    device_scan_ = nullptr;
     debug_.n_points_in = points_deskewed.size();
     debug_.n_points_in_sm_ds = sm_Be_cloud_ds_.size();
+  }
+
+  // The same on a device-resident scan: subset + body transform + down-sampler run on the GPU.  Be_cloud_ is
+  // brought to the host because updateMap inserts it into the map there (geometric.cpp:483-495).
+  void preprocess(ScanFrontEnd & scan, const double ts)
+  {
+    if (!config.enabled) return;
+    ts_ = ts;
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(config.T_B_L.R[i]);
+    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(config.T_B_L.t[i]);
+    ctx_->check(mh_scan_preprocess_geometric(scan.underlying(), R, t, config.scan_to_map.source_voxel_grid_filter_leaf_size,
+                                             20, config.scan_to_map.source_voxel_grid_min_dist_in_voxel, &scan.mutableInfo()),
+                "mh_scan_preprocess_geometric");
+    Be_cloud_ = scan.download(1);
+    sm_Be_cloud_ds_.clear();
+    device_scan_ = &scan;
+    debug_.n_points_in = scan.info().n_full;
+    debug_.n_points_in_sm_ds = scan.info().n_downsampled;
   }
 
   // geometric.cpp:185-328
@@ -351,7 +459,8 @@ public:
                   V6D & degen_directions)
   {
     if (!config.enabled) return;
-    factor_ = std::make_shared<ICPFactor>(key, ivox_map_, sm_Be_cloud_ds_, config.scan_to_map);
+    factor_ = device_scan_ ? std::make_shared<ICPFactor>(key, ivox_map_, *device_scan_, config.scan_to_map)
+                           : std::make_shared<ICPFactor>(key, ivox_map_, sm_Be_cloud_ds_, config.scan_to_map);
     auto tmp = factor_->linearize(values);  // linearized right away so localizability is available (:196)
     (void)tmp;
     V3D tc, rc, tf, rf;
@@ -491,6 +600,7 @@ public:
 private:
   std::shared_ptr<Context> ctx_;
   PointCloud Be_cloud_, sm_Be_cloud_ds_;
+  ScanFrontEnd * device_scan_ = nullptr;  // set by the device preprocess: the factor takes its cloud from there
   ICPFactor::Ptr factor_;
   IncrementalVoxelMapPCL::Ptr ivox_map_;
   std::vector<Pose3> map_poses_;

@@ -116,7 +116,30 @@ int main(int argc, char ** argv)
     auto h2 = std::static_pointer_cast<HessianFactor>(graph2.factors[0]->linearize(values));
     dump_factor("second", geo, *h2, degen);
     geo.updateMap(X0, values);  // too close to the first keyframe: no update
-    std::printf(",\n\"map_updated_2\": %d\n}\n", geo.debug().map_updated ? 1 : 0);
+    std::printf(",\n\"map_updated_2\": %d,\n", geo.debug().map_updated ? 1 : 0);
+
+    // ---- the same scan through the device-resident front end (prepareInput -> deskew -> preprocess) ----
+    auto raw = read_vec<PointOuster>(f);  // the raw (skewed, unfiltered) cloud the scan above came from
+    if (!raw.empty()) {
+      Geometric geo2(ctx, cfg);
+      geo2.map()->insert(map_xyz.data(), map_xyz.size() / 3);
+      ScanFrontEnd fe(ctx);
+      ManagerInputConfig icfg = defaultManagerInputConfig();
+      icfg.create_full_res_pointcloud = 1;
+      icfg.point_skip_divisor = cfg.point_skip_divisor;
+      fe.prepareInput(raw.data(), raw.size(), icfg, 100.0);
+      if (fe.uniqueNs() != unique_ns) throw std::runtime_error("device unique_ns differ from the host ones");
+      fe.deskewPoints(T_Le_Lt);
+      geo2.preprocess(fe, 0.0);
+      values.update(X0, pose_from(&misc[12]));
+      NonlinearFactorGraph graph3;
+      geo2.getFactors(X0, values, graph3, evecs, degen);
+      auto h3 = std::static_pointer_cast<HessianFactor>(graph3.factors[0]->linearize(values));
+      dump_factor("first_device_frontend", geo2, *h3, degen);
+      std::printf(",\n\"corrected_ts\": %.9f\n}\n", fe.correctedTs());
+    } else {
+      std::printf("\"no_raw\": 1\n}\n");
+    }
   } catch (const std::exception & e) {
     std::fprintf(stderr, "host_pipeline: %s\n", e.what());
     return 1;

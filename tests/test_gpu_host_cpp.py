@@ -62,6 +62,11 @@ def test_host_pipeline_matches_oracle(tmp_path):
         w(aux["unique_ns"].astype(np.uint32))
         w(poses)
         w(np.concatenate([_pose12(*T_B_L), _pose12(R_WB, t_WB), _pose12(R_WB2, t_WB2)]))
+        # the raw Ouster cloud of the same scan, for the device-resident front end (ScanFrontEnd)
+        raw, _ = synth.make_raw_scan(32, seed=77, n_cols=256, room=room, sensor_local=np.array([2.3, 2.6, 1.2]),
+                                     dropouts=False)
+        assert np.array_equal(raw["x"], scan["x"]) and np.array_equal(raw["t"], scan["t"])
+        w(raw)
     out = subprocess.run([build_exe(), str(inp)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got = json.loads(out.stdout)
@@ -88,6 +93,11 @@ def test_host_pipeline_matches_oracle(tmp_path):
         want = [float(ref["loc_rot_comp"][i] < cfg["degen_thresh_rot"]) for i in range(3)] + \
                [float(ref["loc_trans_comp"][i] < cfg["degen_thresh_trans"]) for i in range(3)]
         assert g["degen_directions"] == want
+    # device-resident front end: same cloud, same order -> the same factor to the last bit
+    gd = got["first_device_frontend"]
+    assert gd["n_ds"] == got["first"]["n_ds"] and gd["status_hist"] == got["first"]["status_hist"]
+    assert gd["H"] == got["first"]["H"] and gd["g"] == got["first"]["g"] and gd["f"] == got["first"]["f"]
+    assert abs(got["corrected_ts"] - (100.0 + float(scan["t"].max()) * 1e-9)) < 1e-9
     assert got["linearize_count"] == 2 and abs(got["clone_f"] - r1["f"]) <= 1e-5 * r1["f"]
     assert got["map_updated"] == 1 and got["map_updated_2"] == 0
     W = ref_cpu.transform_f32(Be, R_WB.astype(np.float32), t_WB.astype(np.float32))
