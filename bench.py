@@ -264,6 +264,25 @@ def main():
             fe_stats["cpu_oracle"]["note"] = "oracle/ref_cpu (sequential restatement, one core, incl. ctypes marshalling)"
             assert len(kept) == fe_stats["downsampled"], "device and oracle down-samplers disagree"
 
+    # Sequence replay (row f-4): 20 scans along a constant-twist trajectory through room 0 — front end, factor,
+    # 3 Gauss-Newton iterations, keyframe map updates — end to end through the C ABI, scans generated beforehand.
+    rp_stats = None
+    if not args.profile_mode and rank == 0:
+        from mimosa_amd import replay
+        rcfg = replay.ReplayConfig(n_scans=20, rows=args.rows)
+        rscans = replay.make_scans(rcfg)
+        rr = replay.run(rcfg, replay.HipBackend(ctx, rcfg.reg), rscans)
+        rp_stats = {"scans": rcfg.n_scans, "scans_per_s": round(rr["scans_per_s"], 1), "keyframes": rr["n_keyframes"],
+                    "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rr["stage_s"].items()},
+                    "max_trans_err_mm": round(max(rr["trans_err"]) * 1e3, 2),
+                    "max_rot_err_mdeg": round(max(rr["rot_err_deg"]) * 1e3, 2),
+                    "note": "3 cm / 0.3 deg prior noise, 2 cm range noise; errors vs ground truth"}
+        if not args.no_cpu_baseline:
+            from oracle.replay_backend import OracleBackend
+            ccfg = replay.ReplayConfig(n_scans=3, rows=args.rows)
+            cr = replay.run(ccfg, OracleBackend(ccfg.reg), rscans[:3])
+            rp_stats["cpu_oracle_scans_per_s"] = round(cr["scans_per_s"], 2)
+
     # PCIe-inclusive figure: the boundary hands over HOST buffers, so a scan costs a factor creation
     # (4 MiB upload + pack + Morton sort) before its first linearize.  Reported, never the headline.
     cre = []
@@ -377,6 +396,7 @@ def main():
         "value_concurrent": conc,
         "keyframe_map_update": kf_stats,
         "scan_frontend": fe_stats,
+        "sequence_replay": rp_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
                         "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,

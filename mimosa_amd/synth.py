@@ -139,7 +139,7 @@ def _raycast_box(o: np.ndarray, d: np.ndarray, lo: np.ndarray, hi: np.ndarray) -
 
 def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
               v=(2.0, 0.3, 0.0), w=(0.0, 0.0, 0.5), n_cols: int = N_COLS, room=ROOM,
-              sensor_local=SENSOR_LOCAL):
+              sensor_local=SENSOR_LOCAL, yaw: float = SENSOR_YAW):
     """Return (points[POINT_DTYPE] in the sensor frame, aux dict).
 
     skew=False: every ray is cast from the scan-end pose (an already-deskewed cloud).
@@ -149,7 +149,7 @@ def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
                 the inputs of Manager::deskewPoints' hot loop (src/lidar/manager.cpp:496-509).
     """
     room = np.asarray(room, dtype=np.float64)
-    R_end, t_end = rot_z(SENSOR_YAW), room_origin(0, 0) + np.asarray(sensor_local)
+    R_end, t_end = rot_z(yaw), room_origin(0, 0) + np.asarray(sensor_local)
     full = np.linspace(45.9, -45.9, 128)
     alt = np.deg2rad(full[:: 128 // n_rows][:n_rows])
     az = -2.0 * np.pi * (np.arange(n_cols) / n_cols)  # Ouster spins clockwise seen from above
@@ -208,12 +208,13 @@ OUSTER_DTYPE = np.dtype({
 
 
 def make_raw_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, n_cols: int = N_COLS, room=ROOM,
-                  sensor_local=SENSOR_LOCAL, dropouts: bool = True):
+                  sensor_local=SENSOR_LOCAL, dropouts: bool = True, v=(2.0, 0.3, 0.0), w=(0.0, 0.0, 0.5),
+                  yaw: float = SENSOR_YAW):
     """A raw (skewed) Ouster cloud as the driver publishes it: row-major (ring, column), with the defects
     Manager::prepareInput filters (src/lidar/manager.cpp:253-306): NaN returns, NaN / out-of-range
     intensities, returns inside range_min, timestamps past ns_max.  Returns (raw[OUSTER_DTYPE], aux of
     make_scan(skew=True))."""
-    pts, aux = make_scan(n_rows, seed, skew=True, n_cols=n_cols, room=room, sensor_local=sensor_local)
+    pts, aux = make_scan(n_rows, seed, skew=True, v=v, w=w, n_cols=n_cols, room=room, sensor_local=sensor_local, yaw=yaw)
     n = len(pts)
     raw = np.zeros(n, dtype=OUSTER_DTYPE)
     raw["x"], raw["y"], raw["z"] = pts["x"], pts["y"], pts["z"]
