@@ -609,6 +609,85 @@ private:
   GeometricDebug debug_;
 };
 
+// Manager::deskewPoints, pose part (manager.cpp:455-499), for callers that run their own IMU preintegration
+// (gtsam::PreintegratedImuMeasurements stays the caller's: SURVEY.md §7).  Inputs are what that loop has in
+// hand: the interpolated IMU samples (time, accelerometer, gyroscope — `imu_measurements`), the NavState the
+// preintegrator predicted AT each sample time (nav[j] = state at imu_t[j]; nav[0] = the previous state), the
+// bias, the gravity direction (unit) and magnitude, the scan's distinct timestamps and header time, and T_B_S.
+// Output: T_Le_Lt per distinct timestamp, exactly the constant-acceleration / constant-rate extrapolation of
+// :478-489 followed by T_Le_W * T_W_Bt * T_B_S (:493-497).  Timestamps after the last IMU sample get no pose
+// (the reference's vector simply ends there).
+struct NavState
+{
+  Pose3 pose;
+  V3D velocity{0, 0, 0};
+};
+
+inline M33 so3Expmap(const V3D & w)  // gtsam::Rot3::Expmap (Rodrigues)
+{
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+  const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double A, B;
+  if (th < 1e-10) {
+    A = 1.0 - th2 / 6.0;
+    B = 0.5 - th2 / 24.0;
+  } else {
+    A = std::sin(th) / th;
+    B = (1.0 - std::cos(th)) / th2;
+  }
+  M33 R{1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double kk = 0;
+      for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
+      R[3 * i + j] += A * K[3 * i + j] + B * kk;
+    }
+  return R;
+}
+
+inline std::vector<Pose3> computeDeskewPoses(const std::vector<double> & imu_t, const std::vector<V3D> & imu_acc,
+                                             const std::vector<V3D> & imu_gyro, const std::vector<NavState> & nav,
+                                             const V3D & bias_acc, const V3D & bias_gyro, const V3D & gravity_unit,
+                                             const double gravity_norm, const std::vector<uint32_t> & unique_ns,
+                                             const double header_ts, const Pose3 & T_B_S)
+{
+  if (imu_t.size() < 2) throw std::runtime_error("Preintegration not possible as there are less than 2 measurements P1");  // :442-446
+  if (imu_acc.size() != imu_t.size() || imu_gyro.size() != imu_t.size() || nav.size() != imu_t.size())
+    throw std::runtime_error("computeDeskewPoses: one measurement and one state per IMU sample");
+  std::vector<Pose3> T_W_Bts;
+  T_W_Bts.reserve(unique_ns.size());
+  size_t u = 0;
+  for (size_t c = 0; c + 1 < imu_t.size(); ++c) {  // curr = c, next = c + 1 (:459-466)
+    const NavState & curr = nav[c];
+    while (u < unique_ns.size()) {
+      const double ts = header_ts + unique_ns[u] * 1.0e-9;  // globalTs, manager.hpp:94
+      if (ts > imu_t[c + 1]) break;
+      const double dt = ts - imu_t[c];
+      V3D acc, omega;
+      for (int i = 0; i < 3; ++i) {
+        acc[i] = imu_acc[c][i] - bias_acc[i];     // ConstantBias::correctAccelerometer
+        omega[i] = imu_gyro[c][i] - bias_gyro[i];  // ::correctGyroscope
+      }
+      Pose3 T;
+      const M33 E = so3Expmap({omega[0] * dt, omega[1] * dt, omega[2] * dt});
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          T.R[3 * i + j] = curr.pose.R[3 * i] * E[j] + curr.pose.R[3 * i + 1] * E[3 + j] + curr.pose.R[3 * i + 2] * E[6 + j];
+      for (int i = 0; i < 3; ++i) {
+        const double Ra = curr.pose.R[3 * i] * acc[0] + curr.pose.R[3 * i + 1] * acc[1] + curr.pose.R[3 * i + 2] * acc[2];
+        T.t[i] = curr.pose.t[i] + curr.velocity[i] * dt + 0.5 * Ra * dt * dt + 0.5 * gravity_unit[i] * gravity_norm * dt * dt;
+      }
+      T_W_Bts.push_back(T);
+      ++u;
+    }
+  }
+  const Pose3 T_Le_W = T_B_S.inverse() * nav.back().pose.inverse();  // propagated state = T_W_Be (:492-493)
+  std::vector<Pose3> out;
+  out.reserve(T_W_Bts.size());
+  for (const Pose3 & T : T_W_Bts) out.push_back(T_Le_W * T * T_B_S);
+  return out;
+}
+
 // Manager::deskewPoints' per-point part (manager.cpp:496-509).  T_Le_Lt[g] is the pose of the sensor at
 // unique timestamp g in the scan-end frame — computed by the caller's IMU propagation (:455-499), which
 // stays on the CPU.  Points are transformed in place on the GPU.

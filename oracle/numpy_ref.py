@@ -320,3 +320,37 @@ def prepare_input(raw, range_min=0.2, range_max=100.0, intensity_min=0.0, intens
     groups = [np.nonzero(t_kept == u)[0] for u in unique_ns]
     last = int(t_kept.max()) if len(sel) else 0
     return {"points_full": full, "geometric_idxs": geo, "unique_ns": unique_ns, "groups": groups, "last_point_ns": last}
+
+
+def _so3_exp(w):
+    th = float(np.linalg.norm(w))
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], float)
+    if th < 1e-10:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+def deskew_poses(imu_t, imu_acc, imu_gyro, nav_R, nav_p, nav_v, bias_acc, bias_gyro, g_unit, g_norm, unique_ns,
+                 header_ts, T_B_S):
+    """Manager::deskewPoints pose part (src/lidar/manager.cpp:455-499) with 4x4 homogeneous matrices: for each
+    distinct timestamp inside IMU interval [t_c, t_c+1]: R = R_c Exp(omega dt), p = p_c + v_c dt + 1/2 R_c a dt^2
+    + 1/2 g |g| dt^2; T_Le_Lt = T_B_S^-1 T_W_Be^-1 T_W_Bt T_B_S."""
+    def hom(R, p):
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, p
+        return T
+    T_BS = hom(*T_B_S)
+    T_W_Be = hom(nav_R[-1], nav_p[-1])
+    out, u = [], 0
+    for c in range(len(imu_t) - 1):
+        while u < len(unique_ns):
+            ts = header_ts + float(unique_ns[u]) * 1.0e-9
+            if ts > imu_t[c + 1]:
+                break
+            dt = ts - imu_t[c]
+            a, w = np.asarray(imu_acc[c]) - bias_acc, np.asarray(imu_gyro[c]) - bias_gyro
+            R = nav_R[c] @ _so3_exp(w * dt)
+            p = nav_p[c] + nav_v[c] * dt + 0.5 * nav_R[c] @ a * dt * dt + 0.5 * np.asarray(g_unit) * g_norm * dt * dt
+            out.append(np.linalg.inv(T_BS) @ np.linalg.inv(T_W_Be) @ hom(R, p) @ T_BS)
+            u += 1
+    return out
