@@ -7,27 +7,25 @@
 //   K3  icp_linearize_kernel   one thread per source point, 512-thread workgroups (one per CU at
 //       131 072 points), fused:
 //         pose transform (fp64) -> data-association cache test
-//         A. neighbourhood lookup: 8 block-table probes + all neighbour-cell loads issued together,
-//            occupied voxels compacted into a per-lane list in LDS
-//         B. flattened scan of the listed 320-byte buckets (the wave runs max-over-lanes of the
-//            TOTAL candidate count, ~100, instead of offsets x slots, ~300), fp64 distances in the
-//            reference's exact operation order, branch-free top-(k+1) by v_min/v_max_f64 on keys
-//            whose low 10 mantissa bits carry (list slot, bucket slot); a lane whose kept keys
-//            collide after truncation re-runs an exact insertion scan, so the selection is always
-//            bit-identical to KnnResult::push
-//         C. mean / covariance / closed-form symmetric 3x3 eigen / plane gates -> residual, Huber
-//            weight, Jacobian row
+//         A. neighbourhood lookup: one block-table probe + nine 12-byte loads from the block's halo'd cell
+//            table; cell words to a per-lane LDS column, quad counts packed in registers
+//         B. coarse scan of the packed 10-bit buckets (one 16-byte load = 4 candidates): centre voxel, exact
+//            box pruning, then faces -> edges -> corners through a software-pipelined register-only cursor
+//            with re-pruning; sorted-quad bitonic merge into a top-8 of 32-bit keys (distance | position)
+//         C. exact tier: the 8 survivors re-ranked in fp64 in the reference's operation order, proof check,
+//            wave-cooperative KnnResult::push for the rare lane the proof does not cover; mean / covariance /
+//            Newton cubic eigen / plane gates -> residual, Huber weight, Jacobian row
 //         D. LDS tile of rows -> every thread owns one (entry, point-segment) of the 28 (unary) or
 //            91 (binary) sums of v v^T -> per-block partial row (write-through) -> ticket -> the
 //            last-arriving block folds all rows in a fixed order and eigen-decomposes H_rr, H_tt.
 //   K4  icp_localizability_kernel   second pass: component localizabilities in that eigenbasis
 //       (geometric_factor.hpp:434-457) + status histogram (src/lidar/geometric.cpp:280-323).
 //
-// Gather / scan / reduce work bound by the memory system and VALU issue, not a dense contraction:
-// no MFMA.  Measured on MI355X (round 1): cooperating sub-groups of 2/4/8 lanes per query with
-// shuffle-min merges were 1.4x/2.5x/4.9x SLOWER than one lane per query (the kernel is issue-bound,
-// and neighbouring scan points share buckets through L1/L2 anyway), so the wave-level cooperation
-// lives in the reductions, not in the k-NN.
+// Gather / scan / reduce work bound by VALU issue and the memory system at 2 waves per SIMD, not a dense
+// contraction: no MFMA.  Measured on MI355X (round 1): cooperating sub-groups of 2/4/8 lanes per query with
+// shuffle-min merges were 1.4x/2.5x/4.9x SLOWER than one lane per query, and finishing the heaviest lanes'
+// voxels with the whole wave was 2x slower, so the wave-level cooperation lives in the
+// reductions and in the exact fallback, not in the scan.
 #include <hip/hip_runtime.h>
 
 #include "icp_device.hpp"
