@@ -498,7 +498,7 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
   *out = nullptr;
   mh_map * map = new (std::nothrow) mh_map(src->ctx, src->host.config());
   if (!map) return fail(src->ctx, MH_ERR_OOM, "mh_map_copy: host allocation failed");
-  map->host = src->host;  // deep copy of the flat arrays
+  map->host = src->host;  // deep copy of the flat arrays (multi-threaded, recycled pages: voxel_map.hpp)
   map->device_stale = true;
   if (src->dev_valid) {
     // the device mirror is copied device-to-device (what it held at the source's last sync); the host

@@ -29,12 +29,122 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mimosa_hip.h"
 
 namespace mh
 {
+// std::vector whose resize(n) leaves trivially-constructible elements uninitialised: the big arrays of a map
+// copy are sized first and then filled by several threads (first touch and memcpy in parallel) instead of one
+// thread faulting in and copying ~270 MB.
+// Freed blocks of >= 1 MiB are kept (at most kMaxBlocks of them) and handed out again: a keyframe update
+// copies the map, and the previous copy's arrays were released moments earlier — reusing their pages avoids
+// faulting in ~300 MB of fresh memory per keyframe (page faults, not bandwidth, dominated the copy).
+class BigBlockCache
+{
+public:
+  static void * take(size_t bytes)
+  {
+    std::lock_guard<std::mutex> g(mu());
+    auto & v = blocks();
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); ++i)
+      if (v[i].cap >= bytes && v[i].cap <= bytes + bytes / 2 + (size_t(1) << 20) && (best == v.size() || v[i].cap < v[best].cap)) best = i;
+    if (best == v.size()) return nullptr;
+    void * p = v[best].p;
+    live()[p] = v[best].cap;
+    v.erase(v.begin() + static_cast<long>(best));
+    return p;
+  }
+  static void * fresh(size_t bytes)
+  {
+    void * p = ::operator new(bytes);
+    if (bytes >= kMinBytes) {
+      std::lock_guard<std::mutex> g(mu());
+      live()[p] = bytes;
+    }
+    return p;
+  }
+  static void give(void * p, size_t bytes_hint)
+  {
+    size_t cap = 0;
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto it = live().find(p);
+      if (it != live().end()) {
+        cap = it->second;
+        live().erase(it);
+      }
+      if (cap >= kMinBytes && blocks().size() < kMaxBlocks) {
+        blocks().push_back({p, cap});
+        return;
+      }
+    }
+    (void)bytes_hint;
+    ::operator delete(p);
+  }
+  static constexpr size_t kMinBytes = size_t(1) << 20;
+  static constexpr size_t kMaxBlocks = 12;
+
+private:
+  struct Block
+  {
+    void * p;
+    size_t cap;
+  };
+  static std::mutex & mu()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static std::vector<Block> & blocks()
+  {
+    static std::vector<Block> v;
+    return v;
+  }
+  static std::unordered_map<void *, size_t> & live()
+  {
+    static std::unordered_map<void *, size_t> m;
+    return m;
+  }
+};
+
+template <typename T>
+struct NoInitAlloc
+{
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <typename U>
+  NoInitAlloc(const NoInitAlloc<U> &) {}
+  T * allocate(size_t n)
+  {
+    const size_t bytes = n * sizeof(T);
+    if (bytes >= BigBlockCache::kMinBytes)
+      if (void * p = BigBlockCache::take(bytes)) return static_cast<T *>(p);
+    return static_cast<T *>(BigBlockCache::fresh(bytes));
+  }
+  void deallocate(T * p, size_t n) { BigBlockCache::give(p, n * sizeof(T)); }
+  template <typename U, typename... A>
+  void construct(U * p, A &&... a)
+  {
+    if constexpr (sizeof...(A) == 0)
+      ::new (static_cast<void *>(p)) U;
+    else
+      ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+  }
+  template <typename U>
+  bool operator==(const NoInitAlloc<U> &) const { return true; }
+  template <typename U>
+  bool operator!=(const NoInitAlloc<U> &) const { return false; }
+};
+template <typename T>
+using BigVec = std::vector<T, NoInitAlloc<T>>;
+
 constexpr int kBlockLog2 = 2;                       // 4x4x4 voxels per block
 constexpr int kBlockDim = 1 << kBlockLog2;
 constexpr int kHaloDim = kBlockDim + 2;                // block + one-voxel halo
@@ -144,9 +254,9 @@ public:
   size_t n_points() const { return n_points_; }
   uint32_t table_mask() const { return table_mask_; }
   const std::vector<Int4> & table() const { return table_; }
-  const std::vector<uint32_t> & cells() const { return cells_; }
-  const std::vector<Float4> & buckets() const { return buckets_; }
-  const std::vector<uint32_t> & qbuckets() const { return qbuckets_; }
+  const BigVec<uint32_t> & cells() const { return cells_; }
+  const BigVec<Float4> & buckets() const { return buckets_; }
+  const BigVec<uint32_t> & qbuckets() const { return qbuckets_; }
   const std::vector<uint8_t> & counts() const { return vox_count_; }
   // positions (indices into cells()) that hold this voxel's word: home table + adjacent halos
   int voxel_cell_positions(uint32_t vid, const uint32_t ** pos) const
@@ -346,8 +456,8 @@ private:
     std::vector<int32_t> coord;
     std::vector<uint8_t> count;
     std::vector<uint64_t> lru;
-    std::vector<Float4> buckets;
-    std::vector<uint32_t> qb;
+    BigVec<Float4> buckets;
+    BigVec<uint32_t> qb;
     for (size_t v = 0; v < vox_count_.size(); ++v) {
       if (vox_lru_[v] + horizon < lru_counter_) continue;
       coord.insert(coord.end(), {vox_coord_[3 * v], vox_coord_[3 * v + 1], vox_coord_[3 * v + 2]});
@@ -383,12 +493,38 @@ private:
     full_rebuild_ = true;
   }
 
-  template <typename T>
-  static void copy_with_headroom(std::vector<T> & dst, const std::vector<T> & src)
+  template <typename V>
+  static void copy_with_headroom(V & dst, const V & src)
   {
-    std::vector<T> v;
+    V v;
     v.reserve(src.size() + src.size() / 8 + 4096);
     v.assign(src.begin(), src.end());
+    dst.swap(v);
+  }
+  // the big arrays: size without touching, then copy (and first-touch) with several threads
+  template <typename T>
+  static void copy_with_headroom(BigVec<T> & dst, const BigVec<T> & src)
+  {
+    BigVec<T> v;
+    v.reserve(src.size() + src.size() / 8 + 4096);
+    v.resize(src.size());
+    const size_t bytes = src.size() * sizeof(T);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = bytes < (size_t(8) << 20) ? 1 : (hw >= 64 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? 4 : 1)));
+    if (nt == 1) {
+      if (bytes) std::memcpy(static_cast<void *>(v.data()), src.data(), bytes);
+    } else {
+      std::vector<std::thread> th;
+      const size_t chunk = ((bytes / nt) + 4095) & ~size_t(4095);
+      for (size_t k = 0; k < nt; ++k) {
+        const size_t b0 = k * chunk, b1 = b0 + chunk < bytes ? b0 + chunk : bytes;
+        if (b0 >= b1) break;
+        th.emplace_back([&v, &src, b0, b1] {
+          std::memcpy(reinterpret_cast<char *>(v.data()) + b0, reinterpret_cast<const char *>(src.data()) + b0, b1 - b0);
+        });
+      }
+      for (auto & t : th) t.join();
+    }
     dst.swap(v);
   }
   void copy_from(const HostVoxelMap & o)
@@ -434,14 +570,14 @@ private:
   std::vector<int32_t> vox_coord_;
   std::vector<uint8_t> vox_count_;
   std::vector<uint64_t> vox_lru_;
-  std::vector<uint32_t> vox_cells_;   // 8 slots per voxel: indices into cells_ that hold its word (home first)
+  BigVec<uint32_t> vox_cells_;   // 8 slots per voxel: indices into cells_ that hold its word (home first)
   std::vector<uint8_t> vox_ncells_;   // how many of the 8 are used
-  std::vector<Float4> buckets_;
-  std::vector<uint32_t> qbuckets_;
+  BigVec<Float4> buckets_;
+  BigVec<uint32_t> qbuckets_;
   // blocks
   size_t n_blocks_ = 0;
   std::vector<int32_t> block_coord_;
-  std::vector<uint32_t> cells_;
+  BigVec<uint32_t> cells_;
   std::vector<Int4> table_;
   uint32_t table_mask_ = 0;
   int last_block_ = -1;
