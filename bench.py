@@ -156,6 +156,8 @@ def main():
         c.set_profiling(False)
     if args.profile_mode:
         args.no_cpu_baseline, args.concurrent_streams = True, 0
+    if world > 1:
+        args.no_cpu_baseline = True  # cpu_baseline and the oracle-timed legs are N=1, rank-0 figures
     lat = []
     for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
         factor.reset()
@@ -186,7 +188,7 @@ def main():
     # Keyframe map update (Geometric::updateMap, geometric.cpp:427-513): copy the map, insert the scan's
     # geometric subset (every 4th point, world frame), make the device mirror current.
     kf_stats = None
-    if not args.profile_mode:
+    if not args.profile_mode and world == 1:
         sub = pts[::4]
         xyz = synth.points_xyz(sub).astype(np.float64) @ R.T + t
         xyz = xyz.astype(np.float32)
@@ -208,7 +210,7 @@ def main():
     # Scan front end (rows a2-a5 / f-3): raw 128 x 1024 Ouster cloud -> prepareInput -> deskew -> body subset ->
     # voxel down-sampler, on the device (one 4 MiB upload) vs the oracle's sequential CPU code on this host.
     fe_stats = None
-    if not args.profile_mode:
+    if not args.profile_mode and world == 1:
         raw, raux = synth.make_raw_scan(args.rows, seed=synth.BASE_SEED + 1 + rank)
         icfg = capi.make_input_config()
         I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
@@ -267,7 +269,7 @@ def main():
     # Sequence replay (row f-4): 20 scans along a constant-twist trajectory through room 0 — front end, factor,
     # 3 Gauss-Newton iterations, keyframe map updates — end to end through the C ABI, scans generated beforehand.
     rp_stats = None
-    if not args.profile_mode and rank == 0:
+    if not args.profile_mode and world == 1:
         from mimosa_amd import replay
         rcfg = replay.ReplayConfig(n_scans=20, rows=args.rows)
         rscans = replay.make_scans(rcfg)
