@@ -34,7 +34,7 @@ struct DeviceResult
   double loc_comp[6];     // trans xyz, rot xyz
   unsigned long long n_knn, n_cand, n_fallback, n_scanned;
   unsigned int status_hist[9];
-  unsigned int pad;
+  unsigned int seq;  // host slot only: written LAST by K4 (system-scope release) = the call's sequence number
 };
 
 struct IcpArgs
@@ -62,6 +62,7 @@ struct IcpArgs
 struct LocArgs
 {
   DeviceResult * host_result;  // mapped pinned host slot: the last block writes loc_comp / status_hist there (no D2H copy node)
+  unsigned int seq;            // published to host_result->seq after everything else: the host may spin on it
   const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = use result->eig_* from K3
   const float4 * src;
   int n;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -115,6 +116,7 @@ struct PendingCall
   double gz[3];    // global_z = -g_unit
   int parity;
   int linearize_count;
+  unsigned int seq;  // what K4 publishes to the host slot when this call is complete (0: nothing was launched)
   hipEvent_t ev[3];
 };
 
@@ -138,6 +140,7 @@ struct mh_icp
   int linearize_count = 0;
   hipEvent_t events[kMaxPending][3];
   bool events_ready = false;
+  unsigned int seq_counter = 0;
 };
 
 namespace
@@ -853,6 +856,7 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   mh::LocArgs l;
   l.src = a.src;
   l.host_result = nullptr;  // set below once the slot is known
+  l.seq = 0;
   l.eig = nullptr;
   l.n = a.n;
   std::memcpy(l.R, a.R, sizeof(l.R));
@@ -876,8 +880,12 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   } else {
     pc.ev[0] = pc.ev[1] = pc.ev[2] = nullptr;
   }
+  pc.seq = 0;
   if (a.n > 0) {
     a.host_result = icp->d_h_results + slot;
+    if (++icp->seq_counter == 0) ++icp->seq_counter;
+    pc.seq = l.seq = icp->seq_counter;
+    __atomic_store_n(&icp->h_results[slot].seq, 0u, __ATOMIC_RELEASE);  // re-arm the slot before anything is enqueued
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     l.host_result = icp->d_h_results + slot;
@@ -900,7 +908,32 @@ int mh_icp_wait(mh_icp * icp)
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
   mh_ctx * ctx = icp->ctx;
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // Each call's last kernel publishes its sequence number to the mapped host slot after the results: spin on
+  // it instead of paying the runtime's stream-synchronisation latency.  Fall back to the stream when something
+  // was not launched, is being timed by events, or does not show up within the spin budget.
+  bool need_sync = false;
+  for (int s = 0; s < icp->n_pending && !need_sync; ++s) {
+    const PendingCall & pc = icp->pending[s];
+    if (pc.seq == 0 || pc.ev[0]) {
+      need_sync = true;
+      break;
+    }
+    const volatile unsigned int * flag = &icp->h_results[s].seq;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != pc.seq; ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u) {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 20000000L) {  // 20 ms
+          need_sync = true;
+          break;
+        }
+      }
+    }
+  }
+  if (need_sync) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < icp->n_pending; ++s) {
     const PendingCall & pc = icp->pending[s];
     finish_result(icp, icp->h_results[s], pc, pc.out);
@@ -957,6 +990,7 @@ int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const doub
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // e18 is a stack buffer
   mh::LocArgs l;
   l.host_result = icp->d_h_results;  // slot 0
+  l.seq = 0xFFFFFFFFu;  // not waited on by flag: the call below synchronises the stream
   l.eig = static_cast<const double *>(icp->d_eig.p);
   l.src = static_cast<const float4 *>(icp->d_src.p);
   l.n = static_cast<int>(icp->n);
