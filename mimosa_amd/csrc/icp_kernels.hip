@@ -1196,9 +1196,11 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
       a.host_result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
     // completion flag for a host that spins on the slot instead of paying a stream synchronisation: data first
     // (system-scope fence by every writer), then the sequence number with release semantics
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.seq) {  // synchronous callers only: the system-scope fence costs ~2 us of kernel time
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

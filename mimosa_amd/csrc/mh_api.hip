@@ -808,8 +808,11 @@ int mh_icp_reset(mh_icp * icp)
   return MH_OK;
 }
 
-int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
-                           const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+// want_flag: the last kernel publishes a completion sequence number to the host slot (mh_icp_wait then spins
+// on it instead of synchronising the stream).  Worth it for one synchronous call, not for a pipelined batch:
+// the system-scope fence it needs lengthens every K4 by ~2 us.
+static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                             const double * t_tgt, const double g_unit[3], mh_icp_result * out, bool want_flag)
 {
   if (!icp || !R_src || !t_src || !g_unit || !out)
     return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize: NULL argument");
@@ -883,9 +886,11 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   pc.seq = 0;
   if (a.n > 0) {
     a.host_result = icp->d_h_results + slot;
-    if (++icp->seq_counter == 0) ++icp->seq_counter;
-    pc.seq = l.seq = icp->seq_counter;
-    __atomic_store_n(&icp->h_results[slot].seq, 0u, __ATOMIC_RELEASE);  // re-arm the slot before anything is enqueued
+    if (want_flag) {
+      if (++icp->seq_counter == 0) ++icp->seq_counter;
+      pc.seq = l.seq = icp->seq_counter;
+      __atomic_store_n(&icp->h_results[slot].seq, 0u, __ATOMIC_RELEASE);  // re-arm the slot before anything is enqueued
+    }
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     l.host_result = icp->d_h_results + slot;
@@ -901,6 +906,12 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   icp->n_pending++;
   icp->cold = false;
   return MH_OK;
+}
+
+int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+{
+  return linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, false);
 }
 
 int mh_icp_wait(mh_icp * icp)
@@ -951,7 +962,7 @@ int mh_icp_wait(mh_icp * icp)
 int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                      const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
-  const int rc = mh_icp_linearize_async(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out);
+  const int rc = linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, icp && icp->n_pending == 0);
   if (rc != MH_OK) return rc;
   return mh_icp_wait(icp);
 }
