@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -56,6 +58,134 @@ int hip_fail(const mh_ctx * ctx, hipError_t e, const char * what)
     if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
   } while (0)
 
+// Device / pinned-host allocation cache.  A scan creates a factor (a dozen device buffers, a pinned result
+// ring, sort temporaries) and destroys it a few hundred milliseconds later; hipMalloc / hipFree / hipHostMalloc
+// cost 10-200 us each and hipFree synchronises the device.  Freed blocks of 4 KiB .. 64 MiB are kept per
+// (device, rounded size) and handed out again; the cache holds at most kMaxCachedBytes per device.  A cached
+// free still drains the device first (hipDeviceSynchronize: microseconds when idle), because callers rely on
+// hipFree's implicit "nobody is using this any more".
+class AllocCache
+{
+public:
+  static hipError_t alloc(void ** out, size_t bytes)
+  {
+    const size_t cls = size_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cls) {
+      std::lock_guard<std::mutex> g(mu());
+      auto & v = free_list()[key(dev, cls)];
+      if (!v.empty()) {
+        *out = v.back();
+        v.pop_back();
+        cached_bytes()[dev] -= cls;
+        live()[*out] = cls;
+        return hipSuccess;
+      }
+    }
+    const hipError_t e = hipMalloc(out, cls ? cls : bytes);
+    if (e == hipSuccess && cls) {
+      std::lock_guard<std::mutex> g(mu());
+      live()[*out] = cls;
+    }
+    return e;
+  }
+  static void free(void * p)
+  {
+    if (!p) return;
+    size_t cls = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto it = live().find(p);
+      if (it != live().end()) {
+        cls = it->second;
+        live().erase(it);
+      }
+      if (cls && cached_bytes()[dev] + cls <= kMaxCachedBytes) {
+        // in-flight work may still read / write the block: drain before it can be handed out again
+        (void)hipDeviceSynchronize();
+        free_list()[key(dev, cls)].push_back(p);
+        cached_bytes()[dev] += cls;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  // pinned, mapped result rings (one fixed size)
+  static hipError_t alloc_pinned(void ** out, size_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto & v = pinned()[bytes];
+      if (!v.empty()) {
+        *out = v.back();
+        v.pop_back();
+        return hipSuccess;
+      }
+    }
+    return hipHostMalloc(out, bytes, hipHostMallocMapped);
+  }
+  static void free_pinned(void * p, size_t bytes)
+  {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu());
+    auto & v = pinned()[bytes];
+    if (v.size() < 64) {
+      v.push_back(p);
+      return;
+    }
+    (void)hipHostFree(p);
+  }
+
+private:
+  static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
+  static size_t size_class(size_t bytes)
+  {
+    if (bytes > (size_t(64) << 20)) return 0;  // big (map-sized) blocks are not cached
+    size_t c = 4096;
+    while (c < bytes) c += c / 2 >= 4096 ? (c / 4) : c;  // 4K, 8K, 16K, 20K, 25K, ... (~25 % steps)
+    return c;
+  }
+  static uint64_t key(int dev, size_t cls) { return (static_cast<uint64_t>(dev) << 56) | cls; }
+  static std::mutex & mu()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static std::unordered_map<uint64_t, std::vector<void *>> & free_list()
+  {
+    static std::unordered_map<uint64_t, std::vector<void *>> m;
+    return m;
+  }
+  static std::unordered_map<void *, size_t> & live()
+  {
+    static std::unordered_map<void *, size_t> m;
+    return m;
+  }
+  static std::unordered_map<int, size_t> & cached_bytes()
+  {
+    static std::unordered_map<int, size_t> m;
+    return m;
+  }
+  static std::unordered_map<size_t, std::vector<void *>> & pinned()
+  {
+    static std::unordered_map<size_t, std::vector<void *>> m;
+    return m;
+  }
+};
+
+template <typename T>
+hipError_t dev_alloc(T ** out, size_t bytes)
+{
+  void * p = nullptr;
+  const hipError_t e = AllocCache::alloc(&p, bytes);
+  *out = static_cast<T *>(p);
+  return e;
+}
+inline void dev_free(void * p) { AllocCache::free(p); }
+
 // Growable device buffer
 struct DevBuf
 {
@@ -67,7 +197,7 @@ struct DevBuf
     size_t ncap = cap ? cap : 4096;
     while (ncap < bytes) ncap += ncap / 2 + 4096;
     void * np = nullptr;
-    hipError_t e = hipMalloc(&np, ncap);
+    hipError_t e = AllocCache::alloc(&np, ncap);
     if (e != hipSuccess) return e;
     if (keep && p && cap) {
       e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream);
@@ -75,14 +205,14 @@ struct DevBuf
       e = hipStreamSynchronize(stream);
       if (e != hipSuccess) return e;
     }
-    if (p) (void)hipFree(p);
+    if (p) AllocCache::free(p);
     p = np;
     cap = ncap;
     return hipSuccess;
   }
   void release()
   {
-    if (p) (void)hipFree(p);
+    if (p) AllocCache::free(p);
     p = nullptr;
     cap = 0;
   }
@@ -591,20 +721,20 @@ int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * p
   if (n == 0) return MH_OK;
   double *d_q = nullptr, *d_p = nullptr, *d_s = nullptr;
   int32_t * d_f = nullptr;
-  MH_HIP(ctx, hipMalloc(&d_q, n * 3 * sizeof(double)));
-  MH_HIP(ctx, hipMalloc(&d_p, n * k * 3 * sizeof(double)));
-  MH_HIP(ctx, hipMalloc(&d_s, n * k * sizeof(double)));
-  MH_HIP(ctx, hipMalloc(&d_f, n * sizeof(int32_t)));
+  MH_HIP(ctx, dev_alloc(&d_q, n * 3 * sizeof(double)));
+  MH_HIP(ctx, dev_alloc(&d_p, n * k * 3 * sizeof(double)));
+  MH_HIP(ctx, dev_alloc(&d_s, n * k * sizeof(double)));
+  MH_HIP(ctx, dev_alloc(&d_f, n * sizeof(int32_t)));
   MH_HIP(ctx, hipMemcpyAsync(d_q, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, mh::launch_map_knn(map_view(map), d_q, static_cast<int>(n), k, d_p, d_s, d_f, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(point_xyz, d_p, n * k * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(sq_dists, d_s, n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(found, d_f, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_q);
-  (void)hipFree(d_p);
-  (void)hipFree(d_s);
-  (void)hipFree(d_f);
+  dev_free(d_q);
+  dev_free(d_p);
+  dev_free(d_s);
+  dev_free(d_f);
   return MH_OK;
 }
 
@@ -626,8 +756,7 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 16 * sizeof(unsigned long long), ctx->stream, false));
   MH_HIP(ctx, hipMemsetAsync(icp->d_dbg.p, 0, icp->d_dbg.cap, ctx->stream));
 #endif
-  MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending,
-                            hipHostMallocMapped));
+  MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending));
   MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_results), icp->h_results, 0));
   return MH_OK;
 }
@@ -661,13 +790,13 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   if (n) {
     mh_point32 * d_pts = nullptr;
     if (!d_source) {
-      MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
+      MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
       MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
     }
     MH_HIP(ctx, mh::launch_pack_xyz(d_source ? d_source : d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p),
                                     ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d_pts) (void)hipFree(d_pts);
+    if (d_pts) dev_free(d_pts);
     // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
     const char * ns = std::getenv("MH_NO_SORT");
     if (!(ns && ns[0] == '1')) {
@@ -677,10 +806,10 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
       uint32_t *d_keys = nullptr, *d_vals = nullptr;
       void * d_temp = nullptr;
       MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
-      MH_HIP(ctx, hipMalloc(&d_tmp_xyz, n * sizeof(float4)));
-      MH_HIP(ctx, hipMalloc(&d_keys, 2 * n * sizeof(uint32_t)));
-      MH_HIP(ctx, hipMalloc(&d_vals, n * sizeof(uint32_t)));
-      MH_HIP(ctx, hipMalloc(&d_temp, tb ? tb : 16));
+      MH_HIP(ctx, dev_alloc(&d_tmp_xyz, n * sizeof(float4)));
+      MH_HIP(ctx, dev_alloc(&d_keys, 2 * n * sizeof(uint32_t)));
+      MH_HIP(ctx, dev_alloc(&d_vals, n * sizeof(uint32_t)));
+      MH_HIP(ctx, dev_alloc(&d_temp, tb ? tb : 16));
       MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
       float cell = 0.25f;
       if (const char * cs = std::getenv("MH_SORT_CELL")) cell = static_cast<float>(std::atof(cs));
@@ -688,10 +817,10 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
                                            static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
                                            ctx->stream));
       MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      (void)hipFree(d_tmp_xyz);
-      (void)hipFree(d_keys);
-      (void)hipFree(d_vals);
-      (void)hipFree(d_temp);
+      dev_free(d_tmp_xyz);
+      dev_free(d_keys);
+      dev_free(d_vals);
+      dev_free(d_temp);
       icp->ordered = true;
     }
   }
@@ -775,7 +904,7 @@ void mh_icp_destroy(mh_icp * icp)
   icp->d_dbg.release();
   icp->d_perm.release();
   icp->d_eig.release();
-  if (icp->h_results) (void)hipHostFree(icp->h_results);
+  if (icp->h_results) AllocCache::free_pinned(icp->h_results, sizeof(mh::DeviceResult) * kMaxPending);
   if (icp->events_ready)
     for (auto & ev : icp->events)
       for (auto & e : ev) (void)hipEventDestroy(e);
@@ -1036,9 +1165,9 @@ int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, doubl
   int32_t * t_st = nullptr;
   double *t_mean = nullptr, *t_nrm = nullptr;
   if (icp->ordered) {  // back to the caller's point order
-    if (status) MH_HIP(ctx, hipMalloc(&t_st, n * sizeof(int32_t)));
-    if (means) MH_HIP(ctx, hipMalloc(&t_mean, n * 3 * sizeof(double)));
-    if (normals) MH_HIP(ctx, hipMalloc(&t_nrm, n * 3 * sizeof(double)));
+    if (status) MH_HIP(ctx, dev_alloc(&t_st, n * sizeof(int32_t)));
+    if (means) MH_HIP(ctx, dev_alloc(&t_mean, n * 3 * sizeof(double)));
+    if (normals) MH_HIP(ctx, dev_alloc(&t_nrm, n * 3 * sizeof(double)));
     MH_HIP(ctx, mh::launch_unpermute_state(static_cast<const uint32_t *>(icp->d_perm.p), static_cast<int>(n), d_st, d_mean,
                                            d_nrm, t_st, t_mean, t_nrm, ctx->stream));
     d_st = t_st;
@@ -1049,9 +1178,9 @@ int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, doubl
   if (means) MH_HIP(ctx, hipMemcpyAsync(means, d_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (normals) MH_HIP(ctx, hipMemcpyAsync(normals, d_nrm, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (t_st) (void)hipFree(t_st);
-  if (t_mean) (void)hipFree(t_mean);
-  if (t_nrm) (void)hipFree(t_nrm);
+  if (t_st) dev_free(t_st);
+  if (t_mean) dev_free(t_mean);
+  if (t_nrm) dev_free(t_nrm);
   return MH_OK;
 }
 
@@ -1067,9 +1196,9 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
   mh_point32 * d_pts = nullptr;
   uint32_t * d_ns = nullptr;
   float *d_rt = nullptr, *d_body = nullptr;
-  MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
-  MH_HIP(ctx, hipMalloc(&d_ns, (n_groups ? n_groups : 1) * sizeof(uint32_t)));
-  MH_HIP(ctx, hipMalloc(&d_rt, (n_groups ? n_groups : 1) * 12 * sizeof(float)));
+  MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
+  MH_HIP(ctx, dev_alloc(&d_ns, (n_groups ? n_groups : 1) * sizeof(uint32_t)));
+  MH_HIP(ctx, dev_alloc(&d_rt, (n_groups ? n_groups : 1) * 12 * sizeof(float)));
   MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
   if (n_groups) {
     MH_HIP(ctx, hipMemcpyAsync(d_ns, unique_ns, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1079,17 +1208,17 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
     float body[12];
     std::memcpy(body, R_B_L, 9 * sizeof(float));
     std::memcpy(body + 9, t_B_L, 3 * sizeof(float));
-    MH_HIP(ctx, hipMalloc(&d_body, sizeof(body)));
+    MH_HIP(ctx, dev_alloc(&d_body, sizeof(body)));
     MH_HIP(ctx, hipMemcpyAsync(d_body, body, sizeof(body), hipMemcpyHostToDevice, ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `body` is a stack buffer
   }
   MH_HIP(ctx, mh::launch_deskew(d_pts, static_cast<int>(n), d_ns, d_rt, static_cast<int>(n_groups), d_body, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_pts);
-  (void)hipFree(d_ns);
-  (void)hipFree(d_rt);
-  if (d_body) (void)hipFree(d_body);
+  dev_free(d_pts);
+  dev_free(d_ns);
+  dev_free(d_rt);
+  if (d_body) dev_free(d_body);
   return MH_OK;
 }
 
@@ -1103,16 +1232,16 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
   float rt[12];
   std::memcpy(rt, R, 9 * sizeof(float));
   std::memcpy(rt + 9, t, 3 * sizeof(float));
-  MH_HIP(ctx, hipMalloc(&d_pts, n * sizeof(mh_point32)));
-  MH_HIP(ctx, hipMalloc(&d_rt, sizeof(rt)));
+  MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
+  MH_HIP(ctx, dev_alloc(&d_rt, sizeof(rt)));
   MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(d_rt, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MH_HIP(ctx, mh::launch_transform(d_pts, static_cast<int>(n), d_rt, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_pts);
-  (void)hipFree(d_rt);
+  dev_free(d_pts);
+  dev_free(d_rt);
   return MH_OK;
 }
 
