@@ -84,6 +84,27 @@ def main():
     kept = numpy_ref.downsample(cloud, 0.5, 20, 0.15)
     np.savez_compressed(os.path.join(HERE, "downsample.npz"), cloud=cloud, kept=kept)
 
+    # scan front end: Manager::prepareInput on a raw Ouster cloud with dropouts -> deskew -> body subset ->
+    # down-sampler (every stage's output in order)
+    raw, raux = synth.make_raw_scan(16, seed=4242, n_cols=128)
+    fcfg = dict(range_min=2.0, range_max=60.0, intensity_min=10.0, intensity_max=2000.0, ns_max=1.0e9, z_offset=-0.03618,
+                create_full_res_pointcloud=True, point_skip_divisor=2, ring_skip_divisor=1)
+    pi = numpy_ref.prepare_input(raw, **fcfg)
+    full = pi["points_full"]
+    col = {int(u): c for c, u in enumerate(raux["unique_ns"])}
+    Rt12f = np.stack([raux["Rt12"][col[int(u)]] for u in pi["unique_ns"]])
+    fxyz = np.stack([full["x"], full["y"], full["z"]], 1)
+    fdesk = numpy_ref.deskew(fxyz, full["t"], pi["unique_ns"], Rt12f)
+    fbody = numpy_ref.transform_f32(fdesk[pi["geometric_idxs"]], R_B_L, t_B_L)
+    fkept = numpy_ref.downsample(fbody, 1.0, 3, 0.5)  # coarse leaf, cap 3, large min distance: every rule fires
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), raw=raw.view(np.uint8).reshape(len(raw), 32),
+                        cfg_keys=np.array(sorted(fcfg)), cfg_vals=np.array([float(fcfg[k_]) for k_ in sorted(fcfg)]),
+                        full_xyz=fxyz, full_intensity=full["intensity"], full_t=full["t"], full_idx=full["idx"],
+                        full_range=full["range"], geometric_idxs=pi["geometric_idxs"], unique_ns=pi["unique_ns"],
+                        last_point_ns=pi["last_point_ns"], Rt12=Rt12f, R_B_L=R_B_L, t_B_L=t_B_L, deskewed=fdesk,
+                        body=fbody, kept=fkept)
+    print("frontend", len(raw), len(fxyz), len(pi["geometric_idxs"]), len(fkept))
+
     # map insert: kept points in voxel order after three inserts + LRU purge behaviour
     m, _, _ = synth.small_world()
     vm = numpy_ref.VoxelMap(lru_horizon=2, lru_clear_cycle=2)

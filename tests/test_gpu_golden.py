@@ -50,3 +50,29 @@ def test_map_lru_golden(ctx):
     # k-NN still consistent after the purge renumbered the voxels
     pts, sq, found = gm.knn(g["cloud"][:50].astype(np.float64), 1)
     assert (found == 1).all() and np.abs(sq[:, 0]).max() == 0.0
+
+
+def test_frontend_golden_bit_exact(ctx):
+    """Device scan front end vs the committed fixture: every stage, every bit, same order."""
+    from mimosa_amd import capi, synth
+
+    g = load("frontend")
+    raw = np.frombuffer(np.ascontiguousarray(g["raw"]).tobytes(), dtype=synth.OUSTER_DTYPE)
+    kw = {str(k): float(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    for k in ("create_full_res_pointcloud", "point_skip_divisor", "ring_skip_divisor"):
+        kw[k] = int(kw[k])
+    sc = capi.Scan(ctx)
+    info = sc.prepare_input(raw, capi.make_input_config(**kw))
+    full = sc.points(capi.Scan.FULL)
+    assert info["last_point_ns"] == int(g["last_point_ns"])
+    assert np.array_equal(synth.points_xyz(full).view(np.uint32), g["full_xyz"].view(np.uint32))
+    assert np.array_equal(full["t"], g["full_t"]) and np.array_equal(full["idx"], g["full_idx"])
+    assert np.array_equal(full["range"].view(np.uint32), g["full_range"].view(np.uint32))
+    assert np.array_equal(sc.indices(0), g["geometric_idxs"].astype(np.uint32))
+    assert np.array_equal(sc.unique_ns(), g["unique_ns"])
+    sc.deskew(g["Rt12"])
+    assert np.array_equal(synth.points_xyz(sc.points(capi.Scan.FULL)).view(np.uint32), g["deskewed"].view(np.uint32))
+    sc.preprocess_geometric(g["R_B_L"], g["t_B_L"], 1.0, 3, 0.5)
+    assert np.array_equal(synth.points_xyz(sc.points(capi.Scan.BODY)).view(np.uint32), g["body"].view(np.uint32))
+    assert np.array_equal(sc.indices(1), g["kept"].astype(np.uint32))
+    sc.destroy()

@@ -169,3 +169,30 @@ def test_config0_room_plumbing():
     # the perturbation is recovered by one Gauss-Newton step to a few mm / mrad
     dx = np.linalg.solve(r["H_ss"], -r["b_s"])
     assert np.linalg.norm(dx[3:]) < 0.1 and np.linalg.norm(dx[:3]) < 0.03
+
+
+def test_frontend_golden_cpu():
+    """C++ oracle vs the committed front-end fixture (numpy restatement): prepareInput -> deskew -> body -> downsample."""
+    from golden_cases import load
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+
+    g = load("frontend")
+    raw = np.frombuffer(np.ascontiguousarray(g["raw"]).tobytes(), dtype=synth.OUSTER_DTYPE)
+    kw = {str(k): float(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    for k in ("create_full_res_pointcloud", "point_skip_divisor", "ring_skip_divisor"):
+        kw[k] = int(kw[k])
+    o = ref_cpu.prepare_input(raw, ref_cpu.make_input_config(**kw))
+    full = np.frombuffer(o["points_full"].tobytes(), dtype=synth.POINT_DTYPE).copy()
+    assert np.array_equal(synth.points_xyz(full).view(np.uint32), g["full_xyz"].view(np.uint32))
+    assert np.array_equal(full["t"], g["full_t"]) and np.array_equal(full["idx"], g["full_idx"])
+    assert np.array_equal(full["range"].view(np.uint32), g["full_range"].view(np.uint32))
+    assert np.array_equal(full["intensity"].view(np.uint32), g["full_intensity"].view(np.uint32))
+    assert np.array_equal(o["geometric_idxs"], g["geometric_idxs"]) and np.array_equal(o["unique_ns"], g["unique_ns"])
+    assert o["last_point_ns"] == int(g["last_point_ns"])
+    desk = ref_cpu.deskew(full, o["unique_ns"], g["Rt12"])
+    assert np.array_equal(synth.points_xyz(desk).view(np.uint32), g["deskewed"].view(np.uint32))
+    body = ref_cpu.transform_f32(desk[o["geometric_idxs"].astype(np.int64)], g["R_B_L"], g["t_B_L"])
+    assert np.array_equal(synth.points_xyz(body).view(np.uint32), g["body"].view(np.uint32))
+    kept = ref_cpu.downsample(body, 1.0, 3, 0.5)
+    assert np.array_equal(kept, g["kept"]) and 0 < len(kept) < len(body)
