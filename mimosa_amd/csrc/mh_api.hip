@@ -186,6 +186,19 @@ hipError_t dev_alloc(T ** out, size_t bytes)
 }
 inline void dev_free(void * p) { AllocCache::free(p); }
 
+// Scoped device temporary: released (back to the cache) on every exit path, including the early returns of MH_HIP.
+template <typename T>
+struct DevTemp
+{
+  T * p = nullptr;
+  DevTemp() = default;
+  DevTemp(const DevTemp &) = delete;
+  DevTemp & operator=(const DevTemp &) = delete;
+  ~DevTemp() { dev_free(p); }
+  hipError_t alloc(size_t bytes) { return dev_alloc(&p, bytes ? bytes : 16); }
+  operator T *() const { return p; }
+};
+
 // Growable device buffer
 struct DevBuf
 {
@@ -719,22 +732,18 @@ int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * p
   const int rc = map_sync_device(map);
   if (rc != MH_OK) return rc;
   if (n == 0) return MH_OK;
-  double *d_q = nullptr, *d_p = nullptr, *d_s = nullptr;
-  int32_t * d_f = nullptr;
-  MH_HIP(ctx, dev_alloc(&d_q, n * 3 * sizeof(double)));
-  MH_HIP(ctx, dev_alloc(&d_p, n * k * 3 * sizeof(double)));
-  MH_HIP(ctx, dev_alloc(&d_s, n * k * sizeof(double)));
-  MH_HIP(ctx, dev_alloc(&d_f, n * sizeof(int32_t)));
+  DevTemp<double> d_q, d_p, d_s;
+  DevTemp<int32_t> d_f;
+  MH_HIP(ctx, d_q.alloc(n * 3 * sizeof(double)));
+  MH_HIP(ctx, d_p.alloc(n * k * 3 * sizeof(double)));
+  MH_HIP(ctx, d_s.alloc(n * k * sizeof(double)));
+  MH_HIP(ctx, d_f.alloc(n * sizeof(int32_t)));
   MH_HIP(ctx, hipMemcpyAsync(d_q, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, mh::launch_map_knn(map_view(map), d_q, static_cast<int>(n), k, d_p, d_s, d_f, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(point_xyz, d_p, n * k * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(sq_dists, d_s, n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(found, d_f, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(d_q);
-  dev_free(d_p);
-  dev_free(d_s);
-  dev_free(d_f);
   return MH_OK;
 }
 
@@ -758,6 +767,57 @@ static int icp_alloc(mh_icp * icp)
 #endif
   MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending));
   MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_results), icp->h_results, 0));
+  return MH_OK;
+}
+
+// Source cloud (packed, Morton-ordered) and zeroed association state of a freshly allocated factor.  On any
+// failure the caller destroys the handle; the temporaries here are scoped.
+static int icp_init_source(mh_icp * icp, const mh_point32 * source, const mh_point32 * d_source)
+{
+  mh_ctx * ctx = icp->ctx;
+  const size_t n = icp->n;
+  // source cloud: upload the 32-byte records, pack xyz into the 16-byte layout the kernel reads
+  if (n) {
+    DevTemp<mh_point32> d_pts;
+    if (!d_source) {
+      MH_HIP(ctx, d_pts.alloc(n * sizeof(mh_point32)));
+      MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+    }
+    MH_HIP(ctx, mh::launch_pack_xyz(d_source ? d_source : d_pts.p, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p),
+                                    ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
+    const char * ns = std::getenv("MH_NO_SORT");
+    if (!(ns && ns[0] == '1')) {
+      const int ni = static_cast<int>(n);
+      const size_t tb = mh::order_temp_bytes(ni);
+      DevTemp<float4> d_tmp_xyz;
+      DevTemp<uint32_t> d_keys, d_vals;
+      DevTemp<char> d_temp;
+      MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, d_tmp_xyz.alloc(n * sizeof(float4)));
+      MH_HIP(ctx, d_keys.alloc(2 * n * sizeof(uint32_t)));
+      MH_HIP(ctx, d_vals.alloc(n * sizeof(uint32_t)));
+      MH_HIP(ctx, d_temp.alloc(tb));
+      MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+      float cell = 0.25f;
+      if (const char * cs = std::getenv("MH_SORT_CELL")) cell = static_cast<float>(std::atof(cs));
+      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, cell, d_keys, d_vals, d_temp.p, tb,
+                                           static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
+                                           ctx->stream));
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      icp->ordered = true;
+    }
+  }
+  MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
+  // commonConstructor(): all per-point state zero (geometric_factor.hpp:144-156).  Materialised
+  // lazily by the first (cold) linearize; zero here so getters before any linearize read zeros.
+  MH_HIP(ctx, hipMemsetAsync(icp->d_qda.p, 0, icp->d_qda.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_mean.p, 0, icp->d_mean.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_normal.p, 0, icp->d_normal.cap, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(icp->d_status.p, 0, icp->d_status.cap, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
 
@@ -786,53 +846,11 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
     mh_icp_destroy(icp);
     return rc;
   }
-  // source cloud: upload the 32-byte records, pack xyz into the 16-byte layout the kernel reads
-  if (n) {
-    mh_point32 * d_pts = nullptr;
-    if (!d_source) {
-      MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
-      MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
-    }
-    MH_HIP(ctx, mh::launch_pack_xyz(d_source ? d_source : d_pts, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p),
-                                    ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d_pts) dev_free(d_pts);
-    // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
-    const char * ns = std::getenv("MH_NO_SORT");
-    if (!(ns && ns[0] == '1')) {
-      const int ni = static_cast<int>(n);
-      const size_t tb = mh::order_temp_bytes(ni);
-      float4 * d_tmp_xyz = nullptr;
-      uint32_t *d_keys = nullptr, *d_vals = nullptr;
-      void * d_temp = nullptr;
-      MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
-      MH_HIP(ctx, dev_alloc(&d_tmp_xyz, n * sizeof(float4)));
-      MH_HIP(ctx, dev_alloc(&d_keys, 2 * n * sizeof(uint32_t)));
-      MH_HIP(ctx, dev_alloc(&d_vals, n * sizeof(uint32_t)));
-      MH_HIP(ctx, dev_alloc(&d_temp, tb ? tb : 16));
-      MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-      float cell = 0.25f;
-      if (const char * cs = std::getenv("MH_SORT_CELL")) cell = static_cast<float>(std::atof(cs));
-      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, cell, d_keys, d_vals, d_temp, tb,
-                                           static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
-                                           ctx->stream));
-      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      dev_free(d_tmp_xyz);
-      dev_free(d_keys);
-      dev_free(d_vals);
-      dev_free(d_temp);
-      icp->ordered = true;
-    }
+  rc = icp_init_source(icp, source, d_source);
+  if (rc != MH_OK) {
+    mh_icp_destroy(icp);
+    return rc;
   }
-  MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
-  // commonConstructor(): all per-point state zero (geometric_factor.hpp:144-156).  Materialised
-  // lazily by the first (cold) linearize; zero here so getters before any linearize read zeros.
-  MH_HIP(ctx, hipMemsetAsync(icp->d_qda.p, 0, icp->d_qda.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_mean.p, 0, icp->d_mean.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_normal.p, 0, icp->d_normal.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_status.p, 0, icp->d_status.cap, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   icp->cold = true;
   *out = icp;
   return MH_OK;
@@ -980,10 +998,10 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   a.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
   a.host_result = nullptr;  // set below once the slot is known
   a.dbg = static_cast<unsigned long long *>(icp->d_dbg.p);
-  {
-    const char * rp = std::getenv("MH_REPS");
-    a.reps = rp ? std::atoi(rp) : 1;
-  }
+  a.reps = 1;
+#ifdef MH_TIMELINE
+  if (const char * rp = std::getenv("MH_REPS")) a.reps = std::atoi(rp);
+#endif
 
   mh::LocArgs l;
   l.src = a.src;
@@ -1162,25 +1180,22 @@ int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, doubl
   const int32_t * d_st = static_cast<const int32_t *>(icp->d_status.p);
   const double * d_mean = static_cast<const double *>(icp->d_mean.p);
   const double * d_nrm = static_cast<const double *>(icp->d_normal.p);
-  int32_t * t_st = nullptr;
-  double *t_mean = nullptr, *t_nrm = nullptr;
+  DevTemp<int32_t> t_st;
+  DevTemp<double> t_mean, t_nrm;
   if (icp->ordered) {  // back to the caller's point order
-    if (status) MH_HIP(ctx, dev_alloc(&t_st, n * sizeof(int32_t)));
-    if (means) MH_HIP(ctx, dev_alloc(&t_mean, n * 3 * sizeof(double)));
-    if (normals) MH_HIP(ctx, dev_alloc(&t_nrm, n * 3 * sizeof(double)));
+    if (status) MH_HIP(ctx, t_st.alloc(n * sizeof(int32_t)));
+    if (means) MH_HIP(ctx, t_mean.alloc(n * 3 * sizeof(double)));
+    if (normals) MH_HIP(ctx, t_nrm.alloc(n * 3 * sizeof(double)));
     MH_HIP(ctx, mh::launch_unpermute_state(static_cast<const uint32_t *>(icp->d_perm.p), static_cast<int>(n), d_st, d_mean,
-                                           d_nrm, t_st, t_mean, t_nrm, ctx->stream));
-    d_st = t_st;
-    d_mean = t_mean;
-    d_nrm = t_nrm;
+                                           d_nrm, t_st.p, t_mean.p, t_nrm.p, ctx->stream));
+    d_st = t_st.p;
+    d_mean = t_mean.p;
+    d_nrm = t_nrm.p;
   }
   if (status) MH_HIP(ctx, hipMemcpyAsync(status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (means) MH_HIP(ctx, hipMemcpyAsync(means, d_mean, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (normals) MH_HIP(ctx, hipMemcpyAsync(normals, d_nrm, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (t_st) dev_free(t_st);
-  if (t_mean) dev_free(t_mean);
-  if (t_nrm) dev_free(t_nrm);
   return MH_OK;
 }
 
@@ -1193,12 +1208,12 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
   if ((R_B_L == nullptr) != (t_B_L == nullptr)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_deskew: R_B_L and t_B_L go together");
   if (n == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  mh_point32 * d_pts = nullptr;
-  uint32_t * d_ns = nullptr;
-  float *d_rt = nullptr, *d_body = nullptr;
-  MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
-  MH_HIP(ctx, dev_alloc(&d_ns, (n_groups ? n_groups : 1) * sizeof(uint32_t)));
-  MH_HIP(ctx, dev_alloc(&d_rt, (n_groups ? n_groups : 1) * 12 * sizeof(float)));
+  DevTemp<mh_point32> d_pts;
+  DevTemp<uint32_t> d_ns;
+  DevTemp<float> d_rt, d_body;
+  MH_HIP(ctx, d_pts.alloc(n * sizeof(mh_point32)));
+  MH_HIP(ctx, d_ns.alloc((n_groups ? n_groups : 1) * sizeof(uint32_t)));
+  MH_HIP(ctx, d_rt.alloc((n_groups ? n_groups : 1) * 12 * sizeof(float)));
   MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
   if (n_groups) {
     MH_HIP(ctx, hipMemcpyAsync(d_ns, unique_ns, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1208,17 +1223,13 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
     float body[12];
     std::memcpy(body, R_B_L, 9 * sizeof(float));
     std::memcpy(body + 9, t_B_L, 3 * sizeof(float));
-    MH_HIP(ctx, dev_alloc(&d_body, sizeof(body)));
+    MH_HIP(ctx, d_body.alloc(sizeof(body)));
     MH_HIP(ctx, hipMemcpyAsync(d_body, body, sizeof(body), hipMemcpyHostToDevice, ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `body` is a stack buffer
   }
   MH_HIP(ctx, mh::launch_deskew(d_pts, static_cast<int>(n), d_ns, d_rt, static_cast<int>(n_groups), d_body, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(d_pts);
-  dev_free(d_ns);
-  dev_free(d_rt);
-  if (d_body) dev_free(d_body);
   return MH_OK;
 }
 
@@ -1227,21 +1238,19 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
   if (!ctx || (!pts && n) || !R || !t) return fail(ctx, MH_ERR_INVALID_ARG, "mh_transform_f32: NULL argument");
   if (n == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  mh_point32 * d_pts = nullptr;
-  float * d_rt = nullptr;
+  DevTemp<mh_point32> d_pts;
+  DevTemp<float> d_rt;
   float rt[12];
   std::memcpy(rt, R, 9 * sizeof(float));
   std::memcpy(rt + 9, t, 3 * sizeof(float));
-  MH_HIP(ctx, dev_alloc(&d_pts, n * sizeof(mh_point32)));
-  MH_HIP(ctx, dev_alloc(&d_rt, sizeof(rt)));
+  MH_HIP(ctx, d_pts.alloc(n * sizeof(mh_point32)));
+  MH_HIP(ctx, d_rt.alloc(sizeof(rt)));
   MH_HIP(ctx, hipMemcpyAsync(d_pts, pts, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(d_rt, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MH_HIP(ctx, mh::launch_transform(d_pts, static_cast<int>(n), d_rt, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(d_pts);
-  dev_free(d_rt);
   return MH_OK;
 }
 
