@@ -221,6 +221,21 @@ def main():
                     "device_sync_ms": round((a3 - a2) * 1e3, 3), "bytes_uploaded": int(s1["upload_bytes"] - s0["upload_bytes"]),
                     "delta": bool(s1["delta_uploads"] > s0["delta_uploads"]), "mirror_bytes": int(s1["device_bytes"])}
         gmap2.release()
+        # the same update with mh_map_fork (the host structure changes hands, the old map becomes read-only)
+        gsrc = gmap.copy()
+        gsrc.sync()
+        ctx.synchronize()
+        b0 = time.perf_counter()
+        gmap3 = gsrc.fork()
+        b1 = time.perf_counter()
+        gmap3.insert(xyz)
+        b2 = time.perf_counter()
+        gmap3.sync()
+        b3 = time.perf_counter()
+        kf_stats.update({"fork_ms": round((b1 - b0) * 1e3, 3), "fork_insert_ms": round((b2 - b1) * 1e3, 3),
+                         "fork_sync_ms": round((b3 - b2) * 1e3, 3)})
+        gmap3.release()
+        gsrc.release()
 
     # Scan front end (rows a2-a5 / f-3): raw 128 x 1024 Ouster cloud -> prepareInput -> deskew -> body subset ->
     # voxel down-sampler, on the device (one 4 MiB upload) vs the oracle's sequential CPU code on this host.

@@ -197,6 +197,13 @@ int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_float
 /* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by
  * Geometric::updateMap's copy-then-insert (geometric.cpp:494). */
 int mh_map_copy(const mh_map * map, mh_map ** out);
+/* Copy-then-insert without the host copy (Geometric::updateMap, geometric.cpp:494-495, replaces its map with a
+ * copy and inserts into the copy; the old object lives on only through the factors that hold it).  The fork takes
+ * over the source's host-side structure in O(1) and gets a device-to-device copy of its mirror; the SOURCE becomes
+ * read-only: factors keep linearizing against it, mh_map_knn / mh_map_get_cloud / mh_map_get_stats keep working,
+ * mh_map_insert / mh_map_copy / mh_map_fork on it fail with MH_ERR_UNSUPPORTED.  Use mh_map_copy when both maps
+ * must stay writable. */
+int mh_map_fork(mh_map * map, mh_map ** out);
 /* shared_ptr semantics: factors retain the map they were built with. */
 int mh_map_retain(mh_map * map);
 void mh_map_release(mh_map * map);

@@ -20,7 +20,7 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 EXPORTS = [
     "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
-    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
+    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
@@ -163,6 +163,7 @@ def load(build_if_missing: bool = True):
     L.mh_map_create.argtypes = [vp, C.POINTER(MapConfig), pvp]
     L.mh_map_insert.argtypes = [vp, vp, sz, sz]
     L.mh_map_copy.argtypes = [vp, pvp]
+    L.mh_map_fork.argtypes = [vp, pvp]
     L.mh_map_retain.argtypes = [vp]
     L.mh_map_release.argtypes = [vp]
     L.mh_map_release.restype = None
@@ -291,6 +292,13 @@ class VoxelMap:
     def copy(self):
         h = C.c_void_p()
         self.ctx.check(self.L.mh_map_copy(self.h, C.byref(h)))
+        return VoxelMap(self.ctx, _h=h)
+
+    def fork(self):
+        """Copy-then-insert without the host copy: returns the writable successor, this map becomes read-only
+        (factors keep using it; knn / get_cloud / stats still work)."""
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_map_fork(self.h, C.byref(h)))
         return VoxelMap(self.ctx, _h=h)
 
     def sync(self):

@@ -244,6 +244,11 @@ struct mh_map
   int64_t delta_uploads = 0, full_uploads = 0;
   bool device_stale = true;
   int64_t uploads = 0, upload_bytes = 0;
+  // mh_map_fork moved the host structure to the fork: this handle keeps its device mirror (factors read it)
+  // and just enough to answer stats / get_cloud
+  bool frozen = false;
+  std::vector<uint8_t> frozen_counts;
+  int64_t frozen_voxels = 0, frozen_points = 0, frozen_blocks = 0;
   int n_off = 0;
   int8_t off[27][3];
   explicit mh_map(mh_ctx * c, const mh_map_config & cfg) : ctx(c), host(cfg)
@@ -633,6 +638,7 @@ int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_float
 {
   if (!map || (!xyz && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert: NULL argument");
   if (stride_floats < 3) return fail(map->ctx, MH_ERR_INVALID_ARG, "mh_map_insert: stride_floats must be >= 3");
+  if (map->frozen) return fail(map->ctx, MH_ERR_UNSUPPORTED, "mh_map_insert: this map was forked (mh_map_fork) and is read-only");
   map->host.insert(xyz, n, stride_floats);
   map->device_stale = true;
   return MH_OK;
@@ -642,6 +648,7 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
 {
   if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_copy: NULL argument");
   *out = nullptr;
+  if (src->frozen) return fail(src->ctx, MH_ERR_UNSUPPORTED, "mh_map_copy: this map was forked (mh_map_fork); copy the fork");
   mh_map * map = new (std::nothrow) mh_map(src->ctx, src->host.config());
   if (!map) return fail(src->ctx, MH_ERR_OOM, "mh_map_copy: host allocation failed");
   map->host = src->host;  // deep copy of the flat arrays (multi-threaded, recycled pages: voxel_map.hpp)
@@ -703,9 +710,9 @@ int mh_map_sync(mh_map * map)
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
 {
   if (!map || !out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_stats: NULL argument");
-  out->n_voxels = static_cast<int64_t>(map->host.n_voxels());
-  out->n_points = static_cast<int64_t>(map->host.n_points());
-  out->n_blocks = static_cast<int64_t>(map->host.n_blocks());
+  out->n_voxels = map->frozen ? map->frozen_voxels : static_cast<int64_t>(map->host.n_voxels());
+  out->n_points = map->frozen ? map->frozen_points : static_cast<int64_t>(map->host.n_points());
+  out->n_blocks = map->frozen ? map->frozen_blocks : static_cast<int64_t>(map->host.n_blocks());
   out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap + map->d_qbuckets.cap);
   out->uploads = map->uploads;
   out->upload_bytes = map->upload_bytes;
@@ -717,7 +724,69 @@ int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
 int mh_map_get_cloud(const mh_map * map, float * xyz, size_t capacity_points, size_t * n_out)
 {
   if (!map || !n_out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_cloud: NULL argument");
-  *n_out = map->host.get_cloud(xyz, capacity_points);
+  if (!map->frozen) {
+    *n_out = map->host.get_cloud(xyz, capacity_points);
+    return MH_OK;
+  }
+  // forked source: the points live in the device mirror only; the per-voxel counts were kept
+  *n_out = static_cast<size_t>(map->frozen_points);
+  if (!xyz || map->frozen_points == 0) return MH_OK;
+  mh_ctx * ctx = map->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<mh::Float4> b(map->frozen_counts.size() * mh::kBucketStride);
+  MH_HIP(ctx, hipMemcpy(b.data(), map->d_buckets.p, b.size() * sizeof(mh::Float4), hipMemcpyDeviceToHost));
+  size_t n = 0;
+  for (size_t v = 0; v < map->frozen_counts.size(); ++v)
+    for (size_t j = 0; j < map->frozen_counts[v]; ++j, ++n)
+      if (n < capacity_points) {
+        const mh::Float4 & p = b[v * mh::kBucketStride + j];
+        xyz[3 * n + 0] = p.x;
+        xyz[3 * n + 1] = p.y;
+        xyz[3 * n + 2] = p.z;
+      }
+  return MH_OK;
+}
+
+int mh_map_fork(mh_map * src, mh_map ** out)
+{
+  if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_fork: NULL argument");
+  *out = nullptr;
+  mh_ctx * ctx = src->ctx;
+  if (src->frozen) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_fork: this map was already forked; fork the fork");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_sync_device(src);  // the source keeps nothing but its device mirror: make it current first
+  if (rc != MH_OK) return rc;
+  mh_map * map = new (std::nothrow) mh_map(ctx, src->host.config());
+  if (!map) return fail(ctx, MH_ERR_OOM, "mh_map_fork: host allocation failed");
+  // device mirror: device-to-device copy, as in mh_map_copy
+  auto dup = [&](const DevBuf & a, DevBuf & b) -> hipError_t {
+    if (!a.cap) return hipSuccess;
+    hipError_t e = b.reserve(a.cap, ctx->stream, false);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(b.p, a.p, a.cap, hipMemcpyDeviceToDevice, ctx->stream);
+  };
+  hipError_t e = dup(src->d_table, map->d_table);
+  if (e == hipSuccess) e = dup(src->d_cells, map->d_cells);
+  if (e == hipSuccess) e = dup(src->d_buckets, map->d_buckets);
+  if (e == hipSuccess) e = dup(src->d_qbuckets, map->d_qbuckets);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    mh_map_release(map);
+    return hip_fail(ctx, e, "mh_map_fork: device mirror copy");
+  }
+  map->dev_valid = src->dev_valid;
+  map->dev_n_voxels = src->dev_n_voxels;
+  map->dev_n_blocks = src->dev_n_blocks;
+  map->dev_table_cap = src->dev_table_cap;
+  map->device_stale = false;
+  // host structure: moved, not copied
+  src->frozen_counts = src->host.counts();
+  src->frozen_voxels = static_cast<int64_t>(src->host.n_voxels());
+  src->frozen_points = static_cast<int64_t>(src->host.n_points());
+  src->frozen_blocks = static_cast<int64_t>(src->host.n_blocks());
+  map->host.take_from(src->host);
+  src->frozen = true;
+  *out = map;
   return MH_OK;
 }
 

@@ -246,6 +246,13 @@ public:
     if (this != &o) copy_from(o);
     return *this;
   }
+  // mh_map_fork: the whole structure changes hands in O(1); `o` is left an empty map of the same configuration
+  void take_from(HostVoxelMap & o)
+  {
+    HostVoxelMap fresh(o.cfg_);
+    swap_all(o);
+    o.swap_all(fresh);
+  }
 
   const mh_map_config & config() const { return cfg_; }
   double inv_leaf() const { return inv_leaf_; }
@@ -526,6 +533,32 @@ private:
       for (auto & t : th) t.join();
     }
     dst.swap(v);
+  }
+  void swap_all(HostVoxelMap & o)
+  {
+    using std::swap;
+    swap(cfg_, o.cfg_);
+    swap(inv_leaf_, o.inv_leaf_);
+    swap(min_sq_, o.min_sq_);
+    swap(lru_counter_, o.lru_counter_);
+    swap(n_points_, o.n_points_);
+    vox_coord_.swap(o.vox_coord_);
+    vox_count_.swap(o.vox_count_);
+    vox_lru_.swap(o.vox_lru_);
+    vox_cells_.swap(o.vox_cells_);
+    vox_ncells_.swap(o.vox_ncells_);
+    buckets_.swap(o.buckets_);
+    qbuckets_.swap(o.qbuckets_);
+    swap(n_blocks_, o.n_blocks_);
+    block_coord_.swap(o.block_coord_);
+    cells_.swap(o.cells_);
+    table_.swap(o.table_);
+    swap(table_mask_, o.table_mask_);
+    last_block_ = o.last_block_ = -1;
+    dirty_flag_.swap(o.dirty_flag_);
+    dirty_.swap(o.dirty_);
+    swap(structure_changed_, o.structure_changed_);
+    swap(full_rebuild_, o.full_rebuild_);
   }
   void copy_from(const HostVoxelMap & o)
   {

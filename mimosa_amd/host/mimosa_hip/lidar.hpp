@@ -108,6 +108,16 @@ public:
   IncrementalVoxelMapPCL & operator=(const IncrementalVoxelMapPCL &) = delete;
   ~IncrementalVoxelMapPCL() { mh_map_release(map_); }
 
+  // Successor for copy-then-insert (geometric.cpp:494-495) without copying the host structure: the returned map
+  // continues this one; THIS object stays valid for the factors that hold it (k-NN, getCloud) but is read-only.
+  std::shared_ptr<IncrementalVoxelMapPCL> fork()
+  {
+    ensure();
+    std::shared_ptr<IncrementalVoxelMapPCL> next(new IncrementalVoxelMapPCL(ctx_, cfg_, nullptr));
+    ctx_->check(mh_map_fork(map_, &next->map_), "mh_map_fork");
+    return next;
+  }
+
   // iVox setters used at geometric.cpp:25-28 — must precede the first insert
   void set_lru_horizon(size_t h) { require_empty(); cfg_.lru_horizon = static_cast<int64_t>(h); }
   void set_neighbor_voxel_mode(size_t m) { require_empty(); cfg_.neighbor_voxel_mode = static_cast<int32_t>(m); }
@@ -158,6 +168,7 @@ public:
   const std::shared_ptr<Context> & context() const { return ctx_; }
 
 private:
+  IncrementalVoxelMapPCL(const std::shared_ptr<Context> & ctx, const mh_map_config & cfg, std::nullptr_t) : ctx_(ctx), cfg_(cfg) {}
   void ensure()
   {
     if (!map_) ctx_->check(mh_map_create(ctx_->get(), &cfg_, &map_), "mh_map_create");
@@ -536,7 +547,7 @@ public:
     for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
     for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
     if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
-    ivox_map_ = std::make_shared<IncrementalVoxelMapPCL>(*ivox_map_);
+    ivox_map_ = ivox_map_->fork();  // the previous map lives on, read-only, in the factors that hold it
     ivox_map_->insert(W);
     map_poses_.push_back(T_W_Be);
   }

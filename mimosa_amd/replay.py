@@ -114,7 +114,7 @@ class HipBackend:
     def update_map(self, body, R, t):
         # Geometric::updateMap: world transform in f32 (geometric.cpp:483-490), copy-then-insert (:494-495)
         W = self.ctx.transform_f32(body, R.astype(np.float32), t.astype(np.float32))
-        new = self.map.copy()
+        new = self.map.fork()  # the old map stays valid (read-only) for the factors that hold it
         new.insert(np.stack([W["x"], W["y"], W["z"]], 1))
         new.sync()
         self.map.release()

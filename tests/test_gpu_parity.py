@@ -381,3 +381,49 @@ def test_keyframe_update_copy_then_insert_is_a_delta(ctx, small_world):
     gf = capi.ICPFactor(ctx, gb, small_world["pts"], capi.make_reg_config(**cfg))
     rf = ref_cpu.ICP(rb, small_world["pts"], ref_cpu.make_config(**cfg))
     assert_result_parity(gf.linearize(small_world["R"], small_world["t"]), rf.linearize(small_world["R"], small_world["t"]))
+
+
+def test_fork_moves_host_state_and_freezes_the_source(ctx, small_world):
+    """mh_map_fork: the fork continues the map, the source stays usable read-only (k-NN, cloud, stats) and refuses
+    mutation; a factor built on the source keeps its answers while the fork grows."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    w = small_world
+    half = len(w["map_xyz"]) // 2
+    gm = capi.VoxelMap(ctx)
+    rm = ref_cpu.Map()
+    gm.insert(w["map_xyz"][:half])
+    rm.insert(w["map_xyz"][:half])
+    cfg = capi.make_reg_config(**w["cfg"])
+    f_old = capi.ICPFactor(ctx, gm, w["pts"], cfg)
+    r_old = f_old.linearize(w["R"], w["t"])
+    cloud_before, stats_before = gm.get_cloud(), gm.stats()
+
+    g2 = gm.fork()
+    rm2 = rm.copy()
+    g2.insert(w["map_xyz"][half:])
+    rm2.insert(w["map_xyz"][half:])
+    _, _, xyz2 = rm2.export()
+    assert np.array_equal(g2.get_cloud(), xyz2)                      # the fork = copy-then-insert
+    assert g2.stats()["n_points"] == rm2.num_points
+
+    # the source: unchanged content, still answers, refuses writes
+    assert np.array_equal(gm.get_cloud(), cloud_before)
+    s = gm.stats()
+    assert s["n_points"] == stats_before["n_points"] and s["n_voxels"] == stats_before["n_voxels"]
+    q = w["map_xyz"][:200].astype(np.float64) + 0.05
+    _, sq, found = gm.knn(q, 5)
+    _, sq_r, found_r, _ = rm.knn(q, 5)
+    assert np.array_equal(found, found_r) and np.array_equal(sq[found == 5], sq_r[found_r == 5])
+    with pytest.raises(capi.MhError):
+        gm.insert(w["map_xyz"][:10])
+    with pytest.raises(capi.MhError):
+        gm.copy()
+    f_old.reset()
+    r_again = f_old.linearize(w["R"], w["t"])                        # the old factor still sees the old map
+    assert np.array_equal(r_again["H_ss"], r_old["H_ss"]) and r_again["f"] == r_old["f"]
+    # a factor on the fork sees the grown map
+    f_new = capi.ICPFactor(ctx, g2, w["pts"], cfg)
+    rf = ref_cpu.ICP(rm2, w["pts"], ref_cpu.make_config(**w["cfg"]))
+    assert_result_parity(f_new.linearize(w["R"], w["t"]), rf.linearize(w["R"], w["t"]))
