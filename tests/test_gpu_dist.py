@@ -21,3 +21,24 @@ def test_sharded_layer_on_hip_backend_world1():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_sharded_layer_on_hip_backend_world2():
+    """Two ranks on the one GPU of the box (gloo collectives, HIP compute): sharded == unsharded oracle."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker2.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and f"OK {r}" in out, err[-2000:]
