@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   constexpr int EW = BINARY ? 96 : 32;
   constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
   // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [reduce] rows, segment sums.
-  constexpr int kListWords = kMaxOff * kThreads;
+  constexpr int kListWords = NOFF * kThreads;
   constexpr int kTileRows = SEGS * PPS;          // >= kThreads; rows past the block's points are zero
   constexpr int kRowWords = kTileRows * ROWW * 2;
   constexpr int kSegWords = SEGS * NENT * 2;
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   __shared__ uint32_t s_scan[kScanLutWords];
   __shared__ bool s_last;
 
-  uint32_t * s_list = s_arena + threadIdx.x;                                          // [kMaxOff][kThreads]
+  uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][kThreads]
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [kThreads][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
