@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void input_filter_kernel(const mh_ouster_
     flag_full[i] = keep ? 1u : 0u;
     // :318-334 point-skip and ring filters select the geometric subset
     flag_geo[i] = (keep && (i % f.point_skip) == 0 && (p.ring % f.ring_skip) == 0) ? 1u : 0u;
-    if (keep) atomicMax(&counters->last_point_ns, p.t);                                 // :310
+    // (:310 last_point_ns = max t over the kept points falls out of the timestamp sort: unique_scatter_kernel)
   }
 }
 
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(kThreads) void unique_scatter_kernel(const uint32_t
   for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
     if (flags[i]) out[pos[i]] = keys[i];
     if (i == n - 1) c->n_unique_ns = pos[i] + flags[i];
+    // the largest kept timestamp = the last non-sentinel key of the sorted list (manager.cpp:310)
+    if (keys[i] != kNoKey32 && (i == n - 1 || keys[i + 1] == kNoKey32)) c->last_point_ns = keys[i];
   }
 }
 
@@ -179,37 +181,55 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
   }
 }
 
-// One thread per voxel: FlatContainerMinimal::add over the voxel's points in input order.  keep[] is
-// indexed by sorted position; first_idx[i] = input index of the first point of the voxel of position i.
+// One WAVE per voxel: FlatContainerMinimal::add over the voxel's points in input order.  Lane j holds the j-th
+// point kept so far (<= 20); every incoming point is tested against all of them at once (one fp64 distance per
+// lane, one ballot) — a thread-per-voxel walk of the same lists was a chain of dependent scattered loads and took
+// 250 us, 44 % of the whole front end.  keep[] is indexed by sorted position; first_idx[s] = input index of the
+// first point of the voxel of position s.
 __global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * pts, const uint32_t * sorted_idx,
                                                                  const uint32_t * seg_start, const ScanCounters * c,
                                                                  uint32_t max_pts, double min_sq, uint32_t * keep,
                                                                  uint32_t * first_idx)
 {
   const uint32_t nv = c->n_voxels;
-  for (uint32_t v = blockIdx.x * kThreads + threadIdx.x; v < nv; v += gridDim.x * kThreads) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6, n_waves = (gridDim.x * kThreads) >> 6;
+  const uint32_t cap = min(max_pts, static_cast<uint32_t>(kBucketStride));  // utils.hpp:262 size cap
+  for (uint32_t v = wave; v < nv; v += n_waves) {
     const uint32_t s0 = seg_start[v], s1 = seg_start[v + 1];
     const uint32_t first = sorted_idx[s0];  // stable sort: the smallest input index of the voxel
-    uint32_t kept_pos[kBucketStride];       // positions (sorted order) of the points kept so far
+    double kx = 0.0, ky = 0.0, kz = 0.0;    // this lane's kept point (lane < n_kept)
     uint32_t n_kept = 0;
-    for (uint32_t s = s0; s < s1; ++s) {
-      first_idx[s] = first;
-      bool take = n_kept < max_pts && n_kept < static_cast<uint32_t>(kBucketStride);  // utils.hpp:262 size cap
-      if (take) {
+    for (uint32_t base = s0; base < s1; base += 64u) {  // the segment, 64 points at a time (coalesced index loads)
+      const uint32_t s = base + lane;
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (s < s1) {
         const mh_point32 p = pts[sorted_idx[s]];
-        const double px = p.x, py = p.y, pz = p.z;
-        for (uint32_t j = 0; j < n_kept; ++j) {
-          const mh_point32 e = pts[sorted_idx[kept_pos[j]]];
-          const double dx = static_cast<double>(e.x) - px, dy = static_cast<double>(e.y) - py,
-                       dz = static_cast<double>(e.z) - pz;
-          if (dx * dx + (dy * dy + dz * dz) < min_sq) {  // Vector3d squaredNorm: p0 + (p1 + p2); utils.hpp:266-272
-            take = false;
-            break;
+        px = p.x;
+        py = p.y;
+        pz = p.z;
+        first_idx[s] = first;
+      }
+      const uint32_t m = min(64u, s1 - base);
+      uint64_t kept_mask = 0;
+      for (uint32_t u = 0; u < m; ++u) {  // input order
+        const double qx = static_cast<double>(__shfl(px, static_cast<int>(u))), qy = static_cast<double>(__shfl(py, static_cast<int>(u))),
+                     qz = static_cast<double>(__shfl(pz, static_cast<int>(u)));
+        const double dx = kx - qx, dy = ky - qy, dz = kz - qz;
+        // Vector3d squaredNorm: p0 + (p1 + p2); utils.hpp:266-272
+        const bool close = lane < n_kept && dx * dx + (dy * dy + dz * dz) < min_sq;
+        const bool take = n_kept < cap && __ballot(close) == 0ull;
+        if (take) {
+          if (lane == n_kept) {
+            kx = qx;
+            ky = qy;
+            kz = qz;
           }
+          ++n_kept;
+          kept_mask |= 1ull << u;
         }
       }
-      keep[s] = take ? 1u : 0u;
-      if (take) kept_pos[n_kept++] = s;
+      if (s < s1) keep[s] = static_cast<uint32_t>((kept_mask >> lane) & 1ull);
     }
   }
 }
@@ -337,8 +357,8 @@ hipError_t launch_downsample(const mh_point32 * body, uint32_t n, double leaf, u
   hipLaunchKernelGGL(head_flags64_kernel, g, b, 0, stream, keys_b, n, flags);
   if ((e = exclusive_sum(flags, pos, n, temp, temp_bytes, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(segment_starts_kernel, g, b, 0, stream, flags, pos, n, seg_start, counters);
-  hipLaunchKernelGGL(greedy_voxel_kernel, g, b, 0, stream, body, idx_b, seg_start, counters, max_pts, min_sq, flags,
-                     first_idx);  // flags now = keep
+  hipLaunchKernelGGL(greedy_voxel_kernel, dim3(static_cast<int>(min((static_cast<size_t>(n) * 64 + kThreads - 1) / kThreads, static_cast<size_t>(8192)))), b, 0, stream,
+                     body, idx_b, seg_start, counters, max_pts, min_sq, flags, first_idx);  // flags now = keep
   if ((e = exclusive_sum(flags, pos, n, temp, temp_bytes, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(fill64_kernel, g, b, 0, stream, keys_a, n, kNoKey64);
   hipLaunchKernelGGL(order_keys_kernel, g, b, 0, stream, idx_b, flags, pos, first_idx, n, keys_a, counters);
