@@ -37,6 +37,8 @@ struct mh_ctx
   std::string err;
   int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
   hipEvent_t timer[2] = {nullptr, nullptr};
+  void * h_stage = nullptr;  // pinned staging for map delta records (pageable -> device copies run at a few GB/s)
+  size_t h_stage_cap = 0;
 };
 
 namespace
@@ -345,38 +347,53 @@ int map_sync_device(mh_map * m)
                                  hipMemcpyHostToDevice, ctx->stream));
       moved += static_cast<int64_t>(n * (sizeof(mh::Float4) + sizeof(uint32_t)));
     }
-    // (3) scatter: buckets of touched OLD voxels, cell words of every touched voxel that lives in an old block
-    std::vector<mh::MapScatterRecord> recs;
-    std::vector<uint2> cellu;
-    for (const uint32_t vid : H.dirty_voxels()) {
+    // (3) scatter: buckets of touched OLD voxels, cell words of every touched voxel that lives in an old block.
+    //     Records are built straight into pinned memory: [records | cell updates].
+    const auto & dirty = H.dirty_voxels();
+    size_t n_recs = 0, n_cellu_max = 0;
+    for (const uint32_t vid : dirty) {
+      n_recs += vid < m->dev_n_voxels ? 1 : 0;
+      n_cellu_max += 8;
+    }
+    const size_t rb = n_recs * sizeof(mh::MapScatterRecord), rb_al = (rb + 15) & ~size_t(15);
+    const size_t need = rb_al + n_cellu_max * sizeof(uint2) + 16;
+    if (need > ctx->h_stage_cap) {
+      if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+      ctx->h_stage = nullptr;
+      ctx->h_stage_cap = 0;
+      const size_t cap = need + need / 2;
+      MH_HIP(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+      ctx->h_stage_cap = cap;
+    }
+    auto * recs = reinterpret_cast<mh::MapScatterRecord *>(ctx->h_stage);
+    auto * cellu = reinterpret_cast<uint2 *>(static_cast<char *>(ctx->h_stage) + rb_al);
+    size_t ir = 0, ic = 0;
+    for (const uint32_t vid : dirty) {
       const uint32_t * pos = nullptr;
       const int np = H.voxel_cell_positions(vid, &pos);
       for (int k = 0; k < np; ++k)
-        if (pos[k] < m->dev_n_blocks * mh::kCellsPerBlock) cellu.push_back(make_uint2(pos[k], H.cells()[pos[k]]));
+        if (pos[k] < m->dev_n_blocks * mh::kCellsPerBlock) cellu[ic++] = make_uint2(pos[k], H.cells()[pos[k]]);
       if (vid < m->dev_n_voxels) {
-        mh::MapScatterRecord r;
+        mh::MapScatterRecord & r = recs[ir++];
         r.vid = vid;
         r.n_pts = H.counts()[vid];
         r.pad0 = r.pad1 = 0;
         std::memcpy(r.pts, &H.buckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.pts));
         std::memcpy(r.q, &H.qbuckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.q));
-        recs.push_back(r);
       }
     }
-    if (!recs.empty() || !cellu.empty()) {
-      const size_t rb = recs.size() * sizeof(mh::MapScatterRecord), ub = cellu.size() * sizeof(uint2);
-      const size_t rb_al = (rb + 15) & ~size_t(15);
+    if (ir || ic) {
+      const size_t ub = ic * sizeof(uint2);
       MH_HIP(ctx, m->d_stage.reserve(rb_al + ub + 16, ctx->stream, false));
       char * st = static_cast<char *>(m->d_stage.p);
-      if (rb) MH_HIP(ctx, hipMemcpyAsync(st, recs.data(), rb, hipMemcpyHostToDevice, ctx->stream));
-      if (ub) MH_HIP(ctx, hipMemcpyAsync(st + rb_al, cellu.data(), ub, hipMemcpyHostToDevice, ctx->stream));
-      MH_HIP(ctx, mh::launch_map_scatter(reinterpret_cast<const mh::MapScatterRecord *>(st), static_cast<int>(recs.size()),
+      MH_HIP(ctx, hipMemcpyAsync(st, ctx->h_stage, rb_al + ub, hipMemcpyHostToDevice, ctx->stream));
+      MH_HIP(ctx, mh::launch_map_scatter(reinterpret_cast<const mh::MapScatterRecord *>(st), static_cast<int>(ir),
                                          static_cast<float4 *>(m->d_buckets.p), static_cast<uint32_t *>(m->d_qbuckets.p),
-                                         reinterpret_cast<const uint2 *>(st + rb_al), static_cast<int>(cellu.size()),
+                                         reinterpret_cast<const uint2 *>(st + rb_al), static_cast<int>(ic),
                                          static_cast<uint32_t *>(m->d_cells.p), ctx->stream));
       moved += static_cast<int64_t>(rb + ub);
     }
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // recs / cellu are stack-owned
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next sync
     m->delta_uploads++;
   }
   H.clear_dirty();
@@ -578,6 +595,7 @@ void mh_shutdown(mh_ctx * ctx)
   }
   if (ctx->timer[0]) (void)hipEventDestroy(ctx->timer[0]);
   if (ctx->timer[1]) (void)hipEventDestroy(ctx->timer[1]);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   delete ctx;
 }
 
