@@ -148,7 +148,7 @@ __device__ __forceinline__ double lane_get(double v, int l)
 #define MH_STAMP(ptr, i)                                                                       \
   do {                                                                                         \
     if ((ptr) && (threadIdx.x & 63) == 0)                                                      \
-      (ptr)[(static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16 + (i)] = \
+      (ptr)[(static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = \
         __builtin_amdgcn_s_memtime();                                                          \
   } while (0)
 #else
@@ -450,7 +450,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #undef MH_PREFETCH
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
     if (dbg && (threadIdx.x & 63) == 0) {
-      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
+      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
       w_[14] = 4u * trips;  // quad steps the wave executed
     }
 #endif
@@ -536,7 +536,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
     }
     if ((threadIdx.x & 63) == 0) {
-      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)) * 16;
+      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
       w_[13] = sn;  // ~quads scanned by the wave's lanes (centre included)
       w_[15] = static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
     }
@@ -719,11 +719,11 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int * ticket, unsigned i
 // Deterministic parallel fold of the per-block partial rows by the last-arriving block: thread
 // (entry, lane-segment) sums blocks seg, seg+NSEG, ... with four independent accumulators (loads
 // stay in flight), segments are then combined in index order.  Result in s_out[0..n_ent).
-template <int EW>  // entries rounded up: 32 (unary / K4) or 96 (binary)
+template <int EW, int TPB>  // entries rounded up: 32 (unary / K4) or 96 (binary); TPB threads per workgroup
 __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks, int n_ent, double * s_seg,
                                           double * s_out)
 {
-  constexpr int NSEG = kThreads / EW;
+  constexpr int NSEG = TPB / EW;
   const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
   if (seg < NSEG && ent < n_ent) {
     // all of this thread's rows are requested before the first one is consumed: ONE memory round trip for
@@ -759,21 +759,24 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 // ------------------------------------------------------------------------------------------------
 // K3
 // ------------------------------------------------------------------------------------------------
-template <int K, bool BINARY, int NOFF>
-__global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a)
+// TPB = threads per workgroup: 512 for big clouds (one workgroup per CU at 131 072 points), 256 for clouds of up to
+// 65 536 points — the down-sampled clouds the reference feeds the factor are 10-25 k points, and at 512 threads they
+// would occupy a fifth of the CUs with two waves per SIMD; at 256 every wave has a SIMD to itself.
+template <int K, bool BINARY, int NOFF, int TPB>
+__global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
 {
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
-  constexpr int SEGS = kThreads / NENT;         // 18 / 5 point segments reduced in parallel
-  constexpr int PPS = (kThreads + SEGS - 1) / SEGS;
+  constexpr int SEGS = TPB / NENT;         // 18 / 5 point segments reduced in parallel
+  constexpr int PPS = (TPB + SEGS - 1) / SEGS;
   constexpr int EW = BINARY ? 96 : 32;
   constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
   // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [reduce] rows, segment sums.
-  constexpr int kListWords = NOFF * kThreads;
-  constexpr int kTileRows = SEGS * PPS;          // >= kThreads; rows past the block's points are zero
+  constexpr int kListWords = NOFF * TPB;
+  constexpr int kTileRows = SEGS * PPS;          // >= TPB; rows past the block's points are zero
   constexpr int kRowWords = kTileRows * ROWW * 2;
   constexpr int kSegWords = SEGS * NENT * 2;
-  constexpr int kFoldWords = (kThreads / EW) * EW * 2 + EW * 2;
+  constexpr int kFoldWords = (TPB / EW) * EW * 2 + EW * 2;
   constexpr int kReduceWords = kRowWords + (kSegWords > kFoldWords ? kSegWords : kFoldWords);
   constexpr int kArenaWords = kListWords > kReduceWords ? kListWords : kReduceWords;
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
@@ -781,11 +784,11 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   __shared__ uint32_t s_scan[kScanLutWords];
   __shared__ bool s_last;
 
-  uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][kThreads]
-  double * s_rows = reinterpret_cast<double *>(s_arena);                              // [kThreads][ROWW]
+  uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
+  double * s_rows = reinterpret_cast<double *>(s_arena);                              // [TPB][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
-  const int qi = xcd_chunk(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+  const int qi = xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
   fill_scan_lut<NOFF>(s_scan);
   __syncthreads();
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
       double dk;
       bool fell_back;
       uint32_t n_scanned;
-      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, kThreads, s_scan, bi, dk, fell_back, n_scanned, a.dbg);
+      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
       did_fall = fell_back;
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   MH_STAMP(a.dbg, 4);
 #pragma unroll
   for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
-  if (static_cast<int>(threadIdx.x) < (kTileRows - kThreads) * ROWW) s_rows[kThreads * ROWW + threadIdx.x] = 0.0;
+  if (static_cast<int>(threadIdx.x) < (kTileRows - TPB) * ROWW) s_rows[TPB * ROWW + threadIdx.x] = 0.0;
   __syncthreads();
   {
     const int ent = threadIdx.x % NENT, seg = threadIdx.x / NENT;
@@ -1060,8 +1063,8 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
   MH_STAMP(a.dbg, 6);
 
   // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
-  double * s_sum = s_aux + (kThreads / EW) * EW;
-  fold_rows<EW>(a.partials, gridDim.x, NENT + 4, s_aux, s_sum);
+  double * s_sum = s_aux + (TPB / EW) * EW;
+  fold_rows<EW, TPB>(a.partials, gridDim.x, NENT + 4, s_aux, s_sum);
   // Results go to the device struct (K4 reads the eigenbases there) AND straight to the caller's mapped
   // pinned host slot: no D2H copy node, and K4's tail does not have to relay them.
 #define MH_PUT(field, val)                          \
@@ -1109,11 +1112,12 @@ __global__ __launch_bounds__(kThreads) void icp_linearize_kernel(const IcpArgs a
 // normal instead of storing two more per-point vectors.  6 sums by wave shuffles, 9 counts by
 // ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocArgs a)
+template <int TPB>
+__global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a)
 {
-  constexpr int NW = kThreads / 64;
+  constexpr int NW = TPB / 64;
   __shared__ double s_w[NW][16];
-  __shared__ double s_seg[(kThreads / 32) * 32 + 32];
+  __shared__ double s_seg[(TPB / 32) * 32 + 32];
   __shared__ bool s_last;
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
   // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
   // cost is the ticket + fold tail, which scales with the number of partial rows
   for (int ch = 0; ch < a.chunks_per_block; ++ch) {
-  const int i = (blockIdx.x * a.chunks_per_block + ch) * kThreads + threadIdx.x;
+  const int i = (blockIdx.x * a.chunks_per_block + ch) * TPB + threadIdx.x;
   int st = -1;
   if (i < a.n) {
     // status, point and normal are requested together (one memory round trip instead of a dependent chain;
@@ -1183,8 +1187,8 @@ __global__ __launch_bounds__(kThreads) void icp_localizability_kernel(const LocA
     store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + threadIdx.x], s);
   }
   if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
-  double * s_sum = s_seg + (kThreads / 32) * 32;
-  fold_rows<32>(a.partials, gridDim.x, 15, s_seg, s_sum);
+  double * s_sum = s_seg + (TPB / 32) * 32;
+  fold_rows<32, TPB>(a.partials, gridDim.x, 15, s_seg, s_sum);
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
@@ -1257,25 +1261,39 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-int linearize_grid(int n) { return (((n + kThreads - 1) / kThreads) + 7) & ~7; }
+// Threads per workgroup for an n-point cloud (see icp_linearize_kernel).
+static int linearize_tpb(int n) { return n <= 65536 ? 256 : kThreads; }
+int linearize_grid(int n)
+{
+  const int tpb = linearize_tpb(n);
+  return (((n + tpb - 1) / tpb) + 7) & ~7;
+}
 constexpr int kLocChunksPerBlock = 1;  // measured: 1 vs 4 chunks per workgroup makes no difference (launch + round-trip bound)
 int localizability_grid(int n) { return (linearize_grid(n) + kLocChunksPerBlock - 1) / kLocChunksPerBlock; }
 
+template <int NOFF, int TPB>
+static void launch_linearize_nt(const IcpArgs & a, bool binary, hipStream_t stream)
+{
+  const dim3 grid(linearize_grid(a.n)), block(TPB);
+  if (a.k == 5) {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF, TPB>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF, TPB>), grid, block, 0, stream, a);
+  } else {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF, TPB>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF, TPB>), grid, block, 0, stream, a);
+  }
+}
 template <int NOFF>
 static void launch_linearize_n(const IcpArgs & a, bool binary, hipStream_t stream)
 {
-  const dim3 grid(linearize_grid(a.n)), block(kThreads);
-  if (a.k == 5) {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF>), grid, block, 0, stream, a);
-  } else {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF>), grid, block, 0, stream, a);
-  }
+  if (linearize_tpb(a.n) == 256)
+    launch_linearize_nt<NOFF, 256>(a, binary, stream);
+  else
+    launch_linearize_nt<NOFF, kThreads>(a, binary, stream);
 }
 
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -1293,7 +1311,10 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
   a.chunks_per_block = kLocChunksPerBlock;
-  hipLaunchKernelGGL(icp_localizability_kernel, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
+  if (linearize_tpb(a.n) == 256)
+    hipLaunchKernelGGL(icp_localizability_kernel<256>, dim3(localizability_grid(a.n)), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(icp_localizability_kernel<kThreads>, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 
