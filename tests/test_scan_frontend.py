@@ -180,3 +180,31 @@ def test_factor_from_device_scan_equals_factor_from_host_cloud(ctx, small_world)
     sa, sb = f_dev.state(), f_host.state()
     assert np.array_equal(sa[0], sb[0])
     sc.destroy()
+
+
+@pytest.mark.gpu
+def test_scan_api_misuse_is_reported_not_crashed(ctx):
+    """Out-of-order calls and bad arguments come back as error codes with a message."""
+    from mimosa_amd import capi
+    sc = capi.Scan(ctx)
+    I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    with pytest.raises(capi.MhError, match="prepare_input"):
+        sc.deskew(np.zeros((1, 12), np.float32))
+    with pytest.raises(capi.MhError, match="prepare_input"):
+        sc.preprocess_geometric(I3, z3)
+    raw, aux = synth.make_raw_scan(8, n_cols=64)
+    with pytest.raises(capi.MhError, match="divisors"):
+        sc.prepare_input(raw, capi.make_input_config(point_skip_divisor=0))
+    sc.prepare_input(raw, capi.make_input_config())
+    with pytest.raises(capi.MhError, match="one pose per unique timestamp"):
+        sc.deskew(np.zeros((3, 12), np.float32))
+    with pytest.raises(capi.MhError, match="1..20"):
+        sc.preprocess_geometric(I3, z3, 0.5, 21, 0.1)
+    with pytest.raises(capi.MhError, match="leaf_size"):
+        sc.preprocess_geometric(I3, z3, 0.0, 20, 0.1)
+    with pytest.raises(capi.MhError, match="has not run"):
+        sc.points(capi.Scan.DOWNSAMPLED)
+    m = capi.VoxelMap(ctx)
+    with pytest.raises(capi.MhError, match="preprocess_geometric"):
+        sc.make_factor(m, capi.make_reg_config(**synth.enwide_config()))
+    sc.destroy()
