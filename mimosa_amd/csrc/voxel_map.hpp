@@ -286,7 +286,13 @@ public:
   void insert(const float * xyz, size_t n, size_t stride)
   {
     const size_t max_pts = static_cast<size_t>(cfg_.max_points_in_cell);
+    // The loop below is bound by cache misses (cell word, per-voxel counters, bucket lines of a 300 MB structure,
+    // ~8 per point).  A look-ahead of kAhead points issues prefetches for what the loop will touch — hints only:
+    // every decision is still taken by the sequential code, in input order.
+    constexpr size_t kAhead = 12;
     for (size_t i = 0; i < n; ++i) {
+      if (i + kAhead < n) prefetch_for(xyz + (i + kAhead) * stride, 0);      // block table -> cell word
+      if (i + kAhead / 2 < n) prefetch_for(xyz + (i + kAhead / 2) * stride, 1);  // cell word -> per-voxel data, bucket
       const float fx = xyz[i * stride + 0], fy = xyz[i * stride + 1], fz = xyz[i * stride + 2];
       const double px = fx, py = fy, pz = fz;
       const int cx = fast_floor(px * inv_leaf_), cy = fast_floor(py * inv_leaf_), cz = fast_floor(pz * inv_leaf_);
@@ -408,6 +414,33 @@ private:
           cells_[pos] = word;
         }
     vox_ncells_[vid] = static_cast<uint8_t>(n);
+  }
+  // stage 0: locate the cell word of the point's voxel and prefetch it; stage 1: read it (it should have arrived)
+  // and prefetch the voxel's counters and bucket.  No state is changed.
+  void prefetch_for(const float * p, int stage) const
+  {
+    const int cx = fast_floor(static_cast<double>(p[0]) * inv_leaf_), cy = fast_floor(static_cast<double>(p[1]) * inv_leaf_),
+              cz = fast_floor(static_cast<double>(p[2]) * inv_leaf_);
+    const int blk = find_block(cx >> kBlockLog2, cy >> kBlockLog2, cz >> kBlockLog2);
+    if (blk < 0) return;
+    const int m = kBlockDim - 1;
+    const uint32_t * w = &cells_[static_cast<size_t>(blk) * kCellsPerBlock + halo_index(cx & m, cy & m, cz & m)];
+    if (stage == 0) {
+      __builtin_prefetch(w, 0, 1);
+      return;
+    }
+    const uint32_t e = *w;
+    if (e == kEmptyCell) return;
+    const size_t vid = e >> 5;
+    __builtin_prefetch(&vox_count_[vid], 1, 1);
+    __builtin_prefetch(&vox_lru_[vid], 1, 1);
+    __builtin_prefetch(&dirty_flag_[vid], 1, 1);
+    const Float4 * b = &buckets_[vid * kBucketStride];
+    __builtin_prefetch(b, 1, 1);
+    __builtin_prefetch(b + 4, 1, 1);
+    __builtin_prefetch(b + 8, 1, 1);
+    __builtin_prefetch(&qbuckets_[vid * kBucketStride], 1, 1);
+    __builtin_prefetch(&vox_cells_[vid * 8], 0, 1);
   }
   uint32_t find_or_create_voxel(int cx, int cy, int cz)
   {
