@@ -245,7 +245,6 @@ def main():
         icfg = capi.make_input_config()
         I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
         sc = capi.Scan(ctx)
-        col_of = {int(tt_): c for c, tt_ in enumerate(raux["unique_ns"])}
         tg = {"prepare_input_ms": [], "deskew_ms": [], "preprocess_geometric_ms": [], "factor_create_ms": []}
         for it in range(6):
             ctx.synchronize()
@@ -253,7 +252,7 @@ def main():
             finfo = sc.prepare_input(raw, icfg)
             a1 = time.perf_counter()
             uns = sc.unique_ns()
-            Rt12 = np.stack([raux["Rt12"][col_of[int(u)]] for u in uns])
+            Rt12 = raux["Rt12"][np.searchsorted(raux["unique_ns"], uns)]
             a1b = time.perf_counter()
             sc.deskew(Rt12)
             a2 = time.perf_counter()
@@ -281,7 +280,7 @@ def main():
                 o = _rc.prepare_input(raw, ocfg)
                 b1 = time.perf_counter()
                 full = np.frombuffer(o["points_full"].tobytes(), dtype=synth.POINT_DTYPE).copy()
-                Rt12 = np.stack([raux["Rt12"][col_of[int(u)]] for u in o["unique_ns"]])
+                Rt12 = raux["Rt12"][np.searchsorted(raux["unique_ns"], o["unique_ns"])]
                 b1b = time.perf_counter()
                 desk = _rc.deskew(full, o["unique_ns"], Rt12)
                 b2 = time.perf_counter()

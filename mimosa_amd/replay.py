@@ -94,8 +94,7 @@ class HipBackend:
     def front_end(self, raw, aux):
         info = self.scan.prepare_input(raw, self.icfg)
         uns = self.scan.unique_ns()
-        col = {int(u): c for c, u in enumerate(aux["unique_ns"])}
-        self.scan.deskew(np.stack([aux["Rt12"][col[int(u)]] for u in uns]))
+        self.scan.deskew(aux["Rt12"][np.searchsorted(aux["unique_ns"], uns)])  # the pose of each kept timestamp
         info = self.scan.preprocess_geometric(self.I3, self.z3, self.regd["source_voxel_grid_filter_leaf_size"], 20,
                                               self.regd["source_voxel_grid_min_dist_in_voxel"])
         return info["n_downsampled"]

@@ -21,8 +21,7 @@ class OracleBackend:
     def front_end(self, raw, aux):
         o = ref_cpu.prepare_input(raw, self.icfg)
         full = np.frombuffer(o["points_full"].tobytes(), dtype=synth.POINT_DTYPE).copy()
-        col = {int(u): c for c, u in enumerate(aux["unique_ns"])}
-        Rt12 = np.stack([aux["Rt12"][col[int(u)]] for u in o["unique_ns"]])
+        Rt12 = aux["Rt12"][np.searchsorted(aux["unique_ns"], o["unique_ns"])]
         desk = ref_cpu.deskew(full, o["unique_ns"], Rt12)
         self.body = ref_cpu.transform_f32(desk[o["geometric_idxs"].astype(np.int64)], self.I3, self.z3)
         kept = ref_cpu.downsample(self.body, self.regd["source_voxel_grid_filter_leaf_size"], 20,
