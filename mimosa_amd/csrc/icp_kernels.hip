@@ -160,6 +160,72 @@ __device__ __forceinline__ double lane_get(double v, int l)
 #define MH_STAMP_C2(ptr, i) MH_STAMP(ptr, i)
 #endif
 
+// 32-bit literals used per candidate, held in VGPRs: (a & lit) | lit needs two instructions with literal operands
+// (one literal per VOP3), one v_and_or_b32 with register operands.
+struct KeyConsts
+{
+  uint32_t ymask, ymagic, kmask;
+};
+
+// Coarse key of one candidate: packed word w (3 x 10-bit voxel-relative coordinates), voxel offsets in grid units,
+// payload (scan position << 5 | slot), validity.  y is decoded by OR-ing its bit field (bits 10-19) into the mantissa
+// of 2^13 (whose mantissa bit 10 weighs 1, ulp 2^-10): one v_and_or + one v_sub instead of extract + convert + add;
+// the caller folds the 2^13 into the per-voxel offset `mfy` (rounding <= 2^-11 grid units, inside the error budget).
+// The same trick on x (bits 0-9) would need 2^23, whose ulp of one whole grid unit would destroy the sub-grid offset.
+__device__ __forceinline__ uint32_t coarse_key(const KeyConsts & kc, uint32_t w, float ofx, float mfy, float ofz, uint32_t payload,
+                                               bool valid)
+{
+  const float dx = static_cast<float>(w & 1023u) + ofx;
+  const float dy = __uint_as_float((w & kc.ymask) | kc.ymagic) - mfy;
+  const float dz = static_cast<float>((w >> 20) & 1023u) + ofz;
+  const float d = dx * dx + dy * dy + dz * dz;
+  const uint32_t t = (__float_as_uint(d) & kc.kmask) | payload;
+  return valid ? t : 0xFFFFFFFFu;
+}
+
+// compare-exchange: a <- min, b <- max
+__device__ __forceinline__ void cmp_exch(uint32_t & a, uint32_t & b)
+{
+  const uint32_t lo = min(a, b);
+  b = max(a, b);
+  a = lo;
+}
+
+// Four candidates (one 16-byte load) into the sorted top-KK.  KK == 8: sort the quad (5 compare-exchanges),
+// half-clean it against the upper half of the sorted top-8 (C[i] = min(ck[4+i], q[3-i]) keeps the 8 smallest of the
+// 12 as a bitonic sequence), bitonic-merge the 8 (12 compare-exchanges): 38 min/max ops instead of 4 x 15 for four
+// serial insertions.  Other KK (generic k <= 8 path): serial insertion.  mfy: y offset already folded with the 2^13
+// magic; pb: payload of the quad's slot 0; s0: first slot of the quad; cnt: points in the voxel.
+template <int KK>
+__device__ __forceinline__ void merge_quad(uint32_t (&ck)[KK], const KeyConsts & kc, const uint4 qw, float ofx, float mfy, float ofz,
+                                           uint32_t pb, uint32_t s0, uint32_t cnt)
+{
+  uint32_t k0 = coarse_key(kc, qw.x, ofx, mfy, ofz, pb, s0 + 0u < cnt);
+  uint32_t k1 = coarse_key(kc, qw.y, ofx, mfy, ofz, pb | 1u, s0 + 1u < cnt);
+  uint32_t k2 = coarse_key(kc, qw.z, ofx, mfy, ofz, pb | 2u, s0 + 2u < cnt);
+  uint32_t k3 = coarse_key(kc, qw.w, ofx, mfy, ofz, pb | 3u, s0 + 3u < cnt);
+  if constexpr (KK == 8) {
+    cmp_exch(k0, k1); cmp_exch(k2, k3); cmp_exch(k0, k2); cmp_exch(k1, k3); cmp_exch(k1, k2);
+    ck[4] = min(ck[4], k3); ck[5] = min(ck[5], k2); ck[6] = min(ck[6], k1); ck[7] = min(ck[7], k0);
+    cmp_exch(ck[0], ck[4]); cmp_exch(ck[1], ck[5]); cmp_exch(ck[2], ck[6]); cmp_exch(ck[3], ck[7]);
+    cmp_exch(ck[0], ck[2]); cmp_exch(ck[1], ck[3]); cmp_exch(ck[4], ck[6]); cmp_exch(ck[5], ck[7]);
+    cmp_exch(ck[0], ck[1]); cmp_exch(ck[2], ck[3]); cmp_exch(ck[4], ck[5]); cmp_exch(ck[6], ck[7]);
+  } else {
+    const uint32_t kq[4] = {k0, k1, k2, k3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t t = kq[c];
+#pragma unroll
+      for (int i = 0; i < KK - 1; ++i) {
+        const uint32_t lo = min(ck[i], t);
+        t = max(ck[i], t);
+        ck[i] = lo;
+      }
+      ck[KK - 1] = min(ck[KK - 1], t);
+    }
+  }
+}
+
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
 // dk = squared distance of the k-th.  `list` is this lane's column of an LDS array [kMaxOff][stride].  Returns the number of points in all occupied neighbour voxels
@@ -265,65 +331,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint32_t ck[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
-  // 32-bit literals used per candidate live in VGPRs: (a & lit) | lit needs two instructions with literal
-  // operands (one literal per VOP3), one v_and_or_b32 with register operands
-  uint32_t c_ymask = 0xFFC00u, c_ymagic = 0x46000000u, c_kmask = ~0x3FFu;
-  asm volatile("" : "+v"(c_ymask), "+v"(c_ymagic), "+v"(c_kmask));
-  // Key of one candidate (no insertion): packed word w_, voxel offsets in grid units, payload, validity.
-  // y is decoded by OR-ing its bit field (bits 10-19) into the mantissa of 2^13 (whose mantissa bit 10 weighs
-  // 1, ulp 2^-10): one v_and_or + one v_sub instead of extract + convert + add; the 2^13 is folded into the
-  // per-voxel offset by the caller (rounding <= 2^-11 grid units, inside kErrG's slack).  The same trick on x
-  // (bits 0-9) would need 2^23, whose ulp of one whole grid unit would destroy the sub-grid offset.
-#define MH_COARSE_KEY(key_, w_, ofx, mfy, ofz, payload, valid)                                        \
-  do {                                                                                                 \
-    const float dx_ = static_cast<float>((w_) & 1023u) + (ofx);                                        \
-    const float dy_ = __uint_as_float(((w_) & c_ymask) | c_ymagic) - (mfy);                            \
-    const float dz_ = static_cast<float>(((w_) >> 20) & 1023u) + (ofz);                                \
-    const float d_ = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;                                                \
-    const uint32_t t_ = (__float_as_uint(d_) & c_kmask) | (payload);                                   \
-    (key_) = (valid) ? t_ : 0xFFFFFFFFu;                                                               \
-  } while (0)
-#define MH_CE(a_, b_)                        \
-  do {                                       \
-    const uint32_t lo_ = min((a_), (b_));    \
-    (b_) = max((a_), (b_));                  \
-    (a_) = lo_;                              \
-  } while (0)
-  // Four candidates at once.  KK == 8: sort the quad (5 compare-exchanges), half-clean it against the upper
-  // half of the sorted top-8 (C[i] = min(ck[4+i], q[3-i]) keeps the 8 smallest of the 12 as a bitonic
-  // sequence), bitonic-merge the 8 (12 compare-exchanges): 38 min/max ops instead of 4 x 15 for four serial
-  // insertions.  Other KK (generic k <= 8 path): serial insertion.
-#define MH_COARSE_QUAD(qw, ofx, ofy, ofz, o_, s0_, cnt_)                                               \
-  MH_COARSE_QUAD_M(qw, ofx, 8192.0f - (ofy), ofz, (static_cast<uint32_t>(o_) << 5) | (s0_), s0_, cnt_)
-  // core: y offset already folded with the 2^13 magic, pb_ = payload of the quad's slot 0
-#define MH_COARSE_QUAD_M(qw, ofx, mfy_, ofz, pb_, s0_, cnt_)                                           \
-  do {                                                                                                 \
-    uint32_t k0_, k1_, k2_, k3_;                                                                       \
-    MH_COARSE_KEY(k0_, (qw).x, ofx, mfy_, ofz, (pb_), (s0_) + 0u < (cnt_));                            \
-    MH_COARSE_KEY(k1_, (qw).y, ofx, mfy_, ofz, (pb_) | 1u, (s0_) + 1u < (cnt_));                       \
-    MH_COARSE_KEY(k2_, (qw).z, ofx, mfy_, ofz, (pb_) | 2u, (s0_) + 2u < (cnt_));                       \
-    MH_COARSE_KEY(k3_, (qw).w, ofx, mfy_, ofz, (pb_) | 3u, (s0_) + 3u < (cnt_));                       \
-    if constexpr (KK == 8) {                                                                           \
-      MH_CE(k0_, k1_); MH_CE(k2_, k3_); MH_CE(k0_, k2_); MH_CE(k1_, k3_); MH_CE(k1_, k2_);             \
-      ck[4] = min(ck[4], k3_); ck[5] = min(ck[5], k2_); ck[6] = min(ck[6], k1_); ck[7] = min(ck[7], k0_); \
-      MH_CE(ck[0], ck[4]); MH_CE(ck[1], ck[5]); MH_CE(ck[2], ck[6]); MH_CE(ck[3], ck[7]);              \
-      MH_CE(ck[0], ck[2]); MH_CE(ck[1], ck[3]); MH_CE(ck[4], ck[6]); MH_CE(ck[5], ck[7]);              \
-      MH_CE(ck[0], ck[1]); MH_CE(ck[2], ck[3]); MH_CE(ck[4], ck[5]); MH_CE(ck[6], ck[7]);              \
-    } else {                                                                                           \
-      uint32_t kq_[4] = {k0_, k1_, k2_, k3_};                                                          \
-      _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                 \
-      {                                                                                                \
-        uint32_t t_ = kq_[c_];                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < KK - 1; ++i_)                                          \
-        {                                                                                              \
-          const uint32_t lo_ = min(ck[i_], t_);                                                        \
-          t_ = max(ck[i_], t_);                                                                        \
-          ck[i_] = lo_;                                                                                \
-        }                                                                                              \
-        ck[KK - 1] = min(ck[KK - 1], t_);                                                              \
-      }                                                                                                \
-    }                                                                                                  \
-  } while (0)
+  KeyConsts kc{0xFFC00u, 0x46000000u, ~0x3FFu};
+  asm volatile("" : "+v"(kc.ymask), "+v"(kc.ymagic), "+v"(kc.kmask));  // opaque: keeps them in registers
 
   // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
   n_scanned = 0;
@@ -337,7 +346,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     for (int u = 0; u < kBucketStride / 4; ++u) qw[u] = b[static_cast<uint32_t>(4 * u) < cc ? u : 0];  // all issued together
 #pragma unroll
     for (int u = 0; u < kBucketStride / 4; ++u) {
-      if (static_cast<uint32_t>(4 * u) < cc) MH_COARSE_QUAD(qw[u], ofx, ofy, ofz, 0u, static_cast<uint32_t>(4 * u), cc);
+      if (static_cast<uint32_t>(4 * u) < cc) merge_quad<KK>(ck, kc, qw[u], ofx, 8192.0f - ofy, ofz, static_cast<uint32_t>(4 * u), static_cast<uint32_t>(4 * u), cc);
     }
   }
   MH_STAMP(dbg, 10);
@@ -444,7 +453,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
         MH_PREFETCH(u);  // refill this stage
         const uint32_t cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
         n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
-        MH_COARSE_QUAD_M(qw, vo.x + cx0, cy1 - vo.y, vo.z + cz2, ((meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
+        merge_quad<KK>(ck, kc, qw, vo.x + cx0, cy1 - vo.y, vo.z + cz2, ((meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
       }
     }
 #undef MH_PREFETCH
@@ -464,10 +473,6 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   const uint32_t nact = static_cast<uint32_t>(__popcll(act));
   const uint32_t rank = static_cast<uint32_t>(__popcll(act & ((1ull << lane) - 1ull)));
   const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem);  // centre + every neighbour voxel the cursor entered
-#undef MH_COARSE_QUAD
-#undef MH_COARSE_QUAD_M
-#undef MH_COARSE_KEY
-#undef MH_CE
   MH_STAMP(dbg, 2);
 
   // ---- exact tier: re-rank the survivors in fp64 by (distance, traversal rank) -------------------
