@@ -226,6 +226,26 @@ __device__ __forceinline__ void merge_quad(uint32_t (&ck)[KK], const KeyConsts &
   }
 }
 
+// Mask of the neighbour voxels (scan positions 1..NOFF-1) that may still hold a top-k point: a voxel whose BOX is
+// strictly farther from q than a proven upper bound of the current k-th distance cannot (so not even ties are
+// affected).  boxd[] = squared box distances in grid units; the bound undoes the 10-bit key truncation (<= 2^-13
+// relative on d^2) and adds the coarse-tier error err_g; no k-th key yet = keep everything.
+template <int K, int KK, int NOFF>
+__device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], const float (&boxd)[NOFF], int k, float err_g)
+{
+  uint32_t kth = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+    if (i == k - 1) kth = ck[i];
+  const float kv = __uint_as_float(kth & ~0x3FFu) * (1.0f + 2.5e-4f);
+  const float r_up = sqrtf(kv) * (1.0f + 2e-6f) + err_g;
+  const float b_up = kth != 0xFFFFFFFFu ? r_up * r_up : 3.0e38f;
+  uint32_t keep = ~0u;
+#pragma unroll
+  for (int b = 1; b < NOFF; ++b) keep &= boxd[b] > b_up ? ~(1u << b) : ~0u;
+  return keep;
+}
+
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
 // dk = squared distance of the k-th.  `list` is this lane's column of an LDS array [kMaxOff][stride].  Returns the number of points in all occupied neighbour voxels
@@ -368,25 +388,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       boxd[b] = g2x[ent & 3u] + g2y[(ent >> 2) & 3u] + g2z[(ent >> 4) & 3u];
     }
   }
-  // keep_ = mask of the voxels that may still hold a top-k point given the current k-th key
-#define MH_PRUNE(keep_)                                                                              \
-  do {                                                                                               \
-    uint32_t kth_ = 0xFFFFFFFFu;                                                                     \
-    _Pragma("unroll") for (int i_ = 0; i_ < K; ++i_) if (i_ == k - 1) kth_ = ck[i_];                 \
-    /* upper bound (grid units) of the TRUE k-th distance so far: undo the 10-bit key truncation */  \
-    /* (<= 2^-13 relative on d^2), then the coarse error */                                          \
-    const float kv_ = __uint_as_float(kth_ & ~0x3FFu) * (1.0f + 2.5e-4f);                            \
-    const float r_up_ = sqrtf(kv_) * (1.0f + 2e-6f) + kErrG;                                         \
-    const float b_up_ = kth_ != 0xFFFFFFFFu ? r_up_ * r_up_ : 3.0e38f;                               \
-    (keep_) = ~0u;                                                                                   \
-    _Pragma("unroll") for (int b_ = 1; b_ < NOFF; ++b_) (keep_) &= boxd[b_] > b_up_ ? ~(1u << b_) : ~0u; \
-  } while (0)
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
-  {
-    uint32_t keep;
-    MH_PRUNE(keep);
-    rem &= keep;
-  }
+  rem &= prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
   uint32_t alive = rem;  // neighbour voxels never pruned: alive & ~rem (after the scan) = the voxels scanned
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
   const uint32_t amask_unpruned = amask & ~1u;
@@ -437,8 +440,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     for (int trip = 0;; ++trip) {
       if (!__any(static_cast<int>((pmeta[0] >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
       if (trip == 1 || trip == 2) {
-        uint32_t keep;
-        MH_PRUNE(keep);
+        const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
         rem &= keep;
         alive &= keep;
       }
@@ -467,7 +469,6 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // (Measured, round 1: capping the per-lane scan at 16 quads and letting the 64 lanes scan the leftover
   // voxels together, one candidate per lane, was 2x SLOWER — each (lane, voxel) step is a dependent LDS ->
   // HBM -> ballot chain with nothing to overlap it.  The per-lane pipelined cursor stays.)
-#undef MH_PRUNE
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t act = __ballot(1);
   const uint32_t nact = static_cast<uint32_t>(__popcll(act));
