@@ -226,6 +226,48 @@ __device__ __forceinline__ void merge_quad(uint32_t (&ck)[KK], const KeyConsts &
   }
 }
 
+// Register-only (voxel, quad) cursor of the neighbour scan.  `rem` = scan positions not entered yet; quad counts
+// per voxel are packed 3 bits each in qc0 (positions 0..20) / qc1 (21..26).  advance() steps to the next quad —
+// entering the next listed voxel when the current one is exhausted — and issues that quad's loads: the cell word
+// from the lane's LDS list, the voxel offset from the LDS table, the 16-byte packed quad from the map.  There is no
+// select on a load index (a `live ? index : 0` makes the compiler sink the LDS read into a branch: four dependent
+// LDS round trips behind s_waitcnt lgkmcnt(0) per trip): every list entry names a mapped voxel and the quad index
+// is clamped, so a dead stage just loads a quad it never uses.
+struct ScanStage
+{
+  uint4 quad;     // four packed candidates
+  float4 ofs;     // voxel offset in grid units (x, y, z)
+  uint32_t meta;  // scan position << 6 | live point count << 11 | quad index << 16
+};
+template <int NOFF>
+struct ScanCursor
+{
+  uint32_t rem;
+  int o_cur = 0;
+  uint32_t qd = 8u, nq_cur = 0u;  // "exhausted": the first advance() enters the first listed voxel
+  uint64_t qc0, qc1;
+
+  __device__ __forceinline__ ScanStage advance(const uint32_t * list, int lds_stride, const float4 * lut4, const uint4 * qbuckets)
+  {
+    const bool sw = (qd >= nq_cur) && rem != 0u;  // next listed voxel (each holds >= 1 point)
+    o_cur = sw ? __builtin_ctz(rem) : o_cur;
+    rem = sw ? (rem & (rem - 1u)) : rem;
+    qd = sw ? 0u : qd;
+    if constexpr (NOFF <= 21)
+      nq_cur = static_cast<uint32_t>(qc0 >> (3 * o_cur)) & 7u;
+    else
+      nq_cur = static_cast<uint32_t>((o_cur < 21 ? qc0 : qc1) >> (3 * (o_cur < 21 ? o_cur : o_cur - 21))) & 7u;
+    const bool live = qd < nq_cur;
+    const uint32_t e = list[o_cur * lds_stride];  // off the cursor's dependency chain
+    ScanStage st;
+    st.ofs = lut4[o_cur];
+    st.quad = qbuckets[(e >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1))];
+    st.meta = (static_cast<uint32_t>(o_cur) << 6) | ((live ? (e & 31u) : 0u) << 11) | (qd << 16);
+    ++qd;
+    return st;
+  }
+};
+
 // Mask of the neighbour voxels (scan positions 1..NOFF-1) that may still hold a top-k point: a voxel whose BOX is
 // strictly farther from q than a proven upper bound of the current k-th distance cannot (so not even ties are
 // affected).  boxd[] = squared box distances in grid units; the bound undoes the 10-bit key truncation (<= 2^-13
@@ -404,44 +446,23 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // fewer than k points: their first bound is infinite).
   {
     constexpr int kPipe = 4;
-    int o_cur = 0;
-    uint32_t qd = 8u, nq_cur = 0u;  // "exhausted": the first prefetch enters the first listed voxel
-    uint4 pw[kPipe];
-    float4 pofs[kPipe];     // voxel offset in grid units (x, y, z) of the staged quad's voxel
-    uint32_t pmeta[kPipe];  // b << 6 | live point count << 11 | quad << 16
     const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
     const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
-    // No select on the load index: a `live ? index : 0` makes the compiler sink the LDS read of the cell word
-    // into a branch (four dependent LDS round trips behind s_waitcnt lgkmcnt(0) per trip).  Every list entry
-    // names a mapped voxel and the quad index is clamped, so a dead stage just loads a quad it never uses.
-#define MH_PREFETCH(u)                                                                              \
-  do {                                                                                              \
-    const bool sw_ = (qd >= nq_cur) && rem != 0u; /* next listed voxel (each holds >= 1 point) */   \
-    o_cur = sw_ ? __builtin_ctz(rem) : o_cur;                                                       \
-    rem = sw_ ? (rem & (rem - 1u)) : rem;                                                           \
-    qd = sw_ ? 0u : qd;                                                                             \
-    if constexpr (NOFF <= 21)                                                                       \
-      nq_cur = static_cast<uint32_t>(qc0 >> (3 * o_cur)) & 7u;                                      \
-    else                                                                                            \
-      nq_cur = static_cast<uint32_t>((o_cur < 21 ? qc0 : qc1) >> (3 * (o_cur < 21 ? o_cur : o_cur - 21))) & 7u; \
-    const bool live_ = qd < nq_cur;                                                                 \
-    const uint32_t e_ = list[o_cur * lds_stride]; /* off the cursor's dependency chain */           \
-    pofs[u] = lut4[o_cur];                                                                          \
-    const uint32_t idx_ = (e_ >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1)); \
-    pw[u] = map.qbuckets[idx_];                                                                     \
-    pmeta[u] = (static_cast<uint32_t>(o_cur) << 6) | ((live_ ? (e_ & 31u) : 0u) << 11) | (qd << 16); \
-    ++qd;                                                                                           \
-  } while (0)
+    ScanCursor<NOFF> cur;
+    cur.rem = rem;
+    cur.qc0 = qc0;
+    cur.qc1 = qc1;
+    ScanStage stage[kPipe];
 #pragma unroll
-    for (int u = 0; u < kPipe; ++u) MH_PREFETCH(u);
+    for (int u = 0; u < kPipe; ++u) stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
     uint32_t trips = 0;
 #endif
     for (int trip = 0;; ++trip) {
-      if (!__any(static_cast<int>((pmeta[0] >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
+      if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
       if (trip == 1 || trip == 2) {
         const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
-        rem &= keep;
+        cur.rem &= keep;
         alive &= keep;
       }
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
@@ -449,16 +470,14 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #endif
 #pragma unroll
       for (int u = 0; u < kPipe; ++u) {
-        const uint4 qw = pw[u];
-        const uint32_t meta = pmeta[u];
-        const float4 vo = pofs[u];
-        MH_PREFETCH(u);  // refill this stage
-        const uint32_t cnt_ = (meta >> 11) & 31u, s0_ = ((meta >> 16) & 7u) * 4u;
+        const ScanStage st = stage[u];
+        stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);  // refill this stage
+        const uint32_t cnt_ = (st.meta >> 11) & 31u, s0_ = ((st.meta >> 16) & 7u) * 4u;
         n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
-        merge_quad<KK>(ck, kc, qw, vo.x + cx0, cy1 - vo.y, vo.z + cz2, ((meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
+        merge_quad<KK>(ck, kc, st.quad, st.ofs.x + cx0, cy1 - st.ofs.y, st.ofs.z + cz2, ((st.meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
       }
     }
-#undef MH_PREFETCH
+    rem = cur.rem;
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
     if (dbg && (threadIdx.x & 63) == 0) {
       unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
