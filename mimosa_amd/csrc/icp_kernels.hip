@@ -289,24 +289,25 @@ __device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], co
 }
 
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
-// bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found),
-// dk = squared distance of the k-th.  `list` is this lane's column of an LDS array [kMaxOff][stride].  Returns the number of points in all occupied neighbour voxels
-// (what the reference scans); n_scanned = what was actually scanned.
+// bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found), dk = squared
+// distance of the k-th.  `list` is this lane's column of an LDS array [NOFF][stride] (cell words in scan order),
+// `scan_lut` the LDS table of fill_scan_lut.  Returns the number of points in all occupied neighbour voxels (what
+// the reference scans); n_scanned = what was actually scanned.  All lanes of a wave that call must call together
+// (the exact fallback is wave-cooperative); lanes that do not call are simply not helpers.
 //
-// In-kernel timeline + counters (MH_TIMELINE build, round 1): the scan is bound by dependent-issue
-// latency with only ~2 waves/SIMD — not by memory (making every scan load hit one address changed
-// nothing) — so the scan does less work per point, in three exact steps:
-//   prune   the centre voxel is scanned first; a neighbour voxel whose BOX is farther from q than a
-//           proven upper bound of the current k-th distance cannot hold a top-k point and is skipped
-//           (strictly farther, so not even ties are affected): ~83 -> ~35 candidates per query
-//   coarse  every scanned candidate: f32 squared distance (6 VALU ops) -> 32-bit key whose low 10
-//           bits carry (neighbour offset index, bucket slot) -> branch-free top-KK by v_min/max_u32
-//   exact   the KK survivors: fp64 distance in the reference's operation order, ordered by
-//           (distance, traversal rank) exactly like KnnResult::push
-// plus a proof check: every scanned non-survivor's key is >= the KK-th key, so if that bound (minus
-// the f32 error budget) exceeds the exact k-th distance no non-survivor can belong to the answer;
-// otherwise the lane re-runs the exact insertion scan over all voxels (counted in
-// n_exact_fallback).  Either way the selection is bit-identical to the reference.
+// The scan does less work per point than the reference's, in three exact steps:
+//   prune   the centre voxel is scanned first; a neighbour voxel whose BOX is farther from q than a proven upper
+//           bound of the current k-th distance cannot hold a top-k point and is skipped (strictly farther, so not
+//           even ties are affected); neighbours are visited faces -> edges -> corners and the test is repeated on
+//           the voxels not entered yet after the first two trips: ~83 -> ~38 candidates per query
+//   coarse  every scanned candidate: f32 squared distance on the packed 10-bit copy -> 32-bit key whose low 10 bits
+//           carry (scan position, bucket slot) -> sorted-quad bitonic merge into the top-KK (v_min/max_u32)
+//   exact   the KK survivors: fp64 distance in the reference's operation order, ordered by (distance, traversal
+//           rank) exactly like KnnResult::push
+// plus a proof check: every scanned non-survivor's key is >= the KK-th key, so if that bound (minus the f32 error
+// budget) exceeds the exact k-th distance no non-survivor can belong to the answer; otherwise the wave re-runs
+// KnnResult::push for that lane over the scanned voxels (counted in n_exact_fallback).  Either way the selection is
+// bit-identical to the reference.
 template <int K, int NOFF>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
