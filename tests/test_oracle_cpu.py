@@ -196,3 +196,47 @@ def test_frontend_golden_cpu():
     assert np.array_equal(synth.points_xyz(body).view(np.uint32), g["body"].view(np.uint32))
     kept = ref_cpu.downsample(body, 1.0, 3, 0.5)
     assert np.array_equal(kept, g["kept"]) and 0 < len(kept) < len(body)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_restatements_agree_on_random_cases(seed):
+    """The C++ oracle and the numpy restatement, live, on randomised small worlds (density, leaf, neighbour mode, k,
+    Huber, 4-DoF, a second call that straddles the data-association threshold): not only on the committed fixtures."""
+    from mimosa_amd import synth
+    from oracle import numpy_ref, ref_cpu
+
+    rng = np.random.default_rng(700 + seed)
+    room = np.array([rng.uniform(4, 7), rng.uniform(3, 6), rng.uniform(2.5, 3.5)])
+    grid = float(rng.choice([0.11, 0.16, 0.3]))
+    leaf = float(rng.choice([0.3, 0.5, 1.0]))
+    md = float(rng.choice([0.05, 0.15]))
+    mode = int(rng.choice([7, 19, 27]))
+    m = synth.make_room(9000 + seed, 0, 0, grid=grid, room=room)
+    pts, aux = synth.make_scan(n_rows=8, seed=9100 + seed, n_cols=48, room=room,
+                               sensor_local=np.array([room[0] / 2, room[1] / 2, 1.2]))
+    cfg = synth.enwide_config()
+    cfg.update(target_ivox_map_leaf_size=leaf, target_ivox_map_min_dist_in_voxel=md, num_corres_points=int(rng.choice([5, 5, 8])),
+               use_huber=int(rng.integers(0, 2)), reg_4_dof=int(rng.integers(0, 2)),
+               plane_validity_distance=float(rng.choice([0.04, 0.1])))
+    R = aux["R_W_L"] @ synth.so3_exp(np.deg2rad(rng.normal(0, 0.8, 3)))
+    t = aux["t_W_L"] + rng.normal(0, 0.04, 3)
+    M = ref_cpu.Map(leaf=leaf, min_dist=md, mode=mode)
+    V = numpy_ref.VoxelMap(leaf=leaf, min_dist=md, mode=mode, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    M.insert(m)
+    V.insert(m)
+    assert M.num_points == V.num_points
+    f = ref_cpu.ICP(M, pts, ref_cpu.make_config(**cfg))
+    xyz = synth.points_xyz(pts)
+    st = None
+    for step in range(2):
+        r = f.linearize(R, t)
+        n, st = numpy_ref.linearize(V, xyz, cfg, R, t, state=st)
+        assert np.array_equal(np.asarray(r["status_hist"]), np.asarray(n["status_hist"]))
+        for k in ("H_ss", "b_s"):
+            assert rel(r[k], n[k]) <= 1e-9, k
+        assert abs(r["f"] - n["f"]) <= 1e-9 * max(abs(n["f"]), 1e-300)
+        assert int(r["n_knn"]) == int(n["n_knn"])
+        s, mean, nrm, _ = f.state()
+        assert np.array_equal(s, st["status"])
+        assert np.abs(mean - st["mean"]).max() <= 1e-9 and np.abs(nrm - st["normal"]).max() <= 1e-9
+        t = t + rng.normal(0, 1.0, 3) * md / 4.0
