@@ -414,8 +414,10 @@ mh::MapView map_view(const mh_map * m)
   v.cells = static_cast<const uint32_t *>(m->d_cells.p);
   v.buckets = static_cast<const float4 *>(m->d_buckets.p);
   v.qbuckets = static_cast<const uint4 *>(m->d_qbuckets.p);
-  v.inv_leaf = m->host.inv_leaf();
-  v.mask = m->host.table_mask();
+  v.inv_leaf = 1.0 / m->host.config().leaf_size;
+  // the mask of the table the DEVICE holds: after mh_map_fork the host structure has moved to the fork and
+  // m->host is an empty 1024-slot map, while this handle's mirror keeps its real capacity
+  v.mask = static_cast<uint32_t>(m->dev_table_cap ? m->dev_table_cap - 1 : 0);
   v.n_off = m->n_off;
   v.mode_idx = m->n_off == 1 ? 0 : (m->n_off == 7 ? 1 : (m->n_off == 19 ? 2 : 3));
   return v;

@@ -45,3 +45,14 @@ def room_world():
     pts, aux = synth.make_scan(64)
     R, t = synth.query_pose()
     return dict(map_xyz=m, pts=pts, aux=aux, R=R, t=t, cfg=synth.enwide_config())
+
+
+@pytest.fixture(scope="session")
+def big_world():
+    """BASELINE configs[1]: the full 128 x 1024 = 131 072-pt scan against the 2 x 5-room map (~4.96 M stored points)."""
+    from mimosa_amd import synth
+
+    rooms = [xyz for _, _, xyz in synth.make_map_rooms(2, 5)]
+    pts, aux = synth.make_scan(128)
+    R, t = synth.query_pose()
+    return dict(map_rooms=rooms, pts=pts, aux=aux, R=R, t=t, cfg=synth.enwide_config())

@@ -1,0 +1,123 @@
+"""-m gpu: BASELINE.json configs[1] at FULL size inside the test suite (not only in bench.py's parity leg):
+131 072-pt OS0-128 scan vs the ~5 M-pt 2 x 5-room map, k = 5 point-to-plane, ENWIDE parameters.
+HIP path through the C ABI vs the CPU oracle (geometric_factor.hpp:231-562)."""
+import numpy as np
+import pytest
+
+from parity import assert_result_parity, assert_state_parity, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def maps(ctx, big_world):
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm, rm = capi.VoxelMap(ctx), ref_cpu.Map()
+    for xyz in big_world["map_rooms"]:  # one iVox insert() per room
+        gm.insert(xyz)
+        rm.insert(xyz)
+    yield gm, rm
+    gm.release()
+
+
+def _rows(world, pts, R, t, gf):
+    """whitened residuals recomputed from the device's cached plane (mean, normal) for its Valid points"""
+    st, mean, nrm = gf.state()
+    P = np.stack([pts["x"], pts["y"], pts["z"]], 1).astype(np.float64)
+    q = P @ R.T + t
+    e = np.einsum("ij,ij->i", nrm, mean - q)
+    sigma = float(np.float32(world["cfg"]["lidar_point_noise_std_dev"]))
+    hub = float(np.float32(world["cfg"]["huber_threshold"]))
+    w = np.abs(e / sigma)
+    sw = np.where(w > hub, np.sqrt(hub / np.maximum(w, 1e-300)), 1.0)
+    ns = nrm @ R  # R^T n per row
+    J = np.concatenate([np.cross(ns, P), -ns], 1) * (sw / sigma)[:, None]
+    return st, e * sw / sigma, J
+
+
+def test_configs1_map_identical(maps):
+    gm, rm = maps
+    s = gm.stats()
+    assert s["n_points"] == rm.num_points and s["n_voxels"] == rm.num_voxels
+    assert s["n_points"] > 4_900_000
+    assert np.array_equal(gm.get_cloud(), rm.export()[2])
+
+
+def test_configs1_cold_and_relinearize(ctx, big_world, maps):
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm, rm = maps
+    w = big_world
+    assert len(w["pts"]) == 131072
+    gf = capi.ICPFactor(ctx, gm, w["pts"], capi.make_reg_config(**w["cfg"]))
+    rf = ref_cpu.ICP(rm, w["pts"], ref_cpu.make_config(**w["cfg"]))
+    R, t = w["R"], w["t"]
+    g, r = gf.linearize(R, t), rf.linearize(R, t)          # cold: every point runs k-NN
+    assert g["n_knn"] == 131072
+    assert_result_parity(g, r)
+    assert_state_parity(gf.state(), rf.state())
+    # per-point whitened residual and Jacobian rows (north_star: within 1e-5 relative) on points Valid in both
+    e_r, J_r, valid = rf.point_rows(R, t)
+    st, e_g, J_g = _rows(w, w["pts"], R, t, gf)
+    v = (st == 8) & (valid == 1)
+    assert v.sum() > 80000
+    assert rel(e_g[v], e_r[v]) <= 1e-5
+    assert np.abs(e_g[v] - e_r[v]).max() <= 1e-5 * max(1.0, np.abs(e_r[v]).max())
+    assert rel(J_g[v], J_r[v]) <= 1e-5
+    # one re-linearization at a moved pose: part of the points keep their cached plane, part re-associate
+    dR = np.array([[1, -2e-4, 0], [2e-4, 1, 0], [0, 0, 1.0]])
+    R2, t2 = R @ dR, t + np.array([0.02, -0.015, 0.004])
+    g2, r2 = gf.linearize(R2, t2), rf.linearize(R2, t2)
+    assert 0 < g2["n_knn"] < 131072
+    assert_result_parity(g2, r2)
+    assert_state_parity(gf.state(), rf.state())
+    gf.destroy()
+
+
+@pytest.mark.parametrize("n", [65536, 65537])
+def test_configs1_workgroup_size_boundary(ctx, big_world, maps, n):
+    """65 536 points launch 256-thread workgroups, 65 537 launch 512-thread ones: same map, same answers."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm, rm = maps
+    w = big_world
+    pts = w["pts"][:n]
+    gf = capi.ICPFactor(ctx, gm, pts, capi.make_reg_config(**w["cfg"]))
+    rf = ref_cpu.ICP(rm, pts, ref_cpu.make_config(**w["cfg"]))
+    assert_result_parity(gf.linearize(w["R"], w["t"]), rf.linearize(w["R"], w["t"]))
+    assert_state_parity(gf.state(), rf.state())
+    gf.destroy()
+
+
+def test_fork_of_a_big_map_keeps_the_source_queryable(ctx, big_world, maps):
+    """mh_map_fork on a map with far more than 512 blocks (the source handle's hash mask must be the one of the
+    table its device mirror holds): factors and k-NN on the SOURCE keep their answers after the fork."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm, rm = maps
+    w = big_world
+    assert gm.stats()["n_blocks"] >= 512
+    pts = w["pts"][::8]
+    cfg = capi.make_reg_config(**w["cfg"])
+    f_old = capi.ICPFactor(ctx, gm, pts, cfg)
+    before = f_old.linearize(w["R"], w["t"])
+    q = np.concatenate([xyz[:300] for xyz in w["map_rooms"][:4]]).astype(np.float64) + 0.04
+    _, sq0, found0 = gm.knn(q, 5)
+    g2 = gm.fork()
+    extra = (w["map_rooms"][0][:4000] + np.float32(0.09))
+    g2.insert(extra)
+    f_old.reset()
+    after = f_old.linearize(w["R"], w["t"])
+    assert np.array_equal(after["status_hist"], before["status_hist"]) and after["status_hist"][8] > 5000
+    assert np.array_equal(after["H_ss"], before["H_ss"]) and after["f"] == before["f"]
+    _, sq1, found1 = gm.knn(q, 5)
+    assert np.array_equal(found0, found1) and np.array_equal(sq0, sq1) and (found1 == 5).sum() > 1000
+    rf = ref_cpu.ICP(rm, pts, ref_cpu.make_config(**w["cfg"]))
+    assert_result_parity(after, rf.linearize(w["R"], w["t"]))
+    f_old.destroy()
+    g2.release()
