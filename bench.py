@@ -200,6 +200,63 @@ def main():
         assert rr["n_knn"] == 0, "re-linearization leg ran k-NN"
     ctx.set_profiling(False)
 
+    # The sliding window (src/graph/manager.cpp:585-588: smoother_->update + additional_update_iterations re-linearize
+    # every live ICPFactor): 5 factors of ~24 k points (the size the reference's down-sampler feeds the factor, SURVEY
+    # F7), one mh_icp_linearize_batch call (one K3 + one K4 launch) vs the same five one call at a time.
+    win_stats = None
+    if not args.profile_mode and world == 1:
+        nwin, per = 5, 24576
+        wf = [capi.ICPFactor(ctx, gmap, np.ascontiguousarray(pts[i::nwin][:per]), capi.make_reg_config(**cfgd)) for i in range(nwin)]
+        wR = [R for _ in range(nwin)]
+        wt = [t + np.array([0.002, -0.001, 0.0005]) * i for i in range(nwin)]
+        # raw C-ABI calls with pre-marshalled arguments (what a C++ caller pays; the Python binding's result -> dict
+        # conversion costs ~20 us per factor)
+        wRa = np.ascontiguousarray(np.stack(wR).reshape(nwin, 9))
+        wta = np.ascontiguousarray(np.stack(wt))
+        wga = np.ascontiguousarray(np.tile([0.0, 0.0, -1.0], (nwin, 1)))
+        whs = (C.c_void_p * nwin)(*[f.h for f in wf])
+        wout = (capi.IcpResult * nwin)()
+        vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+        def _batch():
+            rc = ctx.L.mh_icp_linearize_batch(whs, nwin, vp(wRa), vp(wta), None, None, vp(wga), wout)
+            assert rc == 0, rc
+        def _one(i):
+            rc = ctx.L.mh_icp_linearize(wf[i].h, vp(wRa[i]), vp(wta[i]), None, None, vp(wga[i]), C.byref(wout[i]))
+            assert rc == 0, rc
+        def _one_by_one():
+            for i in range(nwin):
+                _one(i)
+        def _timed(fn, reps=40, cold=True):
+            ts_ = []
+            for _ in range(reps):
+                if cold:
+                    for f in wf:
+                        f.reset()
+                ctx.synchronize()
+                a = time.perf_counter()
+                fn()
+                ts_.append(time.perf_counter() - a)
+            return float(np.median(ts_) * 1e3)
+        _batch()
+        batch_cold = _timed(_batch)
+        single_cold = _timed(_one_by_one)
+        one_cold = _timed(lambda: _one(0))
+        _batch()
+        batch_relin = _timed(_batch, cold=False)
+        single_relin = _timed(_one_by_one, cold=False)
+        one_relin = _timed(lambda: _one(0), cold=False)
+        win_stats = {"factors": nwin, "points_per_factor": per,
+                     "batch_cold_ms": round(batch_cold, 4), "one_at_a_time_cold_ms": round(single_cold, 4),
+                     "single_factor_cold_ms": round(one_cold, 4),
+                     "batch_vs_single_factor": round(batch_cold / one_cold, 3),
+                     "batch_relinearize_ms": round(batch_relin, 4), "one_at_a_time_relinearize_ms": round(single_relin, 4),
+                     "single_factor_relinearize_ms": round(one_relin, 4),
+                     "batch_cold_mpts_s": round(nwin * per / batch_cold / 1e3, 1),
+                     "note": "median wall time of synchronous raw C-ABI calls (results on the host); cold = every point of "
+                             "every factor runs k-NN; relinearize = every point hits the data-association cache"}
+        for f in wf:
+            f.destroy()
+
     # Keyframe map update (Geometric::updateMap, geometric.cpp:427-513): copy the map, insert the scan's
     # geometric subset (every 4th point, world frame), make the device mirror current.
     kf_stats = None
@@ -428,6 +485,7 @@ def main():
         "keyframe_map_update": kf_stats,
         "scan_frontend": fe_stats,
         "sequence_replay": rp_stats,
+        "relinearize_window": win_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
                         "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,

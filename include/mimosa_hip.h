@@ -244,6 +244,15 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
                            const double * R_tgt, const double * t_tgt, const double g_unit[3],
                            mh_icp_result * out);
 int mh_icp_wait(mh_icp * icp);
+/* Every live ICPFactor of the sliding window re-linearized in ONE pass: what graph::Manager::defineNoLock's
+ * smoother_->update() + additional_update_iterations (src/graph/manager.cpp:585-588) make GTSAM do one factor at
+ * a time.  icps[f] is linearized at (R_src + 9 f, t_src + 3 f[, R_tgt + 9 f, t_tgt + 3 f], g_unit + 3 f) into out[f];
+ * results are bit-identical to n_factors separate mh_icp_linearize calls.  One K3 launch and one K4 launch cover
+ * all factors (two of each when clouds of up to 65 536 points and larger ones are mixed).  All factors must belong to one context, have no call in flight, and agree on unary/binary, on
+ * num_corres_points == 5 and on the map's neighbour mode (MH_ERR_UNSUPPORTED otherwise); at most 64 per call.
+ * R_tgt / t_tgt may be NULL for unary factors.  Blocks until every result is on the host. */
+int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+                           const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out);
 /* Two-phase form for a factor whose map is sharded across GPUs (no reference counterpart; the
  * reference is single-process).  begin = everything of linearize up to the Hessian sums of THIS shard
  * (`partial`: H, b, f, counters; its localizability fields are shard-local and must be ignored);

@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
-    "mh_icp_wait", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
+    "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
     "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
@@ -178,6 +178,7 @@ def load(build_if_missing: bool = True):
     L.mh_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_wait.argtypes = [vp]
+    L.mh_icp_linearize_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     L.mh_icp_linearize_begin.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_linearize_finish.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mh_icp_get_state.argtypes = [vp, vp, vp, vp]
@@ -410,6 +411,21 @@ class Scan:
             self.destroy()
         except Exception:
             pass
+
+
+def linearize_batch(factors, Rs, ts, g_units=None, R_tgts=None, t_tgts=None) -> list:
+    """mh_icp_linearize_batch: every factor of `factors` linearized at its own pose in one K3 + one K4 launch."""
+    n = len(factors)
+    ctx = factors[0].ctx
+    R = np.ascontiguousarray(np.asarray(Rs, np.float64).reshape(n, 9))
+    t = np.ascontiguousarray(np.asarray(ts, np.float64).reshape(n, 3))
+    g = np.ascontiguousarray(np.tile(np.array([0.0, 0.0, -1.0]), (n, 1)) if g_units is None else np.asarray(g_units, np.float64).reshape(n, 3))
+    Rt = None if R_tgts is None else np.ascontiguousarray(np.asarray(R_tgts, np.float64).reshape(n, 9))
+    tt = None if t_tgts is None else np.ascontiguousarray(np.asarray(t_tgts, np.float64).reshape(n, 3))
+    handles = (C.c_void_p * n)(*[f.h for f in factors])
+    out = (IcpResult * n)()
+    ctx.check(ctx.L.mh_icp_linearize_batch(handles, n, _p(R), _p(t), _p(Rt), _p(tt), _p(g), out))
+    return [out[i].as_dict() for i in range(n)]
 
 
 class ICPFactor:

@@ -79,6 +79,14 @@ int linearize_grid(int n);
 int localizability_grid(int n);
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream);
 hipError_t launch_localizability(const LocArgs & a, hipStream_t stream);
+// Batched form: d_args / d_start live in device-visible memory (n_factors argument blocks, n_factors + 1 grid
+// prefix entries); every factor's grid is batch_grid(n, tpb) with one tpb = batch_tpb(max n) for the whole batch.
+int batch_tpb(int max_n);
+int batch_grid(int n, int tpb);
+hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb, int k,
+                                  int n_off, bool binary, hipStream_t stream);
+hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,
+                                       hipStream_t stream);
 hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
                           int32_t * found, hipStream_t stream);
 

@@ -788,8 +788,10 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 // TPB = threads per workgroup: 512 for big clouds (one workgroup per CU at 131 072 points), 256 for clouds of up to
 // 65 536 points — the down-sampled clouds the reference feeds the factor are 10-25 k points, and at 512 threads they
 // would occupy a fifth of the CUs with two waves per SIMD; at 256 every wave has a SIMD to itself.
+// block_id / n_blocks: this workgroup's index within ITS factor's (multiple-of-8) grid: the launch grid for the
+// single-factor kernel, the factor's segment of the launch grid for the batched one.
 template <int K, bool BINARY, int NOFF, int TPB>
-__global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
+__device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [TPB][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
-  const int qi = xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x;
+  const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
   fill_scan_lut<NOFF>(s_scan);
   __syncthreads();
@@ -1076,21 +1078,21 @@ __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < SEGS; ++g) s += s_aux[g * NENT + threadIdx.x];
-    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + threadIdx.x], s);
+    store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x], s);
   }
   // the block's k-NN counters ride along as two more partial entries (exact in fp64): same-line
   // global atomics from every block would serialise at L2
   if (threadIdx.x >= 128 && threadIdx.x < 132)
-    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + NENT + (threadIdx.x - 128)],
+    store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + NENT + (threadIdx.x - 128)],
                   static_cast<double>(s_cnt[threadIdx.x - 128]));
 
   MH_STAMP(a.dbg, 5);
-  if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
+  if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   MH_STAMP(a.dbg, 6);
 
   // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
   double * s_sum = s_aux + (TPB / EW) * EW;
-  fold_rows<EW, TPB>(a.partials, gridDim.x, NENT + 4, s_aux, s_sum);
+  fold_rows<EW, TPB>(a.partials, n_blocks, NENT + 4, s_aux, s_sum);
   // Results go to the device struct (K4 reads the eigenbases there) AND straight to the caller's mapped
   // pinned host slot: no D2H copy node, and K4's tail does not have to relay them.
 #define MH_PUT(field, val)                          \
@@ -1132,6 +1134,60 @@ __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
   MH_STAMP(a.dbg, 7);
 }
 
+template <int K, bool BINARY, int NOFF, int TPB>
+__global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
+{
+  icp_linearize_body<K, BINARY, NOFF, TPB>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+}
+
+// A kernel-argument block read from memory into SGPRs: lane i of the wave loads dword i (one or two coalesced
+// loads per wave), then every dword is broadcast with v_readlane (constant lane index -> SGPR), so the compiler
+// treats the fields as wave-uniform scalars exactly like a by-value kernarg (plain global loads would put R, t
+// and the thresholds into VGPRs of a kernel that has none to spare).  The buffer behind `p` must be readable up
+// to the next multiple of 256 bytes.
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T * p)
+{
+  static_assert(sizeof(T) % 4 == 0, "dword-sized argument blocks only");
+  constexpr int NW = static_cast<int>(sizeof(T) / 4), NL = (NW + 63) / 64;
+  union U {
+    T v;
+    uint32_t w[NW];
+    __device__ U() {}
+  } u;
+  const uint32_t * s = reinterpret_cast<const uint32_t *>(p);
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  uint32_t chunk[NL];
+#pragma unroll
+  for (int c = 0; c < NL; ++c) chunk[c] = s[c * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) u.w[i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(chunk[i / 64]), i % 64));
+  return u.v;
+}
+
+// Which factor of a batch does workgroup b belong to?  start[] = exclusive prefix of the per-factor grids
+// (n_factors + 1 entries, each grid a multiple of 8 so b % 8 — the XCD — is the same inside the segment).
+__device__ __forceinline__ int batch_factor_of(const int * start, int n_factors, int b)
+{
+  int f = 0;
+  for (int i = 1; i < n_factors; ++i) f += (b >= start[i]) ? 1 : 0;  // n_factors <= 64, uniform scalar loop
+  return __builtin_amdgcn_readfirstlane(f);
+}
+
+// The sliding window's live factors in ONE launch (graph::Manager's smoother_->update re-linearizes every live
+// ICPFactor, src/graph/manager.cpp:585-588): one grid over the concatenated per-factor grids; each workgroup
+// picks up its factor's argument block and runs the same body; each factor keeps its own partial rows, ticket
+// and last-block fold, so the results are bit-identical to separate launches.
+template <int K, bool BINARY, int NOFF, int TPB>
+__global__ __launch_bounds__(TPB) void icp_linearize_batch_kernel(const IcpArgs * args, const int * start, int n_factors)
+{
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = batch_factor_of(start, n_factors, b);
+  const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
+  const IcpArgs a = load_uniform(args + f);
+  icp_linearize_body<K, BINARY, NOFF, TPB>(a, b - s0, s1 - s0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: component localizabilities (geometric_factor.hpp:434-457) + status histogram
 // (src/lidar/geometric.cpp:280-323).  Recomputes the unwhitened Jacobian directions from the cached
@@ -1139,7 +1195,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
 // ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
 // ------------------------------------------------------------------------------------------------
 template <int TPB>
-__global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a)
+__device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NW = TPB / 64;
   __shared__ double s_w[NW][16];
@@ -1163,7 +1219,7 @@ __global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a
   // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
   // cost is the ticket + fold tail, which scales with the number of partial rows
   for (int ch = 0; ch < a.chunks_per_block; ++ch) {
-  const int i = (blockIdx.x * a.chunks_per_block + ch) * TPB + threadIdx.x;
+  const int i = (block_id * a.chunks_per_block + ch) * TPB + threadIdx.x;
   int st = -1;
   if (i < a.n) {
     // status, point and normal are requested together (one memory round trip instead of a dependent chain;
@@ -1210,11 +1266,11 @@ __global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a
   if (threadIdx.x < 15) {
     double s = 0.0;
     for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
-    store_partial(&a.partials[static_cast<size_t>(blockIdx.x) * kPartialStride + threadIdx.x], s);
+    store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x], s);
   }
-  if (!arrive_is_last(a.ticket, gridDim.x, &s_last)) return;
+  if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   double * s_sum = s_seg + (TPB / 32) * 32;
-  fold_rows<32, TPB>(a.partials, gridDim.x, 15, s_seg, s_sum);
+  fold_rows<32, TPB>(a.partials, n_blocks, 15, s_seg, s_sum);
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
@@ -1232,6 +1288,21 @@ __global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a
       if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a)
+{
+  icp_localizability_body<TPB>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+}
+template <int TPB>
+__global__ __launch_bounds__(TPB) void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
+{
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = batch_factor_of(start, n_factors, b);
+  const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
+  const LocArgs a = load_uniform(args + f);
+  icp_localizability_body<TPB>(a, b - s0, s1 - s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1341,6 +1412,59 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
     hipLaunchKernelGGL(icp_localizability_kernel<256>, dim3(localizability_grid(a.n)), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(icp_localizability_kernel<kThreads>, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---- batched launches: all factors share (k == 5 or not, binary, neighbour mode, TPB) ------------------------
+int batch_tpb(int max_n) { return linearize_tpb(max_n); }
+int batch_grid(int n, int tpb) { return (((n + tpb - 1) / tpb) + 7) & ~7; }
+
+template <int NOFF, int TPB>
+static void launch_linearize_batch_nt(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int k,
+                                      bool binary, hipStream_t stream)
+{
+  const dim3 grid(total_grid), block(TPB);
+  if (k == 5) {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_batch_kernel<5, true, NOFF, TPB>), grid, block, 0, stream, d_args, d_start, n_factors);
+    else
+      hipLaunchKernelGGL((icp_linearize_batch_kernel<5, false, NOFF, TPB>), grid, block, 0, stream, d_args, d_start, n_factors);
+  } else {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_batch_kernel<8, true, NOFF, TPB>), grid, block, 0, stream, d_args, d_start, n_factors);
+    else
+      hipLaunchKernelGGL((icp_linearize_batch_kernel<8, false, NOFF, TPB>), grid, block, 0, stream, d_args, d_start, n_factors);
+  }
+}
+
+hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb, int k,
+                                  int n_off, bool binary, hipStream_t stream)
+{
+#define MH_BATCH_TPB(NOFF)                                                                                  \
+  do {                                                                                                      \
+    if (tpb == 256)                                                                                         \
+      launch_linearize_batch_nt<NOFF, 256>(d_args, d_start, n_factors, total_grid, k, binary, stream);      \
+    else                                                                                                    \
+      launch_linearize_batch_nt<NOFF, kThreads>(d_args, d_start, n_factors, total_grid, k, binary, stream); \
+  } while (0)
+  if (n_off <= 7)
+    MH_BATCH_TPB(7);
+  else if (n_off == 19)
+    MH_BATCH_TPB(19);
+  else
+    MH_BATCH_TPB(27);
+#undef MH_BATCH_TPB
+  return hipGetLastError();
+}
+
+hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,
+                                       hipStream_t stream)
+{
+  if (tpb == 256)
+    hipLaunchKernelGGL(icp_localizability_batch_kernel<256>, dim3(total_grid), dim3(256), 0, stream, d_args, d_start, n_factors);
+  else
+    hipLaunchKernelGGL(icp_localizability_batch_kernel<kThreads>, dim3(total_grid), dim3(kThreads), 0, stream, d_args, d_start,
+                       n_factors);
   return hipGetLastError();
 }
 

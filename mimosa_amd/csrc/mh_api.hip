@@ -28,6 +28,7 @@ namespace
 {
 thread_local std::string g_err;
 constexpr int kMaxPending = 64;
+constexpr int kMaxBatch = 64;  // factors per mh_icp_linearize_batch call
 }  // namespace
 
 struct mh_ctx
@@ -39,6 +40,8 @@ struct mh_ctx
   hipEvent_t timer[2] = {nullptr, nullptr};
   void * h_stage = nullptr;  // pinned staging for map delta records (pageable -> device copies run at a few GB/s)
   size_t h_stage_cap = 0;
+  void * h_batch = nullptr;  // pinned staging of mh_icp_linearize_batch's argument blocks
+  void * d_batch = nullptr;  // ... and the device copy the batched kernels read
 };
 
 namespace
@@ -598,6 +601,8 @@ void mh_shutdown(mh_ctx * ctx)
   if (ctx->timer[0]) (void)hipEventDestroy(ctx->timer[0]);
   if (ctx->timer[1]) (void)hipEventDestroy(ctx->timer[1]);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+  if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   delete ctx;
 }
 
@@ -1044,11 +1049,13 @@ int mh_icp_reset(mh_icp * icp)
   return MH_OK;
 }
 
-// want_flag: the last kernel publishes a completion sequence number to the host slot (mh_icp_wait then spins
-// on it instead of synchronising the stream).  Worth it for one synchronous call, not for a pipelined batch:
-// the system-scope fence it needs lengthens every K4 by ~2 us.
-static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
-                             const double * t_tgt, const double g_unit[3], mh_icp_result * out, bool want_flag)
+// Argument blocks of one linearize call of `icp` in pending slot n_pending (which it claims): everything of
+// linearize_enqueue except the launches.  want_flag: the last kernel publishes a completion sequence number to the
+// host slot (mh_icp_wait then spins on it instead of synchronising the stream).  Worth it for one synchronous call,
+// not for a pipelined batch: the system-scope fence it needs lengthens every K4 by ~2 us.
+static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                             const double * t_tgt, const double g_unit[3], mh_icp_result * out, bool want_flag, bool allow_timing,
+                             mh::IcpArgs & a, mh::LocArgs & l, bool & timed)
 {
   if (!icp || !R_src || !t_src || !g_unit || !out)
     return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize: NULL argument");
@@ -1064,7 +1071,6 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     icp->events_ready = true;
   }
 
-  mh::IcpArgs a;
   a.map = map_view(icp->map);
   a.src = static_cast<const float4 *>(icp->d_src.p);
   a.n = static_cast<int>(icp->n);
@@ -1092,12 +1098,12 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   if (const char * rp = std::getenv("MH_REPS")) a.reps = std::atoi(rp);
 #endif
 
-  mh::LocArgs l;
   l.src = a.src;
   l.host_result = nullptr;  // set below once the slot is known
   l.seq = 0;
   l.eig = nullptr;
   l.n = a.n;
+  l.chunks_per_block = 1;
   std::memcpy(l.R, a.R, sizeof(l.R));
   l.normal = a.normal;
   l.status = a.status;
@@ -1112,35 +1118,52 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   for (int i = 0; i < 3; ++i) pc.gz[i] = -g_unit[i];
   pc.linearize_count = ++icp->linearize_count;
   // each event record is a barrier + signal packet on the stream (~4 us): sampled calls only
-  const bool timed = ctx->profiling > 0 && (pc.linearize_count % ctx->profiling) == 0;
+  timed = allow_timing && ctx->profiling > 0 && (pc.linearize_count % ctx->profiling) == 0;
   if (timed) {
     for (int i = 0; i < 3; ++i) pc.ev[i] = icp->events[slot][i];
-    MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
   } else {
     pc.ev[0] = pc.ev[1] = pc.ev[2] = nullptr;
   }
   pc.seq = 0;
   if (a.n > 0) {
-    a.host_result = icp->d_h_results + slot;
+    a.host_result = l.host_result = icp->d_h_results + slot;
     if (want_flag) {
       if (++icp->seq_counter == 0) ++icp->seq_counter;
       pc.seq = l.seq = icp->seq_counter;
       __atomic_store_n(&icp->h_results[slot].seq, 0u, __ATOMIC_RELEASE);  // re-arm the slot before anything is enqueued
     }
-    MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
-    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
-    l.host_result = icp->d_h_results + slot;
-    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
-    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
-  } else if (timed) {
-    MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
-    MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   }
-  if (a.n == 0)  // nothing was launched: the (zero) device result is copied the plain way
-    MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
-                               ctx->stream));
   icp->n_pending++;
   icp->cold = false;
+  return MH_OK;
+}
+
+static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                             const double * t_tgt, const double g_unit[3], mh_icp_result * out, bool want_flag)
+{
+  mh::IcpArgs a;
+  mh::LocArgs l;
+  bool timed = false;
+  const int rc = linearize_prepare(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, want_flag, true, a, l, timed);
+  if (rc != MH_OK) return rc;
+  mh_ctx * ctx = icp->ctx;
+  const int slot = icp->n_pending - 1;
+  PendingCall & pc = icp->pending[slot];
+  if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
+  if (a.n > 0) {
+    MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
+    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+  } else {
+    if (timed) {
+      MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
+      MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+    }
+    // nothing was launched: the (zero) device result is copied the plain way
+    MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  }
   return MH_OK;
 }
 
@@ -1201,6 +1224,115 @@ int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3],
   const int rc = linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, icp && icp->n_pending == 0);
   if (rc != MH_OK) return rc;
   return mh_icp_wait(icp);
+}
+
+// ---- all live factors of the sliding window in two launches ------------------------------------------------
+// graph::Manager::defineNoLock (src/graph/manager.cpp:585-588): smoother_->update() + additional_update_iterations
+// re-linearize EVERY live ICPFactor whose pose moved; GTSAM calls them one after the other.  Here one K3 grid
+// and one K4 grid cover all of them (each factor keeps its own partial rows / ticket / fold: bit-identical to
+// separate calls), so the machine sees sum(n_i) points at once instead of 10-25 k.
+int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+                           const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out)
+{
+  if (!icps || !n_factors || !R_src || !t_src || !g_unit || !out)
+    return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: NULL argument");
+  if (n_factors > static_cast<size_t>(kMaxBatch)) return fail(nullptr, MH_ERR_UNSUPPORTED, "mh_icp_linearize_batch: at most 64 factors per call");
+  for (size_t f = 0; f < n_factors; ++f)
+    if (!icps[f]) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: NULL factor");
+  mh_ctx * ctx = icps[0]->ctx;
+  const bool binary = icps[0]->binary;
+  const bool k5 = icps[0]->cfg.num_corres_points == 5;
+  const int n_off = icps[0]->map->n_off;
+  size_t max_n = 0;
+  for (size_t f = 0; f < n_factors; ++f) {
+    const mh_icp * c = icps[f];
+    if (c->ctx != ctx) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: factors of different contexts");
+    if (c->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: a factor has calls in flight");
+    if (c->binary != binary || (c->cfg.num_corres_points == 5) != k5 || c->map->n_off != n_off)
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_linearize_batch: factors must agree on unary/binary, k == 5 and the neighbour mode");
+    if (binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: binary factors need target poses");
+    for (size_t g = 0; g < f; ++g)
+      if (icps[g] == c) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: the same factor twice");
+    max_n = c->n > max_n ? c->n : max_n;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  // staging: [IcpArgs x 64 | LocArgs x 64 | start x 2 x 65], host-pinned + a device copy the kernels read.  Factors
+  // are grouped by the workgroup size their cloud gets in a single call (256 threads up to 65 536 points, 512 above),
+  // one launch pair per non-empty group, so every factor reduces in exactly the order of a separate call.
+  const size_t ab = sizeof(mh::IcpArgs) * kMaxBatch, lb = sizeof(mh::LocArgs) * kMaxBatch, sb = sizeof(int) * 2 * (kMaxBatch + 1);
+  const size_t total = ((ab + lb + sb + 255) & ~size_t(255)) + 256;
+  if (!ctx->h_batch) MH_HIP(ctx, hipHostMalloc(&ctx->h_batch, total, hipHostMallocDefault));
+  if (!ctx->d_batch) MH_HIP(ctx, hipMalloc(&ctx->d_batch, total));
+  auto * h_a = reinterpret_cast<mh::IcpArgs *>(ctx->h_batch);
+  auto * h_l = reinterpret_cast<mh::LocArgs *>(static_cast<char *>(ctx->h_batch) + ab);
+  int * h_s = reinterpret_cast<int *>(static_cast<char *>(ctx->h_batch) + ab + lb);
+  (void)max_n;
+  int group_first[2] = {0, 0}, group_n[2] = {0, 0}, group_grid[2] = {0, 0}, group_tpb[2] = {256, 512};
+  size_t slot_of[kMaxBatch];
+  {
+    size_t pos = 0;
+    for (int g = 0; g < 2; ++g) {
+      group_first[g] = static_cast<int>(pos);
+      for (size_t f = 0; f < n_factors; ++f) {
+        const size_t nf = icps[f]->n;
+        if (nf == 0 || mh::batch_tpb(static_cast<int>(nf)) != group_tpb[g]) continue;
+        slot_of[f] = pos++;
+        group_n[g]++;
+      }
+    }
+  }
+  int * h_start[2] = {h_s, h_s + (kMaxBatch + 1)};
+  for (size_t f = 0; f < n_factors; ++f) {
+    bool timed = false;
+    mh::IcpArgs a;
+    mh::LocArgs l;
+    const int rc = linearize_prepare(icps[f], R_src + 9 * f, t_src + 3 * f, R_tgt ? R_tgt + 9 * f : nullptr,
+                                     t_tgt ? t_tgt + 3 * f : nullptr, g_unit + 3 * f, out + f, true, false, a, l, timed);
+    if (rc != MH_OK) {
+      for (size_t g = 0; g < f; ++g) icps[g]->n_pending = 0;
+      return rc;
+    }
+    if (icps[f]->n == 0) {
+      std::memset(&icps[f]->h_results[0], 0, sizeof(mh::DeviceResult));
+      continue;
+    }
+    h_a[slot_of[f]] = a;
+    h_l[slot_of[f]] = l;
+  }
+  for (int g = 0; g < 2; ++g) {
+    // prefix of the group's grids, in slot order
+    int acc = 0;
+    for (int i = 0; i < group_n[g]; ++i) {
+      h_start[g][i] = acc;
+      acc += mh::batch_grid(h_a[group_first[g] + i].n, group_tpb[g]);
+    }
+    h_start[g][group_n[g]] = acc;
+    group_grid[g] = acc;
+  }
+  if (group_grid[0] + group_grid[1] > 0) {
+    char * d = static_cast<char *>(ctx->d_batch);
+    MH_HIP(ctx, hipMemcpyAsync(d, ctx->h_batch, ab + lb + sb, hipMemcpyHostToDevice, ctx->stream));
+    const int k = k5 ? 5 : 8;
+    for (int g = 0; g < 2; ++g) {
+      if (!group_grid[g]) continue;
+      const auto * da = reinterpret_cast<const mh::IcpArgs *>(d) + group_first[g];
+      const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
+      MH_HIP(ctx, mh::launch_linearize_batch(da, ds, group_n[g], group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
+    }
+    for (int g = 0; g < 2; ++g) {
+      if (!group_grid[g]) continue;
+      const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + group_first[g];
+      const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
+      MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, group_n[g], group_grid[g], group_tpb[g], ctx->stream));
+    }
+  }
+  int rc_all = MH_OK;
+  for (size_t f = 0; f < n_factors; ++f) {
+    if (icps[f]->n == 0) icps[f]->pending[0].seq = 0;  // nothing was launched for it: falls back to a stream sync
+    const int rc = mh_icp_wait(icps[f]);
+    if (rc != MH_OK) rc_all = rc;
+  }
+  return rc_all;
 }
 
 // ---- two-phase form for map-sharded factors (mimosa_amd/dist.py): the Hessian sums of all shards are

@@ -1,0 +1,118 @@
+"""-m gpu: mh_icp_linearize_batch — all live factors of the sliding window (src/graph/manager.cpp:585-588) in one
+K3 + one K4 launch — against (a) the same factors linearized one call at a time (bit-identical) and (b) the oracle."""
+import numpy as np
+import pytest
+
+from parity import assert_result_parity, assert_state_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _window(ctx, world, n_factors, sizes=None, binary=False):
+    """n_factors scans of one room (different subsets / poses), each with a twin for the one-at-a-time run and an
+    oracle factor."""
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+
+    gm, rm = capi.VoxelMap(ctx), ref_cpu.Map()
+    gm.insert(world["map_xyz"])
+    rm.insert(world["map_xyz"])
+    cfg, rcfg = capi.make_reg_config(**world["cfg"]), ref_cpu.make_config(**world["cfg"])
+    pts = world["pts"]
+    fa, fb, fr, poses = [], [], [], []
+    for i in range(n_factors):
+        sub = pts[i::n_factors] if sizes is None else pts[: sizes[i]]
+        fa.append(capi.ICPFactor(ctx, gm, sub, cfg, binary=binary))
+        fb.append(capi.ICPFactor(ctx, gm, sub, cfg, binary=binary))
+        fr.append(ref_cpu.ICP(rm, sub, rcfg, binary=binary))
+        dR = synth.so3_exp(np.array([0.001 * i, -0.0007 * i, 0.002 * i]))
+        poses.append((world["R"] @ dR, world["t"] + np.array([0.01 * i, -0.004 * i, 0.002 * i])))
+    return gm, fa, fb, fr, poses
+
+
+def _same(a, b):
+    for k in ("H_ss", "b_s", "f", "status_hist", "loc_trans_comp", "loc_rot_comp", "loc_trans_final", "loc_rot_final",
+              "eigvec_rot", "eigvec_trans", "n_knn", "mean_candidates", "linearize_count", "H_st", "H_tt", "b_t"):
+        assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+
+
+def test_batch_equals_separate_calls_and_oracle(ctx, room_world):
+    from mimosa_amd import capi
+
+    gm, fa, fb, fr, poses = _window(ctx, room_world, 5)
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    got = capi.linearize_batch(fa, Rs, ts)                       # cold: every point of every factor runs k-NN
+    for i in range(5):
+        one = fb[i].linearize(Rs[i], ts[i])
+        _same(got[i], one)
+        assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
+        assert_state_parity(fa[i].state(), fr[i].state())
+        assert np.array_equal(fa[i].state()[0], fb[i].state()[0])
+    # the update iterations: re-linearize the whole window at slightly moved poses (DA cache partly hit)
+    for it in range(3):
+        ts = [t + np.array([0.012, -0.009, 0.003]) for t in ts]
+        got = capi.linearize_batch(fa, Rs, ts)
+        for i in range(5):
+            _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+            assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
+    for f in fa + fb:
+        f.destroy()
+    gm.release()
+
+
+def test_batch_ragged_sizes(ctx, small_world):
+    """Factors of very different sizes, an EMPTY factor, a single-factor batch, and one cloud past the 256/512-thread
+    boundary mixed with small ones."""
+    from mimosa_amd import capi
+
+    n = len(small_world["pts"])
+    gm, fa, fb, fr, poses = _window(ctx, small_world, 4, sizes=[n, 1, 0, 77])
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    got = capi.linearize_batch(fa, Rs, ts)
+    for i in range(4):
+        _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+    assert got[2]["n_knn"] == 0 and not got[2]["H_ss"].any()
+    one = capi.linearize_batch(fa[:1], Rs[:1], ts[:1])[0]
+    _same(one, fb[0].linearize(Rs[0], ts[0]))
+    with pytest.raises(capi.MhError):
+        capi.linearize_batch([fa[0], fa[0]], Rs[:2], ts[:2])    # the same factor twice
+    for f in fa + fb:
+        f.destroy()
+    gm.release()
+
+
+def test_batch_binary_factors(ctx, small_world):
+    from mimosa_amd import capi, synth
+
+    gm, fa, fb, fr, poses = _window(ctx, small_world, 3, binary=True)
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    Rt = [synth.so3_exp(np.array([0.002, 0.001, -0.003])) for _ in range(3)]
+    tt = [np.array([0.02, -0.01, 0.005]) for _ in range(3)]
+    Rs2 = [Rt[i] @ Rs[i] for i in range(3)]
+    ts2 = [Rt[i] @ ts[i] + tt[i] for i in range(3)]
+    got = capi.linearize_batch(fa, Rs2, ts2, R_tgts=Rt, t_tgts=tt)
+    for i in range(3):
+        _same(got[i], fb[i].linearize(Rs2[i], ts2[i], R_tgt=Rt[i], t_tgt=tt[i]))
+        assert_result_parity(got[i], fr[i].linearize(Rs2[i], ts2[i], R_tgt=Rt[i], t_tgt=tt[i]), binary=True)
+    for f in fa + fb:
+        f.destroy()
+    gm.release()
+
+
+def test_batch_mixed_block_size(ctx, room_world):
+    """One 65 536-pt cloud + a 70 000-pt... the room scan is 65 536 points: a batch whose largest member needs
+    512-thread workgroups runs every member at 512 and still equals the separate calls."""
+    from mimosa_amd import capi
+
+    pts = room_world["pts"]
+    big = np.concatenate([pts, pts[:4000]])  # 69 536 points
+    w = dict(room_world, pts=big)
+    gm, fa, fb, fr, poses = _window(ctx, w, 2, sizes=[len(big), 9000])
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    got = capi.linearize_batch(fa, Rs, ts)
+    for i in range(2):
+        _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+        assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
+    for f in fa + fb:
+        f.destroy()
+    gm.release()

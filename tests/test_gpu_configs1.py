@@ -68,7 +68,8 @@ def test_configs1_cold_and_relinearize(ctx, big_world, maps):
     assert np.abs(e_g[v] - e_r[v]).max() <= 1e-5 * max(1.0, np.abs(e_r[v]).max())
     assert rel(J_g[v], J_r[v]) <= 1e-5
     # one re-linearization at a moved pose: part of the points keep their cached plane, part re-associate
-    dR = np.array([[1, -2e-4, 0], [2e-4, 1, 0], [0, 0, 1.0]])
+    from mimosa_amd import synth
+    dR = synth.so3_exp(np.array([0.0, 0.0, 1.5e-3]))  # 1.5 mrad of yaw: points beyond ~15 m move past the 3.75 cm DA threshold
     R2, t2 = R @ dR, t + np.array([0.02, -0.015, 0.004])
     g2, r2 = gf.linearize(R2, t2), rf.linearize(R2, t2)
     assert 0 < g2["n_knn"] < 131072
