@@ -312,6 +312,137 @@ int mh_scan_get_indices(const mh_scan * scan, int which, uint32_t * out, size_t 
 int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * scan, const mh_reg_config * cfg,
                             int is_binary, mh_icp ** out);
 
+
+/* ---- photometric path: lidar::Photometric + PhotometricFactor ---------------------------------------
+ * replaces include/mimosa/lidar/photometric.hpp:22-86 (class Photometric), src/lidar/photometric.cpp,
+ * include/mimosa/lidar/photometric_factor.hpp:22-357 and src/lidar/photometric_utils.cpp.
+ * An mh_photo is one Photometric instance: configuration, the current Frame (device-resident images, yaw table,
+ * proj_idx, pose table — photometric_utils.hpp:42-92) and the tracked features (map_Le_features_).  Frames are
+ * reference-counted like the reference's shared_ptr<Frame>: a factor keeps the frame it was built on. */
+typedef struct mh_photo mh_photo;
+typedef struct mh_photo_factor mh_photo_factor;
+
+/* lidar::PhotometricConfig, include/mimosa/lidar/photometric_config.hpp:15-87: the fields the arithmetic reads.
+ * Arrays are copied by mh_photo_create.  The derived parameters fx, fy, cx, beam_offset_m
+ * (src/lidar/photometric_config.cpp:98-110) are computed by the library. */
+typedef struct mh_photo_config {
+  int32_t rows, cols;                   /* sensor/lidar_data_format: pixels_per_column, columns_per_frame */
+  int32_t destagger;
+  const int32_t * pixel_shift_by_row;   /* rows entries */
+  const float * beam_altitude_angles;   /* rows entries, degrees, descending */
+  float range_min, range_max;
+  int32_t erosion_buffer, patch_size, margin_size;
+  float intensity_scale, intensity_gamma;
+  int32_t remove_lines, filter_brightness, gaussian_blur, gaussian_blur_size; /* gaussian_blur_size: 3 supported */
+  float gradient_threshold, max_dist_from_mean, max_dist_from_plane;
+  int32_t nma_radius;
+  int32_t num_features_detect;
+  float occlusion_range_diff_threshold;
+  int32_t max_feature_life_time;
+  const double * high_pass_fir;         /* column kernel of removeLines (photometric.cpp:322-327) */
+  int32_t n_high_pass;
+  const double * low_pass_fir;          /* row kernel */
+  int32_t n_low_pass;
+  int32_t brightness_window_size[2];    /* cv::Size(width, height) */
+  float lidar_origin_to_beam_origin_mm;
+  int32_t rotate_patch_to_align_with_gradient; /* must be 0 (false in every shipped configuration) */
+  const int32_t * patch_offsets;        /* edgelet_patch_offsets: n_patch_offsets pairs (du, dv); <= 64 */
+  int32_t n_patch_offsets;
+  int32_t use_robust_cost_function;
+  int32_t robust_cost_function;         /* 0 "huber", 1 "gemanmcclure" */
+  double robust_cost_function_parameter, error_scale, max_error, sigma;
+  double T_B_L_R[9], T_B_L_t[3];        /* lidar/T_B_S */
+  const uint8_t * static_mask;          /* rows * cols, 0 = invalid, or NULL (static_mask_path == "") */
+} mh_photo_config;
+
+/* PhotometricFactor::RejectStatus, photometric_factor.hpp:36-47 */
+typedef enum mh_photo_status {
+  MH_PHOTO_UNPROCESSED = 0,
+  MH_PHOTO_POINT_PROJECT_UNDISTORTED = 1,
+  MH_PHOTO_POINT_RANGE = 2,
+  MH_PHOTO_POINT_PROJECT = 3,
+  MH_PHOTO_POINT_MASK = 4,
+  MH_PHOTO_POINT_MASK_MARGIN = 5,
+  MH_PHOTO_POINT_RANGE_DIFF = 6,
+  MH_PHOTO_MAX_ERROR = 7,
+  MH_PHOTO_VALID = 8
+} mh_photo_status;
+
+/* Feature, include/mimosa/lidar/photometric_utils.hpp:25-40 (per-point arrays travel separately) */
+typedef struct mh_photo_feature {
+  uint32_t id;
+  int32_t life_time;
+  int32_t n_points;
+  int32_t pad;
+  double center[2];
+  double normal[3];
+  double mean_intensity, sigma_intensity;
+} mh_photo_feature;
+
+/* What gtsam::HessianFactor receives from PhotometricFactor::linearize (photometric_factor.hpp:332-353):
+ * unary HessianFactor(key, H_bb, -b_b, f); binary HessianFactor(key_b, key_a, H_bb, H_ba, -b_b, H_aa, -b_a, f). */
+typedef struct mh_photo_result {
+  double H_bb[36], H_ba[36], H_aa[36];
+  double b_b[6], b_a[6];
+  double f;
+  double loc_trans_final[3], loc_rot_final[3], eigvec_trans[9], eigvec_rot[9]; /* getLocalizabilities :51-59 (unary) */
+  int32_t status_hist[9];
+  int32_t n_exceptions; /* features at which the reference would have THROWN (project(): invalid x coordinate,
+                           photometric_utils.cpp:90-97; interpolated_map_T_Le_Lt.at()); reported as
+                           PointProjectUndistorted, the host mirror turns a non-zero count into the exception */
+  float gpu_ms;         /* kernel time of this call, -1 unless mh_set_profiling is on */
+} mh_photo_result;
+
+int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out); /* ctor, photometric.cpp:13-70 */
+void mh_photo_destroy(mh_photo * photo);
+/* Photometric::preprocess (photometric.cpp:92-320): yaw table from points_raw, image formation from points_deskewed,
+ * proj_idx, intensity filter chain, Sobel, mask.  points_raw[i] / points_deskewed[i] are the same measurement before /
+ * after Manager::deskewPoints; the corrected intensities are written back into points_deskewed (:307-314).
+ * unique_ns / T_Le_Lt = interpolated_map_T_Le_Lt_ (lidar/manager.cpp:390-405, :501-503): n_groups ascending
+ * timestamps, 12 doubles each (R row-major, then t).  Replaces the current frame. */
+int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_point32 * points_deskewed, size_t n,
+                        const uint32_t * unique_ns, const double * T_Le_Lt, size_t n_groups);
+/* The same on a device-resident scan (mh_scan_*): points_raw = the scan's points_full_ as they were before
+ * mh_scan_deskew (the scan keeps that copy once mh_scan_keep_raw(scan, 1) was called before mh_scan_deskew),
+ * points_deskewed = its points_full_ now (corrected intensities are written there). */
+int mh_scan_keep_raw(mh_scan * scan, int keep);
+int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups);
+/* One image of the current frame, rows * cols elements.  which: 0 img_intensity (float), 1 img_range (float),
+ * 2 img_dx (float), 3 img_dy (float), 4 img_mask (uint8), 5 img_deskewed_cloud_idx (int32), 6 yaw_angles (float),
+ * 7 proj_idx (int32, x 10 per pixel), 8 gradient magnitude (uint8, photometric.cpp:536-540), 9 detection mask
+ * before the per-feature circles (uint8, :524-525). */
+int mh_photo_get_image(mh_photo * photo, int which, void * out, size_t capacity_bytes);
+/* tracked features (map_Le_features_).  Per-point arrays: n_points entries per feature, concatenated in feature
+ * order: Le_ps (3 doubles per point), intensities, psi_intensities.  Any output pointer may be NULL. */
+int mh_photo_num_features(const mh_photo * photo, size_t * n_features, size_t * n_points_total);
+int mh_photo_get_features(const mh_photo * photo, mh_photo_feature * features, double * Le_ps, double * intensities,
+                          double * psi);
+int mh_photo_set_features(mh_photo * photo, const mh_photo_feature * features, size_t n_features, const double * Le_ps,
+                          const double * intensities, const double * psi);
+/* Photometric::detectFeatures (photometric.cpp:516-745) on the current frame: up to num_to_detect new features are
+ * appended to the tracked ones.  T_W_Be = Values[frame key]; bias_directions: n_directions x 3 (the degenerate
+ * directions Manager::postDefineUpdate passes, lidar/manager.cpp:568-581). */
+int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3],
+                             const double * bias_directions, size_t n_directions);
+/* Photometric::updateMap (photometric.cpp:396-514): feature bookkeeping from the factor's statuses (drop the
+ * non-Valid ones, new centres, life_time, max_feature_life_time), then detectFeatures for the missing ones.
+ * factor may be NULL (no factor was built for this frame). */
+int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double R_W_Be[9], const double t_W_Be[3],
+                        const double * bias_directions, size_t n_directions);
+/* PhotometricFactor ctor (photometric_factor.hpp:86-124) from the current frame and the tracked features (copied).
+ * VSVt: 6x6 row-major = V S V^T of Photometric::getFactors (photometric.cpp:373-394), NULL = identity; ignored for
+ * the binary form. */
+int mh_photo_factor_create(mh_photo * photo, const double * VSVt, int is_binary, mh_photo_factor ** out);
+void mh_photo_factor_destroy(mh_photo_factor * factor);
+/* linearize(Values) (:136-355): T_b = Values[keys[0]] (the frame's pose), T_a = Values[keys[1]] for the binary
+ * form (NULL otherwise).  Blocks until the result is on the host. */
+int mh_photo_factor_linearize(mh_photo_factor * factor, const double R_b[9], const double t_b[3], const double * R_a,
+                              const double * t_a, mh_photo_result * out);
+/* getStatuses / getFeatures().center after the last linearize; rows (optional, parity tooling): per feature and
+ * patch point {whitened residual, J_b[6], valid} = 8 doubles, 64 points per feature. */
+int mh_photo_factor_get_state(const mh_photo_factor * factor, int32_t * statuses, double * centers, double * rows);
+size_t mh_photo_factor_size(const mh_photo_factor * factor);
+
 #ifdef __cplusplus
 }
 #endif

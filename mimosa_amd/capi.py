@@ -27,6 +27,9 @@ EXPORTS = [
     "mh_deskew", "mh_transform_f32",
     "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
+    "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_get_image",
+    "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
+    "mh_photo_factor_create", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_get_state", "mh_photo_factor_size",
 ]
 
 
@@ -113,6 +116,98 @@ class ScanInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "pad"}
 
 
+
+class PhotoConfig(C.Structure):
+    """mh_photo_config (lidar::PhotometricConfig, include/mimosa/lidar/photometric_config.hpp:15-87)."""
+    _fields_ = [
+        ("rows", C.c_int32), ("cols", C.c_int32), ("destagger", C.c_int32),
+        ("pixel_shift_by_row", C.c_void_p), ("beam_altitude_angles", C.c_void_p),
+        ("range_min", C.c_float), ("range_max", C.c_float),
+        ("erosion_buffer", C.c_int32), ("patch_size", C.c_int32), ("margin_size", C.c_int32),
+        ("intensity_scale", C.c_float), ("intensity_gamma", C.c_float),
+        ("remove_lines", C.c_int32), ("filter_brightness", C.c_int32), ("gaussian_blur", C.c_int32), ("gaussian_blur_size", C.c_int32),
+        ("gradient_threshold", C.c_float), ("max_dist_from_mean", C.c_float), ("max_dist_from_plane", C.c_float),
+        ("nma_radius", C.c_int32), ("num_features_detect", C.c_int32), ("occlusion_range_diff_threshold", C.c_float),
+        ("max_feature_life_time", C.c_int32),
+        ("high_pass_fir", C.c_void_p), ("n_high_pass", C.c_int32), ("low_pass_fir", C.c_void_p), ("n_low_pass", C.c_int32),
+        ("brightness_window_size", C.c_int32 * 2), ("lidar_origin_to_beam_origin_mm", C.c_float),
+        ("rotate_patch_to_align_with_gradient", C.c_int32),
+        ("patch_offsets", C.c_void_p), ("n_patch_offsets", C.c_int32),
+        ("use_robust_cost_function", C.c_int32), ("robust_cost_function", C.c_int32),
+        ("robust_cost_function_parameter", C.c_double), ("error_scale", C.c_double), ("max_error", C.c_double), ("sigma", C.c_double),
+        ("T_B_L_R", C.c_double * 9), ("T_B_L_t", C.c_double * 3),
+        ("static_mask", C.c_void_p),
+    ]
+
+
+class PhotoFeature(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("life_time", C.c_int32), ("n_points", C.c_int32), ("pad", C.c_int32),
+                ("center", C.c_double * 2), ("normal", C.c_double * 3), ("mean_intensity", C.c_double), ("sigma_intensity", C.c_double)]
+
+
+class PhotoResult(C.Structure):
+    _fields_ = [
+        ("H_bb", C.c_double * 36), ("H_ba", C.c_double * 36), ("H_aa", C.c_double * 36), ("b_b", C.c_double * 6), ("b_a", C.c_double * 6),
+        ("f", C.c_double), ("loc_trans_final", C.c_double * 3), ("loc_rot_final", C.c_double * 3),
+        ("eigvec_trans", C.c_double * 9), ("eigvec_rot", C.c_double * 9), ("status_hist", C.c_int32 * 9),
+        ("n_exceptions", C.c_int32), ("gpu_ms", C.c_float),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = np.array(v) if hasattr(v, "__len__") else v
+        for k in ("H_bb", "H_ba", "H_aa"):
+            d[k] = d[k].reshape(6, 6)
+        for k in ("eigvec_trans", "eigvec_rot"):
+            d[k] = d[k].reshape(3, 3)
+        return d
+
+
+PHOTO_IMAGES = {"intensity": (0, np.float32, 1), "range": (1, np.float32, 1), "dx": (2, np.float32, 1), "dy": (3, np.float32, 1),
+                "mask": (4, np.uint8, 1), "idx": (5, np.int32, 1), "yaw": (6, np.float32, 1), "proj_idx": (7, np.int32, 10),
+                "grad": (8, np.uint8, 1), "detection_mask": (9, np.uint8, 1)}
+
+
+def make_photo_config(d: dict):
+    """Build an mh_photo_config from a dict (mimosa_amd.synth_photo.photo_config()); returns (struct, keep-alive list)."""
+    c = PhotoConfig()
+    keep = []
+
+    def arr(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    for k, _ in PhotoConfig._fields_:
+        if k in ("pixel_shift_by_row", "patch_offsets"):
+            setattr(c, k, arr(d[k], np.int32))
+        elif k == "beam_altitude_angles":
+            setattr(c, k, arr(d[k], np.float32))
+        elif k in ("high_pass_fir", "low_pass_fir"):
+            setattr(c, k, arr(d[k], np.float64) if d.get(k) is not None and len(d[k]) else None)
+        elif k == "static_mask":
+            setattr(c, k, arr(d[k], np.uint8) if d.get(k) is not None else None)
+        elif k == "brightness_window_size":
+            c.brightness_window_size[0], c.brightness_window_size[1] = int(d[k][0]), int(d[k][1])
+        elif k == "T_B_L_R":
+            for i, v in enumerate(np.asarray(d[k], float).ravel()):
+                c.T_B_L_R[i] = v
+        elif k == "T_B_L_t":
+            for i, v in enumerate(np.asarray(d[k], float).ravel()):
+                c.T_B_L_t[i] = v
+        elif k == "n_high_pass":
+            c.n_high_pass = len(d["high_pass_fir"]) if d.get("high_pass_fir") is not None else 0
+        elif k == "n_low_pass":
+            c.n_low_pass = len(d["low_pass_fir"]) if d.get("low_pass_fir") is not None else 0
+        elif k == "n_patch_offsets":
+            c.n_patch_offsets = len(np.asarray(d["patch_offsets"]).reshape(-1, 2))
+        else:
+            setattr(c, k, d[k])
+    return c, keep
+
+
 def make_input_config(**kw) -> InputConfig:
     """ENWIDE manager block (config/enwide/params.yaml:66-72) + geometric skip divisors (:79-80) by default."""
     d = dict(range_min=0.2, range_max=100.0, intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9, z_offset=0.0,
@@ -197,6 +292,25 @@ def load(build_if_missing: bool = True):
     L.mh_scan_get_points.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     L.mh_scan_get_indices.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     L.mh_icp_create_from_scan.argtypes = [vp, vp, vp, C.POINTER(RegConfig), i32, pvp]
+    L.mh_photo_create.argtypes = [vp, C.POINTER(PhotoConfig), pvp]
+    L.mh_photo_destroy.argtypes = [vp]
+    L.mh_photo_destroy.restype = None
+    L.mh_photo_preprocess.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+    L.mh_scan_keep_raw.argtypes = [vp, i32]
+    L.mh_photo_preprocess_scan.argtypes = [vp, vp, vp, sz]
+    L.mh_photo_get_image.argtypes = [vp, i32, vp, sz]
+    L.mh_photo_num_features.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.mh_photo_get_features.argtypes = [vp, vp, vp, vp, vp]
+    L.mh_photo_set_features.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.mh_photo_detect_features.argtypes = [vp, i32, vp, vp, vp, sz]
+    L.mh_photo_update_map.argtypes = [vp, vp, vp, vp, vp, sz]
+    L.mh_photo_factor_create.argtypes = [vp, vp, i32, pvp]
+    L.mh_photo_factor_destroy.argtypes = [vp]
+    L.mh_photo_factor_destroy.restype = None
+    L.mh_photo_factor_linearize.argtypes = [vp, vp, vp, vp, vp, C.POINTER(PhotoResult)]
+    L.mh_photo_factor_get_state.argtypes = [vp, vp, vp, vp]
+    L.mh_photo_factor_size.argtypes = [vp]
+    L.mh_photo_factor_size.restype = sz
     _LIB = L
     return L
 
@@ -496,6 +610,149 @@ class ICPFactor:
     def destroy(self):
         if getattr(self, "h", None):
             self.L.mh_icp_destroy(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class _PhotoBase:
+    """Shared marshalling of the photometric entry points: the product (libmimosa_hip.so, prefix mh_photo) and the
+    checker (oracle/photo_ref.py, prefix refphoto) export the same shapes."""
+
+    def _features_from(self, nf, npt, get):
+        feats = (PhotoFeature * max(nf, 1))()
+        Le, I, psi = np.zeros((max(npt, 1), 3)), np.zeros(max(npt, 1)), np.zeros(max(npt, 1))
+        get(feats, _p(Le), _p(I), _p(psi))
+        out, o = [], 0
+        for i in range(nf):
+            m = feats[i].n_points
+            out.append(dict(id=int(feats[i].id), life_time=int(feats[i].life_time), center=np.array(feats[i].center),
+                            normal=np.array(feats[i].normal), mean_intensity=feats[i].mean_intensity,
+                            sigma_intensity=feats[i].sigma_intensity, Le_ps=Le[o:o + m].copy(), intensities=I[o:o + m].copy(),
+                            psi=psi[o:o + m].copy()))
+            o += m
+        return out
+
+    @staticmethod
+    def _features_to(features):
+        nf = len(features)
+        feats = (PhotoFeature * max(nf, 1))()
+        Le, I, psi = [], [], []
+        for i, f in enumerate(features):
+            feats[i].id, feats[i].life_time, feats[i].n_points = f["id"], f["life_time"], len(f["Le_ps"])
+            feats[i].center[0], feats[i].center[1] = f["center"]
+            for k in range(3):
+                feats[i].normal[k] = f["normal"][k]
+            feats[i].mean_intensity, feats[i].sigma_intensity = f["mean_intensity"], f["sigma_intensity"]
+            Le.append(np.asarray(f["Le_ps"], float).reshape(-1, 3))
+            I.append(np.asarray(f["intensities"], float))
+            psi.append(np.asarray(f["psi"], float))
+        Le = np.ascontiguousarray(np.concatenate(Le)) if nf else np.zeros((1, 3))
+        I = np.ascontiguousarray(np.concatenate(I)) if nf else np.zeros(1)
+        psi = np.ascontiguousarray(np.concatenate(psi)) if nf else np.zeros(1)
+        return feats, Le, I, psi
+
+
+class Photo(_PhotoBase):
+    """lidar::Photometric counterpart (include/mimosa/lidar/photometric.hpp:22-86) over mh_photo_*."""
+
+    def __init__(self, ctx: Context, cfg: dict):
+        self.ctx, self.L = ctx, ctx.L
+        self.cfgd = cfg
+        self.c, self._keep = make_photo_config(cfg)
+        self.rows, self.cols = cfg["rows"], cfg["cols"]
+        h = C.c_void_p()
+        ctx.check(self.L.mh_photo_create(ctx.h, C.byref(self.c), C.byref(h)))
+        self.h = h
+        ctx._children += 1
+
+    def preprocess(self, raw, desk, unique_ns, T_Le_Lt):
+        """Returns the deskewed cloud with the corrected intensities (a copy)."""
+        raw, desk = np.ascontiguousarray(raw), np.array(desk, copy=True)
+        ns = np.ascontiguousarray(unique_ns, np.uint32)
+        T = np.ascontiguousarray(np.asarray(T_Le_Lt, np.float64).reshape(len(ns), 12))
+        self.ctx.check(self.L.mh_photo_preprocess(self.h, _p(raw), _p(desk), len(desk), _p(ns), _p(T), len(ns)))
+        return desk
+
+    def preprocess_scan(self, scan, T_Le_Lt):
+        T = np.ascontiguousarray(np.asarray(T_Le_Lt, np.float64).reshape(-1, 12))
+        self.ctx.check(self.L.mh_photo_preprocess_scan(self.h, scan.h, _p(T), len(T)))
+
+    def image(self, name):
+        which, dt, k = PHOTO_IMAGES[name]
+        out = np.empty((self.rows, self.cols, k) if k > 1 else (self.rows, self.cols), dt)
+        self.ctx.check(self.L.mh_photo_get_image(self.h, which, _p(out), out.nbytes))
+        return out
+
+    def features(self):
+        nf, npt = C.c_size_t(), C.c_size_t()
+        self.ctx.check(self.L.mh_photo_num_features(self.h, C.byref(nf), C.byref(npt)))
+        return self._features_from(nf.value, npt.value,
+                                   lambda f, a, b, c: self.ctx.check(self.L.mh_photo_get_features(self.h, f, a, b, c)))
+
+    def set_features(self, features):
+        feats, Le, I, psi = self._features_to(features)
+        self.ctx.check(self.L.mh_photo_set_features(self.h, feats, len(features), _p(Le), _p(I), _p(psi)))
+
+    def detect(self, num, R_W_Be, t_W_Be, bias_directions):
+        R, t, b = _f64(R_W_Be), _f64(t_W_Be), np.ascontiguousarray(np.asarray(bias_directions, np.float64).reshape(-1, 3))
+        self.ctx.check(self.L.mh_photo_detect_features(self.h, int(num), _p(R), _p(t), _p(b), len(b)))
+
+    def update_map(self, factor, R_W_Be, t_W_Be, bias_directions):
+        R, t, b = _f64(R_W_Be), _f64(t_W_Be), np.ascontiguousarray(np.asarray(bias_directions, np.float64).reshape(-1, 3))
+        self.ctx.check(self.L.mh_photo_update_map(self.h, factor.h if factor is not None else None, _p(R), _p(t), _p(b), len(b)))
+
+    def make_factor(self, VSVt=None, binary=False):
+        return PhotoFactor(self, VSVt, binary)
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.mh_photo_destroy(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class PhotoFactor:
+    """lidar::PhotometricFactor counterpart (include/mimosa/lidar/photometric_factor.hpp:22-357)."""
+
+    def __init__(self, photo: Photo, VSVt=None, binary=False):
+        self.photo, self.ctx, self.L = photo, photo.ctx, photo.L
+        V = _f64(VSVt) if VSVt is not None else None
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_photo_factor_create(photo.h, _p(V), int(binary), C.byref(h)))
+        self.h = h
+        self.n = int(self.L.mh_photo_factor_size(h))
+        self.ctx._children += 1
+
+    def linearize(self, R_b, t_b, R_a=None, t_a=None) -> dict:
+        out = PhotoResult()
+        Rb, tb = _f64(R_b), _f64(t_b)
+        Ra = _f64(R_a) if R_a is not None else None
+        ta = _f64(t_a) if t_a is not None else None
+        self.ctx.check(self.L.mh_photo_factor_linearize(self.h, _p(Rb), _p(tb), _p(Ra), _p(ta), C.byref(out)))
+        return out.as_dict()
+
+    def state(self, rows=True):
+        st = np.empty(self.n, np.int32)
+        ce = np.empty((self.n, 2))
+        rw = np.empty((self.n, 64, 8)) if rows else None
+        self.ctx.check(self.L.mh_photo_factor_get_state(self.h, _p(st), _p(ce), _p(rw)))
+        return st, ce, rw
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.mh_photo_factor_destroy(self.h)
             self.h = None
             self.ctx._child_released()
 

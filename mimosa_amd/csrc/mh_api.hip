@@ -21,221 +21,9 @@
 #include "../../include/mimosa_hip.h"
 #include "icp_device.hpp"
 #include "math3.hpp"
+#include "mh_internal.hpp"
 #include "scan_device.hpp"
 #include "voxel_map.hpp"
-
-namespace
-{
-thread_local std::string g_err;
-constexpr int kMaxPending = 64;
-constexpr int kMaxBatch = 64;  // factors per mh_icp_linearize_batch call
-}  // namespace
-
-struct mh_ctx
-{
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
-  hipEvent_t timer[2] = {nullptr, nullptr};
-  void * h_stage = nullptr;  // pinned staging for map delta records (pageable -> device copies run at a few GB/s)
-  size_t h_stage_cap = 0;
-  void * h_batch = nullptr;  // pinned staging of mh_icp_linearize_batch's argument blocks
-  void * d_batch = nullptr;  // ... and the device copy the batched kernels read
-};
-
-namespace
-{
-int fail(const mh_ctx * ctx, int code, const std::string & msg)
-{
-  g_err = msg;
-  if (ctx) const_cast<mh_ctx *>(ctx)->err = msg;
-  return code;
-}
-int hip_fail(const mh_ctx * ctx, hipError_t e, const char * what)
-{
-  const int code = (e == hipErrorOutOfMemory) ? MH_ERR_OOM : (e == hipErrorNoDevice ? MH_ERR_NO_DEVICE : MH_ERR_HIP);
-  return fail(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define MH_HIP(ctx, call)                                   \
-  do {                                                      \
-    const hipError_t e_ = (call);                           \
-    if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
-  } while (0)
-
-// Device / pinned-host allocation cache.  A scan creates a factor (a dozen device buffers, a pinned result
-// ring, sort temporaries) and destroys it a few hundred milliseconds later; hipMalloc / hipFree / hipHostMalloc
-// cost 10-200 us each and hipFree synchronises the device.  Freed blocks of 4 KiB .. 64 MiB are kept per
-// (device, rounded size) and handed out again; the cache holds at most kMaxCachedBytes per device.  A cached
-// free still drains the device first (hipDeviceSynchronize: microseconds when idle), because callers rely on
-// hipFree's implicit "nobody is using this any more".
-class AllocCache
-{
-public:
-  static hipError_t alloc(void ** out, size_t bytes)
-  {
-    const size_t cls = size_class(bytes);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (cls) {
-      std::lock_guard<std::mutex> g(mu());
-      auto & v = free_list()[key(dev, cls)];
-      if (!v.empty()) {
-        *out = v.back();
-        v.pop_back();
-        cached_bytes()[dev] -= cls;
-        live()[*out] = cls;
-        return hipSuccess;
-      }
-    }
-    const hipError_t e = hipMalloc(out, cls ? cls : bytes);
-    if (e == hipSuccess && cls) {
-      std::lock_guard<std::mutex> g(mu());
-      live()[*out] = cls;
-    }
-    return e;
-  }
-  static void free(void * p)
-  {
-    if (!p) return;
-    size_t cls = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    {
-      std::lock_guard<std::mutex> g(mu());
-      auto it = live().find(p);
-      if (it != live().end()) {
-        cls = it->second;
-        live().erase(it);
-      }
-      if (cls && cached_bytes()[dev] + cls <= kMaxCachedBytes) {
-        // in-flight work may still read / write the block: drain before it can be handed out again
-        (void)hipDeviceSynchronize();
-        free_list()[key(dev, cls)].push_back(p);
-        cached_bytes()[dev] += cls;
-        return;
-      }
-    }
-    (void)hipFree(p);
-  }
-  // pinned, mapped result rings (one fixed size)
-  static hipError_t alloc_pinned(void ** out, size_t bytes)
-  {
-    {
-      std::lock_guard<std::mutex> g(mu());
-      auto & v = pinned()[bytes];
-      if (!v.empty()) {
-        *out = v.back();
-        v.pop_back();
-        return hipSuccess;
-      }
-    }
-    return hipHostMalloc(out, bytes, hipHostMallocMapped);
-  }
-  static void free_pinned(void * p, size_t bytes)
-  {
-    if (!p) return;
-    std::lock_guard<std::mutex> g(mu());
-    auto & v = pinned()[bytes];
-    if (v.size() < 64) {
-      v.push_back(p);
-      return;
-    }
-    (void)hipHostFree(p);
-  }
-
-private:
-  static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
-  static size_t size_class(size_t bytes)
-  {
-    if (bytes > (size_t(64) << 20)) return 0;  // big (map-sized) blocks are not cached
-    size_t c = 4096;
-    while (c < bytes) c += c / 2 >= 4096 ? (c / 4) : c;  // 4K, 8K, 16K, 20K, 25K, ... (~25 % steps)
-    return c;
-  }
-  static uint64_t key(int dev, size_t cls) { return (static_cast<uint64_t>(dev) << 56) | cls; }
-  static std::mutex & mu()
-  {
-    static std::mutex m;
-    return m;
-  }
-  static std::unordered_map<uint64_t, std::vector<void *>> & free_list()
-  {
-    static std::unordered_map<uint64_t, std::vector<void *>> m;
-    return m;
-  }
-  static std::unordered_map<void *, size_t> & live()
-  {
-    static std::unordered_map<void *, size_t> m;
-    return m;
-  }
-  static std::unordered_map<int, size_t> & cached_bytes()
-  {
-    static std::unordered_map<int, size_t> m;
-    return m;
-  }
-  static std::unordered_map<size_t, std::vector<void *>> & pinned()
-  {
-    static std::unordered_map<size_t, std::vector<void *>> m;
-    return m;
-  }
-};
-
-template <typename T>
-hipError_t dev_alloc(T ** out, size_t bytes)
-{
-  void * p = nullptr;
-  const hipError_t e = AllocCache::alloc(&p, bytes);
-  *out = static_cast<T *>(p);
-  return e;
-}
-inline void dev_free(void * p) { AllocCache::free(p); }
-
-// Scoped device temporary: released (back to the cache) on every exit path, including the early returns of MH_HIP.
-template <typename T>
-struct DevTemp
-{
-  T * p = nullptr;
-  DevTemp() = default;
-  DevTemp(const DevTemp &) = delete;
-  DevTemp & operator=(const DevTemp &) = delete;
-  ~DevTemp() { dev_free(p); }
-  hipError_t alloc(size_t bytes) { return dev_alloc(&p, bytes ? bytes : 16); }
-  operator T *() const { return p; }
-};
-
-// Growable device buffer
-struct DevBuf
-{
-  void * p = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes, hipStream_t stream, bool keep)
-  {
-    if (bytes <= cap) return hipSuccess;
-    size_t ncap = cap ? cap : 4096;
-    while (ncap < bytes) ncap += ncap / 2 + 4096;
-    void * np = nullptr;
-    hipError_t e = AllocCache::alloc(&np, ncap);
-    if (e != hipSuccess) return e;
-    if (keep && p && cap) {
-      e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream);
-      if (e != hipSuccess) return e;
-      e = hipStreamSynchronize(stream);
-      if (e != hipSuccess) return e;
-    }
-    if (p) AllocCache::free(p);
-    p = np;
-    cap = ncap;
-    return hipSuccess;
-  }
-  void release()
-  {
-    if (p) AllocCache::free(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-}  // namespace
 
 struct mh_map
 {
@@ -507,7 +295,7 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
     for (int i = 0; i < 9; ++i) S[i] = Hrr[i] - tmp2[i];
     mh::mat3_inv(S, Sigma);
     mh::compute_localizability(Sigma, out->degen_rot, out->degen_eigvec_rot);
-    for (int i = 0; i < 3; ++i) out->degen_rot[i] *= 180.0 / M_PI;
+    for (int i = 0; i < 3; ++i) out->degen_rot[i] *= 57.29578;  // RAD2DEG (:428) is PCL's macro: (x)*57.29578
     mh::mat3_inv(Hrr, inv);
     mh::mat3_mul(Htr, inv, tmp);
     mh::mat3_mul(tmp, Hrt, tmp2);
@@ -568,7 +356,7 @@ extern "C" {
 
 int mh_abi_version(void) { return MH_ABI_VERSION; }
 
-const char * mh_last_error(const mh_ctx * ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+const char * mh_last_error(const mh_ctx * ctx) { return ctx ? ctx->err.c_str() : g_mh_err.c_str(); }
 
 int mh_init(int device, mh_ctx ** out)
 {
@@ -1478,16 +1266,6 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
 }  // extern "C"
 
 // ---- device-resident scan front end (scan_kernels.hip) ------------------------------------------
-struct mh_scan
-{
-  mh_ctx * ctx;
-  DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_temp, d_rt;
-  DevBuf d_u32[4];  // flag / pos scratch (prepare_input), keys / flags / pos (unique, down-sampler)
-  DevBuf d_u64[2], d_seg, d_first;
-  mh::ScanCounters c{};
-  size_t n_in = 0, n_body = 0;
-  bool prepared = false, preprocessed = false;
-};
 
 namespace
 {
@@ -1530,6 +1308,7 @@ void mh_scan_destroy(mh_scan * s)
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
+  s->d_full_raw.release();
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
                      &s->d_temp, &s->d_rt, &s->d_u32[0], &s->d_u32[1], &s->d_u32[2], &s->d_u32[3], &s->d_u64[0], &s->d_u64[1],
                      &s->d_seg, &s->d_first})
@@ -1545,7 +1324,7 @@ int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, co
   if (cfg->point_skip_divisor < 1 || cfg->ring_skip_divisor < 1)
     return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: skip divisors must be >= 1");
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  s->prepared = s->preprocessed = false;
+  s->prepared = s->preprocessed = s->raw_valid = false;
   s->n_in = n;
   s->n_body = 0;
   const size_t m = n ? n : 1;
@@ -1595,6 +1374,11 @@ int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
   if (n_groups != s->c.n_unique_ns) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_deskew: one pose per unique timestamp");
   if (s->c.n_full == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->keep_raw && !s->raw_valid) {  // points_raw_ = points_full_ before deskewing (lidar/manager.cpp:376-380)
+    MH_HIP(ctx, s->d_full_raw.reserve(s->c.n_full * sizeof(mh_point32), ctx->stream, false));
+    MH_HIP(ctx, hipMemcpyAsync(s->d_full_raw.p, s->d_full.p, s->c.n_full * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream));
+    s->raw_valid = true;
+  }
   MH_HIP(ctx, s->d_rt.reserve((n_groups + 1) * 12 * sizeof(float), ctx->stream, false));
   MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, Rt12, n_groups * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, mh::launch_deskew(static_cast<mh_point32 *>(s->d_full.p), static_cast<int>(s->c.n_full),

@@ -1,0 +1,240 @@
+// Internals shared by the translation units that implement the C ABI (mh_api.hip, photo_api.hip): the context,
+// error plumbing, the device / pinned allocation cache and the growable device buffer.  Not installed, not part of
+// the boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mimosa_hip.h"
+#include "scan_device.hpp"
+
+inline thread_local std::string g_mh_err;
+constexpr int kMaxPending = 64;
+constexpr int kMaxBatch = 64;  // factors per mh_icp_linearize_batch call
+
+struct mh_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
+  hipEvent_t timer[2] = {nullptr, nullptr};
+  void * h_stage = nullptr;  // pinned staging for map delta records (pageable -> device copies run at a few GB/s)
+  size_t h_stage_cap = 0;
+  void * h_batch = nullptr;  // pinned staging of mh_icp_linearize_batch's argument blocks
+  void * d_batch = nullptr;  // ... and the device copy the batched kernels read
+};
+
+inline int fail(const mh_ctx * ctx, int code, const std::string & msg)
+{
+  g_mh_err = msg;
+  if (ctx) const_cast<mh_ctx *>(ctx)->err = msg;
+  return code;
+}
+inline int hip_fail(const mh_ctx * ctx, hipError_t e, const char * what)
+{
+  const int code = (e == hipErrorOutOfMemory) ? MH_ERR_OOM : (e == hipErrorNoDevice ? MH_ERR_NO_DEVICE : MH_ERR_HIP);
+  return fail(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define MH_HIP(ctx, call)                                   \
+  do {                                                      \
+    const hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
+  } while (0)
+
+// Device / pinned-host allocation cache.  A scan creates a factor (a dozen device buffers, a pinned result
+// ring, sort temporaries) and destroys it a few hundred milliseconds later; hipMalloc / hipFree / hipHostMalloc
+// cost 10-200 us each and hipFree synchronises the device.  Freed blocks of 4 KiB .. 64 MiB are kept per
+// (device, rounded size) and handed out again; the cache holds at most kMaxCachedBytes per device.  A cached
+// free still drains the device first (hipDeviceSynchronize: microseconds when idle), because callers rely on
+// hipFree's implicit "nobody is using this any more".
+class AllocCache
+{
+public:
+  static hipError_t alloc(void ** out, size_t bytes)
+  {
+    const size_t cls = size_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cls) {
+      std::lock_guard<std::mutex> g(mu());
+      auto & v = free_list()[key(dev, cls)];
+      if (!v.empty()) {
+        *out = v.back();
+        v.pop_back();
+        cached_bytes()[dev] -= cls;
+        live()[*out] = cls;
+        return hipSuccess;
+      }
+    }
+    const hipError_t e = hipMalloc(out, cls ? cls : bytes);
+    if (e == hipSuccess && cls) {
+      std::lock_guard<std::mutex> g(mu());
+      live()[*out] = cls;
+    }
+    return e;
+  }
+  static void free(void * p)
+  {
+    if (!p) return;
+    size_t cls = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto it = live().find(p);
+      if (it != live().end()) {
+        cls = it->second;
+        live().erase(it);
+      }
+      if (cls && cached_bytes()[dev] + cls <= kMaxCachedBytes) {
+        // in-flight work may still read / write the block: drain before it can be handed out again
+        (void)hipDeviceSynchronize();
+        free_list()[key(dev, cls)].push_back(p);
+        cached_bytes()[dev] += cls;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  // pinned, mapped result rings (one fixed size)
+  static hipError_t alloc_pinned(void ** out, size_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto & v = pinned()[bytes];
+      if (!v.empty()) {
+        *out = v.back();
+        v.pop_back();
+        return hipSuccess;
+      }
+    }
+    return hipHostMalloc(out, bytes, hipHostMallocMapped);
+  }
+  static void free_pinned(void * p, size_t bytes)
+  {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu());
+    auto & v = pinned()[bytes];
+    if (v.size() < 64) {
+      v.push_back(p);
+      return;
+    }
+    (void)hipHostFree(p);
+  }
+
+private:
+  static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
+  static size_t size_class(size_t bytes)
+  {
+    if (bytes > (size_t(64) << 20)) return 0;  // big (map-sized) blocks are not cached
+    size_t c = 4096;
+    while (c < bytes) c += c / 2 >= 4096 ? (c / 4) : c;  // 4K, 8K, 16K, 20K, 25K, ... (~25 % steps)
+    return c;
+  }
+  static uint64_t key(int dev, size_t cls) { return (static_cast<uint64_t>(dev) << 56) | cls; }
+  static std::mutex & mu()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static std::unordered_map<uint64_t, std::vector<void *>> & free_list()
+  {
+    static std::unordered_map<uint64_t, std::vector<void *>> m;
+    return m;
+  }
+  static std::unordered_map<void *, size_t> & live()
+  {
+    static std::unordered_map<void *, size_t> m;
+    return m;
+  }
+  static std::unordered_map<int, size_t> & cached_bytes()
+  {
+    static std::unordered_map<int, size_t> m;
+    return m;
+  }
+  static std::unordered_map<size_t, std::vector<void *>> & pinned()
+  {
+    static std::unordered_map<size_t, std::vector<void *>> m;
+    return m;
+  }
+};
+
+template <typename T>
+inline hipError_t dev_alloc(T ** out, size_t bytes)
+{
+  void * p = nullptr;
+  const hipError_t e = AllocCache::alloc(&p, bytes);
+  *out = static_cast<T *>(p);
+  return e;
+}
+inline void dev_free(void * p) { AllocCache::free(p); }
+
+// Scoped device temporary: released (back to the cache) on every exit path, including the early returns of MH_HIP.
+template <typename T>
+struct DevTemp
+{
+  T * p = nullptr;
+  DevTemp() = default;
+  DevTemp(const DevTemp &) = delete;
+  DevTemp & operator=(const DevTemp &) = delete;
+  ~DevTemp() { dev_free(p); }
+  hipError_t alloc(size_t bytes) { return dev_alloc(&p, bytes ? bytes : 16); }
+  operator T *() const { return p; }
+};
+
+// Growable device buffer
+struct DevBuf
+{
+  void * p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes, hipStream_t stream, bool keep)
+  {
+    if (bytes <= cap) return hipSuccess;
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < bytes) ncap += ncap / 2 + 4096;
+    void * np = nullptr;
+    hipError_t e = AllocCache::alloc(&np, ncap);
+    if (e != hipSuccess) return e;
+    if (keep && p && cap) {
+      e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) {
+        AllocCache::free(np);
+        return e;
+      }
+    }
+    if (p) AllocCache::free(p);
+    p = np;
+    cap = ncap;
+    return hipSuccess;
+  }
+  void release()
+  {
+    if (p) AllocCache::free(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// device-resident scan front end (mh_scan_*): state of one scan
+struct mh_scan
+{
+  mh_ctx * ctx;
+  DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_temp, d_rt;
+  DevBuf d_full_raw;  // points_raw_ (lidar/manager.cpp:376-380): points_full_ as it was before deskewing, kept for the photometric path
+  bool keep_raw = false, raw_valid = false;
+  DevBuf d_u32[4];  // flag / pos scratch (prepare_input), keys / flags / pos (unique, down-sampler)
+  DevBuf d_u64[2], d_seg, d_first;
+  mh::ScanCounters c{};
+  size_t n_in = 0, n_body = 0;
+  bool prepared = false, preprocessed = false;
+};

@@ -1,0 +1,1043 @@
+// C ABI of the photometric path (include/mimosa_hip.h: mh_photo_*): lidar::Photometric and PhotometricFactor.
+//
+// Reference: src/lidar/photometric.cpp (preprocess :92-320, createMask :349-371, updateMap :396-514, detectFeatures
+// :516-745), include/mimosa/lidar/photometric_factor.hpp:136-355, src/lidar/photometric_utils.cpp.
+// Device work is in photo_kernels.hip; what stays on the host here is what the reference does sequentially on a few
+// hundred elements: the std::sort + greedy non-maximum suppression of detectFeatures, the per-candidate 2 x 2
+// structure-tensor eigenvector, the plane check of a new feature, and the 6 x 6 epilogue of the unary factor.
+// There is no CPU fallback: every entry point needs the context's HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "math3.hpp"
+#include "mh_internal.hpp"
+#include "photo_device.hpp"
+
+namespace
+{
+struct PhotoFrame  // include/mimosa/lidar/photometric_utils.hpp:42-92, shared_ptr semantics by `refs`
+{
+  std::atomic<int> refs{1};
+  mh_ctx * ctx = nullptr;
+  int rows = 0, cols = 0, n_poses = 0;
+  size_t n_points = 0;
+  DevBuf d_points, d_intensity, d_range, d_dx, d_dy, d_mask, d_idx, d_proj, d_yaw, d_pose_ns, d_pose_Rt;
+  void release_buffers()
+  {
+    for (DevBuf * b : {&d_points, &d_intensity, &d_range, &d_dx, &d_dy, &d_mask, &d_idx, &d_proj, &d_yaw, &d_pose_ns, &d_pose_Rt})
+      b->release();
+  }
+};
+
+void frame_release(PhotoFrame * f)
+{
+  if (!f) return;
+  if (f->refs.fetch_sub(1) == 1) {
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    f->release_buffers();
+    delete f;
+  }
+}
+
+struct HostFeature
+{
+  mh_photo_feature hdr{};
+  std::vector<double> Le_ps, intensities, psi;
+};
+
+template <typename E>
+int guarded(mh_ctx * ctx, const char * what, E && body)
+{
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, MH_ERR_OOM, std::string(what) + ": host allocation failed");
+  } catch (const std::exception & e) {
+    return fail(ctx, MH_ERR_HIP, std::string(what) + ": " + e.what());
+  } catch (...) {
+    return fail(ctx, MH_ERR_HIP, std::string(what) + ": unknown exception");
+  }
+}
+}  // namespace
+
+struct mh_photo
+{
+  mh_ctx * ctx = nullptr;
+  std::atomic<int> refs{1};
+  mh_photo_config cfg{};  // scalar fields; the pointer members are re-pointed at the copies below
+  std::vector<int32_t> shift, offsets;
+  std::vector<float> alt, hp_f, lp_f;
+  std::vector<uint8_t> static_mask;
+  mh::PhotoModel model{};
+  DevBuf d_alt, d_shift, d_hp, d_lp, d_static;
+  // per-frame scratch
+  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz;
+  mh::PhotoCounters * h_counters = nullptr;  // pinned, mapped
+  mh::PhotoCounters * d_counters = nullptr;
+  float * h_int_out = nullptr;  // pinned staging of the corrected intensities
+  size_t h_int_cap = 0;
+  PhotoFrame * frame = nullptr;
+  std::vector<HostFeature> features;  // map_Le_features_
+  uint32_t next_id = 0;               // monotonic_feature_id_
+};
+
+struct mh_photo_factor
+{
+  mh_photo * photo = nullptr;
+  PhotoFrame * frame = nullptr;
+  bool binary = false;
+  double VSVt[36];
+  std::vector<HostFeature> features;  // a_features_
+  DevBuf d_Le, d_psi, d_npts, d_status, d_centers, d_partials, d_rows;
+  std::vector<int32_t> statuses;
+  std::vector<double> centers, partials, rows;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace
+{
+void photo_release(mh_photo * p)
+{
+  if (!p) return;
+  if (p->refs.fetch_sub(1) != 1) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  frame_release(p->frame);
+  for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
+                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz})
+    b->release();
+  if (p->h_counters) (void)hipHostFree(p->h_counters);
+  if (p->h_int_out) (void)hipHostFree(p->h_int_out);
+  delete p;
+}
+
+// cv::circle(mask, centre, radius, 0, -1): the midpoint-circle spans of OpenCV's drawing.cpp Circle() (assumption O10)
+void fill_circle_zero(std::vector<uint8_t> & img, int rows, int cols, int cx, int cy, int radius)
+{
+  auto hline = [&](int y, int x0, int x1) {
+    if (y < 0 || y >= rows) return;
+    x0 = std::max(x0, 0);
+    x1 = std::min(x1, cols - 1);
+    for (int x = x0; x <= x1; ++x) img[static_cast<size_t>(y) * cols + x] = 0;
+  };
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    hline(cy - dy, cx - dx, cx + dx);
+    hline(cy + dy, cx - dx, cx + dx);
+    hline(cy - dx, cx - dy, cx + dy);
+    hline(cy + dx, cx - dy, cx + dy);
+    dy++;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
+// centre value of cv::cornerEigenValsAndVecs(roi, 5, 3) (assumption O11) -> eigenvector of the larger eigenvalue
+void patch_gradient_direction(const float * I, int cols, int x, int y, float & ix, float & iy)
+{
+  const float scale = static_cast<float>(1.0 / (4.0 * 5.0));
+  float a = 0, b = 0, c = 0;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {
+      const float * p = I + static_cast<size_t>(y + dy) * cols + (x + dx);
+      const float tl = p[-cols - 1], tc = p[-cols], tr = p[-cols + 1], ml = p[-1], mr = p[1], bl = p[cols - 1], bc = p[cols], br = p[cols + 1];
+      const float gx = ((tr - tl) + 2.f * (mr - ml) + (br - bl)) * scale;
+      const float gy = ((bl - tl) + 2.f * (bc - tc) + (br - tr)) * scale;
+      a += gx * gx;
+      b += gx * gy;
+      c += gy * gy;
+    }
+  auto eigvec = [&](double l, float & ex, float & ey) {
+    double xx = b, yy = l - a, e = std::fabs(xx);
+    if (e + std::fabs(yy) < 1e-4) {
+      yy = b;
+      xx = l - c;
+      e = std::fabs(xx);
+      if (e + std::fabs(yy) < 1e-4) {
+        e = 1. / (e + std::fabs(yy) + FLT_EPSILON);
+        xx *= e;
+        yy *= e;
+      }
+    }
+    const double d = 1. / std::sqrt(xx * xx + yy * yy + DBL_EPSILON);
+    ex = static_cast<float>(xx * d);
+    ey = static_cast<float>(yy * d);
+  };
+  const double u = (a + c) * 0.5, v = std::sqrt((a - c) * (a - c) * 0.25 + static_cast<double>(b) * b);
+  const float e1 = static_cast<float>(u + v), e2 = static_cast<float>(u - v);
+  float x1, y1, x2, y2;
+  eigvec(u + v, x1, y1);
+  eigvec(u - v, x2, y2);
+  ix = e1 > e2 ? x1 : x2;
+  iy = e1 > e2 ? y1 : y2;
+}
+
+void projection_jacobian(const mh::PhotoModel & m, double x, double y, double z, double H[6])  // photometric_utils.cpp:186-198
+{
+  const double rxy = std::sqrt(x * x + y * y);
+  const double L = rxy - m.beam_offset_m;
+  const double R2 = L * L + z * z;
+  const double irxy = 1.0 / rxy;
+  const double fx_irxy2 = m.fx * (irxy * irxy);
+  H[0] = -fx_irxy2 * y;
+  H[1] = fx_irxy2 * x;
+  H[2] = 0;
+  H[3] = -m.fy * x * z / ((L + m.beam_offset_m) * R2);
+  H[4] = -m.fy * y * z / ((L + m.beam_offset_m) * R2);
+  H[5] = m.fy * L / R2;
+}
+
+void get_psi(const std::vector<double> & I, double & mean, double & sigma, std::vector<double> & psi)  // photometric_utils.cpp:13-19
+{
+  double s = 0;
+  for (double v : I) s += v;
+  mean = s / static_cast<double>(I.size());
+  double ss = 0;
+  for (double v : I) ss += (v - mean) * (v - mean);
+  sigma = std::sqrt(ss);
+  psi.resize(I.size());
+  for (size_t i = 0; i < I.size(); ++i) psi[i] = (I[i] - mean) / sigma;
+}
+
+struct Pose
+{
+  double R[9], t[3];
+};
+Pose pose_mul(const Pose & a, const Pose & b)
+{
+  Pose r;
+  mh::mat3_mul(a.R, b.R, r.R);
+  for (int i = 0; i < 3; ++i) r.t[i] = a.t[i] + (a.R[3 * i] * b.t[0] + (a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2]));
+  return r;
+}
+Pose pose_inv(const Pose & a)
+{
+  Pose r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.R[3 * i + j] = a.R[3 * j + i];
+  for (int i = 0; i < 3; ++i) r.t[i] = -(r.R[3 * i] * a.t[0] + (r.R[3 * i + 1] * a.t[1] + r.R[3 * i + 2] * a.t[2]));
+  return r;
+}
+void pose_act(const Pose & a, const double p[3], double o[3])
+{
+  for (int i = 0; i < 3; ++i) o[i] = (a.R[3 * i] * p[0] + (a.R[3 * i + 1] * p[1] + a.R[3 * i + 2] * p[2])) + a.t[i];
+}
+
+bool mat6_inv(const double * A, double * inv)  // M66::inverse() (Eigen: partial-pivoting LU)
+{
+  double a[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      a[i][j] = A[6 * i + j];
+      a[i][6 + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+    if (p != c)
+      for (int j = 0; j < 12; ++j) std::swap(a[p][j], a[c][j]);
+    const double d = a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] /= d;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double mlt = a[r][c];
+      for (int j = 0; j < 12; ++j) a[r][j] -= mlt * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) inv[6 * i + j] = a[i][6 + j];
+  return true;
+}
+void mat6_mul(const double * A, const double * B, double * C)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += A[6 * i + k] * B[6 * k + j];
+      C[6 * i + j] = s;
+    }
+}
+
+int upload(mh_ctx * ctx, DevBuf & b, const void * src, size_t bytes)
+{
+  MH_HIP(ctx, b.reserve(bytes ? bytes : 16, ctx->stream, false));
+  if (bytes) MH_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return MH_OK;
+}
+
+// The device part of preprocess on points already resident (d_raw / frame->d_points), then the pose table.
+int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, size_t n, const uint32_t * unique_ns,
+                      const double * T_Le_Lt, size_t n_groups)
+{
+  mh_ctx * ctx = ph->ctx;
+  const mh::PhotoModel & m = ph->model;
+  const int rows = m.rows, cols = m.cols, npx = rows * cols;
+  const size_t fb = static_cast<size_t>(npx) * sizeof(float);
+  for (DevBuf * b : {&fr->d_intensity, &fr->d_range, &fr->d_dx, &fr->d_dy, &fr->d_yaw, &ph->d_img_raw, &ph->d_tmp_a, &ph->d_tmp_b})
+    MH_HIP(ctx, b->reserve(fb, ctx->stream, false));
+  MH_HIP(ctx, fr->d_idx.reserve(static_cast<size_t>(npx) * sizeof(int32_t), ctx->stream, false));
+  MH_HIP(ctx, fr->d_proj.reserve(static_cast<size_t>(npx) * mh::kPhotoDup * sizeof(int32_t), ctx->stream, false));
+  MH_HIP(ctx, fr->d_mask.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, ph->d_mask_raw.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, ph->d_yaw_valid.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, ph->d_int_out.reserve((n ? n : 1) * sizeof(float), ctx->stream, false));
+  int rc = upload(ctx, fr->d_pose_ns, unique_ns, n_groups * sizeof(uint32_t));
+  if (rc != MH_OK) return rc;
+  rc = upload(ctx, fr->d_pose_Rt, T_Le_Lt, n_groups * 12 * sizeof(double));
+  if (rc != MH_OK) return rc;
+  fr->n_poses = static_cast<int>(n_groups);
+  fr->rows = rows;
+  fr->cols = cols;
+  fr->n_points = n;
+  auto * desk = static_cast<mh_point32 *>(fr->d_points.p);
+  float * img_raw = static_cast<float *>(ph->d_img_raw.p);
+  MH_HIP(ctx, hipMemsetAsync(img_raw, 0, fb, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fr->d_range.p, 0, fb, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(ph->d_mask_raw.p, 0, npx, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(ph->d_yaw_valid.p, 0, npx, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fr->d_idx.p, 0xFF, static_cast<size_t>(npx) * sizeof(int32_t), ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fr->d_proj.p, 0x7F, static_cast<size_t>(npx) * mh::kPhotoDup * sizeof(int32_t), ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(ph->d_int_out.p, 0xFF, (n ? n : 1) * sizeof(float), ctx->stream));  // NaN = "this point owns no pixel"
+  ph->h_counters->project_throw = ph->h_counters->pose_missing = 0;
+  const int ni = static_cast<int>(n);
+  MH_HIP(ctx, mh::launch_photo_scatter(m, d_raw, desk, ni, static_cast<float *>(fr->d_yaw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
+                                       img_raw, static_cast<float *>(fr->d_range.p), static_cast<uint8_t *>(ph->d_mask_raw.p),
+                                       static_cast<int32_t *>(fr->d_idx.p), ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_yaw_fill(m, static_cast<float *>(fr->d_yaw.p), static_cast<const uint8_t *>(ph->d_yaw_valid.p), ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_project(m, desk, ni, static_cast<const float *>(fr->d_yaw.p), static_cast<int32_t *>(fr->d_proj.p),
+                                       ph->d_counters, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_proj_finalize(npx, static_cast<int32_t *>(fr->d_proj.p), ctx->stream));
+  // filter chain (photometric.cpp:246-300)
+  const mh_photo_config & c = ph->cfg;
+  const float scale = static_cast<float>(static_cast<double>(c.intensity_scale)), gamma = c.intensity_gamma;
+  float * ta = static_cast<float *>(ph->d_tmp_a.p);
+  float * tb = static_cast<float *>(ph->d_tmp_b.p);
+  const float * cur;
+  if (c.remove_lines) {
+    MH_HIP(ctx, mh::launch_photo_vfir(img_raw, ta, rows, cols, static_cast<const float *>(ph->d_hp.p), c.n_high_pass, scale, gamma, ctx->stream));
+    MH_HIP(ctx, mh::launch_photo_hfir_sub(ta, img_raw, tb, rows, cols, static_cast<const float *>(ph->d_lp.p), c.n_low_pass, scale, gamma,
+                                          ctx->stream));
+    cur = tb;
+  } else {
+    MH_HIP(ctx, mh::launch_photo_scale(img_raw, tb, npx, scale, gamma, ctx->stream));
+    cur = tb;
+  }
+  if (c.filter_brightness) {
+    MH_HIP(ctx, mh::launch_photo_brightness(cur, ta, rows, cols, c.brightness_window_size[0], c.brightness_window_size[1], ctx->stream));
+    cur = ta;
+  }
+  float * fin = static_cast<float *>(fr->d_intensity.p);
+  MH_HIP(ctx, mh::launch_photo_gauss_trunc(cur, fin, rows, cols, c.gaussian_blur ? 1 : 0, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_sobel_writeback(fin, static_cast<float *>(fr->d_dx.p), static_cast<float *>(fr->d_dy.p),
+                                               static_cast<const int32_t *>(fr->d_idx.p), nullptr, static_cast<float *>(ph->d_int_out.p),
+                                               rows, cols, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(ph->d_mask_raw.p),
+                                     ph->static_mask.empty() ? nullptr : static_cast<const uint8_t *>(ph->d_static.p), -1,
+                                     static_cast<uint8_t *>(fr->d_mask.p), rows, cols, c.patch_size + c.erosion_buffer, ctx->stream));
+  return MH_OK;
+}
+
+int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3], const double * bias,
+                         size_t n_dirs)
+{
+  if (num_to_detect <= 0) return MH_OK;  // photometric.cpp:522
+  mh_ctx * ctx = ph->ctx;
+  PhotoFrame * fr = ph->frame;
+  if (!fr) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_detect_features: no frame (call mh_photo_preprocess first)");
+  const mh_photo_config & c = ph->cfg;
+  const int rows = c.rows, cols = c.cols, npx = rows * cols;
+  // per-pixel part on the device: gradient magnitude, detection mask = erode(img_mask & mask_margin_)
+  MH_HIP(ctx, ph->d_grad.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, ph->d_detmask.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, mh::launch_photo_grad(static_cast<const float *>(fr->d_dx.p), static_cast<const float *>(fr->d_dy.p),
+                                    static_cast<uint8_t *>(ph->d_grad.p), npx, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(fr->d_mask.p), nullptr, c.margin_size, static_cast<uint8_t *>(ph->d_detmask.p),
+                                     rows, cols, c.patch_size + c.erosion_buffer, ctx->stream));
+  std::vector<uint8_t> grad(npx), mask(npx);
+  std::vector<float> I(npx);
+  std::vector<int32_t> idx(npx);
+  std::vector<mh_point32> pts(fr->n_points);
+  MH_HIP(ctx, hipMemcpyAsync(grad.data(), ph->d_grad.p, npx, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(mask.data(), ph->d_detmask.p, npx, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(I.data(), fr->d_intensity.p, static_cast<size_t>(npx) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(idx.data(), fr->d_idx.p, static_cast<size_t>(npx) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (fr->n_points)
+    MH_HIP(ctx, hipMemcpyAsync(pts.data(), fr->d_points.p, fr->n_points * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  for (const HostFeature & ft : ph->features)  // :526-530
+    fill_circle_zero(mask, rows, cols, static_cast<int>(ft.hdr.center[0]), static_cast<int>(ft.hdr.center[1]), c.nma_radius);
+  struct Cand
+  {
+    double g;
+    int u, v;
+  };
+  std::vector<Cand> gradients;
+  gradients.reserve(static_cast<size_t>(npx));
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u) {
+      const size_t px = static_cast<size_t>(v) * cols + u;
+      if (!mask[px]) continue;
+      if (grad[px] > c.gradient_threshold) gradients.push_back({static_cast<double>(grad[px]), u, v});
+    }
+  // :556-560 — std::sort with a comparator on the gradient only: the order of equal gradients is libstdc++'s
+  std::sort(gradients.begin(), gradients.end(), [](const Cand & a, const Cand & b) { return a.g > b.g; });
+  std::vector<std::pair<int, int>> cand;
+  for (const Cand & g : gradients) {  // :565-571 non-maximum suppression
+    if (!mask[static_cast<size_t>(g.v) * cols + g.u]) continue;
+    cand.emplace_back(g.u, g.v);
+    fill_circle_zero(mask, rows, cols, g.u, g.v, c.nma_radius);
+  }
+  // :575-625 scores of every candidate along every bias direction
+  std::vector<std::vector<std::pair<double, int>>> scores(n_dirs, std::vector<std::pair<double, int>>(cand.size(), {0.0, 0}));
+  for (size_t i = 0; i < cand.size(); ++i) {
+    float ix, iy;
+    patch_gradient_direction(I.data(), cols, cand[i].first, cand[i].second, ix, iy);
+    const int pidx = idx[static_cast<size_t>(cand[i].second) * cols + cand[i].first];
+    if (pidx < 0) continue;
+    double P[6];
+    projection_jacobian(ph->model, pts[pidx].x, pts[pidx].y, pts[pidx].z, P);
+    for (size_t b = 0; b < n_dirs; ++b) {
+      const double * d = bias + 3 * b;
+      double w0 = P[0] * d[0] + P[1] * d[1] + P[2] * d[2], w1 = P[3] * d[0] + P[4] * d[1] + P[5] * d[2];
+      const double nn = std::sqrt(w0 * w0 + w1 * w1);
+      if (nn > 0) {
+        w0 /= nn;
+        w1 /= nn;
+      }
+      scores[b][i] = {std::fabs(ix * w0 + iy * w1), static_cast<int>(i)};
+    }
+  }
+  for (size_t b = 0; b < n_dirs; ++b)
+    std::sort(scores[b].begin(), scores[b].end(), [](const std::pair<double, int> & a, const std::pair<double, int> & bb) { return a.first > bb.first; });
+  std::vector<int> selected;  // :639-651 round-robin over the directions
+  if (n_dirs)
+    for (size_t i = 0; i < scores[0].size(); ++i)
+      for (size_t b = 0; b < n_dirs; ++b) {
+        const int k = scores[b][i].second;
+        if (std::find(selected.begin(), selected.end(), k) == selected.end()) selected.push_back(k);
+      }
+  Pose TBL, TWB;
+  std::memcpy(TBL.R, c.T_B_L_R, sizeof(TBL.R));
+  std::memcpy(TBL.t, c.T_B_L_t, sizeof(TBL.t));
+  std::memcpy(TWB.R, R_W_Be, sizeof(TWB.R));
+  std::memcpy(TWB.t, t_W_Be, sizeof(TWB.t));
+  const Pose T_map = pose_mul(pose_mul(pose_inv(TBL), TWB), TBL);  // :666-667
+  int num_added = 0;
+  for (const int k : selected) {
+    const int lx = cand[k].first, ly = cand[k].second;
+    HostFeature ft;
+    ft.hdr.id = ph->next_id++;
+    ft.hdr.life_time = 1;
+    ft.hdr.center[0] = lx;
+    ft.hdr.center[1] = ly;
+    const int m = c.n_patch_offsets;
+    ft.hdr.n_points = m;
+    bool missing = false;
+    for (int o = 0; o < m; ++o) {
+      const int u = lx + ph->offsets[2 * o], v = ly + ph->offsets[2 * o + 1];
+      const int pi = (u >= 0 && u < cols && v >= 0 && v < rows) ? idx[static_cast<size_t>(v) * cols + u] : -1;
+      if (pi < 0) {  // the reference indexes the cloud with -1 here (undefined behaviour); the eroded mask makes it unreachable
+        missing = true;
+        break;
+      }
+      const double q[3] = {pts[pi].x, pts[pi].y, pts[pi].z};
+      double w[3];
+      pose_act(T_map, q, w);
+      ft.Le_ps.insert(ft.Le_ps.end(), {w[0], w[1], w[2]});
+      ft.intensities.push_back(I[static_cast<size_t>(v) * cols + u]);
+    }
+    if (missing) continue;
+    double mean[3] = {0, 0, 0};
+    for (int i = 0; i < m; ++i)
+      for (int a = 0; a < 3; ++a) mean[a] += ft.Le_ps[3 * i + a];
+    for (double & v : mean) v /= static_cast<double>(m);
+    bool far = false;
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < m; ++i) {
+      const double d[3] = {ft.Le_ps[3 * i] - mean[0], ft.Le_ps[3 * i + 1] - mean[1], ft.Le_ps[3 * i + 2] - mean[2]};
+      if (std::sqrt(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])) > c.max_dist_from_mean) far = true;
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) cov[3 * r + cc] += d[r] * d[cc];
+    }
+    if (far) continue;  // :685-687
+    for (double & v : cov) v /= static_cast<double>(m - 1);
+    double ev[3], E[9];
+    mh::sym_eigen3(cov, ev, E);
+    double nrm[3] = {E[0], E[3], E[6]};  // eigenvectors().col(0)
+    bool off_plane = false;
+    for (int i = 0; i < m; ++i) {
+      const double d = (ft.Le_ps[3 * i] - mean[0]) * nrm[0] + ((ft.Le_ps[3 * i + 1] - mean[1]) * nrm[1] + (ft.Le_ps[3 * i + 2] - mean[2]) * nrm[2]);
+      if (std::fabs(d) > c.max_dist_from_plane) off_plane = true;
+    }
+    if (off_plane) continue;  // :694-696
+    const double mn = std::sqrt(mean[0] * mean[0] + (mean[1] * mean[1] + mean[2] * mean[2]));
+    if ((nrm[0] * mean[0] + (nrm[1] * mean[1] + nrm[2] * mean[2])) / mn > 0)
+      for (double & v : nrm) v = -v;  // :699-701 the normal points towards the sensor
+    std::memcpy(ft.hdr.normal, nrm, sizeof(nrm));
+    get_psi(ft.intensities, ft.hdr.mean_intensity, ft.hdr.sigma_intensity, ft.psi);
+    ph->features.push_back(std::move(ft));
+    num_added++;
+    if (num_added >= num_to_detect) break;
+  }
+  return MH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out)
+{
+  if (!ctx || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: NULL argument");
+  *out = nullptr;
+  return guarded(ctx, "mh_photo_create", [&]() -> int {
+    if (cfg->rows < 1 || cfg->cols < 16 || cfg->cols > 4096) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: rows >= 1, 16 <= cols <= 4096");
+    if (!cfg->pixel_shift_by_row || !cfg->beam_altitude_angles) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: NULL table");
+    if (cfg->rows < 2) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: at least two beams");
+    if (cfg->n_patch_offsets < 2 || cfg->n_patch_offsets > mh::kPhotoMaxPatch || !cfg->patch_offsets)
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: 2..64 patch offsets");
+    if (cfg->rotate_patch_to_align_with_gradient)
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: rotate_patch_to_align_with_gradient is not supported (false in every shipped configuration)");
+    if (cfg->remove_lines && (cfg->n_high_pass < 1 || cfg->n_low_pass < 1 || cfg->n_high_pass > mh::kPhotoMaxTaps || cfg->n_low_pass > mh::kPhotoMaxTaps ||
+                              !(cfg->n_high_pass & 1) || !(cfg->n_low_pass & 1) || !cfg->high_pass_fir || !cfg->low_pass_fir))
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: FIR kernels must have an odd length <= 129");
+    if (cfg->gaussian_blur && cfg->gaussian_blur_size != 3) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: gaussian_blur_size must be 3");
+    if (cfg->filter_brightness && (cfg->brightness_window_size[0] < 1 || cfg->brightness_window_size[0] > 63 || cfg->brightness_window_size[1] < 1 ||
+                                   cfg->brightness_window_size[1] > 31))
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: brightness window up to 63 x 31");
+    const int ek = cfg->patch_size + cfg->erosion_buffer;
+    if (ek < 1 || ek > 33) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: patch_size + erosion_buffer must be in 1..33");
+    if (!(cfg->range_min < cfg->range_max)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: range_min < range_max");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    mh_photo * p = new mh_photo;
+    p->ctx = ctx;
+    p->cfg = *cfg;
+    p->shift.assign(cfg->pixel_shift_by_row, cfg->pixel_shift_by_row + cfg->rows);
+    p->alt.assign(cfg->beam_altitude_angles, cfg->beam_altitude_angles + cfg->rows);
+    p->offsets.assign(cfg->patch_offsets, cfg->patch_offsets + 2 * cfg->n_patch_offsets);
+    if (cfg->remove_lines) {
+      for (int i = 0; i < cfg->n_high_pass; ++i) p->hp_f.push_back(static_cast<float>(cfg->high_pass_fir[i]));  // O2: kernel in the float working type
+      for (int i = 0; i < cfg->n_low_pass; ++i) p->lp_f.push_back(static_cast<float>(cfg->low_pass_fir[i]));
+    }
+    if (cfg->static_mask) p->static_mask.assign(cfg->static_mask, cfg->static_mask + static_cast<size_t>(cfg->rows) * cfg->cols);
+    p->cfg.pixel_shift_by_row = p->shift.data();
+    p->cfg.beam_altitude_angles = p->alt.data();
+    p->cfg.patch_offsets = p->offsets.data();
+    p->cfg.high_pass_fir = p->cfg.low_pass_fir = nullptr;
+    p->cfg.static_mask = nullptr;
+    int rc = upload(ctx, p->d_alt, p->alt.data(), p->alt.size() * sizeof(float));
+    if (rc == MH_OK) rc = upload(ctx, p->d_shift, p->shift.data(), p->shift.size() * sizeof(int32_t));
+    if (rc == MH_OK) rc = upload(ctx, p->d_hp, p->hp_f.data(), p->hp_f.size() * sizeof(float));
+    if (rc == MH_OK) rc = upload(ctx, p->d_lp, p->lp_f.data(), p->lp_f.size() * sizeof(float));
+    if (rc == MH_OK) rc = upload(ctx, p->d_static, p->static_mask.data(), p->static_mask.size());
+    hipError_t e = hipSuccess;
+    if (rc == MH_OK) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_counters), sizeof(mh::PhotoCounters), hipHostMallocMapped);
+    if (rc == MH_OK && e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_counters), p->h_counters, 0);
+    if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (rc != MH_OK || e != hipSuccess) {
+      photo_release(p);
+      return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_create");
+    }
+    std::memset(p->h_counters, 0, sizeof(*p->h_counters));
+    // derived parameters (photometric_config.cpp:98-110); DEG2RAD is PCL's macro (x * 0.017453293)
+    mh::PhotoModel & m = p->model;
+    m.rows = cfg->rows;
+    m.cols = cfg->cols;
+    m.destagger = cfg->destagger;
+    m.fx = -static_cast<float>(cfg->cols) / (2 * M_PI);
+    m.cx = static_cast<float>(cfg->cols) / 2.0;
+    m.fy = -static_cast<float>(cfg->rows) / std::fabs(static_cast<double>(p->alt.front() - p->alt.back()) * 0.017453293);
+    m.beam_offset_m = static_cast<float>(cfg->lidar_origin_to_beam_origin_mm / 1000.0);
+    m.range_min = cfg->range_min;
+    m.range_max = cfg->range_max;
+    m.alt_first = p->alt.front();
+    m.alt_last = p->alt.back();
+    m.margin_size = cfg->margin_size;
+    m.occlusion_range_diff_threshold = cfg->occlusion_range_diff_threshold;
+    m.alt = static_cast<const float *>(p->d_alt.p);
+    m.pixel_shift = static_cast<const int *>(p->d_shift.p);
+    *out = p;
+    return MH_OK;
+  });
+}
+
+void mh_photo_destroy(mh_photo * photo) { photo_release(photo); }
+
+int mh_scan_keep_raw(mh_scan * scan, int keep)
+{
+  if (!scan) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_scan_keep_raw: scan is NULL");
+  scan->keep_raw = keep != 0;
+  return MH_OK;
+}
+
+static int photo_finish_preprocess(mh_photo * photo, PhotoFrame * fr, mh_point32 * host_desk, size_t n)
+{
+  mh_ctx * ctx = photo->ctx;
+  // corrected intensities back into the caller's cloud (:307-314)
+  if (host_desk && n) {
+    if (photo->h_int_cap < n) {
+      if (photo->h_int_out) (void)hipHostFree(photo->h_int_out);
+      photo->h_int_out = nullptr;
+      photo->h_int_cap = 0;
+      MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&photo->h_int_out), (n + n / 2) * sizeof(float), hipHostMallocDefault));
+      photo->h_int_cap = n + n / 2;
+    }
+    MH_HIP(ctx, hipMemcpyAsync(photo->h_int_out, photo->d_int_out.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (photo->h_counters->project_throw) {
+    frame_release(fr);
+    return fail(ctx, MH_ERR_INVALID_ARG,
+                "mh_photo_preprocess: project(): invalid x coordinate for a deskewed point (the reference throws, photometric_utils.cpp:90-97)");
+  }
+  frame_release(photo->frame);
+  photo->frame = fr;
+  return MH_OK;
+}
+
+int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_point32 * points_deskewed, size_t n,
+                        const uint32_t * unique_ns, const double * T_Le_Lt, size_t n_groups)
+{
+  if (!photo || (n && (!points_raw || !points_deskewed)) || (n_groups && (!unique_ns || !T_Le_Lt)))
+    return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_preprocess: NULL argument");
+  mh_ctx * ctx = photo->ctx;
+  return guarded(ctx, "mh_photo_preprocess", [&]() -> int {
+    if (n > static_cast<size_t>(photo->cfg.rows) * photo->cfg.cols)
+      return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess: number of points exceeds the image size (photometric.cpp:103-110)");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    PhotoFrame * fr = new PhotoFrame;
+    fr->ctx = ctx;
+    const size_t pb = (n ? n : 1) * sizeof(mh_point32);
+    hipError_t e = fr->d_points.reserve(pb, ctx->stream, false);
+    if (e == hipSuccess) e = photo->d_raw_pts.reserve(pb, ctx->stream, false);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(photo->d_raw_pts.p, points_raw, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(fr->d_points.p, points_deskewed, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      frame_release(fr);
+      return hip_fail(ctx, e, "mh_photo_preprocess: upload");
+    }
+    int rc = preprocess_device(photo, fr, static_cast<const mh_point32 *>(photo->d_raw_pts.p), n, unique_ns, T_Le_Lt, n_groups);
+    if (rc != MH_OK) {
+      frame_release(fr);
+      return rc;
+    }
+    rc = photo_finish_preprocess(photo, fr, points_deskewed, n);
+    if (rc != MH_OK) return rc;
+    // the Frame keeps the cloud as it was handed over; the corrected intensities go to the caller's copy only (:115-116, :307-314)
+    for (size_t i = 0; i < n; ++i) {
+      const float v = photo->h_int_out[i];
+      if (v == v) points_deskewed[i].intensity = v;  // NaN = "no pixel"
+    }
+    return MH_OK;
+  });
+}
+
+int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups)
+{
+  if (!photo || !scan || (n_groups && !T_Le_Lt))
+    return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: NULL argument");
+  mh_ctx * ctx = photo->ctx;
+  return guarded(ctx, "mh_photo_preprocess_scan", [&]() -> int {
+    if (scan->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: scan lives on another device");
+    if (!scan->prepared) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: no mh_scan_prepare_input before");
+    if (!scan->raw_valid) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: call mh_scan_keep_raw(scan, 1) before mh_scan_deskew");
+    if (n_groups != scan->c.n_unique_ns) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: one pose per unique timestamp");
+    const size_t n = scan->c.n_full;
+    if (n > static_cast<size_t>(photo->cfg.rows) * photo->cfg.cols)
+      return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: number of points exceeds the image size");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    if (scan->ctx != ctx) MH_HIP(ctx, hipStreamSynchronize(scan->ctx->stream));
+    PhotoFrame * fr = new PhotoFrame;
+    fr->ctx = ctx;
+    hipError_t e = fr->d_points.reserve((n ? n : 1) * sizeof(mh_point32), ctx->stream, false);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(fr->d_points.p, scan->d_full.p, n * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      frame_release(fr);
+      return hip_fail(ctx, e, "mh_photo_preprocess_scan: frame copy");
+    }
+    std::vector<uint32_t> uns(n_groups);
+    if (n_groups) MH_HIP(ctx, hipMemcpyAsync(uns.data(), scan->d_unique.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = preprocess_device(photo, fr, static_cast<const mh_point32 *>(scan->d_full_raw.p), n, uns.data(), T_Le_Lt, n_groups);
+    if (rc != MH_OK) {
+      frame_release(fr);
+      return rc;
+    }
+    // corrected intensities into the scan's resident cloud
+    if (n) MH_HIP(ctx, mh::launch_photo_sobel_writeback(static_cast<const float *>(fr->d_intensity.p), static_cast<float *>(fr->d_dx.p),
+                                                        static_cast<float *>(fr->d_dy.p), static_cast<const int32_t *>(fr->d_idx.p),
+                                                        static_cast<mh_point32 *>(scan->d_full.p), nullptr, photo->cfg.rows, photo->cfg.cols,
+                                                        ctx->stream));
+    return photo_finish_preprocess(photo, fr, nullptr, n);
+  });
+}
+
+int mh_photo_get_image(mh_photo * photo, int which, void * out, size_t capacity_bytes)
+{
+  if (!photo || !out) return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_get_image: NULL argument");
+  mh_ctx * ctx = photo->ctx;
+  return guarded(ctx, "mh_photo_get_image", [&]() -> int {
+    PhotoFrame * fr = photo->frame;
+    if (!fr) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_get_image: no frame");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npx = static_cast<size_t>(fr->rows) * fr->cols;
+    const void * src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+      case 0: src = fr->d_intensity.p; bytes = npx * 4; break;
+      case 1: src = fr->d_range.p; bytes = npx * 4; break;
+      case 2: src = fr->d_dx.p; bytes = npx * 4; break;
+      case 3: src = fr->d_dy.p; bytes = npx * 4; break;
+      case 4: src = fr->d_mask.p; bytes = npx; break;
+      case 5: src = fr->d_idx.p; bytes = npx * 4; break;
+      case 6: src = fr->d_yaw.p; bytes = npx * 4; break;
+      case 7: src = fr->d_proj.p; bytes = npx * 4 * mh::kPhotoDup; break;
+      case 8:
+      case 9: {
+        MH_HIP(ctx, photo->d_grad.reserve(npx, ctx->stream, false));
+        MH_HIP(ctx, photo->d_detmask.reserve(npx, ctx->stream, false));
+        MH_HIP(ctx, mh::launch_photo_grad(static_cast<const float *>(fr->d_dx.p), static_cast<const float *>(fr->d_dy.p),
+                                          static_cast<uint8_t *>(photo->d_grad.p), static_cast<int>(npx), ctx->stream));
+        MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(fr->d_mask.p), nullptr, photo->cfg.margin_size,
+                                           static_cast<uint8_t *>(photo->d_detmask.p), fr->rows, fr->cols,
+                                           photo->cfg.patch_size + photo->cfg.erosion_buffer, ctx->stream));
+        src = which == 8 ? photo->d_grad.p : photo->d_detmask.p;
+        bytes = npx;
+        break;
+      }
+      default: return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_get_image: which must be 0..9");
+    }
+    if (capacity_bytes < bytes) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_get_image: buffer too small");
+    MH_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MH_OK;
+  });
+}
+
+int mh_photo_num_features(const mh_photo * photo, size_t * n_features, size_t * n_points_total)
+{
+  if (!photo) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_num_features: photo is NULL");
+  size_t np = 0;
+  for (const HostFeature & f : photo->features) np += static_cast<size_t>(f.hdr.n_points);
+  if (n_features) *n_features = photo->features.size();
+  if (n_points_total) *n_points_total = np;
+  return MH_OK;
+}
+
+int mh_photo_get_features(const mh_photo * photo, mh_photo_feature * features, double * Le_ps, double * intensities, double * psi)
+{
+  if (!photo) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_get_features: photo is NULL");
+  size_t o = 0;
+  for (size_t i = 0; i < photo->features.size(); ++i) {
+    const HostFeature & f = photo->features[i];
+    const size_t m = static_cast<size_t>(f.hdr.n_points);
+    if (features) features[i] = f.hdr;
+    if (Le_ps) std::memcpy(Le_ps + 3 * o, f.Le_ps.data(), 3 * m * sizeof(double));
+    if (intensities) std::memcpy(intensities + o, f.intensities.data(), m * sizeof(double));
+    if (psi) std::memcpy(psi + o, f.psi.data(), m * sizeof(double));
+    o += m;
+  }
+  return MH_OK;
+}
+
+int mh_photo_set_features(mh_photo * photo, const mh_photo_feature * features, size_t n_features, const double * Le_ps,
+                          const double * intensities, const double * psi)
+{
+  if (!photo || (n_features && (!features || !Le_ps || !intensities || !psi)))
+    return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_set_features: NULL argument");
+  return guarded(photo->ctx, "mh_photo_set_features", [&]() -> int {
+    std::vector<HostFeature> nf(n_features);
+    size_t o = 0;
+    for (size_t i = 0; i < n_features; ++i) {
+      const int m = features[i].n_points;
+      if (m < 2 || m > mh::kPhotoMaxPatch) return fail(photo->ctx, MH_ERR_UNSUPPORTED, "mh_photo_set_features: 2..64 points per feature");
+      nf[i].hdr = features[i];
+      nf[i].Le_ps.assign(Le_ps + 3 * o, Le_ps + 3 * (o + m));
+      nf[i].intensities.assign(intensities + o, intensities + o + m);
+      nf[i].psi.assign(psi + o, psi + o + m);
+      o += static_cast<size_t>(m);
+      if (features[i].id >= photo->next_id) photo->next_id = features[i].id + 1;
+    }
+    photo->features.swap(nf);
+    return MH_OK;
+  });
+}
+
+int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3],
+                             const double * bias_directions, size_t n_directions)
+{
+  if (!photo || !R_W_Be || !t_W_Be || (n_directions && !bias_directions))
+    return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_detect_features: NULL argument");
+  return guarded(photo->ctx, "mh_photo_detect_features", [&]() -> int {
+    MH_HIP(photo->ctx, hipSetDevice(photo->ctx->device));
+    return detect_features_impl(photo, num_to_detect, R_W_Be, t_W_Be, bias_directions, n_directions);
+  });
+}
+
+int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double R_W_Be[9], const double t_W_Be[3],
+                        const double * bias_directions, size_t n_directions)
+{
+  if (!photo || !R_W_Be || !t_W_Be || (n_directions && !bias_directions))
+    return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_update_map: NULL argument");
+  return guarded(photo->ctx, "mh_photo_update_map", [&]() -> int {
+    MH_HIP(photo->ctx, hipSetDevice(photo->ctx->device));
+    if (factor) {  // photometric.cpp:402-494
+      if (factor->photo != photo) return fail(photo->ctx, MH_ERR_INVALID_ARG, "mh_photo_update_map: the factor belongs to another mh_photo");
+      if (factor->statuses.size() != photo->features.size())
+        return fail(photo->ctx, MH_ERR_INVALID_ARG, "mh_photo_update_map: the tracked features changed since the factor was built");
+      std::vector<size_t> invalid;
+      for (size_t i = 0; i < factor->statuses.size(); ++i) {
+        if (factor->statuses[i] != MH_PHOTO_VALID) {
+          invalid.push_back(i);
+        } else {
+          HostFeature & f = photo->features[i];
+          f.hdr.center[0] = factor->centers[2 * i];
+          f.hdr.center[1] = factor->centers[2 * i + 1];
+          f.hdr.life_time++;
+          if (f.hdr.life_time >= photo->cfg.max_feature_life_time) invalid.push_back(i);
+        }
+      }
+      for (auto it = invalid.rbegin(); it != invalid.rend(); ++it) photo->features.erase(photo->features.begin() + static_cast<long>(*it));
+    }
+    const int want = photo->cfg.num_features_detect - static_cast<int>(photo->features.size());  // :507-509
+    return detect_features_impl(photo, want, R_W_Be, t_W_Be, bias_directions, n_directions);
+  });
+}
+
+int mh_photo_factor_create(mh_photo * photo, const double * VSVt, int is_binary, mh_photo_factor ** out)
+{
+  if (!photo || !out) return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_create: NULL argument");
+  *out = nullptr;
+  mh_ctx * ctx = photo->ctx;
+  return guarded(ctx, "mh_photo_factor_create", [&]() -> int {
+    if (!photo->frame) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_create: no frame (call mh_photo_preprocess first)");
+    if (photo->features.empty()) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_create: No features in a_features (photometric_factor.hpp:97-99)");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    mh_photo_factor * f = new mh_photo_factor;
+    f->photo = photo;
+    photo->refs.fetch_add(1);
+    f->frame = photo->frame;
+    f->frame->refs.fetch_add(1);
+    f->binary = is_binary != 0;
+    for (int i = 0; i < 36; ++i) f->VSVt[i] = VSVt ? VSVt[i] : ((i % 7 == 0) ? 1.0 : 0.0);
+    f->features = photo->features;
+    const size_t nf = f->features.size();
+    std::vector<double> Le(nf * mh::kPhotoMaxPatch * 3, 0.0), ps(nf * mh::kPhotoMaxPatch, 0.0);
+    std::vector<int32_t> np(nf);
+    for (size_t i = 0; i < nf; ++i) {
+      const HostFeature & hf = f->features[i];
+      np[i] = hf.hdr.n_points;
+      std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
+      std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
+    }
+    int rc = upload(ctx, f->d_Le, Le.data(), Le.size() * sizeof(double));
+    if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps.data(), ps.size() * sizeof(double));
+    if (rc == MH_OK) rc = upload(ctx, f->d_npts, np.data(), np.size() * sizeof(int32_t));
+    hipError_t e = hipSuccess;
+    if (rc == MH_OK) e = f->d_status.reserve(nf * sizeof(int32_t), ctx->stream, false);
+    if (rc == MH_OK && e == hipSuccess) e = f->d_centers.reserve(nf * 2 * sizeof(double), ctx->stream, false);
+    if (rc == MH_OK && e == hipSuccess) e = f->d_partials.reserve(nf * mh::kPhotoPartial * sizeof(double), ctx->stream, false);
+    if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
+    if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
+    if (rc != MH_OK || e != hipSuccess) {
+      mh_photo_factor_destroy(f);
+      return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_factor_create");
+    }
+    f->statuses.assign(nf, MH_PHOTO_UNPROCESSED);
+    f->centers.assign(2 * nf, 0.0);
+    for (size_t i = 0; i < nf; ++i) {
+      f->centers[2 * i] = f->features[i].hdr.center[0];
+      f->centers[2 * i + 1] = f->features[i].hdr.center[1];
+    }
+    *out = f;
+    return MH_OK;
+  });
+}
+
+void mh_photo_factor_destroy(mh_photo_factor * f)
+{
+  if (!f) return;
+  mh_ctx * ctx = f->photo->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_status, &f->d_centers, &f->d_partials, &f->d_rows}) b->release();
+  for (auto & e : f->ev)
+    if (e) (void)hipEventDestroy(e);
+  frame_release(f->frame);
+  photo_release(f->photo);
+  delete f;
+}
+
+size_t mh_photo_factor_size(const mh_photo_factor * f) { return f ? f->features.size() : 0; }
+
+int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const double t_b[3], const double * R_a, const double * t_a,
+                              mh_photo_result * out)
+{
+  if (!f || !R_b || !t_b || !out) return fail(f ? f->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: NULL argument");
+  mh_ctx * ctx = f->photo->ctx;
+  return guarded(ctx, "mh_photo_factor_linearize", [&]() -> int {
+    if (f->binary && (!R_a || !t_a)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: the binary factor needs T_a");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    const mh_photo_config & c = f->photo->cfg;
+    const size_t nf = f->features.size();
+    Pose Tb, Ta, TBL;
+    std::memcpy(Tb.R, R_b, sizeof(Tb.R));
+    std::memcpy(Tb.t, t_b, sizeof(Tb.t));
+    for (int i = 0; i < 9; ++i) Ta.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    Ta.t[0] = Ta.t[1] = Ta.t[2] = 0.0;
+    if (f->binary) {
+      std::memcpy(Ta.R, R_a, sizeof(Ta.R));
+      std::memcpy(Ta.t, t_a, sizeof(Ta.t));
+    }
+    std::memcpy(TBL.R, c.T_B_L_R, sizeof(TBL.R));
+    std::memcpy(TBL.t, c.T_B_L_t, sizeof(TBL.t));
+    const Pose dBe = pose_mul(pose_inv(Tb), Ta);                     // :147
+    const Pose dLe = pose_mul(pose_mul(pose_inv(TBL), dBe), TBL);    // :148-149
+    mh::PhotoLinArgs a;
+    a.model = f->photo->model;
+    PhotoFrame * fr = f->frame;
+    a.frame.points = static_cast<const mh_point32 *>(fr->d_points.p);
+    a.frame.n_points = static_cast<int>(fr->n_points);
+    a.frame.intensity = static_cast<const float *>(fr->d_intensity.p);
+    a.frame.range = static_cast<const float *>(fr->d_range.p);
+    a.frame.dx = static_cast<const float *>(fr->d_dx.p);
+    a.frame.dy = static_cast<const float *>(fr->d_dy.p);
+    a.frame.mask = static_cast<const uint8_t *>(fr->d_mask.p);
+    a.frame.idx = static_cast<const int32_t *>(fr->d_idx.p);
+    a.frame.proj = static_cast<const int32_t *>(fr->d_proj.p);
+    a.frame.yaw = static_cast<const float *>(fr->d_yaw.p);
+    a.frame.pose_ns = static_cast<const uint32_t *>(fr->d_pose_ns.p);
+    a.frame.pose_Rt = static_cast<const double *>(fr->d_pose_Rt.p);
+    a.frame.n_poses = fr->n_poses;
+    a.Le_ps = static_cast<const double *>(f->d_Le.p);
+    a.psi_a = static_cast<const double *>(f->d_psi.p);
+    a.n_pts = static_cast<const int32_t *>(f->d_npts.p);
+    a.n_features = static_cast<int>(nf);
+    a.binary = f->binary ? 1 : 0;
+    std::memcpy(a.dLe_R, dLe.R, sizeof(a.dLe_R));
+    std::memcpy(a.dLe_t, dLe.t, sizeof(a.dLe_t));
+    std::memcpy(a.dBe_R, dBe.R, sizeof(a.dBe_R));
+    std::memcpy(a.dBe_t, dBe.t, sizeof(a.dBe_t));
+    std::memcpy(a.TBL_R, TBL.R, sizeof(a.TBL_R));
+    std::memcpy(a.TBL_t, TBL.t, sizeof(a.TBL_t));
+    a.sigma = c.sigma;
+    a.max_error = c.max_error;
+    a.robust_param = c.robust_cost_function_parameter;
+    a.use_robust = c.use_robust_cost_function;
+    a.robust_is_huber = c.robust_cost_function == 0;
+    a.status = static_cast<int32_t *>(f->d_status.p);
+    a.centers = static_cast<double *>(f->d_centers.p);
+    a.partials = static_cast<double *>(f->d_partials.p);
+    a.rows_out = static_cast<double *>(f->d_rows.p);
+    a.counters = f->photo->d_counters;
+    f->photo->h_counters->project_throw = f->photo->h_counters->pose_missing = 0;
+    const bool timed = ctx->profiling > 0;
+    if (timed && !f->ev[0]) {
+      MH_HIP(ctx, hipEventCreate(&f->ev[0]));
+      MH_HIP(ctx, hipEventCreate(&f->ev[1]));
+    }
+    MH_HIP(ctx, hipMemsetAsync(f->d_rows.p, 0, nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(f->d_partials.p, 0, nf * mh::kPhotoPartial * sizeof(double), ctx->stream));
+    if (timed) MH_HIP(ctx, hipEventRecord(f->ev[0], ctx->stream));
+    MH_HIP(ctx, mh::launch_photo_linearize(a, ctx->stream));
+    if (timed) MH_HIP(ctx, hipEventRecord(f->ev[1], ctx->stream));
+    f->partials.resize(nf * mh::kPhotoPartial);
+    std::vector<double> new_centers(2 * nf);
+    MH_HIP(ctx, hipMemcpyAsync(f->statuses.data(), f->d_status.p, nf * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(new_centers.data(), f->d_centers.p, nf * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(f->partials.data(), f->d_partials.p, nf * mh::kPhotoPartial * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->gpu_ms = -1.f;
+    if (timed) (void)hipEventElapsedTime(&out->gpu_ms, f->ev[0], f->ev[1]);
+    out->n_exceptions = static_cast<int32_t>(f->photo->h_counters->project_throw + f->photo->h_counters->pose_missing);
+    // accumulate the per-feature sums in feature order (the reference's serial loop, :157-330)
+    const int NV = f->binary ? 13 : 7;
+    auto ent = [NV](int r, int cc) {
+      if (r > cc) std::swap(r, cc);
+      return r * NV - r * (r - 1) / 2 + (cc - r);
+    };
+    double Hbb[36] = {0}, Hba[36] = {0}, Haa[36] = {0}, bb[6] = {0}, ba[6] = {0}, fs = 0;
+    for (size_t i = 0; i < nf; ++i) {
+      out->status_hist[f->statuses[i]]++;
+      if (f->statuses[i] != MH_PHOTO_VALID) continue;
+      f->centers[2 * i] = new_centers[2 * i];
+      f->centers[2 * i + 1] = new_centers[2 * i + 1];
+      f->features[i].hdr.center[0] = new_centers[2 * i];
+      f->features[i].hdr.center[1] = new_centers[2 * i + 1];
+      const double * p = &f->partials[i * mh::kPhotoPartial];
+      for (int r = 0; r < 6; ++r) {
+        for (int cc = 0; cc < 6; ++cc) Hbb[6 * r + cc] += p[ent(r, cc)];
+        bb[r] += p[ent(r, NV - 1)];
+      }
+      fs += p[ent(NV - 1, NV - 1)];
+      if (f->binary)
+        for (int r = 0; r < 6; ++r) {
+          for (int cc = 0; cc < 6; ++cc) {
+            Hba[6 * r + cc] += p[ent(r, 6 + cc)];
+            Haa[6 * r + cc] += p[ent(6 + r, 6 + cc)];
+          }
+          ba[r] += p[ent(6 + r, 12)];
+        }
+    }
+    out->f = fs;
+    if (f->binary) {
+      std::memcpy(out->H_bb, Hbb, sizeof(Hbb));
+      std::memcpy(out->H_ba, Hba, sizeof(Hba));
+      std::memcpy(out->H_aa, Haa, sizeof(Haa));
+      std::memcpy(out->b_b, bb, sizeof(bb));
+      std::memcpy(out->b_a, ba, sizeof(ba));
+      return MH_OK;
+    }
+    // :336-351  J_b_T_J_b = VSVt J_I VSVt;  J_b_T_b = VSVt J_I VSVt J_I^-1 b_I;  localizabilities of the result
+    double t1[36], t2[36], inv[36], t3[36];
+    mat6_mul(f->VSVt, Hbb, t1);
+    mat6_mul(t1, f->VSVt, t2);
+    mat6_inv(Hbb, inv);
+    mat6_mul(t2, inv, t3);
+    std::memcpy(out->H_bb, t2, sizeof(t2));
+    for (int r = 0; r < 6; ++r) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += t3[6 * r + k] * bb[k];
+      out->b_b[r] = s;
+    }
+    double Hr[9], Ht[9];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        Hr[3 * r + cc] = t2[6 * r + cc];
+        Ht[3 * r + cc] = t2[6 * (3 + r) + 3 + cc];
+      }
+    mh::compute_localizability(Hr, out->loc_rot_final, out->eigvec_rot);
+    mh::compute_localizability(Ht, out->loc_trans_final, out->eigvec_trans);
+    return MH_OK;
+  });
+}
+
+int mh_photo_factor_get_state(const mh_photo_factor * f, int32_t * statuses, double * centers, double * rows)
+{
+  if (!f) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_get_state: factor is NULL");
+  mh_ctx * ctx = f->photo->ctx;
+  const size_t nf = f->features.size();
+  if (statuses) std::memcpy(statuses, f->statuses.data(), nf * sizeof(int32_t));
+  if (centers) std::memcpy(centers, f->centers.data(), 2 * nf * sizeof(double));
+  if (rows) {
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, hipMemcpy(rows, f->d_rows.p, nf * mh::kPhotoMaxPatch * 8 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// LiDAR photometric path: device-side structs and launcher declarations shared by
+// photo_kernels.hip and the C ABI (photo_api.hip).
+// Reference: src/lidar/photometric.cpp, include/mimosa/lidar/photometric_factor.hpp, src/lidar/photometric_utils.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/mimosa_hip.h"
+
+namespace mh
+{
+constexpr int kPhotoDup = 10;        // DUPLICATE_POINTS, include/mimosa/lidar/photometric_utils.hpp:17
+constexpr int kPhotoMaxPatch = 64;   // points per feature: one wave lane each (5 x 5 = 25 by default, 8 x 8 = 64)
+constexpr int kPhotoMaxTaps = 129;   // FIR length limit (the shipped filters have 33 taps)
+constexpr int kPhotoPartial = 96;    // per-feature sums: 28 (unary) or 91 (binary) used
+
+// Projection model + thresholds: the derived parameters of src/lidar/photometric_config.cpp:98-110 and the
+// PhotometricConfig fields the kernels read.  Plain scalars only (kernel argument).
+struct PhotoModel
+{
+  int rows, cols;
+  int destagger;
+  double fx, fy, cx;
+  float beam_offset_m;
+  float range_min, range_max;
+  float alt_first, alt_last;  // beam_altitude_angles.front() / .back()
+  int margin_size;
+  float occlusion_range_diff_threshold;
+  const float * alt;          // beam_altitude_angles (rows, degrees, descending)
+  const int * pixel_shift;    // pixel_shift_by_row (rows)
+};
+
+// Device view of a Frame (include/mimosa/lidar/photometric_utils.hpp:42-92)
+struct PhotoFrameView
+{
+  const mh_point32 * points;  // points_deskewed
+  int n_points;
+  const float * intensity;
+  const float * range;
+  const float * dx;
+  const float * dy;
+  const uint8_t * mask;
+  const int32_t * idx;       // img_deskewed_cloud_idx
+  const int32_t * proj;      // proj_idx: rows * cols * kPhotoDup
+  const float * yaw;
+  const uint32_t * pose_ns;  // interpolated_map_T_Le_Lt keys, ascending
+  const double * pose_Rt;    // 12 doubles per key: R row-major, t
+  int n_poses;
+};
+
+struct PhotoCounters
+{
+  uint32_t project_throw;  // project(): "Invalid x coordinate" (photometric_utils.cpp:90-97) — the reference throws
+  uint32_t pose_missing;   // interpolated_map_T_Le_Lt.at(): out_of_range
+  uint32_t pad[2];
+};
+
+// preprocess stage 1 (photometric.cpp:121-130, 204-217): yaw of the raw points, image fill from the deskewed ones
+hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
+                                uint8_t * yaw_valid, float * intensity, float * range, uint8_t * mask, int32_t * idx,
+                                hipStream_t stream);
+// stage 2 (:135-199): per-row interpolation of the missing yaw angles
+hipError_t launch_photo_yaw_fill(const PhotoModel & m, float * yaw, const uint8_t * yaw_valid, hipStream_t stream);
+// stage 3 (:218-244): project every deskewed point with the yaw table, build proj_idx (first 9 indices per pixel)
+hipError_t launch_photo_project(const PhotoModel & m, const mh_point32 * desk, int n, const float * yaw, int32_t * proj,
+                                PhotoCounters * counters, hipStream_t stream);
+hipError_t launch_photo_proj_finalize(int n_pixels, int32_t * proj, hipStream_t stream);
+// filter chain (:246-317): every stage reads `in` and writes `out` (rows x cols f32)
+hipError_t launch_photo_vfir(const float * in, float * out, int rows, int cols, const float * taps, int n_taps, float scale,
+                             float gamma, hipStream_t stream);
+hipError_t launch_photo_hfir_sub(const float * hp, const float * raw_in, float * out, int rows, int cols, const float * taps,
+                                 int n_taps, float scale, float gamma, hipStream_t stream);
+hipError_t launch_photo_scale(const float * in, float * out, int n, float scale, float gamma, hipStream_t stream);
+hipError_t launch_photo_brightness(const float * in, float * out, int rows, int cols, int win_w, int win_h, hipStream_t stream);
+hipError_t launch_photo_gauss_trunc(const float * in, float * out, int rows, int cols, int do_gauss, hipStream_t stream);
+// Sobel (:316-317) + corrected intensities back into the cloud (:307-314)
+hipError_t launch_photo_sobel_writeback(const float * img, float * dx, float * dy, const int32_t * idx, mh_point32 * desk,
+                                        float * intensity_out, int rows, int cols, hipStream_t stream);
+// createMask (:349-371): static mask, erosion with a k x k ones kernel (O6: out-of-image pixels are ignored)
+hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out, int rows, int cols,
+                              int k, hipStream_t stream);
+// detectFeatures' per-pixel part (:524-540): gradient magnitude image
+hipError_t launch_photo_grad(const float * dx, const float * dy, uint8_t * grad, int n, hipStream_t stream);
+
+// PhotometricFactor::linearize (photometric_factor.hpp:136-355): one wave per feature
+struct PhotoLinArgs
+{
+  PhotoModel model;
+  PhotoFrameView frame;
+  const double * Le_ps;   // n_features x kPhotoMaxPatch x 3
+  const double * psi_a;   // n_features x kPhotoMaxPatch
+  const int32_t * n_pts;  // n_features
+  int n_features;
+  int binary;
+  double dLe_R[9], dLe_t[3];  // delta_pose_b_a_Le
+  double dBe_R[9], dBe_t[3];  // delta_pose_b_a_Be
+  double TBL_R[9], TBL_t[3];  // T_B_L
+  double sigma, max_error, robust_param;
+  int use_robust, robust_is_huber;
+  // outputs
+  int32_t * status;      // n_features
+  double * centers;      // n_features x 2 (written for Valid features)
+  double * partials;     // n_features x kPhotoPartial: upper triangle of sum v v^T, v = [J_b(6) (, J_a(6)), e]
+  double * rows_out;     // optional (parity tooling): n_features x kPhotoMaxPatch x 8 = {e, J_b[6], valid}
+  PhotoCounters * counters;
+};
+hipError_t launch_photo_linearize(const PhotoLinArgs & a, hipStream_t stream);
+
+}  // namespace mh

@@ -1,0 +1,784 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the LiDAR photometric path — SURVEY.md §8 row f-2, BASELINE configs[3].
+//
+// Reference: Photometric::preprocess src/lidar/photometric.cpp:92-320 (image formation, yaw table, proj_idx, filter
+// chain, Sobel, mask), Photometric::detectFeatures :524-540 (gradient magnitude), PhotometricFactor::linearize
+// include/mimosa/lidar/photometric_factor.hpp:136-355, project / projectUndistorted / getProjectionJacobian /
+// getSubPixelValue / getPsi / getPsiJacobian src/lidar/photometric_utils.cpp:13-388.  The OpenCV / Eigen / PCL
+// behaviour these kernels reproduce is listed as assumptions O1-O12 in oracle/photo_ref.hpp.
+//
+// Compiled with -ffp-contract=off: the image chain is f32 arithmetic whose rounding the oracle reproduces bit for
+// bit (no FMA in the reference's baseline x86-64 build), and projected pixel coordinates feed round() / floor().
+//
+// Shapes: a 128 x 1024 f32 image is 512 KiB — every stage is a streaming pass over <= 131 072 points or pixels, far
+// from any bandwidth limit; what the chain costs is launches (each stage is one kernel, the whole preprocess is 12).
+// Separable filters stage their tile + halo in LDS (REFLECT_101 resolved at load time); the factor runs one wave
+// per feature, one lane per patch point, with wave shuffles for the NCC sums and the 28 / 91 Hessian sums.
+#include <hip/hip_runtime.h>
+
+#include "photo_device.hpp"
+
+namespace mh
+{
+namespace
+{
+constexpr int kT = 256;
+constexpr int kProjEmpty = 0x7F7F7F7F;  // proj_idx slots are memset to 0x7F bytes before the build
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// raw point index -> destaggered pixel (photometric.cpp:72-90, inverted)
+__device__ __forceinline__ void idx_to_pixel(const PhotoModel & m, uint32_t idx, int & u, int & v)
+{
+  v = static_cast<int>(idx / static_cast<uint32_t>(m.cols));
+  const int c = static_cast<int>(idx % static_cast<uint32_t>(m.cols));
+  u = m.destagger ? (c + m.pixel_shift[v]) % m.cols : c;
+}
+
+__device__ __forceinline__ float prep(float v, float scale, float gamma)
+{
+  if (scale != 1.0f) v = v * scale;          // img *= intensity_scale (O7)
+  if (gamma != 1.0f) v = powf(v, gamma);     // cv::pow (O12: not restated; skipped by every shipped config)
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// preprocess stage 1
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void photo_scatter_kernel(const PhotoModel m, const mh_point32 * raw, const mh_point32 * desk,
+                                                            int n, float * yaw, uint8_t * yaw_valid, float * intensity,
+                                                            float * range, uint8_t * mask, int32_t * idx)
+{
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int npx = m.rows * m.cols;
+  {
+    const mh_point32 p = raw[i];
+    if (p.idx < static_cast<uint32_t>(npx)) {
+      int u, v;
+      idx_to_pixel(m, p.idx, u, v);
+      yaw[v * m.cols + u] = static_cast<float>(atan2(static_cast<double>(p.y), static_cast<double>(p.x)));  // :127
+      yaw_valid[v * m.cols + u] = 1;
+    }
+  }
+  {
+    const mh_point32 p = desk[i];
+    if (p.range < m.range_min || p.range > m.range_max) return;  // :209
+    if (p.idx >= static_cast<uint32_t>(npx)) return;
+    int u, v;
+    idx_to_pixel(m, p.idx, u, v);
+    const int px = v * m.cols + u;
+    intensity[px] = p.intensity;
+    range[px] = p.range;
+    mask[px] = 1;
+    idx[px] = i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// preprocess stage 2: one workgroup per image row
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxCols = 4096;
+__global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, float * yaw, const uint8_t * yaw_valid)
+{
+  __shared__ float s_yaw[kMaxCols];
+  __shared__ int s_prev[kMaxCols], s_next[kMaxCols];
+  __shared__ int s_clast[kT], s_cfirst[kT];
+  const int v = blockIdx.x, cols = m.cols;
+  float * yr = yaw + static_cast<size_t>(v) * cols;
+  const uint8_t * vr = yaw_valid + static_cast<size_t>(v) * cols;
+  const int per = (cols + kT - 1) / kT, c0 = threadIdx.x * per, c1 = min(cols, c0 + per);
+  int last = -1, first = -1;
+  for (int u = c0; u < c1; ++u) {
+    const bool ok = vr[u] != 0;
+    s_yaw[u] = ok ? yr[u] : 0.f;
+    last = ok ? u : last;
+    s_prev[u] = last;  // chunk-local
+  }
+  for (int u = c1 - 1; u >= c0; --u) {
+    first = vr[u] ? u : first;
+    s_next[u] = first;
+  }
+  s_clast[threadIdx.x] = last;
+  s_cfirst[threadIdx.x] = first;
+  __syncthreads();
+  int carry_prev = -1, carry_next = -1;
+  for (int t = static_cast<int>(threadIdx.x) - 1; t >= 0 && carry_prev < 0; --t) carry_prev = s_clast[t];
+  for (int t = threadIdx.x + 1; t < kT && carry_next < 0; ++t) carry_next = s_cfirst[t];
+  const double kPi = 3.14159265358979323846;
+  for (int u = c0; u < c1; ++u) {
+    if (vr[u]) continue;
+    const int pv = s_prev[u] >= 0 ? s_prev[u] : carry_prev, nx = s_next[u] >= 0 ? s_next[u] : carry_next;
+    float out;
+    if (pv < 0 && nx < 0) {  // :148-155 no valid column in this row
+      const float t = static_cast<float>(u) / static_cast<float>(cols - 1);
+      out = static_cast<float>(static_cast<double>(1.0f - t) * kPi + static_cast<double>(t) * (-kPi));
+    } else if (pv < 0) {  // :158-167 before the first valid column
+      const float t = static_cast<float>(u) / static_cast<float>(nx);
+      out = static_cast<float>(static_cast<double>(1.0f - t) * kPi + static_cast<double>(t * s_yaw[nx]));
+    } else if (nx < 0) {  // :187-198 after the last valid column
+      const int gap = cols - 1 - pv;
+      const float t = static_cast<float>(u - pv) / static_cast<float>(gap);
+      out = static_cast<float>(static_cast<double>((1.0f - t) * s_yaw[pv]) + static_cast<double>(t) * (-kPi));
+    } else {  // :170-185 between two valid columns
+      const float yl = s_yaw[pv], yrr = s_yaw[nx], denom = static_cast<float>(nx - pv);
+      const float t = static_cast<float>(u - pv) / denom;
+      out = yl + t * (yrr - yl);
+    }
+    yr[u] = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// project() with the yaw table (photometric_utils.cpp:80-198).  Returns 1 ok, 0 = false, -1 = the reference throws.
+// PCL's DEG2RAD / RAD2DEG macro constants (see oracle/photo_ref.hpp).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * yaw, double px, double py, double pz, double & ux,
+                                           double & uy)
+{
+  const double L = sqrt(px * px + py * py) - static_cast<double>(m.beam_offset_m);
+  const double R = sqrt(L * L + pz * pz);
+  const double phi = atan2(py, px);
+  const double theta = asin(pz / R);
+  ux = m.fx * phi + m.cx;
+  if (ux < 0 || ux >= static_cast<double>(m.cols)) return -1;
+  if (ux < 5 || ux > static_cast<double>(m.cols - 5)) return 0;
+  if (theta > static_cast<double>(m.alt_first) * 0.017453293 || theta < static_cast<double>(m.alt_last) * 0.017453293) return 0;
+  const double th_deg = theta * 57.29578;
+  // greater = last altitude (descending table) that is > th_deg; clamped where the reference would read out of range
+  int lo = 0, hi = m.rows;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (static_cast<double>(m.alt[mid]) > th_deg)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int g = lo - 1;
+  g = g < 0 ? 0 : (g > m.rows - 2 ? m.rows - 2 : g);
+  const float ag = m.alt[g], as = m.alt[g + 1];
+  uy = static_cast<double>(g) + (static_cast<double>(ag) - th_deg) / static_cast<double>(ag - as);
+  const int approx_y = static_cast<int>(round(uy));
+  if (approx_y < 0 || approx_y >= m.rows) return 0;
+  const float * row = yaw + static_cast<size_t>(approx_y) * m.cols;
+  int il = static_cast<int>(ux) - 5, ir = static_cast<int>(ux) + 5;
+  il = il < 0 ? 0 : il;
+  ir = ir > m.cols - 1 ? m.cols - 1 : ir;
+  while (ir - il > 1) {
+    const int mid = il + (ir - il) / 2;
+    const float ym = row[mid];
+    if (static_cast<double>(ym) == phi) {
+      ux = static_cast<double>(mid);
+      return (ux >= 0 && ux <= m.cols - 1 && uy >= 0 && uy <= m.rows - 1) ? 1 : 0;
+    } else if (static_cast<double>(ym) < phi) {
+      ir = mid;
+    } else {
+      il = mid;
+    }
+  }
+  const float yl = row[il], yr = row[ir];
+  ux = static_cast<double>(il) + (static_cast<double>(yl) - phi) / static_cast<double>(yl - yr);
+  return (ux >= 0 && ux <= m.cols - 1 && uy >= 0 && uy <= m.rows - 1) ? 1 : 0;
+}
+
+// preprocess stage 3: project + proj_idx.  Slots 1..9 of a pixel hold its 9 smallest point indices in ascending
+// order, kept by a carry chain of atomicMin (the displaced larger value moves on to the next slot); the reference
+// appends in index order and stops at 9 (photometric.cpp:232-244) — the same set in the same order.
+__global__ __launch_bounds__(kT) void photo_project_kernel(const PhotoModel m, const mh_point32 * desk, int n, const float * yaw,
+                                                            int32_t * proj, PhotoCounters * counters)
+{
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const mh_point32 p = desk[i];
+  if (p.range < m.range_min || p.range > m.range_max) return;
+  double ux, uy;
+  const int r = project_yaw(m, yaw, static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z), ux, uy);
+  if (r < 0) atomicAdd(&counters->project_throw, 1u);
+  if (r <= 0) return;
+  const int u = static_cast<int>(round(ux)), v = static_cast<int>(round(uy));
+  if (u < 0 || v < 0) return;
+  int32_t * slot = proj + (static_cast<size_t>(v) * m.cols + u) * kPhotoDup;
+  int cur = i;
+#pragma unroll 1
+  for (int s = 1; s < kPhotoDup && cur != kProjEmpty; ++s) {
+    const int old = atomicMin(&slot[s], cur);
+    cur = max(old, cur);
+  }
+}
+
+__global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, int32_t * proj)
+{
+  const int px = blockIdx.x * kT + threadIdx.x;
+  if (px >= n_pixels) return;
+  int32_t * slot = proj + static_cast<size_t>(px) * kPhotoDup;
+  int cnt = 0;
+  for (int s = 1; s < kPhotoDup; ++s) {
+    if (slot[s] != kProjEmpty)
+      ++cnt;
+    else
+      slot[s] = 0;
+  }
+  slot[0] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter chain
+// ------------------------------------------------------------------------------------------------
+// removeLines part 1 (:322-327): vertical correlation with the high-pass FIR.  Tile = 64 rows x 64 columns + halo.
+constexpr int kVT_R = 64, kVT_C = 64;
+__global__ __launch_bounds__(kT) void photo_vfir_kernel(const float * in, float * out, int rows, int cols, const float * taps,
+                                                         int n_taps, float scale, float gamma)
+{
+  __shared__ float s_tile[(kVT_R + kPhotoMaxTaps - 1) * kVT_C];
+  __shared__ float s_taps[kPhotoMaxTaps];
+  const int a = n_taps / 2, r0 = blockIdx.y * kVT_R, c0 = blockIdx.x * kVT_C, th = kVT_R + n_taps - 1;
+  for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
+  for (int e = threadIdx.x; e < th * kVT_C; e += kT) {
+    const int ty = e / kVT_C, tx = e % kVT_C;
+    const int y = reflect101(r0 + ty - a, rows), x = c0 + tx;
+    s_tile[e] = x < cols ? prep(in[static_cast<size_t>(y) * cols + x], scale, gamma) : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kVT_R * kVT_C; e += kT) {
+    const int ty = e / kVT_C, tx = e % kVT_C;
+    if (r0 + ty >= rows || c0 + tx >= cols) continue;
+    float s = 0.f;
+    for (int k = 0; k < n_taps; ++k) s = s + s_taps[k] * s_tile[(ty + k) * kVT_C + tx];  // O2: tap order, float
+    out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = s;
+  }
+}
+
+// removeLines part 2 (:328-336): horizontal low-pass of the high-passed image = the line artefacts; subtract, clip.
+constexpr int kHT_R = 8, kHT_C = 128;
+__global__ __launch_bounds__(kT) void photo_hfir_sub_kernel(const float * hp, const float * raw_in, float * out, int rows, int cols,
+                                                             const float * taps, int n_taps, float scale, float gamma)
+{
+  __shared__ float s_tile[kHT_R * (kHT_C + kPhotoMaxTaps - 1)];
+  __shared__ float s_taps[kPhotoMaxTaps];
+  const int a = n_taps / 2, r0 = blockIdx.y * kHT_R, c0 = blockIdx.x * kHT_C, tw = kHT_C + n_taps - 1;
+  for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
+  for (int e = threadIdx.x; e < kHT_R * tw; e += kT) {
+    const int ty = e / tw, tx = e % tw;
+    const int y = r0 + ty, x = reflect101(c0 + tx - a, cols);
+    s_tile[e] = y < rows ? hp[static_cast<size_t>(y) * cols + x] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kHT_R * kHT_C; e += kT) {
+    const int ty = e / kHT_C, tx = e % kHT_C;
+    if (r0 + ty >= rows || c0 + tx >= cols) continue;
+    float s = 0.f;
+    for (int k = 0; k < n_taps; ++k) s = s + s_taps[k] * s_tile[ty * tw + tx + k];
+    const size_t px = static_cast<size_t>(r0 + ty) * cols + c0 + tx;
+    const float v = prep(raw_in[px], scale, gamma) - s;
+    out[px] = v < 0.f ? 0.f : v;
+  }
+}
+
+__global__ __launch_bounds__(kT) void photo_scale_kernel(const float * in, float * out, int n, float scale, float gamma)
+{
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) out[i] = prep(in[i], scale, gamma);
+}
+
+// filterBrightness (:339-347): normalised box mean (double sums, O3) + 1, img = 140 * img / brightness (O7)
+constexpr int kBT_R = 16, kBT_C = 64, kBMaxW = 63, kBMaxH = 31;
+__global__ __launch_bounds__(kT) void photo_brightness_kernel(const float * in, float * out, int rows, int cols, int w, int h)
+{
+  __shared__ float s_raw[(kBT_R + kBMaxH - 1) * (kBT_C + kBMaxW - 1)];
+  __shared__ double s_rs[(kBT_R + kBMaxH - 1) * kBT_C];
+  const int ax = w / 2, ay = h / 2, r0 = blockIdx.y * kBT_R, c0 = blockIdx.x * kBT_C, tw = kBT_C + w - 1, th = kBT_R + h - 1;
+  for (int e = threadIdx.x; e < th * tw; e += kT) {
+    const int ty = e / tw, tx = e % tw;
+    s_raw[e] = in[static_cast<size_t>(reflect101(r0 + ty - ay, rows)) * cols + reflect101(c0 + tx - ax, cols)];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < th * kBT_C; e += kT) {
+    const int ty = e / kBT_C, tx = e % kBT_C;
+    double s = 0;
+    for (int k = 0; k < w; ++k) s += static_cast<double>(s_raw[ty * tw + tx + k]);
+    s_rs[e] = s;
+  }
+  __syncthreads();
+  const double scl = 1.0 / (static_cast<double>(w) * static_cast<double>(h));
+  for (int e = threadIdx.x; e < kBT_R * kBT_C; e += kT) {
+    const int ty = e / kBT_C, tx = e % kBT_C;
+    if (r0 + ty >= rows || c0 + tx >= cols) continue;
+    double s = 0;
+    for (int k = 0; k < h; ++k) s += s_rs[(ty + k) * kBT_C + tx];
+    const float b = static_cast<float>(s * scl) + 1.0f;
+    const float v = s_raw[(ty + ay) * tw + tx + ax];
+    out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = b != 0.f ? (v * 140.0f) / b : 0.f;
+  }
+}
+
+// GaussianBlur 3 x 3 (:350-353, O4) + threshold TRUNC 255 (:298-300, O8)
+constexpr int kGT_R = 16, kGT_C = 64;
+__global__ __launch_bounds__(kT) void photo_gauss_trunc_kernel(const float * in, float * out, int rows, int cols, int do_gauss)
+{
+  __shared__ float s_raw[(kGT_R + 2) * (kGT_C + 2)];
+  __shared__ float s_tmp[(kGT_R + 2) * kGT_C];
+  const int r0 = blockIdx.y * kGT_R, c0 = blockIdx.x * kGT_C, tw = kGT_C + 2;
+  for (int e = threadIdx.x; e < (kGT_R + 2) * tw; e += kT) {
+    const int ty = e / tw, tx = e % tw;
+    s_raw[e] = in[static_cast<size_t>(reflect101(r0 + ty - 1, rows)) * cols + reflect101(c0 + tx - 1, cols)];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < (kGT_R + 2) * kGT_C; e += kT) {
+    const int ty = e / kGT_C, tx = e % kGT_C;
+    const float l = s_raw[ty * tw + tx], c = s_raw[ty * tw + tx + 1], r = s_raw[ty * tw + tx + 2];
+    s_tmp[e] = do_gauss ? 0.5f * c + 0.25f * (l + r) : c;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kGT_R * kGT_C; e += kT) {
+    const int ty = e / kGT_C, tx = e % kGT_C;
+    if (r0 + ty >= rows || c0 + tx >= cols) continue;
+    const float u = s_tmp[ty * kGT_C + tx], c = s_tmp[(ty + 1) * kGT_C + tx], d = s_tmp[(ty + 2) * kGT_C + tx];
+    float v = do_gauss ? 0.5f * c + 0.25f * (u + d) : c;
+    v = v > 255.0f ? 255.0f : v;
+    out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = v;
+  }
+}
+
+// Sobel ksize 1, scale 0.5 (:316-317, O5) + corrected intensities back into the cloud (:307-314)
+__global__ __launch_bounds__(kT) void photo_sobel_writeback_kernel(const float * img, float * dx, float * dy, const int32_t * idx,
+                                                                    mh_point32 * desk, float * intensity_out, int rows, int cols)
+{
+  const int px = blockIdx.x * kT + threadIdx.x;
+  if (px >= rows * cols) return;
+  const int y = px / cols, x = px % cols;
+  const float c = img[px];
+  dx[px] = (img[y * cols + reflect101(x + 1, cols)] - img[y * cols + reflect101(x - 1, cols)]) * 0.5f;
+  dy[px] = (img[reflect101(y + 1, rows) * cols + x] - img[reflect101(y - 1, rows) * cols + x]) * 0.5f;
+  const int i = idx[px];
+  if (i >= 0) {
+    if (desk) desk[i].intensity = c;
+    if (intensity_out) intensity_out[i] = c;
+  }
+}
+
+// erode with a k x k ones kernel, anchor k / 2 (O6).  in &= static_mask (and the margin rectangle when margin >= 0:
+// detectFeatures' `img_mask & mask_margin_`, photometric.cpp:524) before the erosion.
+constexpr int kET_R = 16, kET_C = 64, kEMaxK = 33;
+__global__ __launch_bounds__(kT) void photo_erode_kernel(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out,
+                                                          int rows, int cols, int k)
+{
+  __shared__ uint8_t s_raw[(kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1)];
+  __shared__ uint8_t s_row[(kET_R + kEMaxK - 1) * kET_C];
+  const int a = k / 2, r0 = blockIdx.y * kET_R, c0 = blockIdx.x * kET_C, tw = kET_C + k - 1, th = kET_R + k - 1;
+  for (int e = threadIdx.x; e < th * tw; e += kT) {
+    const int ty = e / tw, tx = e % tw;
+    const int y = r0 + ty - a, x = c0 + tx - a;
+    uint8_t v = 255;  // outside the image: never lowers the minimum
+    if (y >= 0 && y < rows && x >= 0 && x < cols) {
+      v = in[static_cast<size_t>(y) * cols + x];
+      if (static_mask && static_mask[static_cast<size_t>(y) * cols + x] == 0) v = 0;
+      if (margin >= 0 && !(y >= margin && y < rows - margin && x >= margin && x < cols - margin)) v = 0;
+    }
+    s_raw[e] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < th * kET_C; e += kT) {
+    const int ty = e / kET_C, tx = e % kET_C;
+    uint8_t mn = 255;
+    for (int j = 0; j < k; ++j) mn = min(mn, s_raw[ty * tw + tx + j]);
+    s_row[e] = mn;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kET_R * kET_C; e += kT) {
+    const int ty = e / kET_C, tx = e % kET_C;
+    if (r0 + ty >= rows || c0 + tx >= cols) continue;
+    uint8_t mn = 255;
+    for (int j = 0; j < k; ++j) mn = min(mn, s_row[(ty + j) * kET_C + tx]);
+    out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = mn;
+  }
+}
+
+// convertScaleAbs + addWeighted(.5, .5) (photometric.cpp:536-540, O9): round half to even, saturate
+__device__ __forceinline__ uint8_t sat_u8(float v)
+{
+  const float r = rintf(v);
+  return static_cast<uint8_t>(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+__global__ __launch_bounds__(kT) void photo_grad_kernel(const float * dx, const float * dy, uint8_t * grad, int n)
+{
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t ax = sat_u8(fabsf(dx[i])), ay = sat_u8(fabsf(dy[i]));
+  grad[i] = sat_u8(static_cast<float>(ax) * 0.5f + static_cast<float>(ay) * 0.5f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PhotometricFactor::linearize — one wave per feature, lane = patch point
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ double bilinear(const float * img, int cols, double x, double y)  // photometric_utils.cpp:368-388
+{
+  const int x0 = static_cast<int>(floor(x)), y0 = static_cast<int>(floor(y));
+  const double dx = x - x0, dy = y - y0;
+  const float * r0 = img + static_cast<size_t>(y0) * cols + x0;
+  const float * r1 = r0 + cols;
+  return (1 - dx) * (1 - dy) * static_cast<double>(r0[0]) + dx * (1 - dy) * static_cast<double>(r0[1]) +
+         (1 - dx) * dy * static_cast<double>(r1[0]) + dx * dy * static_cast<double>(r1[1]);
+}
+
+enum
+{
+  PS_UNPROCESSED = 0,
+  PS_PROJECT_UNDISTORTED,
+  PS_RANGE,
+  PS_PROJECT,
+  PS_MASK,
+  PS_MASK_MARGIN,
+  PS_RANGE_DIFF,
+  PS_MAX_ERROR,
+  PS_VALID
+};
+
+__device__ __forceinline__ void mat3_vec(const double * R, double x, double y, double z, double & ox, double & oy, double & oz)
+{
+  ox = R[0] * x + (R[1] * y + R[2] * z);
+  oy = R[3] * x + (R[4] * y + R[5] * z);
+  oz = R[6] * x + (R[7] * y + R[8] * z);
+}
+
+constexpr int kFeatPerBlock = 4;
+__global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(const PhotoLinArgs a)
+{
+  const int lane = threadIdx.x & 63, f = blockIdx.x * kFeatPerBlock + (threadIdx.x >> 6);
+  if (f >= a.n_features) return;  // whole waves
+  const PhotoModel & m = a.model;
+  const PhotoFrameView & fr = a.frame;
+  const int npts = a.n_pts[f];
+  const bool act = lane < npts;
+  const double * Lp = a.Le_ps + (static_cast<size_t>(f) * kPhotoMaxPatch + (act ? lane : 0)) * 3;
+  const double ax = Lp[0], ay = Lp[1], az = Lp[2];
+  int st = PS_UNPROCESSED;
+  int threw = 0;  // 1: project() would throw, 2: interpolated_map_T_Le_Lt.at() would throw
+  double ux = 0, uy = 0, lx = 0, ly = 0, lz = 0, Ib = 0;
+  double TR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (act) {
+    // p_Le_b = delta_pose_b_a_Le * Le_p (:168)
+    double bx, by, bz;
+    mat3_vec(a.dLe_R, ax, ay, az, bx, by, bz);
+    bx += a.dLe_t[0];
+    by += a.dLe_t[1];
+    bz += a.dLe_t[2];
+    // projectUndistorted (photometric_utils.cpp:287-366)
+    double kx, ky;
+    int r = project_yaw(m, fr.yaw, bx, by, bz, kx, ky);
+    bool ok = r > 0;
+    if (r < 0) threw = 1;
+    int dist_idx = -1;
+    if (ok) {
+      kx = round(kx);
+      ky = round(ky);
+      int row = static_cast<int>(ky);
+      const int col = static_cast<int>(kx);
+      const int32_t * pj = fr.proj + (static_cast<size_t>(row) * m.cols + col) * kPhotoDup;
+      if (pj[0] == 0) {  // search the column for any row with projections (:305-313)
+        row = 0;
+        for (; row < m.rows; ++row) {
+          pj = fr.proj + (static_cast<size_t>(row) * m.cols + col) * kPhotoDup;
+          if (pj[0] > 0) break;
+        }
+        if (row >= m.rows) ok = false;
+      }
+      if (ok) {
+        if (pj[0] > 1) {
+          float min_sq = 3.402823466e+38f;
+          for (int i = 1; i <= pj[0]; ++i) {
+            const int j = pj[i];
+            const mh_point32 q = fr.points[j];
+            const double ddx = bx - static_cast<double>(q.x), ddy = by - static_cast<double>(q.y), ddz = bz - static_cast<double>(q.z);
+            const float sq = static_cast<float>(ddx * ddx + (ddy * ddy + ddz * ddz));
+            if (sq < min_sq) {
+              min_sq = sq;
+              dist_idx = j;
+            }
+          }
+        } else {
+          dist_idx = pj[1];
+        }
+        if (dist_idx < 0) ok = false;
+      }
+    }
+    if (ok) {
+      // T_Le_Lt = interpolated_map_T_Le_Lt.at(points_deskewed[distortion_idx].t)
+      const uint32_t ns = fr.points[dist_idx].t;
+      int lo = 0, hi = fr.n_poses;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fr.pose_ns[mid] < ns)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo >= fr.n_poses || fr.pose_ns[lo] != ns) {
+        threw = 2;
+        ok = false;
+      } else {
+        const double * T = fr.pose_Rt + static_cast<size_t>(lo) * 12;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) TR[q] = T[q];
+        // Li_p = T_Le_Lt.inverse() * Le_p:  R^T p + (-(R^T t))   (gtsam Pose3::inverse then act)
+        const double itx = -(TR[0] * T[9] + (TR[3] * T[10] + TR[6] * T[11])), ity = -(TR[1] * T[9] + (TR[4] * T[10] + TR[7] * T[11])),
+                     itz = -(TR[2] * T[9] + (TR[5] * T[10] + TR[8] * T[11]));
+        lx = (TR[0] * bx + (TR[3] * by + TR[6] * bz)) + itx;
+        ly = (TR[1] * bx + (TR[4] * by + TR[7] * bz)) + ity;
+        lz = (TR[2] * bx + (TR[5] * by + TR[8] * bz)) + itz;
+        r = project_yaw(m, fr.yaw, lx, ly, lz, ux, uy);
+        if (r < 0) threw = 1;
+        ok = r > 0;
+      }
+    }
+    if (!ok) {
+      st = PS_PROJECT_UNDISTORTED;
+    } else {
+      const double rng = sqrt(lx * lx + (ly * ly + lz * lz));
+      const int rx = static_cast<int>(round(ux)), ry = static_cast<int>(round(uy));
+      if (rng < static_cast<double>(m.range_min) || rng > static_cast<double>(m.range_max)) {
+        st = PS_RANGE;
+      } else if (!fr.mask[static_cast<size_t>(ry) * m.cols + rx]) {
+        st = PS_MASK;
+      } else if (rx < m.margin_size || rx >= m.cols - m.margin_size || ry < m.margin_size || ry >= m.rows - m.margin_size) {
+        st = PS_MASK_MARGIN;
+      } else if (fabs(static_cast<double>(fr.range[static_cast<size_t>(ry) * m.cols + rx]) - rng) >
+                 static_cast<double>(m.occlusion_range_diff_threshold)) {
+        st = PS_RANGE_DIFF;
+      } else if (ux > m.cols - 2 || uy > m.rows - 2) {
+        st = PS_PROJECT_UNDISTORTED;  // bilinear footprint outside the image: the reference's getSubPixelValue reads out of bounds
+      } else {
+        Ib = bilinear(fr.intensity, m.cols, ux, uy);
+      }
+    }
+  }
+  // the loop over the patch breaks at the FIRST failing point (:170-216): its status is the feature's
+  const unsigned long long failing = __ballot(act && st != PS_UNPROCESSED);
+  if (failing) {
+    const int first = __ffsll(static_cast<long long>(failing)) - 1;
+    const int fst = __shfl(st, first, 64);
+    if (lane == 0) a.status[f] = fst;
+    // only the first failing point is ever evaluated by the reference: count ITS exception, if any
+    if (lane == first && threw) atomicAdd(threw == 1 ? &a.counters->project_throw : &a.counters->pose_missing, 1u);
+    return;
+  }
+  // getPsi (photometric_utils.cpp:13-19)
+  const double md = static_cast<double>(npts);
+  const double mean = wave_sum(act ? Ib : 0.0) / md;
+  const double cen = act ? Ib - mean : 0.0;
+  const double sigma = sqrt(wave_sum(cen * cen));
+  const double psi = cen / sigma;
+  const double e0 = act ? psi - a.psi_a[static_cast<size_t>(f) * kPhotoMaxPatch + lane] : 0.0;
+  const double e2 = wave_sum(e0 * e0);
+  const double e_ncc = (2 - e2) / 2;
+  if (e_ncc < a.max_error) {
+    if (lane == 0) a.status[f] = PS_MAX_ERROR;
+    return;
+  }
+  {
+    const int cl = npts / 2;  // a_feature.center = uv_bs[uv_bs.size() / 2]
+    const double cxv = __shfl(ux, cl, 64), cyv = __shfl(uy, cl, 64);
+    if (lane == 0) {
+      a.status[f] = PS_VALID;
+      a.centers[2 * f] = cxv;
+      a.centers[2 * f + 1] = cyv;
+    }
+  }
+  // Jacobian rows: dI/duv * duv/dp * dp/dT  (:243-279)
+  double Db[6] = {0, 0, 0, 0, 0, 0}, Da[6] = {0, 0, 0, 0, 0, 0};
+  if (act) {
+    const double gx = bilinear(fr.dx, m.cols, ux, uy), gy = bilinear(fr.dy, m.cols, ux, uy);
+    // getProjectionJacobian (photometric_utils.cpp:186-198)
+    const double rxy = sqrt(lx * lx + ly * ly);
+    const double L = rxy - static_cast<double>(m.beam_offset_m);
+    const double R2 = L * L + lz * lz;
+    const double irxy = 1.0 / rxy;
+    const double fx_irxy2 = m.fx * (irxy * irxy);
+    const double den = (L + static_cast<double>(m.beam_offset_m)) * R2;
+    const double P0 = -fx_irxy2 * ly, P1 = fx_irxy2 * lx, P3 = -m.fy * lx * lz / den, P4 = -m.fy * ly * lz / den, P5 = m.fy * L / R2;
+    const double g0 = gx * P0 + gy * P3, g1 = gx * P1 + gy * P4, g2 = gy * P5;
+    // p_Be_a = T_B_L * Le_p;  p_Be_b = delta_pose_b_a_Be * p_Be_a
+    double pax, pay, paz, pbx, pby, pbz;
+    mat3_vec(a.TBL_R, ax, ay, az, pax, pay, paz);
+    pax += a.TBL_t[0];
+    pay += a.TBL_t[1];
+    paz += a.TBL_t[2];
+    mat3_vec(a.dBe_R, pax, pay, paz, pbx, pby, pbz);
+    pbx += a.dBe_t[0];
+    pby += a.dBe_t[1];
+    pbz += a.dBe_t[2];
+    // R_Lk_b_Be_b = R_Le_Lt^T * R_B_L^T ;  w = g^T R  (1 x 3)
+    double Rk[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rk[3 * i + j] = TR[i] * a.TBL_R[3 * j] + (TR[3 + i] * a.TBL_R[3 * j + 1] + TR[6 + i] * a.TBL_R[3 * j + 2]);
+    const double w0 = g0 * Rk[0] + g1 * Rk[3] + g2 * Rk[6], w1 = g0 * Rk[1] + g1 * Rk[4] + g2 * Rk[7],
+                 w2 = g0 * Rk[2] + g1 * Rk[5] + g2 * Rk[8];
+    // w * Hat(p) = (p x w)^T ... row vector times skew: (w^T [p]x)_k = (w x p)_k with sign: w^T [p]x = (p x w)^T * (-1)?
+    // [p]x v = p x v, so w^T [p]x = -(p x w)^T... computed explicitly:
+    Db[0] = w1 * pbz - w2 * pby;  // (w^T Hat(p))_0 = w1 * p_z - w2 * p_y
+    Db[1] = w2 * pbx - w0 * pbz;
+    Db[2] = w0 * pby - w1 * pbx;
+    Db[3] = -w0;
+    Db[4] = -w1;
+    Db[5] = -w2;
+    if (a.binary) {
+      // R_Lk_b_Be_a = R_Lk_b_Be_b * R(delta_pose_b_a_Be);  wa = g^T R_a
+      const double wa0 = w0 * a.dBe_R[0] + w1 * a.dBe_R[3] + w2 * a.dBe_R[6], wa1 = w0 * a.dBe_R[1] + w1 * a.dBe_R[4] + w2 * a.dBe_R[7],
+                   wa2 = w0 * a.dBe_R[2] + w1 * a.dBe_R[5] + w2 * a.dBe_R[8];
+      Da[0] = -(wa1 * paz - wa2 * pay);
+      Da[1] = -(wa2 * pax - wa0 * paz);
+      Da[2] = -(wa0 * pay - wa1 * pax);
+      Da[3] = wa0;
+      Da[4] = wa1;
+      Da[5] = wa2;
+    }
+  }
+  // J = ((I - psi psi^T) / sigma) (I - 1 1^T / m) D   (getPsiJacobian, photometric_utils.cpp:21-27)
+  const double whitened = sqrt(e2) / a.sigma;
+  double sw = 1.0;
+  if (a.use_robust) {
+    const double p = a.robust_param;
+    sw = a.robust_is_huber ? (fabs(whitened) <= p ? 1.0 : sqrt(p / fabs(whitened))) : p * p / (p * p + whitened * whitened);
+  }
+  const double wgt = sw / a.sigma;
+  double row[13];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double cm = wave_sum(Db[k]) / md;
+    const double dc = act ? Db[k] - cm : 0.0;
+    const double pd = wave_sum(psi * dc);
+    row[k] = act ? ((dc - psi * pd) / sigma) * wgt : 0.0;
+  }
+  const int NV = a.binary ? 13 : 7;
+  if (a.binary) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double cm = wave_sum(Da[k]) / md;
+      const double dc = act ? Da[k] - cm : 0.0;
+      const double pd = wave_sum(psi * dc);
+      row[6 + k] = act ? ((dc - psi * pd) / sigma) * wgt : 0.0;
+    }
+    row[12] = e0 * wgt;
+  } else {
+    row[6] = e0 * wgt;
+  }
+  if (a.rows_out && act) {
+    double * ro = a.rows_out + (static_cast<size_t>(f) * kPhotoMaxPatch + lane) * 8;
+    ro[0] = e0 * wgt;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ro[1 + k] = row[k];
+    ro[7] = 1.0;
+  }
+  // per-feature sums of v v^T (upper triangle), v = [J_b (, J_a), e]
+  double * part = a.partials + static_cast<size_t>(f) * kPhotoPartial;
+  int ent = 0;
+  for (int r = 0; r < NV; ++r)
+    for (int c = r; c < NV; ++c) {
+      const double s = wave_sum(row[r] * row[c]);
+      if (lane == 0) part[ent] = s;
+      ++ent;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 g1(int n) { return dim3((n + kT - 1) / kT); }
+
+hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
+                                uint8_t * yaw_valid, float * intensity, float * range, uint8_t * mask, int32_t * idx,
+                                hipStream_t stream)
+{
+  if (n > 0) hipLaunchKernelGGL(photo_scatter_kernel, g1(n), dim3(kT), 0, stream, m, raw, desk, n, yaw, yaw_valid, intensity, range, mask, idx);
+  return hipGetLastError();
+}
+hipError_t launch_photo_yaw_fill(const PhotoModel & m, float * yaw, const uint8_t * yaw_valid, hipStream_t stream)
+{
+  hipLaunchKernelGGL(photo_yaw_fill_kernel, dim3(m.rows), dim3(kT), 0, stream, m, yaw, yaw_valid);
+  return hipGetLastError();
+}
+hipError_t launch_photo_project(const PhotoModel & m, const mh_point32 * desk, int n, const float * yaw, int32_t * proj,
+                                PhotoCounters * counters, hipStream_t stream)
+{
+  if (n > 0) hipLaunchKernelGGL(photo_project_kernel, g1(n), dim3(kT), 0, stream, m, desk, n, yaw, proj, counters);
+  return hipGetLastError();
+}
+hipError_t launch_photo_proj_finalize(int n_pixels, int32_t * proj, hipStream_t stream)
+{
+  hipLaunchKernelGGL(photo_proj_finalize_kernel, g1(n_pixels), dim3(kT), 0, stream, n_pixels, proj);
+  return hipGetLastError();
+}
+hipError_t launch_photo_vfir(const float * in, float * out, int rows, int cols, const float * taps, int n_taps, float scale,
+                             float gamma, hipStream_t stream)
+{
+  const dim3 grid((cols + kVT_C - 1) / kVT_C, (rows + kVT_R - 1) / kVT_R);
+  hipLaunchKernelGGL(photo_vfir_kernel, grid, dim3(kT), 0, stream, in, out, rows, cols, taps, n_taps, scale, gamma);
+  return hipGetLastError();
+}
+hipError_t launch_photo_hfir_sub(const float * hp, const float * raw_in, float * out, int rows, int cols, const float * taps,
+                                 int n_taps, float scale, float gamma, hipStream_t stream)
+{
+  const dim3 grid((cols + kHT_C - 1) / kHT_C, (rows + kHT_R - 1) / kHT_R);
+  hipLaunchKernelGGL(photo_hfir_sub_kernel, grid, dim3(kT), 0, stream, hp, raw_in, out, rows, cols, taps, n_taps, scale, gamma);
+  return hipGetLastError();
+}
+hipError_t launch_photo_scale(const float * in, float * out, int n, float scale, float gamma, hipStream_t stream)
+{
+  hipLaunchKernelGGL(photo_scale_kernel, g1(n), dim3(kT), 0, stream, in, out, n, scale, gamma);
+  return hipGetLastError();
+}
+hipError_t launch_photo_brightness(const float * in, float * out, int rows, int cols, int win_w, int win_h, hipStream_t stream)
+{
+  if (win_w > kBMaxW || win_h > kBMaxH || win_w < 1 || win_h < 1) return hipErrorInvalidValue;
+  const dim3 grid((cols + kBT_C - 1) / kBT_C, (rows + kBT_R - 1) / kBT_R);
+  hipLaunchKernelGGL(photo_brightness_kernel, grid, dim3(kT), 0, stream, in, out, rows, cols, win_w, win_h);
+  return hipGetLastError();
+}
+hipError_t launch_photo_gauss_trunc(const float * in, float * out, int rows, int cols, int do_gauss, hipStream_t stream)
+{
+  const dim3 grid((cols + kGT_C - 1) / kGT_C, (rows + kGT_R - 1) / kGT_R);
+  hipLaunchKernelGGL(photo_gauss_trunc_kernel, grid, dim3(kT), 0, stream, in, out, rows, cols, do_gauss);
+  return hipGetLastError();
+}
+hipError_t launch_photo_sobel_writeback(const float * img, float * dx, float * dy, const int32_t * idx, mh_point32 * desk,
+                                        float * intensity_out, int rows, int cols, hipStream_t stream)
+{
+  hipLaunchKernelGGL(photo_sobel_writeback_kernel, g1(rows * cols), dim3(kT), 0, stream, img, dx, dy, idx, desk, intensity_out, rows, cols);
+  return hipGetLastError();
+}
+hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out, int rows, int cols,
+                              int k, hipStream_t stream)
+{
+  if (k < 1 || k > kEMaxK) return hipErrorInvalidValue;
+  const dim3 grid((cols + kET_C - 1) / kET_C, (rows + kET_R - 1) / kET_R);
+  hipLaunchKernelGGL(photo_erode_kernel, grid, dim3(kT), 0, stream, in, static_mask, margin, out, rows, cols, k);
+  return hipGetLastError();
+}
+hipError_t launch_photo_grad(const float * dx, const float * dy, uint8_t * grad, int n, hipStream_t stream)
+{
+  hipLaunchKernelGGL(photo_grad_kernel, g1(n), dim3(kT), 0, stream, dx, dy, grad, n);
+  return hipGetLastError();
+}
+hipError_t launch_photo_linearize(const PhotoLinArgs & a, hipStream_t stream)
+{
+  if (a.n_features <= 0) return hipSuccess;
+  const int grid = (a.n_features + kFeatPerBlock - 1) / kFeatPerBlock;
+  hipLaunchKernelGGL(photo_linearize_kernel, dim3(grid), dim3(64 * kFeatPerBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mh

@@ -530,7 +530,7 @@ public:
       const double ypr_max = std::max(std::fabs(yaw), std::max(std::fabs(pitch), std::fabs(roll)));
       if (min_diff_trans > config.map_keyframe_trans_thresh)
         update_map = true;
-      else if (ypr_max > config.map_keyframe_rot_thresh_deg * M_PI / 180.0)
+      else if (ypr_max > config.map_keyframe_rot_thresh_deg * 0.017453293)  // DEG2RAD = PCL's macro (x)*0.017453293
         update_map = true;
       else
         update_map = false;

@@ -207,7 +207,7 @@ def linearize(vmap: VoxelMap, pts_xyz_f32, cfg: dict, R_src, t_src, g_unit=(0, 0
             S_tt = np.linalg.inv(H[3:, 3:] - H[3:, :3] @ np.linalg.inv(H[:3, :3]) @ H[:3, 3:])
             degen_rot, dE_rot = sqrt_eig(S_rr)
             degen_trans, dE_trans = sqrt_eig(S_tt)
-            degen_rot = np.rad2deg(degen_rot)
+            degen_rot = degen_rot * 57.29578  # RAD2DEG = PCL macro (x)*57.29578
         except np.linalg.LinAlgError:
             degen_rot = degen_trans = np.full(3, np.nan)
             dE_rot = dE_trans = np.full((3, 3), np.nan)

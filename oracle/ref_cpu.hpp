@@ -849,7 +849,7 @@ public:
     const M3 Sigma_tt = inverse(Htt - Htr * inverse(Hrr) * Hrt);
     compute_localizability(Sigma_rr, degen_rot_, degen_eig_rot_);
     compute_localizability(Sigma_tt, degen_trans_, degen_eig_trans_);
-    const double rad2deg = 180.0 / M_PI;
+    const double rad2deg = 57.29578;  // RAD2DEG is PCL's macro ((x)*57.29578), pcl/pcl_macros.h — the reference defines none
     degen_rot_ = rad2deg * degen_rot_;
 
     // :434-457 component localizabilities

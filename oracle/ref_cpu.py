@@ -68,7 +68,7 @@ def make_config(**kw) -> RegistrationConfig:
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libref_cpu.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ref_cpu_capi.cpp", "ref_cpu.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("ref_cpu_capi.cpp", "ref_cpu.hpp", "photo_ref_capi.cpp", "photo_ref.hpp")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libref_cpu.so"], stdout=subprocess.DEVNULL)
     return so

@@ -1,0 +1,274 @@
+"""-m gpu: the photometric path (BASELINE configs[3]) — Photometric::preprocess, detectFeatures,
+updateMap and PhotometricFactor::linearize through the C ABI (mh_photo_*) against the CPU oracle (oracle/photo_ref.hpp)
+on identical synthetic frames: a 128 x 1024 staggered, skewed OS0-128-style scan of a textured room."""
+import numpy as np
+import pytest
+
+from parity import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from mimosa_amd import synth_photo as sp
+
+    cfg = sp.photo_config()
+    return cfg, [sp.make_frame(cfg, k) for k in range(3)]
+
+
+def _both(ctx, cfg):
+    from mimosa_amd import capi
+    from oracle import photo_ref
+
+    return capi.Photo(ctx, cfg), photo_ref.Photo(cfg)
+
+
+def _pre(P, f):
+    return P.preprocess(f["raw"], f["deskewed"], f["unique_ns"], f["T_Le_Lt"])
+
+
+def _assert_images(g, r):
+    # integer / byte images and the f32 filter chain: bit for bit
+    for name in ("range", "mask", "idx", "intensity", "dx", "dy", "grad", "detection_mask"):
+        a, b = g.image(name), r.image(name)
+        assert np.array_equal(a, b), (name, int((a != b).sum()))
+    # yaw: atan2 evaluated in fp64 by two different libms, then rounded to f32: identical up to a handful of 1-ulp cases
+    ya, yb = g.image("yaw"), r.image("yaw")
+    bad = ya != yb
+    assert bad.sum() <= 8 and np.abs(ya - yb).max() <= 5e-7, int(bad.sum())
+    # proj_idx depends on round(project(p)): identical unless a projection sits on a rounding tie
+    pa, pb = g.image("proj_idx"), r.image("proj_idx")
+    assert (np.any(pa != pb, axis=2)).sum() <= 4
+
+
+def test_preprocess_matches_oracle(ctx, frames):
+    cfg, fr = frames
+    g, r = _both(ctx, cfg)
+    for f in fr[:2]:
+        dg, dr = _pre(g, f), _pre(r, f)
+        _assert_images(g, r)
+        assert dg.tobytes() == dr.tobytes()                     # corrected intensities written back into the cloud
+        assert not np.array_equal(dg["intensity"], f["deskewed"]["intensity"])
+    pj = g.image("proj_idx")
+    assert (pj[:, :, 0] > 1).sum() > 500 and pj[:, :, 0].max() <= 9      # duplicates exist and are capped
+    assert 0.5 < g.image("mask").mean() < 1.0
+    g.destroy()
+
+
+def _same_features(fa, fb, tol=1e-9):
+    assert len(fa) == len(fb)
+    for a, b in zip(fa, fb):
+        assert a["id"] == b["id"] and a["life_time"] == b["life_time"]
+        assert np.array_equal(a["center"], b["center"])
+        assert np.abs(a["Le_ps"] - b["Le_ps"]).max() <= tol
+        assert np.array_equal(a["intensities"], b["intensities"])
+        assert np.abs(a["psi"] - b["psi"]).max() <= tol
+        assert min(np.abs(a["normal"] - b["normal"]).max(), np.abs(a["normal"] + b["normal"]).max()) <= 1e-7
+        assert np.dot(a["normal"], b["normal"]) > 0.999                  # same "towards the sensor" orientation
+
+
+def test_detect_features_matches_oracle(ctx, frames):
+    from mimosa_amd import synth_photo as sp
+
+    cfg, fr = frames
+    g, r = _both(ctx, cfg)
+    _pre(g, fr[0]), _pre(r, fr[0])
+    for P in (g, r):
+        P.detect(25, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    assert len(g.features()) == 25
+    _same_features(g.features(), r.features())
+    for P in (g, r):                                                     # a second call keeps clear of the tracked ones
+        P.detect(35, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS[:2])
+    fa = g.features()
+    assert len(fa) == 60
+    _same_features(fa, r.features())
+    c = np.array([f["center"] for f in fa])
+    d = np.linalg.norm(c[:, None] - c[None], axis=2) + 1e9 * np.eye(len(c))
+    assert d.min() > cfg["nma_radius"] - 1                               # non-maximum suppression radius respected
+    g.destroy()
+
+
+def _assert_factor(gr, rr, gs, rs, binary=False):
+    assert np.array_equal(gr["status_hist"], rr["status_hist"]), (gr["status_hist"], rr["status_hist"])
+    assert gr["n_exceptions"] == rr["n_exceptions"]
+    assert np.array_equal(gs[0], rs[0])
+    v = gs[0] == 8
+    assert v.sum() >= 10
+    assert np.abs(gs[1][v] - rs[1][v]).max() <= 1e-8                      # new centres (sub-pixel)
+    tol = 1e-5  # north_star: within 1e-5 relative
+    assert rel(gr["H_bb"], rr["H_bb"]) <= tol and rel(gr["b_b"], rr["b_b"]) <= tol
+    assert abs(gr["f"] - rr["f"]) <= tol * abs(rr["f"])
+    if binary:
+        assert rel(gr["H_ba"], rr["H_ba"]) <= tol and rel(gr["H_aa"], rr["H_aa"]) <= tol and rel(gr["b_a"], rr["b_a"]) <= tol
+    else:
+        assert rel(gr["loc_rot_final"], rr["loc_rot_final"]) <= tol and rel(gr["loc_trans_final"], rr["loc_trans_final"]) <= tol
+    # per patch point: whitened NCC residual and Jacobian row (north_star "8x8 patch residuals + image Jacobians")
+    ga, ra = gs[2][v], rs[2][v]
+    assert np.array_equal(ga[:, :, 7], ra[:, :, 7])
+    assert rel(ga[:, :, 0], ra[:, :, 0]) <= tol
+    assert rel(ga[:, :, 1:7], ra[:, :, 1:7]) <= tol
+
+
+def _tracked(ctx, cfg, fr, n_detect=60):
+    from mimosa_amd import synth_photo as sp
+
+    g, r = _both(ctx, cfg)
+    _pre(g, fr[0]), _pre(r, fr[0])
+    for P in (g, r):
+        P.detect(n_detect, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    _pre(g, fr[1]), _pre(r, fr[1])
+    return g, r
+
+
+def test_unary_factor_parity(ctx, frames):
+    from mimosa_amd import synth
+
+    cfg, fr = frames
+    g, r = _tracked(ctx, cfg, fr)
+    gf, rf = g.make_factor(), r.make_factor()
+    poses = [(fr[1]["R_W_Be"], fr[1]["t_W_Be"]),
+             (fr[1]["R_W_Be"] @ synth.so3_exp(np.array([0.002, -0.001, 0.003])), fr[1]["t_W_Be"] + np.array([0.02, -0.01, 0.01])),
+             (fr[1]["R_W_Be"] @ synth.so3_exp(np.array([-0.004, 0.003, -0.002])), fr[1]["t_W_Be"] + np.array([-0.03, 0.02, 0.0]))]
+    for R, t in poses:
+        gr, rr = gf.linearize(R, t), rf.linearize(R, t)
+        assert rr["status_hist"][8] >= 30
+        _assert_factor(gr, rr, gf.state(), rf.state())
+    # V S V^T of Photometric::getFactors: only the degenerate directions of the geometric factor are constrained
+    V = synth.so3_exp(np.array([0.3, -0.2, 0.5]))
+    V6 = np.block([[V, np.zeros((3, 3))], [np.zeros((3, 3)), V.T]])
+    S = np.diag([1.0, 0, 1, 0, 1, 1])
+    VSVt = V6 @ S @ V6.T
+    gf2, rf2 = g.make_factor(VSVt), r.make_factor(VSVt)
+    R, t = poses[1]
+    gr, rr = gf2.linearize(R, t), rf2.linearize(R, t)
+    assert np.array_equal(gr["status_hist"], rr["status_hist"])
+    assert rel(gr["H_bb"], rr["H_bb"]) <= 1e-5 and rel(gr["b_b"], rr["b_b"]) <= 1e-5
+    for f in (gf, gf2):
+        f.destroy()
+    g.destroy()
+
+
+def test_binary_factor_parity(ctx, frames):
+    from mimosa_amd import synth
+
+    cfg, fr = frames
+    g, r = _both(ctx, cfg)
+    _pre(g, fr[0]), _pre(r, fr[0])
+    I3, z3 = np.eye(3), np.zeros(3)
+    for P in (g, r):                      # binary form: features live in the Le frame of frame a (T_W_Be = identity at detection)
+        P.detect(40, I3, z3, np.eye(3))
+    _pre(g, fr[1]), _pre(r, fr[1])
+    gf, rf = g.make_factor(binary=True), r.make_factor(binary=True)
+    Ra, ta = fr[0]["R_W_Be"], fr[0]["t_W_Be"]
+    Rb, tb = fr[1]["R_W_Be"] @ synth.so3_exp(np.array([0.001, 0.002, -0.002])), fr[1]["t_W_Be"] + np.array([0.01, 0.015, -0.005])
+    gr, rr = gf.linearize(Rb, tb, Ra, ta), rf.linearize(Rb, tb, Ra, ta)
+    _assert_factor(gr, rr, gf.state(), rf.state(), binary=True)
+    gf.destroy()
+    g.destroy()
+
+
+def test_8x8_patches_configs3(ctx):
+    """BASELINE configs[3] words the patches as 8 x 8 (the reference default is 5 x 5): 64 points per
+    feature, one wave lane each."""
+    from mimosa_amd import synth, synth_photo as sp
+
+    cfg = sp.photo_config(patch=8)
+    fr = [sp.make_frame(cfg, k) for k in range(2)]
+    g, r = _tracked(ctx, cfg, fr)
+    assert all(len(f["Le_ps"]) == 64 for f in g.features())
+    gf, rf = g.make_factor(), r.make_factor()
+    R, t = fr[1]["R_W_Be"] @ synth.so3_exp(np.array([0.002, 0.001, -0.001])), fr[1]["t_W_Be"] + np.array([0.01, 0.02, -0.01])
+    _assert_factor(gf.linearize(R, t), rf.linearize(R, t), gf.state(), rf.state())
+    gf.destroy()
+    g.destroy()
+
+
+def test_update_map_bookkeeping(ctx, frames):
+    """Photometric::updateMap over three frames: invalid features dropped, centres / life times updated, the missing
+    ones re-detected — the tracked set stays identical to the oracle's."""
+    from mimosa_amd import synth_photo as sp
+
+    cfg, fr = frames
+    g, r = _both(ctx, cfg)
+    for k, f in enumerate(fr):
+        _pre(g, f), _pre(r, f)
+        gf = rf = None
+        if g.features():
+            gf, rf = g.make_factor(), r.make_factor()
+            gr, rr = gf.linearize(f["R_W_Be"], f["t_W_Be"]), rf.linearize(f["R_W_Be"], f["t_W_Be"])
+            assert np.array_equal(gr["status_hist"], rr["status_hist"])
+        g.update_map(gf, f["R_W_Be"], f["t_W_Be"], sp.BIAS_DIRECTIONS)
+        r.update_map(rf, f["R_W_Be"], f["t_W_Be"], sp.BIAS_DIRECTIONS)
+        fa, fb = g.features(), r.features()
+        assert len(fa) == len(fb) and len(fa) > 40
+        for a, b in zip(fa, fb):
+            assert a["id"] == b["id"] and a["life_time"] == b["life_time"]
+            assert np.abs(a["center"] - b["center"]).max() <= 1e-8
+        if gf is not None:
+            gf.destroy()
+        if k == 2:
+            assert max(f_["life_time"] for f_ in fa) == 3
+    g.destroy()
+
+
+def test_ragged_inputs(ctx, frames):
+    """Empty cloud, everything out of range, an image row without a single return, too many points."""
+    from mimosa_amd import capi
+
+    cfg, fr = frames
+    g, r = _both(ctx, cfg)
+    f = fr[0]
+    e = f["raw"][:0]
+    for P in (g, r):
+        P.preprocess(e, e, f["unique_ns"], f["T_Le_Lt"])
+    _assert_images(g, r)
+    assert g.image("mask").sum() == 0
+    far = f["deskewed"].copy()
+    far["range"] = 99.0                                         # beyond range_max: no image content, yaw table still built
+    for P in (g, r):
+        P.preprocess(f["raw"], far, f["unique_ns"], f["T_Le_Lt"])
+    _assert_images(g, r)
+    keep = (f["raw"]["idx"] // cfg["cols"]) != 17                 # row 17 never returns: linear yaw ramp +pi .. -pi
+    for P in (g, r):
+        P.preprocess(f["raw"][keep], f["deskewed"][keep], f["unique_ns"], f["T_Le_Lt"])
+    _assert_images(g, r)
+    with pytest.raises(capi.MhError):
+        big = np.concatenate([f["raw"], f["raw"][:4000]])
+        g.preprocess(big, big, f["unique_ns"], f["T_Le_Lt"])
+    with pytest.raises(capi.MhError):
+        capi.Photo(ctx, dict(cfg, rotate_patch_to_align_with_gradient=1))
+    g.destroy()
+
+
+def test_preprocess_from_resident_scan(ctx, frames):
+    """mh_photo_preprocess_scan: raw cloud and deskewed cloud taken from a device-resident mh_scan."""
+    from mimosa_amd import capi, synth
+
+    cfg, fr = frames
+    f = fr[0]
+    raw = np.zeros(len(f["raw"]), dtype=synth.OUSTER_DTYPE)
+    for k in ("x", "y", "z", "intensity", "t"):
+        raw[k] = f["raw"][k]
+    # prepareInput wants the full raw grid in index order to reproduce idx = position: rebuild it with NaN holes
+    full = np.zeros(cfg["rows"] * cfg["cols"], dtype=synth.OUSTER_DTYPE)
+    full["x"] = np.nan
+    full[f["raw"]["idx"]] = raw
+    full["ring"] = (np.arange(len(full)) // cfg["cols"]).astype(np.uint16)
+    sc = capi.Scan(ctx)
+    ctx.check(ctx.L.mh_scan_keep_raw(sc.h, 1))
+    info = sc.prepare_input(full, capi.make_input_config(range_min=0.0, range_max=1000.0))
+    assert info["n_full"] == len(f["raw"])
+    uns = sc.unique_ns()
+    sel = np.searchsorted(f["unique_ns"], uns)
+    sc.deskew(f["T_Le_Lt"][sel].astype(np.float32))
+    g, g2 = capi.Photo(ctx, cfg), capi.Photo(ctx, cfg)
+    got_full = sc.points(0)                                      # deskewed on the device, intensities still raw
+    g2.preprocess_scan(sc, f["T_Le_Lt"][sel])
+    corrected = g.preprocess(f["raw"], got_full, uns, f["T_Le_Lt"][sel])  # the host-buffer entry point on the same two clouds
+    assert sc.points(0).tobytes() == corrected.tobytes()         # the resident cloud received the corrected intensities
+    for name in ("range", "mask", "idx", "intensity", "dx", "dy", "yaw", "proj_idx"):
+        assert np.array_equal(g.image(name), g2.image(name)), name
+    g.destroy()
+    g2.destroy()
+    sc.destroy()
