@@ -257,6 +257,84 @@ def main():
         for f in wf:
             f.destroy()
 
+    # Photometric path (BASELINE configs[3], row f-2): 128 x 1024 Ouster intensity image — Photometric::preprocess
+    # (image formation, yaw table, proj_idx, filter chain, Sobel, mask), detectFeatures, and the NCC patch factor
+    # (60 features, 8 x 8 = 64-point patches as configs[3] words it; the reference default 5 x 5 alongside).
+    ph_stats = None
+    if not args.profile_mode and world == 1:
+        from mimosa_amd import synth_photo as sp
+        rel = lambda a_, b_: float(np.linalg.norm(np.asarray(a_) - np.asarray(b_)) / np.linalg.norm(np.asarray(b_)))
+        ph_stats = {}
+        for patch in (8, 5):
+            pcfg = sp.photo_config(patch=patch)
+            pf = [sp.make_frame(pcfg, k) for k in range(2)]
+            G = capi.Photo(ctx, pcfg)
+            def _pre(k):
+                return G.preprocess(pf[k]["raw"], pf[k]["deskewed"], pf[k]["unique_ns"], pf[k]["T_Le_Lt"])
+            _pre(0)
+            tp = []
+            for _ in range(8):
+                ctx.synchronize()
+                a = time.perf_counter()
+                _pre(0)
+                tp.append(time.perf_counter() - a)
+            ctx.synchronize()
+            a = time.perf_counter()
+            G.detect(60, pf[0]["R_W_Be"], pf[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+            t_detect = time.perf_counter() - a
+            nfeat = len(G.features())
+            _pre(1)
+            GF = G.make_factor()
+            Rp = pf[1]["R_W_Be"] @ synth.so3_exp(np.array([0.002, -0.001, 0.003]))
+            tpp = pf[1]["t_W_Be"] + np.array([0.02, -0.01, 0.01])
+            ctx.set_profiling(1)
+            res = GF.linearize(Rp, tpp)
+            tl, kl = [], []
+            for _ in range(30):
+                ctx.synchronize()
+                a = time.perf_counter()
+                res = GF.linearize(Rp, tpp)
+                tl.append(time.perf_counter() - a)
+                kl.append(res["gpu_ms"])
+            ctx.set_profiling(False)
+            # device-resident variant: raw + deskewed clouds already on the device (mh_scan), no 8 MB upload
+            npx = pcfg["rows"] * pcfg["cols"]
+            n_pts = len(pf[0]["raw"])
+            alg_bytes = n_pts * 64 + npx * (4 * 6 + 1 + 4 * 10) + npx * 8 * 5   # clouds in, images + proj_idx out, 5 filter passes
+            entry = {"features": nfeat, "points_per_feature": patch * patch,
+                     "preprocess_ms_host_buffers": round(float(np.median(tp)) * 1e3, 4),
+                     "detect_features_ms": round(t_detect * 1e3, 3),
+                     "factor_linearize_sync_ms": round(float(np.median(tl)) * 1e3, 4),
+                     "factor_kernel_ms": round(float(np.median(kl)), 5),
+                     "factor_status_hist": [int(v) for v in res["status_hist"]],
+                     "preprocess_algorithmic_bytes": int(alg_bytes)}
+            if not args.no_cpu_baseline:
+                from oracle import photo_ref as _pr
+                O = _pr.Photo(pcfg)
+                to = []
+                for _ in range(3):
+                    a = time.perf_counter()
+                    O.preprocess(pf[0]["raw"], pf[0]["deskewed"], pf[0]["unique_ns"], pf[0]["T_Le_Lt"])
+                    to.append(time.perf_counter() - a)
+                a = time.perf_counter()
+                O.detect(60, pf[0]["R_W_Be"], pf[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+                od = time.perf_counter() - a
+                O.preprocess(pf[1]["raw"], pf[1]["deskewed"], pf[1]["unique_ns"], pf[1]["T_Le_Lt"])
+                OF = O.make_factor()
+                ol = []
+                for _ in range(5):
+                    a = time.perf_counter()
+                    ro = OF.linearize(Rp, tpp)
+                    ol.append(time.perf_counter() - a)
+                entry["cpu_oracle"] = {"preprocess_ms": round(float(np.median(to)) * 1e3, 3), "detect_features_ms": round(od * 1e3, 3),
+                                       "factor_linearize_ms": round(float(np.median(ol)) * 1e3, 4), "cores": 1,
+                                       "note": "oracle/photo_ref.hpp, single thread (the reference's photometric code is sequential)"}
+                entry["parity_vs_oracle"] = {"H_rel": rel(res["H_bb"], ro["H_bb"]),
+                                             "status_hist_equal": bool(np.array_equal(res["status_hist"], ro["status_hist"]))}
+            GF.destroy()
+            G.destroy()
+            ph_stats[f"{patch}x{patch}"] = entry
+
     # Keyframe map update (Geometric::updateMap, geometric.cpp:427-513): copy the map, insert the scan's
     # geometric subset (every 4th point, world frame), make the device mirror current.
     kf_stats = None
@@ -486,6 +564,7 @@ def main():
         "scan_frontend": fe_stats,
         "sequence_replay": rp_stats,
         "relinearize_window": win_stats,
+        "photometric": ph_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
                         "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,

@@ -304,13 +304,10 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   fr->n_points = n;
   auto * desk = static_cast<mh_point32 *>(fr->d_points.p);
   float * img_raw = static_cast<float *>(ph->d_img_raw.p);
-  MH_HIP(ctx, hipMemsetAsync(img_raw, 0, fb, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fr->d_range.p, 0, fb, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(ph->d_mask_raw.p, 0, npx, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(ph->d_yaw_valid.p, 0, npx, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fr->d_idx.p, 0xFF, static_cast<size_t>(npx) * sizeof(int32_t), ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fr->d_proj.p, 0x7F, static_cast<size_t>(npx) * mh::kPhotoDup * sizeof(int32_t), ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(ph->d_int_out.p, 0xFF, (n ? n : 1) * sizeof(float), ctx->stream));  // NaN = "this point owns no pixel"
+  MH_HIP(ctx, mh::launch_photo_clear(npx, static_cast<int>(n), img_raw, static_cast<float *>(fr->d_range.p),
+                                     static_cast<uint8_t *>(ph->d_mask_raw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
+                                     static_cast<int32_t *>(fr->d_idx.p), static_cast<int32_t *>(fr->d_proj.p),
+                                     static_cast<float *>(ph->d_int_out.p), ctx->stream));
   ph->h_counters->project_throw = ph->h_counters->pose_missing = 0;
   const int ni = static_cast<int>(n);
   MH_HIP(ctx, mh::launch_photo_scatter(m, d_raw, desk, ni, static_cast<float *>(fr->d_yaw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
@@ -949,8 +946,6 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
       MH_HIP(ctx, hipEventCreate(&f->ev[0]));
       MH_HIP(ctx, hipEventCreate(&f->ev[1]));
     }
-    MH_HIP(ctx, hipMemsetAsync(f->d_rows.p, 0, nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream));
-    MH_HIP(ctx, hipMemsetAsync(f->d_partials.p, 0, nf * mh::kPhotoPartial * sizeof(double), ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[0], ctx->stream));
     MH_HIP(ctx, mh::launch_photo_linearize(a, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[1], ctx->stream));

@@ -57,6 +57,9 @@ struct PhotoCounters
   uint32_t pad[2];
 };
 
+// frame reset: intensity / range / masks 0, idx -1, proj_idx "empty", corrected-intensity staging NaN
+hipError_t launch_photo_clear(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw, uint8_t * yaw_valid,
+                              int32_t * idx, int32_t * proj, float * int_out, hipStream_t stream);
 // preprocess stage 1 (photometric.cpp:121-130, 204-217): yaw of the raw points, image fill from the deskewed ones
 hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
                                 uint8_t * yaw_valid, float * intensity, float * range, uint8_t * mask, int32_t * idx,

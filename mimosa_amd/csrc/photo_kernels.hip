@@ -47,6 +47,24 @@ __device__ __forceinline__ float prep(float v, float scale, float gamma)
 }
 
 // ------------------------------------------------------------------------------------------------
+// frame reset: one launch instead of six memsets (each a ~4 us fill kernel of its own)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void photo_clear_kernel(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw,
+                                                          uint8_t * yaw_valid, int32_t * idx, int32_t * proj, float * int_out)
+{
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < npx) {
+    img_raw[i] = 0.f;
+    range[i] = 0.f;
+    mask_raw[i] = 0;
+    yaw_valid[i] = 0;
+    idx[i] = -1;
+  }
+  for (int k = i; k < npx * kPhotoDup; k += gridDim.x * kT) proj[k] = kProjEmpty;
+  if (i < n_pts) int_out[i] = __uint_as_float(0xFFFFFFFFu);  // NaN = "this point owns no pixel"
+}
+
+// ------------------------------------------------------------------------------------------------
 // preprocess stage 1
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void photo_scatter_kernel(const PhotoModel m, const mh_point32 * raw, const mh_point32 * desk,
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, i
 // filter chain
 // ------------------------------------------------------------------------------------------------
 // removeLines part 1 (:322-327): vertical correlation with the high-pass FIR.  Tile = 64 rows x 64 columns + halo.
-constexpr int kVT_R = 64, kVT_C = 64;
+constexpr int kVT_R = 16, kVT_C = 64;  // 8 x 16 = 128 workgroups for a 128 x 1024 image
 __global__ __launch_bounds__(kT) void photo_vfir_kernel(const float * in, float * out, int rows, int cols, const float * taps,
                                                          int n_taps, float scale, float gamma)
 {
@@ -458,6 +476,11 @@ __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(con
   if (f >= a.n_features) return;  // whole waves
   const PhotoModel & m = a.model;
   const PhotoFrameView & fr = a.frame;
+  if (a.rows_out) {  // rows of features that do not end Valid read as zero
+    double * ro = a.rows_out + (static_cast<size_t>(f) * kPhotoMaxPatch + lane) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ro[k] = 0.0;
+  }
   const int npts = a.n_pts[f];
   const bool act = lane < npts;
   const double * Lp = a.Le_ps + (static_cast<size_t>(f) * kPhotoMaxPatch + (act ? lane : 0)) * 3;
@@ -699,6 +722,13 @@ __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(con
 // ------------------------------------------------------------------------------------------------
 static inline dim3 g1(int n) { return dim3((n + kT - 1) / kT); }
 
+hipError_t launch_photo_clear(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw, uint8_t * yaw_valid,
+                              int32_t * idx, int32_t * proj, float * int_out, hipStream_t stream)
+{
+  const int n = npx > n_pts ? npx : n_pts;
+  hipLaunchKernelGGL(photo_clear_kernel, g1(n), dim3(kT), 0, stream, npx, n_pts, img_raw, range, mask_raw, yaw_valid, idx, proj, int_out);
+  return hipGetLastError();
+}
 hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
                                 uint8_t * yaw_valid, float * intensity, float * range, uint8_t * mask, int32_t * idx,
                                 hipStream_t stream)

@@ -179,7 +179,11 @@ inline bool project(const V3 & p, double uv[2], const std::vector<float> & yaw, 
   const auto & alt = c.beam_altitude_angles;
   const double th_deg = rad2deg(theta);
   const auto rit = std::upper_bound(alt.rbegin(), alt.rend(), th_deg, [](double v, float a) { return v < a; });
-  const auto greater = (rit + 1).base();
+  // DEG2RAD * RAD2DEG = 1 + 1e-8, so an angle that passed the radian bounds can lie (by < 1e-8 relative) outside the
+  // table in degrees: the reference then dereferences one element before / after the table (undefined behaviour).
+  // Defined here, and identically in the product: the table index is clamped to [0, rows - 2].
+  auto greater = rit == alt.rend() ? alt.begin() : (rit + 1).base();
+  if (greater + 1 == alt.end()) greater = alt.end() - 2;
   const auto smaller = greater + 1;
   uv[1] = static_cast<double>(greater - alt.begin());
   uv[1] += (*greater - th_deg) / (*greater - *smaller);  // float difference in the denominator, double quotient

@@ -272,3 +272,15 @@ def test_preprocess_from_resident_scan(ctx, frames):
     g.destroy()
     g2.destroy()
     sc.destroy()
+
+
+def test_hip_matches_golden_fixture(ctx):
+    """The committed fixture (generated by the independent numpy restatement) pins the HIP path as it pins the oracle."""
+    from mimosa_amd import capi
+    from photo_golden import check_against_golden, golden_case
+
+    cfg, f0, f1, g, feats = golden_case()
+    P = capi.Photo(ctx, cfg)
+    F = check_against_golden(P, cfg, f0, f1, g, feats)
+    F.destroy()
+    P.destroy()
