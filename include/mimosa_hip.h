@@ -128,10 +128,10 @@ typedef struct mh_map_stats {
   int64_t n_points;
   int64_t n_blocks;          /* 4x4x4-voxel blocks in the device block table */
   int64_t device_bytes;      /* HBM held by this map */
-  int64_t uploads;           /* number of host->device synchronisations so far */
-  int64_t upload_bytes;      /* total bytes pushed host->device */
-  int64_t delta_uploads;     /* synchronisations that moved only the touched buckets / cells / new ranges */
-  int64_t full_uploads;      /* synchronisations that re-sent the whole mirror (first one, after an LRU purge, mass edits) */
+  int64_t uploads;           /* insert calls so far */
+  int64_t upload_bytes;      /* bytes of point batches pushed host->device (nothing else ever travels) */
+  int64_t delta_uploads;     /* == uploads: an insert only ever moves its own batch */
+  int64_t full_uploads;      /* always 0 since the map is maintained on the device (kept for ABI stability) */
 } mh_map_stats;
 
 /*
@@ -188,27 +188,31 @@ int mh_timer_begin(mh_ctx * ctx);
 int mh_timer_end(mh_ctx * ctx, float * ms);
 
 /* ---- target map: IncrementalVoxelMapPCL / gtsam_points::iVox --------------------------------
- * replaces include/mimosa/lidar/incremental_voxel_map.hpp:22-54, src/lidar/incremental_voxel_map.cpp:14-62 */
+ * replaces include/mimosa/lidar/incremental_voxel_map.hpp:22-54, src/lidar/incremental_voxel_map.cpp:14-62.
+ * The map lives on the device and is maintained there: insertion (greedy first-come-first-kept per voxel, min-distance
+ * rule, per-voxel cap, voxels numbered in creation order), the LRU purge, getCloud and the copy are kernels; the
+ * host keeps counters.  Mutations are synchronous and drain the device first, so factors of any context that share
+ * the map see either the old or the new state, never a half-written one. */
 int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out); /* ctor, geometric.cpp:23-28 */
-/* IncrementalVoxelMapPCL::insert (incremental_voxel_map.cpp:19-24): greedy first-come-first-kept
- * insertion in input order (min-distance rule, per-voxel cap, LRU purge) then device sync of the
- * touched buckets.  xyz: n points, `stride_floats` floats apart (3 for packed xyz, 8 for mh_point32). */
+/* IncrementalVoxelMapPCL::insert (incremental_voxel_map.cpp:19-24).  xyz: n host points, `stride_floats` floats apart
+ * (3 for packed xyz, 8 for mh_point32).  MH_ERR_UNSUPPORTED if a point is NaN or farther than 2^20 voxels from the origin. */
 int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_floats);
-/* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by
- * Geometric::updateMap's copy-then-insert (geometric.cpp:494). */
+/* The same for a batch that is already on the map's device (d_points: device pointer).  R, t (both or neither): the
+ * f32 rigid transform p <- R p + t applied first — Geometric::updateMap's world transform (geometric.cpp:483-490),
+ * Eigen's evaluation order, no FMA. */
+int mh_map_insert_device(mh_map * map, const void * d_points, size_t n, size_t stride_floats, const float * R, const float * t);
+/* Geometric::updateMap's insert (geometric.cpp:483-495) straight from a device-resident scan: Be_cloud_ (the body-frame
+ * geometric subset of mh_scan_preprocess_geometric) transformed by T_W_Be in f32 and inserted, no host round trip. */
+int mh_map_insert_from_scan(mh_map * map, const mh_scan * scan, const float R_W_Be[9], const float t_W_Be[3]);
+/* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by Geometric::updateMap's
+ * copy-then-insert (geometric.cpp:494): device to device, both maps stay writable. */
 int mh_map_copy(const mh_map * map, mh_map ** out);
-/* Copy-then-insert without the host copy (Geometric::updateMap, geometric.cpp:494-495, replaces its map with a
- * copy and inserts into the copy; the old object lives on only through the factors that hold it).  The fork takes
- * over the source's host-side structure in O(1) and gets a device-to-device copy of its mirror; the SOURCE becomes
- * read-only: factors keep linearizing against it, mh_map_knn / mh_map_get_cloud / mh_map_get_stats keep working,
- * mh_map_insert / mh_map_copy / mh_map_fork on it fail with MH_ERR_UNSUPPORTED.  Use mh_map_copy when both maps
- * must stay writable. */
+/* Round-1 name of the cheap copy; identical to mh_map_copy now that every copy is device-to-device. */
 int mh_map_fork(mh_map * map, mh_map ** out);
 /* shared_ptr semantics: factors retain the map they were built with. */
 int mh_map_retain(mh_map * map);
 void mh_map_release(mh_map * map);
-/* Pushes pending inserts to the device mirror now (otherwise done lazily by the next linearize / knn):
- * only the touched buckets, cell words and appended ranges travel unless the voxels were renumbered. */
+/* No-op (the device arrays ARE the map); kept for callers of the round-1 interface. */
 int mh_map_sync(mh_map * map);
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out);
 /* IncrementalVoxelMapPCL::getCloud (incremental_voxel_map.cpp:34-38): all points in voxel order.

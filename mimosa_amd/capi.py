@@ -20,7 +20,7 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 EXPORTS = [
     "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
-    "mh_map_create", "mh_map_insert", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
+    "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
@@ -257,6 +257,8 @@ def load(build_if_missing: bool = True):
     L.mh_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
     L.mh_map_create.argtypes = [vp, C.POINTER(MapConfig), pvp]
     L.mh_map_insert.argtypes = [vp, vp, sz, sz]
+    L.mh_map_insert_device.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.mh_map_insert_from_scan.argtypes = [vp, vp, vp, vp]
     L.mh_map_copy.argtypes = [vp, pvp]
     L.mh_map_fork.argtypes = [vp, pvp]
     L.mh_map_retain.argtypes = [vp]
@@ -403,6 +405,11 @@ class VoxelMap:
     def insert(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         self.ctx.check(self.L.mh_map_insert(self.h, _p(xyz), xyz.shape[0], 3))
+
+    def insert_from_scan(self, scan, R_W_Be, t_W_Be):
+        R = np.ascontiguousarray(R_W_Be, np.float32)
+        t = np.ascontiguousarray(t_W_Be, np.float32)
+        self.ctx.check(self.L.mh_map_insert_from_scan(self.h, scan.h, _p(R), _p(t)))
 
     def copy(self):
         h = C.c_void_p()

@@ -82,35 +82,9 @@ __global__ __launch_bounds__(kThreads) void pack_xyz_kernel(const float4 * pts, 
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) xyz[i] = pts[2 * i];
 }
 
-// Delta upload of the voxel map (row f-1 of SURVEY.md §8): after a keyframe insert only the touched
-// buckets / cell words travel to the device.  One 64-lane wave per dirty voxel record (20 float4 + 20
-// packed words, coalesced), then one thread per changed cell word.
-__global__ __launch_bounds__(kThreads) void map_scatter_kernel(const MapScatterRecord * recs, int n_recs, float4 * buckets,
-                                                               uint32_t * qbuckets, const uint2 * cell_updates, int n_cells,
-                                                               uint32_t * cells)
-{
-  const int lane = threadIdx.x & 63, wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * kThreads) >> 6;
-  for (int r = wave; r < n_recs; r += n_waves) {
-    const MapScatterRecord & rec = recs[r];
-    const size_t base = static_cast<size_t>(rec.vid) * kBucketStride;
-    if (lane < kBucketStride) buckets[base + lane] = rec.pts[lane];
-    else if (lane < 2 * kBucketStride) qbuckets[base + lane - kBucketStride] = rec.q[lane - kBucketStride];
-  }
-  for (int i = blockIdx.x * kThreads + threadIdx.x; i < n_cells; i += gridDim.x * kThreads) cells[cell_updates[i].x] = cell_updates[i].y;
-}
-
 int grid_for(int n) { return max(1, min((n + kThreads - 1) / kThreads, 2048)); }
 }  // namespace
 
-hipError_t launch_map_scatter(const MapScatterRecord * recs, int n_recs, float4 * buckets, uint32_t * qbuckets,
-                              const uint2 * cell_updates, int n_cells, uint32_t * cells, hipStream_t stream)
-{
-  const int work = max(n_recs * 64, n_cells);
-  hipLaunchKernelGGL(map_scatter_kernel, dim3(grid_for(work)), dim3(kThreads), 0, stream, recs, n_recs, buckets, qbuckets,
-                     cell_updates, n_cells, cells);
-  return hipGetLastError();
-}
 
 hipError_t launch_deskew(mh_point32 * pts, int n, const uint32_t * unique_ns, const float * Rt12, int n_groups,
                          const float * body_Rt12, hipStream_t stream)

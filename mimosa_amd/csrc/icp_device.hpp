@@ -90,16 +90,6 @@ hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_sta
 hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
                           int32_t * found, hipStream_t stream);
 
-// map delta upload (deskew_kernels.hip): scatter dirty voxels' buckets and cell words into the device mirror
-struct MapScatterRecord
-{
-  uint32_t vid, n_pts, pad0, pad1;
-  float4 pts[kBucketStride];
-  uint32_t q[kBucketStride];
-};
-hipError_t launch_map_scatter(const MapScatterRecord * recs, int n_recs, float4 * buckets, uint32_t * qbuckets,
-                              const uint2 * cell_updates, int n_cells, uint32_t * cells, hipStream_t stream);
-
 // order_kernels.hip
 size_t order_temp_bytes(int n);
 hipError_t launch_spatial_order(const float4 * xyz_in, int n, float cell, uint32_t * keys2, uint32_t * vals, void * temp,

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include "icp_device.hpp"
+#include "map_device.hpp"
 #include "math3.hpp"
 
 namespace mh
@@ -327,13 +328,18 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
   int blk_id;
   {
+    // table entry = {key lo, key hi, block id, -}: 3 x 21-bit packed block coordinate; hi word -1 = empty slot
+    const uint64_t key = pack_coord_key(bx, by, bz);
+    const int klo = static_cast<int>(static_cast<uint32_t>(key)), khi = static_cast<int>(static_cast<uint32_t>(key >> 32));
     uint32_t h = block_hash(bx, by, bz) & map.mask;
     int4 e = map.table[h];
-    while (e.w >= 0 && !(e.x == bx && e.y == by && e.z == bz)) {  // collision: linear probe (load <= 0.5)
+    while (e.y != -1 && !(e.x == klo && e.y == khi)) {  // collision: linear probe (load <= 0.5)
       h = (h + 1) & map.mask;
       e = map.table[h];
     }
-    blk_id = e.w;
+    constexpr int kB = 1 << (kVoxCoordBits - 1 - kBlockLog2);  // block coordinates the key can hold: [-kB, kB)
+    const bool in_range = ((static_cast<uint32_t>(bx + kB) | static_cast<uint32_t>(by + kB) | static_cast<uint32_t>(bz + kB)) >> (kVoxCoordBits - kBlockLog2)) == 0u;
+    blk_id = (e.y != -1 && in_range) ? e.z : -1;
   }
   MH_STAMP(dbg, 8);
   uint32_t col[9][3];

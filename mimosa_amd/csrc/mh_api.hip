@@ -25,31 +25,6 @@
 #include "scan_device.hpp"
 #include "voxel_map.hpp"
 
-struct mh_map
-{
-  mh_ctx * ctx;
-  std::atomic<int> refs{1};
-  mh::HostVoxelMap host;
-  DevBuf d_table, d_cells, d_buckets, d_qbuckets, d_stage;
-  // what the device mirror currently holds (delta uploads append / scatter relative to this)
-  bool dev_valid = false;
-  size_t dev_n_voxels = 0, dev_n_blocks = 0, dev_table_cap = 0;
-  int64_t delta_uploads = 0, full_uploads = 0;
-  bool device_stale = true;
-  int64_t uploads = 0, upload_bytes = 0;
-  // mh_map_fork moved the host structure to the fork: this handle keeps its device mirror (factors read it)
-  // and just enough to answer stats / get_cloud
-  bool frozen = false;
-  std::vector<uint8_t> frozen_counts;
-  int64_t frozen_voxels = 0, frozen_points = 0, frozen_blocks = 0;
-  int n_off = 0;
-  int8_t off[27][3];
-  explicit mh_map(mh_ctx * c, const mh_map_config & cfg) : ctx(c), host(cfg)
-  {
-    n_off = mh::neighbor_offsets(cfg.neighbor_voxel_mode, off);
-  }
-};
-
 struct PendingCall
 {
   mh_icp_result * out;
@@ -86,134 +61,6 @@ struct mh_icp
 
 namespace
 {
-int map_sync_device(mh_map * m)
-{
-  if (!m->device_stale) return MH_OK;
-  mh_ctx * ctx = m->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
-  auto & H = m->host;
-  const size_t tb = H.table().size() * sizeof(mh::Int4);
-  const size_t cb = H.cells().size() * sizeof(uint32_t);
-  const size_t bb = H.buckets().size() * sizeof(mh::Float4);
-  const size_t qb = H.qbuckets().size() * sizeof(uint32_t);
-  // Factors on this context may still be reading the buffers: drain before touching them.
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const bool rebuilt = H.take_full_rebuild();  // LRU purge renumbered the voxels
-  const size_t n_dirty = H.dirty_voxels().size();
-  const bool delta = m->dev_valid && !rebuilt && n_dirty * 4 < H.n_voxels() + 1024;
-  const bool keep = delta;
-  MH_HIP(ctx, m->d_table.reserve(tb, ctx->stream, false));
-  MH_HIP(ctx, m->d_cells.reserve(cb ? cb : sizeof(uint32_t) * mh::kCellsPerBlock, ctx->stream, keep));
-  // one bucket of slack after the last voxel: the kernels' branch-free loads of "no survivor" / "past the end
-  // of this lane's work" slots may touch up to slot 31 of the last voxel (values unused, address must be mapped)
-  MH_HIP(ctx, m->d_buckets.reserve(bb + mh::kBucketStride * sizeof(mh::Float4), ctx->stream, keep));
-  MH_HIP(ctx, m->d_qbuckets.reserve(qb + mh::kBucketStride * sizeof(uint32_t), ctx->stream, keep));
-  int64_t moved = 0;
-  if (!delta) {
-    MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
-    if (cb) MH_HIP(ctx, hipMemcpyAsync(m->d_cells.p, H.cells().data(), cb, hipMemcpyHostToDevice, ctx->stream));
-    if (bb) MH_HIP(ctx, hipMemcpyAsync(m->d_buckets.p, H.buckets().data(), bb, hipMemcpyHostToDevice, ctx->stream));
-    if (qb) MH_HIP(ctx, hipMemcpyAsync(m->d_qbuckets.p, H.qbuckets().data(), qb, hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    moved = static_cast<int64_t>(tb + cb + bb + qb);
-    m->full_uploads++;
-  } else {
-    // (1) block table: only when blocks were added (or it was rehashed)
-    if (H.n_blocks() != m->dev_n_blocks || H.table().size() != m->dev_table_cap) {
-      MH_HIP(ctx, hipMemcpyAsync(m->d_table.p, H.table().data(), tb, hipMemcpyHostToDevice, ctx->stream));
-      moved += static_cast<int64_t>(tb);
-    }
-    // (2) appended ranges: cells of new blocks, buckets of new voxels
-    if (H.n_blocks() > m->dev_n_blocks) {
-      const size_t o = m->dev_n_blocks * mh::kCellsPerBlock, n = (H.n_blocks() - m->dev_n_blocks) * mh::kCellsPerBlock;
-      MH_HIP(ctx, hipMemcpyAsync(static_cast<uint32_t *>(m->d_cells.p) + o, H.cells().data() + o, n * sizeof(uint32_t),
-                                 hipMemcpyHostToDevice, ctx->stream));
-      moved += static_cast<int64_t>(n * sizeof(uint32_t));
-    }
-    if (H.n_voxels() > m->dev_n_voxels) {
-      const size_t o = m->dev_n_voxels * mh::kBucketStride, n = (H.n_voxels() - m->dev_n_voxels) * mh::kBucketStride;
-      MH_HIP(ctx, hipMemcpyAsync(static_cast<mh::Float4 *>(m->d_buckets.p) + o, H.buckets().data() + o, n * sizeof(mh::Float4),
-                                 hipMemcpyHostToDevice, ctx->stream));
-      MH_HIP(ctx, hipMemcpyAsync(static_cast<uint32_t *>(m->d_qbuckets.p) + o, H.qbuckets().data() + o, n * sizeof(uint32_t),
-                                 hipMemcpyHostToDevice, ctx->stream));
-      moved += static_cast<int64_t>(n * (sizeof(mh::Float4) + sizeof(uint32_t)));
-    }
-    // (3) scatter: buckets of touched OLD voxels, cell words of every touched voxel that lives in an old block.
-    //     Records are built straight into pinned memory: [records | cell updates].
-    const auto & dirty = H.dirty_voxels();
-    size_t n_recs = 0, n_cellu_max = 0;
-    for (const uint32_t vid : dirty) {
-      n_recs += vid < m->dev_n_voxels ? 1 : 0;
-      n_cellu_max += 8;
-    }
-    const size_t rb = n_recs * sizeof(mh::MapScatterRecord), rb_al = (rb + 15) & ~size_t(15);
-    const size_t need = rb_al + n_cellu_max * sizeof(uint2) + 16;
-    if (need > ctx->h_stage_cap) {
-      if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-      ctx->h_stage = nullptr;
-      ctx->h_stage_cap = 0;
-      const size_t cap = need + need / 2;
-      MH_HIP(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
-      ctx->h_stage_cap = cap;
-    }
-    auto * recs = reinterpret_cast<mh::MapScatterRecord *>(ctx->h_stage);
-    auto * cellu = reinterpret_cast<uint2 *>(static_cast<char *>(ctx->h_stage) + rb_al);
-    size_t ir = 0, ic = 0;
-    for (const uint32_t vid : dirty) {
-      const uint32_t * pos = nullptr;
-      const int np = H.voxel_cell_positions(vid, &pos);
-      for (int k = 0; k < np; ++k)
-        if (pos[k] < m->dev_n_blocks * mh::kCellsPerBlock) cellu[ic++] = make_uint2(pos[k], H.cells()[pos[k]]);
-      if (vid < m->dev_n_voxels) {
-        mh::MapScatterRecord & r = recs[ir++];
-        r.vid = vid;
-        r.n_pts = H.counts()[vid];
-        r.pad0 = r.pad1 = 0;
-        std::memcpy(r.pts, &H.buckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.pts));
-        std::memcpy(r.q, &H.qbuckets()[static_cast<size_t>(vid) * mh::kBucketStride], sizeof(r.q));
-      }
-    }
-    if (ir || ic) {
-      const size_t ub = ic * sizeof(uint2);
-      MH_HIP(ctx, m->d_stage.reserve(rb_al + ub + 16, ctx->stream, false));
-      char * st = static_cast<char *>(m->d_stage.p);
-      MH_HIP(ctx, hipMemcpyAsync(st, ctx->h_stage, rb_al + ub, hipMemcpyHostToDevice, ctx->stream));
-      MH_HIP(ctx, mh::launch_map_scatter(reinterpret_cast<const mh::MapScatterRecord *>(st), static_cast<int>(ir),
-                                         static_cast<float4 *>(m->d_buckets.p), static_cast<uint32_t *>(m->d_qbuckets.p),
-                                         reinterpret_cast<const uint2 *>(st + rb_al), static_cast<int>(ic),
-                                         static_cast<uint32_t *>(m->d_cells.p), ctx->stream));
-      moved += static_cast<int64_t>(rb + ub);
-    }
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next sync
-    m->delta_uploads++;
-  }
-  H.clear_dirty();
-  m->device_stale = false;
-  m->dev_valid = true;
-  m->dev_n_voxels = H.n_voxels();
-  m->dev_n_blocks = H.n_blocks();
-  m->dev_table_cap = H.table().size();
-  m->uploads++;
-  m->upload_bytes += moved;
-  return MH_OK;
-}
-
-mh::MapView map_view(const mh_map * m)
-{
-  mh::MapView v;
-  v.table = static_cast<const int4 *>(m->d_table.p);
-  v.cells = static_cast<const uint32_t *>(m->d_cells.p);
-  v.buckets = static_cast<const float4 *>(m->d_buckets.p);
-  v.qbuckets = static_cast<const uint4 *>(m->d_qbuckets.p);
-  v.inv_leaf = 1.0 / m->host.config().leaf_size;
-  // the mask of the table the DEVICE holds: after mh_map_fork the host structure has moved to the fork and
-  // m->host is an empty 1024-slot map, while this handle's mirror keeps its real capacity
-  v.mask = static_cast<uint32_t>(m->dev_table_cap ? m->dev_table_cap - 1 : 0);
-  v.n_off = m->n_off;
-  v.mode_idx = m->n_off == 1 ? 0 : (m->n_off == 7 ? 1 : (m->n_off == 19 ? 2 : 3));
-  return v;
-}
-
 void pose_inverse_compose(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t)
 {
   // delta = T_tgt^-1 * T_src (geometric_factor.hpp:251); unary: T_tgt = identity
@@ -429,206 +276,9 @@ int mh_timer_end(mh_ctx * ctx, float * ms)
   return MH_OK;
 }
 
-// ---- map ---------------------------------------------------------------------------------------
-int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out)
-{
-  if (!ctx || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: NULL argument");
-  *out = nullptr;
-  if (!(cfg->leaf_size > 0)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: leaf_size must be > 0");
-  if (cfg->max_points_in_cell < 1 || cfg->max_points_in_cell > mh::kBucketStride)
-    return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_create: max_points_in_cell must be in 1..20");
-  const int m = cfg->neighbor_voxel_mode;
-  if (m != 1 && m != 7 && m != 19 && m != 27)
-    return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: neighbor_voxel_mode must be 1, 7, 19 or 27");
-  if (cfg->lru_clear_cycle < 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_clear_cycle must be >= 1");
-  mh_map * map = new (std::nothrow) mh_map(ctx, *cfg);
-  if (!map) return fail(ctx, MH_ERR_OOM, "mh_map_create: host allocation failed");
-  *out = map;
-  return MH_OK;
-}
+}  // extern "C"
 
-int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_floats)
-{
-  if (!map || (!xyz && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert: NULL argument");
-  if (stride_floats < 3) return fail(map->ctx, MH_ERR_INVALID_ARG, "mh_map_insert: stride_floats must be >= 3");
-  if (map->frozen) return fail(map->ctx, MH_ERR_UNSUPPORTED, "mh_map_insert: this map was forked (mh_map_fork) and is read-only");
-  map->host.insert(xyz, n, stride_floats);
-  map->device_stale = true;
-  return MH_OK;
-}
-
-int mh_map_copy(const mh_map * src, mh_map ** out)
-{
-  if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_copy: NULL argument");
-  *out = nullptr;
-  if (src->frozen) return fail(src->ctx, MH_ERR_UNSUPPORTED, "mh_map_copy: this map was forked (mh_map_fork); copy the fork");
-  mh_map * map = new (std::nothrow) mh_map(src->ctx, src->host.config());
-  if (!map) return fail(src->ctx, MH_ERR_OOM, "mh_map_copy: host allocation failed");
-  map->host = src->host;  // deep copy of the flat arrays (multi-threaded, recycled pages: voxel_map.hpp)
-  map->device_stale = true;
-  if (src->dev_valid) {
-    // the device mirror is copied device-to-device (what it held at the source's last sync); the host
-    // copy carries the source's pending dirty list, so the next sync of the copy is a delta on top
-    mh_ctx * ctx = src->ctx;
-    MH_HIP(ctx, hipSetDevice(ctx->device));
-    auto dup = [&](const DevBuf & a, DevBuf & b) -> hipError_t {
-      if (!a.cap) return hipSuccess;
-      hipError_t e = b.reserve(a.cap, ctx->stream, false);
-      if (e != hipSuccess) return e;
-      return hipMemcpyAsync(b.p, a.p, a.cap, hipMemcpyDeviceToDevice, ctx->stream);
-    };
-    MH_HIP(ctx, dup(src->d_table, map->d_table));
-    MH_HIP(ctx, dup(src->d_cells, map->d_cells));
-    MH_HIP(ctx, dup(src->d_buckets, map->d_buckets));
-    MH_HIP(ctx, dup(src->d_qbuckets, map->d_qbuckets));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    map->dev_valid = true;
-    map->dev_n_voxels = src->dev_n_voxels;
-    map->dev_n_blocks = src->dev_n_blocks;
-    map->dev_table_cap = src->dev_table_cap;
-    map->device_stale = src->device_stale;
-  }
-  *out = map;
-  return MH_OK;
-}
-
-int mh_map_retain(mh_map * map)
-{
-  if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_retain: map is NULL");
-  map->refs.fetch_add(1);
-  return MH_OK;
-}
-
-void mh_map_release(mh_map * map)
-{
-  if (!map) return;
-  if (map->refs.fetch_sub(1) == 1) {
-    (void)hipSetDevice(map->ctx->device);
-    (void)hipStreamSynchronize(map->ctx->stream);
-    map->d_table.release();
-    map->d_cells.release();
-    map->d_buckets.release();
-    map->d_qbuckets.release();
-    map->d_stage.release();
-    delete map;
-  }
-}
-
-int mh_map_sync(mh_map * map)
-{
-  if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_sync: map is NULL");
-  return map_sync_device(map);
-}
-
-int mh_map_get_stats(const mh_map * map, mh_map_stats * out)
-{
-  if (!map || !out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_stats: NULL argument");
-  out->n_voxels = map->frozen ? map->frozen_voxels : static_cast<int64_t>(map->host.n_voxels());
-  out->n_points = map->frozen ? map->frozen_points : static_cast<int64_t>(map->host.n_points());
-  out->n_blocks = map->frozen ? map->frozen_blocks : static_cast<int64_t>(map->host.n_blocks());
-  out->device_bytes = static_cast<int64_t>(map->d_table.cap + map->d_cells.cap + map->d_buckets.cap + map->d_qbuckets.cap);
-  out->uploads = map->uploads;
-  out->upload_bytes = map->upload_bytes;
-  out->delta_uploads = map->delta_uploads;
-  out->full_uploads = map->full_uploads;
-  return MH_OK;
-}
-
-int mh_map_get_cloud(const mh_map * map, float * xyz, size_t capacity_points, size_t * n_out)
-{
-  if (!map || !n_out) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_get_cloud: NULL argument");
-  if (!map->frozen) {
-    *n_out = map->host.get_cloud(xyz, capacity_points);
-    return MH_OK;
-  }
-  // forked source: the points live in the device mirror only; the per-voxel counts were kept
-  *n_out = static_cast<size_t>(map->frozen_points);
-  if (!xyz || map->frozen_points == 0) return MH_OK;
-  mh_ctx * ctx = map->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
-  std::vector<mh::Float4> b(map->frozen_counts.size() * mh::kBucketStride);
-  MH_HIP(ctx, hipMemcpy(b.data(), map->d_buckets.p, b.size() * sizeof(mh::Float4), hipMemcpyDeviceToHost));
-  size_t n = 0;
-  for (size_t v = 0; v < map->frozen_counts.size(); ++v)
-    for (size_t j = 0; j < map->frozen_counts[v]; ++j, ++n)
-      if (n < capacity_points) {
-        const mh::Float4 & p = b[v * mh::kBucketStride + j];
-        xyz[3 * n + 0] = p.x;
-        xyz[3 * n + 1] = p.y;
-        xyz[3 * n + 2] = p.z;
-      }
-  return MH_OK;
-}
-
-int mh_map_fork(mh_map * src, mh_map ** out)
-{
-  if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_fork: NULL argument");
-  *out = nullptr;
-  mh_ctx * ctx = src->ctx;
-  if (src->frozen) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_fork: this map was already forked; fork the fork");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = map_sync_device(src);  // the source keeps nothing but its device mirror: make it current first
-  if (rc != MH_OK) return rc;
-  mh_map * map = new (std::nothrow) mh_map(ctx, src->host.config());
-  if (!map) return fail(ctx, MH_ERR_OOM, "mh_map_fork: host allocation failed");
-  // device mirror: device-to-device copy, as in mh_map_copy
-  auto dup = [&](const DevBuf & a, DevBuf & b) -> hipError_t {
-    if (!a.cap) return hipSuccess;
-    hipError_t e = b.reserve(a.cap, ctx->stream, false);
-    if (e != hipSuccess) return e;
-    return hipMemcpyAsync(b.p, a.p, a.cap, hipMemcpyDeviceToDevice, ctx->stream);
-  };
-  hipError_t e = dup(src->d_table, map->d_table);
-  if (e == hipSuccess) e = dup(src->d_cells, map->d_cells);
-  if (e == hipSuccess) e = dup(src->d_buckets, map->d_buckets);
-  if (e == hipSuccess) e = dup(src->d_qbuckets, map->d_qbuckets);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    mh_map_release(map);
-    return hip_fail(ctx, e, "mh_map_fork: device mirror copy");
-  }
-  map->dev_valid = src->dev_valid;
-  map->dev_n_voxels = src->dev_n_voxels;
-  map->dev_n_blocks = src->dev_n_blocks;
-  map->dev_table_cap = src->dev_table_cap;
-  map->device_stale = false;
-  // host structure: moved, not copied
-  src->frozen_counts = src->host.counts();
-  src->frozen_voxels = static_cast<int64_t>(src->host.n_voxels());
-  src->frozen_points = static_cast<int64_t>(src->host.n_points());
-  src->frozen_blocks = static_cast<int64_t>(src->host.n_blocks());
-  map->host.take_from(src->host);
-  src->frozen = true;
-  *out = map;
-  return MH_OK;
-}
-
-int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * point_xyz, double * sq_dists,
-               int32_t * found)
-{
-  if (!map || !queries || !point_xyz || !sq_dists || !found)
-    return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_knn: NULL argument");
-  if (k < 1 || k > 8) return fail(map->ctx, MH_ERR_UNSUPPORTED, "mh_map_knn: k must be in 1..8");
-  mh_ctx * ctx = map->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
-  const int rc = map_sync_device(map);
-  if (rc != MH_OK) return rc;
-  if (n == 0) return MH_OK;
-  DevTemp<double> d_q, d_p, d_s;
-  DevTemp<int32_t> d_f;
-  MH_HIP(ctx, d_q.alloc(n * 3 * sizeof(double)));
-  MH_HIP(ctx, d_p.alloc(n * k * 3 * sizeof(double)));
-  MH_HIP(ctx, d_s.alloc(n * k * sizeof(double)));
-  MH_HIP(ctx, d_f.alloc(n * sizeof(int32_t)));
-  MH_HIP(ctx, hipMemcpyAsync(d_q, queries, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  MH_HIP(ctx, mh::launch_map_knn(map_view(map), d_q, static_cast<int>(n), k, d_p, d_s, d_f, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(point_xyz, d_p, n * k * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(sq_dists, d_s, n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(found, d_f, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MH_OK;
-}
-
+extern "C" {
 // ---- factor ------------------------------------------------------------------------------------
 static int icp_alloc(mh_icp * icp)
 {
@@ -851,8 +501,6 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   if (icp->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize: binary factor needs the target pose");
   if (icp->n_pending >= kMaxPending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_async: too many calls in flight");
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = map_sync_device(icp->map);
-  if (rc != MH_OK) return rc;
   if (ctx->profiling && !icp->events_ready) {
     for (auto & ev : icp->events)
       for (auto & e : ev) MH_HIP(ctx, hipEventCreate(&e));

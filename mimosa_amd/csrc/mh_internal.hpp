@@ -14,6 +14,10 @@
 #include <vector>
 
 #include "../../include/mimosa_hip.h"
+#include <atomic>
+
+#include "icp_device.hpp"
+#include "map_device.hpp"
 #include "scan_device.hpp"
 
 inline thread_local std::string g_mh_err;
@@ -238,3 +242,40 @@ struct mh_scan
   size_t n_in = 0, n_body = 0;
   bool prepared = false, preprocessed = false;
 };
+
+// IncrementalVoxelMapPCL counterpart: the device-resident voxel map (map_device.hpp / map_kernels.hip).  The device
+// arrays ARE the map; the host keeps counters only (refreshed from the mapped state after every mutation).
+struct mh_map
+{
+  mh_ctx * ctx = nullptr;
+  std::atomic<int> refs{1};
+  mh_map_config cfg{};
+  double inv_leaf = 0, min_sq = 0;
+  DevBuf d_table, d_cells, d_buckets, d_qbuckets, d_vox, d_lru;
+  size_t table_cap = 0, vox_cap = 0, block_cap = 0;  // capacities in entries (table slots, voxels, blocks)
+  mh::MapState * d_state = nullptr;                  // device counters the kernels maintain
+  mh::MapState * h_state = nullptr;                  // pinned host copy
+  uint32_t n_voxels = 0, n_blocks = 0;
+  uint64_t n_points = 0, lru_counter = 0;
+  // insert scratch (grown on demand, reused)
+  DevBuf s_in, s_pts, s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_flags, s_pos, s_seg_start, s_seg_vid, s_newflag, s_newrank, s_temp, s_rt;
+  void * h_in = nullptr;  // pinned staging of a host batch
+  size_t h_in_cap = 0;
+  int64_t inserts = 0, upload_bytes = 0, purges = 0;
+  int n_off = 0;
+  int8_t off[27][3];
+};
+
+inline mh::MapView map_view(const mh_map * m)
+{
+  mh::MapView v;
+  v.table = static_cast<const int4 *>(m->d_table.p);
+  v.cells = static_cast<const uint32_t *>(m->d_cells.p);
+  v.buckets = static_cast<const float4 *>(m->d_buckets.p);
+  v.qbuckets = static_cast<const uint4 *>(m->d_qbuckets.p);
+  v.inv_leaf = m->inv_leaf;
+  v.mask = static_cast<uint32_t>(m->table_cap - 1);
+  v.n_off = m->n_off;
+  v.mode_idx = m->n_off == 1 ? 0 : (m->n_off == 7 ? 1 : (m->n_off == 19 ? 2 : 3));
+  return v;
+}

@@ -547,7 +547,7 @@ public:
     for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
     for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
     if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
-    ivox_map_ = ivox_map_->fork();  // the previous map lives on, read-only, in the factors that hold it
+    ivox_map_ = ivox_map_->fork();  // device-to-device copy; the previous map lives on in the factors that hold it
     ivox_map_->insert(W);
     map_poses_.push_back(T_W_Be);
   }

@@ -111,11 +111,10 @@ class HipBackend:
         return b
 
     def update_map(self, body, R, t):
-        # Geometric::updateMap: world transform in f32 (geometric.cpp:483-490), copy-then-insert (:494-495)
-        W = self.ctx.transform_f32(body, R.astype(np.float32), t.astype(np.float32))
-        new = self.map.fork()  # the old map stays valid (read-only) for the factors that hold it
-        new.insert(np.stack([W["x"], W["y"], W["z"]], 1))
-        new.sync()
+        # Geometric::updateMap: copy-then-insert (geometric.cpp:494-495) with the f32 world transform (:483-490) applied
+        # on the device to the resident Be_cloud_: nothing crosses PCIe, the old map stays valid for the factors holding it
+        new = self.map.copy()
+        new.insert_from_scan(self.scan, R, t)
         self.map.release()
         self.map = new
 

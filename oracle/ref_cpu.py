@@ -81,6 +81,7 @@ def lib():
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.ref_map_create.restype = vp
         L.ref_map_create.argtypes = [dbl, dbl, C.c_int, C.c_int, C.c_int]
+        L.ref_map_set_lru_clear_cycle.argtypes = [vp, C.c_int]
         L.ref_map_copy.restype = vp
         L.ref_map_copy.argtypes = [vp]
         L.ref_map_destroy.argtypes = [vp]
@@ -129,6 +130,9 @@ class Map:
 
     def copy(self):
         return Map(_h=self.L.ref_map_copy(self.h))
+
+    def set_lru_clear_cycle(self, cycle: int):
+        self.L.ref_map_set_lru_clear_cycle(self.h, int(cycle))
 
     def insert(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

@@ -40,6 +40,7 @@ ref_map * ref_map_create(double leaf, double min_dist_in_cell, int max_pts, int 
   m->ivox->set_lru_horizon(static_cast<size_t>(lru_horizon));
   return m;
 }
+void ref_map_set_lru_clear_cycle(ref_map * m, int cycle) { m->ivox->set_lru_clear_cycle(static_cast<size_t>(cycle)); }
 // Geometric::updateMap's "copy then insert" (geometric.cpp:494): shallow-per-voxel copy.
 ref_map * ref_map_copy(const ref_map * o)
 {
