@@ -14,19 +14,6 @@
 
 namespace
 {
-template <typename E>
-int guarded(mh_ctx * ctx, const char * what, E && body)
-{
-  try {
-    return body();
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, MH_ERR_OOM, std::string(what) + ": host allocation failed");
-  } catch (const std::exception & e) {
-    return fail(ctx, MH_ERR_HIP, std::string(what) + ": " + e.what());
-  } catch (...) {
-    return fail(ctx, MH_ERR_HIP, std::string(what) + ": unknown exception");
-  }
-}
 
 mh::MapArrays arrays_of(const mh_map * m)
 {

@@ -205,7 +205,7 @@ int mh_abi_version(void) { return MH_ABI_VERSION; }
 
 const char * mh_last_error(const mh_ctx * ctx) { return ctx ? ctx->err.c_str() : g_mh_err.c_str(); }
 
-int mh_init(int device, mh_ctx ** out)
+static int mh_init_impl(int device, mh_ctx ** out)
 {
   if (!out) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init: out is NULL");
   *out = nullptr;
@@ -214,6 +214,13 @@ int mh_init(int device, mh_ctx ** out)
   if (e != hipSuccess || count <= 0)
     return fail(nullptr, MH_ERR_NO_DEVICE, "mh_init: no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= count) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init: device index out of range");
+  {
+    // the kernels are gfx950 code objects (wave64, DPP, s_memtime, agent-scope write-through hand-offs): refuse anything else
+    hipDeviceProp_t prop;
+    MH_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(nullptr, MH_ERR_NO_DEVICE, std::string("mh_init: device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+  }
   MH_HIP(nullptr, hipSetDevice(device));
   mh_ctx * ctx = new (std::nothrow) mh_ctx;
   if (!ctx) return fail(nullptr, MH_ERR_OOM, "mh_init: host allocation failed");
@@ -223,6 +230,10 @@ int mh_init(int device, mh_ctx ** out)
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[1]));
   *out = ctx;
   return MH_OK;
+}
+int mh_init(int device, mh_ctx ** out)
+{
+  return guarded(nullptr, "mh_init", [&]() -> int { return mh_init_impl(device, out); });
 }
 
 void mh_shutdown(mh_ctx * ctx)
@@ -241,32 +252,44 @@ void mh_shutdown(mh_ctx * ctx)
   delete ctx;
 }
 
-int mh_set_profiling(mh_ctx * ctx, int on)
+static int mh_set_profiling_impl(mh_ctx * ctx, int on)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_set_profiling: ctx is NULL");
   ctx->profiling = on < 0 ? 0 : on;
   return MH_OK;
 }
+int mh_set_profiling(mh_ctx * ctx, int on)
+{
+  return guarded(nullptr, "mh_set_profiling", [&]() -> int { return mh_set_profiling_impl(ctx, on); });
+}
 
 void * mh_stream(mh_ctx * ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 
-int mh_synchronize(mh_ctx * ctx)
+static int mh_synchronize_impl(mh_ctx * ctx)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_synchronize: ctx is NULL");
   MH_HIP(ctx, hipSetDevice(ctx->device));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_synchronize(mh_ctx * ctx)
+{
+  return guarded(nullptr, "mh_synchronize", [&]() -> int { return mh_synchronize_impl(ctx); });
+}
 
-int mh_timer_begin(mh_ctx * ctx)
+static int mh_timer_begin_impl(mh_ctx * ctx)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_timer_begin: ctx is NULL");
   MH_HIP(ctx, hipSetDevice(ctx->device));
   MH_HIP(ctx, hipEventRecord(ctx->timer[0], ctx->stream));
   return MH_OK;
 }
+int mh_timer_begin(mh_ctx * ctx)
+{
+  return guarded(nullptr, "mh_timer_begin", [&]() -> int { return mh_timer_begin_impl(ctx); });
+}
 
-int mh_timer_end(mh_ctx * ctx, float * ms)
+static int mh_timer_end_impl(mh_ctx * ctx, float * ms)
 {
   if (!ctx || !ms) return fail(ctx, MH_ERR_INVALID_ARG, "mh_timer_end: NULL argument");
   MH_HIP(ctx, hipSetDevice(ctx->device));
@@ -274,6 +297,10 @@ int mh_timer_end(mh_ctx * ctx, float * ms)
   MH_HIP(ctx, hipEventSynchronize(ctx->timer[1]));
   MH_HIP(ctx, hipEventElapsedTime(ms, ctx->timer[0], ctx->timer[1]));
   return MH_OK;
+}
+int mh_timer_end(mh_ctx * ctx, float * ms)
+{
+  return guarded(nullptr, "mh_timer_end", [&]() -> int { return mh_timer_end_impl(ctx, ms); });
 }
 
 }  // extern "C"
@@ -388,14 +415,19 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   return MH_OK;
 }
 
-int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
+static int mh_icp_create_impl(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
                   int is_binary, mh_icp ** out)
 {
   if (!ctx || !map || !cfg || !out || (!source && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: NULL argument");
   return icp_create_common(ctx, map, source, nullptr, n, cfg, is_binary, out);
 }
+int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
+                  int is_binary, mh_icp ** out)
+{
+  return guarded(nullptr, "mh_icp_create", [&]() -> int { return mh_icp_create_impl(ctx, map, source, n, cfg, is_binary, out); });
+}
 
-int mh_icp_clone(const mh_icp * src, mh_icp ** out)
+static int mh_icp_clone_impl(const mh_icp * src, mh_icp ** out)
 {
   if (!src || !out) return fail(src ? src->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_clone: NULL argument");
   *out = nullptr;
@@ -436,6 +468,10 @@ int mh_icp_clone(const mh_icp * src, mh_icp ** out)
   icp->linearize_count = src->linearize_count;
   *out = icp;
   return MH_OK;
+}
+int mh_icp_clone(const mh_icp * src, mh_icp ** out)
+{
+  return guarded(nullptr, "mh_icp_clone", [&]() -> int { return mh_icp_clone_impl(src, out); });
 }
 
 void mh_icp_destroy(mh_icp * icp)
@@ -480,11 +516,15 @@ int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_word
 }
 #endif
 
-int mh_icp_reset(mh_icp * icp)
+static int mh_icp_reset_impl(mh_icp * icp)
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_reset: icp is NULL");
   icp->cold = true;  // the next linearize treats the cached state as all-zero (no memset needed)
   return MH_OK;
+}
+int mh_icp_reset(mh_icp * icp)
+{
+  return guarded(nullptr, "mh_icp_reset", [&]() -> int { return mh_icp_reset_impl(icp); });
 }
 
 // Argument blocks of one linearize call of `icp` in pending slot n_pending (which it claims): everything of
@@ -603,13 +643,18 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   return MH_OK;
 }
 
-int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+static int mh_icp_linearize_async_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                            const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
   return linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, false);
 }
+int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+{
+  return guarded(nullptr, "mh_icp_linearize_async", [&]() -> int { return mh_icp_linearize_async_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
+}
 
-int mh_icp_wait(mh_icp * icp)
+static int mh_icp_wait_impl(mh_icp * icp)
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
   mh_ctx * ctx = icp->ctx;
@@ -653,13 +698,22 @@ int mh_icp_wait(mh_icp * icp)
   icp->n_pending = 0;
   return MH_OK;
 }
+int mh_icp_wait(mh_icp * icp)
+{
+  return guarded(nullptr, "mh_icp_wait", [&]() -> int { return mh_icp_wait_impl(icp); });
+}
 
-int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+static int mh_icp_linearize_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                      const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
   const int rc = linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, icp && icp->n_pending == 0);
   if (rc != MH_OK) return rc;
   return mh_icp_wait(icp);
+}
+int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                     const double * t_tgt, const double g_unit[3], mh_icp_result * out)
+{
+  return guarded(nullptr, "mh_icp_linearize", [&]() -> int { return mh_icp_linearize_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
 }
 
 // ---- all live factors of the sliding window in two launches ------------------------------------------------
@@ -667,7 +721,7 @@ int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3],
 // re-linearize EVERY live ICPFactor whose pose moved; GTSAM calls them one after the other.  Here one K3 grid
 // and one K4 grid cover all of them (each factor keeps its own partial rows / ticket / fold: bit-identical to
 // separate calls), so the machine sees sum(n_i) points at once instead of 10-25 k.
-int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out)
 {
   if (!icps || !n_factors || !R_src || !t_src || !g_unit || !out)
@@ -770,10 +824,15 @@ int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double
   }
   return rc_all;
 }
+int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+                           const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out)
+{
+  return guarded(nullptr, "mh_icp_linearize_batch", [&]() -> int { return mh_icp_linearize_batch_impl(icps, n_factors, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
+}
 
 // ---- two-phase form for map-sharded factors (mimosa_amd/dist.py): the Hessian sums of all shards are
 // all-reduced between the two phases and the component-localizability pass runs in the GLOBAL eigenbasis.
-int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+static int mh_icp_linearize_begin_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                            const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
 {
   if (!icp || !partial) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin: NULL argument");
@@ -784,8 +843,13 @@ int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_s
   icp->split_open = true;
   return MH_OK;
 }
+int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
+{
+  return guarded(nullptr, "mh_icp_linearize_begin", [&]() -> int { return mh_icp_linearize_begin_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial); });
+}
 
-int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
+static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
                             double loc_rot_comp[3], int32_t status_hist[9])
 {
   if (!icp || !eigvec_rot || !eigvec_trans || !loc_trans_comp || !loc_rot_comp)
@@ -826,8 +890,13 @@ int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const doub
     for (int i = 0; i < 9; ++i) status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
   return MH_OK;
 }
+int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
+                            double loc_rot_comp[3], int32_t status_hist[9])
+{
+  return guarded(nullptr, "mh_icp_linearize_finish", [&]() -> int { return mh_icp_linearize_finish_impl(icp, eigvec_rot, eigvec_trans, loc_trans_comp, loc_rot_comp, status_hist); });
+}
 
-int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals)
+static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * means, double * normals)
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_get_state: icp is NULL");
   mh_ctx * ctx = icp->ctx;
@@ -855,9 +924,13 @@ int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, doubl
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals)
+{
+  return guarded(nullptr, "mh_icp_get_state", [&]() -> int { return mh_icp_get_state_impl(icp, status, means, normals); });
+}
 
 // ---- deskew / transforms -----------------------------------------------------------------------
-int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns, const float * Rt12, size_t n_groups,
+static int mh_deskew_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns, const float * Rt12, size_t n_groups,
               const float * R_B_L, const float * t_B_L)
 {
   if (!ctx || (!pts && n) || (!unique_ns && n_groups) || (!Rt12 && n_groups))
@@ -889,8 +962,13 @@ int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns, const float * Rt12, size_t n_groups,
+              const float * R_B_L, const float * t_B_L)
+{
+  return guarded(nullptr, "mh_deskew", [&]() -> int { return mh_deskew_impl(ctx, pts, n, unique_ns, Rt12, n_groups, R_B_L, t_B_L); });
+}
 
-int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
+static int mh_transform_f32_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
 {
   if (!ctx || (!pts && n) || !R || !t) return fail(ctx, MH_ERR_INVALID_ARG, "mh_transform_f32: NULL argument");
   if (n == 0) return MH_OK;
@@ -909,6 +987,10 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
   MH_HIP(ctx, hipMemcpyAsync(pts, d_pts, n * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
+}
+int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
+{
+  return guarded(nullptr, "mh_transform_f32", [&]() -> int { return mh_transform_f32_impl(ctx, pts, n, R, t); });
 }
 
 }  // extern "C"
@@ -940,7 +1022,7 @@ void scan_fill_info(const mh_scan * s, mh_scan_info * info)
 
 extern "C" {
 
-int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
+static int mh_scan_create_impl(mh_ctx * ctx, mh_scan ** out)
 {
   if (!ctx || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_create: NULL argument");
   *out = nullptr;
@@ -949,6 +1031,10 @@ int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
   s->ctx = ctx;
   *out = s;
   return MH_OK;
+}
+int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
+{
+  return guarded(nullptr, "mh_scan_create", [&]() -> int { return mh_scan_create_impl(ctx, out); });
 }
 
 void mh_scan_destroy(mh_scan * s)
@@ -964,7 +1050,7 @@ void mh_scan_destroy(mh_scan * s)
   delete s;
 }
 
-int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
+static int mh_scan_prepare_input_impl(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
 {
   if (!s || !cfg || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -999,8 +1085,12 @@ int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, co
   scan_fill_info(s, info);
   return MH_OK;
 }
+int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
+{
+  return guarded(nullptr, "mh_scan_prepare_input", [&]() -> int { return mh_scan_prepare_input_impl(s, raw, n, cfg, info); });
+}
 
-int mh_scan_get_unique_ns(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
+static int mh_scan_get_unique_ns_impl(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
 {
   if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_unique_ns: NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -1013,8 +1103,12 @@ int mh_scan_get_unique_ns(const mh_scan * s, uint32_t * out, size_t capacity, si
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_scan_get_unique_ns(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
+{
+  return guarded(nullptr, "mh_scan_get_unique_ns", [&]() -> int { return mh_scan_get_unique_ns_impl(s, out, capacity, n_out); });
+}
 
-int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
+static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
 {
   if (!s || (!Rt12 && n_groups)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_deskew: NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -1036,8 +1130,12 @@ int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
   s->preprocessed = false;
   return MH_OK;
 }
+int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
+{
+  return guarded(nullptr, "mh_scan_deskew", [&]() -> int { return mh_scan_deskew_impl(s, Rt12, n_groups); });
+}
 
-int mh_scan_preprocess_geometric(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
+static int mh_scan_preprocess_geometric_impl(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
                                  int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info)
 {
   if (!s || !R_B_L || !t_B_L) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_preprocess_geometric: NULL argument");
@@ -1082,8 +1180,13 @@ int mh_scan_preprocess_geometric(mh_scan * s, const float R_B_L[9], const float 
   scan_fill_info(s, info);
   return MH_OK;
 }
+int mh_scan_preprocess_geometric(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
+                                 int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info)
+{
+  return guarded(nullptr, "mh_scan_preprocess_geometric", [&]() -> int { return mh_scan_preprocess_geometric_impl(s, R_B_L, t_B_L, leaf_size, max_points_per_voxel, min_dist_in_voxel, info); });
+}
 
-int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
+static int mh_scan_get_points_impl(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
 {
   if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_points: NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -1098,8 +1201,12 @@ int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t ca
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
+{
+  return guarded(nullptr, "mh_scan_get_points", [&]() -> int { return mh_scan_get_points_impl(s, which, out, capacity, n_out); });
+}
 
-int mh_scan_get_indices(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
+static int mh_scan_get_indices_impl(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
 {
   if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_indices: NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -1114,8 +1221,12 @@ int mh_scan_get_indices(const mh_scan * s, int which, uint32_t * out, size_t cap
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
+int mh_scan_get_indices(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
+{
+  return guarded(nullptr, "mh_scan_get_indices", [&]() -> int { return mh_scan_get_indices_impl(s, which, out, capacity, n_out); });
+}
 
-int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
+static int mh_icp_create_from_scan_impl(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
                             mh_icp ** out)
 {
   if (!ctx || !map || !s || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: NULL argument");
@@ -1124,6 +1235,11 @@ int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const
   // the scan's stream has been synchronised by mh_scan_preprocess_geometric: its buffers are complete
   return icp_create_common(ctx, map, nullptr, static_cast<const mh_point32 *>(s->d_ds.p), s->c.n_downsampled, cfg, is_binary,
                            out);
+}
+int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
+                            mh_icp ** out)
+{
+  return guarded(nullptr, "mh_icp_create_from_scan", [&]() -> int { return mh_icp_create_from_scan_impl(ctx, map, s, cfg, is_binary, out); });
 }
 
 }  // extern "C"

@@ -48,6 +48,20 @@ inline int hip_fail(const mh_ctx * ctx, hipError_t e, const char * what)
   const int code = (e == hipErrorOutOfMemory) ? MH_ERR_OOM : (e == hipErrorNoDevice ? MH_ERR_NO_DEVICE : MH_ERR_HIP);
   return fail(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
 }
+// Nothing throws across the C boundary (include/mimosa_hip.h): every extern "C" body runs inside this.
+template <typename E>
+inline int guarded(const mh_ctx * ctx, const char * what, E && body)
+{
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, MH_ERR_OOM, std::string(what) + ": host allocation failed");
+  } catch (const std::exception & e) {
+    return fail(ctx, MH_ERR_HIP, std::string(what) + ": " + e.what());
+  } catch (...) {
+    return fail(ctx, MH_ERR_HIP, std::string(what) + ": unknown exception");
+  }
+}
 #define MH_HIP(ctx, call)                                   \
   do {                                                      \
     const hipError_t e_ = (call);                           \

@@ -53,19 +53,6 @@ struct HostFeature
   std::vector<double> Le_ps, intensities, psi;
 };
 
-template <typename E>
-int guarded(mh_ctx * ctx, const char * what, E && body)
-{
-  try {
-    return body();
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, MH_ERR_OOM, std::string(what) + ": host allocation failed");
-  } catch (const std::exception & e) {
-    return fail(ctx, MH_ERR_HIP, std::string(what) + ": " + e.what());
-  } catch (...) {
-    return fail(ctx, MH_ERR_HIP, std::string(what) + ": unknown exception");
-  }
-}
 }  // namespace
 
 struct mh_photo
