@@ -447,6 +447,50 @@ int mh_photo_factor_linearize(mh_photo_factor * factor, const double R_b[9], con
 int mh_photo_factor_get_state(const mh_photo_factor * factor, int32_t * statuses, double * centers, double * rows);
 size_t mh_photo_factor_size(const mh_photo_factor * factor);
 
+
+/* ---- map sharded across GPUs (BASELINE configs[2]) ------------------------------------------------
+ * No reference counterpart: the reference is single-process.  One process per GPU; the map is partitioned into shard
+ * blocks of 2^block_log2 voxels per axis owned by XORVector3iHash(block) mod world (the reference's hash,
+ * include/mimosa/lidar/utils.hpp:228-238), every rank also stores the one-voxel halo of its blocks, and every source
+ * point is linearized on the rank that owns the centre voxel of its CURRENT position — so the sharded factor equals the
+ * unsharded ICPFactor::linearize (geometric_factor.hpp:231-562) point for point.  The exchange between ranks (the
+ * all-to-all of migrating points, two small all-reduces) is the caller's, e.g. torch.distributed over RCCL / xGMI:
+ * these entry points produce and consume plain DEVICE buffers and enqueue on the context stream without waiting.
+ *
+ * Per linearize:  mh_icp_shard_plan -> (all-to-all of the counts) -> mh_icp_shard_pack -> (all-to-all of 112-byte records)
+ * -> mh_icp_shard_unpack -> mh_icp_linearize_begin_device -> (all-reduce 32 doubles) -> mh_icp_linearize_finish_device
+ * -> (all-reduce 16 doubles) -> mh_icp_global_epilogue. */
+#define MH_SHARD_RECORD_BYTES 112
+/* A context on an existing HIP stream (not owned): kernels, the caller's collectives and its tensor ops are ordered by it. */
+int mh_init_on_stream(int device, void * hip_stream, mh_ctx ** out);
+/* This rank's share of IncrementalVoxelMapPCL::insert: of the batch (identical on every rank) the points of owned shard
+ * blocks plus their one-voxel halo are inserted, in the original order. */
+int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride_floats, int world, int rank, int block_log2);
+/* ICPFactor ctor (geometric_factor.hpp:119-142) from a cloud that is already on the device; the point order is kept. */
+int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg,
+                              int is_binary, mh_icp ** out);
+/* Which local points belong to another rank at this pose (owner of the centre voxel of T_tgt^-1 T_src p)?
+ * send_counts[world] receives how many leave for each rank.  Blocks until the counts are on the host. */
+int mh_icp_shard_plan(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt,
+                      int world, int rank, int block_log2, int64_t * send_counts);
+/* Writes the leaving points WITH their data-association state (q_da, mean, normal, status: the DA cache of
+ * geometric_factor.hpp:279-317 travels with the point) to d_send — sum(send_counts) records of MH_SHARD_RECORD_BYTES,
+ * grouped by destination rank — and removes them from the factor (the rest keeps its order). */
+int mh_icp_shard_pack(mh_icp * icp, void * d_send);
+/* Appends n_recv arriving records. */
+int mh_icp_shard_unpack(mh_icp * icp, const void * d_recv, size_t n_recv);
+/* Per-point state of the points this rank currently holds: origin = (first rank << 32 | index there). Any pointer may be NULL. */
+int mh_icp_shard_get_state(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals);
+/* linearize of THIS shard up to the raw Hessian sums: d_sums32 (device, 32 doubles) = 28 sums of [J(6), e][J(6), e]^T
+ * (upper triangle, row-major) + n_knn, n_candidates, n_exact_fallback, n_scanned.  No epilogue is applied. */
+int mh_icp_linearize_begin_device(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32);
+/* Component localizabilities (geometric_factor.hpp:434-457) of this shard in the eigenbasis of the GLOBAL (all-reduced)
+ * sums + status histogram: d_loc16 (device, 16 doubles) = trans xyz, rot xyz, 9 histogram counts, 0. */
+int mh_icp_linearize_finish_device(mh_icp * icp, const double * d_global_sums32, double * d_loc16);
+/* Host epilogue on the all-reduced values: localizabilities of the global H, Schur degeneracy info, 4-DoF projection and
+ * the degeneracy branch (geometric_factor.hpp:405-428, 464-557) — applied once, to the global sums. */
+int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,8 @@ EXPORTS = [
     "mh_deskew", "mh_transform_f32",
     "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
+    "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
+    "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
     "mh_photo_factor_create", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_get_state", "mh_photo_factor_size",
@@ -294,6 +296,16 @@ def load(build_if_missing: bool = True):
     L.mh_scan_get_points.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     L.mh_scan_get_indices.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     L.mh_icp_create_from_scan.argtypes = [vp, vp, vp, C.POINTER(RegConfig), i32, pvp]
+    L.mh_init_on_stream.argtypes = [i32, vp, pvp]
+    L.mh_map_insert_shard.argtypes = [vp, vp, sz, sz, i32, i32, i32]
+    L.mh_icp_create_from_device.argtypes = [vp, vp, vp, sz, C.POINTER(RegConfig), i32, pvp]
+    L.mh_icp_shard_plan.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.mh_icp_shard_pack.argtypes = [vp, vp]
+    L.mh_icp_shard_unpack.argtypes = [vp, vp, sz]
+    L.mh_icp_shard_get_state.argtypes = [vp, vp, vp, vp, vp]
+    L.mh_icp_linearize_begin_device.argtypes = [vp, vp, vp, vp, vp]
+    L.mh_icp_linearize_finish_device.argtypes = [vp, vp, vp]
+    L.mh_icp_global_epilogue.argtypes = [vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_photo_create.argtypes = [vp, C.POINTER(PhotoConfig), pvp]
     L.mh_photo_destroy.argtypes = [vp]
     L.mh_photo_destroy.restype = None

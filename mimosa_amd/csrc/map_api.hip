@@ -265,7 +265,7 @@ void map_free(mh_map * m)
 {
   for (DevBuf * b : {&m->d_table, &m->d_cells, &m->d_buckets, &m->d_qbuckets, &m->d_vox, &m->d_lru, &m->s_in, &m->s_pts, &m->s_keys_a, &m->s_keys_b,
                      &m->s_idx_a, &m->s_idx_b, &m->s_flags, &m->s_pos, &m->s_seg_start, &m->s_seg_vid, &m->s_newflag, &m->s_newrank, &m->s_temp,
-                     &m->s_rt})
+                     &m->s_rt, &m->s_shard})
     b->release();
   if (m->d_state) dev_free(m->d_state);
   if (m->h_state) (void)hipHostFree(m->h_state);
@@ -326,6 +326,35 @@ int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out)
   });
 }
 
+// the batch goes to the device through pinned staging as packed xyz (a pageable strided source would copy at a few GB/s)
+static int stage_batch(mh_map * map, const float * xyz, size_t n, size_t stride_floats)
+{
+  mh_ctx * ctx = map->ctx;
+  if (n > (size_t(1) << 40) / 12) return fail(ctx, MH_ERR_OOM, "mh_map_insert: batch too large");
+  const size_t bytes = n * 3 * sizeof(float);
+  if (map->h_in_cap < bytes) {
+    if (map->h_in) (void)hipHostFree(map->h_in);
+    map->h_in = nullptr;
+    map->h_in_cap = 0;
+    MH_HIP(ctx, hipHostMalloc(&map->h_in, bytes + bytes / 2, hipHostMallocDefault));
+    map->h_in_cap = bytes + bytes / 2;
+  }
+  float * st = static_cast<float *>(map->h_in);
+  if (stride_floats == 3) {
+    std::memcpy(st, xyz, bytes);
+  } else {
+    for (size_t i = 0; i < n; ++i) {
+      st[3 * i] = xyz[i * stride_floats];
+      st[3 * i + 1] = xyz[i * stride_floats + 1];
+      st[3 * i + 2] = xyz[i * stride_floats + 2];
+    }
+  }
+  MH_HIP(ctx, map->s_in.reserve(bytes, ctx->stream, false));
+  MH_HIP(ctx, hipMemcpyAsync(map->s_in.p, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+  map->upload_bytes += static_cast<int64_t>(bytes);
+  return MH_OK;
+}
+
 int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_floats)
 {
   if (!map || (!xyz && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert: NULL argument");
@@ -334,31 +363,43 @@ int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_float
     if (stride_floats < 3) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert: stride_floats must be >= 3");
     MH_HIP(ctx, hipSetDevice(ctx->device));
     if (n) {
-      // the batch goes through pinned staging as packed xyz (a pageable strided source would copy at a few GB/s)
-      if (n > (size_t(1) << 40) / 12) return fail(ctx, MH_ERR_OOM, "mh_map_insert: batch too large");
-      const size_t bytes = n * 3 * sizeof(float);
-      if (map->h_in_cap < bytes) {
-        if (map->h_in) (void)hipHostFree(map->h_in);
-        map->h_in = nullptr;
-        map->h_in_cap = 0;
-        MH_HIP(ctx, hipHostMalloc(&map->h_in, bytes + bytes / 2, hipHostMallocDefault));
-        map->h_in_cap = bytes + bytes / 2;
-      }
-      float * st = static_cast<float *>(map->h_in);
-      if (stride_floats == 3) {
-        std::memcpy(st, xyz, bytes);
-      } else {
-        for (size_t i = 0; i < n; ++i) {
-          st[3 * i] = xyz[i * stride_floats];
-          st[3 * i + 1] = xyz[i * stride_floats + 1];
-          st[3 * i + 2] = xyz[i * stride_floats + 2];
-        }
-      }
-      MH_HIP(ctx, map->s_in.reserve(bytes, ctx->stream, false));
-      MH_HIP(ctx, hipMemcpyAsync(map->s_in.p, st, bytes, hipMemcpyHostToDevice, ctx->stream));
-      map->upload_bytes += static_cast<int64_t>(bytes);
+      const int rc = stage_batch(map, xyz, n, stride_floats);
+      if (rc != MH_OK) return rc;
     }
     return insert_device(map, static_cast<const float *>(map->s_in.p), n, 3, nullptr);
+  });
+}
+
+/* One rank's share of an insert into a map that is sharded by spatial hash: of the batch every rank
+ * receives, this rank keeps the points whose voxel lies in one of its shard blocks or in their one-voxel halo, in
+ * the original order (iVox's insertion rule is per voxel), and inserts those. */
+int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride_floats, int world, int rank, int block_log2)
+{
+  if (!map || (!xyz && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert_shard: NULL argument");
+  mh_ctx * ctx = map->ctx;
+  return guarded(ctx, "mh_map_insert_shard", [&]() -> int {
+    if (stride_floats < 3) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard: stride_floats must be >= 3");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 10)
+      return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard: world in 1..64, 0 <= rank < world, block_log2 in 0..10");
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    size_t kept = 0;
+    if (n) {
+      if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_insert_shard: batch too large");
+      int rc = stage_batch(map, xyz, n, stride_floats);
+      if (rc != MH_OK) return rc;
+      MH_HIP(ctx, map->s_flags.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, map->s_pos.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, map->s_temp.reserve(mh::shard_temp_bytes(n) > mh::map_temp_bytes(n) ? mh::shard_temp_bytes(n) : mh::map_temp_bytes(n), ctx->stream, false));
+      MH_HIP(ctx, map->s_shard.reserve(n * 3 * sizeof(float), ctx->stream, false));
+      MH_HIP(ctx, mh::launch_shard_filter(static_cast<const float *>(map->s_in.p), static_cast<uint32_t>(n), 3, map->inv_leaf, static_cast<uint32_t>(world),
+                                          static_cast<uint32_t>(rank), block_log2, static_cast<uint32_t *>(map->s_flags.p),
+                                          static_cast<uint32_t *>(map->s_pos.p), static_cast<float *>(map->s_shard.p), &map->d_state->n_keep, map->s_temp.p,
+                                          map->s_temp.cap, ctx->stream));
+      rc = fetch_state(map);
+      if (rc != MH_OK) return rc;
+      kept = map->h_state->n_keep;
+    }
+    return insert_device(map, static_cast<const float *>(map->s_shard.p), kept, 3, nullptr);
   });
 }
 

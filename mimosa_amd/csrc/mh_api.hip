@@ -23,6 +23,7 @@
 #include "math3.hpp"
 #include "mh_internal.hpp"
 #include "scan_device.hpp"
+#include "shard_device.hpp"
 #include "voxel_map.hpp"
 
 struct PendingCall
@@ -57,6 +58,15 @@ struct mh_icp
   hipEvent_t events[kMaxPending][3];
   bool events_ready = false;
   unsigned int seq_counter = 0;
+  // map-sharded use (mh_icp_shard_*): points migrate between ranks with their association state
+  bool no_order = false;  // keep the caller's point order (no Morton re-ordering)
+  DevBuf d_origin, x_src, x_qda, x_mean, x_normal, x_status, x_origin;  // origin ids; the second set of arrays pack compacts into
+  DevBuf s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_counts, s_temp, d_sums;
+  uint32_t * h_counts = nullptr;  // pinned
+  bool origin_ready = false, plan_open = false;
+  uint32_t n_movers = 0;
+  int shard_world = 0, shard_rank = 0, shard_log2 = 3;
+  bool dev_split_open = false;
 };
 
 namespace
@@ -242,7 +252,7 @@ void mh_shutdown(mh_ctx * ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   }
   if (ctx->timer[0]) (void)hipEventDestroy(ctx->timer[0]);
   if (ctx->timer[1]) (void)hipEventDestroy(ctx->timer[1]);
@@ -347,7 +357,7 @@ static int icp_init_source(mh_icp * icp, const mh_point32 * source, const mh_poi
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
     const char * ns = std::getenv("MH_NO_SORT");
-    if (!(ns && ns[0] == '1')) {
+    if (!(ns && ns[0] == '1') && !icp->no_order) {
       const int ni = static_cast<int>(n);
       const size_t tb = mh::order_temp_bytes(ni);
       DevTemp<float4> d_tmp_xyz;
@@ -382,7 +392,7 @@ static int icp_init_source(mh_icp * icp, const mh_point32 * source, const mh_poi
 
 // source: host cloud (d_source == nullptr) or a cloud already on the device (source == nullptr)
 static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_point32 * d_source, size_t n,
-                             const mh_reg_config * cfg, int is_binary, mh_icp ** out)
+                             const mh_reg_config * cfg, int is_binary, mh_icp ** out, bool no_order = false)
 {
   *out = nullptr;
   // A map may be shared read-only by factors of several contexts (= HIP streams) of the SAME device:
@@ -400,6 +410,7 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   icp->n = n;
   icp->cfg = *cfg;
   icp->binary = is_binary != 0;
+  icp->no_order = no_order;
   int rc = icp_alloc(icp);
   if (rc != MH_OK) {
     mh_icp_destroy(icp);
@@ -490,6 +501,10 @@ void mh_icp_destroy(mh_icp * icp)
   icp->d_dbg.release();
   icp->d_perm.release();
   icp->d_eig.release();
+  for (DevBuf * b : {&icp->d_origin, &icp->x_src, &icp->x_qda, &icp->x_mean, &icp->x_normal, &icp->x_status, &icp->x_origin, &icp->s_keys_a,
+                     &icp->s_keys_b, &icp->s_idx_a, &icp->s_idx_b, &icp->s_counts, &icp->s_temp, &icp->d_sums})
+    b->release();
+  if (icp->h_counts) (void)hipHostFree(icp->h_counts);
   if (icp->h_results) AllocCache::free_pinned(icp->h_results, sizeof(mh::DeviceResult) * kMaxPending);
   if (icp->events_ready)
     for (auto & ev : icp->events)
@@ -547,6 +562,8 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
     icp->events_ready = true;
   }
 
+  MH_HIP(ctx, icp->d_partials.reserve(static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * mh::kPartialStride * sizeof(double),
+                                      ctx->stream, false));
   a.map = map_view(icp->map);
   a.src = static_cast<const float4 *>(icp->d_src.p);
   a.n = static_cast<int>(icp->n);
@@ -1240,6 +1257,292 @@ int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const
                             mh_icp ** out)
 {
   return guarded(nullptr, "mh_icp_create_from_scan", [&]() -> int { return mh_icp_create_from_scan_impl(ctx, map, s, cfg, is_binary, out); });
+}
+
+}  // extern "C"
+
+// ---- map-sharded factor (BASELINE configs[2]) ------------------------------------------------
+// No reference counterpart (the reference is single-process).  One process per GPU; the data path between ranks —
+// the all-to-all of migrating points and the two small all-reduces — is the caller's (torch.distributed over RCCL):
+// these entry points produce / consume plain device buffers.
+namespace
+{
+mh::ShardArrays shard_arrays(mh_icp * icp, bool alt)
+{
+  mh::ShardArrays a;
+  a.src = static_cast<float4 *>((alt ? icp->x_src : icp->d_src).p);
+  a.q_da = static_cast<double *>((alt ? icp->x_qda : icp->d_qda).p);
+  a.mean = static_cast<double *>((alt ? icp->x_mean : icp->d_mean).p);
+  a.normal = static_cast<double *>((alt ? icp->x_normal : icp->d_normal).p);
+  a.status = static_cast<int32_t *>((alt ? icp->x_status : icp->d_status).p);
+  a.origin = static_cast<unsigned long long *>((alt ? icp->x_origin : icp->d_origin).p);
+  return a;
+}
+int shard_reserve(mh_icp * icp, size_t n, bool alt, bool keep)
+{
+  mh_ctx * ctx = icp->ctx;
+  const size_t k = n ? n : 1;
+  MH_HIP(ctx, (alt ? icp->x_src : icp->d_src).reserve(k * sizeof(float4), ctx->stream, keep));
+  MH_HIP(ctx, (alt ? icp->x_qda : icp->d_qda).reserve(k * 3 * sizeof(double), ctx->stream, keep));
+  MH_HIP(ctx, (alt ? icp->x_mean : icp->d_mean).reserve(k * 3 * sizeof(double), ctx->stream, keep));
+  MH_HIP(ctx, (alt ? icp->x_normal : icp->d_normal).reserve(k * 3 * sizeof(double), ctx->stream, keep));
+  MH_HIP(ctx, (alt ? icp->x_status : icp->d_status).reserve(k * sizeof(int32_t), ctx->stream, keep));
+  MH_HIP(ctx, (alt ? icp->x_origin : icp->d_origin).reserve(k * sizeof(unsigned long long), ctx->stream, keep));
+  return MH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+static int mh_init_on_stream_impl(int device, void * hip_stream, mh_ctx ** out)
+{
+  mh_ctx * ctx = nullptr;
+  const int rc = mh_init(device, &ctx);
+  if (rc != MH_OK) return rc;
+  (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  ctx->owns_stream = false;
+  *out = ctx;
+  return MH_OK;
+}
+int mh_init_on_stream(int device, void * hip_stream, mh_ctx ** out)
+{
+  if (!out) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init_on_stream: out is NULL");
+  *out = nullptr;
+  return guarded(nullptr, "mh_init_on_stream", [&]() -> int { return mh_init_on_stream_impl(device, hip_stream, out); });
+}
+
+static int mh_icp_create_from_device_impl(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg, int is_binary,
+                                          mh_icp ** out)
+{
+  if (!ctx || !map || !cfg || !out || (!d_points && n)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_device: NULL argument");
+  return icp_create_common(ctx, map, nullptr, n ? d_points : reinterpret_cast<const mh_point32 *>(map->d_vox.p), n, cfg, is_binary, out, true);
+}
+int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg, int is_binary, mh_icp ** out)
+{
+  return guarded(ctx, "mh_icp_create_from_device", [&]() -> int { return mh_icp_create_from_device_impl(ctx, map, d_points, n, cfg, is_binary, out); });
+}
+
+static int mh_icp_shard_plan_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, int world,
+                                  int rank, int block_log2, int64_t * send_counts)
+{
+  if (!icp || !R_src || !t_src || !send_counts) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (world < 1 || world > 64 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 10)
+    return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: world in 1..64, 0 <= rank < world, block_log2 in 0..10");
+  if (icp->binary) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: unary factors only");
+  if (icp->ordered) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: create the factor with mh_icp_create_from_device (caller's point order)");
+  if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: calls in flight");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = icp->n, k = n ? n : 1;
+  if (!icp->origin_ready) {
+    MH_HIP(ctx, icp->d_origin.reserve(k * sizeof(unsigned long long), ctx->stream, false));
+    MH_HIP(ctx, mh::launch_shard_origin(static_cast<unsigned long long *>(icp->d_origin.p), static_cast<uint32_t>(n), static_cast<uint32_t>(rank), ctx->stream));
+    icp->origin_ready = true;
+  }
+  for (DevBuf * b : {&icp->s_keys_a, &icp->s_keys_b, &icp->s_idx_a, &icp->s_idx_b}) MH_HIP(ctx, b->reserve(k * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, icp->s_counts.reserve(64 * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, icp->s_temp.reserve(mh::shard_temp_bytes(k), ctx->stream, false));
+  if (!icp->h_counts) MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
+  mh::ShardPose P;
+  pose_inverse_compose(R_src, t_src, R_tgt, t_tgt, P.R, P.t);
+  MH_HIP(ctx, mh::launch_shard_plan(P, static_cast<const float4 *>(icp->d_src.p), static_cast<uint32_t>(n), 1.0 / icp->map->cfg.leaf_size,
+                                    static_cast<uint32_t>(world), static_cast<uint32_t>(rank), block_log2, static_cast<uint32_t *>(icp->s_keys_a.p),
+                                    static_cast<uint32_t *>(icp->s_keys_b.p), static_cast<uint32_t *>(icp->s_idx_a.p),
+                                    static_cast<uint32_t *>(icp->s_idx_b.p), static_cast<uint32_t *>(icp->s_counts.p), icp->s_temp.p, icp->s_temp.cap,
+                                    ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(icp->h_counts, icp->s_counts.p, static_cast<size_t>(world) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t movers = 0;
+  for (int r = 0; r < world; ++r) {
+    send_counts[r] = icp->h_counts[r];
+    movers += icp->h_counts[r];
+  }
+  icp->n_movers = movers;
+  icp->shard_world = world;
+  icp->shard_rank = rank;
+  icp->shard_log2 = block_log2;
+  icp->plan_open = true;
+  return MH_OK;
+}
+int mh_icp_shard_plan(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, int world, int rank,
+                      int block_log2, int64_t * send_counts)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_plan",
+                 [&]() -> int { return mh_icp_shard_plan_impl(icp, R_src, t_src, R_tgt, t_tgt, world, rank, block_log2, send_counts); });
+}
+
+static int mh_icp_shard_pack_impl(mh_icp * icp, void * d_send)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: icp is NULL");
+  mh_ctx * ctx = icp->ctx;
+  if (!icp->plan_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: no mh_icp_shard_plan before");
+  icp->plan_open = false;
+  if (icp->n_movers == 0) return MH_OK;  // nothing leaves: the arrays stay as they are
+  if (!d_send) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: d_send is NULL");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = icp->n;
+  int rc = shard_reserve(icp, n, true, false);
+  if (rc != MH_OK) return rc;
+  MH_HIP(ctx, mh::launch_shard_pack(shard_arrays(icp, false), shard_arrays(icp, true), static_cast<const uint32_t *>(icp->s_idx_b.p),
+                                    static_cast<uint32_t>(n), icp->n_movers, static_cast<mh::ShardRecord *>(d_send), ctx->stream));
+  std::swap(icp->d_src, icp->x_src);
+  std::swap(icp->d_qda, icp->x_qda);
+  std::swap(icp->d_mean, icp->x_mean);
+  std::swap(icp->d_normal, icp->x_normal);
+  std::swap(icp->d_status, icp->x_status);
+  std::swap(icp->d_origin, icp->x_origin);
+  icp->n = n - icp->n_movers;
+  icp->n_movers = 0;
+  icp->cold = false;  // the state arrays are explicit from now on (they were zero-initialised at creation)
+  return MH_OK;
+}
+int mh_icp_shard_pack(mh_icp * icp, void * d_send)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_pack", [&]() -> int { return mh_icp_shard_pack_impl(icp, d_send); });
+}
+
+static int mh_icp_shard_unpack_impl(mh_icp * icp, const void * d_recv, size_t n_recv)
+{
+  if (!icp || (!d_recv && n_recv)) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_unpack: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (!icp->origin_ready) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_unpack: no mh_icp_shard_plan before");
+  if (n_recv == 0) return MH_OK;
+  if (icp->n + n_recv > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_unpack: cloud too large");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc = shard_reserve(icp, icp->n + n_recv, false, true);
+  if (rc != MH_OK) return rc;
+  MH_HIP(ctx, mh::launch_shard_unpack(shard_arrays(icp, false), static_cast<uint32_t>(icp->n), static_cast<const mh::ShardRecord *>(d_recv),
+                                      static_cast<uint32_t>(n_recv), ctx->stream));
+  icp->n += n_recv;
+  icp->cold = false;
+  return MH_OK;
+}
+int mh_icp_shard_unpack(mh_icp * icp, const void * d_recv, size_t n_recv)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_unpack", [&]() -> int { return mh_icp_shard_unpack_impl(icp, d_recv, n_recv); });
+}
+
+static int mh_icp_shard_get_state_impl(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_get_state: icp is NULL");
+  mh_ctx * ctx = icp->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = icp->n;
+  if (n == 0) return MH_OK;
+  if (origin) {
+    if (!icp->origin_ready) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_get_state: no mh_icp_shard_plan before");
+    MH_HIP(ctx, hipMemcpyAsync(origin, icp->d_origin.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (status) MH_HIP(ctx, hipMemcpyAsync(status, icp->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (means) MH_HIP(ctx, hipMemcpyAsync(means, icp->d_mean.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (normals) MH_HIP(ctx, hipMemcpyAsync(normals, icp->d_normal.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+int mh_icp_shard_get_state(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_get_state", [&]() -> int { return mh_icp_shard_get_state_impl(icp, origin, status, means, normals); });
+}
+
+static int mh_icp_linearize_begin_device_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32)
+{
+  if (!icp || !d_sums32) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin_device: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (icp->binary) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_linearize_begin_device: unary factors only");
+  if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin_device: calls in flight");
+  static mh_icp_result scratch;  // never read: the epilogue runs on the all-reduced sums
+  mh::IcpArgs a;
+  mh::LocArgs l;
+  bool timed = false;
+  const int rc = linearize_prepare(icp, R_src, t_src, nullptr, nullptr, g_unit, &scratch, false, false, a, l, timed);
+  if (rc != MH_OK) return rc;
+  a.host_result = nullptr;  // results stay on the device
+  if (a.n > 0)
+    MH_HIP(ctx, mh::launch_linearize(a, false, ctx->stream));
+  else
+    MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
+  MH_HIP(ctx, mh::launch_shard_pack_sums(static_cast<const mh::DeviceResult *>(icp->d_result.p), d_sums32, ctx->stream));
+  std::memcpy(icp->split_R, icp->pending[0].R, sizeof(icp->split_R));
+  icp->dev_split_open = true;
+  return MH_OK;
+}
+int mh_icp_linearize_begin_device(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_begin_device",
+                 [&]() -> int { return mh_icp_linearize_begin_device_impl(icp, R_src, t_src, g_unit, d_sums32); });
+}
+
+static int mh_icp_linearize_finish_device_impl(mh_icp * icp, const double * d_global_sums32, double * d_loc16)
+{
+  if (!icp || !d_global_sums32 || !d_loc16) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (!icp->dev_split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: no mh_icp_linearize_begin_device before");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, icp->d_eig.reserve(18 * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, mh::launch_shard_eig(d_global_sums32, static_cast<double *>(icp->d_eig.p), ctx->stream));
+  if (icp->n > 0) {
+    mh::LocArgs l;
+    l.host_result = nullptr;
+    l.seq = 0;
+    l.eig = static_cast<const double *>(icp->d_eig.p);
+    l.src = static_cast<const float4 *>(icp->d_src.p);
+    l.n = static_cast<int>(icp->n);
+    l.chunks_per_block = 1;
+    std::memcpy(l.R, icp->split_R, sizeof(l.R));
+    l.normal = static_cast<const double *>(icp->d_normal.p);
+    l.status = static_cast<const int32_t *>(icp->d_status.p);
+    l.partials = static_cast<double *>(icp->d_partials.p);
+    l.ticket = static_cast<unsigned int *>(icp->d_ticket.p) + 1;
+    l.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
+    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+  }
+  MH_HIP(ctx, mh::launch_shard_pack_loc(static_cast<const mh::DeviceResult *>(icp->d_result.p), d_loc16, ctx->stream));
+  return MH_OK;
+}
+int mh_icp_linearize_finish_device(mh_icp * icp, const double * d_global_sums32, double * d_loc16)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_finish_device",
+                 [&]() -> int { return mh_icp_linearize_finish_device_impl(icp, d_global_sums32, d_loc16); });
+}
+
+static int mh_icp_global_epilogue_impl(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out)
+{
+  if (!icp || !sums32 || !loc16 || !out) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_global_epilogue: NULL argument");
+  mh_ctx * ctx = icp->ctx;
+  if (!icp->dev_split_open || icp->n_pending != 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_global_epilogue: no open two-phase linearize");
+  icp->dev_split_open = false;
+  mh::DeviceResult d;
+  std::memset(&d, 0, sizeof(d));
+  for (int i = 0; i < 28; ++i) d.sums[i] = sums32[i];
+  d.n_knn = static_cast<unsigned long long>(sums32[28]);
+  d.n_cand = static_cast<unsigned long long>(sums32[29]);
+  d.n_fallback = static_cast<unsigned long long>(sums32[30]);
+  d.n_scanned = static_cast<unsigned long long>(sums32[31]);
+  for (int i = 0; i < 6; ++i) d.loc_comp[i] = loc16[i];
+  for (int i = 0; i < 9; ++i) d.status_hist[i] = static_cast<unsigned int>(loc16[6 + i]);
+  // localizabilities of the GLOBAL H (geometric_factor.hpp:405-411)
+  double Hr[9], Ht[9];
+  auto ent = [](int r, int c) {
+    if (r > c) std::swap(r, c);
+    return r * 7 - r * (r - 1) / 2 + (c - r);
+  };
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      Hr[3 * r + c] = sums32[ent(r, c)];
+      Ht[3 * r + c] = sums32[ent(3 + r, 3 + c)];
+    }
+  mh::compute_localizability(Hr, d.loc_rot_final, d.eig_rot);
+  mh::compute_localizability(Ht, d.loc_trans_final, d.eig_trans);
+  const PendingCall pc = icp->pending[0];
+  icp->n_pending = 0;
+  finish_result(icp, d, pc, out);  // Schur degeneracy info, 4-DoF projection, degeneracy quirk: once, on the global sums
+  out->gpu_ms_linearize = out->gpu_ms_localizability = -1.0f;
+  return MH_OK;
+}
+int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out)
+{
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_global_epilogue", [&]() -> int { return mh_icp_global_epilogue_impl(icp, sums32, loc16, out); });
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@
 #include "icp_device.hpp"
 #include "map_device.hpp"
 #include "scan_device.hpp"
+#include "shard_device.hpp"
 
 inline thread_local std::string g_mh_err;
 constexpr int kMaxPending = 64;
@@ -28,6 +29,7 @@ struct mh_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;  // false: adopted from the caller (mh_init_on_stream)
   std::string err;
   int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
   hipEvent_t timer[2] = {nullptr, nullptr};
@@ -272,7 +274,7 @@ struct mh_map
   uint32_t n_voxels = 0, n_blocks = 0;
   uint64_t n_points = 0, lru_counter = 0;
   // insert scratch (grown on demand, reused)
-  DevBuf s_in, s_pts, s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_flags, s_pos, s_seg_start, s_seg_vid, s_newflag, s_newrank, s_temp, s_rt;
+  DevBuf s_in, s_pts, s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_flags, s_pos, s_seg_start, s_seg_vid, s_newflag, s_newrank, s_temp, s_rt, s_shard;
   void * h_in = nullptr;  // pinned staging of a host batch
   size_t h_in_cap = 0;
   int64_t inserts = 0, upload_bytes = 0, purges = 0;

@@ -1,33 +1,38 @@
-"""Multi-GPU layer for the geometric factor: map sharded by spatial hash, queries
-routed to the owner of their centre voxel, partial Hessians combined with one small all-reduce.
+"""Multi-GPU layer for the geometric factor (BASELINE configs[2]): the map sharded by spatial hash
+across the GPUs of a node, every source point linearized on the rank that owns the centre voxel of its CURRENT position,
+partial Hessians combined with two small all-reduces.  One process per GPU; torch.distributed carries the exchange
+(backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU tests).  Plumbing, not arithmetic: the kernels are behind the
+C ABI (mh_map_insert_shard, mh_icp_shard_*, mh_icp_linearize_begin_device / _finish_device, mh_icp_global_epilogue).
 
-Partition.  Voxels are grouped into shard blocks of 8 x 8 x 8 voxels (4 m cubes at the 0.5 m leaf);
-block b is owned by rank  XORVector3iHash(b) mod P  (the reference's hash, include/mimosa/lidar/
-utils.hpp:228-238).  Besides the voxels of its own blocks every rank also stores a ONE-VOXEL HALO: a
-point whose voxel is adjacent (27-neighbourhood) to an owned block is inserted there too.  iVox's
-insertion rule is per voxel and order-dependent only within a voxel, and every rank inserts its
-subsequence in the original order, so a voxel has identical contents on every rank that stores it.
-A query routed to the owner of its centre voxel therefore finds all 1/7/19/27 neighbour voxels
-locally, bit-identically: the exchange step is one all-to-all(v) of the query points (16 B each), not
-a per-neighbour candidate exchange, and interior memory overhead is the halo (~+40 % at 8^3 blocks on
-planar content).
+Partition.  Voxels are grouped into shard blocks of 8 x 8 x 8 voxels (4 m cubes at the 0.5 m leaf); block b is owned by
+rank  XORVector3iHash(b) mod P  (the reference's hash, include/mimosa/lidar/utils.hpp:228-238).  Besides the voxels of its
+own blocks every rank also stores a ONE-VOXEL HALO: a point whose voxel is adjacent (27-neighbourhood) to an owned block is
+inserted there too.  iVox's insertion rule is per voxel and order-dependent only within a voxel, and every rank inserts its
+subsequence in the original order, so a voxel has identical contents on every rank that stores it.  A query on the owner
+of its centre voxel therefore finds all 1/7/19/27 neighbour voxels locally, bit-identically.
 
-Collectives (torch.distributed; backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU tests):
-  C1  all_to_all_single   source points -> owner ranks         (n x 32 B mh_point32 records)
-  C3  all_reduce(SUM)     H (36) + b (6) + f (1) + status histogram (9) + counters (2) = 54 doubles
-The component-localizability pass (geometric_factor.hpp:434-457) needs the eigenvectors of the GLOBAL
-H, so it runs after C3 (the device path splits linearize at the K3 / K4 boundary — round 2).
+Per linearize (the pose changes between Gauss-Newton iterations, so does the owner of points near block borders):
+  plan     owner of every local point at the new pose (kernel) -> counts          C0  all_to_all of the counts (P int64)
+  migrate  points that changed owner leave WITH their data-association state      C1  all_to_all(v) of 112-byte records
+           (q_da, mean, normal, status: geometric_factor.hpp:279-317's cache), the rest is compacted; arrivals appended
+  K3       local linearize up to the raw Hessian sums                             C3a all_reduce(SUM) of 32 doubles
+  K4       component localizabilities in the eigenbasis of the GLOBAL H           C3b all_reduce(SUM) of 16 doubles
+  epilogue degeneracy info / 4-DoF / degeneracy projection once, on the global sums (host, 48 doubles)
 
-This module is backend-agnostic: `make_map(points) -> map` and `make_factor(map, points) -> factor
-with .linearize(R, t) -> dict` are injected (the HIP classes of mimosa_amd.capi on GPUs; the tests
-inject the CPU oracle as the checker-side backend).
+Two implementations of the same protocol:
+  ShardedICPDevice  the product path: device tensors end to end, HIP kernels through the C ABI
+  ShardedICP        host-staged, backend-agnostic (a factory for maps / factors is injected): what the CPU suite runs over
+                    gloo with the oracle standing in for the device backend
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
 SHARD_BLOCK_LOG2 = 3
 _P1, _P2, _P3 = np.uint64(9132043225175502913), np.uint64(7277549399757405689), np.uint64(6673468629021231217)
+RECORD_BYTES = 112
 
 
 def voxel_coords(xyz, leaf: float) -> np.ndarray:
@@ -60,14 +65,167 @@ def shard_insert_mask(xyz, leaf: float, world: int, rank: int) -> np.ndarray:
 
 
 def query_owner(pts_xyz_f32, R, t, leaf: float, world: int) -> np.ndarray:
-    """Owner rank of each source point = owner of the centre voxel of q = R p + t (fp64 like
-    geometric_factor.hpp:276-277)."""
-    q = np.asarray(pts_xyz_f32, np.float32).astype(np.float64) @ np.asarray(R, float).T + np.asarray(t, float)
+    """Owner rank of each source point = owner of the centre voxel of q = R p + t (fp64, the reference's evaluation order
+    r0 x + (r1 y + r2 z), geometric_factor.hpp:276-277)."""
+    p = np.asarray(pts_xyz_f32, np.float32).astype(np.float64)
+    R, t = np.asarray(R, float), np.asarray(t, float)
+    q = np.stack([(R[k, 0] * p[:, 0] + (R[k, 1] * p[:, 1] + R[k, 2] * p[:, 2])) + t[k] for k in range(3)], 1)
     return owner_of_voxel(voxel_coords(q, leaf), world)
 
 
+# ---- collectives that work for device tensors over RCCL and for the gloo test backend -------------------------------
+def _staged(dist, comm, t):
+    return dist.get_backend(comm) == "gloo" and t.is_cuda
+
+
+def all_to_all_counts(dist, comm, send_counts, device):
+    import torch
+    sc = torch.as_tensor(np.asarray(send_counts, np.int64))
+    rc = torch.empty_like(sc)
+    if dist.get_backend(comm) != "gloo":
+        sc, rc = sc.to(device), rc.to(device)
+    dist.all_to_all_single(rc, sc, group=comm)
+    return rc.cpu().numpy()
+
+
+def all_to_all_rows(dist, comm, send, send_counts, recv_counts):
+    """send: (sum(send_counts), W) uint8 tensor grouped by destination -> (sum(recv_counts), W) tensor on the same device."""
+    import torch
+    stage = _staged(dist, comm, send)
+    s = send.cpu() if stage else send
+    r = torch.empty((int(np.sum(recv_counts)), send.shape[1]), dtype=send.dtype, device=s.device)
+    dist.all_to_all_single(r, s, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts], group=comm)
+    return r.to(send.device) if stage else r
+
+
+def all_reduce_sum(dist, comm, t):
+    if _staged(dist, comm, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=comm)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=comm)
+    return t
+
+
+class ShardedICPDevice:
+    """One rank's view of a map-sharded scan-to-map factor; everything between the calls stays on the device."""
+
+    def __init__(self, comm, ctx, leaf: float, reg_cfg, device):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.torch, self.dist, self.comm, self.capi = torch, dist, comm, capi
+        self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
+        self.ctx, self.L, self.leaf, self.reg, self.device = ctx, ctx.L, leaf, reg_cfg, device
+        self.map = None
+        self.fh = None
+        self.sums = torch.zeros(32, dtype=torch.float64, device=device)
+        self.loc = torch.zeros(16, dtype=torch.float64, device=device)
+        self.n_migrated = 0
+
+    def build_map(self, insert_batches, **map_kw):
+        """insert_batches: iterable of float32 (n,3) arrays, identical on every rank (one iVox insert call each)."""
+        self.map = self.capi.VoxelMap(self.ctx, **map_kw)
+        for xyz in insert_batches:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+            self.ctx.check(self.L.mh_map_insert_shard(self.map.h, xyz.ctypes.data_as(C.c_void_p), len(xyz), 3, self.world, self.rank,
+                                                      SHARD_BLOCK_LOG2))
+        return self.map
+
+    def set_scan(self, my_points):
+        """This rank's slice of the scan (POINT_DTYPE records): uploaded once, routed by the first linearize."""
+        pts = np.ascontiguousarray(my_points)
+        t = self.torch.from_numpy(pts.view(np.uint8).reshape(-1, 32).copy()).to(self.device)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        h = C.c_void_p()
+        self.ctx.check(self.L.mh_icp_create_from_device(self.ctx.h, self.map.h, C.c_void_p(t.data_ptr()), len(pts), C.byref(self.reg), 0, C.byref(h)))
+        self.ctx.synchronize()
+        if self.fh is not None:
+            self.L.mh_icp_destroy(self.fh)
+        self.fh = h
+
+    def linearize(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> dict:
+        capi, L, torch = self.capi, self.L, self.torch
+        R, tv, g = capi._f64(R), capi._f64(t), capi._f64(g_unit)
+        p = capi._p
+        sc = np.zeros(self.world, np.int64)
+        self.ctx.check(L.mh_icp_shard_plan(self.fh, p(R), p(tv), None, None, self.world, self.rank, SHARD_BLOCK_LOG2, p(sc)))
+        rc = all_to_all_counts(self.dist, self.comm, sc, self.device)                                   # C0
+        send = torch.empty((int(sc.sum()), RECORD_BYTES), dtype=torch.uint8, device=self.device)
+        self.ctx.check(L.mh_icp_shard_pack(self.fh, C.c_void_p(send.data_ptr()) if len(send) else None))
+        if int(sc.sum()) or int(rc.sum()):
+            self._sync_for_torch()
+            recv = all_to_all_rows(self.dist, self.comm, send, sc, rc)                                   # C1
+            self._sync_from_torch()
+            self.ctx.check(L.mh_icp_shard_unpack(self.fh, C.c_void_p(recv.data_ptr()) if len(recv) else None, len(recv)))
+            self._keep = recv
+        self.n_migrated = int(rc.sum())
+        self.ctx.check(L.mh_icp_linearize_begin_device(self.fh, p(R), p(tv), p(g), C.c_void_p(self.sums.data_ptr())))
+        self._sync_for_torch()
+        all_reduce_sum(self.dist, self.comm, self.sums)                                                 # C3a
+        self._sync_from_torch()
+        self.ctx.check(L.mh_icp_linearize_finish_device(self.fh, C.c_void_p(self.sums.data_ptr()), C.c_void_p(self.loc.data_ptr())))
+        self._sync_for_torch()
+        all_reduce_sum(self.dist, self.comm, self.loc)                                                  # C3b
+        host = torch.cat([self.sums, self.loc]).cpu().numpy()
+        out = capi.IcpResult()
+        s32, l16 = np.ascontiguousarray(host[:32]), np.ascontiguousarray(host[32:])
+        self.ctx.check(L.mh_icp_global_epilogue(self.fh, p(s32), p(l16), C.byref(out)))
+        d = out.as_dict()
+        d["n_local"] = int(L.mh_icp_size(self.fh))
+        d["n_migrated_in"] = self.n_migrated
+        return d
+
+    # the context runs on torch's current stream when created with on_torch_stream(); otherwise order explicitly
+    def _sync_for_torch(self):
+        if not getattr(self.ctx, "on_torch_stream", False):
+            self.ctx.synchronize()
+
+    def _sync_from_torch(self):
+        if not getattr(self.ctx, "on_torch_stream", False):
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def state(self):
+        """(origin, status, mean, normal) of the points this rank holds now."""
+        n = int(self.L.mh_icp_size(self.fh))
+        origin, st = np.empty(n, np.uint64), np.empty(n, np.int32)
+        mean, nrm = np.empty((n, 3)), np.empty((n, 3))
+        p = self.capi._p
+        self.ctx.check(self.L.mh_icp_shard_get_state(self.fh, p(origin), p(st), p(mean), p(nrm)))
+        return origin, st, mean, nrm
+
+    def close(self):
+        if self.fh is not None:
+            self.L.mh_icp_destroy(self.fh)
+            self.fh = None
+        if self.map is not None:
+            self.map.release()
+            self.map = None
+
+
+def context_on_torch_stream(device_index: int):
+    """A libmimosa_hip context bound to torch's current HIP stream: kernels launched through the C ABI, torch tensor ops and
+    the collectives torch enqueues are then ordered by that one stream (no host synchronisation between them)."""
+    import torch
+    from . import capi
+    L = capi.load()
+    h = C.c_void_p()
+    stream = torch.cuda.current_stream(device_index).cuda_stream
+    rc = L.mh_init_on_stream(device_index, C.c_void_p(stream), C.byref(h))
+    if rc != capi.MH_OK:
+        raise capi.MhError(rc, (L.mh_last_error(None) or b"").decode())
+    ctx = capi.Context.__new__(capi.Context)
+    ctx.L, ctx.h, ctx.device, ctx._children, ctx._closing = L, h, device_index, 0, False
+    ctx.on_torch_stream = True
+    return ctx
+
+
 class ShardedICP:
-    """One rank's view of a map-sharded scan-to-map factor."""
+    """Host-staged form of the same protocol, backend-agnostic: `make_map() -> map` and `make_factor(map, points) -> factor`
+    are injected; the factor must offer linearize(R, t), da_state() and set_da_state() (the CPU oracle does: it is the
+    checker-side stand-in for the device backend in the gloo tests).  Only configurations without the unary epilogue
+    (reg_4_dof, project_on_degneneracy) are supported here: this path all-reduces the shard results as they come."""
 
     def __init__(self, comm, make_map, make_factor, leaf: float):
         import torch.distributed as dist
@@ -75,70 +233,60 @@ class ShardedICP:
         self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
         self.make_map, self.make_factor, self.leaf = make_map, make_factor, leaf
         self.map = None
-        self.factor = None
-        self.n_local = 0
+        self.rec = None
+        self.lin_count = 0
 
     def build_map(self, insert_batches):
-        """insert_batches: iterable of float32 (n,3) arrays, identical on every rank (one iVox insert
-        call each).  Each rank keeps only its shard + halo, in the original order."""
         self.map = self.make_map()
-        self.halo_points = 0
         for xyz in insert_batches:
             xyz = np.ascontiguousarray(xyz, dtype=np.float32)
-            m = shard_insert_mask(xyz, self.leaf, self.world, self.rank)
-            self.map.insert(xyz[m])
+            self.map.insert(xyz[shard_insert_mask(xyz, self.leaf, self.world, self.rank)])
         return self.map
 
-    def scatter_scan(self, my_points, R, t, device=None):
-        """C1: route this rank's slice of the scan to the owners; build the local factor."""
-        import torch
+    def set_scan(self, my_points):
         pts = np.ascontiguousarray(my_points)
-        xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1)
-        own = query_owner(xyz, R, t, self.leaf, self.world)
-        order = np.argsort(own, kind="stable")
-        send_counts = np.bincount(own, minlength=self.world).astype(np.int64)
-        send = torch.from_numpy(pts[order].view(np.uint8).reshape(-1, 32).copy())
-        sc = torch.from_numpy(send_counts)
-        rc = torch.empty_like(sc)
-        if device is not None:
-            send, sc, rc = send.to(device), sc.to(device), rc.to(device)
-        self.dist.all_to_all_single(rc, sc, group=self.comm)
-        recv = torch.empty((int(rc.sum().item()), 32), dtype=torch.uint8, device=send.device)
-        self.dist.all_to_all_single(recv, send, output_split_sizes=rc.tolist(), input_split_sizes=sc.tolist(),
-                                    group=self.comm)
-        local = recv.cpu().numpy().reshape(-1).view(pts.dtype)
-        self.n_local = len(local)
-        self.factor = self.make_factor(self.map, local)
-        return local
+        n = len(pts)
+        self.rec = dict(pts=pts, status=np.zeros(n, np.int32), mean=np.zeros((n, 3)), normal=np.zeros((n, 3)), q_da=np.zeros((n, 3)),
+                        origin=(np.uint64(self.rank) << np.uint64(32)) | np.arange(n, dtype=np.uint64))
 
-    def linearize(self, R, t, device=None):
-        """Local linearize + C3 all-reduce of H, b, f, histogram and counters; when the backend offers the
-        two-phase form (mh_icp_linearize_begin / _finish) the component localizabilities are computed in
-        the GLOBAL eigenbasis and all-reduced too."""
+    def _migrate(self, R, t):
         import torch
-        two_phase = hasattr(self.factor, "linearize_begin")
-        r = self.factor.linearize_begin(R, t) if two_phase else self.factor.linearize(R, t)
-        n_knn = float(r["n_knn"])
-        vec = np.concatenate([np.asarray(r["H_ss"], float).ravel(), np.asarray(r["b_s"], float), [float(r["f"])],
-                              np.asarray(r["status_hist"], float), [n_knn, float(r["mean_candidates"]) * n_knn]])
+        r = self.rec
+        xyz = np.stack([r["pts"]["x"], r["pts"]["y"], r["pts"]["z"]], 1)
+        own = query_owner(xyz, R, t, self.leaf, self.world)
+        go = own != self.rank
+        order = np.argsort(own[go], kind="stable")
+        sc = np.bincount(own[go], minlength=self.world).astype(np.int64)
+        rc = all_to_all_counts(self.dist, self.comm, sc, None)
+        packed = np.concatenate([r["pts"][go].view(np.uint8).reshape(-1, 32), r["status"][go].view(np.uint8).reshape(-1, 4),
+                                 r["mean"][go].view(np.uint8).reshape(-1, 24), r["normal"][go].view(np.uint8).reshape(-1, 24),
+                                 r["q_da"][go].view(np.uint8).reshape(-1, 24), r["origin"][go].view(np.uint8).reshape(-1, 8)], 1)[order]
+        recv = all_to_all_rows(self.dist, self.comm, torch.from_numpy(np.ascontiguousarray(packed)), sc, rc).numpy()
+        keep = ~go
+        f = lambda a, dt, w: np.ascontiguousarray(a).view(dt).reshape(-1, w) if w > 1 else np.ascontiguousarray(a).view(dt).reshape(-1)
+        self.rec = dict(
+            pts=np.concatenate([r["pts"][keep], f(recv[:, :32], r["pts"].dtype, 1)]),
+            status=np.concatenate([r["status"][keep], f(recv[:, 32:36], np.int32, 1)]),
+            mean=np.concatenate([r["mean"][keep], f(recv[:, 36:60], np.float64, 3)]),
+            normal=np.concatenate([r["normal"][keep], f(recv[:, 60:84], np.float64, 3)]),
+            q_da=np.concatenate([r["q_da"][keep], f(recv[:, 84:108], np.float64, 3)]),
+            origin=np.concatenate([r["origin"][keep], f(recv[:, 108:116], np.uint64, 1)]))
+        return int(rc.sum())
+
+    def linearize(self, R, t):
+        import torch
+        n_in = self._migrate(R, t)
+        r = self.rec
+        fac = self.make_factor(self.map, r["pts"])
+        fac.set_da_state(r["status"], r["mean"], r["normal"], r["q_da"], self.lin_count)
+        res = fac.linearize(R, t)
+        self.lin_count = int(res["linearize_count"])
+        r["status"], r["mean"], r["normal"], r["q_da"] = fac.da_state()
+        n_knn = float(res["n_knn"])
+        vec = np.concatenate([np.asarray(res["H_ss"], float).ravel(), np.asarray(res["b_s"], float), [float(res["f"])],
+                              np.asarray(res["status_hist"], float), [n_knn, float(res["mean_candidates"]) * n_knn]])
         tv = torch.from_numpy(vec)
-        if device is not None:
-            tv = tv.to(device)
         self.dist.all_reduce(tv, op=self.dist.ReduceOp.SUM, group=self.comm)
-        v = tv.cpu().numpy()
-        extra = {}
-        if two_phase:
-            H = v[:36].reshape(6, 6)
-            wr, Er = np.linalg.eigh(H[:3, :3])
-            wt, Et = np.linalg.eigh(H[3:, 3:])
-            tc, rc, _ = self.factor.linearize_finish(Er, Et)
-            lv = torch.from_numpy(np.concatenate([tc, rc]))
-            if device is not None:
-                lv = lv.to(device)
-            self.dist.all_reduce(lv, op=self.dist.ReduceOp.SUM, group=self.comm)
-            lv = lv.cpu().numpy()
-            with np.errstate(invalid="ignore"):
-                extra = dict(loc_trans_comp=lv[:3], loc_rot_comp=lv[3:], eigvec_rot=Er, eigvec_trans=Et,
-                             loc_rot_final=np.sqrt(wr), loc_trans_final=np.sqrt(wt))
-        return dict(**extra, H_ss=v[:36].reshape(6, 6), b_s=v[36:42], f=float(v[42]), status_hist=v[43:52].astype(np.int64),
-                    n_knn=int(v[52]), mean_candidates=(v[53] / v[52] if v[52] else 0.0), n_local=self.n_local)
+        v = tv.numpy()
+        return dict(H_ss=v[:36].reshape(6, 6), b_s=v[36:42], f=float(v[42]), status_hist=v[43:52].astype(np.int64), n_knn=int(v[52]),
+                    mean_candidates=(v[53] / v[52] if v[52] else 0.0), n_local=len(r["pts"]), n_migrated_in=n_in)

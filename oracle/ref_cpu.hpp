@@ -645,6 +645,19 @@ public:
   const std::vector<V3> & means() const { return corres_means_target_; }
   const std::vector<V3> & normals() const { return corres_normals_target_; }
   const std::vector<V3> & transed() const { return transed_point_target_; }
+  const std::vector<V3> & transed_da() const { return transed_point_target_da_; }
+  // test tooling for the map-sharded layer: a point that migrates to another rank takes its association state along
+  void set_state(const int32_t * st, const double * means, const double * normals, const double * q_da, int linearize_count)
+  {
+    const size_t n = size();
+    for (size_t i = 0; i < n; ++i) {
+      statuses_[i] = st[i];
+      corres_means_target_[i] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+      corres_normals_target_[i] = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+      transed_point_target_da_[i] = {q_da[3 * i], q_da[3 * i + 1], q_da[3 * i + 2]};
+    }
+    linearize_count_ = linearize_count;
+  }
 
   // estimatePlane, :176-229
   bool estimate_plane(size_t i, const size_t * idx, const V3 & source_origin_in_target)

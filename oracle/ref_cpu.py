@@ -101,6 +101,8 @@ def lib():
         L.ref_icp_set_threads.argtypes = [vp, C.c_int]
         L.ref_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(LinearizeResult)]
         L.ref_icp_get_state.argtypes = [vp, vp, vp, vp, vp]
+        L.ref_icp_get_da.argtypes = [vp, vp]
+        L.ref_icp_set_state.argtypes = [vp, vp, vp, vp, vp, C.c_int]
         L.ref_icp_point_rows.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ref_icp_time_cold.argtypes = [vp, vp, i64, C.POINTER(RegistrationConfig), vp, vp, vp, C.c_int,
                                         C.c_int, vp, C.POINTER(LinearizeResult)]
@@ -211,6 +213,18 @@ class ICP:
         transed = np.empty((self.n, 3))
         self.L.ref_icp_get_state(self.h, _p(st), _p(means), _p(normals), _p(transed))
         return st, means, normals, transed
+
+    def da_state(self):
+        """(status, mean, normal, q_da): everything a point's data association consists of."""
+        st, means, normals, _ = self.state()
+        q = np.empty((self.n, 3))
+        self.L.ref_icp_get_da(self.h, _p(q))
+        return st, means, normals, q
+
+    def set_da_state(self, st, means, normals, q_da, linearize_count=0):
+        st = np.ascontiguousarray(st, np.int32)
+        means, normals, q_da = _f64(means), _f64(normals), _f64(q_da)
+        self.L.ref_icp_set_state(self.h, _p(st), _p(means), _p(normals), _p(q_da), int(linearize_count))
 
     def point_rows(self, R, t):
         e = np.empty(self.n)

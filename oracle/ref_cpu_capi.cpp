@@ -115,6 +115,11 @@ void ref_icp_linearize(
   if (R_tgt && t_tgt) Tt = pose_from(R_tgt, t_tgt);
   h->f->linearize(Ts, (R_tgt && t_tgt) ? &Tt : nullptr, {g_unit[0], g_unit[1], g_unit[2]}, *out);
 }
+void ref_icp_get_da(const ref_icp * h, double * q_da) { std::memcpy(q_da, h->f->transed_da().data(), h->f->size() * 3 * sizeof(double)); }
+void ref_icp_set_state(ref_icp * h, const int32_t * status, const double * means, const double * normals, const double * q_da, int count)
+{
+  h->f->set_state(status, means, normals, q_da, count);
+}
 void ref_icp_get_state(const ref_icp * h, int32_t * status, double * means, double * normals, double * transed)
 {
   const size_t n = h->f->size();

@@ -1,9 +1,8 @@
-"""Subprocess body of tests/test_gpu_dist.py: torch.distributed ("nccl" = RCCL) + the sharding layer
-driving the HIP backend, world size 1 on cuda:0.  Prints "OK" on success."""
+"""Subprocess body of tests/test_gpu_dist.py: torch.distributed ("nccl" = RCCL) + the sharding layer on the HIP backend,
+world size 1 on cuda:0 (the only size the one-GPU test box offers to RCCL), the libmimosa_hip context bound to torch's
+current stream so kernels, collectives and tensor ops are ordered without host synchronisation.  Prints "OK" on success."""
 import os
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,28 +14,11 @@ import torch.distributed as dist  # noqa: E402
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 
-from mimosa_amd import capi, dist as mdist, synth  # noqa: E402
-from oracle import ref_cpu  # noqa: E402
-from parity import rel  # noqa: E402
+from mimosa_amd import dist as mdist  # noqa: E402
+import dist_gpu_common  # noqa: E402
 
-ctx = capi.Context(0)
-room = np.array([20.0, 14.0, 3.0])
-map_xyz = synth.make_room(4321, 0, 0, room=room)
-scan, aux = synth.make_scan(n_rows=32, seed=99, n_cols=128, room=room, sensor_local=np.array([9.3, 6.6, 1.2]))
-R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
-cfg = synth.enwide_config()
-sh = mdist.ShardedICP(dist.group.WORLD, lambda: capi.VoxelMap(ctx),
-                      lambda m, pts: capi.ICPFactor(ctx, m, pts, capi.make_reg_config(**cfg)), leaf=0.5)
-sh.build_map(np.array_split(map_xyz, 3))
-sh.scatter_scan(scan, R, t, device="cuda")
-got = sh.linearize(R, t, device="cuda")
-M = ref_cpu.Map()
-for c in np.array_split(map_xyz, 3):
-    M.insert(c)
-ref = ref_cpu.ICP(M, scan, ref_cpu.make_config(**cfg)).linearize(R, t)
-assert np.array_equal(got["status_hist"], ref["status_hist"])
-assert rel(got["H_ss"], ref["H_ss"]) <= 1e-5 and rel(got["b_s"], ref["b_s"]) <= 1e-5
-assert rel(got["loc_trans_comp"], ref["loc_trans_comp"]) <= 1e-5
-assert rel(got["loc_rot_comp"], ref["loc_rot_comp"]) <= 1e-5
+ctx = mdist.context_on_torch_stream(0)
+dist_gpu_common.run(dist, ctx, torch.device("cuda", 0))
+dist_gpu_common.run(dist, ctx, torch.device("cuda", 0), dict(reg_4_dof=1))   # the epilogue runs once, on the global sums
 dist.destroy_process_group()
 print("OK")

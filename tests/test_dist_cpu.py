@@ -20,6 +20,21 @@ def _free_port():
     return p
 
 
+POSE_STEPS = [  # cumulative perturbations of the query pose: a cache-hit step, then centimetres / a degree away
+    (np.zeros(3), np.array([0.004, 0.003, -0.002])),
+    (np.array([0.0, 0.0, 0.012]), np.array([0.06, -0.05, 0.02])),
+    (np.array([0.004, -0.003, 0.02]), np.array([-0.09, 0.11, 0.03])),
+]
+
+
+def _poses(R, t):
+    from mimosa_amd import synth
+    out = [(R, t)]
+    for w, d in POSE_STEPS:
+        out.append((R @ synth.so3_exp(w), t + d))
+    return out
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -43,15 +58,15 @@ def _worker(rank, world, port, out_dir):
         return ref_cpu.ICP(m, pts, ref_cpu.make_config(**cfg))
 
     sh = mdist.ShardedICP(dist.group.WORLD, make_map, make_factor, leaf=0.5)
-    batches = np.array_split(map_xyz, 3)
-    sh.build_map(batches)
-    mine = np.array_split(scan, world)[rank]  # every rank starts with a contiguous slice of the scan
-    local = sh.scatter_scan(mine, R, t)
-    res = sh.linearize(R, t)
-    res2 = sh.linearize(R, t + np.array([0.004, 0.003, -0.002]))  # everything hits the DA cache
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), H=res["H_ss"], b=res["b_s"], f=res["f"], hist=res["status_hist"],
-             n_knn=res["n_knn"], cq=res["mean_candidates"], n_local=res["n_local"], map_points=sh.map.num_points,
-             H2=res2["H_ss"], n_knn2=res2["n_knn"], local_idx=local["idx"])
+    sh.build_map(np.array_split(map_xyz, 3))
+    sh.set_scan(np.array_split(scan, world)[rank])  # every rank starts with a contiguous slice of the scan
+    out = {}
+    for k, (Rk, tk) in enumerate(_poses(R, t)):
+        res = sh.linearize(Rk, tk)
+        out.update({f"H{k}": res["H_ss"], f"b{k}": res["b_s"], f"f{k}": res["f"], f"hist{k}": res["status_hist"], f"n_knn{k}": res["n_knn"],
+                    f"cq{k}": res["mean_candidates"], f"n_local{k}": res["n_local"], f"moved{k}": res["n_migrated_in"]})
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), map_points=sh.map.num_points, origin=sh.rec["origin"], status=sh.rec["status"],
+             mean=sh.rec["mean"], **out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +89,8 @@ def test_partition_properties():
 
 
 def test_sharded_equals_unsharded_world2(tmp_path):
+    """Cold linearize, a cache-hit re-linearization and two re-linearizations centimetres / a degree away: at every pose
+    the sharded factor (points re-routed with their data-association state) equals the unsharded one."""
     import torch.multiprocessing as mp
     from mimosa_amd import synth
     from oracle import ref_cpu
@@ -91,17 +108,28 @@ def test_sharded_equals_unsharded_world2(tmp_path):
     M = ref_cpu.Map()
     for c in np.array_split(map_xyz, 3):
         M.insert(c)
-    full = ref_cpu.ICP(M, scan, ref_cpu.make_config(**synth.enwide_config())).linearize(R, t)
-
-    for r in (r0, r1):  # both ranks hold the all-reduced result
-        assert np.array_equal(r["hist"], full["status_hist"])
-        assert rel(r["H"], full["H_ss"]) <= 1e-12 and rel(r["b"], full["b_s"]) <= 1e-10
-        assert abs(float(r["f"]) - full["f"]) <= 1e-12 * full["f"]
-        assert int(r["n_knn"]) == full["n_knn"] and abs(float(r["cq"]) - full["mean_candidates"]) < 1e-9
-        assert int(r["n_knn2"]) == 0
-    # the scan was really split across the ranks, nothing lost or duplicated, and each shard is smaller
-    # than the whole map but larger than half of it (halo)
-    assert int(r0["n_local"]) + int(r1["n_local"]) == len(scan) and min(int(r0["n_local"]), int(r1["n_local"])) > 0
-    assert sorted(np.concatenate([r0["local_idx"], r1["local_idx"]]).tolist()) == sorted(scan["idx"].tolist())
+    F = ref_cpu.ICP(M, scan, ref_cpu.make_config(**synth.enwide_config()))
+    moved_later = 0
+    for k, (Rk, tk) in enumerate(_poses(R, t)):
+        full = F.linearize(Rk, tk)
+        for r in (r0, r1):  # both ranks hold the all-reduced result
+            assert np.array_equal(r[f"hist{k}"], full["status_hist"]), k
+            assert rel(r[f"H{k}"], full["H_ss"]) <= 1e-12 and rel(r[f"b{k}"], full["b_s"]) <= 1e-10, k
+            assert abs(float(r[f"f{k}"]) - full["f"]) <= 1e-12 * full["f"]
+            assert int(r[f"n_knn{k}"]) == full["n_knn"] and abs(float(r[f"cq{k}"]) - full["mean_candidates"]) < 1e-9
+        assert int(r0[f"n_local{k}"]) + int(r1[f"n_local{k}"]) == len(scan) and min(int(r0[f"n_local{k}"]), int(r1[f"n_local{k}"])) > 0
+        if k >= 2:
+            moved_later += int(r0[f"moved{k}"]) + int(r1[f"moved{k}"])
+    assert int(r0["n_knn1"]) == 0 and 0 < int(r0["n_knn2"]) < len(scan)   # step 1 hit the cache everywhere, step 2 did not
+    assert moved_later > 0                                                 # points really changed owner between the poses
+    # per-point state followed the points: the union of the ranks' records is the unsharded factor's state
+    st, mean, _, _ = F.da_state()
+    origin = np.concatenate([r0["origin"], r1["origin"]])
+    split = np.array_split(np.arange(len(scan)), world)
+    glob = np.array([split[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin])
+    assert sorted(glob.tolist()) == list(range(len(scan)))
+    assert np.array_equal(np.concatenate([r0["status"], r1["status"]]), st[glob])
+    assert np.abs(np.concatenate([r0["mean"], r1["mean"]]) - mean[glob]).max() <= 1e-12
+    # each shard is smaller than the whole map but larger than half of it (halo)
     assert M.num_points // 2 < int(r0["map_points"]) < M.num_points
     assert int(r0["map_points"]) + int(r1["map_points"]) > M.num_points
