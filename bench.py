@@ -51,6 +51,10 @@ def parse():
                          "(an event record costs ~4 us of stream time; 1 = every call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--shard-rooms", type=str, default="auto",
+                    help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
+                         "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
+    ap.add_argument("--sharded", action="store_true", help="run the map-sharded leg at --gpus 1 too (world 1 over RCCL)")
     return ap.parse_args()
 
 
@@ -67,11 +71,22 @@ def build_world(rank: int, rooms: str, rows: int):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout; RCCL prints a version banner there when a communicator comes up.  Everything
+    # else this process (and the libraries it loads) writes to fd 1 goes to stderr; the JSON line is written to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ:  # under torch.distributed.run
+    if args.sharded and "MASTER_ADDR" not in os.environ:  # plain `python bench.py --sharded`: a one-rank RCCL group
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        sk.close()
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ or args.sharded:  # under torch.distributed.run
         import torch
         import torch.distributed as dist
 
@@ -665,8 +680,63 @@ def main():
             "status_hist_equal": bool(np.array_equal(last["status_hist"], res4["status_hist"])),
         }
 
+    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node (mimosa_amd/dist.py): every
+    # rank stores the blocks it owns + a one-voxel halo, points are routed to the owner of their centre voxel with their
+    # association state (all-to-all over RCCL / xGMI), the Hessian sums and component localizabilities are all-reduced.  Reported
+    # NEXT TO the replica figure (`value`); all ranks take part.
+    sharded = None
+    if dist is not None and (world > 1 or args.sharded) and args.shard_rooms != "none":
+        import torch
+        from mimosa_amd import dist as mdist
+        sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else "4x5")
+        snx, sny = (int(v) for v in sr.lower().split("x"))
+        sctx = mdist.context_on_torch_stream(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sh = mdist.ShardedICPDevice(dist.group.WORLD, sctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), dev)
+        t0s = time.time()
+        sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), leaf=cfgd["target_ivox_map_leaf_size"],
+                     min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
+                     lru_horizon=synth.ENWIDE_LRU_HORIZON)
+        build_s = time.time() - t0s
+        spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
+        sh.set_scan(np.array_split(spts, world)[rank])
+        first_s = sh.linearize(R, t)                                         # routes the points to their owners
+        ksh, wsh = max(20, args.steps // 4), 5
+        def _sh_steps(k):
+            for _ in range(k):
+                sctx.check(sctx.L.mh_icp_reset(sh.fh))
+                sh.linearize(R, t)
+        _sh_steps(wsh)
+        dist.barrier()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        _sh_steps(ksh)
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - a
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        nloc = torch.tensor([float(first_s["n_local"]), float(sh.map.stats()["n_points"])], dtype=torch.float64, device="cuda")
+        nmax = nloc.clone()
+        dist.all_reduce(nloc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+        sharded = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
+                               f"(shard blocks of 8^3 voxels + one-voxel halo), cold linearize per step",
+                   "n_ranks": world, "backend": dist.get_backend(), "steps": ksh,
+                   "ms_per_linearize": round(el / ksh * 1e3, 4), "value": round(len(spts) * ksh / el / 1e6, 2), "unit": "Mpts/s",
+                   "scan_points_total": int(nloc[0].item()), "scan_points_max_per_rank": int(nmax[0].item()),
+                   "map_points_stored_total": int(nloc[1].item()), "map_points_max_per_rank": int(nmax[1].item()),
+                   "map_build_s": round(build_s, 2), "status_hist": [int(v) for v in first_s["status_hist"]],
+                   "collectives_per_linearize": "all_to_all(counts) + [all_to_all(records) when points change owner] + all_reduce(32 f64) + all_reduce(16 f64)",
+                   "note": "one scan is latency-bound when sharded (a few thousand points per rank and four collectives per linearize): "
+                           "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode"}
+        sh.close()
+    line["sharded"] = sharded
+
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     for f in factors:
         f.destroy()
     gmap.release()
