@@ -69,18 +69,18 @@ def _texture(hit_w: np.ndarray, face: np.ndarray) -> np.ndarray:
 
 
 def make_frame(cfg: dict, frame: int = 0, seed: int = synth.BASE_SEED + 77, room=ROOM, v=(1.2, 0.2, 0.0), w=(0.0, 0.0, 0.35),
-               col_ns: int = 97_656, dropout: float = 0.01):
+               col_ns: int = 97_656, dropout: float = 0.01, dt_frame: float = 0.1):
     """One staggered, skewed scan.  Returns dict(raw, deskewed, unique_ns, T_Le_Lt (n_cols x 12, fp64), R_W_L, t_W_L,
     R_W_Be, t_W_Be): raw / deskewed are POINT_DTYPE clouds with identical indexing (points_raw_ / points_full_ of
-    lidar/manager.cpp:376-380, :496-509); frame k is taken 0.1 s of the constant twist (v, w) after frame k - 1."""
+    lidar/manager.cpp:376-380, :496-509); frame k is taken dt_frame seconds of the constant twist (v, w) after frame k - 1."""
     rows, cols = cfg["rows"], cfg["cols"]
     room = np.asarray(room, float)
     v, w = np.asarray(v, float), np.asarray(w, float)
     # scan-end pose of this frame: integrate the twist from the start pose
     R_end, t_end = synth.rot_z(synth.SENSOR_YAW), synth.room_origin(0, 0) + SENSOR_LOCAL
     for _ in range(frame):
-        t_end = t_end + R_end @ (v * 0.1)
-        R_end = R_end @ synth.so3_exp(w * 0.1)
+        t_end = t_end + R_end @ (v * dt_frame)
+        R_end = R_end @ synth.so3_exp(w * dt_frame)
     shift = np.asarray(cfg["pixel_shift_by_row"], np.int64)
     alt = np.deg2rad(np.asarray(cfg["beam_altitude_angles"], np.float64))
     r_, c_ = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")

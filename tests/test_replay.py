@@ -1,37 +1,62 @@
-"""Sequence replay (SURVEY.md §8 "next" row f-4): front end -> factor -> Gauss-Newton -> keyframe map update.
+"""Sequence replay (SURVEY.md §8 "next" row f-4, BASELINE configs[4]): front end -> IMU-propagated deskew -> geometric +
+photometric factors -> fixed-lag Gauss-Newton window (all live ICP factors re-linearized per iteration) -> keyframe map update.
 
-CPU: the loop on the oracle converges to the ground-truth trajectory (checks the Jacobian / retraction
-convention end to end, with no GPU involved).  GPU: the same loop through the C ABI produces the same
-trajectory as the oracle loop, scan by scan."""
+CPU: the loop on the oracle tracks the ground-truth trajectory (checks Jacobian / retraction / between-factor conventions end to
+end, no GPU involved).  GPU: the same loop through the C ABI (batched re-linearization, device-resident front end, map and
+photometric frame) produces the same trajectory as the oracle loop, scan by scan."""
 import numpy as np
 import pytest
 
-from mimosa_amd import replay, synth
+from mimosa_amd import replay
 from oracle.replay_backend import OracleBackend
 
 
-def small_cfg(n=5):
-    return replay.ReplayConfig(n_scans=n, rows=32, cols=256, v=(0.6, 0.2, 0.0), w=(0.0, 0.0, 0.3), start_local=(4.0, 4.0, 1.2),
-                               room=(12.0, 10.0, 3.0), keyframe_trans_thresh=0.1, keyframe_rot_thresh_deg=5.0)
+def small_cfg(n=6, **kw):
+    return replay.ReplayConfig(n_scans=n, rows=64, cols=512, room=(12.0, 10.0, 3.0), keyframe_trans_thresh=0.2,
+                               keyframe_rot_thresh_deg=5.0, **kw)
 
 
-def test_replay_converges_on_oracle():
-    cfg = small_cfg(5)
+def test_replay_tracks_ground_truth_on_oracle():
+    cfg = small_cfg(6)
     scans = replay.make_scans(cfg)
-    r = replay.run(cfg, OracleBackend(cfg.reg), scans)
+    r = replay.run(cfg, OracleBackend(cfg), scans)
     assert r["n_keyframes"] >= 2
-    assert max(r["trans_err"]) < 0.01 and max(r["rot_err_deg"]) < 0.05   # from 3 cm / 0.3 deg priors
-    for fs in r["costs"]:
-        assert fs[-1] < fs[0]                                             # every optimisation lowered the cost
+    # from a 3 cm / 0.3 deg first guess; the ~5 mm floor is the small room's corner bias of 5-point plane fits, not noise
+    assert max(r["trans_err"]) < 0.012 and max(r["rot_err_deg"]) < 0.06
+    assert r["costs"][0][-1] < r["costs"][0][0]                          # the first window really had to move
+    assert len(r["photo_valid"]) == 5 and min(r["photo_valid"]) >= 20     # features are tracked from scan to scan
+    # without the photometric factor the geometric window alone tracks as well
+    cfg2 = small_cfg(4, photometric=False)
+    r2 = replay.run(cfg2, OracleBackend(cfg2), scans[:4])
+    assert max(r2["trans_err"]) < 0.012
+
+
+def test_imu_propagation_matches_the_exact_twist():
+    """propagate() — Manager::deskewPoints' host part — against the closed-form constant-twist motion."""
+    from mimosa_amd import synth
+
+    cfg = small_cfg(2, imu_gyro_noise=0.0, imu_acc_noise=0.0)
+    scans = replay.make_scans(cfg)
+    s0, s1 = scans
+    uns = s1["frame"]["unique_ns"]
+    T, (Rp, pp, vp) = replay.propagate(s0["R_gt"], s0["t_gt"], s0["R_gt"] @ np.array(cfg.v), s1["imu"], s1["header_ts"], uns)
+    w, v = np.array(cfg.w), np.array(cfg.v)
+    assert np.abs(Rp - s0["R_gt"] @ synth.so3_exp(w * cfg.dt)).max() < 1e-9
+    # exact: p(dt) = p0 + R0 * int_0^dt Exp(w s) v ds; the scan generator steps first-order, 0.5 |w x v| dt^2 ~ 2 mm apart
+    ss = np.linspace(0, cfg.dt, 2001)
+    exact = s0["t_gt"] + s0["R_gt"] @ (np.trapezoid(np.stack([synth.so3_exp(w * x) @ v for x in ss]), ss, axis=0))
+    assert np.linalg.norm(pp - exact) < 2e-5
+    assert np.linalg.norm(pp - s1["t_gt"]) < 3e-3
+    assert np.abs(T[-1, :9].reshape(3, 3) - Rp).max() < 1e-12 and np.abs(T[-1, 9:] - pp).max() < 1e-12
 
 
 @pytest.mark.gpu
 def test_replay_hip_equals_oracle(ctx):
-    cfg = small_cfg(5)
+    cfg = small_cfg(6)
     scans = replay.make_scans(cfg)
-    ro = replay.run(cfg, OracleBackend(cfg.reg), scans)
-    rh = replay.run(cfg, replay.HipBackend(ctx, cfg.reg), scans)
-    assert rh["n_keyframes"] == ro["n_keyframes"]
+    ro = replay.run(cfg, OracleBackend(cfg), scans)
+    rh = replay.run(cfg, replay.HipBackend(ctx, cfg), scans)
+    assert rh["n_keyframes"] == ro["n_keyframes"] and rh["photo_valid"] == ro["photo_valid"]
     for (Ra, ta), (Rb, tb) in zip(rh["poses_est"], ro["poses_est"]):
-        assert np.max(np.abs(ta - tb)) < 1e-8 and np.max(np.abs(Ra - Rb)) < 1e-9
-    assert max(rh["trans_err"]) < 0.01
+        assert np.max(np.abs(ta - tb)) < 1e-7 and np.max(np.abs(Ra - Rb)) < 1e-8
+    assert max(rh["trans_err"]) < 0.012

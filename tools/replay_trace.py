@@ -6,5 +6,5 @@ from mimosa_amd import capi, replay
 ctx = capi.Context(0)
 cfg = replay.ReplayConfig(n_scans=20)
 scans = replay.make_scans(cfg)
-r = replay.run(cfg, replay.HipBackend(ctx, cfg.reg), scans)
+r = replay.run(cfg, replay.HipBackend(ctx, cfg), scans)
 print("scans/s", r["scans_per_s"], r["stage_s"])
