@@ -314,8 +314,8 @@ def main():
             ctx.set_profiling(False)
             # device-resident variant: raw + deskewed clouds already on the device (mh_scan), no 8 MB upload
             npx = pcfg["rows"] * pcfg["cols"]
-            n_pts = len(pf[0]["raw"])
-            alg_bytes = n_pts * 64 + npx * (4 * 6 + 1 + 4 * 10) + npx * 8 * 5   # clouds in, images + proj_idx out, 5 filter passes
+            n_photo_pts = len(pf[0]["raw"])
+            alg_bytes = n_photo_pts * 64 + npx * (4 * 6 + 1 + 4 * 10) + npx * 8 * 5   # clouds in, images + proj_idx out, 5 filter passes
             entry = {"features": nfeat, "points_per_feature": patch * patch,
                      "preprocess_ms_host_buffers": round(float(np.median(tp)) * 1e3, 4),
                      "detect_features_ms": round(t_detect * 1e3, 3),

@@ -238,6 +238,7 @@ static int mh_init_impl(int device, mh_ctx ** out)
   MH_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[0]));
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[1]));
+  AllocCache::contexts()++;
   *out = ctx;
   return MH_OK;
 }
@@ -259,7 +260,12 @@ void mh_shutdown(mh_ctx * ctx)
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  const int dev = ctx->device;
   delete ctx;
+  if (--AllocCache::contexts() <= 0) {  // the last context is gone: hand the cached device / pinned blocks back
+    AllocCache::contexts() = 0;
+    AllocCache::trim(dev);
+  }
 }
 
 static int mh_set_profiling_impl(mh_ctx * ctx, int on)

@@ -91,35 +91,41 @@ public:
         *out = v.back();
         v.pop_back();
         cached_bytes()[dev] -= cls;
-        live()[*out] = cls;
+        live()[*out] = Block{cls, dev};
         return hipSuccess;
       }
     }
     const hipError_t e = hipMalloc(out, cls ? cls : bytes);
     if (e == hipSuccess && cls) {
       std::lock_guard<std::mutex> g(mu());
-      live()[*out] = cls;
+      live()[*out] = Block{cls, dev};
     }
     return e;
   }
   static void free(void * p)
   {
     if (!p) return;
-    size_t cls = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    Block b{0, 0};
     {
       std::lock_guard<std::mutex> g(mu());
       auto it = live().find(p);
       if (it != live().end()) {
-        cls = it->second;
+        b = it->second;
         live().erase(it);
       }
-      if (cls && cached_bytes()[dev] + cls <= kMaxCachedBytes) {
-        // in-flight work may still read / write the block: drain before it can be handed out again
-        (void)hipDeviceSynchronize();
-        free_list()[key(dev, cls)].push_back(p);
-        cached_bytes()[dev] += cls;
+    }
+    if (b.cls) {
+      // in-flight work may still read / write the block: drain ITS device before it can be handed out again — outside
+      // the lock, on the device the block was allocated on (not whatever device is current at free time)
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      if (cur != b.dev) (void)hipSetDevice(b.dev);
+      (void)hipDeviceSynchronize();
+      if (cur != b.dev) (void)hipSetDevice(cur);
+      std::lock_guard<std::mutex> g(mu());
+      if (cached_bytes()[b.dev] + b.cls <= kMaxCachedBytes) {
+        free_list()[key(b.dev, b.cls)].push_back(p);
+        cached_bytes()[b.dev] += b.cls;
         return;
       }
     }
@@ -142,16 +148,49 @@ public:
   static void free_pinned(void * p, size_t bytes)
   {
     if (!p) return;
-    std::lock_guard<std::mutex> g(mu());
-    auto & v = pinned()[bytes];
-    if (v.size() < 64) {
-      v.push_back(p);
-      return;
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto & v = pinned()[bytes];
+      if (v.size() < 64) {
+        v.push_back(p);
+        return;
+      }
     }
     (void)hipHostFree(p);
   }
+  // mh_shutdown of the last context of a device: give the cached blocks of that device back to the runtime
+  static void trim(int dev)
+  {
+    std::vector<void *> dead, dead_pinned;
+    {
+      std::lock_guard<std::mutex> g(mu());
+      for (auto & kv : free_list())
+        if (static_cast<int>(kv.first >> 56) == dev) {
+          dead.insert(dead.end(), kv.second.begin(), kv.second.end());
+          kv.second.clear();
+        }
+      cached_bytes()[dev] = 0;
+      if (contexts() == 0)
+        for (auto & kv : pinned()) {
+          dead_pinned.insert(dead_pinned.end(), kv.second.begin(), kv.second.end());
+          kv.second.clear();
+        }
+    }
+    for (void * p : dead) (void)hipFree(p);
+    for (void * p : dead_pinned) (void)hipHostFree(p);
+  }
+  static int & contexts()
+  {
+    static int n = 0;
+    return n;
+  }
 
 private:
+  struct Block
+  {
+    size_t cls;
+    int dev;
+  };
   static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
   static size_t size_class(size_t bytes)
   {
@@ -171,9 +210,9 @@ private:
     static std::unordered_map<uint64_t, std::vector<void *>> m;
     return m;
   }
-  static std::unordered_map<void *, size_t> & live()
+  static std::unordered_map<void *, Block> & live()
   {
-    static std::unordered_map<void *, size_t> m;
+    static std::unordered_map<void *, Block> m;
     return m;
   }
   static std::unordered_map<int, size_t> & cached_bytes()

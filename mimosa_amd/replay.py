@@ -155,16 +155,25 @@ def propagate(R, p, vel, imu, header_ts, unique_ns):
         d = ts[c + 1] - ts[c]
         aw = Rc @ acc[c] + GRAVITY
         states.append((Rc @ synth.so3_exp(gyro[c] * d), pc + vc * d + 0.5 * aw * d * d, vc + aw * d))
-    out = np.empty((len(unique_ns), 12))
-    c = 0
-    for u, ns in enumerate(unique_ns):
-        tq = header_ts + float(ns) * 1e-9
-        while c + 2 < len(ts) and tq > ts[c + 1]:
-            c += 1
-        Rc, pc, vc = states[c]
-        d = tq - ts[c]
-        out[u, :9] = (Rc @ synth.so3_exp(gyro[c] * d)).ravel()
-        out[u, 9:] = pc + vc * d + 0.5 * (Rc @ acc[c]) * d * d + 0.5 * GRAVITY * d * d
+    # every distinct timestamp: sample interval c with ts[c] < tq <= ts[c + 1] (manager.cpp:470-476), vectorised
+    tq = header_ts + np.asarray(unique_ns, np.float64) * 1e-9
+    ci = np.clip(np.searchsorted(ts[1:-1], tq, side="left"), 0, len(ts) - 2)
+    Rs = np.stack([s_[0] for s_ in states])[ci]
+    ps = np.stack([s_[1] for s_ in states])[ci]
+    vs = np.stack([s_[2] for s_ in states])[ci]
+    d = (tq - ts[ci])[:, None]
+    wv = gyro[ci] * d
+    th = np.linalg.norm(wv, axis=1)
+    th2 = th * th
+    with np.errstate(invalid="ignore", divide="ignore"):
+        A = np.where(th < 1e-12, 1.0 - th2 / 6.0, np.sin(th) / th)
+        B = np.where(th < 1e-12, 0.5 - th2 / 24.0, (1.0 - np.cos(th)) / th2)
+    K = np.zeros((len(tq), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -wv[:, 2], wv[:, 1], wv[:, 2], -wv[:, 0], -wv[:, 1], wv[:, 0]
+    E = np.eye(3)[None] + A[:, None, None] * K + B[:, None, None] * (K @ K)
+    out = np.empty((len(tq), 12))
+    out[:, :9] = (Rs @ E).reshape(-1, 9)
+    out[:, 9:] = ps + vs * d + 0.5 * np.einsum("nij,nj->ni", Rs, acc[ci]) * d * d + 0.5 * GRAVITY * d * d
     return out, states[-1]
 
 
@@ -257,10 +266,8 @@ def run(cfg: ReplayConfig, backend, scans=None, rng_seed=7):
             R_start, p_start, vel_start = R_prev, t_prev, vel_prev
         T_W_Bt, (R_pred, p_pred, vel_pred) = propagate(R_start, p_start, vel_start, sc["imu"], sc["header_ts"], uns)
         T_Le_Lt = np.empty_like(T_W_Bt)
-        for u in range(len(uns)):
-            Ru, pu = T_W_Bt[u, :9].reshape(3, 3), T_W_Bt[u, 9:]
-            T_Le_Lt[u, :9] = (R_pred.T @ Ru).ravel()
-            T_Le_Lt[u, 9:] = R_pred.T @ (pu - p_pred)
+        T_Le_Lt[:, :9] = (R_pred.T @ T_W_Bt[:, :9].reshape(-1, 3, 3)).reshape(-1, 9)
+        T_Le_Lt[:, 9:] = (T_W_Bt[:, 9:] - p_pred) @ R_pred
         a2 = time.perf_counter()
         backend.deskew_and_preprocess(T_Le_Lt)
         a3 = time.perf_counter()
