@@ -421,8 +421,40 @@ def main():
                 tg["factor_create_ms"].append(a4 - a3)
         fe_stats = {k: round(float(np.median(v)) * 1e3, 3) for k, v in tg.items()}
         fe_stats.update({"raw_points": int(len(raw)), "points_full": finfo["n_full"], "geometric_subset": finfo["n_geometric"],
-                         "downsampled": finfo["n_downsampled"], "unique_timestamps": finfo["n_unique_ns"]})
+                         "downsampled": finfo["n_downsampled"], "unique_timestamps": finfo["n_unique_ns"],
+                         "kernel_launches": {"prepare_input": 3, "deskew": 1, "preprocess_geometric": "7 + 1 memset"}})
+        # the same scan with the raw cloud already resident (mh_scan_prepare_input_device): the figure without the 4 MiB
+        # PCIe upload; and the dense variant (every point in the geometric subset) of the down-sampler
+        import ctypes as _C
+        _hip = _C.CDLL("libamdhip64.so")
+        d_raw = _C.c_void_p()
+        assert _hip.hipMalloc(_C.byref(d_raw), _C.c_size_t(raw.nbytes)) == 0
+        assert _hip.hipMemcpy(d_raw, _C.c_void_p(raw.ctypes.data), _C.c_size_t(raw.nbytes), 1) == 0
+        dense_cfg = capi.make_input_config(point_skip_divisor=1)
+        tr, td, tt = [], [], []
+        for it in range(8):
+            ctx.synchronize()
+            a0 = time.perf_counter()
+            sc.prepare_input_device(d_raw.value, len(raw), icfg)
+            a1 = time.perf_counter()
+            if it:
+                tr.append(a1 - a0)
+        for it in range(6):
+            sc.prepare_input_device(d_raw.value, len(raw), dense_cfg)
+            sc.deskew(Rt12)
+            ctx.synchronize()
+            a0 = time.perf_counter()
+            dinfo = sc.preprocess_geometric(I3, z3, cfgd["source_voxel_grid_filter_leaf_size"], 20,
+                                            cfgd["source_voxel_grid_min_dist_in_voxel"])
+            a1 = time.perf_counter()
+            if it:
+                td.append(a1 - a0)
+        fe_stats["prepare_input_resident_ms"] = round(float(np.median(tr)) * 1e3, 3)
+        fe_stats["resident_total_ms"] = round(fe_stats["prepare_input_resident_ms"] + fe_stats["deskew_ms"] + fe_stats["preprocess_geometric_ms"], 3)
+        fe_stats["dense_subset"] = {"geometric_subset": dinfo["n_geometric"], "downsampled": dinfo["n_downsampled"],
+                                    "preprocess_geometric_ms": round(float(np.median(td)) * 1e3, 3)}
         sc.destroy()
+        _hip.hipFree(d_raw)
         if not args.no_cpu_baseline:
             from oracle import ref_cpu as _rc
             ocfg = _rc.make_input_config()

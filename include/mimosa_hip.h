@@ -298,6 +298,10 @@ void mh_scan_destroy(mh_scan * scan);
  * z offset, points_full_ (order preserved), geometric subset indices, distinct timestamps (ascending). */
 int mh_scan_prepare_input(mh_scan * scan, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg,
                           mh_scan_info * info);
+/* Same, for a raw cloud that is already in device memory (a driver that DMAs packets to the GPU, or a benchmark that
+ * wants the figure without the PCIe upload): d_raw must stay valid and unchanged until the call returns. */
+int mh_scan_prepare_input_device(mh_scan * scan, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg,
+                                 mh_scan_info * info);
 /* unique_ns_ (lidar/manager.cpp:344-368), ascending; the caller's IMU propagation needs them on the host. */
 int mh_scan_get_unique_ns(const mh_scan * scan, uint32_t * out, size_t capacity, size_t * n_out);
 /* Manager::deskewPoints' per-point part (lidar/manager.cpp:496-509) on points_full_, in place:

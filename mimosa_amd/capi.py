@@ -25,7 +25,7 @@ EXPORTS = [
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
-    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_get_unique_ns", "mh_scan_deskew",
+    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
@@ -290,6 +290,7 @@ def load(build_if_missing: bool = True):
     L.mh_scan_destroy.argtypes = [vp]
     L.mh_scan_destroy.restype = None
     L.mh_scan_prepare_input.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
+    L.mh_scan_prepare_input_device.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
     L.mh_scan_get_unique_ns.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.mh_scan_deskew.argtypes = [vp, vp, sz]
     L.mh_scan_preprocess_geometric.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.POINTER(ScanInfo)]
@@ -489,6 +490,12 @@ class Scan:
         assert raw.dtype.itemsize == 32
         info = ScanInfo()
         self.ctx.check(self.L.mh_scan_prepare_input(self.h, _p(raw), len(raw), C.byref(cfg), C.byref(info)))
+        return info.as_dict()
+
+    def prepare_input_device(self, d_raw_ptr: int, n: int, cfg: InputConfig) -> dict:
+        """raw cloud (32-byte Ouster records) already in device memory at address d_raw_ptr"""
+        info = ScanInfo()
+        self.ctx.check(self.L.mh_scan_prepare_input_device(self.h, C.c_void_p(d_raw_ptr), n, C.byref(cfg), C.byref(info)))
         return info.as_dict()
 
     def unique_ns(self):

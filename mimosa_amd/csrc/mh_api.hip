@@ -1025,8 +1025,15 @@ namespace
 int scan_fetch_counters(mh_scan * s)
 {
   mh_ctx * ctx = s->ctx;
-  MH_HIP(ctx, hipMemcpyAsync(&s->c, s->d_counters.p, sizeof(s->c), hipMemcpyDeviceToHost, ctx->stream));
+  if (!s->h_c) {
+    void * p = nullptr;
+    MH_HIP(ctx, AllocCache::alloc_pinned(&p, sizeof(mh::ScanCounters)));
+    s->h_c = static_cast<mh::ScanCounters *>(p);
+  }
+  MH_HIP(ctx, hipMemcpyAsync(s->h_c, s->d_counters.p, sizeof(s->c), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  s->c = *s->h_c;
+  s->c.n_unique_ns += s->c.has_max_ns;  // the value 0xFFFFFFFF travels as a flag (scan_kernels.hip: input_scatter_kernel)
   return MH_OK;
 }
 void scan_fill_info(const mh_scan * s, mh_scan_info * info)
@@ -1067,41 +1074,40 @@ void mh_scan_destroy(mh_scan * s)
   (void)hipStreamSynchronize(s->ctx->stream);
   s->d_full_raw.release();
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
-                     &s->d_temp, &s->d_rt, &s->d_u32[0], &s->d_u32[1], &s->d_u32[2], &s->d_u32[3], &s->d_u64[0], &s->d_u64[1],
-                     &s->d_seg, &s->d_first})
+                     &s->d_rt, &s->d_prep, &s->d_vox})
     b->release();
+  AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters));
   delete s;
 }
 
-static int mh_scan_prepare_input_impl(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
+static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool raw_on_device, size_t n, const mh_input_config * cfg,
+                               mh_scan_info * info, const char * who)
 {
-  if (!s || !cfg || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: NULL argument");
+  if (!s || !cfg || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
   mh_ctx * ctx = s->ctx;
-  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_prepare_input: cloud too large");
+  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": cloud too large");
   if (cfg->point_skip_divisor < 1 || cfg->ring_skip_divisor < 1)
-    return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_prepare_input: skip divisors must be >= 1");
+    return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": skip divisors must be >= 1");
   MH_HIP(ctx, hipSetDevice(ctx->device));
   s->prepared = s->preprocessed = s->raw_valid = false;
   s->n_in = n;
   s->n_body = 0;
   const size_t m = n ? n : 1;
-  MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));
+  if (!raw_on_device) MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));
   MH_HIP(ctx, s->d_full.reserve(m * sizeof(mh_point32), ctx->stream, false));
   MH_HIP(ctx, s->d_geo_idx.reserve(m * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, s->d_unique.reserve(m * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, s->d_unique.reserve((m + 1) * sizeof(uint32_t), ctx->stream, false));
   MH_HIP(ctx, s->d_counters.reserve(sizeof(mh::ScanCounters), ctx->stream, false));
-  for (auto & b : s->d_u32) MH_HIP(ctx, b.reserve(m * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, s->d_temp.reserve(mh::scan_temp_bytes(m), ctx->stream, false));
-  if (n) MH_HIP(ctx, hipMemcpyAsync(s->d_raw.p, raw, n * sizeof(mh_ouster_point), hipMemcpyHostToDevice, ctx->stream));
-  auto * cnt = static_cast<mh::ScanCounters *>(s->d_counters.p);
-  uint32_t * u[4];
-  for (int i = 0; i < 4; ++i) u[i] = static_cast<uint32_t *>(s->d_u32[i].p);
-  MH_HIP(ctx, mh::launch_input_filter(static_cast<const mh_ouster_point *>(s->d_raw.p), static_cast<uint32_t>(n), *cfg, u[0],
-                                      u[1], u[2], u[3], static_cast<mh_point32 *>(s->d_full.p),
-                                      static_cast<uint32_t *>(s->d_geo_idx.p), cnt, s->d_temp.p, s->d_temp.cap, ctx->stream));
-  MH_HIP(ctx, mh::launch_unique_ns(static_cast<const mh_point32 *>(s->d_full.p), cnt, static_cast<uint32_t>(n), u[0], u[1],
-                                   u[2], u[3], static_cast<uint32_t *>(s->d_unique.p), cnt, s->d_temp.p, s->d_temp.cap,
-                                   ctx->stream));
+  MH_HIP(ctx, s->d_prep.reserve(mh::prepare_layout(n).words * sizeof(uint32_t), ctx->stream, false));
+  const mh_ouster_point * d_raw = raw;
+  if (!raw_on_device) {
+    if (n) MH_HIP(ctx, hipMemcpyAsync(s->d_raw.p, raw, n * sizeof(mh_ouster_point), hipMemcpyHostToDevice, ctx->stream));
+    d_raw = static_cast<const mh_ouster_point *>(s->d_raw.p);
+  }
+  MH_HIP(ctx, mh::launch_prepare_input(d_raw, static_cast<uint32_t>(n), *cfg, static_cast<uint32_t *>(s->d_prep.p),
+                                       static_cast<mh_point32 *>(s->d_full.p), static_cast<uint32_t *>(s->d_geo_idx.p),
+                                       static_cast<uint32_t *>(s->d_unique.p), static_cast<mh::ScanCounters *>(s->d_counters.p),
+                                       ctx->stream));
   const int rc = scan_fetch_counters(s);
   if (rc != MH_OK) return rc;
   s->prepared = true;
@@ -1110,7 +1116,13 @@ static int mh_scan_prepare_input_impl(mh_scan * s, const mh_ouster_point * raw, 
 }
 int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
 {
-  return guarded(nullptr, "mh_scan_prepare_input", [&]() -> int { return mh_scan_prepare_input_impl(s, raw, n, cfg, info); });
+  return guarded(nullptr, "mh_scan_prepare_input",
+                 [&]() -> int { return scan_prepare_common(s, raw, false, n, cfg, info, "mh_scan_prepare_input"); });
+}
+int mh_scan_prepare_input_device(mh_scan * s, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
+{
+  return guarded(nullptr, "mh_scan_prepare_input_device",
+                 [&]() -> int { return scan_prepare_common(s, d_raw, true, n, cfg, info, "mh_scan_prepare_input_device"); });
 }
 
 static int mh_scan_get_unique_ns_impl(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
@@ -1173,31 +1185,18 @@ static int mh_scan_preprocess_geometric_impl(mh_scan * s, const float R_B_L[9], 
   MH_HIP(ctx, s->d_body.reserve(m * sizeof(mh_point32), ctx->stream, false));
   MH_HIP(ctx, s->d_ds.reserve(m * sizeof(mh_point32), ctx->stream, false));
   MH_HIP(ctx, s->d_kept_idx.reserve(m * sizeof(uint32_t), ctx->stream, false));
-  for (auto & b : s->d_u64) MH_HIP(ctx, b.reserve(m * sizeof(uint64_t), ctx->stream, false));
-  MH_HIP(ctx, s->d_seg.reserve((m + 1) * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, s->d_first.reserve(m * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, s->d_rt.reserve(12 * sizeof(float), ctx->stream, false));
-  float rt[12];
-  std::memcpy(rt, R_B_L, 9 * sizeof(float));
-  std::memcpy(rt + 9, t_B_L, 3 * sizeof(float));
-  MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rt is a stack buffer
+  MH_HIP(ctx, s->d_vox.reserve(mh::voxel_layout(n).bytes, ctx->stream, false));
+  mh::Rt12 rt;  // passed to the kernel by value: no staging copy
+  std::memcpy(rt.v, R_B_L, 9 * sizeof(float));
+  std::memcpy(rt.v + 9, t_B_L, 3 * sizeof(float));
   auto * cnt = static_cast<mh::ScanCounters *>(s->d_counters.p);
-  MH_HIP(ctx, mh::launch_gather_transform(static_cast<const mh_point32 *>(s->d_full.p),
-                                          static_cast<const uint32_t *>(s->d_geo_idx.p), static_cast<uint32_t>(n),
-                                          static_cast<const float *>(s->d_rt.p), static_cast<mh_point32 *>(s->d_body.p),
-                                          ctx->stream));
-  MH_HIP(ctx, mh::launch_downsample(static_cast<const mh_point32 *>(s->d_body.p), static_cast<uint32_t>(n), leaf_size,
-                                    static_cast<uint32_t>(max_points_per_voxel), min_dist_in_voxel,
-                                    static_cast<uint64_t *>(s->d_u64[0].p), static_cast<uint64_t *>(s->d_u64[1].p),
-                                    static_cast<uint32_t *>(s->d_u32[0].p), static_cast<uint32_t *>(s->d_u32[1].p),
-                                    static_cast<uint32_t *>(s->d_u32[2].p), static_cast<uint32_t *>(s->d_u32[3].p),
-                                    static_cast<uint32_t *>(s->d_seg.p), static_cast<uint32_t *>(s->d_first.p),
-                                    static_cast<uint32_t *>(s->d_kept_idx.p), static_cast<mh_point32 *>(s->d_ds.p), cnt,
-                                    s->d_temp.p, s->d_temp.cap, ctx->stream));
+  MH_HIP(ctx, mh::launch_preprocess(static_cast<const mh_point32 *>(s->d_full.p), static_cast<const uint32_t *>(s->d_geo_idx.p),
+                                    static_cast<uint32_t>(n), rt, leaf_size, static_cast<uint32_t>(max_points_per_voxel),
+                                    min_dist_in_voxel, s->d_vox.p, static_cast<mh_point32 *>(s->d_body.p),
+                                    static_cast<uint32_t *>(s->d_kept_idx.p), static_cast<mh_point32 *>(s->d_ds.p), cnt, ctx->stream));
   const int rc = scan_fetch_counters(s);
   if (rc != MH_OK) return rc;
-  if (n == 0) s->c.n_downsampled = 0;
+  if (n == 0) s->c.n_downsampled = s->c.bad_coord = 0;
   if (s->c.bad_coord) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_preprocess_geometric: a voxel coordinate exceeds +-2^20");
   s->preprocessed = true;
   scan_fill_info(s, info);

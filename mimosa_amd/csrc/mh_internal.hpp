@@ -288,11 +288,11 @@ struct DevBuf
 struct mh_scan
 {
   mh_ctx * ctx;
-  DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_temp, d_rt;
+  DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_rt;
   DevBuf d_full_raw;  // points_raw_ (lidar/manager.cpp:376-380): points_full_ as it was before deskewing, kept for the photometric path
   bool keep_raw = false, raw_valid = false;
-  DevBuf d_u32[4];  // flag / pos scratch (prepare_input), keys / flags / pos (unique, down-sampler)
-  DevBuf d_u64[2], d_seg, d_first;
+  DevBuf d_prep, d_vox;  // scratch of launch_prepare_input / launch_preprocess (scan_device.hpp: prepare_layout, voxel_layout)
+  mh::ScanCounters * h_c = nullptr;  // pinned landing buffer of the device counters
   mh::ScanCounters c{};
   size_t n_in = 0, n_body = 0;
   bool prepared = false, preprocessed = false;

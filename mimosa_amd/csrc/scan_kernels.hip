@@ -9,23 +9,31 @@
 //   Geometric::downsample   src/lidar/geometric.cpp:55-126 + FlatContainerMinimal::add
 //                           include/mimosa/lidar/utils.hpp:260-278 (greedy per-voxel min-distance filter)
 //
-// All of it is order-dependent sequential code in the reference; the device forms reproduce the SAME outputs
-// in the same order:
-//   * filter: per-point predicate -> exclusive scan -> scatter (an order-preserving compaction);
-//   * down-sampler: the greedy rule only couples points of one voxel, in input order.  A stable radix sort
-//     by voxel key makes every voxel a contiguous segment still in input order; one thread walks each
-//     segment exactly like FlatContainerMinimal::add; the output order "voxels in first-seen order, points
-//     in acceptance order" is the ascending order of (first input index of the voxel, input index), one
-//     more radix sort of the kept points.
-// HBM-bound streaming / sorting work (32 B records, <= 131 072 of them): no MFMA, no LDS tiling to speak of.
-// Compiled with -ffp-contract=off: the reference is a baseline x86-64 build (no FMA) and both the range
-// filter and the voxel assignment are threshold tests on these f32 / f64 values.
+// All of it is order-dependent sequential code in the reference; the device forms reproduce the SAME outputs in
+// the same order with 11 kernels + 1 memset per scan and no library sort:
+//   prepare (3 kernels)
+//     input_count      per 1024-point block: how many points pass the filter / belong to the geometric subset
+//     input_scatter    block prefix (sum of the preceding block counts) + in-block scan -> order-preserving
+//                      compaction into points_full_ / geometric_point_idxs_; every kept timestamp goes through a
+//                      hash set, first-inserters append it to an unsorted list; max timestamp by atomicMax
+//     unique_sort      rank sort of the distinct timestamps (distinct => rank = number of smaller ones), tiles in LDS
+//   deskew (1 kernel, deskew_kernels.hip)
+//   preprocess (memset + 7 kernels)
+//     body_voxel       gather + f32 body transform + voxel key -> hash table: slot of the voxel, atomicMin of the
+//                      first input index, atomicAdd of the point count
+//     voxel_count / voxel_offsets   scan over input positions of "count of the voxel whose first point I am":
+//                      voxels laid out in first-seen order (geometric.cpp:103-109), compact voxel list
+//     voxel_scatter    every point into its voxel's segment (atomic cursor: unordered inside the segment)
+//     greedy_voxel     one wave per voxel: sort the segment by input index (rank sort in registers / from L1; a
+//                      wave-level binary LSD radix for > 1024 points), then FlatContainerMinimal::add in input order
+//     keep_count / keep_scatter     order-preserving compaction of the kept points = "voxels in first-seen order,
+//                      points in acceptance order"
+// HBM/L2-bound streaming, hashing and small-sort work (32 B records, <= 131 072 of them): no MFMA.  Compiled with
+// -ffp-contract=off: the reference is a baseline x86-64 build (no FMA) and both the range filter and the voxel
+// assignment are threshold tests on these f32 / f64 values.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "scan_device.hpp"
 #include "voxel_map.hpp"
@@ -35,10 +43,103 @@ namespace mh
 namespace
 {
 constexpr int kThreads = 256;
-constexpr uint32_t kNoKey32 = 0xFFFFFFFFu;
-constexpr uint64_t kNoKey64 = ~0ull;
+constexpr int kItems = 4;                         // consecutive elements per thread in the blocked kernels
+constexpr uint32_t kBlockItems = kThreads * kItems;
+constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
+constexpr uint64_t kEmpty64 = ~0ull;
 
-int grid_for(uint32_t n) { return static_cast<int>(max(1u, min((n + kThreads - 1) / kThreads, 4096u))); }
+uint32_t blocks_for(uint32_t n) { return n ? (n + kBlockItems - 1) / kBlockItems : 1u; }
+
+// ---- block-level helpers (256 threads = 4 waves) ------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d);
+    if (lane >= static_cast<uint32_t>(d)) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// exclusive prefix of (a, b) over the block's threads + block totals.  lds: 8 words.
+__device__ __forceinline__ void block_exclusive_sum2(uint32_t a, uint32_t b, uint32_t & ea, uint32_t & eb, uint32_t & ta,
+                                                     uint32_t & tb, uint32_t * lds)
+{
+  const uint32_t ia = wave_inclusive_sum(a), ib = wave_inclusive_sum(b);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 63u) {
+    lds[wave] = ia;
+    lds[4 + wave] = ib;
+  }
+  __syncthreads();
+  uint32_t oa = 0, ob = 0;
+  ta = tb = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; ++w) {
+    const uint32_t xa = lds[w], xb = lds[4 + w];
+    if (w < wave) {
+      oa += xa;
+      ob += xb;
+    }
+    ta += xa;
+    tb += xb;
+  }
+  ea = oa + ia - a;
+  eb = ob + ib - b;
+  __syncthreads();
+}
+
+// sum of blk_a[0..b) and blk_b[0..b): the block's offset in a two-kernel (count, then place) compaction
+__device__ __forceinline__ void block_offsets2(const uint32_t * blk_a, const uint32_t * blk_b, uint32_t b, uint32_t & off_a,
+                                               uint32_t & off_b, uint32_t * lds)
+{
+  uint32_t sa = 0, sb = 0;
+  for (uint32_t i = threadIdx.x; i < b; i += kThreads) {
+    sa += blk_a[i];
+    sb += blk_b[i];
+  }
+  sa = wave_sum(sa);
+  sb = wave_sum(sb);
+  if ((threadIdx.x & 63u) == 0) {
+    lds[threadIdx.x >> 6] = sa;
+    lds[4 + (threadIdx.x >> 6)] = sb;
+  }
+  __syncthreads();
+  off_a = lds[0] + lds[1] + lds[2] + lds[3];
+  off_b = lds[4] + lds[5] + lds[6] + lds[7];
+  __syncthreads();
+}
+
+__device__ __forceinline__ float lane_value(float v, uint32_t lane)  // lane: wave-uniform
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(lane)));
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t mix64(uint64_t k)
+{
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return static_cast<uint32_t>(k);
+}
 
 // ---- prepareInput ------------------------------------------------------------------------------------
 struct FilterParams
@@ -49,172 +150,359 @@ struct FilterParams
 
 __device__ __forceinline__ float range_sq_of(const mh_ouster_point & p) { return p.x * p.x + p.y * p.y + p.z * p.z; }
 
-__global__ __launch_bounds__(kThreads) void input_filter_kernel(const mh_ouster_point * raw, uint32_t n, FilterParams f,
-                                                                 uint32_t * flag_full, uint32_t * flag_geo,
-                                                                 ScanCounters * counters)
+// bit 0: the point goes into points_full_; bit 1: it also belongs to the geometric subset
+__device__ __forceinline__ uint32_t filter_point(const mh_ouster_point & p, uint32_t i, const FilterParams & f)
 {
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    const mh_ouster_point p = raw[i];
-    bool keep = (i % f.stride) == 0;                                                   // :246 loop stride
-    keep = keep && !(isnan(p.x) || isnan(p.y) || isnan(p.z));                           // :253
-    keep = keep && !(isnan(p.intensity) || p.intensity < f.intensity_min || p.intensity > f.intensity_max);  // :272-276
-    const float r2 = range_sq_of(p);
-    keep = keep && !(r2 < f.range_min_sq || r2 > f.range_max_sq);                       // :281-282
-    keep = keep && !(static_cast<float>(p.t) > f.ns_max);                               // :306 (uint32 promoted to float)
-    flag_full[i] = keep ? 1u : 0u;
-    // :318-334 point-skip and ring filters select the geometric subset
-    flag_geo[i] = (keep && (i % f.point_skip) == 0 && (p.ring % f.ring_skip) == 0) ? 1u : 0u;
-    // (:310 last_point_ns = max t over the kept points falls out of the timestamp sort: unique_scatter_kernel)
-  }
+  bool keep = (i % f.stride) == 0;                                                   // :246 loop stride
+  keep = keep && !(isnan(p.x) || isnan(p.y) || isnan(p.z));                           // :253
+  keep = keep && !(isnan(p.intensity) || p.intensity < f.intensity_min || p.intensity > f.intensity_max);  // :272-276
+  const float r2 = range_sq_of(p);
+  keep = keep && !(r2 < f.range_min_sq || r2 > f.range_max_sq);                       // :281-282
+  keep = keep && !(static_cast<float>(p.t) > f.ns_max);                               // :306 (uint32 promoted to float)
+  // :318-334 point-skip and ring filters select the geometric subset
+  const bool geo = keep && (i % f.point_skip) == 0 && (p.ring % f.ring_skip) == 0;
+  return (keep ? 1u : 0u) | (geo ? 2u : 0u);
 }
 
-__global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster_point * raw, uint32_t n, FilterParams f,
-                                                                  const uint32_t * flag_full, const uint32_t * flag_geo,
-                                                                  const uint32_t * pos_full, const uint32_t * pos_geo,
-                                                                  mh_point32 * points_full, uint32_t * geo_idx,
-                                                                  ScanCounters * counters)
+__global__ __launch_bounds__(kThreads) void input_count_kernel(const mh_ouster_point * __restrict__ raw, uint32_t n, FilterParams f,
+                                                                uint32_t * __restrict__ blk_full, uint32_t * __restrict__ blk_geo,
+                                                                uint32_t * __restrict__ ns_table, uint32_t ns_cap,
+                                                                ScanCounters * counters)
 {
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    if (flag_full[i]) {
-      const mh_ouster_point p = raw[i];
-      mh_point32 o;
-      o.x = p.x;
-      o.y = p.y;
-      o.z = p.z + f.z_offset;
-      o.pad = 0.f;
-      o.intensity = p.intensity;
-      o.t = p.t;
-      o.idx = i;
-      // :312-313 std::sqrt(float): correctly rounded.  sqrt in double then one rounding to float is exact for
-      // that (53 >= 2 * 24 + 2 bits) and does not depend on how the compiler lowers f32 sqrt
-      o.range = static_cast<float>(sqrt(static_cast<double>(range_sq_of(p))));
-      points_full[pos_full[i]] = o;
-      if (flag_geo[i]) geo_idx[pos_geo[i]] = pos_full[i];
+  __shared__ uint32_t lds[8];
+  // the timestamp hash set of input_scatter_kernel: every block clears its share
+  const uint32_t per = (ns_cap + gridDim.x - 1) / gridDim.x, c0 = blockIdx.x * per;
+  for (uint32_t i = c0 + threadIdx.x; i < min(c0 + per, ns_cap); i += kThreads) ns_table[i] = kEmpty32;
+  if (blockIdx.x == 0 && threadIdx.x < sizeof(ScanCounters) / 4) reinterpret_cast<uint32_t *>(counters)[threadIdx.x] = 0u;
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  uint32_t c_full = 0, c_geo = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k)
+    if (base + k < n) {
+      const uint32_t fl = filter_point(raw[base + k], base + k, f);
+      c_full += fl & 1u;
+      c_geo += fl >> 1;
     }
-    if (i == n - 1) {
-      counters->n_full = pos_full[i] + flag_full[i];
-      counters->n_geometric = pos_geo[i] + flag_geo[i];
-    }
+  c_full = wave_sum(c_full);
+  c_geo = wave_sum(c_geo);
+  if ((threadIdx.x & 63u) == 0) {
+    lds[threadIdx.x >> 6] = c_full;
+    lds[4 + (threadIdx.x >> 6)] = c_geo;
   }
-}
-
-// ---- distinct timestamps --------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void ns_keys_kernel(const mh_point32 * pts, const ScanCounters * c, uint32_t n_cap,
-                                                            uint32_t * keys)
-{
-  const uint32_t n = c->n_full;
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_cap; i += gridDim.x * kThreads)
-    keys[i] = i < n ? pts[i].t : kNoKey32;
-}
-__global__ __launch_bounds__(kThreads) void head_flags32_kernel(const uint32_t * keys, uint32_t n, uint32_t * flags)
-{
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-    flags[i] = (keys[i] != kNoKey32 && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
-}
-__global__ __launch_bounds__(kThreads) void unique_scatter_kernel(const uint32_t * keys, const uint32_t * flags,
-                                                                   const uint32_t * pos, uint32_t n, uint32_t * out,
-                                                                   ScanCounters * c)
-{
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    if (flags[i]) out[pos[i]] = keys[i];
-    if (i == n - 1) c->n_unique_ns = pos[i] + flags[i];
-    // the largest kept timestamp = the last non-sentinel key of the sorted list (manager.cpp:310)
-    if (keys[i] != kNoKey32 && (i == n - 1 || keys[i + 1] == kNoKey32)) c->last_point_ns = keys[i];
-  }
-}
-
-// ---- Geometric::preprocess --------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void gather_transform_kernel(const mh_point32 * pts, const uint32_t * geo_idx,
-                                                                     uint32_t n, const float * Rt12, mh_point32 * body)
-{
-  __shared__ float P[12];
-  if (threadIdx.x < 12) P[threadIdx.x] = Rt12[threadIdx.x];
   __syncthreads();
-  for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < n; j += gridDim.x * kThreads) {
-    mh_point32 p = pts[geo_idx[j]];
-    const float px = p.x, py = p.y, pz = p.z;  // Eigen's coefficient order r0*x + (r1*y + r2*z), then + t
-    p.x = (P[0] * px + (P[1] * py + P[2] * pz)) + P[9];
-    p.y = (P[3] * px + (P[4] * py + P[5] * pz)) + P[10];
-    p.z = (P[6] * px + (P[7] * py + P[8] * pz)) + P[11];
-    body[j] = p;
+  if (threadIdx.x == 0) {
+    blk_full[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    blk_geo[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
   }
 }
 
-// ---- Geometric::downsample --------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster_point * __restrict__ raw, uint32_t n, FilterParams f,
+                                                                  const uint32_t * __restrict__ blk_full,
+                                                                  const uint32_t * __restrict__ blk_geo, uint32_t * ns_table,
+                                                                  uint32_t ns_mask, uint32_t * __restrict__ ns_unsorted,
+                                                                  mh_point32 * __restrict__ points_full,
+                                                                  uint32_t * __restrict__ geo_idx, ScanCounters * counters)
+{
+  __shared__ uint32_t lds[8];
+  uint32_t off_full, off_geo;
+  block_offsets2(blk_full, blk_geo, blockIdx.x, off_full, off_geo, lds);
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  mh_ouster_point p[kItems];
+  uint32_t fl[kItems];
+  uint32_t c_full = 0, c_geo = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k) {
+    fl[k] = 0;
+    if (base + k < n) {
+      p[k] = raw[base + k];
+      fl[k] = filter_point(p[k], base + k, f);
+      c_full += fl[k] & 1u;
+      c_geo += fl[k] >> 1;
+    }
+  }
+  uint32_t e_full, e_geo, t_full, t_geo;
+  block_exclusive_sum2(c_full, c_geo, e_full, e_geo, t_full, t_geo, lds);
+  uint32_t pos_full = off_full + e_full, pos_geo = off_geo + e_geo;
+  uint32_t t_max = 0;
+  bool any = false;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k) {
+    if (!(fl[k] & 1u)) continue;
+    mh_point32 o;
+    o.x = p[k].x;
+    o.y = p[k].y;
+    o.z = p[k].z + f.z_offset;
+    o.pad = 0.f;
+    o.intensity = p[k].intensity;
+    o.t = p[k].t;
+    o.idx = base + k;
+    // :312-313 std::sqrt(float): correctly rounded.  sqrt in double then one rounding to float is exact for
+    // that (53 >= 2 * 24 + 2 bits) and does not depend on how the compiler lowers f32 sqrt
+    o.range = static_cast<float>(sqrt(static_cast<double>(range_sq_of(p[k]))));
+    points_full[pos_full] = o;
+    if (fl[k] & 2u) geo_idx[pos_geo++] = pos_full;
+    ++pos_full;
+    // distinct timestamps (:340-368): hash set; the first thread to claim a slot appends the value
+    const uint32_t t = p[k].t;
+    any = true;
+    t_max = max(t_max, t);
+    if (t == kEmpty32) {  // the table's empty marker itself: carried by a flag, appended last by unique_sort_kernel
+      atomicOr(&counters->has_max_ns, 1u);
+      continue;
+    }
+    uint32_t slot = mix32(t) & ns_mask;
+    for (;;) {
+      uint32_t cur = __hip_atomic_load(&ns_table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == kEmpty32) {
+        cur = atomicCAS(&ns_table[slot], kEmpty32, t);
+        if (cur == kEmpty32) {  // claimed: this thread is the one that lists the value
+          ns_unsorted[atomicAdd(&counters->n_unique_ns, 1u)] = t;
+          break;
+        }
+      }
+      if (cur == t) break;
+      slot = (slot + 1) & ns_mask;
+    }
+  }
+  // :310 last_point_ns = max t over the kept points
+  const uint64_t anyone = __ballot(any);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) t_max = max(t_max, static_cast<uint32_t>(__shfl_xor(t_max, d)));
+  if (anyone && (threadIdx.x & 63u) == 0) atomicMax(&counters->last_point_ns, t_max);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    counters->n_full = off_full + t_full;
+    counters->n_geometric = off_geo + t_geo;
+  }
+}
+
+// the distinct timestamps, ascending: rank = number of smaller values (they are distinct).  The whole list passes
+// through LDS in 1024-value tiles; O(m^2) compares, m is the column count of the sensor (1024 / 2048) in practice.
+__global__ __launch_bounds__(kThreads) void unique_sort_kernel(const uint32_t * __restrict__ ns_unsorted, uint32_t * __restrict__ unique_ns,
+                                                                const ScanCounters * counters)
+{
+  __shared__ uint4 tile[kThreads];
+  const uint32_t m = counters->n_unique_ns;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && counters->has_max_ns) unique_ns[m] = kEmpty32;
+  if (blockIdx.x * kThreads >= m) return;
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t v = i < m ? ns_unsorted[i] : 0u;
+  uint32_t rank = 0;
+  for (uint32_t t0 = 0; t0 < m; t0 += kBlockItems) {
+    uint4 q;
+    const uint32_t j = t0 + threadIdx.x * 4;
+    q.x = j + 0 < m ? ns_unsorted[j + 0] : kEmpty32;  // the padding value is never smaller than anything
+    q.y = j + 1 < m ? ns_unsorted[j + 1] : kEmpty32;
+    q.z = j + 2 < m ? ns_unsorted[j + 2] : kEmpty32;
+    q.w = j + 3 < m ? ns_unsorted[j + 3] : kEmpty32;
+    __syncthreads();
+    tile[threadIdx.x] = q;
+    __syncthreads();
+    const uint32_t lim = min(kThreads, (m - t0 + 3) / 4);
+    for (uint32_t u = 0; u < lim; ++u) {
+      const uint4 w = tile[u];  // broadcast read
+      rank += (w.x < v) + (w.y < v) + (w.z < v) + (w.w < v);
+    }
+  }
+  if (i < m) unique_ns[rank] = v;
+}
+
+// ---- Geometric::preprocess + the voxel assignment of Geometric::downsample ------------------------------------
 constexpr int kCoordBits = 21;
 constexpr int kCoordBias = 1 << (kCoordBits - 1);
 
-__global__ __launch_bounds__(kThreads) void voxel_keys_kernel(const mh_point32 * pts, uint32_t n, double inv_leaf,
-                                                               uint64_t * keys, uint32_t * idx, ScanCounters * c)
+__global__ __launch_bounds__(kThreads) void body_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ geo_idx,
+                                                               uint32_t n, Rt12 P, double inv_leaf, mh_point32 * __restrict__ body,
+                                                               VoxelHash h, uint32_t * __restrict__ slot_of)
 {
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    const mh_point32 p = pts[i];
-    // :77-80 coord = fast_floor(double(p) * inv_leaf)
-    const int cx = fast_floor(static_cast<double>(p.x) * inv_leaf), cy = fast_floor(static_cast<double>(p.y) * inv_leaf),
-              cz = fast_floor(static_cast<double>(p.z) * inv_leaf);
-    const int bx = cx + kCoordBias, by = cy + kCoordBias, bz = cz + kCoordBias;
-    if (((bx | by | bz) >> kCoordBits) != 0) atomicOr(&c->bad_coord, 1u);
-    keys[i] = (static_cast<uint64_t>(bx & ((1 << kCoordBits) - 1)) << (2 * kCoordBits)) |
-              (static_cast<uint64_t>(by & ((1 << kCoordBits) - 1)) << kCoordBits) |
-              static_cast<uint64_t>(bz & ((1 << kCoordBits) - 1));
-    idx[i] = i;
+  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n) return;
+  mh_point32 p = pts[geo_idx[j]];
+  const float px = p.x, py = p.y, pz = p.z;  // Eigen's coefficient order r0*x + (r1*y + r2*z), then + t (geometric.cpp:154-161)
+  p.x = (P.v[0] * px + (P.v[1] * py + P.v[2] * pz)) + P.v[9];
+  p.y = (P.v[3] * px + (P.v[4] * py + P.v[5] * pz)) + P.v[10];
+  p.z = (P.v[6] * px + (P.v[7] * py + P.v[8] * pz)) + P.v[11];
+  body[j] = p;
+  // :77-80 coord = fast_floor(double(p) * inv_leaf)
+  const int cx = fast_floor(static_cast<double>(p.x) * inv_leaf), cy = fast_floor(static_cast<double>(p.y) * inv_leaf),
+            cz = fast_floor(static_cast<double>(p.z) * inv_leaf);
+  const int bx = cx + kCoordBias, by = cy + kCoordBias, bz = cz + kCoordBias;
+  if (((bx | by | bz) >> kCoordBits) != 0) *h.bad = 0u;  // (memset to all-ones: any other value = "a coordinate did not fit")
+  const uint64_t key = (static_cast<uint64_t>(bx & ((1 << kCoordBits) - 1)) << (2 * kCoordBits)) |
+                       (static_cast<uint64_t>(by & ((1 << kCoordBits) - 1)) << kCoordBits) |
+                       static_cast<uint64_t>(bz & ((1 << kCoordBits) - 1));
+  uint32_t slot = mix64(key) & h.mask;
+  for (;;) {
+    unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&h.keys[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmpty64) {
+      cur = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[slot]), static_cast<unsigned long long>(kEmpty64),
+                      static_cast<unsigned long long>(key));
+      if (cur == kEmpty64) cur = key;
+    }
+    if (cur == key) break;
+    slot = (slot + 1) & h.mask;
+  }
+  atomicMin(&h.first[slot], j);  // all-ones before: the voxel's first point in input order
+  atomicAdd(&h.cnt[slot], 1u);   // all-ones before: stored value = count - 1
+  slot_of[j] = slot;
+}
+
+// value of input position j in the two scans: (points of the voxel, 1) if j is the first point of its voxel, else (0, 0)
+__device__ __forceinline__ void voxel_head(const VoxelHash & h, uint32_t slot, uint32_t j, uint32_t & c, uint32_t & v)
+{
+  const bool head = h.first[slot] == j;
+  c = head ? h.cnt[slot] + 1u : 0u;
+  v = head ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void voxel_count_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
+                                                                uint32_t * __restrict__ blk_pts, uint32_t * __restrict__ blk_vox)
+{
+  __shared__ uint32_t lds[8];
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  uint32_t c = 0, v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k)
+    if (base + k < n) {
+      uint32_t ck, vk;
+      voxel_head(h, slot_of[base + k], base + k, ck, vk);
+      c += ck;
+      v += vk;
+    }
+  c = wave_sum(c);
+  v = wave_sum(v);
+  if ((threadIdx.x & 63u) == 0) {
+    lds[threadIdx.x >> 6] = c;
+    lds[4 + (threadIdx.x >> 6)] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blk_pts[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    blk_vox[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
   }
 }
 
-__global__ __launch_bounds__(kThreads) void head_flags64_kernel(const uint64_t * keys, uint32_t n, uint32_t * flags)
+// off[slot] = start of the voxel's segment (voxels in first-seen order); vox_slot[v] = slot of the v-th voxel
+__global__ __launch_bounds__(kThreads) void voxel_offsets_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
+                                                                  const uint32_t * __restrict__ blk_pts,
+                                                                  const uint32_t * __restrict__ blk_vox, uint32_t * __restrict__ vox_slot,
+                                                                  ScanCounters * counters)
 {
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-
-// seg_start[v] = first sorted position of voxel v; seg_start[n_voxels] = n
-__global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t * flags, const uint32_t * pos, uint32_t n,
-                                                                   uint32_t * seg_start, ScanCounters * c)
-{
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-    if (flags[i]) seg_start[pos[i]] = i;
-    if (i == n - 1) {
-      const uint32_t nv = pos[i] + flags[i];
-      c->n_voxels = nv;
-      seg_start[nv] = n;
+  __shared__ uint32_t lds[8];
+  uint32_t off_pts, off_vox;
+  block_offsets2(blk_pts, blk_vox, blockIdx.x, off_pts, off_vox, lds);
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  uint32_t ck[kItems], vk[kItems], sl[kItems], c = 0, v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k) {
+    ck[k] = vk[k] = sl[k] = 0;
+    if (base + k < n) {
+      sl[k] = slot_of[base + k];
+      voxel_head(h, sl[k], base + k, ck[k], vk[k]);
+      c += ck[k];
+      v += vk[k];
     }
   }
+  uint32_t ec, ev, tc, tv;
+  block_exclusive_sum2(c, v, ec, ev, tc, tv, lds);
+  uint32_t pc = off_pts + ec, pv = off_vox + ev;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k)
+    if (vk[k]) {
+      h.off[sl[k]] = pc;
+      vox_slot[pv] = sl[k];
+      pc += ck[k];
+      ++pv;
+    }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters->n_voxels = off_vox + tv;
 }
 
-// One WAVE per voxel: FlatContainerMinimal::add over the voxel's points in input order.  Lane j holds the j-th
-// point kept so far (<= 20); every incoming point is tested against all of them at once (one fp64 distance per
-// lane, one ballot) — a thread-per-voxel walk of the same lists was a chain of dependent scattered loads and took
-// 250 us, 44 % of the whole front end.  keep[] is indexed by sorted position; first_idx[s] = input index of the
-// first point of the voxel of position s.
-__global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * pts, const uint32_t * sorted_idx,
-                                                                 const uint32_t * seg_start, const ScanCounters * c,
-                                                                 uint32_t max_pts, double min_sq, uint32_t * keep,
-                                                                 uint32_t * first_idx)
+__global__ __launch_bounds__(kThreads) void voxel_scatter_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
+                                                                  uint32_t * __restrict__ idx_unsorted)
 {
-  const uint32_t nv = c->n_voxels;
+  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t slot = slot_of[j];
+  idx_unsorted[h.off[slot] + (atomicAdd(&h.cur[slot], 1u) + 1u)] = j;  // cursor starts at all-ones
+}
+
+// One WAVE per voxel.  (1) the voxel's point indices, unordered after the scatter, ascending into idx_sorted: input
+// order.  (2) FlatContainerMinimal::add over them: lane j holds the j-th point kept so far (<= 20); every incoming
+// point is tested against all of them at once (one fp64 distance per lane, one ballot).  keep[] is indexed by position
+// in idx_sorted.
+__global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ idx_unsorted,
+                                                                 uint32_t * idx_sorted, uint32_t * idx_tmp, const uint32_t * __restrict__ vox_slot,
+                                                                 VoxelHash h, const ScanCounters * counters, uint32_t idx_bits,
+                                                                 uint32_t max_pts, double min_sq, uint32_t * __restrict__ keep)
+{
+  const uint32_t nv = counters->n_voxels;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
   const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6, n_waves = (gridDim.x * kThreads) >> 6;
   const uint32_t cap = min(max_pts, static_cast<uint32_t>(kBucketStride));  // utils.hpp:262 size cap
   for (uint32_t v = wave; v < nv; v += n_waves) {
-    const uint32_t s0 = seg_start[v], s1 = seg_start[v + 1];
-    const uint32_t first = sorted_idx[s0];  // stable sort: the smallest input index of the voxel
-    double kx = 0.0, ky = 0.0, kz = 0.0;    // this lane's kept point (lane < n_kept)
+    const uint32_t slot = vox_slot[v];
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(h.off[slot]), len = __builtin_amdgcn_readfirstlane(h.cnt[slot] + 1u);
+    const uint32_t s1 = s0 + len;
+    uint32_t first_chunk = 0;  // sorted index of position s0 + lane, when the whole voxel fits one wave
+    if (len <= 64u) {
+      const uint32_t e = lane < len ? idx_unsorted[s0 + lane] : kEmpty32;
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < len; ++u) rank += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e), static_cast<int>(u))) < e ? 1u : 0u;
+      if (lane >= len) rank = lane;
+      first_chunk = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(rank << 2), static_cast<int>(e)));  // lane r <- the value of rank r
+      if (lane < len) idx_sorted[s0 + lane] = first_chunk;
+    } else if (len <= 1024u) {
+      for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+        const bool valid = c0 + lane < len;
+        const uint32_t e = valid ? idx_unsorted[s0 + c0 + lane] : 0u;
+        uint32_t rank = 0;
+        for (uint32_t u = 0; u < len; ++u) rank += idx_unsorted[s0 + u] < e ? 1u : 0u;  // wave-uniform address
+        if (valid) idx_sorted[s0 + rank] = e;
+      }
+      __threadfence_block();
+    } else {
+      // binary LSD radix, the wave ping-pongs the segment between idx_sorted and idx_tmp so that the last pass lands in
+      // idx_sorted; every pass is a stable split by one bit
+      const uint32_t * src = idx_unsorted + s0;
+      for (uint32_t bit = 0; bit < idx_bits; ++bit) {
+        uint32_t * dst = (((idx_bits - 1u - bit) & 1u) ? idx_tmp : idx_sorted) + s0;
+        uint32_t zeros = 0;
+        for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+          const bool valid = c0 + lane < len;
+          const uint32_t e = valid ? __hip_atomic_load(&src[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+          zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !((e >> bit) & 1u))));
+        }
+        uint32_t z_run = 0, o_run = zeros;
+        for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+          const bool valid = c0 + lane < len;
+          const uint32_t e = valid ? __hip_atomic_load(&src[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+          const bool one = (e >> bit) & 1u;
+          const uint64_t m0 = __ballot(valid && !one), m1 = __ballot(valid && one);
+          if (valid) dst[one ? o_run + static_cast<uint32_t>(__popcll(m1 & lanes_below)) : z_run + static_cast<uint32_t>(__popcll(m0 & lanes_below))] = e;
+          z_run += static_cast<uint32_t>(__popcll(m0));
+          o_run += static_cast<uint32_t>(__popcll(m1));
+        }
+        __threadfence_block();
+        src = dst;
+      }
+    }
+    double kx = 0.0, ky = 0.0, kz = 0.0;  // this lane's kept point (lane < n_kept)
     uint32_t n_kept = 0;
-    for (uint32_t base = s0; base < s1; base += 64u) {  // the segment, 64 points at a time (coalesced index loads)
+    for (uint32_t base = s0; base < s1; base += 64u) {  // the segment, 64 points at a time
       const uint32_t s = base + lane;
       float px = 0.f, py = 0.f, pz = 0.f;
       if (s < s1) {
-        const mh_point32 p = pts[sorted_idx[s]];
+        const uint32_t j = len <= 64u ? first_chunk : __hip_atomic_load(&idx_sorted[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const mh_point32 p = pts[j];
         px = p.x;
         py = p.y;
         pz = p.z;
-        first_idx[s] = first;
       }
       const uint32_t m = min(64u, s1 - base);
       uint64_t kept_mask = 0;
       for (uint32_t u = 0; u < m; ++u) {  // input order
-        const double qx = static_cast<double>(__shfl(px, static_cast<int>(u))), qy = static_cast<double>(__shfl(py, static_cast<int>(u))),
-                     qz = static_cast<double>(__shfl(pz, static_cast<int>(u)));
+        const double qx = static_cast<double>(lane_value(px, u)), qy = static_cast<double>(lane_value(py, u)),
+                     qz = static_cast<double>(lane_value(pz, u));
         const double dx = kx - qx, dy = ky - qy, dz = kz - qz;
         // Vector3d squaredNorm: p0 + (p1 + p2); utils.hpp:266-272
         const bool close = lane < n_kept && dx * dx + (dy * dy + dz * dz) < min_sq;
@@ -234,65 +522,86 @@ __global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32
   }
 }
 
-// kept point at sorted position s -> key (first index of its voxel, own input index): ascending order of
-// these keys is "voxels in first-seen order, points in acceptance order" (geometric.cpp:103-109)
-__global__ __launch_bounds__(kThreads) void order_keys_kernel(const uint32_t * sorted_idx, const uint32_t * keep,
-                                                               const uint32_t * pos, const uint32_t * first_idx, uint32_t n,
-                                                               uint64_t * keys, ScanCounters * c)
+__global__ __launch_bounds__(kThreads) void keep_count_kernel(const uint32_t * __restrict__ keep, uint32_t n, uint32_t * __restrict__ blk_keep)
 {
-  for (uint32_t s = blockIdx.x * kThreads + threadIdx.x; s < n; s += gridDim.x * kThreads) {
-    if (keep[s]) keys[pos[s]] = (static_cast<uint64_t>(first_idx[s]) << 32) | sorted_idx[s];
-    if (s == n - 1) c->n_downsampled = pos[s] + keep[s];
-  }
-}
-__global__ __launch_bounds__(kThreads) void fill64_kernel(uint64_t * keys, uint32_t n, uint64_t v)
-{
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) keys[i] = v;
-}
-__global__ __launch_bounds__(kThreads) void gather_kept_kernel(const mh_point32 * pts, const uint64_t * keys,
-                                                                const ScanCounters * c, uint32_t n_cap, uint32_t * kept_idx,
-                                                                mh_point32 * out)
-{
-  const uint32_t n = c->n_downsampled;
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n_cap; i += gridDim.x * kThreads) {
-    if (i >= n) continue;
-    const uint32_t j = static_cast<uint32_t>(keys[i] & 0xFFFFFFFFull);
-    kept_idx[i] = j;
-    out[i] = pts[j];
-  }
+  __shared__ uint32_t lds[4];
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k)
+    if (base + k < n) c += keep[base + k];
+  c = wave_sum(c);
+  if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_keep[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-hipError_t exclusive_sum(const uint32_t * in, uint32_t * out, uint32_t n, void * temp, size_t temp_bytes, hipStream_t stream)
+// kept points in position order = "voxels in first-seen order, points in acceptance order" (geometric.cpp:103-109)
+__global__ __launch_bounds__(kThreads) void keep_scatter_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ idx_sorted,
+                                                                 const uint32_t * __restrict__ keep, uint32_t n,
+                                                                 const uint32_t * __restrict__ blk_keep, const uint32_t * bad,
+                                                                 uint32_t * __restrict__ kept_idx, mh_point32 * __restrict__ out,
+                                                                 ScanCounters * counters)
 {
-  size_t tb = temp_bytes;
-  return rocprim::exclusive_scan(temp, tb, in, out, 0u, static_cast<size_t>(n), rocprim::plus<uint32_t>(), stream);
+  __shared__ uint32_t lds[8];
+  uint32_t off, unused;
+  block_offsets2(blk_keep, blk_keep, blockIdx.x, off, unused, lds);
+  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
+  uint32_t kk[kItems], c = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k) {
+    kk[k] = base + k < n ? keep[base + k] : 0u;
+    c += kk[k];
+  }
+  uint32_t e, e2, t, t2;
+  block_exclusive_sum2(c, 0u, e, e2, t, t2, lds);
+  uint32_t pos = off + e;
+#pragma unroll
+  for (uint32_t k = 0; k < kItems; ++k)
+    if (kk[k]) {
+      const uint32_t j = idx_sorted[base + k];
+      kept_idx[pos] = j;
+      out[pos] = pts[j];
+      ++pos;
+    }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    counters->n_downsampled = off + t;
+    counters->bad_coord = *bad != kEmpty32 ? 1u : 0u;
+  }
 }
 }  // namespace
 
-size_t scan_temp_bytes(size_t n)
+// ---- host side ---------------------------------------------------------------------------------------------
+static uint32_t pow2_at_least(uint64_t v)
 {
-  if (n == 0) n = 1;
-  size_t best = 0, tb = 0;
-  uint32_t * k32 = nullptr;
-  uint64_t * k64 = nullptr;
-  (void)rocprim::radix_sort_keys(nullptr, tb, k32, k32, n, 0, 32, hipStream_t(nullptr));
-  best = tb > best ? tb : best;
-  tb = 0;
-  (void)rocprim::radix_sort_keys(nullptr, tb, k64, k64, n, 0, 64, hipStream_t(nullptr));
-  best = tb > best ? tb : best;
-  tb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tb, k64, k64, k32, k32, n, 0, 64, hipStream_t(nullptr));
-  best = tb > best ? tb : best;
-  tb = 0;
-  (void)rocprim::exclusive_scan(nullptr, tb, k32, k32, 0u, n, rocprim::plus<uint32_t>(), hipStream_t(nullptr));
-  best = tb > best ? tb : best;
-  return best + 256;
+  uint64_t c = 1024;
+  while (c < v) c <<= 1;
+  return static_cast<uint32_t>(c);
 }
 
-hipError_t launch_input_filter(const mh_ouster_point * raw, uint32_t n, const mh_input_config & cfg, uint32_t * flag_full,
-                               uint32_t * flag_geo, uint32_t * pos_full, uint32_t * pos_geo, mh_point32 * points_full,
-                               uint32_t * geo_idx, ScanCounters * counters, void * temp, size_t temp_bytes,
-                               hipStream_t stream)
+PrepareLayout prepare_layout(size_t n)
+{
+  PrepareLayout L;
+  L.n_blocks = blocks_for(static_cast<uint32_t>(n));
+  L.ns_cap = pow2_at_least(2 * static_cast<uint64_t>(n));
+  L.words = 2 * static_cast<size_t>(L.n_blocks) + L.ns_cap + (n ? n : 1);
+  return L;
+}
+
+VoxelLayout voxel_layout(size_t n)
+{
+  VoxelLayout L;
+  L.n_blocks = blocks_for(static_cast<uint32_t>(n));
+  L.cap = pow2_at_least(2 * static_cast<uint64_t>(n));
+  L.clear_bytes = static_cast<size_t>(L.cap) * (8 + 4 + 4 + 4) + 16;
+  const size_t m = n ? n : 1;
+  L.bytes = L.clear_bytes + static_cast<size_t>(L.cap) * 4 + (6 * m + 3 * static_cast<size_t>(L.n_blocks)) * 4;
+  return L;
+}
+
+hipError_t launch_prepare_input(const mh_ouster_point * raw, uint32_t n, const mh_input_config & cfg, uint32_t * scratch,
+                                mh_point32 * points_full, uint32_t * geo_idx, uint32_t * unique_ns, ScanCounters * counters,
+                                hipStream_t stream)
 {
   FilterParams f;
   f.range_min_sq = cfg.range_min * cfg.range_min;  // manager.cpp:19-20 (float products)
@@ -304,67 +613,57 @@ hipError_t launch_input_filter(const mh_ouster_point * raw, uint32_t n, const mh
   f.point_skip = static_cast<uint32_t>(cfg.point_skip_divisor > 0 ? cfg.point_skip_divisor : 1);
   f.ring_skip = static_cast<uint32_t>(cfg.ring_skip_divisor > 0 ? cfg.ring_skip_divisor : 1);
   f.stride = cfg.create_full_res_pointcloud ? 1u : f.point_skip;
-  hipError_t e = hipMemsetAsync(counters, 0, sizeof(ScanCounters), stream);
-  if (e != hipSuccess || n == 0) return e;
-  hipLaunchKernelGGL(input_filter_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, raw, n, f, flag_full, flag_geo,
-                     counters);
-  if ((e = exclusive_sum(flag_full, pos_full, n, temp, temp_bytes, stream)) != hipSuccess) return e;
-  if ((e = exclusive_sum(flag_geo, pos_geo, n, temp, temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(input_scatter_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, raw, n, f, flag_full, flag_geo,
-                     pos_full, pos_geo, points_full, geo_idx, counters);
+  const PrepareLayout L = prepare_layout(n);
+  uint32_t * blk_full = scratch, * blk_geo = blk_full + L.n_blocks, * ns_table = blk_geo + L.n_blocks, * ns_unsorted = ns_table + L.ns_cap;
+  const dim3 g(L.n_blocks), b(kThreads);
+  hipLaunchKernelGGL(input_count_kernel, g, b, 0, stream, raw, n, f, blk_full, blk_geo, ns_table, L.ns_cap, counters);
+  hipLaunchKernelGGL(input_scatter_kernel, g, b, 0, stream, raw, n, f, blk_full, blk_geo, ns_table, L.ns_cap - 1u, ns_unsorted,
+                     points_full, geo_idx, counters);
+  hipLaunchKernelGGL(unique_sort_kernel, dim3((n + kThreads - 1) / kThreads ? (n + kThreads - 1) / kThreads : 1u), b, 0, stream,
+                     ns_unsorted, unique_ns, counters);
   return hipGetLastError();
 }
 
-hipError_t launch_unique_ns(const mh_point32 * points_full, const ScanCounters * counters, uint32_t n_cap, uint32_t * keys_a,
-                            uint32_t * keys_b, uint32_t * flags, uint32_t * pos, uint32_t * unique_ns,
-                            ScanCounters * counters_out, void * temp, size_t temp_bytes, hipStream_t stream)
-{
-  if (n_cap == 0) return hipSuccess;
-  hipLaunchKernelGGL(ns_keys_kernel, dim3(grid_for(n_cap)), dim3(kThreads), 0, stream, points_full, counters, n_cap, keys_a);
-  size_t tb = temp_bytes;
-  hipError_t e = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, static_cast<size_t>(n_cap), 0, 32, stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(head_flags32_kernel, dim3(grid_for(n_cap)), dim3(kThreads), 0, stream, keys_b, n_cap, flags);
-  if ((e = exclusive_sum(flags, pos, n_cap, temp, temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(unique_scatter_kernel, dim3(grid_for(n_cap)), dim3(kThreads), 0, stream, keys_b, flags, pos, n_cap,
-                     unique_ns, counters_out);
-  return hipGetLastError();
-}
-
-hipError_t launch_gather_transform(const mh_point32 * points_full, const uint32_t * geo_idx, uint32_t n_geo,
-                                   const float * Rt12, mh_point32 * body, hipStream_t stream)
-{
-  if (n_geo == 0) return hipSuccess;
-  hipLaunchKernelGGL(gather_transform_kernel, dim3(grid_for(n_geo)), dim3(kThreads), 0, stream, points_full, geo_idx, n_geo,
-                     Rt12, body);
-  return hipGetLastError();
-}
-
-hipError_t launch_downsample(const mh_point32 * body, uint32_t n, double leaf, uint32_t max_pts, double min_dist,
-                             uint64_t * keys_a, uint64_t * keys_b, uint32_t * idx_a, uint32_t * idx_b, uint32_t * flags,
-                             uint32_t * pos, uint32_t * seg_start, uint32_t * first_idx, uint32_t * kept_idx,
-                             mh_point32 * out, ScanCounters * counters, void * temp, size_t temp_bytes, hipStream_t stream)
+hipError_t launch_preprocess(const mh_point32 * points_full, const uint32_t * geo_idx, uint32_t n, const Rt12 & body_from_lidar,
+                             double leaf, uint32_t max_pts, double min_dist, void * scratch, mh_point32 * body,
+                             uint32_t * kept_idx, mh_point32 * out, ScanCounters * counters, hipStream_t stream)
 {
   if (n == 0) return hipSuccess;
+  const VoxelLayout L = voxel_layout(n);
+  hipError_t e = hipMemsetAsync(scratch, 0xFF, L.clear_bytes, stream);
+  if (e != hipSuccess) return e;
+  VoxelHash h;
+  char * p = static_cast<char *>(scratch);
+  h.keys = reinterpret_cast<uint64_t *>(p);
+  p += static_cast<size_t>(L.cap) * 8;
+  h.first = reinterpret_cast<uint32_t *>(p);
+  p += static_cast<size_t>(L.cap) * 4;
+  h.cnt = reinterpret_cast<uint32_t *>(p);
+  p += static_cast<size_t>(L.cap) * 4;
+  h.cur = reinterpret_cast<uint32_t *>(p);
+  p += static_cast<size_t>(L.cap) * 4;
+  h.bad = reinterpret_cast<uint32_t *>(p);
+  p += 16;
+  h.off = reinterpret_cast<uint32_t *>(p);
+  p += static_cast<size_t>(L.cap) * 4;
+  h.mask = L.cap - 1u;
+  uint32_t * w = reinterpret_cast<uint32_t *>(p);
+  uint32_t * slot_of = w, * idx_unsorted = w + n, * idx_sorted = w + 2 * static_cast<size_t>(n), * idx_tmp = w + 3 * static_cast<size_t>(n),
+           * keep = w + 4 * static_cast<size_t>(n), * vox_slot = w + 5 * static_cast<size_t>(n), * blk = w + 6 * static_cast<size_t>(n);
+  uint32_t * blk_pts = blk, * blk_vox = blk + L.n_blocks, * blk_keep = blk + 2 * L.n_blocks;
   const double inv_leaf = 1.0 / leaf;            // geometric.cpp:61
   const double min_sq = min_dist * min_dist;     // :63
-  const dim3 g(grid_for(n)), b(kThreads);
-  hipLaunchKernelGGL(voxel_keys_kernel, g, b, 0, stream, body, n, inv_leaf, keys_a, idx_a, counters);
-  size_t tb = temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, idx_a, idx_b, static_cast<size_t>(n), 0, 3 * kCoordBits,
-                                           stream);  // stable: input order survives inside a voxel
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(head_flags64_kernel, g, b, 0, stream, keys_b, n, flags);
-  if ((e = exclusive_sum(flags, pos, n, temp, temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(segment_starts_kernel, g, b, 0, stream, flags, pos, n, seg_start, counters);
-  hipLaunchKernelGGL(greedy_voxel_kernel, dim3(static_cast<int>(min((static_cast<size_t>(n) * 64 + kThreads - 1) / kThreads, static_cast<size_t>(8192)))), b, 0, stream,
-                     body, idx_b, seg_start, counters, max_pts, min_sq, flags, first_idx);  // flags now = keep
-  if ((e = exclusive_sum(flags, pos, n, temp, temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(fill64_kernel, g, b, 0, stream, keys_a, n, kNoKey64);
-  hipLaunchKernelGGL(order_keys_kernel, g, b, 0, stream, idx_b, flags, pos, first_idx, n, keys_a, counters);
-  tb = temp_bytes;
-  if ((e = rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, static_cast<size_t>(n), 0, 64, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(gather_kept_kernel, g, b, 0, stream, body, keys_b, counters, n, kept_idx, out);
+  uint32_t idx_bits = 1;
+  while (idx_bits < 32 && (1ull << idx_bits) < n) ++idx_bits;
+  const dim3 gp((n + kThreads - 1) / kThreads), gb(L.n_blocks), b(kThreads);
+  hipLaunchKernelGGL(body_voxel_kernel, gp, b, 0, stream, points_full, geo_idx, n, body_from_lidar, inv_leaf, body, h, slot_of);
+  hipLaunchKernelGGL(voxel_count_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox);
+  hipLaunchKernelGGL(voxel_offsets_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox, vox_slot, counters);
+  hipLaunchKernelGGL(voxel_scatter_kernel, gp, b, 0, stream, slot_of, n, h, idx_unsorted);
+  hipLaunchKernelGGL(greedy_voxel_kernel, dim3(static_cast<uint32_t>(min((static_cast<size_t>(n) * 64 + kThreads - 1) / kThreads, static_cast<size_t>(8192)))),
+                     b, 0, stream, body, idx_unsorted, idx_sorted, idx_tmp, vox_slot, h, counters, idx_bits, max_pts, min_sq, keep);
+  hipLaunchKernelGGL(keep_count_kernel, gb, b, 0, stream, keep, n, blk_keep);
+  hipLaunchKernelGGL(keep_scatter_kernel, gb, b, 0, stream, body, idx_sorted, keep, n, blk_keep, h.bad, kept_idx, out, counters);
   return hipGetLastError();
 }
 

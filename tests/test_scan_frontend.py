@@ -156,6 +156,69 @@ def test_scan_frontend_voxel_cap_and_duplicates(ctx):
 
 
 @pytest.mark.gpu
+def test_scan_frontend_long_voxel_segments(ctx):
+    """Voxels with 1 / a few / ~300 / ~6000 points: all three sorting paths of the greedy kernel (one wave's registers,
+    rank sort over <= 1024 indices, wave-level radix above), interleaved in the input order."""
+    from mimosa_amd import capi
+    rng = np.random.default_rng(11)
+    n = 16384
+    xyz = rng.uniform(-20.0, 20.0, size=(n, 3)).astype(np.float32)            # mostly singletons
+    big = rng.permutation(n)[:6000]
+    xyz[big] = rng.uniform(4.0, 4.5, size=(6000, 3)).astype(np.float32)        # one voxel, 6000 points
+    mid = rng.permutation(np.setdiff1d(np.arange(n), big))[:900]
+    xyz[mid] = (np.array([-7.0, 3.0, 1.0]) + rng.uniform(0.0, 0.5, size=(900, 3)) + np.array([0.5, 0.0, 0.0]) * rng.integers(0, 3, size=(900, 1))).astype(np.float32)
+    raw = np.zeros(n, dtype=synth.OUSTER_DTYPE)
+    raw["x"], raw["y"], raw["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    raw["intensity"] = 10.0
+    raw["t"] = (np.arange(n) % 512 * 977).astype(np.uint32)
+    kw = dict(point_skip_divisor=1, range_min=0.0)
+    I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    o = ref_cpu.prepare_input(raw, ref_cpu.make_input_config(**kw))
+    body = _as_points(o["points_full"])[o["geometric_idxs"].astype(np.int64)]
+    sc = capi.Scan(ctx)
+    sc.prepare_input(raw, capi.make_input_config(**kw))
+    for min_dist in (0.02, 0.15):
+        kept = ref_cpu.downsample(body, 0.5, 20, min_dist)
+        info = sc.preprocess_geometric(I3, z3, 0.5, 20, min_dist)
+        assert info["n_downsampled"] == len(kept)
+        assert np.array_equal(sc.indices(1), kept)
+        _same_points(sc.points(capi.Scan.DOWNSAMPLED), body[kept])
+    sc.destroy()
+
+
+@pytest.mark.gpu
+def test_scan_frontend_many_distinct_timestamps_and_device_input(ctx):
+    """Every point its own timestamp (the rank sort loops over many tiles), the value 0xFFFFFFFF among them (the hash
+    set's empty marker), and the same cloud handed over as a device buffer."""
+    import torch
+    from mimosa_amd import capi
+    rng = np.random.default_rng(3)
+    raw, _ = synth.make_raw_scan(16, n_cols=512)
+    n = len(raw)
+    raw["t"] = rng.permutation(np.arange(n, dtype=np.uint64) * 4099 % (1 << 32)).astype(np.uint32)
+    raw["t"][5] = 0xFFFFFFFF
+    raw["t"][77] = raw["t"][78]                      # one duplicate pair
+    kw = dict(ns_max=1.0e10)
+    o = ref_cpu.prepare_input(raw, ref_cpu.make_input_config(**kw))
+    assert o["unique_ns"][-1] == 0xFFFFFFFF and len(o["unique_ns"]) > 5000
+    sc = capi.Scan(ctx)
+    info = sc.prepare_input(raw, capi.make_input_config(**kw))
+    assert info["n_unique_ns"] == len(o["unique_ns"]) and info["last_point_ns"] == o["last_point_ns"] == 0xFFFFFFFF
+    assert np.array_equal(sc.unique_ns(), o["unique_ns"])
+    _same_points(sc.points(capi.Scan.FULL), _as_points(o["points_full"]))
+    d_raw = torch.from_numpy(np.frombuffer(raw.tobytes(), np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    sc2 = capi.Scan(ctx)
+    info2 = sc2.prepare_input_device(d_raw.data_ptr(), n, capi.make_input_config(**kw))
+    assert info2 == info
+    assert np.array_equal(sc2.unique_ns(), o["unique_ns"])
+    _same_points(sc2.points(capi.Scan.FULL), _as_points(o["points_full"]))
+    assert np.array_equal(sc2.indices(0), o["geometric_idxs"].astype(np.uint32))
+    sc.destroy()
+    sc2.destroy()
+
+
+@pytest.mark.gpu
 def test_factor_from_device_scan_equals_factor_from_host_cloud(ctx, small_world):
     from mimosa_amd import capi
     w = small_world
