@@ -8,8 +8,9 @@
 // product coefficient-wise as r0*x + (r1*y + r2*z), then adds t.  This file is compiled with
 // -ffp-contract=off so the results are bit-identical: a 1-ulp difference is harmless for the ICP
 // residual but can move a point across a voxel boundary in the down-sampler / map insert.
-// Pure streaming work: 32 B in, 12 B (xyz) out per point; the <=1024-entry pose table is staged in
-// LDS (48 KiB) and the timestamp -> group lookup is a binary search in LDS.
+// Pure streaming work: 32 B in, 12 B (xyz) out per point; the timestamp -> group lookup is a binary search over the
+// <= 4096 distinct timestamps staged in LDS (16 KiB); the group's pose (48 B) comes through L1 / L2 (staging the whole
+// pose table per block cost more than it saved: 48 KiB x 512 blocks of extra reads for a 4 MiB cloud).
 #include <hip/hip_runtime.h>
 
 #include "icp_device.hpp"
@@ -19,7 +20,7 @@ namespace mh
 namespace
 {
 constexpr int kThreads = 256;
-constexpr int kMaxGroupsLds = 1024;
+constexpr int kMaxGroupsLds = 4096;
 
 __device__ __forceinline__ void xform(const float * P, float & x, float & y, float & z)
 {
@@ -34,17 +35,14 @@ __global__ __launch_bounds__(kThreads) void deskew_kernel(float4 * pts, int n, c
                                                            const float * Rt12, int n_groups, const float * body,
                                                            int use_lds)
 {
-  __shared__ float s_pose[kMaxGroupsLds * 12];
   __shared__ uint32_t s_ns[kMaxGroupsLds];
   __shared__ float s_body[12];
-  if (use_lds) {
-    for (int i = threadIdx.x; i < n_groups * 12; i += kThreads) s_pose[i] = Rt12[i];
+  if (use_lds)
     for (int i = threadIdx.x; i < n_groups; i += kThreads) s_ns[i] = unique_ns[i];
-  }
   if (body && threadIdx.x < 12) s_body[threadIdx.x] = body[threadIdx.x];
   __syncthreads();
   const uint32_t * ns = use_lds ? s_ns : unique_ns;
-  const float * poses = use_lds ? s_pose : Rt12;
+  const float * poses = Rt12;
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
     float4 a = pts[2 * i];
     const float4 b = pts[2 * i + 1];

@@ -14,18 +14,21 @@
 //   prepare (3 kernels)
 //     input_count      per 1024-point block: how many points pass the filter / belong to the geometric subset
 //     input_scatter    block prefix (sum of the preceding block counts) + in-block scan -> order-preserving
-//                      compaction into points_full_ / geometric_point_idxs_; every kept timestamp goes through a
-//                      hash set, first-inserters append it to an unsorted list; max timestamp by atomicMax
-//     unique_sort      rank sort of the distinct timestamps (distinct => rank = number of smaller ones), tiles in LDS
+//                      compaction into points_full_ / geometric_point_idxs_; the kept timestamps go through a
+//                      block-level set in LDS, then a global hash set, first-inserters append to an unsorted list
+//     unique_sort      rank sort of the distinct timestamps (distinct => rank = number of smaller ones), tiles in
+//                      LDS; the last rank is last_point_ns
 //   deskew (1 kernel, deskew_kernels.hip)
 //   preprocess (memset + 7 kernels)
 //     body_voxel       gather + f32 body transform + voxel key -> hash table: slot of the voxel, atomicMin of the
-//                      first input index, atomicAdd of the point count
+//                      first input index, atomicAdd of the point count (one probe + one pair of atomics per run of
+//                      consecutive lanes in the same voxel)
 //     voxel_count / voxel_offsets   scan over input positions of "count of the voxel whose first point I am":
 //                      voxels laid out in first-seen order (geometric.cpp:103-109), compact voxel list
 //     voxel_scatter    every point into its voxel's segment (atomic cursor: unordered inside the segment)
-//     greedy_voxel     one wave per voxel: sort the segment by input index (rank sort in registers / from L1; a
-//                      wave-level binary LSD radix for > 1024 points), then FlatContainerMinimal::add in input order
+//     greedy_voxel     one wave per voxel: sort the segment by input index (<= 64: rank sort in registers; <= 1024:
+//                      wave-level binary LSD radix in LDS; above: the same radix on global scratch), then
+//                      FlatContainerMinimal::add in input order
 //     keep_count / keep_scatter     order-preserving compaction of the kept points = "voxels in first-seen order,
 //                      points in acceptance order"
 // HBM/L2-bound streaming, hashing and small-sort work (32 B records, <= 131 072 of them): no MFMA.  Compiled with
@@ -43,7 +46,8 @@ namespace mh
 namespace
 {
 constexpr int kThreads = 256;
-constexpr int kItems = 4;                         // consecutive elements per thread in the blocked kernels
+constexpr int kItems = 1;                         // consecutive elements per thread in the blocked kernels: these kernels are
+                                                  // latency-bound (<= 131 072 elements), more blocks beat wider threads
 constexpr uint32_t kBlockItems = kThreads * kItems;
 constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
 constexpr uint64_t kEmpty64 = ~0ull;
@@ -223,8 +227,6 @@ __global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster
   uint32_t e_full, e_geo, t_full, t_geo;
   block_exclusive_sum2(c_full, c_geo, e_full, e_geo, t_full, t_geo, lds);
   uint32_t pos_full = off_full + e_full, pos_geo = off_geo + e_geo;
-  uint32_t t_max = 0;
-  bool any = false;
 #pragma unroll
   for (uint32_t k = 0; k < kItems; ++k) {
     if (!(fl[k] & 1u)) continue;
@@ -242,33 +244,68 @@ __global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster
     points_full[pos_full] = o;
     if (fl[k] & 2u) geo_idx[pos_geo++] = pos_full;
     ++pos_full;
-    // distinct timestamps (:340-368): hash set; the first thread to claim a slot appends the value
-    const uint32_t t = p[k].t;
-    any = true;
-    t_max = max(t_max, t);
-    if (t == kEmpty32) {  // the table's empty marker itself: carried by a flag, appended last by unique_sort_kernel
-      atomicOr(&counters->has_max_ns, 1u);
-      continue;
+  }
+  // Distinct timestamps (:340-368), a set: any assignment of points to threads will do.  The block takes the points
+  // blockIdx + k * gridDim: in an organised cloud (row-major, 2^k columns) those share a handful of columns, so the
+  // block-level set in LDS leaves a few values per block for the global hash set (device-scope atomics: the expensive
+  // part) instead of one per point.  The first thread to claim a global slot lists the value.
+  __shared__ uint32_t block_set[2 * kThreads];
+  block_set[threadIdx.x] = kEmpty32;
+  block_set[kThreads + threadIdx.x] = kEmpty32;
+  __syncthreads();
+  bool claimed = false;
+  uint32_t t = 0;
+  {
+    const uint64_t i2 = blockIdx.x + static_cast<uint64_t>(threadIdx.x) * gridDim.x;
+    bool mine = false;
+    if (i2 < n) {
+      const mh_ouster_point q = raw[i2];
+      t = q.t;
+      mine = (filter_point(q, static_cast<uint32_t>(i2), f) & 1u) != 0u;
     }
-    uint32_t slot = mix32(t) & ns_mask;
-    for (;;) {
-      uint32_t cur = __hip_atomic_load(&ns_table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur == kEmpty32) {
-        cur = atomicCAS(&ns_table[slot], kEmpty32, t);
-        if (cur == kEmpty32) {  // claimed: this thread is the one that lists the value
-          ns_unsorted[atomicAdd(&counters->n_unique_ns, 1u)] = t;
+    if (mine && t == kEmpty32) {  // the table's empty marker itself: carried by a flag, appended last by unique_sort_kernel
+      atomicOr(&counters->has_max_ns, 1u);
+      mine = false;
+    }
+    if (mine) {
+      uint32_t slot = mix32(t) & (2 * kThreads - 1);
+      for (;;) {
+        const uint32_t cur = atomicCAS(&block_set[slot], kEmpty32, t);
+        if (cur == kEmpty32) break;  // first in the block
+        if (cur == t) {
+          mine = false;
           break;
         }
+        slot = (slot + 1) & (2 * kThreads - 1);
       }
-      if (cur == t) break;
-      slot = (slot + 1) & ns_mask;
+    }
+    if (mine) {
+      uint32_t slot = mix32(t) & ns_mask;
+      for (;;) {
+        uint32_t cur = __hip_atomic_load(&ns_table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmpty32) {
+          cur = atomicCAS(&ns_table[slot], kEmpty32, t);
+          if (cur == kEmpty32) {
+            claimed = true;
+            break;
+          }
+        }
+        if (cur == t) break;
+        slot = (slot + 1) & ns_mask;
+      }
     }
   }
-  // :310 last_point_ns = max t over the kept points
-  const uint64_t anyone = __ballot(any);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) t_max = max(t_max, static_cast<uint32_t>(__shfl_xor(t_max, d)));
-  if (anyone && (threadIdx.x & 63u) == 0) atomicMax(&counters->last_point_ns, t_max);
+  {  // the claimed values of the wave are appended with one atomicAdd
+    const uint64_t cm = __ballot(claimed);
+    if (cm != 0ull) {
+      const uint32_t lane = threadIdx.x & 63u;
+      const int leader = __ffsll(static_cast<long long>(cm)) - 1;
+      uint32_t at = 0;
+      if (lane == static_cast<uint32_t>(leader)) at = atomicAdd(&counters->n_unique_ns, static_cast<uint32_t>(__popcll(cm)));
+      at = __shfl(at, leader);
+      if (claimed) ns_unsorted[at + static_cast<uint32_t>(__popcll(cm & ((1ull << lane) - 1ull)))] = t;
+    }
+  }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     counters->n_full = off_full + t_full;
     counters->n_geometric = off_geo + t_geo;
@@ -277,17 +314,26 @@ __global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster
 
 // the distinct timestamps, ascending: rank = number of smaller values (they are distinct).  The whole list passes
 // through LDS in 1024-value tiles; O(m^2) compares, m is the column count of the sensor (1024 / 2048) in practice.
+// :310 last_point_ns = max t over the kept points = the value of the last rank.
+// A block ranks 64 values; its 4 waves each scan a quarter of every tile.
+constexpr uint32_t kTile = kThreads * 4;
 __global__ __launch_bounds__(kThreads) void unique_sort_kernel(const uint32_t * __restrict__ ns_unsorted, uint32_t * __restrict__ unique_ns,
-                                                                const ScanCounters * counters)
+                                                                ScanCounters * counters)
 {
   __shared__ uint4 tile[kThreads];
+  __shared__ uint32_t part[4][64];
   const uint32_t m = counters->n_unique_ns;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && counters->has_max_ns) unique_ns[m] = kEmpty32;
-  if (blockIdx.x * kThreads >= m) return;
-  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const bool has_max = counters->has_max_ns != 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && has_max) {
+    unique_ns[m] = kEmpty32;
+    counters->last_point_ns = kEmpty32;
+  }
+  if (blockIdx.x * 64u >= m) return;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t i = blockIdx.x * 64u + lane;
   const uint32_t v = i < m ? ns_unsorted[i] : 0u;
   uint32_t rank = 0;
-  for (uint32_t t0 = 0; t0 < m; t0 += kBlockItems) {
+  for (uint32_t t0 = 0; t0 < m; t0 += kTile) {
     uint4 q;
     const uint32_t j = t0 + threadIdx.x * 4;
     q.x = j + 0 < m ? ns_unsorted[j + 0] : kEmpty32;  // the padding value is never smaller than anything
@@ -297,53 +343,90 @@ __global__ __launch_bounds__(kThreads) void unique_sort_kernel(const uint32_t * 
     __syncthreads();
     tile[threadIdx.x] = q;
     __syncthreads();
-    const uint32_t lim = min(kThreads, (m - t0 + 3) / 4);
-    for (uint32_t u = 0; u < lim; ++u) {
+    const uint32_t lim = min(static_cast<uint32_t>(kThreads), (m - t0 + 3) / 4);
+#pragma unroll 4
+    for (uint32_t u = wave * 64u; u < min(lim, wave * 64u + 64u); ++u) {
       const uint4 w = tile[u];  // broadcast read
       rank += (w.x < v) + (w.y < v) + (w.z < v) + (w.w < v);
     }
   }
-  if (i < m) unique_ns[rank] = v;
+  part[wave][lane] = rank;
+  __syncthreads();
+  if (wave == 0 && i < m) {
+    rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    unique_ns[rank] = v;
+    if (rank == m - 1 && !has_max) counters->last_point_ns = v;
+  }
 }
 
 // ---- Geometric::preprocess + the voxel assignment of Geometric::downsample ------------------------------------
 constexpr int kCoordBits = 21;
 constexpr int kCoordBias = 1 << (kCoordBits - 1);
 
+// Runs of consecutive lanes with the same voxel (neighbouring columns of one ring mostly are): one hash probe and one
+// set of atomics per run instead of per point.  head_lane = the run's first lane, run_len on the head lane.
+struct LaneRun
+{
+  bool head;
+  uint32_t head_lane, run_len;
+};
+__device__ __forceinline__ LaneRun lane_runs(bool valid, bool differs_from_previous_lane)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  LaneRun r;
+  r.head = valid && (lane == 0u || differs_from_previous_lane);
+  const uint64_t heads = __ballot(r.head);
+  const uint32_t n_valid = static_cast<uint32_t>(__popcll(__ballot(valid)));  // valid lanes are a prefix of the wave
+  const uint64_t upto = heads & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));
+  r.head_lane = upto ? 63u - static_cast<uint32_t>(__clzll(upto)) : 0u;
+  const uint64_t later = lane == 63u ? 0ull : (heads >> (lane + 1u));
+  const uint32_t end = later ? lane + static_cast<uint32_t>(__ffsll(static_cast<long long>(later))) : n_valid;
+  r.run_len = end - lane;
+  return r;
+}
+
 __global__ __launch_bounds__(kThreads) void body_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ geo_idx,
                                                                uint32_t n, Rt12 P, double inv_leaf, mh_point32 * __restrict__ body,
                                                                VoxelHash h, uint32_t * __restrict__ slot_of)
 {
   const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
-  if (j >= n) return;
-  mh_point32 p = pts[geo_idx[j]];
-  const float px = p.x, py = p.y, pz = p.z;  // Eigen's coefficient order r0*x + (r1*y + r2*z), then + t (geometric.cpp:154-161)
-  p.x = (P.v[0] * px + (P.v[1] * py + P.v[2] * pz)) + P.v[9];
-  p.y = (P.v[3] * px + (P.v[4] * py + P.v[5] * pz)) + P.v[10];
-  p.z = (P.v[6] * px + (P.v[7] * py + P.v[8] * pz)) + P.v[11];
-  body[j] = p;
-  // :77-80 coord = fast_floor(double(p) * inv_leaf)
-  const int cx = fast_floor(static_cast<double>(p.x) * inv_leaf), cy = fast_floor(static_cast<double>(p.y) * inv_leaf),
-            cz = fast_floor(static_cast<double>(p.z) * inv_leaf);
-  const int bx = cx + kCoordBias, by = cy + kCoordBias, bz = cz + kCoordBias;
-  if (((bx | by | bz) >> kCoordBits) != 0) *h.bad = 0u;  // (memset to all-ones: any other value = "a coordinate did not fit")
-  const uint64_t key = (static_cast<uint64_t>(bx & ((1 << kCoordBits) - 1)) << (2 * kCoordBits)) |
-                       (static_cast<uint64_t>(by & ((1 << kCoordBits) - 1)) << kCoordBits) |
-                       static_cast<uint64_t>(bz & ((1 << kCoordBits) - 1));
-  uint32_t slot = mix64(key) & h.mask;
-  for (;;) {
-    unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&h.keys[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == kEmpty64) {
-      cur = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[slot]), static_cast<unsigned long long>(kEmpty64),
-                      static_cast<unsigned long long>(key));
-      if (cur == kEmpty64) cur = key;
-    }
-    if (cur == key) break;
-    slot = (slot + 1) & h.mask;
+  const bool valid = j < n;
+  uint64_t key = kEmpty64;
+  if (valid) {
+    mh_point32 p = pts[geo_idx[j]];
+    const float px = p.x, py = p.y, pz = p.z;  // Eigen's coefficient order r0*x + (r1*y + r2*z), then + t (geometric.cpp:154-161)
+    p.x = (P.v[0] * px + (P.v[1] * py + P.v[2] * pz)) + P.v[9];
+    p.y = (P.v[3] * px + (P.v[4] * py + P.v[5] * pz)) + P.v[10];
+    p.z = (P.v[6] * px + (P.v[7] * py + P.v[8] * pz)) + P.v[11];
+    body[j] = p;
+    // :77-80 coord = fast_floor(double(p) * inv_leaf)
+    const int cx = fast_floor(static_cast<double>(p.x) * inv_leaf), cy = fast_floor(static_cast<double>(p.y) * inv_leaf),
+              cz = fast_floor(static_cast<double>(p.z) * inv_leaf);
+    const int bx = cx + kCoordBias, by = cy + kCoordBias, bz = cz + kCoordBias;
+    if (((bx | by | bz) >> kCoordBits) != 0) *h.bad = 0u;  // (memset to all-ones: any other value = "a coordinate did not fit")
+    key = (static_cast<uint64_t>(bx & ((1 << kCoordBits) - 1)) << (2 * kCoordBits)) |
+          (static_cast<uint64_t>(by & ((1 << kCoordBits) - 1)) << kCoordBits) | static_cast<uint64_t>(bz & ((1 << kCoordBits) - 1));
   }
-  atomicMin(&h.first[slot], j);  // all-ones before: the voxel's first point in input order
-  atomicAdd(&h.cnt[slot], 1u);   // all-ones before: stored value = count - 1
-  slot_of[j] = slot;
+  const uint32_t klo = static_cast<uint32_t>(key), khi = static_cast<uint32_t>(key >> 32);
+  const LaneRun run = lane_runs(valid, __shfl_up(klo, 1) != klo || __shfl_up(khi, 1) != khi);
+  uint32_t slot = 0;
+  if (run.head) {
+    slot = mix64(key) & h.mask;
+    for (;;) {
+      unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&h.keys[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == kEmpty64) {
+        cur = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[slot]), static_cast<unsigned long long>(kEmpty64),
+                        static_cast<unsigned long long>(key));
+        if (cur == kEmpty64) cur = key;
+      }
+      if (cur == key) break;
+      slot = (slot + 1) & h.mask;
+    }
+    atomicMin(&h.first[slot], j);            // all-ones before: the voxel's first point in input order (the head has the run's smallest j)
+    atomicAdd(&h.cnt[slot], run.run_len);    // all-ones before: stored value = count - 1
+  }
+  slot = __shfl(slot, static_cast<int>(run.head_lane));
+  if (valid) slot_of[j] = slot;
 }
 
 // value of input position j in the two scans: (points of the voxel, 1) if j is the first point of its voxel, else (0, 0)
@@ -381,10 +464,10 @@ __global__ __launch_bounds__(kThreads) void voxel_count_kernel(const uint32_t * 
   }
 }
 
-// off[slot] = start of the voxel's segment (voxels in first-seen order); vox_slot[v] = slot of the v-th voxel
+// off[slot] = start of the voxel's segment (voxels in first-seen order); vox_seg[v] = (start, length) of the v-th voxel
 __global__ __launch_bounds__(kThreads) void voxel_offsets_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
                                                                   const uint32_t * __restrict__ blk_pts,
-                                                                  const uint32_t * __restrict__ blk_vox, uint32_t * __restrict__ vox_slot,
+                                                                  const uint32_t * __restrict__ blk_vox, uint2 * __restrict__ vox_seg,
                                                                   ScanCounters * counters)
 {
   __shared__ uint32_t lds[8];
@@ -409,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void voxel_offsets_kernel(const uint32_t 
   for (uint32_t k = 0; k < kItems; ++k)
     if (vk[k]) {
       h.off[sl[k]] = pc;
-      vox_slot[pv] = sl[k];
+      vox_seg[pv] = make_uint2(pc, ck[k]);
       pc += ck[k];
       ++pv;
     }
@@ -420,104 +503,132 @@ __global__ __launch_bounds__(kThreads) void voxel_scatter_kernel(const uint32_t 
                                                                   uint32_t * __restrict__ idx_unsorted)
 {
   const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t slot = slot_of[j];
-  idx_unsorted[h.off[slot] + (atomicAdd(&h.cur[slot], 1u) + 1u)] = j;  // cursor starts at all-ones
+  const bool valid = j < n;
+  const uint32_t slot = valid ? slot_of[j] : kEmpty32;
+  const LaneRun run = lane_runs(valid, __shfl_up(slot, 1) != slot);
+  uint32_t at = 0;
+  if (run.head) at = h.off[slot] + (atomicAdd(&h.cur[slot], run.run_len) + 1u);  // cursor starts at all-ones
+  at = __shfl(at, static_cast<int>(run.head_lane));
+  if (valid) idx_unsorted[at + ((threadIdx.x & 63u) - run.head_lane)] = j;
 }
 
-// One WAVE per voxel.  (1) the voxel's point indices, unordered after the scatter, ascending into idx_sorted: input
-// order.  (2) FlatContainerMinimal::add over them: lane j holds the j-th point kept so far (<= 20); every incoming
-// point is tested against all of them at once (one fp64 distance per lane, one ballot).  keep[] is indexed by position
-// in idx_sorted.
-__global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ idx_unsorted,
-                                                                 uint32_t * idx_sorted, uint32_t * idx_tmp, const uint32_t * __restrict__ vox_slot,
-                                                                 VoxelHash h, const ScanCounters * counters, uint32_t idx_bits,
-                                                                 uint32_t max_pts, double min_sq, uint32_t * __restrict__ keep)
+// One wave sorts len distinct values ascending: binary LSD radix, one stable split per bit that varies, ping-pong between
+// a and b so that the last pass lands in a.  src / a / b: LDS or global (distinct arrays).
+__device__ __forceinline__ void wave_radix_sort(const uint32_t * src, uint32_t * a, uint32_t * b, uint32_t len)
 {
-  const uint32_t nv = counters->n_voxels;
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
+  uint32_t zeros = 0, diff = 0;
+  const uint32_t e0 = src[0];
+  for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+    const bool valid = c0 + lane < len;
+    const uint32_t e = valid ? src[c0 + lane] : e0;
+    diff |= e ^ e0;
+    zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !(e & 1u))));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) diff |= __shfl_xor(diff, d);
+  const uint32_t n_bits = diff ? 32u - static_cast<uint32_t>(__clz(diff)) : 1u;
+  for (uint32_t bit = 0; bit < n_bits; ++bit) {
+    uint32_t * dst = ((n_bits - 1u - bit) & 1u) ? b : a;
+    uint32_t z_run = 0, o_run = zeros, next_zeros = 0;
+    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+      const bool valid = c0 + lane < len;
+      const uint32_t e = valid ? src[c0 + lane] : 0u;
+      const bool one = (e >> bit) & 1u;
+      const uint64_t m0 = __ballot(valid && !one), m1 = __ballot(valid && one);
+      if (valid) dst[one ? o_run + static_cast<uint32_t>(__popcll(m1 & lanes_below)) : z_run + static_cast<uint32_t>(__popcll(m0 & lanes_below))] = e;
+      next_zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !((e >> (bit + 1u)) & 1u))));
+      z_run += static_cast<uint32_t>(__popcll(m0));
+      o_run += static_cast<uint32_t>(__popcll(m1));
+    }
+    __threadfence_block();
+    src = dst;
+    zeros = next_zeros;
+  }
+}
+
+// One WAVE per voxel.  (1) the voxel's point indices, unordered after the scatter, ascending: input order.  <= 64: rank
+// sort in registers; <= kLdsSort: radix in LDS; above: the same radix on global scratch.  (2) FlatContainerMinimal::add
+// over them: lane j holds the j-th point kept so far (<= 20); every incoming point is tested against all of them at
+// once (one fp64 distance per lane, one ballot).  idx_sorted / keep are indexed by position in the first-seen layout.
+constexpr uint32_t kLdsSort = 1024;
+__global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ idx_unsorted,
+                                                                 uint32_t * idx_sorted, uint32_t * idx_tmp, const uint2 * __restrict__ vox_seg,
+                                                                 const ScanCounters * counters, uint32_t max_pts, double min_sq,
+                                                                 uint32_t * __restrict__ keep)
+{
+  __shared__ uint32_t sort_lds[kThreads / 64][2][kLdsSort];
+  const uint32_t nv = counters->n_voxels;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_in_block = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6, n_waves = (gridDim.x * kThreads) >> 6;
   const uint32_t cap = min(max_pts, static_cast<uint32_t>(kBucketStride));  // utils.hpp:262 size cap
   for (uint32_t v = wave; v < nv; v += n_waves) {
-    const uint32_t slot = vox_slot[v];
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(h.off[slot]), len = __builtin_amdgcn_readfirstlane(h.cnt[slot] + 1u);
+    const uint2 seg = vox_seg[v];
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg.x), len = __builtin_amdgcn_readfirstlane(seg.y);
     const uint32_t s1 = s0 + len;
     uint32_t first_chunk = 0;  // sorted index of position s0 + lane, when the whole voxel fits one wave
     if (len <= 64u) {
       const uint32_t e = lane < len ? idx_unsorted[s0 + lane] : kEmpty32;
       uint32_t rank = 0;
-      for (uint32_t u = 0; u < len; ++u) rank += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e), static_cast<int>(u))) < e ? 1u : 0u;
+      for (uint32_t u = 0; u < len; ++u)
+        rank += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e), static_cast<int>(u))) < e ? 1u : 0u;
       if (lane >= len) rank = lane;
       first_chunk = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(rank << 2), static_cast<int>(e)));  // lane r <- the value of rank r
-      if (lane < len) idx_sorted[s0 + lane] = first_chunk;
-    } else if (len <= 1024u) {
-      for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-        const bool valid = c0 + lane < len;
-        const uint32_t e = valid ? idx_unsorted[s0 + c0 + lane] : 0u;
-        uint32_t rank = 0;
-        for (uint32_t u = 0; u < len; ++u) rank += idx_unsorted[s0 + u] < e ? 1u : 0u;  // wave-uniform address
-        if (valid) idx_sorted[s0 + rank] = e;
-      }
-      __threadfence_block();
+    } else if (len <= kLdsSort) {
+      wave_radix_sort(idx_unsorted + s0, sort_lds[wave_in_block][0], sort_lds[wave_in_block][1], len);
     } else {
-      // binary LSD radix, the wave ping-pongs the segment between idx_sorted and idx_tmp so that the last pass lands in
-      // idx_sorted; every pass is a stable split by one bit
-      const uint32_t * src = idx_unsorted + s0;
-      for (uint32_t bit = 0; bit < idx_bits; ++bit) {
-        uint32_t * dst = (((idx_bits - 1u - bit) & 1u) ? idx_tmp : idx_sorted) + s0;
-        uint32_t zeros = 0;
-        for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-          const bool valid = c0 + lane < len;
-          const uint32_t e = valid ? __hip_atomic_load(&src[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-          zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !((e >> bit) & 1u))));
-        }
-        uint32_t z_run = 0, o_run = zeros;
-        for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-          const bool valid = c0 + lane < len;
-          const uint32_t e = valid ? __hip_atomic_load(&src[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-          const bool one = (e >> bit) & 1u;
-          const uint64_t m0 = __ballot(valid && !one), m1 = __ballot(valid && one);
-          if (valid) dst[one ? o_run + static_cast<uint32_t>(__popcll(m1 & lanes_below)) : z_run + static_cast<uint32_t>(__popcll(m0 & lanes_below))] = e;
-          z_run += static_cast<uint32_t>(__popcll(m0));
-          o_run += static_cast<uint32_t>(__popcll(m1));
-        }
-        __threadfence_block();
-        src = dst;
-      }
+      wave_radix_sort(idx_unsorted + s0, idx_sorted + s0, idx_tmp + s0, len);
     }
-    double kx = 0.0, ky = 0.0, kz = 0.0;  // this lane's kept point (lane < n_kept)
+    // FlatContainerMinimal::add, 64 candidates at a time: (a) every candidate against the points kept so far (<= 20
+    // broadcasts), (b) the survivors in input order: the first one is kept and knocks out the later ones near it.  A
+    // candidate is kept iff no EARLIER KEPT point is closer than min_dist and the voxel is not full — the sequential
+    // rule, with the sequential part reduced to the points that are actually kept.
+    float kx = 0.f, ky = 0.f, kz = 0.f;  // this lane's kept point (lane < n_kept)
     uint32_t n_kept = 0;
-    for (uint32_t base = s0; base < s1; base += 64u) {  // the segment, 64 points at a time
+    for (uint32_t base = s0; base < s1; base += 64u) {
       const uint32_t s = base + lane;
+      const bool valid = s < s1;
       float px = 0.f, py = 0.f, pz = 0.f;
-      if (s < s1) {
-        const uint32_t j = len <= 64u ? first_chunk : __hip_atomic_load(&idx_sorted[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (valid) {
+        uint32_t j;
+        if (len <= 64u)
+          j = first_chunk;
+        else if (len <= kLdsSort)
+          j = sort_lds[wave_in_block][0][s - s0];
+        else
+          j = __hip_atomic_load(&idx_sorted[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (len <= kLdsSort) idx_sorted[s] = j;
         const mh_point32 p = pts[j];
         px = p.x;
         py = p.y;
         pz = p.z;
       }
-      const uint32_t m = min(64u, s1 - base);
-      uint64_t kept_mask = 0;
-      for (uint32_t u = 0; u < m; ++u) {  // input order
-        const double qx = static_cast<double>(lane_value(px, u)), qy = static_cast<double>(lane_value(py, u)),
-                     qz = static_cast<double>(lane_value(pz, u));
-        const double dx = kx - qx, dy = ky - qy, dz = kz - qz;
+      const double qx = static_cast<double>(px), qy = static_cast<double>(py), qz = static_cast<double>(pz);
+      bool blocked = !valid;
+      for (uint32_t i = 0; i < n_kept; ++i) {
+        const double dx = static_cast<double>(lane_value(kx, i)) - qx, dy = static_cast<double>(lane_value(ky, i)) - qy,
+                     dz = static_cast<double>(lane_value(kz, i)) - qz;
         // Vector3d squaredNorm: p0 + (p1 + p2); utils.hpp:266-272
-        const bool close = lane < n_kept && dx * dx + (dy * dy + dz * dz) < min_sq;
-        const bool take = n_kept < cap && __ballot(close) == 0ull;
-        if (take) {
-          if (lane == n_kept) {
-            kx = qx;
-            ky = qy;
-            kz = qz;
-          }
-          ++n_kept;
-          kept_mask |= 1ull << u;
-        }
+        blocked = blocked || dx * dx + (dy * dy + dz * dz) < min_sq;
       }
-      if (s < s1) keep[s] = static_cast<uint32_t>((kept_mask >> lane) & 1ull);
+      uint64_t open = __ballot(!blocked), kept_mask = 0;
+      while (open != 0ull && n_kept < cap) {  // utils.hpp:262 size cap
+        const uint32_t u = static_cast<uint32_t>(__ffsll(static_cast<long long>(open))) - 1u;
+        const float ux = lane_value(px, u), uy = lane_value(py, u), uz = lane_value(pz, u);
+        if (lane == n_kept) {
+          kx = ux;
+          ky = uy;
+          kz = uz;
+        }
+        ++n_kept;
+        kept_mask |= 1ull << u;
+        const double dx = static_cast<double>(ux) - qx, dy = static_cast<double>(uy) - qy, dz = static_cast<double>(uz) - qz;
+        blocked = blocked || dx * dx + (dy * dy + dz * dz) < min_sq;
+        open = __ballot(!blocked) & (u == 63u ? 0ull : (~0ull << (u + 1u)));
+      }
+      if (valid) keep[s] = static_cast<uint32_t>((kept_mask >> lane) & 1ull);
     }
   }
 }
@@ -595,7 +706,7 @@ VoxelLayout voxel_layout(size_t n)
   L.cap = pow2_at_least(2 * static_cast<uint64_t>(n));
   L.clear_bytes = static_cast<size_t>(L.cap) * (8 + 4 + 4 + 4) + 16;
   const size_t m = n ? n : 1;
-  L.bytes = L.clear_bytes + static_cast<size_t>(L.cap) * 4 + (6 * m + 3 * static_cast<size_t>(L.n_blocks)) * 4;
+  L.bytes = L.clear_bytes + static_cast<size_t>(L.cap) * 4 + (7 * m + 3 * static_cast<size_t>(L.n_blocks)) * 4;
   return L;
 }
 
@@ -619,7 +730,7 @@ hipError_t launch_prepare_input(const mh_ouster_point * raw, uint32_t n, const m
   hipLaunchKernelGGL(input_count_kernel, g, b, 0, stream, raw, n, f, blk_full, blk_geo, ns_table, L.ns_cap, counters);
   hipLaunchKernelGGL(input_scatter_kernel, g, b, 0, stream, raw, n, f, blk_full, blk_geo, ns_table, L.ns_cap - 1u, ns_unsorted,
                      points_full, geo_idx, counters);
-  hipLaunchKernelGGL(unique_sort_kernel, dim3((n + kThreads - 1) / kThreads ? (n + kThreads - 1) / kThreads : 1u), b, 0, stream,
+  hipLaunchKernelGGL(unique_sort_kernel, dim3((n + 63u) / 64u ? (n + 63u) / 64u : 1u), b, 0, stream,
                      ns_unsorted, unique_ns, counters);
   return hipGetLastError();
 }
@@ -648,20 +759,20 @@ hipError_t launch_preprocess(const mh_point32 * points_full, const uint32_t * ge
   p += static_cast<size_t>(L.cap) * 4;
   h.mask = L.cap - 1u;
   uint32_t * w = reinterpret_cast<uint32_t *>(p);
-  uint32_t * slot_of = w, * idx_unsorted = w + n, * idx_sorted = w + 2 * static_cast<size_t>(n), * idx_tmp = w + 3 * static_cast<size_t>(n),
-           * keep = w + 4 * static_cast<size_t>(n), * vox_slot = w + 5 * static_cast<size_t>(n), * blk = w + 6 * static_cast<size_t>(n);
+  const size_t nn = n;
+  uint2 * vox_seg = reinterpret_cast<uint2 *>(w);  // 8-byte aligned: everything before it is a multiple of 8 bytes
+  uint32_t * slot_of = w + 2 * nn, * idx_unsorted = w + 3 * nn, * idx_sorted = w + 4 * nn, * idx_tmp = w + 5 * nn, * keep = w + 6 * nn,
+           * blk = w + 7 * nn;
   uint32_t * blk_pts = blk, * blk_vox = blk + L.n_blocks, * blk_keep = blk + 2 * L.n_blocks;
   const double inv_leaf = 1.0 / leaf;            // geometric.cpp:61
   const double min_sq = min_dist * min_dist;     // :63
-  uint32_t idx_bits = 1;
-  while (idx_bits < 32 && (1ull << idx_bits) < n) ++idx_bits;
   const dim3 gp((n + kThreads - 1) / kThreads), gb(L.n_blocks), b(kThreads);
   hipLaunchKernelGGL(body_voxel_kernel, gp, b, 0, stream, points_full, geo_idx, n, body_from_lidar, inv_leaf, body, h, slot_of);
   hipLaunchKernelGGL(voxel_count_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox);
-  hipLaunchKernelGGL(voxel_offsets_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox, vox_slot, counters);
+  hipLaunchKernelGGL(voxel_offsets_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox, vox_seg, counters);
   hipLaunchKernelGGL(voxel_scatter_kernel, gp, b, 0, stream, slot_of, n, h, idx_unsorted);
   hipLaunchKernelGGL(greedy_voxel_kernel, dim3(static_cast<uint32_t>(min((static_cast<size_t>(n) * 64 + kThreads - 1) / kThreads, static_cast<size_t>(8192)))),
-                     b, 0, stream, body, idx_unsorted, idx_sorted, idx_tmp, vox_slot, h, counters, idx_bits, max_pts, min_sq, keep);
+                     b, 0, stream, body, idx_unsorted, idx_sorted, idx_tmp, vox_seg, counters, max_pts, min_sq, keep);
   hipLaunchKernelGGL(keep_count_kernel, gb, b, 0, stream, keep, n, blk_keep);
   hipLaunchKernelGGL(keep_scatter_kernel, gb, b, 0, stream, body, idx_sorted, keep, n, blk_keep, h.bad, kept_idx, out, counters);
   return hipGetLastError();

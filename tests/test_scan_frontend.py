@@ -190,7 +190,7 @@ def test_scan_frontend_long_voxel_segments(ctx):
 def test_scan_frontend_many_distinct_timestamps_and_device_input(ctx):
     """Every point its own timestamp (the rank sort loops over many tiles), the value 0xFFFFFFFF among them (the hash
     set's empty marker), and the same cloud handed over as a device buffer."""
-    import torch
+    import ctypes as C
     from mimosa_amd import capi
     rng = np.random.default_rng(3)
     raw, _ = synth.make_raw_scan(16, n_cols=512)
@@ -206,16 +206,19 @@ def test_scan_frontend_many_distinct_timestamps_and_device_input(ctx):
     assert info["n_unique_ns"] == len(o["unique_ns"]) and info["last_point_ns"] == o["last_point_ns"] == 0xFFFFFFFF
     assert np.array_equal(sc.unique_ns(), o["unique_ns"])
     _same_points(sc.points(capi.Scan.FULL), _as_points(o["points_full"]))
-    d_raw = torch.from_numpy(np.frombuffer(raw.tobytes(), np.uint8).copy()).cuda()
-    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    d_raw = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_raw), C.c_size_t(raw.nbytes)) == 0
+    assert hip.hipMemcpy(d_raw, C.c_void_p(raw.ctypes.data), C.c_size_t(raw.nbytes), 1) == 0
     sc2 = capi.Scan(ctx)
-    info2 = sc2.prepare_input_device(d_raw.data_ptr(), n, capi.make_input_config(**kw))
+    info2 = sc2.prepare_input_device(d_raw.value, n, capi.make_input_config(**kw))
     assert info2 == info
     assert np.array_equal(sc2.unique_ns(), o["unique_ns"])
     _same_points(sc2.points(capi.Scan.FULL), _as_points(o["points_full"]))
     assert np.array_equal(sc2.indices(0), o["geometric_idxs"].astype(np.uint32))
     sc.destroy()
     sc2.destroy()
+    hip.hipFree(d_raw)
 
 
 @pytest.mark.gpu

@@ -14,4 +14,9 @@ for _ in range(20):
     uns = sc.unique_ns()
     sc.deskew(np.stack([aux["Rt12"][col[int(u)]] for u in uns]))
     sc.preprocess_geometric(I3, z3, 0.5, 20, 0.15)
+if len(sys.argv) > 1 and sys.argv[1] == "dense":  # every point in the geometric subset
+    for _ in range(20):
+        sc.prepare_input(raw, capi.make_input_config(point_skip_divisor=1))
+        sc.deskew(np.stack([aux["Rt12"][col[int(u)]] for u in sc.unique_ns()]))
+        sc.preprocess_geometric(I3, z3, 0.5, 20, 0.15)
 print("done")
