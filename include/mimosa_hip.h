@@ -441,6 +441,8 @@ int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double
  * VSVt: 6x6 row-major = V S V^T of Photometric::getFactors (photometric.cpp:373-394), NULL = identity; ignored for
  * the binary form. */
 int mh_photo_factor_create(mh_photo * photo, const double * VSVt, int is_binary, mh_photo_factor ** out);
+/* clone() (photometric_factor.hpp:120-124): member-wise copy — same frame (shared), own feature list and statuses. */
+int mh_photo_factor_clone(const mh_photo_factor * factor, mh_photo_factor ** out);
 void mh_photo_factor_destroy(mh_photo_factor * factor);
 /* linearize(Values) (:136-355): T_b = Values[keys[0]] (the frame's pose), T_a = Values[keys[1]] for the binary
  * form (NULL otherwise).  Blocks until the result is on the host. */

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
-    "mh_photo_factor_create", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_get_state", "mh_photo_factor_size",
+    "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_get_state", "mh_photo_factor_size",
 ]
 
 
@@ -320,6 +320,7 @@ def load(build_if_missing: bool = True):
     L.mh_photo_detect_features.argtypes = [vp, i32, vp, vp, vp, sz]
     L.mh_photo_update_map.argtypes = [vp, vp, vp, vp, vp, sz]
     L.mh_photo_factor_create.argtypes = [vp, vp, i32, pvp]
+    L.mh_photo_factor_clone.argtypes = [vp, pvp]
     L.mh_photo_factor_destroy.argtypes = [vp]
     L.mh_photo_factor_destroy.restype = None
     L.mh_photo_factor_linearize.argtypes = [vp, vp, vp, vp, vp, C.POINTER(PhotoResult)]
@@ -752,11 +753,14 @@ class Photo(_PhotoBase):
 class PhotoFactor:
     """lidar::PhotometricFactor counterpart (include/mimosa/lidar/photometric_factor.hpp:22-357)."""
 
-    def __init__(self, photo: Photo, VSVt=None, binary=False):
+    def __init__(self, photo: Photo, VSVt=None, binary=False, _clone_of=None):
         self.photo, self.ctx, self.L = photo, photo.ctx, photo.L
         V = _f64(VSVt) if VSVt is not None else None
         h = C.c_void_p()
-        self.ctx.check(self.L.mh_photo_factor_create(photo.h, _p(V), int(binary), C.byref(h)))
+        if _clone_of is not None:
+            self.ctx.check(self.L.mh_photo_factor_clone(_clone_of.h, C.byref(h)))
+        else:
+            self.ctx.check(self.L.mh_photo_factor_create(photo.h, _p(V), int(binary), C.byref(h)))
         self.h = h
         self.n = int(self.L.mh_photo_factor_size(h))
         self.ctx._children += 1
@@ -768,6 +772,10 @@ class PhotoFactor:
         ta = _f64(t_a) if t_a is not None else None
         self.ctx.check(self.L.mh_photo_factor_linearize(self.h, _p(Rb), _p(tb), _p(Ra), _p(ta), C.byref(out)))
         return out.as_dict()
+
+    def clone(self) -> "PhotoFactor":
+        """clone() (photometric_factor.hpp:120-124)"""
+        return PhotoFactor(self.photo, _clone_of=self)
 
     def state(self, rows=True):
         st = np.empty(self.n, np.int32)

@@ -801,6 +801,52 @@ int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double
   });
 }
 
+// PhotometricFactor ctor body shared by create (current frame + tracked features) and clone (the source factor's)
+static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::vector<HostFeature> & feats, const double * VSVt,
+                              bool binary, mh_photo_factor ** out)
+{
+  mh_ctx * ctx = photo->ctx;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_photo_factor * f = new mh_photo_factor;
+  f->photo = photo;
+  photo->refs.fetch_add(1);
+  f->frame = frame;
+  f->frame->refs.fetch_add(1);
+  f->binary = binary;
+  for (int i = 0; i < 36; ++i) f->VSVt[i] = VSVt ? VSVt[i] : ((i % 7 == 0) ? 1.0 : 0.0);
+  f->features = feats;
+  const size_t nf = f->features.size();
+  std::vector<double> Le(nf * mh::kPhotoMaxPatch * 3, 0.0), ps(nf * mh::kPhotoMaxPatch, 0.0);
+  std::vector<int32_t> np(nf);
+  for (size_t i = 0; i < nf; ++i) {
+    const HostFeature & hf = f->features[i];
+    np[i] = hf.hdr.n_points;
+    std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
+    std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
+  }
+  int rc = upload(ctx, f->d_Le, Le.data(), Le.size() * sizeof(double));
+  if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps.data(), ps.size() * sizeof(double));
+  if (rc == MH_OK) rc = upload(ctx, f->d_npts, np.data(), np.size() * sizeof(int32_t));
+  hipError_t e = hipSuccess;
+  if (rc == MH_OK) e = f->d_status.reserve(nf * sizeof(int32_t), ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = f->d_centers.reserve(nf * 2 * sizeof(double), ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = f->d_partials.reserve(nf * mh::kPhotoPartial * sizeof(double), ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
+  if (rc != MH_OK || e != hipSuccess) {
+    mh_photo_factor_destroy(f);
+    return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_factor_create");
+  }
+  f->statuses.assign(nf, MH_PHOTO_UNPROCESSED);
+  f->centers.assign(2 * nf, 0.0);
+  for (size_t i = 0; i < nf; ++i) {
+    f->centers[2 * i] = f->features[i].hdr.center[0];
+    f->centers[2 * i + 1] = f->features[i].hdr.center[1];
+  }
+  *out = f;
+  return MH_OK;
+}
+
 int mh_photo_factor_create(mh_photo * photo, const double * VSVt, int is_binary, mh_photo_factor ** out)
 {
   if (!photo || !out) return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_create: NULL argument");
@@ -809,44 +855,21 @@ int mh_photo_factor_create(mh_photo * photo, const double * VSVt, int is_binary,
   return guarded(ctx, "mh_photo_factor_create", [&]() -> int {
     if (!photo->frame) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_create: no frame (call mh_photo_preprocess first)");
     if (photo->features.empty()) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_create: No features in a_features (photometric_factor.hpp:97-99)");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
-    mh_photo_factor * f = new mh_photo_factor;
-    f->photo = photo;
-    photo->refs.fetch_add(1);
-    f->frame = photo->frame;
-    f->frame->refs.fetch_add(1);
-    f->binary = is_binary != 0;
-    for (int i = 0; i < 36; ++i) f->VSVt[i] = VSVt ? VSVt[i] : ((i % 7 == 0) ? 1.0 : 0.0);
-    f->features = photo->features;
-    const size_t nf = f->features.size();
-    std::vector<double> Le(nf * mh::kPhotoMaxPatch * 3, 0.0), ps(nf * mh::kPhotoMaxPatch, 0.0);
-    std::vector<int32_t> np(nf);
-    for (size_t i = 0; i < nf; ++i) {
-      const HostFeature & hf = f->features[i];
-      np[i] = hf.hdr.n_points;
-      std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
-      std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
-    }
-    int rc = upload(ctx, f->d_Le, Le.data(), Le.size() * sizeof(double));
-    if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps.data(), ps.size() * sizeof(double));
-    if (rc == MH_OK) rc = upload(ctx, f->d_npts, np.data(), np.size() * sizeof(int32_t));
-    hipError_t e = hipSuccess;
-    if (rc == MH_OK) e = f->d_status.reserve(nf * sizeof(int32_t), ctx->stream, false);
-    if (rc == MH_OK && e == hipSuccess) e = f->d_centers.reserve(nf * 2 * sizeof(double), ctx->stream, false);
-    if (rc == MH_OK && e == hipSuccess) e = f->d_partials.reserve(nf * mh::kPhotoPartial * sizeof(double), ctx->stream, false);
-    if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
-    if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
-    if (rc != MH_OK || e != hipSuccess) {
-      mh_photo_factor_destroy(f);
-      return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_factor_create");
-    }
-    f->statuses.assign(nf, MH_PHOTO_UNPROCESSED);
-    f->centers.assign(2 * nf, 0.0);
-    for (size_t i = 0; i < nf; ++i) {
-      f->centers[2 * i] = f->features[i].hdr.center[0];
-      f->centers[2 * i + 1] = f->features[i].hdr.center[1];
-    }
-    *out = f;
+    return photo_factor_build(photo, photo->frame, photo->features, VSVt, is_binary != 0, out);
+  });
+}
+
+int mh_photo_factor_clone(const mh_photo_factor * src, mh_photo_factor ** out)
+{
+  if (!src || !out) return fail(src ? src->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_clone: NULL argument");
+  *out = nullptr;
+  mh_ctx * ctx = src->photo->ctx;
+  return guarded(ctx, "mh_photo_factor_clone", [&]() -> int {
+    const int rc = photo_factor_build(src->photo, src->frame, src->features, src->VSVt, src->binary, out);
+    if (rc != MH_OK) return rc;
+    (*out)->statuses = src->statuses;  // the copy constructor's member-wise copy (photometric_factor.hpp:120-124)
+    (*out)->centers = src->centers;
+    (*out)->features = src->features;
     return MH_OK;
   });
 }

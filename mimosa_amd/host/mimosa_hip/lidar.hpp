@@ -108,13 +108,13 @@ public:
   IncrementalVoxelMapPCL & operator=(const IncrementalVoxelMapPCL &) = delete;
   ~IncrementalVoxelMapPCL() { mh_map_release(map_); }
 
-  // Successor for copy-then-insert (geometric.cpp:494-495) without copying the host structure: the returned map
-  // continues this one; THIS object stays valid for the factors that hold it (k-NN, getCloud) but is read-only.
+  // Successor for copy-then-insert (geometric.cpp:494-495): a deep copy, device to device (the map lives on the GPU;
+  // 0.2 ms for a 5 M-point map).  THIS object stays valid and unchanged for the factors that hold it.
   std::shared_ptr<IncrementalVoxelMapPCL> fork()
   {
     ensure();
     std::shared_ptr<IncrementalVoxelMapPCL> next(new IncrementalVoxelMapPCL(ctx_, cfg_, nullptr));
-    ctx_->check(mh_map_fork(map_, &next->map_), "mh_map_fork");
+    ctx_->check(mh_map_copy(map_, &next->map_), "mh_map_copy");
     return next;
   }
 
@@ -133,6 +133,16 @@ public:
   {
     ensure();
     ctx_->check(mh_map_insert(map_, xyz, n, 3), "mh_map_insert");
+  }
+  // Geometric::updateMap's insert (geometric.cpp:483-495) of a device-resident scan's Be_cloud_: f32 world transform
+  // + greedy insert on the GPU, nothing crosses PCIe.  (ScanFrontEnd is declared below.)
+  void insertBodyCloud(mh_scan * scan, const Pose3 & T_W_Be)
+  {
+    ensure();
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
+    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
+    ctx_->check(mh_map_insert_from_scan(map_, scan, R, t), "mh_map_insert_from_scan");
   }
   // incremental_voxel_map.cpp:26-32: true iff k neighbours were found; coordinates instead of ids
   bool knn_search(const V3D & point, const size_t k, std::vector<V3D> & neighbours, std::vector<double> & sq_dists)
@@ -227,6 +237,9 @@ public:
     size_t m = 0;
     ctx_->check(mh_scan_get_unique_ns(scan_, unique_ns_.data(), unique_ns_.size(), &m), "mh_scan_get_unique_ns");
   }
+  // points_raw_ (manager.cpp:376-380): keep a copy of points_full_ as it was before deskewPoints — Photometric::preprocess
+  // reads it (call before deskewPoints)
+  void keepRaw(bool keep) { ctx_->check(mh_scan_keep_raw(scan_, keep ? 1 : 0), "mh_scan_keep_raw"); }
   const std::vector<uint32_t> & uniqueNs() const { return unique_ns_; }  // the IMU propagation runs over these
   double correctedTs() const { return corrected_ts_; }
   const mh_scan_info & info() const { return info_; }
@@ -320,17 +333,43 @@ public:
                                  c.gravityUnit().data(), &r),
                 "mh_icp_linearize");
     last_ = r;
-    auto h = std::make_shared<HessianFactor>();
-    h->keys = keys();
-    std::memcpy(h->G11.data(), r.H_ss, sizeof(r.H_ss));
-    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_s[i];  // HessianFactor(key, H, -b, f), :559-560
-    h->f = r.f;
-    if (is_binary_) {  // :460-462
-      std::memcpy(h->G12.data(), r.H_st, sizeof(r.H_st));
-      std::memcpy(h->G22.data(), r.H_tt, sizeof(r.H_tt));
-      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_t[i];
+    return toHessian(r);
+  }
+
+  // Every live factor of the smoother window re-linearized in ONE device pass (what ISAM2's update + additional
+  // iterations, src/graph/manager.cpp:585-588, do one factor at a time): same results as factors[i]->linearize(c), bit
+  // for bit.  All factors unary or all binary, one context.
+  static std::vector<std::shared_ptr<GaussianFactor>> linearizeBatch(const std::vector<Ptr> & factors, const Values & c)
+  {
+    std::vector<std::shared_ptr<GaussianFactor>> out;
+    if (factors.empty()) return out;
+    const size_t n = factors.size();
+    const bool binary = factors[0]->is_binary_;
+    std::vector<mh_icp *> h(n);
+    std::vector<double> Rs(9 * n), ts(3 * n), Rt(binary ? 9 * n : 0), tt(binary ? 3 * n : 0), g(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+      const ICPFactor & f = *factors[i];
+      if (f.is_binary_ != binary) throw std::runtime_error("ICPFactor::linearizeBatch: unary and binary factors mixed");
+      h[i] = f.icp_;
+      const Pose3 & Ts = c.atPose3(f.keys()[0]);
+      std::memcpy(&Rs[9 * i], Ts.R.data(), 72);
+      std::memcpy(&ts[3 * i], Ts.t.data(), 24);
+      if (binary) {
+        const Pose3 & Tt = c.atPose3(f.keys()[1]);
+        std::memcpy(&Rt[9 * i], Tt.R.data(), 72);
+        std::memcpy(&tt[3 * i], Tt.t.data(), 24);
+      }
+      std::memcpy(&g[3 * i], c.gravityUnit().data(), 24);
     }
-    return h;
+    std::vector<mh_icp_result> r(n);
+    factors[0]->ctx().check(mh_icp_linearize_batch(h.data(), n, Rs.data(), ts.data(), binary ? Rt.data() : nullptr,
+                                                   binary ? tt.data() : nullptr, g.data(), r.data()),
+                            "mh_icp_linearize_batch");
+    for (size_t i = 0; i < n; ++i) {
+      factors[i]->last_ = r[i];
+      out.push_back(factors[i]->toHessian(r[i]));
+    }
+    return out;
   }
 
   // getters, :48-72
@@ -375,6 +414,20 @@ public:
   const mh_icp_result & lastResult() const { return last_; }  // incl. the status histogram of geometric.cpp:280-323
 
 private:
+  std::shared_ptr<HessianFactor> toHessian(const mh_icp_result & r) const
+  {
+    auto h = std::make_shared<HessianFactor>();
+    h->keys = keys();
+    std::memcpy(h->G11.data(), r.H_ss, sizeof(r.H_ss));
+    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_s[i];  // HessianFactor(key, H, -b, f), :559-560
+    h->f = r.f;
+    if (is_binary_) {  // :460-462
+      std::memcpy(h->G12.data(), r.H_st, sizeof(r.H_st));
+      std::memcpy(h->G22.data(), r.H_tt, sizeof(r.H_tt));
+      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_t[i];
+    }
+    return h;
+  }
   struct CloneTag
   {
   };
@@ -446,8 +499,8 @@ public:
     debug_.n_points_in_sm_ds = sm_Be_cloud_ds_.size();
   }
 
-  // The same on a device-resident scan: subset + body transform + down-sampler run on the GPU.  Be_cloud_ is
-  // brought to the host because updateMap inserts it into the map there (geometric.cpp:483-495).
+  // The same on a device-resident scan: subset + body transform + down-sampler run on the GPU; Be_cloud_ stays there
+  // (updateMap inserts it into the map on the device, geometric.cpp:483-495).
   void preprocess(ScanFrontEnd & scan, const double ts)
   {
     if (!config.enabled) return;
@@ -458,7 +511,7 @@ public:
     ctx_->check(mh_scan_preprocess_geometric(scan.underlying(), R, t, config.scan_to_map.source_voxel_grid_filter_leaf_size,
                                              20, config.scan_to_map.source_voxel_grid_min_dist_in_voxel, &scan.mutableInfo()),
                 "mh_scan_preprocess_geometric");
-    Be_cloud_ = scan.download(1);
+    Be_cloud_.clear();
     sm_Be_cloud_ds_.clear();
     device_scan_ = &scan;
     debug_.n_points_in = scan.info().n_full;
@@ -542,13 +595,17 @@ public:
     debug_.map_updated = update_map;
     if (!update_map) return;
     // world transform in f32 (:483-490), then copy-then-insert so live factors keep their snapshot (:494-495)
-    PointCloud W = Be_cloud_;
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
-    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
-    if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
     ivox_map_ = ivox_map_->fork();  // device-to-device copy; the previous map lives on in the factors that hold it
-    ivox_map_->insert(W);
+    if (device_scan_) {
+      ivox_map_->insertBodyCloud(device_scan_->underlying(), T_W_Be);  // transform + insert on the device
+    } else {
+      PointCloud W = Be_cloud_;
+      float R[9], t[3];
+      for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
+      for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
+      if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
+      ivox_map_->insert(W);
+    }
     map_poses_.push_back(T_W_Be);
   }
 

@@ -136,6 +136,14 @@ int main(int argc, char ** argv)
       geo2.getFactors(X0, values, graph3, evecs, degen);
       auto h3 = std::static_pointer_cast<HessianFactor>(graph3.factors[0]->linearize(values));
       dump_factor("first_device_frontend", geo2, *h3, degen);
+      // the window in one pass: the device factor and a clone of it at two poses ≡ their own linearize calls
+      std::vector<ICPFactor::Ptr> window{geo2.factor(), std::static_pointer_cast<ICPFactor>(geo2.factor()->clone())};
+      const auto hb = ICPFactor::linearizeBatch(window, values);
+      const auto hs = std::static_pointer_cast<HessianFactor>(window[1]->linearize(values));
+      const auto hb1 = std::static_pointer_cast<HessianFactor>(hb[1]);
+      std::printf(",\n\"batch_equal\": %d", (hb1->G11 == hs->G11 && hb1->g1 == hs->g1 && hb1->f == hs->f) ? 1 : 0);
+      geo2.updateMap(X0, values);  // Be_cloud_ never left the device: transform + insert there
+      std::printf(",\n\"map_points_after_device\": %zu", geo2.map()->getCloud().size());
       std::printf(",\n\"corrected_ts\": %.9f\n}\n", fe.correctedTs());
     } else {
       std::printf("\"no_raw\": 1\n}\n");

@@ -1,0 +1,141 @@
+// Drives the C++ host mirror of the photometric classes (mimosa_amd/host/mimosa_hip/photometric.hpp) through the
+// reference's call order
+//   preprocess(frame 0) -> updateMap (detectFeatures) -> preprocess(frame 1) -> getFactors -> linearize -> clone ->
+//   updateMap (bookkeeping from the statuses + re-detection)
+// on inputs written by tests/test_gpu_host_cpp.py, and prints the results as JSON for comparison with the oracle.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "../../mimosa_amd/host/mimosa_hip/photometric.hpp"
+
+using namespace mimosa_hip;
+using namespace mimosa_hip::lidar;
+
+template <typename T>
+static std::vector<T> read_vec(std::ifstream & f)
+{
+  uint64_t n = 0;
+  f.read(reinterpret_cast<char *>(&n), 8);
+  std::vector<T> v(n);
+  f.read(reinterpret_cast<char *>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
+  return v;
+}
+static Pose3 pose_from(const double * p)
+{
+  Pose3 T;
+  for (int i = 0; i < 9; ++i) T.R[i] = p[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = p[9 + i];
+  return T;
+}
+static void dump(const char * name, const double * v, int n)
+{
+  std::printf("\"%s\": [", name);
+  for (int i = 0; i < n; ++i) std::printf("%.17g%s", v[i], i + 1 < n ? ", " : "");
+  std::printf("],\n");
+}
+
+int main(int argc, char ** argv)
+{
+  if (argc < 2) return 2;
+  std::ifstream f(argv[1], std::ios::binary);
+  const auto I = read_vec<int32_t>(f);
+  const auto D = read_vec<double>(f);
+  PhotometricConfig cfg;
+  cfg.rows = static_cast<size_t>(I[0]);
+  cfg.cols = static_cast<size_t>(I[1]);
+  cfg.destagger = I[2] != 0;
+  cfg.erosion_buffer = I[3];
+  cfg.patch_size = I[4];
+  cfg.margin_size = I[5];
+  cfg.remove_lines = I[6] != 0;
+  cfg.filter_brightness = I[7] != 0;
+  cfg.gaussian_blur = I[8] != 0;
+  cfg.gaussian_blur_size = I[9];
+  cfg.nma_radius = I[10];
+  cfg.num_features_detect = static_cast<size_t>(I[11]);
+  cfg.max_feature_life_time = I[12];
+  cfg.rotate_patch_to_align_with_gradient = I[13] != 0;
+  cfg.use_robust_cost_function = I[14] != 0;
+  cfg.robust_cost_function = I[15] == 0 ? "huber" : "gemanmcclure";
+  cfg.brightness_window_size = {I[16], I[17]};
+  cfg.range_min = static_cast<float>(D[0]);
+  cfg.range_max = static_cast<float>(D[1]);
+  cfg.intensity_scale = static_cast<float>(D[2]);
+  cfg.intensity_gamma = static_cast<float>(D[3]);
+  cfg.gradient_threshold = static_cast<float>(D[4]);
+  cfg.max_dist_from_mean = static_cast<float>(D[5]);
+  cfg.max_dist_from_plane = static_cast<float>(D[6]);
+  cfg.occlusion_range_diff_threshold = static_cast<float>(D[7]);
+  cfg.lidar_origin_to_beam_origin_mm = static_cast<float>(D[8]);
+  cfg.robust_cost_function_parameter = D[9];
+  cfg.error_scale = D[10];
+  cfg.max_error = D[11];
+  cfg.sigma = D[12];
+  cfg.pixel_shift_by_row = read_vec<int32_t>(f);
+  cfg.beam_altitude_angles = read_vec<float>(f);
+  cfg.high_pass_fir = read_vec<double>(f);
+  cfg.low_pass_fir = read_vec<double>(f);
+  const auto offs = read_vec<int32_t>(f);
+  cfg.edgelet_patch_offsets.clear();
+  for (size_t i = 0; i + 1 < offs.size(); i += 2) cfg.edgelet_patch_offsets.emplace_back(offs[i], offs[i + 1]);
+  const auto TBL = read_vec<double>(f);
+  cfg.T_B_L = pose_from(TBL.data());
+  const auto bias = read_vec<double>(f);
+  std::vector<V3D> bias_directions;
+  for (size_t i = 0; i + 2 < bias.size(); i += 3) bias_directions.push_back({bias[i], bias[i + 1], bias[i + 2]});
+  try {
+    auto ctx = std::make_shared<Context>(0);
+    Photometric photo(ctx, cfg);
+    Values values;
+    std::printf("{\n");
+    for (int k = 0; k < 2; ++k) {
+      auto raw = read_vec<Point>(f);
+      auto desk = read_vec<Point>(f);
+      const auto ns = read_vec<uint32_t>(f);
+      const auto T = read_vec<double>(f);
+      const auto pose = read_vec<double>(f);
+      std::vector<std::pair<uint32_t, Pose3>> interp(ns.size());
+      for (size_t g = 0; g < ns.size(); ++g) interp[g] = {ns[g], pose_from(&T[12 * g])};
+      const Key X = static_cast<Key>(10 + k);
+      values.insert(X, pose_from(pose.data()));
+      photo.preprocess(raw, desk, interp, 0.1 * k, X);
+      double isum = 0;  // corrected intensities were written back into the deskewed cloud (photometric.cpp:307-314)
+      for (const Point & p : desk) isum += p.intensity;
+      std::printf("\"intensity_sum_%d\": %.17g,\n", k, isum);
+      NonlinearFactorGraph graph;
+      photo.getFactors(values, graph);  // frame 0: no features yet -> no factor (photometric.cpp:381)
+      std::printf("\"n_factors_%d\": %zu,\n", k, graph.factors.size());
+      if (!graph.factors.empty()) {
+        auto h = std::static_pointer_cast<HessianFactor>(graph.factors[0]->linearize(values));
+        dump("H", h->G11.data(), 36);
+        dump("g", h->g1.data(), 6);
+        std::printf("\"f\": %.17g,\n", h->f);
+        std::printf("\"status_hist\": [");
+        for (int i = 0; i < 9; ++i) std::printf("%d%s", photo.factor()->lastResult().status_hist[i], i < 8 ? ", " : "");
+        std::printf("],\n");
+        V3D tf, rf;
+        M33 et, er;
+        photo.factor()->getLocalizabilities(tf, rf, et, er);
+        dump("loc_trans_final", tf.data(), 3);
+        auto cl = graph.factors[0]->clone();  // ISAM2 clones factors
+        auto hc = std::static_pointer_cast<HessianFactor>(cl->linearize(values));
+        std::printf("\"clone_equal\": %d,\n", (hc->G11 == h->G11 && hc->g1 == h->g1 && hc->f == h->f) ? 1 : 0);
+        int valid = 0;
+        for (const auto s : photo.factor()->getStatuses()) valid += s == PhotometricFactor::RejectStatus::Valid;
+        std::printf("\"n_valid\": %d,\n", valid);
+      }
+      photo.updateMap(values, bias_directions);
+      const auto feats = photo.features();
+      std::printf("\"n_features_%d\": %zu,\n", k, feats.size());
+      double csum = 0;
+      for (const auto & ft : feats) csum += ft.center[0] + 1e-3 * ft.center[1] + ft.life_time;
+      std::printf("\"feature_sum_%d\": %.17g,\n", k, csum);
+    }
+    std::printf("\"ok\": 1\n}\n");
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "photo_pipeline: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

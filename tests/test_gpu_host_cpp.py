@@ -13,13 +13,13 @@ from parity import rel
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_exe():
+def build_exe(name="host_pipeline"):
     from mimosa_amd import build
     lib = build.build()
-    exe = os.path.join(os.path.dirname(lib), "host_pipeline")
-    src = os.path.join(ROOT, "tests", "cpp", "host_pipeline.cpp")
-    hdr = os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", "lidar.hpp")
-    if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lib)) > os.path.getmtime(exe):
+    exe = os.path.join(os.path.dirname(lib), name)
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    hdrs = [os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", h) for h in ("lidar.hpp", "photometric.hpp", "types.hpp")]
+    if not os.path.exists(exe) or max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(exe):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, src, "-o", exe,
                                "-L", os.path.dirname(lib), "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
     return exe
@@ -28,6 +28,7 @@ def build_exe():
 def test_host_layer_compiles():
     """CPU-runnable: the header-only host mirror builds warning-free against the C ABI."""
     assert os.path.exists(build_exe())
+    assert os.path.exists(build_exe("photo_pipeline"))
 
 
 def _pose12(R, t):
@@ -98,6 +99,8 @@ def test_host_pipeline_matches_oracle(tmp_path):
     assert gd["n_ds"] == got["first"]["n_ds"] and gd["status_hist"] == got["first"]["status_hist"]
     assert gd["H"] == got["first"]["H"] and gd["g"] == got["first"]["g"] and gd["f"] == got["first"]["f"]
     assert abs(got["corrected_ts"] - (100.0 + float(scan["t"].max()) * 1e-9)) < 1e-9
+    assert got["batch_equal"] == 1
+    assert got["map_points_after_device"] == got["map_points_after"]   # device-side updateMap ≡ host-cloud updateMap
     assert got["linearize_count"] == 2 and abs(got["clone_f"] - r1["f"]) <= 1e-5 * r1["f"]
     assert got["map_updated"] == 1 and got["map_updated_2"] == 0
     W = ref_cpu.transform_f32(Be, R_WB.astype(np.float32), t_WB.astype(np.float32))
@@ -110,3 +113,64 @@ def test_host_pipeline_matches_oracle(tmp_path):
     g = got["second"]
     assert g["status_hist"] == [int(v) for v in r2["status_hist"]]
     assert rel(np.array(g["H"]).reshape(6, 6), r2["H_ss"]) <= 1e-5 and abs(g["f"] - r2["f"]) <= 1e-5 * r2["f"]
+
+
+@pytest.mark.gpu
+def test_photometric_host_pipeline_matches_oracle(tmp_path):
+    """Photometric / PhotometricFactor of the C++ mirror through preprocess -> updateMap -> preprocess -> getFactors ->
+    linearize -> clone -> updateMap, against the oracle doing the same steps."""
+    from mimosa_amd import synth_photo as sp
+    from oracle import photo_ref
+
+    cfg = sp.photo_config(rows=64, cols=512)
+    frames = [sp.make_frame(cfg, k) for k in range(2)]
+    inp = tmp_path / "photo.bin"
+    with open(inp, "wb") as f:
+        def w(arr, dtype=None):
+            arr = np.ascontiguousarray(arr if dtype is None else np.asarray(arr, dtype))
+            f.write(struct.pack("<Q", len(arr) if arr.dtype.itemsize == 32 else arr.size))
+            f.write(arr.tobytes())
+        w([cfg["rows"], cfg["cols"], cfg["destagger"], cfg["erosion_buffer"], cfg["patch_size"], cfg["margin_size"], cfg["remove_lines"],
+           cfg["filter_brightness"], cfg["gaussian_blur"], cfg["gaussian_blur_size"], cfg["nma_radius"], cfg["num_features_detect"],
+           cfg["max_feature_life_time"], cfg["rotate_patch_to_align_with_gradient"], cfg["use_robust_cost_function"],
+           cfg["robust_cost_function"], cfg["brightness_window_size"][0], cfg["brightness_window_size"][1]], np.int32)
+        w([cfg["range_min"], cfg["range_max"], cfg["intensity_scale"], cfg["intensity_gamma"], cfg["gradient_threshold"],
+           cfg["max_dist_from_mean"], cfg["max_dist_from_plane"], cfg["occlusion_range_diff_threshold"],
+           cfg["lidar_origin_to_beam_origin_mm"], cfg["robust_cost_function_parameter"], cfg["error_scale"], cfg["max_error"],
+           cfg["sigma"]], np.float64)
+        w(cfg["pixel_shift_by_row"], np.int32)
+        w(cfg["beam_altitude_angles"], np.float32)
+        w(cfg["high_pass_fir"], np.float64)
+        w(cfg["low_pass_fir"], np.float64)
+        w(np.asarray(cfg["patch_offsets"], np.int32).ravel())
+        w(_pose12(cfg["T_B_L_R"], cfg["T_B_L_t"]))
+        w(np.asarray(sp.BIAS_DIRECTIONS, np.float64).ravel())
+        for fr in frames:
+            w(fr["raw"])
+            w(fr["deskewed"])
+            w(fr["unique_ns"].astype(np.uint32))
+            w(np.asarray(fr["T_Le_Lt"], np.float64).ravel())
+            w(_pose12(fr["R_W_Be"], fr["t_W_Be"]))
+    out = subprocess.run([build_exe("photo_pipeline"), str(inp)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout)
+
+    ref = photo_ref.Photo(cfg)
+    d0 = ref.preprocess(frames[0]["raw"], frames[0]["deskewed"], frames[0]["unique_ns"], frames[0]["T_Le_Lt"])
+    assert got["n_factors_0"] == 0 and abs(got["intensity_sum_0"] - float(d0["intensity"].astype(np.float64).sum())) < 1e-6
+    ref.update_map(None, frames[0]["R_W_Be"], frames[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    feats = ref.features()
+    assert got["n_features_0"] == len(feats) > 20
+    assert abs(got["feature_sum_0"] - sum(ft["center"][0] + 1e-3 * ft["center"][1] + ft["life_time"] for ft in feats)) < 1e-9
+    ref.preprocess(frames[1]["raw"], frames[1]["deskewed"], frames[1]["unique_ns"], frames[1]["T_Le_Lt"])
+    pf = ref.make_factor()
+    r = pf.linearize(frames[1]["R_W_Be"], frames[1]["t_W_Be"])
+    assert got["n_factors_1"] == 1 and got["status_hist"] == [int(v) for v in r["status_hist"]]
+    assert got["n_valid"] == int(r["status_hist"][8]) >= 10 and got["clone_equal"] == 1
+    assert rel(np.array(got["H"]).reshape(6, 6), np.asarray(r["H_bb"]).reshape(6, 6)) <= 1e-5
+    assert rel(np.array(got["g"]), -np.asarray(r["b_b"])) <= 1e-5 and abs(got["f"] - r["f"]) <= 1e-5 * abs(r["f"])
+    assert rel(got["loc_trans_final"], r["loc_trans_final"]) <= 1e-5
+    ref.update_map(pf, frames[1]["R_W_Be"], frames[1]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    feats = ref.features()
+    assert got["n_features_1"] == len(feats)
+    assert abs(got["feature_sum_1"] - sum(ft["center"][0] + 1e-3 * ft["center"][1] + ft["life_time"] for ft in feats)) < 1e-6

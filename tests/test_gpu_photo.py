@@ -144,7 +144,14 @@ def test_unary_factor_parity(ctx, frames):
     gr, rr = gf2.linearize(R, t), rf2.linearize(R, t)
     assert np.array_equal(gr["status_hist"], rr["status_hist"])
     assert rel(gr["H_bb"], rr["H_bb"]) <= 1e-5 and rel(gr["b_b"], rr["b_b"]) <= 1e-5
-    for f in (gf, gf2):
+    # clone() (ISAM2 clones factors): an independent factor on the same frame, same bits; survives its source
+    gc = gf2.clone()
+    assert np.array_equal(gc.state(rows=False)[0], gf2.state(rows=False)[0])
+    gf2.destroy()
+    g._pre_frame = None
+    gr2 = gc.linearize(R, t)
+    assert np.array_equal(gr2["H_bb"], gr["H_bb"]) and np.array_equal(gr2["b_b"], gr["b_b"]) and gr2["f"] == gr["f"]
+    for f in (gf, gc):
         f.destroy()
     g.destroy()
 
