@@ -51,6 +51,8 @@ def parse():
                          "(an event record costs ~4 us of stream time; 1 = every call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--shard-timeout", type=float, default=240.0,
+                    help="seconds the sharded leg may take before the line is printed without it")
     ap.add_argument("--shard-rooms", type=str, default="auto",
                     help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
                          "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
@@ -722,52 +724,75 @@ def main():
     # NEXT TO the replica figure (`value`); all ranks take part.
     sharded = None
     if dist is not None and (world > 1 or args.sharded) and args.shard_rooms != "none":
+        # The leg runs under a deadline in a worker thread: a failure or a stuck collective in it must not cost the
+        # job its JSON line (the replica figure above is complete at this point).
+        import threading
+        box = {}
+
+        def _sharded_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                from mimosa_amd import dist as mdist
+                sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else "4x5")
+                snx, sny = (int(v) for v in sr.lower().split("x"))
+                sctx = mdist.context_on_torch_stream(local_rank)
+                dev = torch.device("cuda", local_rank)
+                sh = mdist.ShardedICPDevice(dist.group.WORLD, sctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), dev)
+                t0s = time.time()
+                sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), leaf=cfgd["target_ivox_map_leaf_size"],
+                             min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
+                             lru_horizon=synth.ENWIDE_LRU_HORIZON)
+                build_s = time.time() - t0s
+                spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
+                sh.set_scan(np.array_split(spts, world)[rank])
+                first_s = sh.linearize(R, t)                                         # routes the points to their owners
+                ksh, wsh = max(20, args.steps // 4), 5
+                def _sh_steps(k):
+                    for _ in range(k):
+                        sctx.check(sctx.L.mh_icp_reset(sh.fh))
+                        sh.linearize(R, t)
+                _sh_steps(wsh)
+                dist.barrier()
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                _sh_steps(ksh)
+                dist.barrier()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - a
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+                nloc = torch.tensor([float(first_s["n_local"]), float(sh.map.stats()["n_points"])], dtype=torch.float64, device="cuda")
+                nmax = nloc.clone()
+                dist.all_reduce(nloc, op=dist.ReduceOp.SUM)
+                dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+                result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
+                                       f"(shard blocks of 8^3 voxels + one-voxel halo), cold linearize per step",
+                           "n_ranks": world, "backend": dist.get_backend(), "steps": ksh,
+                           "ms_per_linearize": round(el / ksh * 1e3, 4), "value": round(len(spts) * ksh / el / 1e6, 2), "unit": "Mpts/s",
+                           "scan_points_total": int(nloc[0].item()), "scan_points_max_per_rank": int(nmax[0].item()),
+                           "map_points_stored_total": int(nloc[1].item()), "map_points_max_per_rank": int(nmax[1].item()),
+                           "map_build_s": round(build_s, 2), "status_hist": [int(v) for v in first_s["status_hist"]],
+                           "collectives_per_linearize": "all_to_all(counts) + [all_to_all(records) when points change owner] + all_reduce(32 f64) + all_reduce(16 f64)",
+                           "note": "one scan is latency-bound when sharded (a few thousand points per rank and four collectives per linearize): "
+                                   "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode"}
+                sh.close()
+                box["result"] = result
+            except Exception as exc:  # noqa: BLE001 - reported in the line
+                box["error"] = f"{type(exc).__name__}: {exc}"
+
         import torch
-        from mimosa_amd import dist as mdist
-        sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else "4x5")
-        snx, sny = (int(v) for v in sr.lower().split("x"))
-        sctx = mdist.context_on_torch_stream(local_rank)
-        dev = torch.device("cuda", local_rank)
-        sh = mdist.ShardedICPDevice(dist.group.WORLD, sctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), dev)
-        t0s = time.time()
-        sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), leaf=cfgd["target_ivox_map_leaf_size"],
-                     min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
-                     lru_horizon=synth.ENWIDE_LRU_HORIZON)
-        build_s = time.time() - t0s
-        spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
-        sh.set_scan(np.array_split(spts, world)[rank])
-        first_s = sh.linearize(R, t)                                         # routes the points to their owners
-        ksh, wsh = max(20, args.steps // 4), 5
-        def _sh_steps(k):
-            for _ in range(k):
-                sctx.check(sctx.L.mh_icp_reset(sh.fh))
-                sh.linearize(R, t)
-        _sh_steps(wsh)
-        dist.barrier()
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        _sh_steps(ksh)
-        dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - a
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        nloc = torch.tensor([float(first_s["n_local"]), float(sh.map.stats()["n_points"])], dtype=torch.float64, device="cuda")
-        nmax = nloc.clone()
-        dist.all_reduce(nloc, op=dist.ReduceOp.SUM)
-        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-        sharded = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
-                               f"(shard blocks of 8^3 voxels + one-voxel halo), cold linearize per step",
-                   "n_ranks": world, "backend": dist.get_backend(), "steps": ksh,
-                   "ms_per_linearize": round(el / ksh * 1e3, 4), "value": round(len(spts) * ksh / el / 1e6, 2), "unit": "Mpts/s",
-                   "scan_points_total": int(nloc[0].item()), "scan_points_max_per_rank": int(nmax[0].item()),
-                   "map_points_stored_total": int(nloc[1].item()), "map_points_max_per_rank": int(nmax[1].item()),
-                   "map_build_s": round(build_s, 2), "status_hist": [int(v) for v in first_s["status_hist"]],
-                   "collectives_per_linearize": "all_to_all(counts) + [all_to_all(records) when points change owner] + all_reduce(32 f64) + all_reduce(16 f64)",
-                   "note": "one scan is latency-bound when sharded (a few thousand points per rank and four collectives per linearize): "
-                           "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode"}
-        sh.close()
+        th = threading.Thread(target=_sharded_leg, daemon=True)
+        th.start()
+        th.join(args.shard_timeout)
+        if th.is_alive():
+            sharded = {"error": f"no result within {args.shard_timeout} s (stuck collective?)", "n_ranks": world}
+            line["sharded"] = sharded
+            if rank == 0:
+                sys.stdout.flush()
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            os._exit(0)  # the worker may sit in a collective for ever: no clean-up is possible
+        sharded = box.get("result") or {"error": box.get("error", "unknown"), "n_ranks": world}
     line["sharded"] = sharded
 
     if rank == 0:

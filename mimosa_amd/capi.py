@@ -242,6 +242,8 @@ def load(build_if_missing: bool = True):
         if not build_if_missing:
             raise FileNotFoundError(path)
         _build.build()
+    # kernel-tuning experiments (tools/variant.sh) load a differently compiled build of the SAME library
+    path = os.environ.get("MH_LIB_OVERRIDE", path)
     L = C.CDLL(path)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     pvp = C.POINTER(C.c_void_p)

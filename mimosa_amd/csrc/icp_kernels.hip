@@ -29,6 +29,10 @@
 #include <hip/hip_runtime.h>
 
 #include "icp_device.hpp"
+
+#ifndef MH_PIPE
+#define MH_PIPE 4  // quads in flight per lane in the neighbour scan (knn_query)
+#endif
 #include "map_device.hpp"
 #include "math3.hpp"
 
@@ -452,7 +456,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // tightened bound prunes the voxels not entered yet (what matters for lanes whose centre voxel held
   // fewer than k points: their first bound is infinite).
   {
-    constexpr int kPipe = 4;
+    constexpr int kPipe = MH_PIPE;
     const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
     const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
     ScanCursor<NOFF> cur;
