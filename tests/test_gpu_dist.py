@@ -42,3 +42,25 @@ def test_sharded_layer_on_hip_backend_world2():
                 q.kill()
             raise
         assert p.returncode == 0 and f"OK {r}" in out, err[-2000:]
+
+
+def test_sharded_configs2_size_world2():
+    """BASELINE configs[2] at full size on the one GPU of the box: 131 072-pt scan vs the ~50 M-pt map sharded over two ranks
+    == the unsharded HIP factor on the full map."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker3.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        try:
+            out, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and f"OK {r}" in out, err[-2000:]
