@@ -87,6 +87,20 @@ hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, i
                                   int n_off, bool binary, hipStream_t stream);
 hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,
                                        hipStream_t stream);
+// Small windows (<= kBatchInline factors per launch): the argument blocks travel IN the kernel-argument segment — no
+// staging copy before the launch.  start[] = exclusive prefix of the per-factor grids.
+constexpr int kBatchInline = 8;
+template <typename A>
+struct BatchInline
+{
+  A a[kBatchInline];
+  int start[kBatchInline + 1];
+  int n;
+  char pad[256];  // load_uniform reads whole 256-byte chunks: keep the last block's read inside the segment
+};
+hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int tpb, int k, int n_off, bool binary,
+                                         hipStream_t stream);
+hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream);
 hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
                           int32_t * found, hipStream_t stream);
 

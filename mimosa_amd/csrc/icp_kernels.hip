@@ -1198,6 +1198,20 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_kernel(const IcpArgs 
   icp_linearize_body<K, BINARY, NOFF, TPB>(a, b - s0, s1 - s0);
 }
 
+// The same with the argument blocks inside the kernel-argument segment.  They are read through the segment pointer:
+// indexing the by-value parameter itself with a runtime index makes the compiler copy the whole struct to scratch.
+template <int K, bool BINARY, int NOFF, int TPB>
+__global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const BatchInline<IcpArgs> blk)
+{
+  (void)blk;
+  const auto * p = (const BatchInline<IcpArgs> *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = batch_factor_of(p->start, p->n, b);
+  const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
+  const IcpArgs a = load_uniform(p->a + f);
+  icp_linearize_body<K, BINARY, NOFF, TPB>(a, b - s0, s1 - s0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: component localizabilities (geometric_factor.hpp:434-457) + status histogram
 // (src/lidar/geometric.cpp:280-323).  Recomputes the unwhitened Jacobian directions from the cached
@@ -1312,6 +1326,18 @@ __global__ __launch_bounds__(TPB) void icp_localizability_batch_kernel(const Loc
   const int f = batch_factor_of(start, n_factors, b);
   const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
   const LocArgs a = load_uniform(args + f);
+  icp_localizability_body<TPB>(a, b - s0, s1 - s0);
+}
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
+{
+  (void)blk;
+  const auto * p = (const BatchInline<LocArgs> *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = batch_factor_of(p->start, p->n, b);
+  const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
+  const LocArgs a = load_uniform(p->a + f);
   icp_localizability_body<TPB>(a, b - s0, s1 - s0);
 }
 
@@ -1475,6 +1501,52 @@ hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_sta
   else
     hipLaunchKernelGGL(icp_localizability_batch_kernel<kThreads>, dim3(total_grid), dim3(kThreads), 0, stream, d_args, d_start,
                        n_factors);
+  return hipGetLastError();
+}
+
+template <int NOFF, int TPB>
+static void launch_linearize_batch_inline_nt(const BatchInline<IcpArgs> & blk, int total_grid, int k, bool binary, hipStream_t stream)
+{
+  const dim3 grid(total_grid), block(TPB);
+  if (k == 5) {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, true, NOFF, TPB>), grid, block, 0, stream, blk);
+    else
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, false, NOFF, TPB>), grid, block, 0, stream, blk);
+  } else {
+    if (binary)
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, true, NOFF, TPB>), grid, block, 0, stream, blk);
+    else
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, false, NOFF, TPB>), grid, block, 0, stream, blk);
+  }
+}
+
+hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int tpb, int k, int n_off, bool binary,
+                                         hipStream_t stream)
+{
+#define MH_BATCH_TPB(NOFF)                                                                       \
+  do {                                                                                           \
+    if (tpb == 256)                                                                              \
+      launch_linearize_batch_inline_nt<NOFF, 256>(blk, total_grid, k, binary, stream);           \
+    else                                                                                         \
+      launch_linearize_batch_inline_nt<NOFF, kThreads>(blk, total_grid, k, binary, stream);      \
+  } while (0)
+  if (n_off <= 7)
+    MH_BATCH_TPB(7);
+  else if (n_off == 19)
+    MH_BATCH_TPB(19);
+  else
+    MH_BATCH_TPB(27);
+#undef MH_BATCH_TPB
+  return hipGetLastError();
+}
+
+hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream)
+{
+  if (tpb == 256)
+    hipLaunchKernelGGL(icp_localizability_batch_inline_kernel<256>, dim3(total_grid), dim3(256), 0, stream, blk);
+  else
+    hipLaunchKernelGGL(icp_localizability_batch_inline_kernel<kThreads>, dim3(total_grid), dim3(kThreads), 0, stream, blk);
   return hipGetLastError();
 }
 

@@ -823,20 +823,43 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     group_grid[g] = acc;
   }
   if (group_grid[0] + group_grid[1] > 0) {
-    char * d = static_cast<char *>(ctx->d_batch);
-    MH_HIP(ctx, hipMemcpyAsync(d, ctx->h_batch, ab + lb + sb, hipMemcpyHostToDevice, ctx->stream));
     const int k = k5 ? 5 : 8;
-    for (int g = 0; g < 2; ++g) {
-      if (!group_grid[g]) continue;
-      const auto * da = reinterpret_cast<const mh::IcpArgs *>(d) + group_first[g];
-      const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
-      MH_HIP(ctx, mh::launch_linearize_batch(da, ds, group_n[g], group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
-    }
-    for (int g = 0; g < 2; ++g) {
-      if (!group_grid[g]) continue;
-      const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + group_first[g];
-      const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
-      MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, group_n[g], group_grid[g], group_tpb[g], ctx->stream));
+    const bool inline_args = group_n[0] <= mh::kBatchInline && group_n[1] <= mh::kBatchInline;
+    if (inline_args) {
+      // small window: the argument blocks ride in the kernel-argument segment, nothing is copied before the launches
+      for (int g = 0; g < 2; ++g) {
+        if (!group_grid[g]) continue;
+        mh::BatchInline<mh::IcpArgs> blk;
+        std::memset(&blk, 0, sizeof(blk));
+        for (int i = 0; i < group_n[g]; ++i) blk.a[i] = h_a[group_first[g] + i];
+        for (int i = 0; i <= group_n[g]; ++i) blk.start[i] = h_start[g][i];
+        blk.n = group_n[g];
+        MH_HIP(ctx, mh::launch_linearize_batch_inline(blk, group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
+      }
+      for (int g = 0; g < 2; ++g) {
+        if (!group_grid[g]) continue;
+        mh::BatchInline<mh::LocArgs> blk;
+        std::memset(&blk, 0, sizeof(blk));
+        for (int i = 0; i < group_n[g]; ++i) blk.a[i] = h_l[group_first[g] + i];
+        for (int i = 0; i <= group_n[g]; ++i) blk.start[i] = h_start[g][i];
+        blk.n = group_n[g];
+        MH_HIP(ctx, mh::launch_localizability_batch_inline(blk, group_grid[g], group_tpb[g], ctx->stream));
+      }
+    } else {
+      char * d = static_cast<char *>(ctx->d_batch);
+      MH_HIP(ctx, hipMemcpyAsync(d, ctx->h_batch, ab + lb + sb, hipMemcpyHostToDevice, ctx->stream));
+      for (int g = 0; g < 2; ++g) {
+        if (!group_grid[g]) continue;
+        const auto * da = reinterpret_cast<const mh::IcpArgs *>(d) + group_first[g];
+        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
+        MH_HIP(ctx, mh::launch_linearize_batch(da, ds, group_n[g], group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
+      }
+      for (int g = 0; g < 2; ++g) {
+        if (!group_grid[g]) continue;
+        const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + group_first[g];
+        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
+        MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, group_n[g], group_grid[g], group_tpb[g], ctx->stream));
+      }
     }
   }
   int rc_all = MH_OK;

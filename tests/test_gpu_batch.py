@@ -116,3 +116,24 @@ def test_batch_mixed_block_size(ctx, room_world):
     for f in fa + fb:
         f.destroy()
     gm.release()
+
+
+def test_batch_larger_than_the_inline_window(ctx, small_world):
+    """More than 8 factors: the argument blocks go through the staged device copy instead of the kernel-argument segment
+    (<= 8 is the other tests' path); both equal the separate calls bit for bit."""
+    from mimosa_amd import capi
+
+    n = 11
+    gm, fa, fb, fr, poses = _window(ctx, small_world, n)
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    got = capi.linearize_batch(fa, Rs, ts)
+    for i in range(n):
+        _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+    got8 = capi.linearize_batch(fa[:8], Rs[:8], ts[:8])          # exactly the inline capacity, re-linearization
+    for i in range(8):
+        _same(got8[i], fb[i].linearize(Rs[i], ts[i]))
+        fr[i].linearize(Rs[i], ts[i])                             # the oracle through the same call sequence: cold, then warm
+        assert_result_parity(got8[i], fr[i].linearize(Rs[i], ts[i]))
+    for f in fa + fb:
+        f.destroy()
+    gm.release()
