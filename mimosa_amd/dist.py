@@ -78,14 +78,19 @@ def _staged(dist, comm, t):
     return dist.get_backend(comm) == "gloo" and t.is_cuda
 
 
-def all_to_all_counts(dist, comm, send_counts, device):
+def exchange_counts(dist, comm, send_counts, device):
+    """All ranks' send-count vectors (world x world, row = sender).  Returns (recv_counts of this rank, total number of
+    records moving anywhere): the total is what decides whether the record exchange — a collective every rank must enter
+    or skip TOGETHER — runs at all; a rank's own row and column alone cannot tell (A idle while B sends to C)."""
     import torch
+    world, rank = dist.get_world_size(comm), dist.get_rank(comm)
     sc = torch.as_tensor(np.asarray(send_counts, np.int64))
-    rc = torch.empty_like(sc)
     if dist.get_backend(comm) != "gloo":
-        sc, rc = sc.to(device), rc.to(device)
-    dist.all_to_all_single(rc, sc, group=comm)
-    return rc.cpu().numpy()
+        sc = sc.to(device)
+    rows = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(rows, sc, group=comm)
+    m = torch.stack(rows).cpu().numpy()
+    return m[:, rank].copy(), int(m.sum())
 
 
 def all_to_all_rows(dist, comm, send, send_counts, recv_counts):
@@ -151,10 +156,10 @@ class ShardedICPDevice:
         p = capi._p
         sc = np.zeros(self.world, np.int64)
         self.ctx.check(L.mh_icp_shard_plan(self.fh, p(R), p(tv), None, None, self.world, self.rank, SHARD_BLOCK_LOG2, p(sc)))
-        rc = all_to_all_counts(self.dist, self.comm, sc, self.device)                                   # C0
+        rc, moving = exchange_counts(self.dist, self.comm, sc, self.device)                             # C0
         send = torch.empty((int(sc.sum()), RECORD_BYTES), dtype=torch.uint8, device=self.device)
         self.ctx.check(L.mh_icp_shard_pack(self.fh, C.c_void_p(send.data_ptr()) if len(send) else None))
-        if int(sc.sum()) or int(rc.sum()):
+        if moving:  # a global fact: every rank enters the record exchange or none does
             self._sync_for_torch()
             recv = all_to_all_rows(self.dist, self.comm, send, sc, rc)                                   # C1
             self._sync_from_torch()
@@ -257,7 +262,7 @@ class ShardedICP:
         go = own != self.rank
         order = np.argsort(own[go], kind="stable")
         sc = np.bincount(own[go], minlength=self.world).astype(np.int64)
-        rc = all_to_all_counts(self.dist, self.comm, sc, None)
+        rc, _ = exchange_counts(self.dist, self.comm, sc, None)
         packed = np.concatenate([r["pts"][go].view(np.uint8).reshape(-1, 32), r["status"][go].view(np.uint8).reshape(-1, 4),
                                  r["mean"][go].view(np.uint8).reshape(-1, 24), r["normal"][go].view(np.uint8).reshape(-1, 24),
                                  r["q_da"][go].view(np.uint8).reshape(-1, 24), r["origin"][go].view(np.uint8).reshape(-1, 8)], 1)[order]

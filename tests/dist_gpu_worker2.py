@@ -1,4 +1,4 @@
-"""Subprocess body of tests/test_gpu_dist.py::test_sharded_layer_on_hip_backend_world2: TWO ranks (gloo carries the
+"""Subprocess body of tests/test_gpu_dist.py::test_sharded_layer_on_hip_backend_multi_rank: WORLD_SIZE ranks (gloo carries the
 collectives: RCCL does not allow two ranks on one device and the test box has one GPU) both driving the HIP backend on
 cuda:0 with device-resident buffers.  Prints "OK <rank>" on success."""
 import os

@@ -23,44 +23,35 @@ def test_sharded_layer_on_hip_backend_world1():
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
 
 
-def test_sharded_layer_on_hip_backend_world2():
-    """Two ranks on the one GPU of the box (gloo collectives, HIP compute): sharded == unsharded oracle."""
+def _run_ranks(worker, world, timeout=600):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker2.py")], env=env,
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for r, p in enumerate(procs):
         try:
-            out, err = p.communicate(timeout=600)
+            out, err = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
         assert p.returncode == 0 and f"OK {r}" in out, err[-2000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_layer_on_hip_backend_multi_rank(world):
+    """Two / three ranks on the one GPU of the box (gloo collectives, HIP compute): sharded == unsharded oracle.  With three
+    ranks a pose step can leave one rank without anything to send or receive while the other two trade points: the record
+    exchange must still be entered (or skipped) by all of them together."""
+    _run_ranks("dist_gpu_worker2.py", world)
 
 
 def test_sharded_configs2_size_world2():
     """BASELINE configs[2] at full size on the one GPU of the box: 131 072-pt scan vs the ~50 M-pt map sharded over two ranks
     == the unsharded HIP factor on the full map."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker3.py")], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    for r, p in enumerate(procs):
-        try:
-            out, err = p.communicate(timeout=900)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0 and f"OK {r}" in out, err[-2000:]
+    _run_ranks("dist_gpu_worker3.py", 2, timeout=900)
