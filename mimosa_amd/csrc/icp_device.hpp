@@ -108,6 +108,9 @@ hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, d
 size_t order_temp_bytes(int n);
 hipError_t launch_spatial_order(const float4 * xyz_in, int n, float cell, uint32_t * keys2, uint32_t * vals, void * temp,
                                 size_t temp_bytes, uint32_t * perm, float4 * xyz_out, hipStream_t stream);
+size_t source_order_scratch_bytes(int n);
+hipError_t launch_source_order(const mh_point32 * d_pts, int n, float cell, void * scratch, uint32_t * perm, float4 * xyz_out,
+                               uint32_t * zero_a, int n_zero_a, uint32_t * zero_b, int n_zero_b, hipStream_t stream);
 hipError_t launch_unpermute_state(const uint32_t * perm, int n, const int32_t * st_in, const double * mean_in,
                                   const double * nrm_in, int32_t * st_out, double * mean_out, double * nrm_out,
                                   hipStream_t stream);

@@ -260,6 +260,7 @@ void mh_shutdown(mh_ctx * ctx)
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   const int dev = ctx->device;
   delete ctx;
   if (--AllocCache::contexts() <= 0) {  // the last context is gone: hand the cached device / pinned blocks back
@@ -345,54 +346,61 @@ static int icp_alloc(mh_icp * icp)
   return MH_OK;
 }
 
-// Source cloud (packed, Morton-ordered) and zeroed association state of a freshly allocated factor.  On any
-// failure the caller destroys the handle; the temporaries here are scoped.
+// Source cloud (packed, Morton-ordered) of a freshly allocated factor.  Everything is enqueued on the context stream;
+// the temporaries live in the context's stream-ordered scratch (no allocation, no free, no synchronisation per factor),
+// the only wait is for a HOST source buffer, which the caller owns.
 static int icp_init_source(mh_icp * icp, const mh_point32 * source, const mh_point32 * d_source)
 {
   mh_ctx * ctx = icp->ctx;
   const size_t n = icp->n;
-  // source cloud: upload the 32-byte records, pack xyz into the 16-byte layout the kernel reads
+  auto * zero_a = static_cast<uint32_t *>(icp->d_ticket.p);
+  auto * zero_b = static_cast<uint32_t *>(icp->d_result.p);
   if (n) {
-    DevTemp<mh_point32> d_pts;
-    if (!d_source) {
-      MH_HIP(ctx, d_pts.alloc(n * sizeof(mh_point32)));
-      MH_HIP(ctx, hipMemcpyAsync(d_pts, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+    const char * ns = std::getenv("MH_NO_SORT");  // MH_NO_SORT=1 keeps input order (diagnostics)
+    const bool order = !(ns && ns[0] == '1') && !icp->no_order;
+    const int ni = static_cast<int>(n);
+    const size_t up = d_source ? 0 : ((n * sizeof(mh_point32) + 255) & ~size_t(255));
+    const size_t need = up + (order ? mh::source_order_scratch_bytes(ni) : 0) + 256;
+    if (need > ctx->d_scratch_cap) {
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier users of the old block
+      if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+      ctx->d_scratch = nullptr;
+      ctx->d_scratch_cap = 0;
+      MH_HIP(ctx, hipMalloc(&ctx->d_scratch, need + need / 4));
+      ctx->d_scratch_cap = need + need / 4;
     }
-    MH_HIP(ctx, mh::launch_pack_xyz(d_source ? d_source : d_pts.p, static_cast<int>(n), static_cast<float4 *>(icp->d_src.p),
-                                    ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // Spatial (Morton) ordering of the copy: see order_kernels.hip.  MH_NO_SORT=1 keeps input order.
-    const char * ns = std::getenv("MH_NO_SORT");
-    if (!(ns && ns[0] == '1') && !icp->no_order) {
-      const int ni = static_cast<int>(n);
-      const size_t tb = mh::order_temp_bytes(ni);
-      DevTemp<float4> d_tmp_xyz;
-      DevTemp<uint32_t> d_keys, d_vals;
-      DevTemp<char> d_temp;
+    char * sc = static_cast<char *>(ctx->d_scratch);
+    const mh_point32 * d_pts = d_source;
+    if (!d_source) {
+      MH_HIP(ctx, hipMemcpyAsync(sc, source, n * sizeof(mh_point32), hipMemcpyHostToDevice, ctx->stream));
+      d_pts = reinterpret_cast<const mh_point32 *>(sc);
+    }
+    if (order) {  // spatial (Morton) ordering of the copy: see order_kernels.hip
       MH_HIP(ctx, icp->d_perm.reserve(n * sizeof(uint32_t), ctx->stream, false));
-      MH_HIP(ctx, d_tmp_xyz.alloc(n * sizeof(float4)));
-      MH_HIP(ctx, d_keys.alloc(2 * n * sizeof(uint32_t)));
-      MH_HIP(ctx, d_vals.alloc(n * sizeof(uint32_t)));
-      MH_HIP(ctx, d_temp.alloc(tb));
-      MH_HIP(ctx, hipMemcpyAsync(d_tmp_xyz, icp->d_src.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
       float cell = 0.25f;
       if (const char * cs = std::getenv("MH_SORT_CELL")) cell = static_cast<float>(std::atof(cs));
-      MH_HIP(ctx, mh::launch_spatial_order(d_tmp_xyz, ni, cell, d_keys, d_vals, d_temp.p, tb,
-                                           static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
-                                           ctx->stream));
-      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MH_HIP(ctx, mh::launch_source_order(d_pts, ni, cell, sc + up, static_cast<uint32_t *>(icp->d_perm.p), static_cast<float4 *>(icp->d_src.p),
+                                          zero_a, 2, zero_b, static_cast<int>(sizeof(mh::DeviceResult) / 4), ctx->stream));
       icp->ordered = true;
+    } else {
+      MH_HIP(ctx, mh::launch_pack_xyz(d_pts, ni, static_cast<float4 *>(icp->d_src.p), ctx->stream));
+      MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+      MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
     }
+  } else {
+    MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
   }
-  MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
-  // commonConstructor(): all per-point state zero (geometric_factor.hpp:144-156).  Materialised
-  // lazily by the first (cold) linearize; zero here so getters before any linearize read zeros.
-  MH_HIP(ctx, hipMemsetAsync(icp->d_qda.p, 0, icp->d_qda.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_mean.p, 0, icp->d_mean.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_normal.p, 0, icp->d_normal.cap, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(icp->d_status.p, 0, icp->d_status.cap, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // commonConstructor(): all per-point state zero (geometric_factor.hpp:144-156).  A cold factor's state is never read
+  // (the first linearize treats it as zero without touching memory, the getters answer zeros while `cold`); only a
+  // factor that receives foreign records before its first linearize (the sharded path, no_order) needs real zeros.
+  if (icp->no_order) {
+    MH_HIP(ctx, hipMemsetAsync(icp->d_qda.p, 0, icp->d_qda.cap, ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(icp->d_mean.p, 0, icp->d_mean.cap, ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(icp->d_normal.p, 0, icp->d_normal.cap, ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(icp->d_status.p, 0, icp->d_status.cap, ctx->stream));
+  }
+  if (!d_source) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host buffer may go away now
   return MH_OK;
 }
 
@@ -496,20 +504,20 @@ void mh_icp_destroy(mh_icp * icp)
   if (!icp) return;
   (void)hipSetDevice(icp->ctx->device);
   (void)hipStreamSynchronize(icp->ctx->stream);
-  icp->d_src.release();
-  icp->d_qda.release();
-  icp->d_mean.release();
-  icp->d_normal.release();
-  icp->d_status.release();
-  icp->d_partials.release();
-  icp->d_ticket.release();
-  icp->d_result.release();
-  icp->d_dbg.release();
-  icp->d_perm.release();
-  icp->d_eig.release();
+  icp->d_src.release(true);
+  icp->d_qda.release(true);
+  icp->d_mean.release(true);
+  icp->d_normal.release(true);
+  icp->d_status.release(true);
+  icp->d_partials.release(true);
+  icp->d_ticket.release(true);
+  icp->d_result.release(true);
+  icp->d_dbg.release(true);
+  icp->d_perm.release(true);
+  icp->d_eig.release(true);
   for (DevBuf * b : {&icp->d_origin, &icp->x_src, &icp->x_qda, &icp->x_mean, &icp->x_normal, &icp->x_status, &icp->x_origin, &icp->s_keys_a,
                      &icp->s_keys_b, &icp->s_idx_a, &icp->s_idx_b, &icp->s_counts, &icp->s_temp, &icp->d_sums})
-    b->release();
+    b->release(true);
   if (icp->h_counts) (void)hipHostFree(icp->h_counts);
   if (icp->h_results) AllocCache::free_pinned(icp->h_results, sizeof(mh::DeviceResult) * kMaxPending);
   if (icp->events_ready)
@@ -949,6 +957,12 @@ static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * 
   MH_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = icp->n;
   if (n == 0) return MH_OK;
+  if (icp->cold) {  // fresh factor / after mh_icp_reset: commonConstructor()'s zeros (geometric_factor.hpp:144-156)
+    if (status) std::memset(status, 0, n * sizeof(int32_t));
+    if (means) std::memset(means, 0, n * 3 * sizeof(double));
+    if (normals) std::memset(normals, 0, n * 3 * sizeof(double));
+    return MH_OK;
+  }
   const int32_t * d_st = static_cast<const int32_t *>(icp->d_status.p);
   const double * d_mean = static_cast<const double *>(icp->d_mean.p);
   const double * d_nrm = static_cast<const double *>(icp->d_normal.p);
@@ -1095,10 +1109,10 @@ void mh_scan_destroy(mh_scan * s)
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
-  s->d_full_raw.release();
+  s->d_full_raw.release(true);
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
                      &s->d_rt, &s->d_prep, &s->d_vox})
-    b->release();
+    b->release(true);
   AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters));
   delete s;
 }
@@ -1277,9 +1291,11 @@ static int mh_icp_create_from_scan_impl(mh_ctx * ctx, mh_map * map, const mh_sca
   if (!ctx || !map || !s || !cfg || !out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: NULL argument");
   if (!s->preprocessed) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: no mh_scan_preprocess_geometric before");
   if (s->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create_from_scan: scan lives on another device");
-  // the scan's stream has been synchronised by mh_scan_preprocess_geometric: its buffers are complete
-  return icp_create_common(ctx, map, nullptr, static_cast<const mh_point32 *>(s->d_ds.p), s->c.n_downsampled, cfg, is_binary,
-                           out);
+  // the scan's stream has been synchronised by mh_scan_preprocess_geometric: its buffers are complete.  The factor reads
+  // them asynchronously on ITS context's stream: stream order protects them when that is the scan's stream too
+  const int rc = icp_create_common(ctx, map, nullptr, static_cast<const mh_point32 *>(s->d_ds.p), s->c.n_downsampled, cfg, is_binary, out);
+  if (rc == MH_OK && s->ctx != ctx) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return rc;
 }
 int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
                             mh_icp ** out)

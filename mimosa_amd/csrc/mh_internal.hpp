@@ -37,6 +37,8 @@ struct mh_ctx
   size_t h_stage_cap = 0;
   void * h_batch = nullptr;  // pinned staging of mh_icp_linearize_batch's argument blocks
   void * d_batch = nullptr;  // ... and the device copy the batched kernels read
+  void * d_scratch = nullptr;  // stream-ordered scratch of factor creation (source ordering): reused, never freed per call
+  size_t d_scratch_cap = 0;
 };
 
 inline int fail(const mh_ctx * ctx, int code, const std::string & msg)
@@ -102,7 +104,9 @@ public:
     }
     return e;
   }
-  static void free(void * p)
+  // drained: the caller has already waited for every stream that ever touched the block (a factor's or a scan's own
+  // buffers after a synchronisation of their context's stream): no device-wide drain is needed before reuse
+  static void free(void * p, bool drained = false)
   {
     if (!p) return;
     Block b{0, 0};
@@ -117,11 +121,13 @@ public:
     if (b.cls) {
       // in-flight work may still read / write the block: drain ITS device before it can be handed out again — outside
       // the lock, on the device the block was allocated on (not whatever device is current at free time)
-      int cur = 0;
-      (void)hipGetDevice(&cur);
-      if (cur != b.dev) (void)hipSetDevice(b.dev);
-      (void)hipDeviceSynchronize();
-      if (cur != b.dev) (void)hipSetDevice(cur);
+      if (!drained) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != b.dev) (void)hipSetDevice(b.dev);
+        (void)hipDeviceSynchronize();
+        if (cur != b.dev) (void)hipSetDevice(cur);
+      }
       std::lock_guard<std::mutex> g(mu());
       if (cached_bytes()[b.dev] + b.cls <= kMaxCachedBytes) {
         free_list()[key(b.dev, b.cls)].push_back(p);
@@ -276,9 +282,9 @@ struct DevBuf
     cap = ncap;
     return hipSuccess;
   }
-  void release()
+  void release(bool drained = false)
   {
-    if (p) AllocCache::free(p);
+    if (p) AllocCache::free(p, drained);
     p = nullptr;
     cap = 0;
   }

@@ -44,6 +44,25 @@ __global__ __launch_bounds__(kThreads) void morton_keys_kernel(const float4 * xy
   }
 }
 
+// the same from the 32-byte point records (two float4 each): packs xyz on the way
+__global__ __launch_bounds__(kThreads) void pack_morton_kernel(const float4 * pts2, int n, float inv_cell, float4 * xyz, uint32_t * keys,
+                                                               uint32_t * vals, uint32_t * zero_a, int n_zero_a, uint32_t * zero_b, int n_zero_b)
+{
+  if (blockIdx.x == 0) {  // the factor's ticket / result block start at zero
+    for (int i = threadIdx.x; i < n_zero_a; i += kThreads) zero_a[i] = 0u;
+    for (int i = threadIdx.x; i < n_zero_b; i += kThreads) zero_b[i] = 0u;
+  }
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const float4 p = pts2[2 * i];
+    xyz[i] = p;
+    const int qx = min(1023, max(0, static_cast<int>(floorf(p.x * inv_cell)) + 512));
+    const int qy = min(1023, max(0, static_cast<int>(floorf(p.y * inv_cell)) + 512));
+    const int qz = min(1023, max(0, static_cast<int>(floorf(p.z * inv_cell)) + 512));
+    keys[i] = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
+    vals[i] = static_cast<uint32_t>(i);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void gather_xyz_kernel(const float4 * in, const uint32_t * perm, int n, float4 * out)
 {
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) out[i] = in[perm[i]];
@@ -92,6 +111,31 @@ hipError_t launch_spatial_order(const float4 * xyz_in, int n, float cell, uint32
                                            stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(gather_xyz_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, xyz_in, perm, n, xyz_out);
+  return hipGetLastError();
+}
+
+// Factor creation: d_pts (n 32-byte records, device) -> perm (sorted position -> original index) and xyz_out (packed,
+// sorted).  scratch: source_order_scratch_bytes(n) bytes, stream-ordered.  zero_a / zero_b: dword ranges cleared on the way.
+size_t source_order_scratch_bytes(int n)
+{
+  const size_t m = static_cast<size_t>(n);
+  return ((m * sizeof(float4) + 255) & ~size_t(255)) + ((3 * m * sizeof(uint32_t) + 255) & ~size_t(255)) + order_temp_bytes(n) + 256;
+}
+hipError_t launch_source_order(const mh_point32 * d_pts, int n, float cell, void * scratch, uint32_t * perm, float4 * xyz_out,
+                               uint32_t * zero_a, int n_zero_a, uint32_t * zero_b, int n_zero_b, hipStream_t stream)
+{
+  const size_t m = static_cast<size_t>(n);
+  char * sc = static_cast<char *>(scratch);
+  float4 * xyz_tmp = reinterpret_cast<float4 *>(sc);
+  sc += (m * sizeof(float4) + 255) & ~size_t(255);
+  uint32_t * keys2 = reinterpret_cast<uint32_t *>(sc), * vals = keys2 + 2 * m;
+  sc += (3 * m * sizeof(uint32_t) + 255) & ~size_t(255);
+  size_t tb = order_temp_bytes(n);
+  hipLaunchKernelGGL(pack_morton_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, reinterpret_cast<const float4 *>(d_pts), n,
+                     1.0f / cell, xyz_tmp, keys2, vals, zero_a, n_zero_a, zero_b, n_zero_b);
+  hipError_t e = rocprim::radix_sort_pairs(sc, tb, keys2, keys2 + m, vals, perm, m, 0, 30, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gather_xyz_kernel, dim3(grid_for(n)), dim3(kThreads), 0, stream, xyz_tmp, perm, n, xyz_out);
   return hipGetLastError();
 }
 
