@@ -75,5 +75,18 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     return lib
 
 
+def build_replay_native(force: bool = False) -> str:
+    """The native sequence-replay driver (host/replay_main.cpp over the header-only host mirror): plain g++, links the library."""
+    lib = build()
+    exe = os.path.join(LIBDIR, "replay_native")
+    host = os.path.join(HERE, "host")
+    src = os.path.join(host, "replay_main.cpp")
+    deps = [src, lib] + [os.path.join(host, "mimosa_hip", h) for h in ("replay.hpp", "binio.hpp", "photometric.hpp", "lidar.hpp", "types.hpp")]
+    if force or _stale(exe, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, src, "-o", exe,
+                               "-L", LIBDIR, "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

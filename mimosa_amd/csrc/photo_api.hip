@@ -66,7 +66,7 @@ struct mh_photo
   mh::PhotoModel model{};
   DevBuf d_alt, d_shift, d_hp, d_lp, d_static;
   // per-frame scratch
-  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz;
+  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather;
   mh::PhotoCounters * h_counters = nullptr;  // pinned, mapped
   mh::PhotoCounters * d_counters = nullptr;
   float * h_int_out = nullptr;  // pinned staging of the corrected intensities
@@ -99,7 +99,7 @@ void photo_release(mh_photo * p)
   (void)hipStreamSynchronize(p->ctx->stream);
   frame_release(p->frame);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
-                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz})
+                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather})
     b->release();
   if (p->h_counters) (void)hipHostFree(p->h_counters);
   if (p->h_int_out) (void)hipHostFree(p->h_int_out);
@@ -350,50 +350,73 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
                                     static_cast<uint8_t *>(ph->d_grad.p), npx, ctx->stream));
   MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(fr->d_mask.p), nullptr, c.margin_size, static_cast<uint8_t *>(ph->d_detmask.p),
                                      rows, cols, c.patch_size + c.erosion_buffer, ctx->stream));
-  std::vector<uint8_t> grad(npx), mask(npx);
-  std::vector<float> I(npx);
-  std::vector<int32_t> idx(npx);
-  std::vector<mh_point32> pts(fr->n_points);
-  MH_HIP(ctx, hipMemcpyAsync(grad.data(), ph->d_grad.p, npx, hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(mask.data(), ph->d_detmask.p, npx, hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(I.data(), fr->d_intensity.p, static_cast<size_t>(npx) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(idx.data(), fr->d_idx.p, static_cast<size_t>(npx) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (fr->n_points)
-    MH_HIP(ctx, hipMemcpyAsync(pts.data(), fr->d_points.p, fr->n_points * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
+  // candidate pixels (mask != 0, gradient > threshold) compacted on the device in row-major order: ~100 KB come back
+  // instead of the gradient / mask / intensity / index planes and the cloud (5.3 MB)
+  const int n_blk = (npx + 255) / 256;
+  MH_HIP(ctx, ph->d_cand.reserve((static_cast<size_t>(npx) + n_blk + 4) * sizeof(uint32_t), ctx->stream, false));
+  uint32_t * d_list = static_cast<uint32_t *>(ph->d_cand.p), * d_blk = d_list + npx, * d_n = d_blk + n_blk;
+  MH_HIP(ctx, mh::launch_photo_candidates(static_cast<const uint8_t *>(ph->d_grad.p), static_cast<const uint8_t *>(ph->d_detmask.p), npx,
+                                          c.gradient_threshold, d_blk, d_list, d_n, ctx->stream));
+  uint32_t n_list = 0;
+  MH_HIP(ctx, hipMemcpyAsync(&n_list, d_n, sizeof(n_list), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-
+  std::vector<uint32_t> gradients(n_list);
+  if (n_list) {
+    MH_HIP(ctx, hipMemcpyAsync(gradients.data(), d_list, n_list * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // the detection mask is only ever asked about candidate pixels (set by construction): `alive` carries the circles
+  std::vector<uint8_t> alive(static_cast<size_t>(npx), 1);
   for (const HostFeature & ft : ph->features)  // :526-530
-    fill_circle_zero(mask, rows, cols, static_cast<int>(ft.hdr.center[0]), static_cast<int>(ft.hdr.center[1]), c.nma_radius);
-  struct Cand
-  {
-    double g;
-    int u, v;
-  };
-  std::vector<Cand> gradients;
-  gradients.reserve(static_cast<size_t>(npx));
-  for (int v = 0; v < rows; ++v)
-    for (int u = 0; u < cols; ++u) {
-      const size_t px = static_cast<size_t>(v) * cols + u;
-      if (!mask[px]) continue;
-      if (grad[px] > c.gradient_threshold) gradients.push_back({static_cast<double>(grad[px]), u, v});
-    }
-  // :556-560 — std::sort with a comparator on the gradient only: the order of equal gradients is libstdc++'s
-  std::sort(gradients.begin(), gradients.end(), [](const Cand & a, const Cand & b) { return a.g > b.g; });
+    fill_circle_zero(alive, rows, cols, static_cast<int>(ft.hdr.center[0]), static_cast<int>(ft.hdr.center[1]), c.nma_radius);
+  // the reference zeroes the circles in the mask BEFORE it collects the candidates (:526-555): the sequence handed to
+  // std::sort must be exactly that one
+  gradients.erase(std::remove_if(gradients.begin(), gradients.end(), [&](uint32_t g) { return !alive[static_cast<size_t>(g & 0xFFFFFFu)]; }),
+                  gradients.end());
+  // :556-560 — std::sort with a comparator on the gradient only: the order of equal gradients is libstdc++'s (it depends
+  // on the sequence of comparison outcomes alone, so sorting the packed words moves them exactly like the reference's pairs)
+  std::sort(gradients.begin(), gradients.end(), [](uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); });
   std::vector<std::pair<int, int>> cand;
-  for (const Cand & g : gradients) {  // :565-571 non-maximum suppression
-    if (!mask[static_cast<size_t>(g.v) * cols + g.u]) continue;
-    cand.emplace_back(g.u, g.v);
-    fill_circle_zero(mask, rows, cols, g.u, g.v, c.nma_radius);
+  for (const uint32_t g : gradients) {  // :565-571 non-maximum suppression
+    const int px = static_cast<int>(g & 0xFFFFFFu);
+    if (!alive[static_cast<size_t>(px)]) continue;
+    cand.emplace_back(px % cols, px / cols);
+    fill_circle_zero(alive, rows, cols, px % cols, px / cols, c.nma_radius);
+  }
+  // what the selection below reads, gathered on the device for the surviving candidates only
+  const int m_off = c.n_patch_offsets, n_cand = static_cast<int>(cand.size()), per = m_off + 1;
+  std::vector<float> win(static_cast<size_t>(n_cand) * 49);
+  std::vector<float> rec(static_cast<size_t>(n_cand) * per * 4);
+  std::vector<int32_t> rec_idx(static_cast<size_t>(n_cand) * per);
+  if (n_cand) {
+    std::vector<int32_t> uv(2 * static_cast<size_t>(m_off + n_cand));
+    std::memcpy(uv.data(), ph->offsets.data(), 2 * static_cast<size_t>(m_off) * sizeof(int32_t));
+    for (int i = 0; i < n_cand; ++i) {
+      uv[2 * (m_off + i)] = cand[i].first;
+      uv[2 * (m_off + i) + 1] = cand[i].second;
+    }
+    const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (win.size() * 4 + 255) & ~size_t(255), b_rec = (rec.size() * 4 + 255) & ~size_t(255);
+    MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_win + b_rec + rec_idx.size() * 4 + 256, ctx->stream, false));
+    char * d = static_cast<char *>(ph->d_gather.p);
+    MH_HIP(ctx, hipMemcpyAsync(d, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_cand, static_cast<const float *>(fr->d_intensity.p),
+                                        static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
+                                        reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
+                                        reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(win.data(), d + b_uv, win.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(rec.data(), d + b_uv + b_win, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(rec_idx.data(), d + b_uv + b_win + b_rec, rec_idx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   // :575-625 scores of every candidate along every bias direction
   std::vector<std::vector<std::pair<double, int>>> scores(n_dirs, std::vector<std::pair<double, int>>(cand.size(), {0.0, 0}));
   for (size_t i = 0; i < cand.size(); ++i) {
     float ix, iy;
-    patch_gradient_direction(I.data(), cols, cand[i].first, cand[i].second, ix, iy);
-    const int pidx = idx[static_cast<size_t>(cand[i].second) * cols + cand[i].first];
-    if (pidx < 0) continue;
+    patch_gradient_direction(&win[i * 49], 7, 3, 3, ix, iy);
+    const size_t ctr = i * per + m_off;
+    if (rec_idx[ctr] < 0) continue;
     double P[6];
-    projection_jacobian(ph->model, pts[pidx].x, pts[pidx].y, pts[pidx].z, P);
+    projection_jacobian(ph->model, rec[4 * ctr], rec[4 * ctr + 1], rec[4 * ctr + 2], P);
     for (size_t b = 0; b < n_dirs; ++b) {
       const double * d = bias + 3 * b;
       double w0 = P[0] * d[0] + P[1] * d[1] + P[2] * d[2], w1 = P[3] * d[0] + P[4] * d[1] + P[5] * d[2];
@@ -432,17 +455,16 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     ft.hdr.n_points = m;
     bool missing = false;
     for (int o = 0; o < m; ++o) {
-      const int u = lx + ph->offsets[2 * o], v = ly + ph->offsets[2 * o + 1];
-      const int pi = (u >= 0 && u < cols && v >= 0 && v < rows) ? idx[static_cast<size_t>(v) * cols + u] : -1;
-      if (pi < 0) {  // the reference indexes the cloud with -1 here (undefined behaviour); the eroded mask makes it unreachable
+      const size_t at = static_cast<size_t>(k) * per + o;  // pixel (lx, ly) + patch offset o
+      if (rec_idx[at] < 0) {  // the reference indexes the cloud with -1 here (undefined behaviour); the eroded mask makes it unreachable
         missing = true;
         break;
       }
-      const double q[3] = {pts[pi].x, pts[pi].y, pts[pi].z};
+      const double q[3] = {rec[4 * at], rec[4 * at + 1], rec[4 * at + 2]};
       double w[3];
       pose_act(T_map, q, w);
       ft.Le_ps.insert(ft.Le_ps.end(), {w[0], w[1], w[2]});
-      ft.intensities.push_back(I[static_cast<size_t>(v) * cols + u]);
+      ft.intensities.push_back(rec[4 * at + 3]);
     }
     if (missing) continue;
     double mean[3] = {0, 0, 0};

@@ -715,6 +715,80 @@ __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// detectFeatures' candidate list (photometric.cpp:541-555): the pixels with mask != 0 and gradient > threshold, in
+// row-major order (the order the reference pushes them in, which decides how std::sort arranges equal gradients).
+// Two-kernel order-preserving compaction: per-block counts, then block prefix + in-block scan.  Entry = px | grad << 24.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_candidate(const uint8_t * grad, const uint8_t * mask, int px, float thr)
+{
+  return mask[px] != 0 && static_cast<float>(grad[px]) > thr;
+}
+__global__ __launch_bounds__(kT) void photo_cand_count_kernel(const uint8_t * grad, const uint8_t * mask, int npx, float thr, uint32_t * blk)
+{
+  const int px = blockIdx.x * kT + threadIdx.x;
+  const bool c = px < npx && is_candidate(grad, mask, px, thr);
+  const int n = __syncthreads_count(c ? 1 : 0);
+  if (threadIdx.x == 0) blk[blockIdx.x] = static_cast<uint32_t>(n);
+}
+__global__ __launch_bounds__(kT) void photo_cand_scatter_kernel(const uint8_t * grad, const uint8_t * mask, int npx, float thr,
+                                                                 const uint32_t * blk, uint32_t * out, uint32_t * n_out)
+{
+  __shared__ uint32_t s_w[kT / 64], s_off;
+  uint32_t off = 0;
+  for (int i = threadIdx.x; i < static_cast<int>(blockIdx.x); i += kT) off += blk[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) off += __shfl_xor(off, d);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = off;
+  __syncthreads();
+  if (threadIdx.x == 0) s_off = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  const int px = blockIdx.x * kT + threadIdx.x;
+  const bool c = px < npx && is_candidate(grad, mask, px, thr);
+  const uint64_t m = __ballot(c);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_w[wave] = static_cast<uint32_t>(__popcll(m));
+  __syncthreads();
+  uint32_t before = s_off;
+  for (uint32_t w = 0; w < wave; ++w) before += s_w[w];
+  if (c) out[before + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = static_cast<uint32_t>(px) | (static_cast<uint32_t>(grad[px]) << 24);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = s_off + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// What the host-side selection needs of each candidate that survived the non-maximum suppression: the 7 x 7 intensity
+// window around it (cornerEigenValsAndVecs, O11), and for the patch pixels + the centre: point index, point, intensity.
+// uv: n_off patch offsets, then n_cand candidate centres.  One block per candidate.
+__global__ __launch_bounds__(128) void photo_gather_kernel(const int2 * uv, int n_off, int n_cand, const float * I, const int32_t * idx,
+                                                           const mh_point32 * pts, int rows, int cols, float * win49, float4 * rec, int32_t * rec_idx)
+{
+  const int c = blockIdx.x;
+  if (c >= n_cand) return;
+  const int2 ctr = uv[n_off + c];
+  const int t = threadIdx.x;
+  if (t < 49) {
+    const int u = min(max(ctr.x + (t % 7) - 3, 0), cols - 1), v = min(max(ctr.y + (t / 7) - 3, 0), rows - 1);
+    win49[static_cast<size_t>(c) * 49 + t] = I[static_cast<size_t>(v) * cols + u];
+  }
+  if (t <= n_off) {
+    const int u = ctr.x + (t < n_off ? uv[t].x : 0), v = ctr.y + (t < n_off ? uv[t].y : 0);
+    int32_t pi = -1;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u >= 0 && u < cols && v >= 0 && v < rows) {
+      pi = idx[static_cast<size_t>(v) * cols + u];
+      r.w = I[static_cast<size_t>(v) * cols + u];
+      if (pi >= 0) {
+        const mh_point32 p = pts[pi];
+        r.x = p.x;
+        r.y = p.y;
+        r.z = p.z;
+      }
+    }
+    rec[static_cast<size_t>(c) * (n_off + 1) + t] = r;
+    rec_idx[static_cast<size_t>(c) * (n_off + 1) + t] = pi;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -801,6 +875,21 @@ hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, i
 hipError_t launch_photo_grad(const float * dx, const float * dy, uint8_t * grad, int n, hipStream_t stream)
 {
   hipLaunchKernelGGL(photo_grad_kernel, g1(n), dim3(kT), 0, stream, dx, dy, grad, n);
+  return hipGetLastError();
+}
+hipError_t launch_photo_candidates(const uint8_t * grad, const uint8_t * mask, int npx, float thr, uint32_t * blk, uint32_t * out,
+                                   uint32_t * n_out, hipStream_t stream)
+{
+  const dim3 g((npx + kT - 1) / kT);
+  hipLaunchKernelGGL(photo_cand_count_kernel, g, dim3(kT), 0, stream, grad, mask, npx, thr, blk);
+  hipLaunchKernelGGL(photo_cand_scatter_kernel, g, dim3(kT), 0, stream, grad, mask, npx, thr, blk, out, n_out);
+  return hipGetLastError();
+}
+hipError_t launch_photo_gather(const int2 * uv, int n_off, int n_cand, const float * I, const int32_t * idx, const mh_point32 * pts, int rows,
+                               int cols, float * win49, float4 * rec, int32_t * rec_idx, hipStream_t stream)
+{
+  if (n_cand <= 0) return hipSuccess;
+  hipLaunchKernelGGL(photo_gather_kernel, dim3(n_cand), dim3(128), 0, stream, uv, n_off, n_cand, I, idx, pts, rows, cols, win49, rec, rec_idx);
   return hipGetLastError();
 }
 hipError_t launch_photo_linearize(const PhotoLinArgs & a, hipStream_t stream)

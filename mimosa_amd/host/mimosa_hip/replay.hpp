@@ -1,0 +1,402 @@
+// Sequence replay on the host mirror (SURVEY.md §8 "next" row f-4, BASELINE configs[4]): the native counterpart of
+// mimosa_amd/replay.py — same loop, same arithmetic, no Python between the library calls.
+//
+// Per scan, in the reference's LiDAR call order (src/lidar/manager.cpp:45-147):
+//   prepareInput -> IMU propagation over the distinct timestamps (manager.cpp:455-499) -> deskewPoints ->
+//   Photometric::preprocess -> Geometric::preprocess -> ICPFactor / PhotometricFactor ctors -> smoother update with
+//   EVERY live ICPFactor re-linearized per iteration (src/graph/manager.cpp:585-588; here ONE mh_icp_linearize_batch call)
+//   -> Geometric::updateMap (keyframe test geometric.cpp:445-478, copy-then-insert on the device) + Photometric::updateMap.
+// What stands in for GTSAM / ISAM2 (out of scope): a dense Gauss-Newton over the `window` most recent poses — unary ICP
+// Hessian factors, the photometric factor on the newest pose, between factors from the IMU propagation, a prior on the
+// oldest pose.  Retraction T <- T Exp(xi), xi = (omega, v): the perturbation the reference's Jacobians are taken against
+// (geometric_factor.hpp:341-355, photometric_factor.hpp:262-279).
+#pragma once
+
+#include <chrono>
+#include <deque>
+
+#include "photometric.hpp"
+
+namespace mimosa_hip
+{
+namespace replay
+{
+using lidar::ICPFactor;
+using lidar::IncrementalVoxelMapPCL;
+using lidar::Photometric;
+using lidar::PhotometricFactor;
+using lidar::ScanFrontEnd;
+
+inline M33 matmul(const M33 & a, const M33 & b)
+{
+  M33 c{};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  return c;
+}
+inline M33 transpose(const M33 & a) { return {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; }
+inline V3D matvec(const M33 & a, const V3D & v)
+{
+  return {a[0] * v[0] + a[1] * v[1] + a[2] * v[2], a[3] * v[0] + a[4] * v[1] + a[5] * v[2], a[6] * v[0] + a[7] * v[1] + a[8] * v[2]};
+}
+inline M33 hat(const V3D & v) { return {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}; }
+inline V3D so3Log(const M33 & R)
+{
+  double c = (R[0] + R[4] + R[8] - 1.0) / 2.0;
+  c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+  const double th = std::acos(c);
+  const double s = th < 1e-9 ? 0.5 : th / (2.0 * std::sin(th));
+  return {(R[7] - R[5]) * s, (R[2] - R[6]) * s, (R[3] - R[1]) * s};
+}
+// T <- T * Exp(xi), first order in the translation
+inline void retract(Pose3 & T, const double * xi)
+{
+  const V3D d = matvec(T.R, {xi[3], xi[4], xi[5]});
+  T.R = matmul(T.R, lidar::so3Expmap({xi[0], xi[1], xi[2]}));
+  for (int i = 0; i < 3; ++i) T.t[i] += d[i];
+}
+inline Pose3 between(const Pose3 & a, const Pose3 & b)
+{
+  Pose3 r;
+  const M33 Rt = transpose(a.R);
+  r.R = matmul(Rt, b.R);
+  r.t = matvec(Rt, {b.t[0] - a.t[0], b.t[1] - a.t[1], b.t[2] - a.t[2]});
+  return r;
+}
+// Ad(R, t) in (rotation, translation) tangent order
+inline M66 adjoint(const M33 & R, const V3D & t)
+{
+  M66 A{};
+  const M33 hR = matmul(hat(t), R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      A[6 * i + j] = R[3 * i + j];
+      A[6 * (3 + i) + 3 + j] = R[3 * i + j];
+      A[6 * (3 + i) + j] = hR[3 * i + j];
+    }
+  return A;
+}
+// A x = b, Gaussian elimination with partial pivoting (what LAPACK's gesv does); A is n x n row-major, overwritten
+inline std::vector<double> solve(std::vector<double> A, std::vector<double> b)
+{
+  const size_t n = b.size();
+  for (size_t c = 0; c < n; ++c) {
+    size_t piv = c;
+    for (size_t r = c + 1; r < n; ++r)
+      if (std::fabs(A[r * n + c]) > std::fabs(A[piv * n + c])) piv = r;
+    if (A[piv * n + c] == 0.0) throw std::runtime_error("replay::solve: singular system");
+    if (piv != c) {
+      for (size_t j = 0; j < n; ++j) std::swap(A[c * n + j], A[piv * n + j]);
+      std::swap(b[c], b[piv]);
+    }
+    for (size_t r = c + 1; r < n; ++r) {
+      const double f = A[r * n + c] / A[c * n + c];
+      if (f == 0.0) continue;
+      for (size_t j = c; j < n; ++j) A[r * n + j] -= f * A[c * n + j];
+      b[r] -= f * b[c];
+    }
+  }
+  for (size_t i = n; i-- > 0;) {
+    double s = b[i];
+    for (size_t j = i + 1; j < n; ++j) s -= A[i * n + j] * b[j];
+    b[i] = s / A[i * n + i];
+  }
+  return b;
+}
+
+struct ImuSamples
+{
+  std::vector<double> ts;
+  std::vector<V3D> gyro, acc;
+};
+struct State
+{
+  Pose3 T;
+  V3D vel{0, 0, 0};
+};
+
+// Manager::deskewPoints' host part (src/lidar/manager.cpp:455-499): states at the IMU sample times by integrating sample
+// to sample, then constant-acc / omega extrapolation to every distinct timestamp.  `s0` = state at the first sample.
+// Returns T_W_Bt per timestamp; `last` = state at the last sample.
+inline std::vector<Pose3> propagate(const State & s0, const ImuSamples & imu, const double header_ts, const std::vector<uint32_t> & unique_ns,
+                                    const V3D & gravity, State & last)
+{
+  const size_t m = imu.ts.size();
+  if (m < 2) throw std::runtime_error("Preintegration not possible as there are less than 2 measurements P1");  // :442-446
+  std::vector<State> st(m);
+  st[0] = s0;
+  for (size_t c = 0; c + 1 < m; ++c) {
+    const double d = imu.ts[c + 1] - imu.ts[c];
+    const V3D Ra = matvec(st[c].T.R, imu.acc[c]);
+    const V3D aw{Ra[0] + gravity[0], Ra[1] + gravity[1], Ra[2] + gravity[2]};
+    st[c + 1].T.R = matmul(st[c].T.R, lidar::so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d}));
+    for (int i = 0; i < 3; ++i) {
+      st[c + 1].T.t[i] = st[c].T.t[i] + st[c].vel[i] * d + 0.5 * aw[i] * d * d;
+      st[c + 1].vel[i] = st[c].vel[i] + aw[i] * d;
+    }
+  }
+  std::vector<Pose3> out(unique_ns.size());
+  size_t c = 0;
+  for (size_t u = 0; u < unique_ns.size(); ++u) {
+    const double tq = header_ts + unique_ns[u] * 1.0e-9;
+    while (c + 2 < m && imu.ts[c + 1] < tq) ++c;  // interval with ts[c] < tq <= ts[c + 1] (:470-476)
+    const double d = tq - imu.ts[c];
+    const M33 E = lidar::so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d});
+    out[u].R = matmul(st[c].T.R, E);
+    const V3D Ra = matvec(st[c].T.R, imu.acc[c]);
+    for (int i = 0; i < 3; ++i) out[u].t[i] = st[c].T.t[i] + st[c].vel[i] * d + 0.5 * Ra[i] * d * d + 0.5 * gravity[i] * d * d;
+  }
+  last = st[m - 1];
+  return out;
+}
+
+struct Config
+{
+  int window = 5;
+  int update_iters = 6;
+  double between_sigma_rot = 2e-3, between_sigma_trans = 1e-2;
+  double keyframe_trans_thresh = 1.0, keyframe_rot_thresh_deg = 20.0;
+  bool photometric = true;
+  V3D gravity{0.0, 0.0, -9.81};
+  lidar::RegistrationConfig reg = lidar::defaultRegistrationConfig();
+  lidar::ManagerInputConfig input = lidar::defaultManagerInputConfig();
+  size_t neighbor_voxel_mode = 19;
+  lidar::PhotometricConfig photo;
+  std::vector<V3D> bias_directions;
+};
+
+struct ScanInput
+{
+  std::vector<lidar::PointOuster> raw;
+  ImuSamples imu;
+  double header_ts = 0;
+};
+
+struct Result
+{
+  std::vector<Pose3> poses;
+  std::vector<int> photo_valid;
+  std::vector<std::vector<double>> costs;
+  int n_keyframes = 0;
+  double seconds = 0, stage[5] = {0, 0, 0, 0, 0};  // front_end, imu, factor_create, optimise, update_map
+};
+
+class FixedLagReplay
+{
+public:
+  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx)
+  {
+    map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, cfg_.reg.target_ivox_map_leaf_size);
+    map_->set_lru_horizon(lru_horizon);
+    map_->set_neighbor_voxel_mode(cfg_.neighbor_voxel_mode);
+    map_->set_min_dist_in_cell(cfg_.reg.target_ivox_map_min_dist_in_voxel);
+    if (cfg_.photometric) {
+      photo_.reset(new Photometric(ctx_, cfg_.photo));
+      scan_.keepRaw(true);
+    }
+  }
+  void seedMap(const float * xyz, size_t n) { map_->insert(xyz, n); }
+
+  // state0: the state at the first IMU sample of the first sweep (the caller's first guess)
+  Result run(const std::vector<ScanInput> & scans, const State & state0)
+  {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    Result res;
+    struct Live
+    {
+      size_t k;
+      Pose3 T;
+      ICPFactor::Ptr f;
+      bool has_Z;
+      Pose3 Z;
+    };
+    std::deque<Live> win;
+    std::vector<Pose3> kf_poses;
+    State prev = state0;
+    bool have_prev = false;
+    const double wr = 1.0 / (cfg_.between_sigma_rot * cfg_.between_sigma_rot), wt = 1.0 / (cfg_.between_sigma_trans * cfg_.between_sigma_trans);
+    const double Wb[6] = {wr, wr, wr, wt, wt, wt};
+    const float I3f[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3f[3] = {0, 0, 0};
+    const auto t_begin = clk::now();
+    for (size_t k = 0; k < scans.size(); ++k) {
+      const ScanInput & sc = scans[k];
+      const auto a0 = clk::now();
+      scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
+      const auto a1 = clk::now();
+      State pred;
+      const std::vector<Pose3> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
+      std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
+      {
+        const M33 Rt = transpose(pred.T.R);
+        for (size_t g = 0; g < T_W_Bt.size(); ++g) {
+          T_Le_Lt[g].R = matmul(Rt, T_W_Bt[g].R);
+          T_Le_Lt[g].t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
+        }
+      }
+      const auto a2 = clk::now();
+      scan_.deskewPoints(T_Le_Lt);
+      const Key X = static_cast<Key>(k);
+      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, X);
+      ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
+                                               cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
+                  "mh_scan_preprocess_geometric");
+      const auto a3 = clk::now();
+      Live lv;
+      lv.k = k;
+      lv.T = pred.T;
+      lv.f = std::make_shared<ICPFactor>(X, map_, scan_, cfg_.reg);
+      lv.has_Z = have_prev;
+      if (have_prev) lv.Z = between(prev.T, pred.T);
+      Values values;
+      NonlinearFactorGraph photo_graph;
+      if (photo_) {
+        values.insert(X, pred.T);
+        photo_->getFactors(values, photo_graph);  // no factor while nothing is tracked (photometric.cpp:381)
+      }
+      PhotometricFactor::Ptr pf = photo_ ? photo_->factor() : nullptr;
+      win.push_back(lv);
+      if (static_cast<int>(win.size()) > cfg_.window) win.pop_front();
+      const auto a4 = clk::now();
+      // ---- smoother update: every live factor re-linearized per iteration ----------------------------------------
+      const size_t nW = win.size(), dim = 6 * nW;
+      std::vector<double> fs;
+      for (int it = 0; it < cfg_.update_iters; ++it) {
+        std::vector<ICPFactor::Ptr> factors(nW);
+        Values v;
+        for (size_t i = 0; i < nW; ++i) {
+          factors[i] = win[i].f;
+          v.insert(static_cast<Key>(win[i].k), win[i].T);
+        }
+        const auto lin = ICPFactor::linearizeBatch(factors, v);
+        std::vector<double> A(dim * dim, 0.0), g(dim, 0.0);
+        double cost = 0.0;
+        for (size_t i = 0; i < nW; ++i) {
+          const auto & h = *std::static_pointer_cast<HessianFactor>(lin[i]);
+          for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < 6; ++c) A[(6 * i + r) * dim + 6 * i + c] += h.G11[6 * r + c];
+            g[6 * i + r] += -h.g1[r];  // the HessianFactor carries -b
+          }
+          cost += h.f;
+        }
+        if (pf) {
+          const auto hp = std::static_pointer_cast<HessianFactor>(pf->linearize(v));
+          bool finite = pf->lastResult().status_hist[8] > 0;
+          for (int q = 0; q < 36 && finite; ++q) finite = std::isfinite(hp->G11[q]);
+          for (int q = 0; q < 6 && finite; ++q) finite = std::isfinite(hp->g1[q]);
+          if (finite) {
+            const size_t o = 6 * (nW - 1);
+            for (int r = 0; r < 6; ++r) {
+              for (int c = 0; c < 6; ++c) A[(o + r) * dim + o + c] += hp->G11[6 * r + c];
+              g[o + r] += -hp->g1[r];
+            }
+            cost += hp->f;
+          }
+        }
+        for (size_t i = 1; i < nW; ++i) {
+          if (!win[i].has_Z) continue;
+          const Pose3 ab = between(win[i - 1].T, win[i].T);
+          const M33 Rzt = transpose(win[i].Z.R);
+          const M33 Re = matmul(Rzt, ab.R);
+          const V3D te = matvec(Rzt, {ab.t[0] - win[i].Z.t[0], ab.t[1] - win[i].Z.t[1], ab.t[2] - win[i].Z.t[2]});  // Z^-1 * between
+          const V3D lr = so3Log(Re);
+          const double r[6] = {lr[0], lr[1], lr[2], te[0], te[1], te[2]};
+          const M33 Rabt = transpose(ab.R);
+          const V3D tinv = matvec(Rabt, {-ab.t[0], -ab.t[1], -ab.t[2]});
+          const M66 Ad = adjoint(Rabt, tinv);  // J_a = -Ad(between^-1), J_b = I
+          // A += J^T W J, g += J^T W r over the two 6-blocks (a = i - 1, b = i)
+          const size_t oa = 6 * (i - 1), ob = 6 * i;
+          for (int p = 0; p < 6; ++p)
+            for (int q = 0; q < 6; ++q) {
+              double aa = 0;
+              for (int m = 0; m < 6; ++m) aa += Ad[6 * m + p] * Wb[m] * Ad[6 * m + q];
+              A[(oa + p) * dim + oa + q] += aa;
+              A[(oa + p) * dim + ob + q] += -Ad[6 * q + p] * Wb[q];
+              A[(ob + p) * dim + oa + q] += -Wb[p] * Ad[6 * p + q];
+            }
+          for (int p = 0; p < 6; ++p) {
+            A[(ob + p) * dim + ob + p] += Wb[p];
+            g[ob + p] += Wb[p] * r[p];
+            double ga = 0;
+            for (int m = 0; m < 6; ++m) ga += -Ad[6 * m + p] * Wb[m] * r[m];
+            g[oa + p] += ga;
+            cost += r[p] * Wb[p] * r[p];
+          }
+        }
+        // what marginalisation leaves on the oldest pose; loose while that pose has never been optimised
+        const bool loose = win[0].k == 0 && static_cast<int>(k) < cfg_.window;
+        const double sr = loose ? 0.017453292519943295 : 1e-4, st = loose ? 0.1 : 1e-4;
+        for (int p = 0; p < 3; ++p) {
+          A[p * dim + p] += 1.0 / (sr * sr);
+          A[(3 + p) * dim + 3 + p] += 1.0 / (st * st);
+        }
+        for (size_t p = 0; p < dim; ++p) {
+          A[p * dim + p] += 1e-9;
+          g[p] = -g[p];
+        }
+        const std::vector<double> xi = solve(std::move(A), std::move(g));
+        for (size_t i = 0; i < nW; ++i) retract(win[i].T, &xi[6 * i]);
+        fs.push_back(cost);
+      }
+      res.costs.push_back(fs);
+      const auto a5 = clk::now();
+      const Pose3 T = win.back().T;
+      // ---- Geometric::updateMap's keyframe test (geometric.cpp:445-478)
+      bool is_kf = true;
+      if (!kf_poses.empty()) {
+        size_t j = 0;
+        double best = std::numeric_limits<double>::max();
+        for (size_t i = 0; i < kf_poses.size(); ++i) {
+          const double dx = T.t[0] - kf_poses[i].t[0], dy = T.t[1] - kf_poses[i].t[1], dz = T.t[2] - kf_poses[i].t[2];
+          const double d = std::sqrt(dx * dx + dy * dy + dz * dz);
+          if (d < best) {
+            best = d;
+            j = i;
+          }
+        }
+        const M33 d = matmul(transpose(kf_poses[j].R), T.R);
+        const double yaw = std::atan2(d[3], d[0]), pitch = std::atan2(-d[6], std::hypot(d[7], d[8])), roll = std::atan2(d[7], d[8]);
+        const double ypr = std::max(std::fabs(yaw), std::max(std::fabs(pitch), std::fabs(roll)));
+        is_kf = best > cfg_.keyframe_trans_thresh || ypr > cfg_.keyframe_rot_thresh_deg * 0.017453293;
+      }
+      if (is_kf) {
+        map_ = map_->fork();  // copy-then-insert (geometric.cpp:494-495): live factors keep the map they were built on
+        map_->insertBodyCloud(scan_.underlying(), T);
+        kf_poses.push_back(T);
+        ++res.n_keyframes;
+      }
+      if (photo_) {
+        values.update(X, T);
+        if (pf) {
+          (void)pf->linearize(values);  // statuses / centres at the final pose feed the bookkeeping
+          res.photo_valid.push_back(pf->lastResult().status_hist[8]);
+        }
+        photo_->updateMap(values, cfg_.bias_directions);
+      }
+      const auto a6 = clk::now();
+      res.stage[0] += secs(a0, a1) + secs(a2, a3);
+      res.stage[1] += secs(a1, a2);
+      res.stage[2] += secs(a3, a4);
+      res.stage[3] += secs(a4, a5);
+      res.stage[4] += secs(a5, a6);
+      res.poses.push_back(T);
+      // velocity: the propagated one, carried into the corrected attitude
+      prev.T = T;
+      prev.vel = matvec(T.R, matvec(transpose(pred.T.R), pred.vel));
+      have_prev = true;
+    }
+    win.clear();
+    res.seconds = secs(t_begin, clk::now());
+    return res;
+  }
+
+private:
+  std::shared_ptr<lidar::Context> ctx_;
+  Config cfg_;
+  ScanFrontEnd scan_;
+  IncrementalVoxelMapPCL::Ptr map_;
+  std::unique_ptr<Photometric> photo_;
+};
+
+}  // namespace replay
+}  // namespace mimosa_hip

@@ -1,0 +1,88 @@
+// Native sequence replay: drives mimosa_hip::replay::FixedLagReplay (host/mimosa_hip/replay.hpp) on an input file written
+// by mimosa_amd/replay.py:write_native_input and prints one JSON object (estimated poses, per-stage seconds, scans/s).
+//   replay_native <input.bin> [repeats]      (repeats > 1: the whole sequence again, timing of the last pass is reported)
+#include <cstdio>
+#include <cstring>
+
+#include "mimosa_hip/binio.hpp"
+#include "mimosa_hip/replay.hpp"
+
+using namespace mimosa_hip;
+using binio::read_vec;
+
+int main(int argc, char ** argv)
+{
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: replay_native <input.bin> [repeats]\n");
+    return 2;
+  }
+  const int repeats = argc > 2 ? std::atoi(argv[2]) : 1;
+  try {
+    std::ifstream f(argv[1], std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open the input file");
+    const auto I = read_vec<int32_t>(f);   // window, update_iters, photometric, neighbour mode, lru_horizon
+    const auto D = read_vec<double>(f);    // between sigmas (rot, trans), keyframe thresholds (trans, rot deg), gravity xyz
+    const auto regb = read_vec<uint8_t>(f);
+    const auto inpb = read_vec<uint8_t>(f);
+    if (I.size() != 5 || D.size() != 7 || regb.size() != sizeof(mh_reg_config) || inpb.size() != sizeof(mh_input_config))
+      throw std::runtime_error("configuration block has the wrong shape");
+    replay::Config cfg;
+    cfg.window = I[0];
+    cfg.update_iters = I[1];
+    cfg.photometric = I[2] != 0;
+    cfg.neighbor_voxel_mode = static_cast<size_t>(I[3]);
+    cfg.between_sigma_rot = D[0];
+    cfg.between_sigma_trans = D[1];
+    cfg.keyframe_trans_thresh = D[2];
+    cfg.keyframe_rot_thresh_deg = D[3];
+    cfg.gravity = {D[4], D[5], D[6]};
+    std::memcpy(&cfg.reg, regb.data(), sizeof(cfg.reg));
+    std::memcpy(&cfg.input, inpb.data(), sizeof(cfg.input));
+    if (cfg.photometric) cfg.photo = binio::read_photo_config(f);
+    const auto bias = read_vec<double>(f);
+    for (size_t i = 0; i + 2 < bias.size(); i += 3) cfg.bias_directions.push_back({bias[i], bias[i + 1], bias[i + 2]});
+    const auto seed = read_vec<float>(f);
+    const auto s0 = read_vec<double>(f);  // R (9), t (3), velocity (3): the state at the first IMU sample of the first sweep
+    const auto nsc = read_vec<int32_t>(f);
+    std::vector<replay::ScanInput> scans(static_cast<size_t>(nsc.at(0)));
+    for (auto & sc : scans) {
+      sc.raw = read_vec<lidar::PointOuster>(f);
+      sc.imu.ts = read_vec<double>(f);
+      const auto gy = read_vec<double>(f), ac = read_vec<double>(f);
+      for (size_t j = 0; j < sc.imu.ts.size(); ++j) {
+        sc.imu.gyro.push_back({gy[3 * j], gy[3 * j + 1], gy[3 * j + 2]});
+        sc.imu.acc.push_back({ac[3 * j], ac[3 * j + 1], ac[3 * j + 2]});
+      }
+      sc.header_ts = read_vec<double>(f).at(0);
+    }
+    replay::State st0;
+    st0.T = binio::pose_from(s0.data());
+    st0.vel = {s0[12], s0[13], s0[14]};
+    auto ctx = std::make_shared<lidar::Context>(0);
+    replay::Result r;
+    for (int rep = 0; rep < repeats; ++rep) {
+      replay::FixedLagReplay run(ctx, cfg, static_cast<size_t>(I[4]));
+      run.seedMap(seed.data(), seed.size() / 3);
+      r = run.run(scans, st0);
+    }
+    std::printf("{\"scans\": %zu, \"seconds\": %.9f, \"scans_per_s\": %.3f, \"n_keyframes\": %d,\n", scans.size(), r.seconds,
+                static_cast<double>(scans.size()) / r.seconds, r.n_keyframes);
+    std::printf("\"stage_s\": {\"front_end\": %.9f, \"imu\": %.9f, \"factor_create\": %.9f, \"optimise\": %.9f, \"update_map\": %.9f},\n",
+                r.stage[0], r.stage[1], r.stage[2], r.stage[3], r.stage[4]);
+    std::printf("\"photo_valid\": [");
+    for (size_t i = 0; i < r.photo_valid.size(); ++i) std::printf("%d%s", r.photo_valid[i], i + 1 < r.photo_valid.size() ? ", " : "");
+    std::printf("],\n\"first_costs\": [");
+    for (size_t i = 0; i < r.costs.at(0).size(); ++i) std::printf("%.17g%s", r.costs[0][i], i + 1 < r.costs[0].size() ? ", " : "");
+    std::printf("],\n\"poses\": [");
+    for (size_t k = 0; k < r.poses.size(); ++k) {
+      std::printf("[");
+      for (int i = 0; i < 9; ++i) std::printf("%.17g, ", r.poses[k].R[i]);
+      std::printf("%.17g, %.17g, %.17g]%s", r.poses[k].t[0], r.poses[k].t[1], r.poses[k].t[2], k + 1 < r.poses.size() ? ", " : "");
+    }
+    std::printf("]}\n");
+  } catch (const std::exception & e) {
+    std::fprintf(stderr, "replay_native: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

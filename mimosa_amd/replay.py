@@ -238,10 +238,81 @@ class HipBackend:
         f.destroy()
 
 
+def first_state(cfg: ReplayConfig, scan0, rng_seed=7):
+    """State at the first IMU sample of the first sweep: ground truth + the prior error (the caller's first guess)."""
+    rng = np.random.default_rng(rng_seed)
+    Rs = scan0["R_gt"] @ synth.so3_exp(np.deg2rad(cfg.prior_rot_noise_deg) * rng.standard_normal(3))
+    ps = scan0["t_gt"] + cfg.prior_trans_noise * rng.standard_normal(3)
+    w_, v_body = np.asarray(cfg.w, float), np.asarray(cfg.v, float)
+    R_start = Rs @ synth.so3_exp(-w_ * cfg.dt)
+    p_start = ps - R_start @ (v_body * cfg.dt)
+    return R_start, p_start, R_start @ v_body
+
+
+def write_native_input(path, cfg: ReplayConfig, scans, rng_seed=7, mode=synth.ENWIDE_NEIGHBOR_MODE):
+    """The input file of the native harness (mimosa_amd/host/replay_main.cpp): length-prefixed little-endian vectors."""
+    import struct
+    from . import capi
+    with open(path, "wb") as f:
+        def w(arr, dtype=None):
+            arr = np.ascontiguousarray(arr if dtype is None else np.asarray(arr, dtype))
+            f.write(struct.pack("<Q", len(arr) if arr.dtype.itemsize == 32 else arr.size))
+            f.write(arr.tobytes())
+        w([cfg.window, cfg.update_iters, int(cfg.photometric), mode, 1000], np.int32)
+        w([cfg.between_sigma_rot, cfg.between_sigma_trans, cfg.keyframe_trans_thresh, cfg.keyframe_rot_thresh_deg, *GRAVITY], np.float64)
+        w(np.frombuffer(bytes(capi.make_reg_config(**cfg.reg)), np.uint8))
+        w(np.frombuffer(bytes(capi.make_input_config()), np.uint8))
+        if cfg.photometric:
+            pc = cfg.photo
+            w([pc["rows"], pc["cols"], pc["destagger"], pc["erosion_buffer"], pc["patch_size"], pc["margin_size"], pc["remove_lines"],
+               pc["filter_brightness"], pc["gaussian_blur"], pc["gaussian_blur_size"], pc["nma_radius"], pc["num_features_detect"],
+               pc["max_feature_life_time"], pc["rotate_patch_to_align_with_gradient"], pc["use_robust_cost_function"],
+               pc["robust_cost_function"], pc["brightness_window_size"][0], pc["brightness_window_size"][1]], np.int32)
+            w([pc["range_min"], pc["range_max"], pc["intensity_scale"], pc["intensity_gamma"], pc["gradient_threshold"],
+               pc["max_dist_from_mean"], pc["max_dist_from_plane"], pc["occlusion_range_diff_threshold"],
+               pc["lidar_origin_to_beam_origin_mm"], pc["robust_cost_function_parameter"], pc["error_scale"], pc["max_error"],
+               pc["sigma"]], np.float64)
+            w(pc["pixel_shift_by_row"], np.int32)
+            w(pc["beam_altitude_angles"], np.float32)
+            w(pc["high_pass_fir"], np.float64)
+            w(pc["low_pass_fir"], np.float64)
+            w(np.asarray(pc["patch_offsets"], np.int32).ravel())
+            w(np.concatenate([np.asarray(pc["T_B_L_R"], float).ravel(), np.asarray(pc["T_B_L_t"], float)]))
+        w(np.asarray(synth_photo.BIAS_DIRECTIONS, np.float64).ravel())
+        w(synth.make_room(synth.BASE_SEED, 0, 0, room=np.asarray(cfg.room)).astype(np.float32).ravel())
+        R0, p0, v0 = first_state(cfg, scans[0], rng_seed)
+        w(np.concatenate([R0.ravel(), p0, v0]))
+        w([len(scans)], np.int32)
+        for sc in scans:
+            ts, gyro, acc = sc["imu"]
+            w(sc["raw"])
+            w(ts, np.float64)
+            w(np.asarray(gyro, np.float64).ravel())
+            w(np.asarray(acc, np.float64).ravel())
+            w([sc["header_ts"]], np.float64)
+
+
+def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7):
+    """The same replay through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls."""
+    import json
+    import os
+    import subprocess
+    from . import build
+    exe = build.build_replay_native()
+    path = os.path.join(workdir, "replay_input.bin")
+    write_native_input(path, cfg, scans, rng_seed)
+    out = subprocess.run([exe, path, str(repeats)], capture_output=True, text=True, timeout=900)
+    os.remove(path)
+    if out.returncode != 0:
+        raise RuntimeError("replay_native failed: " + out.stderr[-2000:])
+    r = json.loads(out.stdout)
+    r["poses_est"] = [(np.array(p[:9]).reshape(3, 3), np.array(p[9:])) for p in r.pop("poses")]
+    return r
+
+
 def run(cfg: ReplayConfig, backend, scans=None, rng_seed=7):
     """Replay: returns dict(poses_est, errors, keyframes, per-stage seconds, ...)."""
     scans = scans if scans is not None else make_scans(cfg)
-    rng = np.random.default_rng(rng_seed)
     backend.seed_map(synth.make_room(synth.BASE_SEED, 0, 0, room=np.asarray(cfg.room)))
     stage = {"front_end": 0.0, "imu": 0.0, "factor_create": 0.0, "optimise": 0.0, "update_map": 0.0}
     v_body = np.asarray(cfg.v, float)
@@ -256,12 +327,7 @@ def run(cfg: ReplayConfig, backend, scans=None, rng_seed=7):
         a1 = time.perf_counter()
         # IMU propagation from the previous scan's estimate (first scan: ground truth + the prior error)
         if R_prev is None:
-            Rs = sc["R_gt"] @ synth.so3_exp(np.deg2rad(cfg.prior_rot_noise_deg) * rng.standard_normal(3))
-            ps = sc["t_gt"] + cfg.prior_trans_noise * rng.standard_normal(3)
-            w_ = np.asarray(cfg.w, float)
-            R_start = Rs @ synth.so3_exp(-w_ * cfg.dt)          # state at the first IMU sample of this sweep
-            p_start = ps - R_start @ (v_body * cfg.dt)
-            vel_start = R_start @ v_body
+            R_start, p_start, vel_start = first_state(cfg, sc, rng_seed)   # state at the first IMU sample of this sweep
         else:
             R_start, p_start, vel_start = R_prev, t_prev, vel_prev
         T_W_Bt, (R_pred, p_pred, vel_pred) = propagate(R_start, p_start, vel_start, sc["imu"], sc["header_ts"], uns)

@@ -7,27 +7,13 @@
 #include <fstream>
 #include <iostream>
 
-#include "../../mimosa_amd/host/mimosa_hip/photometric.hpp"
+#include "../../mimosa_amd/host/mimosa_hip/binio.hpp"
 
 using namespace mimosa_hip;
 using namespace mimosa_hip::lidar;
+using mimosa_hip::binio::pose_from;
+using mimosa_hip::binio::read_vec;
 
-template <typename T>
-static std::vector<T> read_vec(std::ifstream & f)
-{
-  uint64_t n = 0;
-  f.read(reinterpret_cast<char *>(&n), 8);
-  std::vector<T> v(n);
-  f.read(reinterpret_cast<char *>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
-  return v;
-}
-static Pose3 pose_from(const double * p)
-{
-  Pose3 T;
-  for (int i = 0; i < 9; ++i) T.R[i] = p[i];
-  for (int i = 0; i < 3; ++i) T.t[i] = p[9 + i];
-  return T;
-}
 static void dump(const char * name, const double * v, int n)
 {
   std::printf("\"%s\": [", name);
@@ -39,48 +25,7 @@ int main(int argc, char ** argv)
 {
   if (argc < 2) return 2;
   std::ifstream f(argv[1], std::ios::binary);
-  const auto I = read_vec<int32_t>(f);
-  const auto D = read_vec<double>(f);
-  PhotometricConfig cfg;
-  cfg.rows = static_cast<size_t>(I[0]);
-  cfg.cols = static_cast<size_t>(I[1]);
-  cfg.destagger = I[2] != 0;
-  cfg.erosion_buffer = I[3];
-  cfg.patch_size = I[4];
-  cfg.margin_size = I[5];
-  cfg.remove_lines = I[6] != 0;
-  cfg.filter_brightness = I[7] != 0;
-  cfg.gaussian_blur = I[8] != 0;
-  cfg.gaussian_blur_size = I[9];
-  cfg.nma_radius = I[10];
-  cfg.num_features_detect = static_cast<size_t>(I[11]);
-  cfg.max_feature_life_time = I[12];
-  cfg.rotate_patch_to_align_with_gradient = I[13] != 0;
-  cfg.use_robust_cost_function = I[14] != 0;
-  cfg.robust_cost_function = I[15] == 0 ? "huber" : "gemanmcclure";
-  cfg.brightness_window_size = {I[16], I[17]};
-  cfg.range_min = static_cast<float>(D[0]);
-  cfg.range_max = static_cast<float>(D[1]);
-  cfg.intensity_scale = static_cast<float>(D[2]);
-  cfg.intensity_gamma = static_cast<float>(D[3]);
-  cfg.gradient_threshold = static_cast<float>(D[4]);
-  cfg.max_dist_from_mean = static_cast<float>(D[5]);
-  cfg.max_dist_from_plane = static_cast<float>(D[6]);
-  cfg.occlusion_range_diff_threshold = static_cast<float>(D[7]);
-  cfg.lidar_origin_to_beam_origin_mm = static_cast<float>(D[8]);
-  cfg.robust_cost_function_parameter = D[9];
-  cfg.error_scale = D[10];
-  cfg.max_error = D[11];
-  cfg.sigma = D[12];
-  cfg.pixel_shift_by_row = read_vec<int32_t>(f);
-  cfg.beam_altitude_angles = read_vec<float>(f);
-  cfg.high_pass_fir = read_vec<double>(f);
-  cfg.low_pass_fir = read_vec<double>(f);
-  const auto offs = read_vec<int32_t>(f);
-  cfg.edgelet_patch_offsets.clear();
-  for (size_t i = 0; i + 1 < offs.size(); i += 2) cfg.edgelet_patch_offsets.emplace_back(offs[i], offs[i + 1]);
-  const auto TBL = read_vec<double>(f);
-  cfg.T_B_L = pose_from(TBL.data());
+  const PhotometricConfig cfg = binio::read_photo_config(f);
   const auto bias = read_vec<double>(f);
   std::vector<V3D> bias_directions;
   for (size_t i = 0; i + 2 < bias.size(); i += 3) bias_directions.push_back({bias[i], bias[i + 1], bias[i + 2]});
