@@ -83,7 +83,12 @@ struct mh_photo_factor
   bool binary = false;
   double VSVt[36];
   std::vector<HostFeature> features;  // a_features_
-  DevBuf d_Le, d_psi, d_npts, d_status, d_centers, d_partials, d_rows;
+  DevBuf d_Le, d_psi, d_npts, d_rows;
+  // per-feature outputs of the kernel (statuses, new centres, Hessian sums): mapped pinned host memory the kernel writes
+  // straight into — ~21 KB per linearize, no copy nodes behind the kernel
+  void * h_out = nullptr;
+  void * d_out = nullptr;  // device address of h_out
+  size_t out_bytes = 0;
   std::vector<int32_t> statuses;
   std::vector<double> centers, partials, rows;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -850,9 +855,9 @@ static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::v
   if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps.data(), ps.size() * sizeof(double));
   if (rc == MH_OK) rc = upload(ctx, f->d_npts, np.data(), np.size() * sizeof(int32_t));
   hipError_t e = hipSuccess;
-  if (rc == MH_OK) e = f->d_status.reserve(nf * sizeof(int32_t), ctx->stream, false);
-  if (rc == MH_OK && e == hipSuccess) e = f->d_centers.reserve(nf * 2 * sizeof(double), ctx->stream, false);
-  if (rc == MH_OK && e == hipSuccess) e = f->d_partials.reserve(nf * mh::kPhotoPartial * sizeof(double), ctx->stream, false);
+  f->out_bytes = (nf * (2 + mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 64 + 4095) & ~size_t(4095);  // few size classes for the pinned cache
+  if (rc == MH_OK) e = AllocCache::alloc_pinned(&f->h_out, f->out_bytes);
+  if (rc == MH_OK && e == hipSuccess) e = hipHostGetDevicePointer(&f->d_out, f->h_out, 0);
   if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
   if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
   if (rc != MH_OK || e != hipSuccess) {
@@ -902,7 +907,8 @@ void mh_photo_factor_destroy(mh_photo_factor * f)
   mh_ctx * ctx = f->photo->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_status, &f->d_centers, &f->d_partials, &f->d_rows}) b->release();
+  for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_rows}) b->release(true);
+  if (f->h_out) AllocCache::free_pinned(f->h_out, f->out_bytes);
   for (auto & e : f->ev)
     if (e) (void)hipEventDestroy(e);
   frame_release(f->frame);
@@ -967,9 +973,10 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
     a.robust_param = c.robust_cost_function_parameter;
     a.use_robust = c.use_robust_cost_function;
     a.robust_is_huber = c.robust_cost_function == 0;
-    a.status = static_cast<int32_t *>(f->d_status.p);
-    a.centers = static_cast<double *>(f->d_centers.p);
-    a.partials = static_cast<double *>(f->d_partials.p);
+    // layout of the mapped block: centres (2 nf doubles) | partial sums (nf x kPhotoPartial doubles) | statuses (nf int32)
+    a.centers = static_cast<double *>(f->d_out);
+    a.partials = a.centers + 2 * nf;
+    a.status = reinterpret_cast<int32_t *>(a.partials + nf * mh::kPhotoPartial);
     a.rows_out = static_cast<double *>(f->d_rows.p);
     a.counters = f->photo->d_counters;
     f->photo->h_counters->project_throw = f->photo->h_counters->pose_missing = 0;
@@ -981,12 +988,10 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[0], ctx->stream));
     MH_HIP(ctx, mh::launch_photo_linearize(a, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[1], ctx->stream));
-    f->partials.resize(nf * mh::kPhotoPartial);
-    std::vector<double> new_centers(2 * nf);
-    MH_HIP(ctx, hipMemcpyAsync(f->statuses.data(), f->d_status.p, nf * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(new_centers.data(), f->d_centers.p, nf * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(f->partials.data(), f->d_partials.p, nf * mh::kPhotoPartial * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the end of the kernel makes its host writes visible
+    const double * new_centers = static_cast<const double *>(f->h_out);
+    f->partials.assign(new_centers + 2 * nf, new_centers + 2 * nf + nf * mh::kPhotoPartial);
+    std::memcpy(f->statuses.data(), new_centers + 2 * nf + nf * mh::kPhotoPartial, nf * sizeof(int32_t));
     std::memset(out, 0, sizeof(*out));
     out->gpu_ms = -1.f;
     if (timed) (void)hipEventElapsedTime(&out->gpu_ms, f->ev[0], f->ev[1]);
