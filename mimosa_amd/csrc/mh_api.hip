@@ -257,7 +257,6 @@ void mh_shutdown(mh_ctx * ctx)
   }
   if (ctx->timer[0]) (void)hipEventDestroy(ctx->timer[0]);
   if (ctx->timer[1]) (void)hipEventDestroy(ctx->timer[1]);
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);

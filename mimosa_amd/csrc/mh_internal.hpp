@@ -33,8 +33,6 @@ struct mh_ctx
   std::string err;
   int profiling = 0;  // 0 off; n: HIP events around the kernels of every n-th linearize call of a factor
   hipEvent_t timer[2] = {nullptr, nullptr};
-  void * h_stage = nullptr;  // pinned staging for map delta records (pageable -> device copies run at a few GB/s)
-  size_t h_stage_cap = 0;
   void * h_batch = nullptr;  // pinned staging of mh_icp_linearize_batch's argument blocks
   void * d_batch = nullptr;  // ... and the device copy the batched kernels read
   void * d_scratch = nullptr;  // stream-ordered scratch of factor creation (source ordering): reused, never freed per call
