@@ -1395,7 +1395,10 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // Launchers
 // ------------------------------------------------------------------------------------------------
 // Threads per workgroup for an n-point cloud (see icp_linearize_kernel).
-static int linearize_tpb(int n) { return n <= 65536 ? 256 : kThreads; }
+#ifndef MH_TPB_SPLIT
+#define MH_TPB_SPLIT 65536  // clouds up to this many points run 256-thread workgroups, larger ones 512
+#endif
+static int linearize_tpb(int n) { return n <= MH_TPB_SPLIT ? 256 : kThreads; }
 int linearize_grid(int n)
 {
   const int tpb = linearize_tpb(n);

@@ -1058,18 +1058,25 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
 
 namespace
 {
-int scan_fetch_counters(mh_scan * s)
+int scan_fetch_counters(mh_scan * s, bool with_unique = false)
 {
   mh_ctx * ctx = s->ctx;
+  constexpr size_t kBytes = sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t);
   if (!s->h_c) {
     void * p = nullptr;
-    MH_HIP(ctx, AllocCache::alloc_pinned(&p, sizeof(mh::ScanCounters)));
+    MH_HIP(ctx, AllocCache::alloc_pinned(&p, kBytes));
     s->h_c = static_cast<mh::ScanCounters *>(p);
   }
   MH_HIP(ctx, hipMemcpyAsync(s->h_c, s->d_counters.p, sizeof(s->c), hipMemcpyDeviceToHost, ctx->stream));
+  size_t n_copy = 0;
+  if (with_unique) {  // the distinct timestamps ride along: the caller asks for them next (IMU propagation), one wait instead of two
+    n_copy = std::min(mh_scan::kUniqueCached, s->d_unique.cap / sizeof(uint32_t));
+    MH_HIP(ctx, hipMemcpyAsync(s->h_c + 1, s->d_unique.p, n_copy * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   s->c = *s->h_c;
   s->c.n_unique_ns += s->c.has_max_ns;  // the value 0xFFFFFFFF travels as a flag (scan_kernels.hip: input_scatter_kernel)
+  if (with_unique) s->n_unique_cached = s->c.n_unique_ns <= n_copy ? s->c.n_unique_ns : 0;
   return MH_OK;
 }
 void scan_fill_info(const mh_scan * s, mh_scan_info * info)
@@ -1112,7 +1119,7 @@ void mh_scan_destroy(mh_scan * s)
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
                      &s->d_rt, &s->d_prep, &s->d_vox})
     b->release(true);
-  AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters));
+  AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t));
   delete s;
 }
 
@@ -1126,6 +1133,7 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
     return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": skip divisors must be >= 1");
   MH_HIP(ctx, hipSetDevice(ctx->device));
   s->prepared = s->preprocessed = s->raw_valid = false;
+  s->n_unique_cached = 0;
   s->n_in = n;
   s->n_body = 0;
   const size_t m = n ? n : 1;
@@ -1144,7 +1152,7 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
                                        static_cast<mh_point32 *>(s->d_full.p), static_cast<uint32_t *>(s->d_geo_idx.p),
                                        static_cast<uint32_t *>(s->d_unique.p), static_cast<mh::ScanCounters *>(s->d_counters.p),
                                        ctx->stream));
-  const int rc = scan_fetch_counters(s);
+  const int rc = scan_fetch_counters(s, true);
   if (rc != MH_OK) return rc;
   s->prepared = true;
   scan_fill_info(s, info);
@@ -1169,6 +1177,10 @@ static int mh_scan_get_unique_ns_impl(const mh_scan * s, uint32_t * out, size_t 
   *n_out = s->c.n_unique_ns;
   if (!out) return MH_OK;
   if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_unique_ns: buffer too small");
+  if (s->n_unique_cached == *n_out) {  // came back with the counters of mh_scan_prepare_input
+    std::memcpy(out, s->h_c + 1, *n_out * sizeof(uint32_t));
+    return MH_OK;
+  }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, s->d_unique.p, *n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -296,7 +296,9 @@ struct mh_scan
   DevBuf d_full_raw;  // points_raw_ (lidar/manager.cpp:376-380): points_full_ as it was before deskewing, kept for the photometric path
   bool keep_raw = false, raw_valid = false;
   DevBuf d_prep, d_vox;  // scratch of launch_prepare_input / launch_preprocess (scan_device.hpp: prepare_layout, voxel_layout)
-  mh::ScanCounters * h_c = nullptr;  // pinned landing buffer of the device counters
+  mh::ScanCounters * h_c = nullptr;  // pinned landing buffer: the device counters, then the first kUniqueCached distinct timestamps
+  static constexpr size_t kUniqueCached = 4096;
+  size_t n_unique_cached = 0;        // how many of unique_ns_ sit behind h_c (0 = ask the device)
   mh::ScanCounters c{};
   size_t n_in = 0, n_body = 0;
   bool prepared = false, preprocessed = false;

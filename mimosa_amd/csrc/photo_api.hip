@@ -680,8 +680,12 @@ int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_
       return hip_fail(ctx, e, "mh_photo_preprocess_scan: frame copy");
     }
     std::vector<uint32_t> uns(n_groups);
-    if (n_groups) MH_HIP(ctx, hipMemcpyAsync(uns.data(), scan->d_unique.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_groups && scan->n_unique_cached == n_groups) {  // the host copy that came back with mh_scan_prepare_input's counters
+      std::memcpy(uns.data(), scan->h_c + 1, n_groups * sizeof(uint32_t));
+    } else {
+      if (n_groups) MH_HIP(ctx, hipMemcpyAsync(uns.data(), scan->d_unique.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     int rc = preprocess_device(photo, fr, static_cast<const mh_point32 *>(scan->d_full_raw.p), n, uns.data(), T_Le_Lt, n_groups);
     if (rc != MH_OK) {
       frame_release(fr);
