@@ -182,15 +182,21 @@ __global__ __launch_bounds__(kT) void map_create_voxels_kernel(const MapArrays m
 // ---- phase C ---------------------------------------------------------------------------------------------
 // One wave per touched voxel: FlatContainer::add over its segment (input order).  Lane j holds the j-th point of the
 // bucket.  Distance in Eigen's SSE2 Vector4d squaredNorm order (dx2 + dz2) + (dy2 + dw2), dw = 0, like the k-NN.
+// 64 candidates at a time: (a) every candidate against the points already in the bucket (<= 20 broadcasts), (b) the
+// survivors in input order — the first one is added and knocks out the later ones within min_dist.  A candidate is
+// added iff no EARLIER ADDED point (or resident point) is closer than min_dist and the bucket is not full: the
+// sequential rule, with the sequential part run once per added point instead of once per point.
+__device__ __forceinline__ float lane_value(float v, uint32_t lane)  // lane: wave-uniform
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(lane)));
+}
 __global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m, const float4 * pts, const uint32_t * sorted_idx,
-                                                                const uint32_t * seg_start, const uint32_t * seg_vid, uint32_t n_voxels_before,
-                                                                uint32_t n_voxels_after, uint32_t max_pts, double min_sq, double inv_leaf,
-                                                                unsigned long long lru_counter)
+                                                                const uint32_t * seg_start, const uint32_t * seg_vid, uint32_t * seg_added,
+                                                                uint32_t max_pts, double min_sq, double inv_leaf, unsigned long long lru_counter)
 {
   const uint32_t ns = m.state->n_segments;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * kT + threadIdx.x) >> 6, n_waves = (gridDim.x * kT) >> 6;
-  unsigned long long added_total = 0;
   for (uint32_t s = wave; s < ns; s += n_waves) {
     const uint32_t vid = seg_vid[s], s0 = seg_start[s], s1 = seg_start[s + 1];
     const int4 vx = m.vox[vid];  // created in phase B when new (count 0)
@@ -205,27 +211,34 @@ __global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m
     }
     for (uint32_t base = s0; base < s1 && count < max_pts; base += 64u) {
       const uint32_t sp = base + lane;
+      const bool valid = sp < s1;
       float px = 0.f, py = 0.f, pz = 0.f;
-      if (sp < s1) {
+      if (valid) {
         const float4 p = pts[sorted_idx[sp]];
         px = p.x;
         py = p.y;
         pz = p.z;
       }
-      const uint32_t mcount = min(64u, s1 - base);
-      for (uint32_t u = 0; u < mcount && count < max_pts; ++u) {
-        const float qxf = __shfl(px, static_cast<int>(u)), qyf = __shfl(py, static_cast<int>(u)), qzf = __shfl(pz, static_cast<int>(u));
-        const double dx = static_cast<double>(fx) - static_cast<double>(qxf), dy = static_cast<double>(fy) - static_cast<double>(qyf),
-                     dz = static_cast<double>(fz) - static_cast<double>(qzf);
-        const bool close = lane < count && ((dx * dx + dz * dz) + (dy * dy + 0.0)) < min_sq;
-        if (__ballot(close) == 0ull) {
-          if (lane == count) {
-            fx = qxf;
-            fy = qyf;
-            fz = qzf;
-          }
-          ++count;
+      const double qx = static_cast<double>(px), qy = static_cast<double>(py), qz = static_cast<double>(pz);
+      bool blocked = !valid;
+      for (uint32_t i = 0; i < count; ++i) {
+        const double dx = static_cast<double>(lane_value(fx, i)) - qx, dy = static_cast<double>(lane_value(fy, i)) - qy,
+                     dz = static_cast<double>(lane_value(fz, i)) - qz;
+        blocked = blocked || ((dx * dx + dz * dz) + (dy * dy + 0.0)) < min_sq;
+      }
+      uint64_t open = __ballot(!blocked);
+      while (open != 0ull && count < max_pts) {
+        const uint32_t u = static_cast<uint32_t>(__ffsll(static_cast<long long>(open))) - 1u;
+        const float ux = lane_value(px, u), uy = lane_value(py, u), uz = lane_value(pz, u);
+        if (lane == count) {
+          fx = ux;
+          fy = uy;
+          fz = uz;
         }
+        ++count;
+        const double dx = static_cast<double>(ux) - qx, dy = static_cast<double>(uy) - qy, dz = static_cast<double>(uz) - qz;
+        blocked = blocked || ((dx * dx + dz * dz) + (dy * dy + 0.0)) < min_sq;
+        open = __ballot(!blocked) & (u == 63u ? 0ull : (~0ull << (u + 1u)));
       }
     }
     if (lane >= old_count && lane < count) {
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m
     if (lane == 0) {
       m.vox[vid] = make_int4(vx.x, vx.y, vx.z, static_cast<int>(count));
       m.lru[vid] = lru_counter;  // info.lru = lru_counter for every voxel a point of the batch fell into
-      added_total += count - old_count;
+      seg_added[s] = count - old_count;  // summed by map_totals_kernel: tens of thousands of atomics on one counter cost more than the insert
     }
     if (count != old_count && lane < 8) {  // the voxel's word in its home table and every halo it sits in
       int bx, by, bz;
@@ -257,9 +270,25 @@ __global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m
       }
     }
   }
-  if (added_total) atomicAdd(&m.state->n_points, added_total);
-  if (blockIdx.x == 0 && threadIdx.x == 0) m.state->n_voxels = n_voxels_after;
-  (void)n_voxels_before;
+}
+
+// totals after phase C: n_points += sum of the per-segment additions, n_voxels = the new count.  One workgroup.
+__global__ __launch_bounds__(1024) void map_totals_kernel(const MapArrays m, const uint32_t * seg_added, uint32_t n_voxels_after)
+{
+  __shared__ unsigned long long s_w[16];
+  const uint32_t ns = m.state->n_segments;
+  unsigned long long t = 0;
+  for (uint32_t s = threadIdx.x; s < ns; s += 1024u) t += seg_added[s];
+#pragma unroll
+  for (int mk = 32; mk >= 1; mk >>= 1) t += __shfl_xor(t, mk, 64);
+  if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < 16; ++w) tot += s_w[w];
+    m.state->n_points += tot;
+    m.state->n_voxels = n_voxels_after;
+  }
 }
 
 __global__ __launch_bounds__(kT) void map_rehash_kernel(const int4 * old_table, uint32_t old_cap, int4 * new_table, uint32_t new_mask)
@@ -414,8 +443,9 @@ hipError_t launch_map_insert_points(const MapArrays & m, uint32_t n, uint32_t n_
 {
   const size_t waves = static_cast<size_t>(n);  // <= one wave per point (segments <= points)
   const int grid = static_cast<int>(std::min<size_t>((waves * 64 + kT - 1) / kT, 16384));
-  hipLaunchKernelGGL(map_insert_points_kernel, dim3(grid > 0 ? grid : 1), dim3(kT), 0, stream, m, s.pts, s.idx_b, s.seg_start, s.seg_vid, 0u,
-                     n_voxels_after, max_pts, min_sq, inv_leaf, lru_counter);
+  hipLaunchKernelGGL(map_insert_points_kernel, dim3(grid > 0 ? grid : 1), dim3(kT), 0, stream, m, s.pts, s.idx_b, s.seg_start, s.seg_vid, s.flags,
+                     max_pts, min_sq, inv_leaf, lru_counter);
+  hipLaunchKernelGGL(map_totals_kernel, dim3(1), dim3(1024), 0, stream, m, s.flags, n_voxels_after);
   return hipGetLastError();
 }
 
