@@ -679,6 +679,8 @@ def main():
             "streams": args.streams,
             "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
             "status_hist": [int(v) for v in last["status_hist"]],
+            "status_note": "index = RejectStatus (geometric_factor.hpp:35-46): 5 = Line, 8 = Valid.  A third of the points end as Line on this synthetic "
+                           "world (map points on a 0.16 m jittered grid: 5 neighbours often fall on one grid row); real scans will shift the valid fraction",
             "exact_fallback_queries": int(last["n_exact_fallback"]),
             "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2),
         },
@@ -754,6 +756,9 @@ def main():
                       f"(geometric_factor.hpp:261)",
             "all_cores_value": round(n_pts / med_all / 1e6, 3),
             "all_cores": ncores,
+            "all_cores_note": "the port's OpenMP loop does not scale past a few threads (per-point hash lookups into one shared "
+                              "map: memory-latency bound, and at 256 threads the fork/join + false sharing of the per-thread "
+                              "partial Hessians cost more than the work): slower than the 4-thread row, reported because SURVEY 8(d) asks for it",
         }
         line["parity_vs_oracle"] = {
             "H_rel": rel(last["H_ss"], res4["H_ss"]), "b_rel": rel(last["b_s"], res4["b_s"]),
