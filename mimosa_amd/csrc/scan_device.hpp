@@ -27,19 +27,6 @@ struct Rt12  // row-major R, then t; passed to kernels by value
   float v[12];
 };
 
-// the down-sampler's voxel hash (open addressing, 64-bit packed coordinates).  keys / first / cnt / cur / bad are one
-// allocation cleared to all-ones per call: empty key, first = UINT_MAX for atomicMin, cnt and cur count from -1.
-struct VoxelHash
-{
-  uint64_t * keys;
-  uint32_t * first;  // smallest input index of the voxel's points
-  uint32_t * cnt;    // number of points - 1
-  uint32_t * cur;    // scatter cursor - 1
-  uint32_t * bad;    // != all-ones: a coordinate was out of the key range
-  uint32_t * off;    // start of the voxel's segment in the sorted index list
-  uint32_t mask;
-};
-
 struct PrepareLayout
 {
   uint32_t n_blocks, ns_cap;

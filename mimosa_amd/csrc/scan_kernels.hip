@@ -39,92 +39,14 @@
 #include <cstring>
 
 #include "scan_device.hpp"
+#include "voxel_group.hpp"
 #include "voxel_map.hpp"
 
 namespace mh
 {
 namespace
 {
-constexpr int kThreads = 256;
-constexpr int kItems = 1;                         // consecutive elements per thread in the blocked kernels: these kernels are
-                                                  // latency-bound (<= 131 072 elements), more blocks beat wider threads
-constexpr uint32_t kBlockItems = kThreads * kItems;
-constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
-constexpr uint64_t kEmpty64 = ~0ull;
-
-uint32_t blocks_for(uint32_t n) { return n ? (n + kBlockItems - 1) / kBlockItems : 1u; }
-
-// ---- block-level helpers (256 threads = 4 waves) ------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(v, d);
-    if (lane >= static_cast<uint32_t>(d)) v += o;
-  }
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
-// exclusive prefix of (a, b) over the block's threads + block totals.  lds: 8 words.
-__device__ __forceinline__ void block_exclusive_sum2(uint32_t a, uint32_t b, uint32_t & ea, uint32_t & eb, uint32_t & ta,
-                                                     uint32_t & tb, uint32_t * lds)
-{
-  const uint32_t ia = wave_inclusive_sum(a), ib = wave_inclusive_sum(b);
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  if (lane == 63u) {
-    lds[wave] = ia;
-    lds[4 + wave] = ib;
-  }
-  __syncthreads();
-  uint32_t oa = 0, ob = 0;
-  ta = tb = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < 4; ++w) {
-    const uint32_t xa = lds[w], xb = lds[4 + w];
-    if (w < wave) {
-      oa += xa;
-      ob += xb;
-    }
-    ta += xa;
-    tb += xb;
-  }
-  ea = oa + ia - a;
-  eb = ob + ib - b;
-  __syncthreads();
-}
-
-// sum of blk_a[0..b) and blk_b[0..b): the block's offset in a two-kernel (count, then place) compaction
-__device__ __forceinline__ void block_offsets2(const uint32_t * blk_a, const uint32_t * blk_b, uint32_t b, uint32_t & off_a,
-                                               uint32_t & off_b, uint32_t * lds)
-{
-  uint32_t sa = 0, sb = 0;
-  for (uint32_t i = threadIdx.x; i < b; i += kThreads) {
-    sa += blk_a[i];
-    sb += blk_b[i];
-  }
-  sa = wave_sum(sa);
-  sb = wave_sum(sb);
-  if ((threadIdx.x & 63u) == 0) {
-    lds[threadIdx.x >> 6] = sa;
-    lds[4 + (threadIdx.x >> 6)] = sb;
-  }
-  __syncthreads();
-  off_a = lds[0] + lds[1] + lds[2] + lds[3];
-  off_b = lds[4] + lds[5] + lds[6] + lds[7];
-  __syncthreads();
-}
-
-__device__ __forceinline__ float lane_value(float v, uint32_t lane)  // lane: wave-uniform
-{
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(lane)));
-}
+using namespace vg;  // block helpers, voxel hash grouping, in-wave index sort (voxel_group.hpp)
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h)
 {
@@ -135,16 +57,6 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h)
   h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ uint32_t mix64(uint64_t k)
-{
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ull;
-  k ^= k >> 33;
-  return static_cast<uint32_t>(k);
-}
-
 // ---- prepareInput ------------------------------------------------------------------------------------
 struct FilterParams
 {
@@ -363,28 +275,6 @@ __global__ __launch_bounds__(kThreads) void unique_sort_kernel(const uint32_t * 
 constexpr int kCoordBits = 21;
 constexpr int kCoordBias = 1 << (kCoordBits - 1);
 
-// Runs of consecutive lanes with the same voxel (neighbouring columns of one ring mostly are): one hash probe and one
-// set of atomics per run instead of per point.  head_lane = the run's first lane, run_len on the head lane.
-struct LaneRun
-{
-  bool head;
-  uint32_t head_lane, run_len;
-};
-__device__ __forceinline__ LaneRun lane_runs(bool valid, bool differs_from_previous_lane)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  LaneRun r;
-  r.head = valid && (lane == 0u || differs_from_previous_lane);
-  const uint64_t heads = __ballot(r.head);
-  const uint32_t n_valid = static_cast<uint32_t>(__popcll(__ballot(valid)));  // valid lanes are a prefix of the wave
-  const uint64_t upto = heads & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));
-  r.head_lane = upto ? 63u - static_cast<uint32_t>(__clzll(upto)) : 0u;
-  const uint64_t later = lane == 63u ? 0ull : (heads >> (lane + 1u));
-  const uint32_t end = later ? lane + static_cast<uint32_t>(__ffsll(static_cast<long long>(later))) : n_valid;
-  r.run_len = end - lane;
-  return r;
-}
-
 __global__ __launch_bounds__(kThreads) void body_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ geo_idx,
                                                                uint32_t n, Rt12 P, double inv_leaf, mh_point32 * __restrict__ body,
                                                                VoxelHash h, uint32_t * __restrict__ slot_of)
@@ -407,152 +297,14 @@ __global__ __launch_bounds__(kThreads) void body_voxel_kernel(const mh_point32 *
     key = (static_cast<uint64_t>(bx & ((1 << kCoordBits) - 1)) << (2 * kCoordBits)) |
           (static_cast<uint64_t>(by & ((1 << kCoordBits) - 1)) << kCoordBits) | static_cast<uint64_t>(bz & ((1 << kCoordBits) - 1));
   }
-  const uint32_t klo = static_cast<uint32_t>(key), khi = static_cast<uint32_t>(key >> 32);
-  const LaneRun run = lane_runs(valid, __shfl_up(klo, 1) != klo || __shfl_up(khi, 1) != khi);
-  uint32_t slot = 0;
-  if (run.head) {
-    slot = mix64(key) & h.mask;
-    for (;;) {
-      unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&h.keys[slot]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur == kEmpty64) {
-        cur = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[slot]), static_cast<unsigned long long>(kEmpty64),
-                        static_cast<unsigned long long>(key));
-        if (cur == kEmpty64) cur = key;
-      }
-      if (cur == key) break;
-      slot = (slot + 1) & h.mask;
-    }
-    atomicMin(&h.first[slot], j);            // all-ones before: the voxel's first point in input order (the head has the run's smallest j)
-    atomicAdd(&h.cnt[slot], run.run_len);    // all-ones before: stored value = count - 1
-  }
-  slot = __shfl(slot, static_cast<int>(run.head_lane));
+  const uint32_t slot = voxel_assign(h, valid, key, j);
   if (valid) slot_of[j] = slot;
-}
-
-// value of input position j in the two scans: (points of the voxel, 1) if j is the first point of its voxel, else (0, 0)
-__device__ __forceinline__ void voxel_head(const VoxelHash & h, uint32_t slot, uint32_t j, uint32_t & c, uint32_t & v)
-{
-  const bool head = h.first[slot] == j;
-  c = head ? h.cnt[slot] + 1u : 0u;
-  v = head ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(kThreads) void voxel_count_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
-                                                                uint32_t * __restrict__ blk_pts, uint32_t * __restrict__ blk_vox)
-{
-  __shared__ uint32_t lds[8];
-  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
-  uint32_t c = 0, v = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kItems; ++k)
-    if (base + k < n) {
-      uint32_t ck, vk;
-      voxel_head(h, slot_of[base + k], base + k, ck, vk);
-      c += ck;
-      v += vk;
-    }
-  c = wave_sum(c);
-  v = wave_sum(v);
-  if ((threadIdx.x & 63u) == 0) {
-    lds[threadIdx.x >> 6] = c;
-    lds[4 + (threadIdx.x >> 6)] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    blk_pts[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-    blk_vox[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
-  }
-}
-
-// off[slot] = start of the voxel's segment (voxels in first-seen order); vox_seg[v] = (start, length) of the v-th voxel
-__global__ __launch_bounds__(kThreads) void voxel_offsets_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
-                                                                  const uint32_t * __restrict__ blk_pts,
-                                                                  const uint32_t * __restrict__ blk_vox, uint2 * __restrict__ vox_seg,
-                                                                  ScanCounters * counters)
-{
-  __shared__ uint32_t lds[8];
-  uint32_t off_pts, off_vox;
-  block_offsets2(blk_pts, blk_vox, blockIdx.x, off_pts, off_vox, lds);
-  const uint32_t base = blockIdx.x * kBlockItems + threadIdx.x * kItems;
-  uint32_t ck[kItems], vk[kItems], sl[kItems], c = 0, v = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kItems; ++k) {
-    ck[k] = vk[k] = sl[k] = 0;
-    if (base + k < n) {
-      sl[k] = slot_of[base + k];
-      voxel_head(h, sl[k], base + k, ck[k], vk[k]);
-      c += ck[k];
-      v += vk[k];
-    }
-  }
-  uint32_t ec, ev, tc, tv;
-  block_exclusive_sum2(c, v, ec, ev, tc, tv, lds);
-  uint32_t pc = off_pts + ec, pv = off_vox + ev;
-#pragma unroll
-  for (uint32_t k = 0; k < kItems; ++k)
-    if (vk[k]) {
-      h.off[sl[k]] = pc;
-      vox_seg[pv] = make_uint2(pc, ck[k]);
-      pc += ck[k];
-      ++pv;
-    }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters->n_voxels = off_vox + tv;
-}
-
-__global__ __launch_bounds__(kThreads) void voxel_scatter_kernel(const uint32_t * __restrict__ slot_of, uint32_t n, VoxelHash h,
-                                                                  uint32_t * __restrict__ idx_unsorted)
-{
-  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
-  const bool valid = j < n;
-  const uint32_t slot = valid ? slot_of[j] : kEmpty32;
-  const LaneRun run = lane_runs(valid, __shfl_up(slot, 1) != slot);
-  uint32_t at = 0;
-  if (run.head) at = h.off[slot] + (atomicAdd(&h.cur[slot], run.run_len) + 1u);  // cursor starts at all-ones
-  at = __shfl(at, static_cast<int>(run.head_lane));
-  if (valid) idx_unsorted[at + ((threadIdx.x & 63u) - run.head_lane)] = j;
-}
-
-// One wave sorts len distinct values ascending: binary LSD radix, one stable split per bit that varies, ping-pong between
-// a and b so that the last pass lands in a.  src / a / b: LDS or global (distinct arrays).
-__device__ __forceinline__ void wave_radix_sort(const uint32_t * src, uint32_t * a, uint32_t * b, uint32_t len)
-{
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t lanes_below = (1ull << lane) - 1ull;
-  uint32_t zeros = 0, diff = 0;
-  const uint32_t e0 = src[0];
-  for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-    const bool valid = c0 + lane < len;
-    const uint32_t e = valid ? src[c0 + lane] : e0;
-    diff |= e ^ e0;
-    zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !(e & 1u))));
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) diff |= __shfl_xor(diff, d);
-  const uint32_t n_bits = diff ? 32u - static_cast<uint32_t>(__clz(diff)) : 1u;
-  for (uint32_t bit = 0; bit < n_bits; ++bit) {
-    uint32_t * dst = ((n_bits - 1u - bit) & 1u) ? b : a;
-    uint32_t z_run = 0, o_run = zeros, next_zeros = 0;
-    for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
-      const bool valid = c0 + lane < len;
-      const uint32_t e = valid ? src[c0 + lane] : 0u;
-      const bool one = (e >> bit) & 1u;
-      const uint64_t m0 = __ballot(valid && !one), m1 = __ballot(valid && one);
-      if (valid) dst[one ? o_run + static_cast<uint32_t>(__popcll(m1 & lanes_below)) : z_run + static_cast<uint32_t>(__popcll(m0 & lanes_below))] = e;
-      next_zeros += static_cast<uint32_t>(__popcll(__ballot(valid && !((e >> (bit + 1u)) & 1u))));
-      z_run += static_cast<uint32_t>(__popcll(m0));
-      o_run += static_cast<uint32_t>(__popcll(m1));
-    }
-    __threadfence_block();
-    src = dst;
-    zeros = next_zeros;
-  }
 }
 
 // One WAVE per voxel.  (1) the voxel's point indices, unordered after the scatter, ascending: input order.  <= 64: rank
 // sort in registers; <= kLdsSort: radix in LDS; above: the same radix on global scratch.  (2) FlatContainerMinimal::add
 // over them: lane j holds the j-th point kept so far (<= 20); every incoming point is tested against all of them at
 // once (one fp64 distance per lane, one ballot).  idx_sorted / keep are indexed by position in the first-seen layout.
-constexpr uint32_t kLdsSort = 1024;
 __global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32 * __restrict__ pts, const uint32_t * __restrict__ idx_unsorted,
                                                                  uint32_t * idx_sorted, uint32_t * idx_tmp, const uint2 * __restrict__ vox_seg,
                                                                  const ScanCounters * counters, uint32_t max_pts, double min_sq,
@@ -568,19 +320,7 @@ __global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32
     const uint2 seg = vox_seg[v];
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg.x), len = __builtin_amdgcn_readfirstlane(seg.y);
     const uint32_t s1 = s0 + len;
-    uint32_t first_chunk = 0;  // sorted index of position s0 + lane, when the whole voxel fits one wave
-    if (len <= 64u) {
-      const uint32_t e = lane < len ? idx_unsorted[s0 + lane] : kEmpty32;
-      uint32_t rank = 0;
-      for (uint32_t u = 0; u < len; ++u)
-        rank += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e), static_cast<int>(u))) < e ? 1u : 0u;
-      if (lane >= len) rank = lane;
-      first_chunk = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(rank << 2), static_cast<int>(e)));  // lane r <- the value of rank r
-    } else if (len <= kLdsSort) {
-      wave_radix_sort(idx_unsorted + s0, sort_lds[wave_in_block][0], sort_lds[wave_in_block][1], len);
-    } else {
-      wave_radix_sort(idx_unsorted + s0, idx_sorted + s0, idx_tmp + s0, len);
-    }
+    const uint32_t first_chunk = sort_segment_indices(idx_unsorted, idx_sorted, idx_tmp, sort_lds[wave_in_block][0], sort_lds[wave_in_block][1], s0, len);
     // FlatContainerMinimal::add, 64 candidates at a time: (a) every candidate against the points kept so far (<= 20
     // broadcasts), (b) the survivors in input order: the first one is kept and knocks out the later ones near it.  A
     // candidate is kept iff no EARLIER KEPT point is closer than min_dist and the voxel is not full — the sequential
@@ -592,13 +332,7 @@ __global__ __launch_bounds__(kThreads) void greedy_voxel_kernel(const mh_point32
       const bool valid = s < s1;
       float px = 0.f, py = 0.f, pz = 0.f;
       if (valid) {
-        uint32_t j;
-        if (len <= 64u)
-          j = first_chunk;
-        else if (len <= kLdsSort)
-          j = sort_lds[wave_in_block][0][s - s0];
-        else
-          j = __hip_atomic_load(&idx_sorted[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t j = sorted_index_at(first_chunk, sort_lds[wave_in_block][0], idx_sorted, s0, len, s);
         if (len <= kLdsSort) idx_sorted[s] = j;
         const mh_point32 p = pts[j];
         px = p.x;
@@ -683,13 +417,6 @@ __global__ __launch_bounds__(kThreads) void keep_scatter_kernel(const mh_point32
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------
-static uint32_t pow2_at_least(uint64_t v)
-{
-  uint64_t c = 1024;
-  while (c < v) c <<= 1;
-  return static_cast<uint32_t>(c);
-}
-
 PrepareLayout prepare_layout(size_t n)
 {
   PrepareLayout L;
@@ -701,12 +428,12 @@ PrepareLayout prepare_layout(size_t n)
 
 VoxelLayout voxel_layout(size_t n)
 {
+  const vg::Layout G = vg::layout(n);
   VoxelLayout L;
-  L.n_blocks = blocks_for(static_cast<uint32_t>(n));
-  L.cap = pow2_at_least(2 * static_cast<uint64_t>(n));
-  L.clear_bytes = static_cast<size_t>(L.cap) * (8 + 4 + 4 + 4) + 16;
-  const size_t m = n ? n : 1;
-  L.bytes = L.clear_bytes + static_cast<size_t>(L.cap) * 4 + (7 * m + 3 * static_cast<size_t>(L.n_blocks)) * 4;
+  L.n_blocks = G.n_blocks;
+  L.cap = G.cap;
+  L.clear_bytes = G.clear_bytes;
+  L.bytes = G.bytes + ((n ? n : 1) + static_cast<size_t>(G.n_blocks)) * 4;  // + keep flags, per-block keep counts
   return L;
 }
 
@@ -743,38 +470,18 @@ hipError_t launch_preprocess(const mh_point32 * points_full, const uint32_t * ge
   const VoxelLayout L = voxel_layout(n);
   hipError_t e = hipMemsetAsync(scratch, 0xFF, L.clear_bytes, stream);
   if (e != hipSuccess) return e;
-  VoxelHash h;
-  char * p = static_cast<char *>(scratch);
-  h.keys = reinterpret_cast<uint64_t *>(p);
-  p += static_cast<size_t>(L.cap) * 8;
-  h.first = reinterpret_cast<uint32_t *>(p);
-  p += static_cast<size_t>(L.cap) * 4;
-  h.cnt = reinterpret_cast<uint32_t *>(p);
-  p += static_cast<size_t>(L.cap) * 4;
-  h.cur = reinterpret_cast<uint32_t *>(p);
-  p += static_cast<size_t>(L.cap) * 4;
-  h.bad = reinterpret_cast<uint32_t *>(p);
-  p += 16;
-  h.off = reinterpret_cast<uint32_t *>(p);
-  p += static_cast<size_t>(L.cap) * 4;
-  h.mask = L.cap - 1u;
-  uint32_t * w = reinterpret_cast<uint32_t *>(p);
-  const size_t nn = n;
-  uint2 * vox_seg = reinterpret_cast<uint2 *>(w);  // 8-byte aligned: everything before it is a multiple of 8 bytes
-  uint32_t * slot_of = w + 2 * nn, * idx_unsorted = w + 3 * nn, * idx_sorted = w + 4 * nn, * idx_tmp = w + 5 * nn, * keep = w + 6 * nn,
-           * blk = w + 7 * nn;
-  uint32_t * blk_pts = blk, * blk_vox = blk + L.n_blocks, * blk_keep = blk + 2 * L.n_blocks;
+  const vg::Buffers B = vg::carve(scratch, n);
+  const VoxelHash & h = B.h;
+  uint32_t * keep = reinterpret_cast<uint32_t *>(static_cast<char *>(scratch) + vg::layout(n).bytes), * blk_keep = keep + n;
   const double inv_leaf = 1.0 / leaf;            // geometric.cpp:61
   const double min_sq = min_dist * min_dist;     // :63
   const dim3 gp((n + kThreads - 1) / kThreads), gb(L.n_blocks), b(kThreads);
-  hipLaunchKernelGGL(body_voxel_kernel, gp, b, 0, stream, points_full, geo_idx, n, body_from_lidar, inv_leaf, body, h, slot_of);
-  hipLaunchKernelGGL(voxel_count_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox);
-  hipLaunchKernelGGL(voxel_offsets_kernel, gb, b, 0, stream, slot_of, n, h, blk_pts, blk_vox, vox_seg, counters);
-  hipLaunchKernelGGL(voxel_scatter_kernel, gp, b, 0, stream, slot_of, n, h, idx_unsorted);
+  hipLaunchKernelGGL(body_voxel_kernel, gp, b, 0, stream, points_full, geo_idx, n, body_from_lidar, inv_leaf, body, h, B.slot_of);
+  if ((e = vg::launch_group(B, n, &counters->n_voxels, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(greedy_voxel_kernel, dim3(static_cast<uint32_t>(min((static_cast<size_t>(n) * 64 + kThreads - 1) / kThreads, static_cast<size_t>(8192)))),
-                     b, 0, stream, body, idx_unsorted, idx_sorted, idx_tmp, vox_seg, counters, max_pts, min_sq, keep);
+                     b, 0, stream, body, B.idx_unsorted, B.idx_sorted, B.idx_tmp, B.seg, counters, max_pts, min_sq, keep);
   hipLaunchKernelGGL(keep_count_kernel, gb, b, 0, stream, keep, n, blk_keep);
-  hipLaunchKernelGGL(keep_scatter_kernel, gb, b, 0, stream, body, idx_sorted, keep, n, blk_keep, h.bad, kept_idx, out, counters);
+  hipLaunchKernelGGL(keep_scatter_kernel, gb, b, 0, stream, body, B.idx_sorted, keep, n, blk_keep, h.bad, kept_idx, out, counters);
   return hipGetLastError();
 }
 
