@@ -105,30 +105,20 @@ int ensure_scratch(mh_map * m, size_t n)
   mh_ctx * ctx = m->ctx;
   const size_t k = n ? n : 1;
   MH_HIP(ctx, m->s_pts.reserve(k * sizeof(float4), ctx->stream, false));
-  MH_HIP(ctx, m->s_keys_a.reserve(k * sizeof(uint64_t), ctx->stream, false));
-  MH_HIP(ctx, m->s_keys_b.reserve(k * sizeof(uint64_t), ctx->stream, false));
-  for (DevBuf * b : {&m->s_idx_a, &m->s_idx_b, &m->s_flags, &m->s_pos, &m->s_seg_vid, &m->s_newflag, &m->s_newrank})
-    MH_HIP(ctx, b->reserve(k * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, m->s_seg_start.reserve((k + 1) * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, m->s_temp.reserve(mh::map_temp_bytes(k), ctx->stream, false));
+  MH_HIP(ctx, m->s_group.reserve(mh::map_group_bytes(k), ctx->stream, false));
+  MH_HIP(ctx, m->s_seg_vid.reserve(k * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, m->s_seg_added.reserve(k * sizeof(uint32_t), ctx->stream, false));
+  MH_HIP(ctx, m->s_blk_new.reserve(((k + 255) / 256 + 1) * sizeof(uint32_t), ctx->stream, false));
   return MH_OK;
 }
 mh::InsertScratch scratch_of(const mh_map * m)
 {
   mh::InsertScratch s;
   s.pts = static_cast<float4 *>(m->s_pts.p);
-  s.keys_a = static_cast<uint64_t *>(m->s_keys_a.p);
-  s.keys_b = static_cast<uint64_t *>(m->s_keys_b.p);
-  s.idx_a = static_cast<uint32_t *>(m->s_idx_a.p);
-  s.idx_b = static_cast<uint32_t *>(m->s_idx_b.p);
-  s.flags = static_cast<uint32_t *>(m->s_flags.p);
-  s.pos = static_cast<uint32_t *>(m->s_pos.p);
-  s.seg_start = static_cast<uint32_t *>(m->s_seg_start.p);
+  s.group = m->s_group.p;
   s.seg_vid = static_cast<uint32_t *>(m->s_seg_vid.p);
-  s.newflag = static_cast<uint32_t *>(m->s_newflag.p);
-  s.newrank = static_cast<uint32_t *>(m->s_newrank.p);
-  s.temp = m->s_temp.p;
-  s.temp_bytes = m->s_temp.cap;
+  s.seg_added = static_cast<uint32_t *>(m->s_seg_added.p);
+  s.blk_new = static_cast<uint32_t *>(m->s_blk_new.p);
   return s;
 }
 
@@ -263,9 +253,8 @@ int insert_device(mh_map * m, const float * d_src, size_t n, size_t stride, cons
 
 void map_free(mh_map * m)
 {
-  for (DevBuf * b : {&m->d_table, &m->d_cells, &m->d_buckets, &m->d_qbuckets, &m->d_vox, &m->d_lru, &m->s_in, &m->s_pts, &m->s_keys_a, &m->s_keys_b,
-                     &m->s_idx_a, &m->s_idx_b, &m->s_flags, &m->s_pos, &m->s_seg_start, &m->s_seg_vid, &m->s_newflag, &m->s_newrank, &m->s_temp,
-                     &m->s_rt, &m->s_shard})
+  for (DevBuf * b : {&m->d_table, &m->d_cells, &m->d_buckets, &m->d_qbuckets, &m->d_vox, &m->d_lru, &m->s_in, &m->s_pts, &m->s_group, &m->s_seg_vid,
+                     &m->s_seg_added, &m->s_blk_new, &m->s_flags, &m->s_pos, &m->s_temp, &m->s_rt, &m->s_shard})
     b->release();
   if (m->d_state) dev_free(m->d_state);
   if (m->h_state) (void)hipHostFree(m->h_state);

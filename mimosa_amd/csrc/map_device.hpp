@@ -59,23 +59,16 @@ struct MapArrays
 struct InsertScratch
 {
   float4 * pts;           // n: the batch as float4 (after the optional f32 transform)
-  uint64_t * keys_a;      // n
-  uint64_t * keys_b;      // n
-  uint32_t * idx_a;       // n
-  uint32_t * idx_b;       // n: sorted -> input index
-  uint32_t * flags;       // n
-  uint32_t * pos;         // n
-  uint32_t * seg_start;   // n + 1
+  void * group;           // voxel_group.hpp scratch of the batch (map_group_bytes(n)): hash, first-seen segments, index lists
   uint32_t * seg_vid;     // n: voxel id of segment s (existing, or n_voxels + creation rank)
-  uint32_t * newflag;     // n: input index i opens a new voxel
-  uint32_t * newrank;     // n
-  void * temp;
-  size_t temp_bytes;
+  uint32_t * seg_added;   // n: points the insert added to segment s
+  uint32_t * blk_new;     // (n + 255) / 256: per-block counts of segments that open a new voxel
 };
 
+size_t map_group_bytes(size_t n);
 size_t map_temp_bytes(size_t n);
-// phase A: keys -> stable sort by voxel -> segments -> which exist / creation ranks.  Publishes n_segments,
-// n_new_voxels, bad_coord.  src: n points `stride_floats` apart (device memory); Rt12 != null applies the f32 rigid
+// phase A: voxel key per point -> first-seen grouping (voxel_group.hpp, no sort) -> which voxels exist / creation ranks
+// of the new ones (first-seen order = the reference's creation order).  Publishes n_segments, n_new_voxels, bad_coord.  src: n points `stride_floats` apart (device memory); Rt12 != null applies the f32 rigid
 // transform p <- R p + t first (Geometric::updateMap's world transform, geometric.cpp:483-490).
 hipError_t launch_map_insert_prepare(const MapArrays & m, const float * src, uint32_t n, uint32_t stride_floats, const float * Rt12,
                                      double inv_leaf, const InsertScratch & s, hipStream_t stream);

@@ -7,10 +7,12 @@
 // src/lidar/geometric.cpp:483-490; mimosa's own restatement of the add rule include/mimosa/lidar/utils.hpp:260-278.
 //
 // The insertion rule is sequential in the reference, but it only couples points of ONE voxel, in input order.
-//   1. voxel key per point -> STABLE radix sort: every touched voxel becomes a contiguous segment, still in input order
-//   2. a segment whose voxel is not in the map yet creates it; creation order = order of the segments' FIRST input
-//      index (a flag per input index + an exclusive scan gives the rank), so voxel ids — and with them getCloud's
-//      order — are exactly the reference's
+//   1. voxel key per point -> the sort-free grouping of voxel_group.hpp (hash assign, first-seen segment layout, atomic
+//      scatter; the consumer wave sorts its segment's indices): every touched voxel is a contiguous segment, segments
+//      in first-seen order, points of a segment in input order
+//   2. a segment whose voxel is not in the map yet creates it; creation order = first-seen order (an exclusive scan of
+//      the "new" flags over the segments gives the rank), so voxel ids — and with them getCloud's order — are
+//      exactly the reference's
 //   3. new voxels claim their home block and the <= 7 adjacent blocks whose halo they touch in the hash table
 //      (64-bit compare-and-swap on the packed block coordinate; block ids are not observable)
 //   4. one WAVE per touched voxel runs FlatContainer::add over its segment: the kept points sit one per lane, every
@@ -23,6 +25,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "map_device.hpp"
+#include "voxel_group.hpp"
 
 namespace mh
 {
@@ -96,10 +99,14 @@ __device__ __forceinline__ bool voxel_block(int cx, int cy, int cz, int which, i
 }
 
 // ---- phase A ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void map_keys_kernel(const float * src, uint32_t n, uint32_t stride, const float * Rt12, double inv_leaf,
-                                                       float4 * pts, uint64_t * keys, uint32_t * idx, uint32_t * newflag, MapState * st)
+// phase A.1: the batch as float4 (after the optional transform), its voxel keys into the batch hash
+__global__ __launch_bounds__(kT) void map_assign_kernel(const float * src, uint32_t n, uint32_t stride, const float * Rt12, double inv_leaf,
+                                                         float4 * pts, VoxelHash h, uint32_t * slot_of, MapState * st)
 {
-  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n; i += gridDim.x * kT) {
+  const uint32_t i = blockIdx.x * kT + threadIdx.x;
+  const bool valid = i < n;
+  uint64_t key = vg::kEmpty64;
+  if (valid) {
     float x = src[static_cast<size_t>(i) * stride], y = src[static_cast<size_t>(i) * stride + 1], z = src[static_cast<size_t>(i) * stride + 2];
     if (Rt12) {  // geometric.cpp:483-490: f32 R p + t, Eigen's r0 x + (r1 y + r2 z) order, no FMA
       const float px = x, py = y, pz = z;
@@ -112,64 +119,70 @@ __global__ __launch_bounds__(kT) void map_keys_kernel(const float * src, uint32_
               cz = fast_floor(static_cast<double>(z) * inv_leaf);
     // one voxel of margin: the blocks a voxel touches must fit the key as well
     const int lim = kVoxCoordBias - 8;
-    if (cx < -lim || cx >= lim || cy < -lim || cy >= lim || cz < -lim || cz >= lim || !(x == x) || !(y == y) || !(z == z)) atomicOr(&st->bad_coord, 1u);
-    keys[i] = pack_coord_key(cx, cy, cz);
-    idx[i] = i;
-    newflag[i] = 0u;
-  }
-}
-
-__global__ __launch_bounds__(kT) void map_head_flags_kernel(const uint64_t * keys, uint32_t n, uint32_t * flags)
-{
-  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n; i += gridDim.x * kT) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-
-// segment starts + the lookup of every segment's voxel; a segment without one flags its first input index
-__global__ __launch_bounds__(kT) void map_segments_kernel(const MapArrays m, const uint64_t * keys, const uint32_t * sorted_idx,
-                                                           const uint32_t * flags, const uint32_t * pos, uint32_t n, uint32_t * seg_start,
-                                                           uint32_t * seg_vid, uint32_t * newflag)
-{
-  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n; i += gridDim.x * kT) {
-    if (i == n - 1) {
-      const uint32_t ns = pos[i] + flags[i];
-      m.state->n_segments = ns;
-      seg_start[ns] = n;
+    if (cx < -lim || cx >= lim || cy < -lim || cy >= lim || cz < -lim || cz >= lim || !(x == x) || !(y == y) || !(z == z)) {
+      atomicOr(&st->bad_coord, 1u);
+      key = pack_coord_key(0, 0, 0);  // keeps the grouping well-formed; the host rejects the batch before anything is modified
+    } else {
+      key = pack_coord_key(cx, cy, cz);
     }
-    if (!flags[i]) continue;
-    const uint32_t s = pos[i];
-    seg_start[s] = i;
-    int cx, cy, cz;
-    unpack_coord_key(keys[i], cx, cy, cz);
-    uint32_t vid = 0xFFFFFFFFu;
-    const int blk = find_block(m, cx >> kBlockLog2, cy >> kBlockLog2, cz >> kBlockLog2);
-    if (blk >= 0) {
-      const uint32_t w = m.cells[static_cast<size_t>(blk) * kCellsPerBlock + halo_index(cx & (kBlockDim - 1), cy & (kBlockDim - 1), cz & (kBlockDim - 1))];
-      if (w != kEmptyCell) vid = w >> 5;
-    }
-    seg_vid[s] = vid;
-    if (vid == 0xFFFFFFFFu) newflag[sorted_idx[i]] = 1u;  // stable sort: sorted_idx[i] is the segment's first input index
   }
+  const uint32_t slot = vg::voxel_assign(h, valid, key, i);
+  if (valid) slot_of[i] = slot;
 }
 
-__global__ __launch_bounds__(kT) void map_new_ids_kernel(const MapArrays m, const uint32_t * sorted_idx, const uint32_t * seg_start, uint32_t n,
-                                                          const uint32_t * newflag, const uint32_t * newrank, uint32_t * seg_vid)
+// voxel id of segment g's voxel, or ~0u when the map does not hold it yet
+__device__ __forceinline__ uint32_t segment_voxel(const MapArrays & m, uint64_t key)
 {
+  int cx, cy, cz;
+  unpack_coord_key(key, cx, cy, cz);
+  const int blk = find_block(m, cx >> kBlockLog2, cy >> kBlockLog2, cz >> kBlockLog2);
+  if (blk < 0) return 0xFFFFFFFFu;
+  const uint32_t w = m.cells[static_cast<size_t>(blk) * kCellsPerBlock + halo_index(cx & (kBlockDim - 1), cy & (kBlockDim - 1), cz & (kBlockDim - 1))];
+  return w != kEmptyCell ? (w >> 5) : 0xFFFFFFFFu;
+}
+
+// phase A.3: look every segment's voxel up (segments are in first-seen order); per-block count of the new ones
+__global__ __launch_bounds__(kT) void map_lookup_kernel(const MapArrays m, VoxelHash h, const uint32_t * vox_slot, uint32_t * seg_vid,
+                                                         uint32_t * blk_new)
+{
+  const uint32_t ns = m.state->n_segments;
+  const uint32_t g = blockIdx.x * kT + threadIdx.x;
+  uint32_t vid = 0;
+  if (g < ns) {
+    vid = segment_voxel(m, h.keys[vox_slot[g]]);
+    seg_vid[g] = vid;
+  }
+  const int n_new = __syncthreads_count(g < ns && vid == 0xFFFFFFFFu);
+  if (threadIdx.x == 0) blk_new[blockIdx.x] = static_cast<uint32_t>(n_new);
+}
+
+// phase A.4: creation ranks = exclusive scan of the "new" flags over the segments (first-seen order = creation order)
+__global__ __launch_bounds__(kT) void map_new_ids_kernel(const MapArrays m, const uint32_t * blk_new, uint32_t * seg_vid)
+{
+  __shared__ uint32_t lds[8];
   const uint32_t ns = m.state->n_segments, nv = m.state->n_voxels;
-  for (uint32_t s = blockIdx.x * kT + threadIdx.x; s < ns; s += gridDim.x * kT)
-    if (seg_vid[s] == 0xFFFFFFFFu) seg_vid[s] = nv + newrank[sorted_idx[seg_start[s]]];  // creation order = first-seen order
-  if (blockIdx.x == 0 && threadIdx.x == 0) m.state->n_new_voxels = n ? newrank[n - 1] + newflag[n - 1] : 0u;
+  const uint32_t n_blocks = (ns + kT - 1) / kT;
+  if (blockIdx.x >= n_blocks && !(blockIdx.x == 0)) return;
+  uint32_t off, unused;
+  vg::block_offsets2(blk_new, blk_new, blockIdx.x, off, unused, lds);
+  const uint32_t g = blockIdx.x * kT + threadIdx.x;
+  const uint32_t is_new = (g < ns && seg_vid[g] == 0xFFFFFFFFu) ? 1u : 0u;
+  uint32_t e, e2, t, t2;
+  vg::block_exclusive_sum2(is_new, 0u, e, e2, t, t2, lds);
+  if (is_new) seg_vid[g] = nv + off + e;
+  if (blockIdx.x == (n_blocks ? n_blocks - 1 : 0) && threadIdx.x == 0) m.state->n_new_voxels = ns ? off + t : 0u;
 }
 
 // ---- phase B ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void map_create_voxels_kernel(const MapArrays m, const uint64_t * keys, const uint32_t * seg_start,
-                                                                const uint32_t * seg_vid, uint32_t n_voxels_before, unsigned long long lru_counter)
+__global__ __launch_bounds__(kT) void map_create_voxels_kernel(const MapArrays m, VoxelHash h, const uint32_t * vox_slot, const uint32_t * seg_vid,
+                                                                uint32_t n_voxels_before, unsigned long long lru_counter)
 {
   const uint32_t ns = m.state->n_segments;
   for (uint32_t s = blockIdx.x * kT + threadIdx.x; s < ns; s += gridDim.x * kT) {
     const uint32_t vid = seg_vid[s];
     if (vid < n_voxels_before) continue;
     int cx, cy, cz;
-    unpack_coord_key(keys[seg_start[s]], cx, cy, cz);
+    unpack_coord_key(h.keys[vox_slot[s]], cx, cy, cz);
     m.vox[vid] = make_int4(cx, cy, cz, 0);
     m.lru[vid] = lru_counter;
     for (int w = 0; w < 8; ++w) {
@@ -190,15 +203,20 @@ __device__ __forceinline__ float lane_value(float v, uint32_t lane)  // lane: wa
 {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(lane)));
 }
-__global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m, const float4 * pts, const uint32_t * sorted_idx,
-                                                                const uint32_t * seg_start, const uint32_t * seg_vid, uint32_t * seg_added,
-                                                                uint32_t max_pts, double min_sq, double inv_leaf, unsigned long long lru_counter)
+__global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m, const float4 * pts, const uint32_t * __restrict__ idx_unsorted,
+                                                                uint32_t * idx_sorted, uint32_t * idx_tmp, const uint2 * __restrict__ seg,
+                                                                const uint32_t * seg_vid, uint32_t * seg_added, uint32_t max_pts, double min_sq,
+                                                                double inv_leaf, unsigned long long lru_counter)
 {
+  __shared__ uint32_t sort_lds[kT / 64][2][vg::kLdsSort];
   const uint32_t ns = m.state->n_segments;
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
   const uint32_t wave = (blockIdx.x * kT + threadIdx.x) >> 6, n_waves = (gridDim.x * kT) >> 6;
   for (uint32_t s = wave; s < ns; s += n_waves) {
-    const uint32_t vid = seg_vid[s], s0 = seg_start[s], s1 = seg_start[s + 1];
+    const uint2 sg = seg[s];
+    const uint32_t vid = seg_vid[s], s0 = __builtin_amdgcn_readfirstlane(sg.x), len = __builtin_amdgcn_readfirstlane(sg.y), s1 = s0 + len;
+    // the segment's point indices ascending = input order (the scatter left them unordered)
+    const uint32_t first_chunk = vg::sort_segment_indices(idx_unsorted, idx_sorted, idx_tmp, sort_lds[wave_in_block][0], sort_lds[wave_in_block][1], s0, len);
     const int4 vx = m.vox[vid];  // created in phase B when new (count 0)
     const uint32_t old_count = static_cast<uint32_t>(vx.w);
     uint32_t count = old_count;
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(kT) void map_insert_points_kernel(const MapArrays m
       const bool valid = sp < s1;
       float px = 0.f, py = 0.f, pz = 0.f;
       if (valid) {
-        const float4 p = pts[sorted_idx[sp]];
+        const float4 p = pts[vg::sorted_index_at(first_chunk, sort_lds[wave_in_block][0], idx_sorted, s0, len, sp)];
         px = p.x;
         py = p.y;
         pz = p.z;
@@ -414,38 +432,40 @@ size_t map_temp_bytes(size_t n)
   return best + 256;
 }
 
+size_t map_group_bytes(size_t n) { return vg::layout(n).bytes; }
+
 hipError_t launch_map_insert_prepare(const MapArrays & m, const float * src, uint32_t n, uint32_t stride_floats, const float * Rt12,
                                      double inv_leaf, const InsertScratch & s, hipStream_t stream)
 {
-  const dim3 g(grid_for(n)), b(kT);
-  hipLaunchKernelGGL(map_keys_kernel, g, b, 0, stream, src, n, stride_floats, Rt12, inv_leaf, s.pts, s.keys_a, s.idx_a, s.newflag, m.state);
-  size_t tb = s.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(s.temp, tb, s.keys_a, s.keys_b, s.idx_a, s.idx_b, static_cast<size_t>(n), 0, 3 * kVoxCoordBits, stream);
+  const vg::Layout L = vg::layout(n);
+  const vg::Buffers B = vg::carve(s.group, n);
+  hipError_t e = hipMemsetAsync(s.group, 0xFF, L.clear_bytes, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(map_head_flags_kernel, g, b, 0, stream, s.keys_b, n, s.flags);
-  if ((e = exclusive_sum(s.flags, s.pos, n, s.temp, s.temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(map_segments_kernel, g, b, 0, stream, m, s.keys_b, s.idx_b, s.flags, s.pos, n, s.seg_start, s.seg_vid, s.newflag);
-  if ((e = exclusive_sum(s.newflag, s.newrank, n, s.temp, s.temp_bytes, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(map_new_ids_kernel, g, b, 0, stream, m, s.idx_b, s.seg_start, n, s.newflag, s.newrank, s.seg_vid);
+  const dim3 g((n + kT - 1) / kT), b(kT);
+  hipLaunchKernelGGL(map_assign_kernel, g, b, 0, stream, src, n, stride_floats, Rt12, inv_leaf, s.pts, B.h, B.slot_of, m.state);
+  if ((e = vg::launch_group(B, n, &m.state->n_segments, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(map_lookup_kernel, g, b, 0, stream, m, B.h, B.vox_slot, s.seg_vid, s.blk_new);  // <= n segments
+  hipLaunchKernelGGL(map_new_ids_kernel, g, b, 0, stream, m, s.blk_new, s.seg_vid);
   return hipGetLastError();
 }
 
 hipError_t launch_map_create_voxels(const MapArrays & m, uint32_t n, uint32_t n_voxels_before, unsigned long long lru_counter,
                                     const InsertScratch & s, hipStream_t stream)
 {
-  hipLaunchKernelGGL(map_create_voxels_kernel, dim3(grid_for(n)), dim3(kT), 0, stream, m, s.keys_b, s.seg_start, s.seg_vid, n_voxels_before,
-                     lru_counter);
+  const vg::Buffers B = vg::carve(s.group, n);
+  hipLaunchKernelGGL(map_create_voxels_kernel, dim3(grid_for(n)), dim3(kT), 0, stream, m, B.h, B.vox_slot, s.seg_vid, n_voxels_before, lru_counter);
   return hipGetLastError();
 }
 
 hipError_t launch_map_insert_points(const MapArrays & m, uint32_t n, uint32_t n_voxels_after, uint32_t max_pts, double min_sq,
                                     double inv_leaf, unsigned long long lru_counter, const InsertScratch & s, hipStream_t stream)
 {
+  const vg::Buffers B = vg::carve(s.group, n);
   const size_t waves = static_cast<size_t>(n);  // <= one wave per point (segments <= points)
   const int grid = static_cast<int>(std::min<size_t>((waves * 64 + kT - 1) / kT, 16384));
-  hipLaunchKernelGGL(map_insert_points_kernel, dim3(grid > 0 ? grid : 1), dim3(kT), 0, stream, m, s.pts, s.idx_b, s.seg_start, s.seg_vid, s.flags,
-                     max_pts, min_sq, inv_leaf, lru_counter);
-  hipLaunchKernelGGL(map_totals_kernel, dim3(1), dim3(1024), 0, stream, m, s.flags, n_voxels_after);
+  hipLaunchKernelGGL(map_insert_points_kernel, dim3(grid > 0 ? grid : 1), dim3(kT), 0, stream, m, s.pts, B.idx_unsorted, B.idx_sorted, B.idx_tmp,
+                     B.seg, s.seg_vid, s.seg_added, max_pts, min_sq, inv_leaf, lru_counter);
+  hipLaunchKernelGGL(map_totals_kernel, dim3(1), dim3(1024), 0, stream, m, s.seg_added, n_voxels_after);
   return hipGetLastError();
 }
 

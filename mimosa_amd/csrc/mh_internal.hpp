@@ -319,7 +319,7 @@ struct mh_map
   uint32_t n_voxels = 0, n_blocks = 0;
   uint64_t n_points = 0, lru_counter = 0;
   // insert scratch (grown on demand, reused)
-  DevBuf s_in, s_pts, s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_flags, s_pos, s_seg_start, s_seg_vid, s_newflag, s_newrank, s_temp, s_rt, s_shard;
+  DevBuf s_in, s_pts, s_group, s_seg_vid, s_seg_added, s_blk_new, s_flags, s_pos, s_temp, s_rt, s_shard;
   void * h_in = nullptr;  // pinned staging of a host batch
   size_t h_in_cap = 0;
   int64_t inserts = 0, upload_bytes = 0, purges = 0;
