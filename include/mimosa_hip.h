@@ -448,6 +448,11 @@ void mh_photo_factor_destroy(mh_photo_factor * factor);
  * form (NULL otherwise).  Blocks until the result is on the host. */
 int mh_photo_factor_linearize(mh_photo_factor * factor, const double R_b[9], const double t_b[3], const double * R_a,
                               const double * t_a, mh_photo_result * out);
+/* The same enqueued on the context stream without waiting: the smoother can queue it next to mh_icp_linearize_batch and
+ * collect both; mh_photo_factor_wait blocks and fills *out.  One call in flight per factor. */
+int mh_photo_factor_linearize_async(mh_photo_factor * factor, const double R_b[9], const double t_b[3], const double * R_a,
+                                    const double * t_a);
+int mh_photo_factor_wait(mh_photo_factor * factor, mh_photo_result * out);
 /* getStatuses / getFeatures().center after the last linearize; rows (optional, parity tooling): per feature and
  * patch point {whitened residual, J_b[6], valid} = 8 doubles, 64 points per feature. */
 int mh_photo_factor_get_state(const mh_photo_factor * factor, int32_t * statuses, double * centers, double * rows);

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
-    "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_get_state", "mh_photo_factor_size",
+    "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_linearize_async", "mh_photo_factor_wait", "mh_photo_factor_get_state", "mh_photo_factor_size",
 ]
 
 
@@ -323,6 +323,8 @@ def load(build_if_missing: bool = True):
     L.mh_photo_update_map.argtypes = [vp, vp, vp, vp, vp, sz]
     L.mh_photo_factor_create.argtypes = [vp, vp, i32, pvp]
     L.mh_photo_factor_clone.argtypes = [vp, pvp]
+    L.mh_photo_factor_linearize_async.argtypes = [vp, vp, vp, vp, vp]
+    L.mh_photo_factor_wait.argtypes = [vp, vp]
     L.mh_photo_factor_destroy.argtypes = [vp]
     L.mh_photo_factor_destroy.restype = None
     L.mh_photo_factor_linearize.argtypes = [vp, vp, vp, vp, vp, C.POINTER(PhotoResult)]
@@ -773,6 +775,17 @@ class PhotoFactor:
         Ra = _f64(R_a) if R_a is not None else None
         ta = _f64(t_a) if t_a is not None else None
         self.ctx.check(self.L.mh_photo_factor_linearize(self.h, _p(Rb), _p(tb), _p(Ra), _p(ta), C.byref(out)))
+        return out.as_dict()
+
+    def linearize_async(self, R_b, t_b, R_a=None, t_a=None):
+        Rb, tb = _f64(R_b), _f64(t_b)
+        Ra = _f64(R_a) if R_a is not None else None
+        ta = _f64(t_a) if t_a is not None else None
+        self.ctx.check(self.L.mh_photo_factor_linearize_async(self.h, _p(Rb), _p(tb), _p(Ra), _p(ta)))
+
+    def wait(self) -> dict:
+        out = PhotoResult()
+        self.ctx.check(self.L.mh_photo_factor_wait(self.h, C.byref(out)))
         return out.as_dict()
 
     def clone(self) -> "PhotoFactor":

@@ -89,6 +89,7 @@ struct mh_photo_factor
   void * h_out = nullptr;
   void * d_out = nullptr;  // device address of h_out
   size_t out_bytes = 0;
+  bool pending = false, pending_timed = false;  // a linearize is enqueued and not yet collected
   std::vector<int32_t> statuses;
   std::vector<double> centers, partials, rows;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -922,12 +923,11 @@ void mh_photo_factor_destroy(mh_photo_factor * f)
 
 size_t mh_photo_factor_size(const mh_photo_factor * f) { return f ? f->features.size() : 0; }
 
-int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const double t_b[3], const double * R_a, const double * t_a,
-                              mh_photo_result * out)
+static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], const double t_b[3], const double * R_a, const double * t_a)
 {
-  if (!f || !R_b || !t_b || !out) return fail(f ? f->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: NULL argument");
   mh_ctx * ctx = f->photo->ctx;
-  return guarded(ctx, "mh_photo_factor_linearize", [&]() -> int {
+  const bool timed = ctx->profiling > 0;
+  {
     if (f->binary && (!R_a || !t_a)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: the binary factor needs T_a");
     MH_HIP(ctx, hipSetDevice(ctx->device));
     const mh_photo_config & c = f->photo->cfg;
@@ -984,7 +984,6 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
     a.rows_out = static_cast<double *>(f->d_rows.p);
     a.counters = f->photo->d_counters;
     f->photo->h_counters->project_throw = f->photo->h_counters->pose_missing = 0;
-    const bool timed = ctx->profiling > 0;
     if (timed && !f->ev[0]) {
       MH_HIP(ctx, hipEventCreate(&f->ev[0]));
       MH_HIP(ctx, hipEventCreate(&f->ev[1]));
@@ -992,6 +991,21 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[0], ctx->stream));
     MH_HIP(ctx, mh::launch_photo_linearize(a, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(f->ev[1], ctx->stream));
+  }
+  f->pending_timed = timed;
+  f->pending = true;
+  return MH_OK;
+}
+
+static int photo_linearize_finish(mh_photo_factor * f, mh_photo_result * out)
+{
+  mh_ctx * ctx = f->photo->ctx;
+  const mh_photo_config & c = f->photo->cfg;
+  (void)c;
+  const size_t nf = f->features.size();
+  const bool timed = f->pending_timed;
+  f->pending = false;
+  {
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the end of the kernel makes its host writes visible
     const double * new_centers = static_cast<const double *>(f->h_out);
     f->partials.assign(new_centers + 2 * nf, new_centers + 2 * nf + nf * mh::kPhotoPartial);
@@ -1059,6 +1073,38 @@ int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const do
     mh::compute_localizability(Hr, out->loc_rot_final, out->eigvec_rot);
     mh::compute_localizability(Ht, out->loc_trans_final, out->eigvec_trans);
     return MH_OK;
+  }
+}
+
+int mh_photo_factor_linearize(mh_photo_factor * f, const double R_b[9], const double t_b[3], const double * R_a, const double * t_a,
+                              mh_photo_result * out)
+{
+  if (!f || !R_b || !t_b || !out) return fail(f ? f->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: NULL argument");
+  mh_ctx * ctx = f->photo->ctx;
+  return guarded(ctx, "mh_photo_factor_linearize", [&]() -> int {
+    if (f->pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: a call is in flight (mh_photo_factor_wait first)");
+    const int rc = photo_linearize_enqueue(f, R_b, t_b, R_a, t_a);
+    return rc != MH_OK ? rc : photo_linearize_finish(f, out);
+  });
+}
+
+int mh_photo_factor_linearize_async(mh_photo_factor * f, const double R_b[9], const double t_b[3], const double * R_a, const double * t_a)
+{
+  if (!f || !R_b || !t_b) return fail(f ? f->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize_async: NULL argument");
+  mh_ctx * ctx = f->photo->ctx;
+  return guarded(ctx, "mh_photo_factor_linearize_async", [&]() -> int {
+    if (f->pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize_async: a call is already in flight");
+    return photo_linearize_enqueue(f, R_b, t_b, R_a, t_a);
+  });
+}
+
+int mh_photo_factor_wait(mh_photo_factor * f, mh_photo_result * out)
+{
+  if (!f || !out) return fail(f ? f->photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_factor_wait: NULL argument");
+  mh_ctx * ctx = f->photo->ctx;
+  return guarded(ctx, "mh_photo_factor_wait", [&]() -> int {
+    if (!f->pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_wait: no call in flight");
+    return photo_linearize_finish(f, out);
   });
 }
 

@@ -116,21 +116,22 @@ public:
     mh_photo_result r;
     ctx_->check(mh_photo_factor_linearize(f_, Tb.R.data(), Tb.t.data(), Ta ? Ta->R.data() : nullptr, Ta ? Ta->t.data() : nullptr, &r),
                 "mh_photo_factor_linearize");
-    if (r.n_exceptions > 0)  // project(): "invalid x coordinate" (photometric_utils.cpp:90-97) / interpolated_map_T_Le_Lt.at()
-      throw std::runtime_error("PhotometricFactor::linearize: " + std::to_string(r.n_exceptions) +
-                               " feature(s) hit a condition the reference throws on");
-    last_ = r;
-    auto h = std::make_shared<HessianFactor>();
-    h->keys = keys();
-    std::memcpy(h->G11.data(), r.H_bb, sizeof(r.H_bb));
-    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_b[i];  // HessianFactor(key, H_bb, -b_b, f), :332-353
-    h->f = r.f;
-    if (is_binary_) {
-      std::memcpy(h->G12.data(), r.H_ba, sizeof(r.H_ba));
-      std::memcpy(h->G22.data(), r.H_aa, sizeof(r.H_aa));
-      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_a[i];
-    }
-    return h;
+    return toHessian(r);
+  }
+
+  // linearize() split in two so that the smoother can queue it next to ICPFactor::linearizeBatch on the same stream
+  void linearizeAsync(const Values & c) const
+  {
+    const Pose3 & Tb = c.atPose3(keys()[0]);
+    const Pose3 * Ta = is_binary_ ? &c.atPose3(keys()[1]) : nullptr;
+    ctx_->check(mh_photo_factor_linearize_async(f_, Tb.R.data(), Tb.t.data(), Ta ? Ta->R.data() : nullptr, Ta ? Ta->t.data() : nullptr),
+                "mh_photo_factor_linearize_async");
+  }
+  std::shared_ptr<GaussianFactor> collect() const
+  {
+    mh_photo_result r;
+    ctx_->check(mh_photo_factor_wait(f_, &r), "mh_photo_factor_wait");
+    return toHessian(r);
   }
 
   std::vector<RejectStatus> getStatuses() const  // :49
@@ -161,6 +162,24 @@ public:
 
 private:
   friend class Photometric;
+  std::shared_ptr<HessianFactor> toHessian(const mh_photo_result & r) const
+  {
+    if (r.n_exceptions > 0)  // project(): "invalid x coordinate" (photometric_utils.cpp:90-97) / interpolated_map_T_Le_Lt.at()
+      throw std::runtime_error("PhotometricFactor::linearize: " + std::to_string(r.n_exceptions) +
+                               " feature(s) hit a condition the reference throws on");
+    last_ = r;
+    auto h = std::make_shared<HessianFactor>();
+    h->keys = keys();
+    std::memcpy(h->G11.data(), r.H_bb, sizeof(r.H_bb));
+    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_b[i];  // HessianFactor(key, H_bb, -b_b, f), :332-353
+    h->f = r.f;
+    if (is_binary_) {
+      std::memcpy(h->G12.data(), r.H_ba, sizeof(r.H_ba));
+      std::memcpy(h->G22.data(), r.H_aa, sizeof(r.H_aa));
+      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_a[i];
+    }
+    return h;
+  }
   PhotometricFactor(std::shared_ptr<Context> ctx, std::vector<Key> keys, bool is_binary)
   : NonlinearFactor(std::move(keys)), ctx_(std::move(ctx)), is_binary_(is_binary)
   {

@@ -268,6 +268,7 @@ public:
           factors[i] = win[i].f;
           v.insert(static_cast<Key>(win[i].k), win[i].T);
         }
+        if (pf) pf->linearizeAsync(v);  // queued ahead of the window: one wait for both
         const auto lin = ICPFactor::linearizeBatch(factors, v);
         std::vector<double> A(dim * dim, 0.0), g(dim, 0.0);
         double cost = 0.0;
@@ -280,7 +281,7 @@ public:
           cost += h.f;
         }
         if (pf) {
-          const auto hp = std::static_pointer_cast<HessianFactor>(pf->linearize(v));
+          const auto hp = std::static_pointer_cast<HessianFactor>(pf->collect());
           bool finite = pf->lastResult().status_hist[8] > 0;
           for (int q = 0; q < 36 && finite; ++q) finite = std::isfinite(hp->G11[q]);
           for (int q = 0; q < 6 && finite; ++q) finite = std::isfinite(hp->g1[q]);

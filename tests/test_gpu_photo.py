@@ -144,6 +144,13 @@ def test_unary_factor_parity(ctx, frames):
     gr, rr = gf2.linearize(R, t), rf2.linearize(R, t)
     assert np.array_equal(gr["status_hist"], rr["status_hist"])
     assert rel(gr["H_bb"], rr["H_bb"]) <= 1e-5 and rel(gr["b_b"], rr["b_b"]) <= 1e-5
+    # the enqueue / collect split (what the smoother uses next to mh_icp_linearize_batch) == the blocking call
+    gf2.linearize_async(R, t)
+    with pytest.raises(Exception, match="in flight"):
+        gf2.linearize_async(R, t)
+    ga = gf2.wait()
+    assert np.array_equal(ga["H_bb"], gr["H_bb"]) and np.array_equal(ga["b_b"], gr["b_b"]) and ga["f"] == gr["f"]
+    assert np.array_equal(ga["status_hist"], gr["status_hist"])
     # clone() (ISAM2 clones factors): an independent factor on the same frame, same bits; survives its source
     gc = gf2.clone()
     assert np.array_equal(gc.state(rows=False)[0], gf2.state(rows=False)[0])
