@@ -62,3 +62,81 @@ def test_random_configuration(ctx, seed):
         R = R @ synth.so3_exp(rng.normal(0, 1.0, 3) * thr / 5.0)
     gf.destroy()
     gm.release()
+
+
+def _random_cloud(rng, n):
+    """Points with every kind of voxel population: uniform background, tight clusters (hundreds to thousands of points in one
+    voxel), exact duplicates, points on voxel faces, a few far away."""
+    xyz = rng.uniform(-30.0, 30.0, size=(n, 3))
+    for _ in range(int(rng.integers(1, 6))):
+        m = min(n, int(rng.integers(50, max(51, n // 4))))
+        c = rng.uniform(-20, 20, 3)
+        sel = rng.permutation(n)[:m]
+        xyz[sel] = c + rng.uniform(0, float(rng.choice([0.05, 0.4, 1.5])), size=(m, 3))
+    dup = rng.permutation(n)[: n // 20]
+    xyz[dup] = xyz[rng.permutation(n)[: len(dup)]]
+    face = rng.permutation(n)[: n // 50]
+    xyz[face] = np.round(xyz[face] * 2.0) / 2.0               # exactly on 0.5 m voxel boundaries
+    return xyz.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scan_frontend(ctx, seed):
+    """prepareInput -> preprocess on random clouds and filter settings: same points, same order, same bits as the oracle."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 20000]))
+    raw = np.zeros(n, dtype=synth.OUSTER_DTYPE)
+    xyz = _random_cloud(rng, n)
+    raw["x"], raw["y"], raw["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    raw["intensity"] = rng.uniform(0, 2000, n).astype(np.float32)
+    raw["t"] = rng.integers(0, int(rng.choice([3, 200, 5000, 2**31])), n, dtype=np.uint32)
+    raw["ring"] = rng.integers(0, 64, n).astype(np.uint16)
+    bad = rng.permutation(n)[: n // 30]
+    raw["x"][bad] = np.nan
+    kw = dict(point_skip_divisor=int(rng.choice([1, 2, 3])), ring_skip_divisor=int(rng.choice([1, 2])),
+              range_min=float(rng.choice([0.0, 2.0])), range_max=float(rng.choice([25.0, 100.0])),
+              intensity_min=float(rng.choice([0.0, 300.0])), create_full_res_pointcloud=int(rng.integers(0, 2)), ns_max=1.0e10)
+    leaf, min_dist = float(rng.choice([0.25, 0.5, 1.0])), float(rng.choice([0.0, 0.05, 0.15]))
+    R = synth.so3_exp(rng.normal(0, 0.3, 3)).astype(np.float32)
+    tt = rng.normal(0, 0.5, 3).astype(np.float32)
+    o = ref_cpu.prepare_input(raw, ref_cpu.make_input_config(**kw))
+    full = np.frombuffer(np.ascontiguousarray(o["points_full"]).tobytes(), dtype=synth.POINT_DTYPE)
+    body = ref_cpu.transform_f32(full[o["geometric_idxs"].astype(np.int64)], R, tt)
+    kept = ref_cpu.downsample(body, leaf, 20, min_dist)
+    sc = capi.Scan(ctx)
+    info = sc.prepare_input(raw, capi.make_input_config(**kw))
+    assert info["n_full"] == len(full) and info["n_geometric"] == len(o["geometric_idxs"]) and info["last_point_ns"] == o["last_point_ns"]
+    assert np.array_equal(sc.unique_ns(), o["unique_ns"])
+    assert sc.points(capi.Scan.FULL).tobytes() == full.tobytes()
+    assert np.array_equal(sc.indices(0), o["geometric_idxs"].astype(np.uint32))
+    info = sc.preprocess_geometric(R, tt, leaf, 20, min_dist)
+    assert info["n_downsampled"] == len(kept)
+    assert np.array_equal(sc.indices(1), kept)
+    assert sc.points(capi.Scan.DOWNSAMPLED).tobytes() == body[kept].tobytes()
+    sc.destroy()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_map_insert_sequences(ctx, seed):
+    """iVox insert + LRU purge over random batch sequences (clusters that saturate voxels, duplicates, boundary points, tiny and
+    large batches): getCloud — points AND order — equals the oracle's after every insert."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    rng = np.random.default_rng(9000 + seed)
+    leaf, md = float(rng.choice([0.3, 0.5, 1.0])), float(rng.choice([0.0, 0.05, 0.15]))
+    horizon, cycle = int(rng.choice([2, 3, 1000])), int(rng.choice([2, 3, 10]))
+    gm = capi.VoxelMap(ctx, leaf=leaf, min_dist=md, mode=19, lru_horizon=horizon, lru_clear_cycle=cycle)
+    rm = ref_cpu.Map(leaf=leaf, min_dist=md, mode=19, lru_horizon=horizon)
+    rm.set_lru_clear_cycle(cycle)
+    for b in range(7):
+        n = int(rng.choice([1, 5, 64, 700, 5000, 30000]))
+        xyz = _random_cloud(rng, n) + np.float32(rng.choice([0.0, 0.0, 15.0]))   # some batches land somewhere new
+        gm.insert(xyz)
+        rm.insert(xyz)
+        assert gm.stats()["n_points"] == rm.num_points, b
+        assert np.array_equal(gm.get_cloud(), rm.export()[2]), b
+    gm.release()
