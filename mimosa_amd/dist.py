@@ -84,12 +84,12 @@ def exchange_counts(dist, comm, send_counts, device):
     or skip TOGETHER — runs at all; a rank's own row and column alone cannot tell (A idle while B sends to C)."""
     import torch
     world, rank = dist.get_world_size(comm), dist.get_rank(comm)
-    sc = torch.as_tensor(np.asarray(send_counts, np.int64))
+    m = torch.zeros((world, world), dtype=torch.int64)
+    m[rank] = torch.as_tensor(np.asarray(send_counts, np.int64))
     if dist.get_backend(comm) != "gloo":
-        sc = sc.to(device)
-    rows = [torch.empty_like(sc) for _ in range(world)]
-    dist.all_gather(rows, sc, group=comm)
-    m = torch.stack(rows).cpu().numpy()
+        m = m.to(device)
+    dist.all_reduce(m, op=dist.ReduceOp.SUM, group=comm)   # every rank contributes its own row: the cheapest collective there is
+    m = m.cpu().numpy()
     return m[:, rank].copy(), int(m.sum())
 
 
