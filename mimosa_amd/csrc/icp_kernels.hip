@@ -30,6 +30,9 @@
 
 #include "icp_device.hpp"
 
+#ifndef MH_PRUNE_TRIPS
+#define MH_PRUNE_TRIPS (trip == 1 || trip == 2)  // when the scan loop re-applies the box-distance pruning
+#endif
 #ifndef MH_PIPE
 #define MH_PIPE 4  // quads in flight per lane in the neighbour scan (knn_query)
 #endif
@@ -471,7 +474,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #endif
     for (int trip = 0;; ++trip) {
       if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
-      if (trip == 1 || trip == 2) {
+      if (MH_PRUNE_TRIPS) {
         const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
         cur.rem &= keep;
         alive &= keep;
