@@ -298,6 +298,38 @@ void mh_scan_destroy(mh_scan * scan);
  * z offset, points_full_ (order preserved), geometric subset indices, distinct timestamps (ascending). */
 int mh_scan_prepare_input(mh_scan * scan, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg,
                           mh_scan_info * info);
+/* Manager::prepareInput<PointT> for the reference's OTHER point types (include/mimosa/lidar/point.hpp:52-131:
+ * PointOusterOdyssey, PointOusterR8, PointHesai, PointLivox, PointLivoxFromCustom2, PointVelodyne,
+ * PointVelodyneAnybotics, PointRslidar) — and PointOuster itself — described by where the fields sit in a record,
+ * i.e. what the sensor_msgs::PointCloud2 `fields` array says.  The per-type branches of the reference are selected by the
+ * layout: time decoding (lidar/manager.cpp:285-304), reflectivity as intensity (:265-271), the Livox tag filter
+ * (:256-262), whether the ring filter applies (:321-332); `transpose` (:177-203, RSAiry / VelodyneAnybotics) and
+ * `organize_by_ring` (:205-241, applied when height == 1 and the layout has a ring field, as there; ring numbers must be
+ * < 128, the size of the reference's tables, else MH_ERR_UNSUPPORTED) reorder the cloud first.  width * height = n.
+ * The double -> uint32 time conversions follow the reference's x86-64 build (truncate to 64 bits, keep the low word). */
+typedef enum mh_time_kind {
+  MH_TIME_U32_NS = 0,     /* t_ns = t                                    PointOuster*, PointLivoxFromCustom2 */
+  MH_TIME_F64_S_ABS = 1,  /* t_ns = (timestamp - header_ts) * 1e9        PointHesai, PointRslidar */
+  MH_TIME_F64_NS_ABS = 2, /* t_ns = timestamp - header_ts * 1e9          PointLivox */
+  MH_TIME_F32_S = 3       /* t_ns = time * 1e9                           PointVelodyne, PointVelodyneAnybotics */
+} mh_time_kind;
+typedef enum mh_ring_kind { MH_RING_NONE = 0, MH_RING_U16 = 1, MH_RING_U8 = 2, MH_RING_F32 = 3 } mh_ring_kind;
+typedef struct mh_point_layout {
+  uint32_t stride;                  /* bytes per record */
+  uint32_t off_x, off_y, off_z;     /* float */
+  uint32_t off_intensity;           /* float intensity, or uint16 reflectivity when intensity_is_u16 (PointOusterOdyssey) */
+  int32_t intensity_is_u16;
+  uint32_t off_time;
+  int32_t time_kind;                /* mh_time_kind */
+  uint32_t off_ring;
+  int32_t ring_kind;                /* mh_ring_kind: the field organize_by_ring and the ring filter read */
+  int32_t ring_filter;              /* 0: `ring % ring_skip_divisor` is not applied (Livox, VelodyneAnybotics, OusterOdyssey) */
+  uint32_t off_tag;                 /* uint8 Livox tag */
+  int32_t has_tag;                  /* keep only (tag & 0x30) == 0x10 or 0x00 */
+} mh_point_layout;
+int mh_scan_prepare_input_layout(mh_scan * scan, const void * raw, size_t n, const mh_point_layout * layout, uint32_t width,
+                                 uint32_t height, int transpose, int organize_by_ring, double header_ts,
+                                 const mh_input_config * cfg, mh_scan_info * info);
 /* Same, for a raw cloud that is already in device memory (a driver that DMAs packets to the GPU, or a benchmark that
  * wants the figure without the PCIe upload): d_raw must stay valid and unchanged until the call returns. */
 int mh_scan_prepare_input_device(mh_scan * scan, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg,

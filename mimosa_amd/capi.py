@@ -25,7 +25,7 @@ EXPORTS = [
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
-    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_get_unique_ns", "mh_scan_deskew",
+    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_prepare_input_layout", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
@@ -106,6 +106,57 @@ class InputConfig(C.Structure):
         ("ns_max", C.c_float), ("z_offset", C.c_float), ("create_full_res_pointcloud", C.c_int32),
         ("point_skip_divisor", C.c_int32), ("ring_skip_divisor", C.c_int32),
     ]
+
+
+class PointLayout(C.Structure):
+    """mh_point_layout: where the fields of a sensor's point record sit (what PointCloud2.fields says)."""
+    _fields_ = [
+        ("stride", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32), ("off_z", C.c_uint32), ("off_intensity", C.c_uint32),
+        ("intensity_is_u16", C.c_int32), ("off_time", C.c_uint32), ("time_kind", C.c_int32), ("off_ring", C.c_uint32),
+        ("ring_kind", C.c_int32), ("ring_filter", C.c_int32), ("off_tag", C.c_uint32), ("has_tag", C.c_int32),
+    ]
+
+
+TIME_U32_NS, TIME_F64_S_ABS, TIME_F64_NS_ABS, TIME_F32_S = 0, 1, 2, 3
+RING_NONE, RING_U16, RING_U8, RING_F32 = 0, 1, 2, 3
+
+
+def _dt(stride, **fields):
+    names, formats, offsets = zip(*[(k, f, o) for k, (f, o) in fields.items()])
+    return np.dtype({"names": list(names), "formats": list(formats), "offsets": list(offsets), "itemsize": stride})
+
+
+# The reference's point types (include/mimosa/lidar/point.hpp:40-131, EIGEN_ALIGN16 structs): numpy record dtype with the
+# members at their C++ offsets, and the mh_point_layout that selects the same branches of Manager::prepareInput<PointT>.
+POINT_TYPES = {
+    "ouster": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), t=("u4", 20), reflectivity=("u2", 24), ring=("u2", 26)),
+               dict(off_intensity=16, off_time=20, time_kind=TIME_U32_NS, off_ring=26, ring_kind=RING_U16, ring_filter=1)),
+    "ouster_odyssey": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), t=("u4", 16), reflectivity=("u2", 20), near_ir=("u2", 22)),
+                       dict(off_intensity=20, intensity_is_u16=1, off_time=16, time_kind=TIME_U32_NS)),
+    "ouster_r8": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), t=("u4", 20), reflectivity=("u2", 24), ring=("u1", 26)),
+                  dict(off_intensity=16, off_time=20, time_kind=TIME_U32_NS, off_ring=26, ring_kind=RING_U8, ring_filter=1)),
+    "hesai": (_dt(48, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), timestamp=("f8", 24), ring=("u2", 32)),
+              dict(off_intensity=16, off_time=24, time_kind=TIME_F64_S_ABS, off_ring=32, ring_kind=RING_U16, ring_filter=1)),
+    "livox": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), tag=("u1", 20), line=("u1", 21), timestamp=("f8", 24)),
+              dict(off_intensity=16, off_time=24, time_kind=TIME_F64_NS_ABS, off_tag=20, has_tag=1)),
+    "livox_custom2": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), t=("u4", 12), intensity=("f4", 16), tag=("u1", 20), line=("u1", 21)),
+                      dict(off_intensity=16, off_time=12, time_kind=TIME_U32_NS, off_tag=20, has_tag=1)),
+    "velodyne": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), ring=("u2", 20), time=("f4", 24)),
+                 dict(off_intensity=16, off_time=24, time_kind=TIME_F32_S, off_ring=20, ring_kind=RING_U16, ring_filter=1)),
+    "velodyne_anybotics": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), ring=("f4", 20), time=("f4", 24)),
+                           dict(off_intensity=16, off_time=24, time_kind=TIME_F32_S, off_ring=20, ring_kind=RING_F32, ring_filter=0)),
+    "rslidar": (_dt(32, x=("f4", 0), y=("f4", 4), z=("f4", 8), intensity=("f4", 16), ring=("u2", 20), timestamp=("f8", 24)),
+                dict(off_intensity=16, off_time=24, time_kind=TIME_F64_S_ABS, off_ring=20, ring_kind=RING_U16, ring_filter=1)),
+}
+
+
+def point_dtype(kind: str) -> np.dtype:
+    return POINT_TYPES[kind][0]
+
+
+def point_layout(kind: str) -> PointLayout:
+    dt, f = POINT_TYPES[kind]
+    return PointLayout(stride=dt.itemsize, off_x=0, off_y=4, off_z=8, **f)
 
 
 class ScanInfo(C.Structure):
@@ -292,6 +343,8 @@ def load(build_if_missing: bool = True):
     L.mh_scan_destroy.argtypes = [vp]
     L.mh_scan_destroy.restype = None
     L.mh_scan_prepare_input.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
+    L.mh_scan_prepare_input_layout.argtypes = [vp, vp, sz, C.POINTER(PointLayout), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double,
+                                               C.POINTER(InputConfig), C.POINTER(ScanInfo)]
     L.mh_scan_prepare_input_device.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
     L.mh_scan_get_unique_ns.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.mh_scan_deskew.argtypes = [vp, vp, sz]
@@ -495,6 +548,18 @@ class Scan:
         assert raw.dtype.itemsize == 32
         info = ScanInfo()
         self.ctx.check(self.L.mh_scan_prepare_input(self.h, _p(raw), len(raw), C.byref(cfg), C.byref(info)))
+        return info.as_dict()
+
+    def prepare_input_layout(self, raw, layout: PointLayout, cfg: InputConfig, width=None, height=1, transpose=False, organize_by_ring=False,
+                             header_ts=0.0) -> dict:
+        """Manager::prepareInput<PointT> for any point record described by `layout` (see POINT_TYPES)."""
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype.itemsize == layout.stride
+        n = len(raw)
+        width = n if width is None else width
+        info = ScanInfo()
+        self.ctx.check(self.L.mh_scan_prepare_input_layout(self.h, _p(raw), n, C.byref(layout), width, height, int(transpose),
+                                                           int(organize_by_ring), header_ts, C.byref(cfg), C.byref(info)))
         return info.as_dict()
 
     def prepare_input_device(self, d_raw_ptr: int, n: int, cfg: InputConfig) -> dict:

@@ -1117,14 +1117,14 @@ void mh_scan_destroy(mh_scan * s)
   (void)hipStreamSynchronize(s->ctx->stream);
   s->d_full_raw.release(true);
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
-                     &s->d_rt, &s->d_prep, &s->d_vox})
+                     &s->d_rt, &s->d_prep, &s->d_vox, &s->d_sensor})
     b->release(true);
   AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t));
   delete s;
 }
 
 static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool raw_on_device, size_t n, const mh_input_config * cfg,
-                               mh_scan_info * info, const char * who)
+                               mh_scan_info * info, const char * who, bool canonical = false, bool ring_filter = true)
 {
   if (!s || !cfg || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
   mh_ctx * ctx = s->ctx;
@@ -1151,7 +1151,7 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
   MH_HIP(ctx, mh::launch_prepare_input(d_raw, static_cast<uint32_t>(n), *cfg, static_cast<uint32_t *>(s->d_prep.p),
                                        static_cast<mh_point32 *>(s->d_full.p), static_cast<uint32_t *>(s->d_geo_idx.p),
                                        static_cast<uint32_t *>(s->d_unique.p), static_cast<mh::ScanCounters *>(s->d_counters.p),
-                                       ctx->stream));
+                                       ctx->stream, canonical, ring_filter));
   const int rc = scan_fetch_counters(s, true);
   if (rc != MH_OK) return rc;
   s->prepared = true;
@@ -1162,6 +1162,58 @@ int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, co
 {
   return guarded(nullptr, "mh_scan_prepare_input",
                  [&]() -> int { return scan_prepare_common(s, raw, false, n, cfg, info, "mh_scan_prepare_input"); });
+}
+// Manager::prepareInput<PointT> for any of the reference's point types: decode into canonical records on the device, then
+// the same filter / compaction / timestamp kernels as the PointOuster path.
+static int mh_scan_prepare_input_layout_impl(mh_scan * s, const void * raw, size_t n, const mh_point_layout * L, uint32_t width, uint32_t height,
+                                             int transpose, int organize_by_ring, double header_ts, const mh_input_config * cfg, mh_scan_info * info)
+{
+  const char * who = "mh_scan_prepare_input_layout";
+  if (!s || !cfg || !L || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": cloud too large");
+  if (static_cast<size_t>(width) * height != n) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": width * height must equal n");
+  const uint32_t ends[] = {L->off_x + 4, L->off_y + 4, L->off_z + 4, L->off_intensity + (L->intensity_is_u16 ? 2u : 4u),
+                           L->off_time + (L->time_kind == MH_TIME_U32_NS || L->time_kind == MH_TIME_F32_S ? 4u : 8u),
+                           L->ring_kind == MH_RING_NONE ? 0u : L->off_ring + (L->ring_kind == MH_RING_U8 ? 1u : (L->ring_kind == MH_RING_U16 ? 2u : 4u)),
+                           L->has_tag ? L->off_tag + 1u : 0u};
+  for (const uint32_t e : ends)
+    if (e > L->stride) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": a field lies outside the record");
+  if (L->time_kind < MH_TIME_U32_NS || L->time_kind > MH_TIME_F32_S || L->ring_kind < MH_RING_NONE || L->ring_kind > MH_RING_F32)
+    return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": unknown time / ring kind");
+  if (L->ring_filter && L->ring_kind == MH_RING_NONE) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": the ring filter needs a ring field");
+  const uint32_t height_after = transpose ? width : height;  // the transposed cloud is height x width
+  // :205-210 only an unorganised cloud is re-ordered, and only for the point types that carry a ring (compiled out for
+  // PointLivox, PointLivoxFromCustom2 and PointOusterOdyssey there: the flag is ignored, not an error)
+  const bool organize = organize_by_ring != 0 && height_after == 1 && L->ring_kind != MH_RING_NONE;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t m = n ? n : 1, n_blk = (m + 255) / 256;
+  const size_t raw_bytes = (m * L->stride + 255) & ~size_t(255), tmp_bytes = organize ? m * sizeof(mh_ouster_point) : 0;
+  MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));  // the canonical records
+  MH_HIP(ctx, s->d_sensor.reserve(raw_bytes + tmp_bytes + (organize ? n_blk * 128 * sizeof(uint32_t) : 0) + 256, ctx->stream, false));
+  MH_HIP(ctx, s->d_counters.reserve(sizeof(mh::ScanCounters), ctx->stream, false));
+  char * base = static_cast<char *>(s->d_sensor.p);
+  auto * tmp = reinterpret_cast<mh_ouster_point *>(base + raw_bytes);
+  auto * hist = reinterpret_cast<uint32_t *>(base + raw_bytes + tmp_bytes);
+  uint32_t * bad_ring = reinterpret_cast<uint32_t *>(static_cast<char *>(s->d_counters.p) + offsetof(mh::ScanCounters, bad_coord));
+  MH_HIP(ctx, hipMemsetAsync(s->d_counters.p, 0, sizeof(mh::ScanCounters), ctx->stream));
+  if (n) MH_HIP(ctx, hipMemcpyAsync(base, raw, n * L->stride, hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, mh::launch_decode_points(base, static_cast<uint32_t>(n), *L, width, height, transpose != 0, organize, header_ts,
+                                       static_cast<mh_ouster_point *>(s->d_raw.p), tmp, hist, bad_ring, ctx->stream));
+  if (organize) {  // a ring number beyond the reference's 128-entry tables (undefined behaviour there) is refused
+    uint32_t bad = 0;
+    MH_HIP(ctx, hipMemcpyAsync(&bad, bad_ring, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": organize_by_ring with a ring number >= 128");
+  }
+  return scan_prepare_common(s, static_cast<const mh_ouster_point *>(s->d_raw.p), true, n, cfg, info, who, true, L->ring_filter != 0);
+}
+int mh_scan_prepare_input_layout(mh_scan * s, const void * raw, size_t n, const mh_point_layout * layout, uint32_t width, uint32_t height,
+                                 int transpose, int organize_by_ring, double header_ts, const mh_input_config * cfg, mh_scan_info * info)
+{
+  return guarded(nullptr, "mh_scan_prepare_input_layout", [&]() -> int {
+    return mh_scan_prepare_input_layout_impl(s, raw, n, layout, width, height, transpose, organize_by_ring, header_ts, cfg, info);
+  });
 }
 int mh_scan_prepare_input_device(mh_scan * s, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
 {

@@ -295,6 +295,7 @@ struct mh_scan
   DevBuf d_raw, d_full, d_geo_idx, d_unique, d_body, d_ds, d_kept_idx, d_counters, d_rt;
   DevBuf d_full_raw;  // points_raw_ (lidar/manager.cpp:376-380): points_full_ as it was before deskewing, kept for the photometric path
   bool keep_raw = false, raw_valid = false;
+  DevBuf d_sensor;       // other sensors (mh_scan_prepare_input_layout): raw records, organise-by-ring scratch
   DevBuf d_prep, d_vox;  // scratch of launch_prepare_input / launch_preprocess (scan_device.hpp: prepare_layout, voxel_layout)
   mh::ScanCounters * h_c = nullptr;  // pinned landing buffer: the device counters, then the first kUniqueCached distinct timestamps
   static constexpr size_t kUniqueCached = 4096;

@@ -44,7 +44,14 @@ VoxelLayout voxel_layout(size_t n);
 // ascending distinct timestamps into unique_ns (capacity n + 1).  3 kernels; zeroes the counters first.
 hipError_t launch_prepare_input(const mh_ouster_point * raw, uint32_t n, const mh_input_config & cfg, uint32_t * scratch,
                                 mh_point32 * points_full, uint32_t * geo_idx, uint32_t * unique_ns, ScanCounters * counters,
-                                hipStream_t stream);
+                                hipStream_t stream, bool canonical = false, bool ring_filter = true);
+// Any sensor's records (device memory, n * layout.stride bytes) -> canonical PointOuster-shaped records in the order the
+// reference's loop sees them: transposed (lidar/manager.cpp:177-203), then organised by ring (:205-241).  canonical
+// `reflectivity` bit 0 = rejected by the Livox tag test.  tmp: n records (organize only); hist: 128 x ceil(n / 256) words;
+// *bad_ring != 0 afterwards: a ring number >= 128 occurred.
+hipError_t launch_decode_points(const void * raw, uint32_t n, const mh_point_layout & layout, uint32_t width, uint32_t height, bool transpose,
+                                bool organize_by_ring, double header_ts, mh_ouster_point * canon, mh_ouster_point * tmp, uint32_t * hist,
+                                uint32_t * bad_ring, hipStream_t stream);
 // Geometric::preprocess (geometric.cpp:154-161): body[j] = R * points_full[geo_idx[j]] + t in f32, then
 // Geometric::downsample (geometric.cpp:55-126) + FlatContainerMinimal::add (lidar/utils.hpp:260-278): kept_idx
 // (indices into body) and out = body[kept_idx], in the reference's output order.  1 memset + 7 kernels.

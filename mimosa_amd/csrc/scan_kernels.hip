@@ -62,6 +62,8 @@ struct FilterParams
 {
   float range_min_sq, range_max_sq, intensity_min, intensity_max, ns_max, z_offset;
   uint32_t stride, point_skip, ring_skip;
+  uint32_t canonical;    // the records came out of decode_points_kernel: `reflectivity` carries its reject flag
+  uint32_t ring_filter;  // the ring filter applies to this sensor (lidar/manager.cpp:321-332)
 };
 
 __device__ __forceinline__ float range_sq_of(const mh_ouster_point & p) { return p.x * p.x + p.y * p.y + p.z * p.z; }
@@ -75,8 +77,9 @@ __device__ __forceinline__ uint32_t filter_point(const mh_ouster_point & p, uint
   const float r2 = range_sq_of(p);
   keep = keep && !(r2 < f.range_min_sq || r2 > f.range_max_sq);                       // :281-282
   keep = keep && !(static_cast<float>(p.t) > f.ns_max);                               // :306 (uint32 promoted to float)
+  keep = keep && !(f.canonical && (p.reflectivity & 1u));                             // :256-262 (Livox tag), set by the decoder
   // :318-334 point-skip and ring filters select the geometric subset
-  const bool geo = keep && (i % f.point_skip) == 0 && (p.ring % f.ring_skip) == 0;
+  const bool geo = keep && (i % f.point_skip) == 0 && (!f.ring_filter || (p.ring % f.ring_skip) == 0);
   return (keep ? 1u : 0u) | (geo ? 2u : 0u);
 }
 
@@ -222,6 +225,116 @@ __global__ __launch_bounds__(kThreads) void input_scatter_kernel(const mh_ouster
     counters->n_full = off_full + t_full;
     counters->n_geometric = off_geo + t_geo;
   }
+}
+
+// ---- other sensors: any point record -> the canonical 32-byte record the filter kernels read -------------------
+// (lidar/manager.cpp:177-203 transpose, :256-271 tag / reflectivity, :285-304 time decoding).  Output index j is the
+// index in the (transposed) cloud; canonical.reflectivity bit 0 = rejected by the Livox tag test; ring as uint16.
+__device__ __forceinline__ float load_f32(const uint8_t * p)
+{
+  float v;
+  memcpy(&v, p, 4);
+  return v;
+}
+// `uint32_t t_ns = <double>` as the reference's x86-64 build evaluates it: truncate to a 64-bit integer (cvttsd2si),
+// keep the low word.  A point stamped slightly BEFORE the header therefore becomes ~2^32 ns and fails the ns_max test
+// rather than saturating to 0 and passing it (v_cvt_u32_f64 saturates).
+__device__ __forceinline__ uint32_t f64_to_u32(double v) { return static_cast<uint32_t>(static_cast<long long>(v)); }
+__global__ __launch_bounds__(kThreads) void decode_points_kernel(const uint8_t * __restrict__ raw, uint32_t n, mh_point_layout L, uint32_t width,
+                                                                  uint32_t height, uint32_t transpose, double header_ts,
+                                                                  mh_ouster_point * __restrict__ out, uint32_t * bad_ring)
+{
+  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= n) return;
+  uint32_t i = j;
+  if (transpose) {  // transposed[new_row * new_width + new_col] = cloud[new_col * width + new_row], new_width = height
+    const uint32_t new_row = j / height, new_col = j % height;
+    i = new_col * width + new_row;
+  }
+  const uint8_t * r = raw + static_cast<size_t>(i) * L.stride;
+  mh_ouster_point o;
+  o.x = load_f32(r + L.off_x);
+  o.y = load_f32(r + L.off_y);
+  o.z = load_f32(r + L.off_z);
+  o.pad = 0.f;
+  if (L.intensity_is_u16) {
+    uint16_t v;
+    memcpy(&v, r + L.off_intensity, 2);
+    o.intensity = static_cast<float>(v);  // :265-271 reflectivity is the intensity
+  } else {
+    o.intensity = load_f32(r + L.off_intensity);
+  }
+  uint32_t t_ns = 0;
+  if (L.time_kind == MH_TIME_U32_NS) {
+    memcpy(&t_ns, r + L.off_time, 4);
+  } else if (L.time_kind == MH_TIME_F32_S) {
+    t_ns = f64_to_u32(static_cast<double>(load_f32(r + L.off_time)) * 1e9);       // :299 time * 1e9
+  } else {
+    double ts;
+    memcpy(&ts, r + L.off_time, 8);
+    t_ns = f64_to_u32(L.time_kind == MH_TIME_F64_S_ABS ? (ts - header_ts) * 1e9   // :291, :301
+                                                        : ts - header_ts * 1e9);    // :293
+  }
+  o.t = t_ns;
+  uint32_t ring = 0;
+  if (L.ring_kind == MH_RING_U16) {
+    uint16_t v;
+    memcpy(&v, r + L.off_ring, 2);
+    ring = v;
+  } else if (L.ring_kind == MH_RING_U8) {
+    ring = r[L.off_ring];
+  } else if (L.ring_kind == MH_RING_F32) {
+    ring = static_cast<uint32_t>(load_f32(r + L.off_ring));
+  }
+  if (ring > 0xFFFFu) ring = 0xFFFFu;
+  o.ring = static_cast<uint16_t>(ring);
+  if (ring >= 128u) *bad_ring = 1u;  // only organize_by_ring cares (its tables hold 128 rings, :215-217)
+  uint32_t flags = 0;
+  if (L.has_tag) {
+    const uint32_t tag = r[L.off_tag];
+    if (!((tag & 0x30u) == 0x10u || (tag & 0x30u) == 0x00u)) flags |= 1u;  // :256-262
+  }
+  o.reflectivity = static_cast<uint16_t>(flags);
+  o.pad2 = 0;
+  out[j] = o;
+}
+
+// organize_pointcloud_by_ring (:205-241): a stable counting sort by ring, 128 rings.  Per-block ring histograms, then
+// every block places its records: offset of (ring, block) = points of lower rings + points of this ring in earlier blocks.
+constexpr uint32_t kRings = 128;
+__global__ __launch_bounds__(kThreads) void ring_histogram_kernel(const mh_ouster_point * __restrict__ in, uint32_t n, uint32_t * __restrict__ hist)
+{
+  __shared__ uint32_t h[kRings];
+  if (threadIdx.x < kRings) h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+  if (j < n) atomicAdd(&h[in[j].ring & (kRings - 1u)], 1u);
+  __syncthreads();
+  if (threadIdx.x < kRings) hist[static_cast<size_t>(blockIdx.x) * kRings + threadIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(kThreads) void ring_place_kernel(const mh_ouster_point * __restrict__ in, uint32_t n, const uint32_t * __restrict__ hist,
+                                                               mh_ouster_point * __restrict__ out)
+{
+  __shared__ uint32_t s_total[kRings], s_before[kRings], s_ring[kThreads];
+  if (threadIdx.x < kRings) {
+    uint32_t tot = 0, before = 0;
+    for (uint32_t b = 0; b < gridDim.x; ++b) {
+      const uint32_t c = hist[static_cast<size_t>(b) * kRings + threadIdx.x];
+      if (b < blockIdx.x) before += c;
+      tot += c;
+    }
+    s_total[threadIdx.x] = tot;
+    s_before[threadIdx.x] = before;
+  }
+  const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t ring = j < n ? (in[j].ring & (kRings - 1u)) : 0xFFFFFFFFu;
+  s_ring[threadIdx.x] = ring;
+  __syncthreads();
+  if (j >= n) return;
+  uint32_t pos = s_before[ring];
+  for (uint32_t r = 0; r < ring; ++r) pos += s_total[r];
+  for (uint32_t t = 0; t < threadIdx.x; ++t) pos += s_ring[t] == ring ? 1u : 0u;  // earlier records of this block, same ring
+  out[pos] = in[j];
 }
 
 // the distinct timestamps, ascending: rank = number of smaller values (they are distinct).  The whole list passes
@@ -437,11 +550,28 @@ VoxelLayout voxel_layout(size_t n)
   return L;
 }
 
+hipError_t launch_decode_points(const void * raw, uint32_t n, const mh_point_layout & layout, uint32_t width, uint32_t height, bool transpose,
+                                bool organize_by_ring, double header_ts, mh_ouster_point * canon, mh_ouster_point * tmp, uint32_t * hist,
+                                uint32_t * bad_ring, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  const dim3 g((n + kThreads - 1) / kThreads), b(kThreads);
+  hipLaunchKernelGGL(decode_points_kernel, g, b, 0, stream, static_cast<const uint8_t *>(raw), n, layout, width, height, transpose ? 1u : 0u,
+                     header_ts, organize_by_ring ? tmp : canon, bad_ring);
+  if (organize_by_ring) {
+    hipLaunchKernelGGL(ring_histogram_kernel, g, b, 0, stream, tmp, n, hist);
+    hipLaunchKernelGGL(ring_place_kernel, g, b, 0, stream, tmp, n, hist, canon);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_prepare_input(const mh_ouster_point * raw, uint32_t n, const mh_input_config & cfg, uint32_t * scratch,
                                 mh_point32 * points_full, uint32_t * geo_idx, uint32_t * unique_ns, ScanCounters * counters,
-                                hipStream_t stream)
+                                hipStream_t stream, bool canonical, bool ring_filter)
 {
   FilterParams f;
+  f.canonical = canonical ? 1u : 0u;
+  f.ring_filter = ring_filter ? 1u : 0u;
   f.range_min_sq = cfg.range_min * cfg.range_min;  // manager.cpp:19-20 (float products)
   f.range_max_sq = cfg.range_max * cfg.range_max;
   f.intensity_min = cfg.intensity_min;

@@ -200,6 +200,104 @@ private:
 using PointOuster = mh_ouster_point;  // include/mimosa/lidar/point.hpp:42-50
 using ManagerInputConfig = mh_input_config;
 
+// The reference's other sensor point types (include/mimosa/lidar/point.hpp:52-131): the records a driver publishes, with
+// the members where PCL's EIGEN_ALIGN16 structs put them, and the layout that selects each type's branches of
+// Manager::prepareInput<PointT> (tag filter, reflectivity-as-intensity, time decoding, whether the ring filter applies).
+struct alignas(16) PointOusterOdyssey { float x, y, z, data_c; uint32_t t; uint16_t reflectivity, near_ir; };
+struct alignas(16) PointOusterR8 { float x, y, z, data_c; float intensity; uint32_t t; uint16_t reflectivity; uint8_t ring; };
+struct alignas(16) PointHesai { float x, y, z, data_c; float intensity; double timestamp; uint16_t ring; };
+struct alignas(16) PointLivox { float x, y, z, data_c; float intensity; uint8_t tag, line; double timestamp; };
+struct alignas(16) PointLivoxFromCustom2 { float x, y, z; uint32_t t; float intensity; uint8_t tag, line; };
+struct alignas(16) PointVelodyne { float x, y, z, data_c; float intensity; uint16_t ring; float time; };
+struct alignas(16) PointVelodyneAnybotics { float x, y, z, data_c; float intensity; float ring; float time; };
+struct alignas(16) PointRslidar { float x, y, z, data_c; float intensity; uint16_t ring; double timestamp; };
+
+namespace detail
+{
+inline mh_point_layout xyz(uint32_t stride, uint32_t off_intensity, uint32_t off_time, mh_time_kind tk)
+{
+  mh_point_layout L{};
+  L.stride = stride;
+  L.off_x = 0;
+  L.off_y = 4;
+  L.off_z = 8;
+  L.off_intensity = off_intensity;
+  L.off_time = off_time;
+  L.time_kind = tk;
+  return L;
+}
+inline mh_point_layout with_ring(mh_point_layout L, uint32_t off, mh_ring_kind kind, bool filter)
+{
+  L.off_ring = off;
+  L.ring_kind = kind;
+  L.ring_filter = filter ? 1 : 0;
+  return L;
+}
+inline mh_point_layout with_tag(mh_point_layout L, uint32_t off)
+{
+  L.off_tag = off;
+  L.has_tag = 1;
+  return L;
+}
+}  // namespace detail
+
+template <typename PointT> mh_point_layout layoutOf();
+template <> inline mh_point_layout layoutOf<PointOuster>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointOuster), offsetof(PointOuster, intensity), offsetof(PointOuster, t), MH_TIME_U32_NS),
+                           offsetof(PointOuster, ring), MH_RING_U16, true);
+}
+template <> inline mh_point_layout layoutOf<PointOusterOdyssey>()
+{
+  mh_point_layout L = detail::xyz(sizeof(PointOusterOdyssey), offsetof(PointOusterOdyssey, reflectivity), offsetof(PointOusterOdyssey, t), MH_TIME_U32_NS);
+  L.intensity_is_u16 = 1;
+  return L;
+}
+template <> inline mh_point_layout layoutOf<PointOusterR8>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointOusterR8), offsetof(PointOusterR8, intensity), offsetof(PointOusterR8, t), MH_TIME_U32_NS),
+                           offsetof(PointOusterR8, ring), MH_RING_U8, true);
+}
+template <> inline mh_point_layout layoutOf<PointHesai>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointHesai), offsetof(PointHesai, intensity), offsetof(PointHesai, timestamp), MH_TIME_F64_S_ABS),
+                           offsetof(PointHesai, ring), MH_RING_U16, true);
+}
+template <> inline mh_point_layout layoutOf<PointLivox>()
+{
+  return detail::with_tag(detail::xyz(sizeof(PointLivox), offsetof(PointLivox, intensity), offsetof(PointLivox, timestamp), MH_TIME_F64_NS_ABS),
+                          offsetof(PointLivox, tag));
+}
+template <> inline mh_point_layout layoutOf<PointLivoxFromCustom2>()
+{
+  return detail::with_tag(detail::xyz(sizeof(PointLivoxFromCustom2), offsetof(PointLivoxFromCustom2, intensity), offsetof(PointLivoxFromCustom2, t),
+                                      MH_TIME_U32_NS),
+                          offsetof(PointLivoxFromCustom2, tag));
+}
+template <> inline mh_point_layout layoutOf<PointVelodyne>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointVelodyne), offsetof(PointVelodyne, intensity), offsetof(PointVelodyne, time), MH_TIME_F32_S),
+                           offsetof(PointVelodyne, ring), MH_RING_U16, true);
+}
+template <> inline mh_point_layout layoutOf<PointVelodyneAnybotics>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointVelodyneAnybotics), offsetof(PointVelodyneAnybotics, intensity),
+                                       offsetof(PointVelodyneAnybotics, time), MH_TIME_F32_S),
+                           offsetof(PointVelodyneAnybotics, ring), MH_RING_F32, false);
+}
+template <> inline mh_point_layout layoutOf<PointRslidar>()
+{
+  return detail::with_ring(detail::xyz(sizeof(PointRslidar), offsetof(PointRslidar, intensity), offsetof(PointRslidar, timestamp), MH_TIME_F64_S_ABS),
+                           offsetof(PointRslidar, ring), MH_RING_U16, true);
+}
+
+// the cloud's shape and the two Manager flags that re-order it first (lidar/manager.hpp:28-29)
+struct CloudOrder
+{
+  uint32_t width = 0, height = 1;  // width 0: n x 1
+  bool transpose_pointcloud = false, organize_pointcloud_by_ring = false;
+};
+
 inline ManagerInputConfig defaultManagerInputConfig()
 {
   // struct defaults of lidar/manager.hpp:24-41 (+ GeometricConfig skip divisors)
@@ -232,6 +330,22 @@ public:
   void prepareInput(const PointOuster * raw, size_t n, const ManagerInputConfig & cfg, const double header_ts)
   {
     ctx_->check(mh_scan_prepare_input(scan_, raw, n, &cfg, &info_), "mh_scan_prepare_input");
+    corrected_ts_ = header_ts + info_.last_point_ns * 1.0e-9;
+    unique_ns_.resize(info_.n_unique_ns);
+    size_t m = 0;
+    ctx_->check(mh_scan_get_unique_ns(scan_, unique_ns_.data(), unique_ns_.size(), &m), "mh_scan_get_unique_ns");
+  }
+  // Manager::prepareInput<PointT> for any of the reference's point types (the sensor's own records go to the device).
+  // transpose_pointcloud is honoured for PointRslidar / PointVelodyneAnybotics only, as in the reference (:177-203).
+  template <typename PointT>
+  void prepareInput(const PointT * raw, size_t n, const ManagerInputConfig & cfg, const double header_ts, const CloudOrder & order)
+  {
+    const mh_point_layout L = layoutOf<PointT>();
+    const bool may_transpose = std::is_same<PointT, PointRslidar>::value || std::is_same<PointT, PointVelodyneAnybotics>::value;
+    const uint32_t width = order.width ? order.width : static_cast<uint32_t>(n);
+    ctx_->check(mh_scan_prepare_input_layout(scan_, raw, n, &L, width, order.height, may_transpose && order.transpose_pointcloud ? 1 : 0,
+                                             order.organize_pointcloud_by_ring ? 1 : 0, header_ts, &cfg, &info_),
+                "mh_scan_prepare_input_layout");
     corrected_ts_ = header_ts + info_.last_point_ns * 1.0e-9;
     unique_ns_.resize(info_.n_unique_ns);
     size_t m = 0;

@@ -18,6 +18,8 @@
 #pragma once
 
 #include <algorithm>
+#include <type_traits>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1063,6 +1065,174 @@ inline void prepare_input(const PointOusterIn * in, size_t n, const InputConfig 
   // :340-342 std::sort on the timestamp only: the order inside one timestamp is unspecified there; a stable
   // sort is one admissible outcome (only the membership of each group is consumed, :504-508)
   std::stable_sort(ns_idx_pairs.begin(), ns_idx_pairs.end(), [](const auto & a, const auto & b) { return a.first < b.first; });
+  for (size_t i = 0; i < ns_idx_pairs.size(); ++i) {
+    if (i == 0 || ns_idx_pairs[i].first != ns_idx_pairs[i - 1].first) {
+      out.unique_ns.push_back(ns_idx_pairs[i].first);
+      out.idxs_at_unique_ns.emplace_back();
+    }
+    out.idxs_at_unique_ns.back().push_back(ns_idx_pairs[i].second);
+  }
+}
+
+// ---- the reference's other point types (include/mimosa/lidar/point.hpp:52-131), restated with the same member order
+// and 16-byte alignment (PCL_ADD_POINT4D = float x, y, z + one float of padding) ---------------------------------
+struct alignas(16) PointOusterOdysseyIn
+{
+  float x, y, z, pad;
+  uint32_t t;
+  uint16_t reflectivity, near_ir;
+};
+struct alignas(16) PointOusterR8In
+{
+  float x, y, z, pad;
+  float intensity;
+  uint32_t t;
+  uint16_t reflectivity;
+  uint8_t ring;
+};
+struct alignas(16) PointHesaiIn
+{
+  float x, y, z, pad;
+  float intensity;
+  double timestamp;
+  uint16_t ring;
+};
+struct alignas(16) PointLivoxIn
+{
+  float x, y, z, pad;
+  float intensity;
+  uint8_t tag, line;
+  double timestamp;
+};
+struct alignas(16) PointLivoxFromCustom2In
+{
+  float x, y, z;
+  uint32_t t;
+  float intensity;
+  uint8_t tag, line;
+};
+struct alignas(16) PointVelodyneIn
+{
+  float x, y, z, pad;
+  float intensity;
+  uint16_t ring;
+  float time;
+};
+struct alignas(16) PointVelodyneAnyboticsIn
+{
+  float x, y, z, pad;
+  float intensity;
+  float ring;
+  float time;
+};
+struct alignas(16) PointRslidarIn
+{
+  float x, y, z, pad;
+  float intensity;
+  uint16_t ring;
+  double timestamp;
+};
+
+struct InputOrder  // lidar/manager.hpp:28-29 + the PointCloud2 shape
+{
+  uint32_t width = 0, height = 1;
+  bool transpose_pointcloud = false, organize_pointcloud_by_ring = false;
+  double header_ts = 0.0;
+};
+
+// Manager::prepareInput<PointT> (src/lidar/manager.cpp:149-383) for every point type, branch for branch.
+template <typename PointT>
+inline void prepare_input_typed(const PointT * in, size_t n, const InputConfig & cfg, const InputOrder & ord, PreparedInput & out)
+{
+  out = PreparedInput();
+  std::vector<PointT> cloud(in, in + n);
+  uint32_t width = ord.width, height = ord.height;
+  if constexpr (std::is_same<PointT, PointRslidarIn>::value || std::is_same<PointT, PointVelodyneAnyboticsIn>::value) {  // :177-203
+    if (ord.transpose_pointcloud) {
+      std::vector<PointT> tr(cloud.size());
+      const uint32_t tw = height, th = width;
+      for (size_t i = 0; i < cloud.size(); ++i) {
+        const size_t current_row = i / width, current_col = i % width;
+        tr[current_col * tw + current_row] = cloud[i];
+      }
+      cloud = tr;
+      width = tw;
+      height = th;
+    }
+  }
+  if constexpr (!std::is_same<PointT, PointLivoxIn>::value && !std::is_same<PointT, PointLivoxFromCustom2In>::value &&
+                !std::is_same<PointT, PointOusterOdysseyIn>::value) {  // :205-241
+    if (ord.organize_pointcloud_by_ring && height == 1) {
+      constexpr uint32_t num_rings = 128;
+      std::array<size_t, num_rings> ring_counts{};
+      for (const auto & point : cloud) ++ring_counts[static_cast<size_t>(point.ring)];
+      std::array<size_t, num_rings> ring_offsets{};
+      size_t offset = 0;
+      for (uint32_t i = 0; i < num_rings; ++i) {
+        ring_offsets[i] = offset;
+        offset += ring_counts[i];
+      }
+      std::vector<PointT> organized(cloud.size());
+      std::array<size_t, num_rings> ring_cursors = ring_offsets;
+      for (const auto & point : cloud) organized[ring_cursors[static_cast<size_t>(point.ring)]++] = point;
+      cloud = std::move(organized);
+    }
+  }
+  const float range_min_sq = cfg.range_min * cfg.range_min;  // manager.cpp:19-20
+  const float range_max_sq = cfg.range_max * cfg.range_max;
+  const size_t point_skip = static_cast<size_t>(cfg.point_skip_divisor);
+  const size_t skip_divisor = cfg.create_full_res_pointcloud ? 1 : point_skip;  // :244-245
+  std::vector<std::pair<uint32_t, uint64_t>> ns_idx_pairs;
+  uint32_t last_point_ns = 0;
+  for (size_t i = 0; i < cloud.size(); i = i + skip_divisor) {
+    const PointT & pin = cloud[i];
+    if (std::isnan(pin.x) || std::isnan(pin.y) || std::isnan(pin.z)) continue;  // :253
+    if constexpr (std::is_same<PointT, PointLivoxIn>::value || std::is_same<PointT, PointLivoxFromCustom2In>::value) {  // :256-262
+      if (!((pin.tag & 0x30) == 0x10 || (pin.tag & 0x30) == 0x00)) continue;
+    }
+    float intensity = 0.0f;
+    if constexpr (std::is_same<PointT, PointOusterOdysseyIn>::value) {  // :265-271
+      if (pin.reflectivity < cfg.intensity_min || pin.reflectivity > cfg.intensity_max) continue;
+      intensity = static_cast<float>(pin.reflectivity);
+    } else {
+      if (std::isnan(pin.intensity) || pin.intensity < cfg.intensity_min || pin.intensity > cfg.intensity_max) continue;  // :272-276
+      intensity = pin.intensity;
+    }
+    const float range_sq = pin.x * pin.x + pin.y * pin.y + pin.z * pin.z;  // :281
+    if (range_sq < range_min_sq || range_sq > range_max_sq) continue;      // :282
+    uint32_t t_ns;  // :285-304
+    if constexpr (std::is_same<PointT, PointOusterIn>::value || std::is_same<PointT, PointOusterOdysseyIn>::value ||
+                  std::is_same<PointT, PointOusterR8In>::value || std::is_same<PointT, PointLivoxFromCustom2In>::value) {
+      t_ns = pin.t;
+    } else if constexpr (std::is_same<PointT, PointHesaiIn>::value || std::is_same<PointT, PointRslidarIn>::value) {
+      t_ns = static_cast<uint32_t>((pin.timestamp - ord.header_ts) * 1e9);
+    } else if constexpr (std::is_same<PointT, PointLivoxIn>::value) {
+      t_ns = static_cast<uint32_t>(pin.timestamp - ord.header_ts * 1e9);
+    } else {
+      t_ns = static_cast<uint32_t>(pin.time * 1e9);  // PointVelodyne, PointVelodyneAnybotics: float * double
+    }
+    if (t_ns > cfg.ns_max) continue;  // :306
+    last_point_ns = std::max(last_point_ns, t_ns);
+    Point32 p{};
+    p.x = pin.x;
+    p.y = pin.y;
+    p.z = pin.z + cfg.z_offset;
+    p.intensity = intensity;
+    p.t = t_ns;
+    p.idx = static_cast<uint32_t>(i);
+    p.range = std::sqrt(range_sq);
+    out.points_full.push_back(p);
+    const uint64_t new_idx = out.points_full.size() - 1;
+    ns_idx_pairs.emplace_back(t_ns, new_idx);
+    if (i % point_skip != 0) continue;  // :318
+    if constexpr (!std::is_same<PointT, PointLivoxIn>::value && !std::is_same<PointT, PointLivoxFromCustom2In>::value &&
+                  !std::is_same<PointT, PointVelodyneAnyboticsIn>::value && !std::is_same<PointT, PointOusterOdysseyIn>::value) {  // :321-332
+      if (pin.ring % cfg.ring_skip_divisor != 0) continue;
+    }
+    out.geometric_point_idxs.push_back(new_idx);
+  }
+  out.last_point_ns = last_point_ns;
+  std::stable_sort(ns_idx_pairs.begin(), ns_idx_pairs.end(), [](const auto & a, const auto & b) { return a.first < b.first; });  // :340-342
   for (size_t i = 0; i < ns_idx_pairs.size(); ++i) {
     if (i == 0 || ns_idx_pairs[i].first != ns_idx_pairs[i - 1].first) {
       out.unique_ns.push_back(ns_idx_pairs[i].first);

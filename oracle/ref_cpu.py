@@ -315,6 +315,34 @@ def prepare_input(raw, cfg: InputConfig):
             "groups": groups, "last_point_ns": int(counts[3])}
 
 
+POINT_KINDS = ("ouster", "ouster_odyssey", "ouster_r8", "hesai", "livox", "livox_custom2", "velodyne", "velodyne_anybotics", "rslidar")
+
+
+def point_sizeof(kind: str) -> int:
+    L = lib()
+    L.ref_point_sizeof.restype = C.c_int64
+    return int(L.ref_point_sizeof(POINT_KINDS.index(kind)))
+
+
+def prepare_input_typed(kind: str, raw, cfg: InputConfig, width=None, height=1, transpose=False, organize=False, header_ts=0.0):
+    """Manager::prepareInput<PointT> (src/lidar/manager.cpp:149-383) for any of the reference's point types."""
+    L = lib()
+    raw = np.ascontiguousarray(raw)
+    n = len(raw)
+    assert raw.dtype.itemsize == point_sizeof(kind), (raw.dtype.itemsize, point_sizeof(kind))
+    width = n if width is None else width
+    full = np.zeros(max(n, 1), dtype=np.dtype((np.void, 32)))
+    geo = np.zeros(max(n, 1), np.uint64)
+    uniq = np.zeros(max(n, 1), np.uint32)
+    counts = np.zeros(4, np.uint64)
+    L.ref_prepare_input_typed.restype = C.c_int64
+    rc = L.ref_prepare_input_typed(POINT_KINDS.index(kind), _p(raw), C.c_int64(n), C.c_uint32(width), C.c_uint32(height), int(transpose),
+                                   int(organize), C.c_double(header_ts), C.byref(cfg), _p(full), _p(geo), _p(uniq), _p(counts))
+    assert rc >= 0
+    nf, ng, nu = int(counts[0]), int(counts[1]), int(counts[2])
+    return {"points_full": full[:nf].copy(), "geometric_idxs": geo[:ng].copy(), "unique_ns": uniq[:nu].copy(), "last_point_ns": int(counts[3])}
+
+
 def downsample(pts, leaf=0.5, max_pts=20, min_dist=0.15):
     pts = np.ascontiguousarray(pts)
     kept = np.empty(len(pts), np.uint32)

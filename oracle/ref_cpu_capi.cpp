@@ -204,6 +204,56 @@ int64_t ref_prepare_input(
   counts[3] = o.last_point_ns;
   return static_cast<int64_t>(o.points_full.size());
 }
+// Manager::prepareInput<PointT> for the other point types.  kind: 0 Ouster, 1 OusterOdyssey, 2 OusterR8, 3 Hesai, 4 Livox,
+// 5 LivoxFromCustom2, 6 Velodyne, 7 VelodyneAnybotics, 8 Rslidar.  ref_point_sizeof(kind) = sizeof of the restated struct.
+int64_t ref_point_sizeof(int kind)
+{
+  switch (kind) {
+    case 0: return sizeof(PointOusterIn);
+    case 1: return sizeof(PointOusterOdysseyIn);
+    case 2: return sizeof(PointOusterR8In);
+    case 3: return sizeof(PointHesaiIn);
+    case 4: return sizeof(PointLivoxIn);
+    case 5: return sizeof(PointLivoxFromCustom2In);
+    case 6: return sizeof(PointVelodyneIn);
+    case 7: return sizeof(PointVelodyneAnyboticsIn);
+    case 8: return sizeof(PointRslidarIn);
+  }
+  return -1;
+}
+int64_t ref_prepare_input_typed(int kind, const void * in, int64_t n, uint32_t width, uint32_t height, int transpose, int organize,
+                                double header_ts, const InputConfig * cfg, Point32 * points_full, uint64_t * geometric_idxs,
+                                uint32_t * unique_ns, uint64_t * counts)
+{
+  PreparedInput o;
+  InputOrder ord;
+  ord.width = width;
+  ord.height = height;
+  ord.transpose_pointcloud = transpose != 0;
+  ord.organize_pointcloud_by_ring = organize != 0;
+  ord.header_ts = header_ts;
+  const size_t m = static_cast<size_t>(n);
+  switch (kind) {
+    case 0: prepare_input_typed(static_cast<const PointOusterIn *>(in), m, *cfg, ord, o); break;
+    case 1: prepare_input_typed(static_cast<const PointOusterOdysseyIn *>(in), m, *cfg, ord, o); break;
+    case 2: prepare_input_typed(static_cast<const PointOusterR8In *>(in), m, *cfg, ord, o); break;
+    case 3: prepare_input_typed(static_cast<const PointHesaiIn *>(in), m, *cfg, ord, o); break;
+    case 4: prepare_input_typed(static_cast<const PointLivoxIn *>(in), m, *cfg, ord, o); break;
+    case 5: prepare_input_typed(static_cast<const PointLivoxFromCustom2In *>(in), m, *cfg, ord, o); break;
+    case 6: prepare_input_typed(static_cast<const PointVelodyneIn *>(in), m, *cfg, ord, o); break;
+    case 7: prepare_input_typed(static_cast<const PointVelodyneAnyboticsIn *>(in), m, *cfg, ord, o); break;
+    case 8: prepare_input_typed(static_cast<const PointRslidarIn *>(in), m, *cfg, ord, o); break;
+    default: return -1;
+  }
+  std::memcpy(points_full, o.points_full.data(), o.points_full.size() * sizeof(Point32));
+  std::memcpy(geometric_idxs, o.geometric_point_idxs.data(), o.geometric_point_idxs.size() * sizeof(uint64_t));
+  std::memcpy(unique_ns, o.unique_ns.data(), o.unique_ns.size() * sizeof(uint32_t));
+  counts[0] = o.points_full.size();
+  counts[1] = o.geometric_point_idxs.size();
+  counts[2] = o.unique_ns.size();
+  counts[3] = o.last_point_ns;
+  return static_cast<int64_t>(o.points_full.size());
+}
 int64_t ref_downsample(
   const Point32 * pts, int64_t n, double leaf, int max_pts, double min_dist, uint32_t * kept)
 {
