@@ -194,6 +194,16 @@ def main():
         raw_linearize(t)
         lat.append(time.perf_counter() - a)
     lat_ms = float(np.median(lat) * 1e3) if lat else float("nan")
+    lat_nc = []  # the same call with the component pass switched off (K3 alone publishes the result)
+    factor.set_components(False)
+    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
+        factor.reset()
+        ctx.synchronize()
+        a = time.perf_counter()
+        raw_linearize(t)
+        lat_nc.append(time.perf_counter() - a)
+    factor.set_components(True)
+    lat_nc_ms = float(np.median(lat_nc) * 1e3) if lat_nc else float("nan")
 
     # The second caller of the path: GTSAM re-linearization (src/graph/manager.cpp:585-588).  The pose moved
     # < min_dist/4, so every point takes the data-association cache branch (geometric_factor.hpp:308-317):
@@ -262,6 +272,18 @@ def main():
         batch_relin = _timed(_batch, cold=False)
         single_relin = _timed(_one_by_one, cold=False)
         one_relin = _timed(lambda: _one(0), cold=False)
+        # the same window with the component pass switched off (mh_icp_set_components(icp, 0)): what the smoother's
+        # re-linearizations need — the reference never reads the components of those calls (geometric.cpp:205-214)
+        for f in wf:
+            f.set_components(False)
+        _batch()
+        nc_batch_cold = _timed(_batch)
+        nc_one_cold = _timed(lambda: _one(0))
+        _batch()
+        nc_batch_relin = _timed(_batch, cold=False)
+        nc_one_relin = _timed(lambda: _one(0), cold=False)
+        for f in wf:
+            f.set_components(True)
         win_stats = {"factors": nwin, "points_per_factor": per,
                      "batch_cold_ms": round(batch_cold, 4), "one_at_a_time_cold_ms": round(single_cold, 4),
                      "single_factor_cold_ms": round(one_cold, 4),
@@ -269,6 +291,12 @@ def main():
                      "batch_relinearize_ms": round(batch_relin, 4), "one_at_a_time_relinearize_ms": round(single_relin, 4),
                      "single_factor_relinearize_ms": round(one_relin, 4),
                      "batch_cold_mpts_s": round(nwin * per / batch_cold / 1e3, 1),
+                     "without_components": {"batch_cold_ms": round(nc_batch_cold, 4), "single_factor_cold_ms": round(nc_one_cold, 4),
+                                            "batch_relinearize_ms": round(nc_batch_relin, 4),
+                                            "single_factor_relinearize_ms": round(nc_one_relin, 4),
+                                            "batch_cold_mpts_s": round(nwin * per / nc_batch_cold / 1e3, 1),
+                                            "note": "K4 skipped: H, b, f, final localizabilities and degeneracy info bit-identical; "
+                                                    "component localizabilities / status histogram not produced"},
                      "note": "median wall time of synchronous raw C-ABI calls (results on the host); cold = every point of "
                              "every factor runs k-NN; relinearize = every point hits the data-association cache"}
         for f in wf:
@@ -728,6 +756,7 @@ def main():
         },
         "sync_latency_ms": round(lat_ms, 4),
         "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
+        "sync_latency_without_components_ms": round(lat_nc_ms, 4),
         "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
         "value_concurrent": conc,
         "keyframe_map_update": kf_stats,

@@ -272,6 +272,15 @@ int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const doub
 int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals);
 /* Forget all data associations (== a freshly constructed factor): enqueued, no host sync. */
 int mh_icp_reset(mh_icp * icp);
+/* The component localizabilities and the status histogram (geometric_factor.hpp:430-457, geometric.cpp:280-323) need a second
+ * pass over the points in the eigenbasis of the finished H — a kernel of its own (K4), a fifth of a call.  The reference
+ * computes them in every linearize() but reads them in ONE place: Geometric::getFactors, right after its own linearize
+ * (geometric.cpp:205-214, getLocalizabilities / the status log); the re-linearizations ISAM2 drives afterwards
+ * (graph/manager.cpp:585-588) never have them looked at.  enabled = 0 skips the pass for this factor's following calls
+ * (also in mh_icp_linearize_batch when no factor of the batch wants it): loc_trans_comp / loc_rot_comp come back NaN and
+ * status_hist -1; H, b, f, the final localizabilities, eigenvectors and degeneracy info are bit-identical either way.
+ * Default: enabled (the reference's behaviour). */
+int mh_icp_set_components(mh_icp * icp, int enabled);
 size_t mh_icp_size(const mh_icp * icp);
 
 /* ---- deskew / rigid transforms ----------------------------------------------------------------

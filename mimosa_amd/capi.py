@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
-    "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_size",
+    "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_set_components", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
     "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_prepare_input_layout", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
@@ -335,6 +335,7 @@ def load(build_if_missing: bool = True):
     L.mh_icp_linearize_finish.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mh_icp_get_state.argtypes = [vp, vp, vp, vp]
     L.mh_icp_reset.argtypes = [vp]
+    L.mh_icp_set_components.argtypes = [vp, C.c_int]
     L.mh_icp_size.argtypes = [vp]
     L.mh_icp_size.restype = sz
     L.mh_deskew.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
@@ -695,6 +696,10 @@ class ICPFactor:
 
     def reset(self):
         self.ctx.check(self.L.mh_icp_reset(self.h))
+
+    def set_components(self, enabled: bool):
+        """component localizabilities + status histogram (K4) on / off for the following linearize calls"""
+        self.ctx.check(self.L.mh_icp_set_components(self.h, int(bool(enabled))))
 
     def state(self):
         st = np.empty(self.n, np.int32)

@@ -55,6 +55,7 @@ struct IcpArgs
   unsigned int * ticket;
   DeviceResult * result;
   DeviceResult * host_result;  // mapped pinned host slot (may be null): the last block writes its part there too
+  unsigned int seq;          // != 0: no K4 follows (components switched off) — the last block publishes the completion number itself
   unsigned long long * dbg;  // MH_TIMELINE diagnostic build only, else null
   int reps;                  // MH_TIMELINE only: repeat the per-point section (warm-cache experiment)
 };

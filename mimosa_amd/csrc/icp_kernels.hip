@@ -1144,6 +1144,13 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     }
   }
 #undef MH_PUT
+  // No K4 behind this call (mh_icp_set_components(icp, 0)): this block's writes are the whole result, so the completion
+  // number a spinning host waits for is published here — data first (system-scope fence by every writer), then the flag.
+  if (a.seq && a.host_result) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   MH_STAMP(a.dbg, 7);
 }
 

@@ -33,7 +33,8 @@ struct PendingCall
   double gz[3];    // global_z = -g_unit
   int parity;
   int linearize_count;
-  unsigned int seq;  // what K4 publishes to the host slot when this call is complete (0: nothing was launched)
+  unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
+  bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
   hipEvent_t ev[3];
 };
 
@@ -54,6 +55,7 @@ struct mh_icp
   int n_pending = 0;
   int parity = 0;
   bool cold = true;
+  bool components = true;  // mh_icp_set_components: run K4 (component localizabilities + status histogram) in every linearize
   int linearize_count = 0;
   hipEvent_t events[kMaxPending][3];
   bool events_ready = false;
@@ -130,8 +132,9 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
   for (int i = 0; i < 3; ++i) {
     out->loc_rot_final[i] = d.loc_rot_final[i];
     out->loc_trans_final[i] = d.loc_trans_final[i];
-    out->loc_trans_comp[i] = d.loc_comp[i];
-    out->loc_rot_comp[i] = d.loc_comp[3 + i];
+    // switched off (mh_icp_set_components): NaN, so that a caller who reads them anyway notices
+    out->loc_trans_comp[i] = pc.components ? d.loc_comp[i] : std::numeric_limits<double>::quiet_NaN();
+    out->loc_rot_comp[i] = pc.components ? d.loc_comp[3 + i] : std::numeric_limits<double>::quiet_NaN();
   }
   std::memcpy(out->eigvec_rot, d.eig_rot, sizeof(double) * 9);
   std::memcpy(out->eigvec_trans, d.eig_trans, sizeof(double) * 9);
@@ -200,7 +203,7 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
       }
     }
   }
-  for (int i = 0; i < 9; ++i) out->status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
+  for (int i = 0; i < 9; ++i) out->status_hist[i] = pc.components ? static_cast<int32_t>(d.status_hist[i]) : -1;
   out->n_knn = static_cast<int64_t>(d.n_knn);
   out->n_exact_fallback = static_cast<int64_t>(d.n_fallback);
   out->mean_scanned = d.n_knn ? static_cast<double>(d.n_scanned) / static_cast<double>(d.n_knn) : 0.0;
@@ -489,6 +492,7 @@ static int mh_icp_clone_impl(const mh_icp * src, mh_icp ** out)
   MH_HIP(ctx, hipMemsetAsync(icp->d_ticket.p, 0, 2 * sizeof(unsigned int), ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   icp->cold = src->cold;
+  icp->components = src->components;
   icp->linearize_count = src->linearize_count;
   *out = icp;
   return MH_OK;
@@ -553,6 +557,18 @@ static int mh_icp_reset_impl(mh_icp * icp)
 int mh_icp_reset(mh_icp * icp)
 {
   return guarded(nullptr, "mh_icp_reset", [&]() -> int { return mh_icp_reset_impl(icp); });
+}
+
+static int mh_icp_set_components_impl(mh_icp * icp, int enabled)
+{
+  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_set_components: icp is NULL");
+  if (icp->n_pending) return fail(icp->ctx, MH_ERR_INVALID_ARG, "mh_icp_set_components: linearize calls in flight");
+  icp->components = enabled != 0;
+  return MH_OK;
+}
+int mh_icp_set_components(mh_icp * icp, int enabled)
+{
+  return guarded(nullptr, "mh_icp_set_components", [&]() -> int { return mh_icp_set_components_impl(icp, enabled); });
 }
 
 // Argument blocks of one linearize call of `icp` in pending slot n_pending (which it claims): everything of
@@ -631,6 +647,8 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
     pc.ev[0] = pc.ev[1] = pc.ev[2] = nullptr;
   }
   pc.seq = 0;
+  pc.components = icp->components;
+  a.seq = 0;
   if (a.n > 0) {
     a.host_result = l.host_result = icp->d_h_results + slot;
     if (want_flag) {
@@ -657,9 +675,10 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   PendingCall & pc = icp->pending[slot];
   if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
   if (a.n > 0) {
+    if (!pc.components) a.seq = l.seq;  // K3 is the call's last kernel: it publishes the completion number
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
-    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+    if (pc.components) MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   } else {
     if (timed) {
@@ -819,6 +838,13 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     h_a[slot_of[f]] = a;
     h_l[slot_of[f]] = l;
   }
+  // K4 is skipped when NO factor of the batch wants its components (the smoother's re-linearizations: nobody reads
+  // them, geometric.cpp:205-214 is the only reader); a mixed batch runs it for all, the others report NaN all the same
+  bool any_components = false;
+  for (size_t f = 0; f < n_factors; ++f) any_components = any_components || (icps[f]->n && icps[f]->components);
+  if (!any_components)
+    for (size_t f = 0; f < n_factors; ++f)
+      if (icps[f]->n) h_a[slot_of[f]].seq = h_l[slot_of[f]].seq;
   for (int g = 0; g < 2; ++g) {
     // prefix of the group's grids, in slot order
     int acc = 0;
@@ -843,7 +869,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
         blk.n = group_n[g];
         MH_HIP(ctx, mh::launch_linearize_batch_inline(blk, group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
       }
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < 2 && any_components; ++g) {
         if (!group_grid[g]) continue;
         mh::BatchInline<mh::LocArgs> blk;
         std::memset(&blk, 0, sizeof(blk));
@@ -861,7 +887,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
         const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
         MH_HIP(ctx, mh::launch_linearize_batch(da, ds, group_n[g], group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
       }
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < 2 && any_components; ++g) {
         if (!group_grid[g]) continue;
         const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + group_first[g];
         const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
@@ -1641,7 +1667,8 @@ static int mh_icp_global_epilogue_impl(mh_icp * icp, const double sums32[32], co
     }
   mh::compute_localizability(Hr, d.loc_rot_final, d.eig_rot);
   mh::compute_localizability(Ht, d.loc_trans_final, d.eig_trans);
-  const PendingCall pc = icp->pending[0];
+  PendingCall pc = icp->pending[0];
+  pc.components = true;  // loc16 carries them: the two-phase form always runs the component pass
   icp->n_pending = 0;
   finish_result(icp, d, pc, out);  // Schur degeneracy info, 4-DoF projection, degeneracy quirk: once, on the global sums
   out->gpu_ms_linearize = out->gpu_ms_localizability = -1.0f;

@@ -435,6 +435,10 @@ public:
     std::shared_ptr<ICPFactor> c(new ICPFactor(*this, CloneTag{}));
     return c;
   }
+  // Whether linearize() also runs the component-localizability / status-histogram pass (getLocalizabilities' *_comp
+  // outputs, lastResult().status_hist).  Geometric::getFactors reads them right after its own linearize and switches the
+  // pass off before the factor goes to the smoother, whose re-linearizations never have them read.
+  void computeComponents(bool on) { ctx().check(mh_icp_set_components(icp_, on ? 1 : 0), "mh_icp_set_components"); }
   size_t dim() const override { return 6; }                  // :166
   double error(const Values &) const override { return 0.0; }  // :168-174 (the reference prints and returns 0)
 
@@ -661,6 +665,9 @@ public:
     debug_.localizability_trans_final = tf;
     debug_.localizability_rot_final = rf;
     for (int i = 0; i < 9; ++i) debug_.n_status[i] = factor_->lastResult().status_hist[i];  // :280-323
+    // nothing reads the components or the histogram of this factor again (the smoother only takes the HessianFactor):
+    // its re-linearizations skip that pass
+    factor_->computeComponents(false);
     graph.add(factor_);
   }
 

@@ -246,6 +246,7 @@ public:
       lv.k = k;
       lv.T = pred.T;
       lv.f = std::make_shared<ICPFactor>(X, map_, scan_, cfg_.reg);
+      lv.f->computeComponents(false);  // the loop below only takes H, b, f
       lv.has_Z = have_prev;
       if (have_prev) lv.Z = between(prev.T, pred.T);
       Values values;

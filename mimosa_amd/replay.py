@@ -210,7 +210,9 @@ class HipBackend:
         return info["n_downsampled"]
 
     def make_factor(self):
-        return self.scan.make_factor(self.map, self.reg)
+        f = self.scan.make_factor(self.map, self.reg)
+        f.set_components(False)  # the loop takes H, b, f only (mh_icp_set_components)
+        return f
 
     def make_photo_factor(self):
         return self.photo.make_factor() if self.photo is not None and self.photo.features() else None

@@ -137,3 +137,74 @@ def test_batch_larger_than_the_inline_window(ctx, small_world):
     for f in fa + fb:
         f.destroy()
     gm.release()
+
+
+_CORE = ("H_ss", "b_s", "f", "loc_trans_final", "loc_rot_final", "eigvec_rot", "eigvec_trans", "degen_rot", "degen_trans",
+         "degen_eigvec_rot", "degen_eigvec_trans", "n_knn", "mean_candidates", "linearize_count", "H_st", "H_tt", "b_t")
+
+
+def _core_same(a, b):
+    for k in _CORE:
+        assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+
+
+def test_components_switched_off_changes_nothing_else(ctx, room_world):
+    """mh_icp_set_components(0): K4 is skipped; H, b, f, final localizabilities, eigenvectors, degeneracy info and the
+    per-point state are bit-identical, the components come back NaN / -1, and switching it on again restores them —
+    single calls (synchronous and pipelined), a clone, and the batch (all off = no K4 launch, mixed = NaN for the off ones)."""
+    from mimosa_amd import capi
+
+    gm, fa, fb, fr, poses = _window(ctx, room_world, 4)
+    Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
+    for f in fa:
+        f.set_components(False)
+    for i in range(4):                                    # cold, then a re-linearization, one call at a time
+        for R, t in ((Rs[i], ts[i]), (Rs[i], ts[i] + np.array([0.003, 0.0, -0.002]))):
+            off, on = fa[i].linearize(R, t), fb[i].linearize(R, t)
+            _core_same(off, on)
+            assert np.all(np.isnan(off["loc_trans_comp"])) and np.all(np.isnan(off["loc_rot_comp"]))
+            assert list(off["status_hist"]) == [-1] * 9
+            assert not np.any(np.isnan(on["loc_trans_comp"])) and sum(on["status_hist"]) == len(fa[i].state()[0])
+        sa, sb = fa[i].state(), fb[i].state()
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y, equal_nan=True)
+    # pipelined calls without components (no flag, the wait synchronises the stream)
+    outs, want = [], []
+    for j in range(3):
+        fb[0].reset()
+        want.append(fb[0].linearize(Rs[0], ts[0] + np.array([0.001 * j, 0, 0])))
+    for j in range(3):
+        fa[0].reset()
+        outs.append(fa[0].linearize_async(Rs[0], ts[0] + np.array([0.001 * j, 0, 0])))
+    fa[0].wait()
+    for a, b in zip(outs, want):
+        a = a.as_dict()
+        for k in ("H_ss", "b_s", "f", "loc_trans_final", "eigvec_rot"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.all(np.isnan(a["loc_trans_comp"]))
+    # a clone inherits the switch; switching it on brings the components back
+    c_off, c_on, d = fa[1].clone(), fa[1].clone(), fb[1].clone()
+    c_on.set_components(True)
+    assert np.all(np.isnan(c_off.linearize(Rs[1], ts[1])["loc_rot_comp"]))
+    _same(c_on.linearize(Rs[1], ts[1]), d.linearize(Rs[1], ts[1]))
+    for f in (c_off, c_on, d):
+        f.destroy()
+    # batch: all off
+    for f in fa + fb:
+        f.reset()
+    got, want = capi.linearize_batch(fa, Rs, ts), capi.linearize_batch(fb, Rs, ts)
+    for i in range(4):
+        _core_same(got[i], want[i])
+        assert np.all(np.isnan(got[i]["loc_trans_comp"])) and list(got[i]["status_hist"]) == [-1] * 9
+    # batch: mixed — K4 runs, the factors that asked for it get their components, the others NaN
+    fa[2].set_components(True)
+    for f in fa + fb:
+        f.reset()
+    got, want = capi.linearize_batch(fa, Rs, ts), capi.linearize_batch(fb, Rs, ts)
+    _same(got[2], want[2])
+    for i in (0, 1, 3):
+        _core_same(got[i], want[i])
+        assert np.all(np.isnan(got[i]["loc_rot_comp"]))
+    for f in fa + fb:
+        f.destroy()
+    gm.release()
