@@ -608,6 +608,17 @@ def main():
         run_steps(args.steps)
     barrier()
     elapsed_noev = max(time.perf_counter() - a, 1e-9)
+    # the same pipelined pass with the component pass switched off: every step is K3 alone
+    for f in factors:
+        f.set_components(False)
+    barrier()
+    a = time.perf_counter()
+    if not args.profile_mode:
+        run_steps(args.steps)
+    barrier()
+    elapsed_nocomp = max(time.perf_counter() - a, 1e-9)
+    for f in factors:
+        f.set_components(True)
 
     # Aggregate throughput with several independent scans in flight (own HIP streams, shared map): a single
     # 131 072-point scan can only put 2 waves on a SIMD, concurrent scans fill the machine.
@@ -758,6 +769,7 @@ def main():
         "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
         "sync_latency_without_components_ms": round(lat_nc_ms, 4),
         "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
+        "value_without_components": round(total_pts / elapsed_nocomp / 1e6, 2),
         "value_concurrent": conc,
         "keyframe_map_update": kf_stats,
         "scan_frontend": fe_stats,

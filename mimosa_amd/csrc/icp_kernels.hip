@@ -664,41 +664,11 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   return total_ref;
 }
 
-// Eigen-decomposition of a symmetric PSD 3x3 (covariance of k points) for the plane fit:
-// eigenvalues ascending + unit eigenvector of the smallest.  Replaces the
-// Eigen::SelfAdjointEigenSolver call of estimatePlane (geometric_factor.hpp:196), which only consumes
-// the three eigenvalues and eigenvector 0 (:202-215).
-//   w0: Newton on the characteristic cubic p(x) = x^3 - c2 x^2 + c1 x - c0 from x = 0.  For a PSD
-//       matrix p is increasing and concave on [0, w0], so the iterates rise monotonically to the
-//       smallest root with no overshoot; convergence is quadratic (<= 6 steps from 0 in fp64).
-//   w1, w2: the deflated quadratic.  v0: best-conditioned cross product of two rows of A - w0 I.
-// fp64 throughout; |dw| ~ eps |A|, far inside the 1e-5 parity bar and the plane gates' margins.
-// (The trigonometric closed form costs three fp64 transcendental calls per point: 2x this.)
-__device__ __forceinline__ void plane_eigen(const double a00, const double a01, const double a02, const double a11,
-                                            const double a12, const double a22, double (&w)[3], double (&v)[3])
+// null vector of M = A - lambda I (lambda ~ an eigenvalue): the largest of the three cross products of its rows
+__device__ __forceinline__ void null_vector3(const double a00, const double a01, const double a02, const double a11, const double a12,
+                                             const double a22, const double lambda, double (&v)[3])
 {
-  const double c2 = a00 + a11 + a22;
-  const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
-  const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
-  double x = 0.0;
-#pragma unroll 1
-  for (int it = 0; it < 8; ++it) {
-    const double p = ((x - c2) * x + c1) * x - c0;
-    const double dp = (3.0 * x - 2.0 * c2) * x + c1;
-    if (!(dp > 0.0)) break;
-    const double step = p / dp;
-    x -= step;
-    if (fabs(step) <= 1e-16 * fabs(x)) break;
-  }
-  const double w0 = x;
-  const double S = c2 - w0;               // w1 + w2
-  const double P = c1 - w0 * S;           // w1 * w2
-  const double disc = sqrt(fmax(S * S - 4.0 * P, 0.0));
-  w[0] = w0;
-  w[1] = 0.5 * (S - disc);
-  w[2] = 0.5 * (S + disc);
-  // eigenvector of w0: rows of M = A - w0 I are orthogonal to it
-  const double m00 = a00 - w0, m11 = a11 - w0, m22 = a22 - w0;
+  const double m00 = a00 - lambda, m11 = a11 - lambda, m22 = a22 - lambda;
   const double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;  // r0 x r1
   const double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;  // r0 x r2
   const double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;  // r1 x r2
@@ -726,6 +696,76 @@ __device__ __forceinline__ void plane_eigen(const double a00, const double a01, 
     v[1] = 0.0;
     v[2] = 0.0;
   }
+}
+
+// Eigen-decomposition of a symmetric PSD 3x3 (covariance of k points) for the plane fit:
+// eigenvalues ascending + unit eigenvector of the smallest.  Replaces the
+// Eigen::SelfAdjointEigenSolver call of estimatePlane (geometric_factor.hpp:196), which only consumes
+// the three eigenvalues and eigenvector 0 (:202-215).
+//   w0: Newton on the characteristic cubic p(x) = x^3 - c2 x^2 + c1 x - c0 from x = 0.  For a PSD
+//       matrix p is increasing and concave on [0, w0], so the iterates rise monotonically to the
+//       smallest root with no overshoot; convergence is quadratic (<= 6 steps from 0 in fp64).
+//   w1, w2: the deflated quadratic.  v0: best-conditioned cross product of two rows of A - w0 I.
+// fp64 throughout; |dw| ~ eps |A|, far inside the 1e-5 parity bar and the plane gates' margins.
+// (The trigonometric closed form costs three fp64 transcendental calls per point: 2x this.)
+__device__ __forceinline__ void plane_eigen(const double a00, const double a01, const double a02, const double a11,
+                                            const double a12, const double a22, double (&w)[3], double (&v)[3])
+{
+  const double c2 = a00 + a11 + a22;
+  const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+  const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+  double x = 0.0;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const double p = ((x - c2) * x + c1) * x - c0;
+    const double dp = (3.0 * x - 2.0 * c2) * x + c1;
+    if (!(dp > 0.0)) break;
+    const double step = p / dp;
+    x -= step;
+    if (fabs(step) <= 1e-16 * fabs(x)) break;
+  }
+  double w0 = x;
+  null_vector3(a00, a01, a02, a11, a12, a22, w0, v);
+  {
+    // Two close smallest eigenvalues (a neighbourhood as thick in one in-plane direction as across the plane; about one
+    // query in a thousand has them within 25 %).  Newton on the characteristic polynomial converges only linearly until it
+    // has resolved the pair (8 steps do not), and even a converged root is good to ~eps w0 w1 / gap only, an error the
+    // eigenvector inherits divided by the gap once more: 5 degrees off in the fuzz case that found this (gap 1.2 % of w1).
+    // So, for those lanes only: finish the Newton iteration (from below it can only reach the smallest root), then
+    // Rayleigh refinement on the MATRIX — lambda = v'Av is second-order accurate in v, so every round squares the error —
+    // which ends at the eps |A| / gap an iterative solver like Eigen's delivers.  The usual lane skips all of it.
+    const double S0 = c2 - w0, P0 = c1 - w0 * S0;
+    const double w1e = 0.5 * (S0 - sqrt(fmax(S0 * S0 - 4.0 * P0, 0.0)));
+    if (w1e - w0 < 0.25 * w1e) {
+      double prev = kDblMax;
+#pragma unroll 1
+      for (int it = 0; it < 56; ++it) {
+        const double p = ((x - c2) * x + c1) * x - c0;
+        const double dp = (3.0 * x - 2.0 * c2) * x + c1;
+        if (!(dp > 0.0)) break;
+        const double step = p / dp;
+        if (!(fabs(step) < 0.75 * prev)) break;  // steps halve while the pair is unresolved, then collapse; noise does neither
+        x -= step;
+        prev = fabs(step);
+        if (fabs(step) <= 1e-16 * fabs(x)) break;
+      }
+      w0 = x;
+      null_vector3(a00, a01, a02, a11, a12, a22, w0, v);
+#pragma unroll 1
+      for (int r = 0; r < 3; ++r) {
+        const double Av0 = a00 * v[0] + a01 * v[1] + a02 * v[2], Av1 = a01 * v[0] + a11 * v[1] + a12 * v[2],
+                     Av2 = a02 * v[0] + a12 * v[1] + a22 * v[2];
+        w0 = v[0] * Av0 + v[1] * Av1 + v[2] * Av2;
+        null_vector3(a00, a01, a02, a11, a12, a22, w0, v);
+      }
+    }
+  }
+  const double S = c2 - w0;               // w1 + w2
+  const double P = c1 - w0 * S;           // w1 * w2
+  const double disc = sqrt(fmax(S * S - 4.0 * P, 0.0));
+  w[0] = w0;
+  w[1] = 0.5 * (S - disc);
+  w[2] = 0.5 * (S + disc);
 }
 
 // Inter-workgroup hand-off of the per-block partial rows (cdna_hip_programming.md §6 G16,

@@ -10,6 +10,12 @@ from parity import assert_result_parity, assert_state_parity
 pytestmark = pytest.mark.gpu
 
 
+def _EXTRA(base):
+    """MH_FUZZ_EXTRA=N: N more seeds per fuzz test (a bug hunt on demand, not part of the default suite)"""
+    import os
+    return [base + i for i in range(int(os.environ.get("MH_FUZZ_EXTRA", "0")))]
+
+
 def _case(seed):
     rng = np.random.default_rng(1000 + seed)
     room = np.array([rng.uniform(5, 14), rng.uniform(4, 11), rng.uniform(2.5, 5)])
@@ -34,7 +40,10 @@ def _case(seed):
     return m, pts, cfg, mode, R, t, rng
 
 
-@pytest.mark.parametrize("seed", range(14))
+# 225, 271, 356, 923: found by the wide sweep (MH_FUZZ_EXTRA=1500) — neighbourhoods whose two smallest covariance
+# eigenvalues are within 1-10 % of each other; 356 put one Valid point's normal 5 degrees off (H 3.5e-5 off) before
+# plane_eigen got its Rayleigh refinement.  238, 1303: 4-5 valid points in all, H singular
+@pytest.mark.parametrize("seed", list(range(14)) + [225, 238, 271, 356, 923, 1303] + _EXTRA(100))
 def test_random_configuration(ctx, seed):
     from mimosa_amd import capi
     from oracle import ref_cpu
@@ -80,7 +89,7 @@ def _random_cloud(rng, n):
     return xyz.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(200))
 def test_random_scan_frontend(ctx, seed):
     """prepareInput -> preprocess on random clouds and filter settings: same points, same order, same bits as the oracle."""
     from mimosa_amd import capi
@@ -119,7 +128,7 @@ def test_random_scan_frontend(ctx, seed):
     sc.destroy()
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", list(range(5)) + _EXTRA(300))
 def test_random_map_insert_sequences(ctx, seed):
     """iVox insert + LRU purge over random batch sequences (clusters that saturate voxels, duplicates, boundary points, tiny and
     large batches): getCloud — points AND order — equals the oracle's after every insert."""
