@@ -149,3 +149,46 @@ def test_random_map_insert_sequences(ctx, seed):
         assert gm.stats()["n_points"] == rm.num_points, b
         assert np.array_equal(gm.get_cloud(), rm.export()[2]), b
     gm.release()
+
+
+@pytest.mark.parametrize("seed", list(range(4)) + _EXTRA(400))
+def test_random_window_batches(ctx, seed):
+    """mh_icp_linearize_batch over random windows — 1..9 factors, ragged sizes from empty to several thousand points, unary or
+    binary, components on for a random subset — is bit-identical to the same factors linearized one call at a time, cold
+    and over a re-linearization walk."""
+    from mimosa_amd import capi
+
+    m, pts, cfg, mode, R, t, rng = _case(seed)
+    leaf, md = cfg["target_ivox_map_leaf_size"], cfg["target_ivox_map_min_dist_in_voxel"]
+    gm = capi.VoxelMap(ctx, leaf=leaf, min_dist=md, mode=mode)
+    gm.insert(m)
+    binary = bool(rng.integers(0, 2))
+    nf = int(rng.integers(1, 10))
+    rc = capi.make_reg_config(**cfg)
+    fa, fb, on = [], [], []
+    for i in range(nf):
+        n = int(rng.choice([0, 1, 63, 64, 65, 300, len(pts) // 2, len(pts)]))
+        sub = np.ascontiguousarray(pts[rng.permutation(len(pts))[:n]])
+        fa.append(capi.ICPFactor(ctx, gm, sub, rc, binary=binary))
+        fb.append(capi.ICPFactor(ctx, gm, sub, rc, binary=binary))
+        on.append(bool(rng.integers(0, 2)))
+        fa[-1].set_components(on[-1])
+        fb[-1].set_components(on[-1])
+    keys = ("H_ss", "b_s", "f", "loc_trans_final", "loc_rot_final", "eigvec_rot", "eigvec_trans", "degen_rot", "degen_trans", "n_knn",
+            "mean_candidates", "linearize_count", "H_st", "H_tt", "b_t", "loc_trans_comp", "loc_rot_comp", "status_hist")
+    thr = md / 4.0
+    Rt, tt = R @ synth.so3_exp(rng.normal(0, 0.01, 3)), t + rng.normal(0, 0.05, 3)
+    for step in range(3):
+        Rs = [R @ synth.so3_exp(rng.normal(0, 1.0, 3) * thr / 5.0) for _ in range(nf)]
+        ts = [t + rng.normal(0, 1.0, 3) * thr * rng.choice([0.3, 1.0, 3.0]) for _ in range(nf)]
+        kw = dict(R_tgts=[Rt] * nf, t_tgts=[tt] * nf) if binary else {}
+        got = capi.linearize_batch(fa, Rs, ts, **kw)
+        for i in range(nf):
+            one = fb[i].linearize(Rs[i], ts[i], R_tgt=Rt, t_tgt=tt) if binary else fb[i].linearize(Rs[i], ts[i])
+            for k in keys:
+                assert np.array_equal(np.asarray(got[i][k], float), np.asarray(one[k], float), equal_nan=True), (step, i, k)
+            for x, y in zip(fa[i].state(), fb[i].state()):
+                assert np.array_equal(x, y, equal_nan=True)
+    for f in fa + fb:
+        f.destroy()
+    gm.release()

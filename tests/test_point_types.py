@@ -233,3 +233,69 @@ def test_layout_misuse_is_reported(ctx):
     info = sc.prepare_input_layout(raw[:0], L, cfg, width=0, height=1)                 # empty cloud
     assert info["n_full"] == 0
     sc.destroy()
+
+
+def _EXTRA(base):
+    import os
+    return [base + i for i in range(int(os.environ.get("MH_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)) + _EXTRA(100))
+def test_random_record_layouts(ctx, seed):
+    """The layout descriptor is general: the same sensor data re-packed into a record with the fields in a random order, at
+    random (also unaligned) offsets and a random stride must give the result of the reference's typed code on the original."""
+    from mimosa_amd import capi
+    rng = np.random.default_rng(4200 + seed)
+    kind = ref_cpu.POINT_KINDS[int(rng.integers(0, len(ref_cpu.POINT_KINDS)))]
+    rows, cols = int(rng.choice([8, 32, 64])), int(rng.choice([33, 128, 200]))
+    order = "col" if rng.integers(0, 2) else "row"
+    raw = make_sensor_scan(kind, rows=rows, cols=cols, seed=int(rng.integers(0, 1000)), order=order)
+    L0, dt0 = capi.point_layout(kind), capi.point_dtype(kind)
+    fields = [("x", "off_x"), ("y", "off_y"), ("z", "off_z")]
+    fields.append(("reflectivity" if L0.intensity_is_u16 else "intensity", "off_intensity"))
+    tname = {capi.TIME_U32_NS: "t", capi.TIME_F64_S_ABS: "timestamp", capi.TIME_F64_NS_ABS: "timestamp", capi.TIME_F32_S: "time"}[L0.time_kind]
+    fields.append((tname, "off_time"))
+    if L0.ring_kind != capi.RING_NONE:
+        fields.append(("ring", "off_ring"))
+    if L0.has_tag:
+        fields.append(("tag", "off_tag"))
+    # random order, random gaps
+    perm = rng.permutation(len(fields))
+    off, names, formats, offsets = int(rng.integers(0, 5)), [], [], []
+    L = capi.point_layout(kind)
+    for i in perm:
+        name, attr = fields[i]
+        fmt = dt0.fields[name][0]
+        names.append(name), formats.append(fmt), offsets.append(off)
+        setattr(L, attr, off)
+        off += fmt.itemsize + int(rng.choice([0, 0, 1, 3, 4, 7]))
+    stride = off + int(rng.choice([0, 1, 5, 16]))
+    L.stride = stride
+    dt = np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": stride})
+    packed = np.zeros(len(raw), dt)
+    junk = rng.integers(0, 256, size=(len(raw), stride), dtype=np.uint8)     # the gaps hold other fields' bytes in real messages
+    packed.view(np.uint8).reshape(len(raw), stride)[:] = junk
+    for name in names:
+        packed[name] = raw[name]
+    kw = dict(point_skip_divisor=int(rng.choice([1, 2, 3, 4])), ring_skip_divisor=int(rng.choice([1, 2, 3])),
+              create_full_res_pointcloud=int(rng.integers(0, 2)), range_min=float(rng.choice([0.0, 1.0])), z_offset=float(rng.choice([0.0, -0.03])))
+    can_transpose = kind in ("rslidar", "velodyne_anybotics")
+    ordr = {}
+    if order == "col" and can_transpose and rng.integers(0, 2):
+        ordr = dict(width=rows, height=cols, transpose=True)
+    elif rng.integers(0, 2):
+        ordr = dict(organize_by_ring=True)
+    else:
+        ordr = dict(width=cols, height=rows) if order == "row" else dict(width=rows, height=cols)
+    cfg = capi.make_input_config(**kw)
+    o = ref_cpu.prepare_input_typed(kind, raw, ref_cpu.make_input_config(**kw), header_ts=HEADER_TS, width=ordr.get("width"),
+                                    height=ordr.get("height", 1), transpose=ordr.get("transpose", False), organize=ordr.get("organize_by_ring", False))
+    sc = capi.Scan(ctx)
+    info = sc.prepare_input_layout(packed, L, cfg, header_ts=HEADER_TS, **ordr)
+    assert info["n_full"] == len(o["points_full"]) and info["n_geometric"] == len(o["geometric_idxs"])
+    assert info["last_point_ns"] == o["last_point_ns"]
+    assert np.array_equal(sc.unique_ns(), o["unique_ns"])
+    _same_points(sc.points(capi.Scan.FULL), _as_points(o["points_full"]))
+    assert np.array_equal(sc.indices(0), o["geometric_idxs"].astype(np.uint32))
+    sc.destroy()
