@@ -49,3 +49,47 @@ def run(dist, ctx, device, cfg_over=None):
         assert stats["n_points"] == M.num_points
     sh.close()
     return moved
+
+
+def run_random(dist, ctx, device, seed):
+    """One random configuration of the sharded path against the unsharded oracle: room, map density, neighbour-independent
+    registration options, how the scan is split over the ranks, and a pose walk from millimetres to decimetres (points change
+    owner).  Every rank draws the same numbers."""
+    from mimosa_amd import capi, dist as mdist, synth
+    from oracle import ref_cpu
+    from parity import assert_result_parity, assert_state_parity
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(88000 + seed)
+    room = np.array([rng.uniform(8, 30), rng.uniform(6, 20), rng.uniform(2.5, 4)])
+    grid = float(rng.choice([0.11, 0.16, 0.3]))
+    map_xyz = synth.make_room(6000 + seed, 0, 0, grid=grid, room=room)
+    loc = np.array([rng.uniform(1.5, room[0] - 1.5), rng.uniform(1.5, room[1] - 1.5), rng.uniform(0.8, room[2] - 0.8)])
+    scan, aux = synth.make_scan(n_rows=int(rng.choice([16, 32])), seed=7000 + seed, n_cols=int(rng.choice([64, 128])), room=room, sensor_local=loc)
+    R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    cfg = dict(synth.enwide_config(), use_huber=int(rng.integers(0, 2)), reg_4_dof=int(rng.integers(0, 2)),
+               project_on_degneneracy=int(rng.integers(0, 2)), degen_thresh_trans=float(rng.choice([15.0, 40.0, 1e9])),
+               max_corres_distance=float(rng.choice([0.5, 1.0])), plane_validity_distance=float(rng.choice([0.04, 0.07, 0.2])))
+    sh = mdist.ShardedICPDevice(dist.group.WORLD, ctx, 0.5, capi.make_reg_config(**cfg), device)
+    chunks = np.array_split(map_xyz, int(rng.integers(1, 5)))
+    sh.build_map(chunks)
+    cuts = np.sort(rng.integers(0, len(scan) + 1, world - 1)) if world > 1 else np.array([], int)   # uneven, possibly empty shares
+    split = np.split(np.arange(len(scan)), cuts)
+    sh.set_scan(scan[split[rank]])
+    M = ref_cpu.Map()
+    for c in chunks:
+        M.insert(c)
+    F = ref_cpu.ICP(M, scan, ref_cpu.make_config(**cfg))
+    Rk, tk = R, t
+    for k in range(4):
+        got, ref = sh.linearize(Rk, tk), F.linearize(Rk, tk)
+        assert_result_parity(got, ref, check_eigvec=False)
+        origin, st, mean, nrm = sh.state()
+        glob = np.array([split[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin], np.int64)
+        rs, rm, rn, _ = F.da_state()
+        if len(glob):
+            assert_state_parity((st, mean, nrm), (rs[glob], rm[glob], rn[glob]))
+        scale = float(rng.choice([0.002, 0.03, 0.15]))
+        Rk = Rk @ synth.so3_exp(rng.normal(0, 1.0, 3) * scale / 5.0)
+        tk = tk + rng.normal(0, 1.0, 3) * scale
+    sh.close()

@@ -22,5 +22,8 @@ ctx = capi.Context(0)
 moved = dist_gpu_common.run(dist, ctx, torch.device("cuda", 0))
 assert moved > 0, "no point changed owner between the poses"
 dist_gpu_common.run(dist, ctx, torch.device("cuda", 0), dict(project_on_degneneracy=1, degen_thresh_trans=1e9))
+# MH_FUZZ_EXTRA=N: N random configurations on top (a bug hunt on demand)
+for seed in range(2 + int(os.environ.get("MH_FUZZ_EXTRA", "0"))):
+    dist_gpu_common.run_random(dist, ctx, torch.device("cuda", 0), seed)
 dist.destroy_process_group()
 print("OK", rank)
