@@ -82,3 +82,28 @@ def test_native_replay_equals_python_replay(ctx, tmp_path):
     assert np.allclose(rn["first_costs"], rp["costs"][0], rtol=1e-9)
     for (Ra, ta), (Rb, tb) in zip(rn["poses_est"], rp["poses_est"]):
         assert np.max(np.abs(ta - tb)) < 1e-7 and np.max(np.abs(Ra - Rb)) < 1e-8
+
+
+def _EXTRA(base):
+    import os
+    return [base + i for i in range(int(os.environ.get("MH_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1] + _EXTRA(10))
+def test_replay_hip_equals_oracle_random_sequences(ctx, seed):
+    """Random platform twists, rooms, image sizes, window lengths and keyframe thresholds: the HIP loop and the oracle loop
+    make the same keyframe decisions, track the same features and produce the same trajectory."""
+    rng = np.random.default_rng(515 + seed)
+    rows, cols = int(rng.choice([32, 64])), int(rng.choice([256, 512]))
+    cfg = replay.ReplayConfig(n_scans=5, rows=rows, cols=cols, room=(float(rng.uniform(9, 16)), float(rng.uniform(8, 12)), float(rng.uniform(2.8, 3.5))),
+                              v=(float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-0.5, 0.5)), 0.0), w=(0.0, 0.0, float(rng.uniform(-0.5, 0.5))),
+                              window=int(rng.choice([2, 3, 5])), update_iters=int(rng.choice([2, 6])),
+                              keyframe_trans_thresh=float(rng.choice([0.1, 0.2, 1.0])), keyframe_rot_thresh_deg=float(rng.choice([2.0, 5.0, 20.0])),
+                              photometric=bool(rng.integers(0, 2)))
+    scans = replay.make_scans(cfg)
+    ro = replay.run(cfg, OracleBackend(cfg), scans)
+    rh = replay.run(cfg, replay.HipBackend(ctx, cfg), scans)
+    assert rh["n_keyframes"] == ro["n_keyframes"] and rh["photo_valid"] == ro["photo_valid"]
+    for (Ra, ta), (Rb, tb) in zip(rh["poses_est"], ro["poses_est"]):
+        assert np.max(np.abs(ta - tb)) < 1e-7 and np.max(np.abs(Ra - Rb)) < 1e-8
