@@ -192,3 +192,79 @@ def test_random_window_batches(ctx, seed):
     for f in fa + fb:
         f.destroy()
     gm.release()
+
+
+@pytest.mark.parametrize("seed", [0] + _EXTRA(500))
+def test_random_large_clouds(ctx, seed):
+    """The 512-thread / multi-XCD regime (clouds of 66 k - 131 k points against rooms sampled with 0.1 - 1.5 M points): random
+    room, density, sensor pose, pose error and registration options; cold + one partial re-association."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    rng = np.random.default_rng(64000 + seed)
+    room = np.array([rng.uniform(15, 40), rng.uniform(12, 25), rng.uniform(3, 6)])
+    grid = float(rng.choice([0.05, 0.08, 0.12]))
+    m = synth.make_room(8000 + seed, 0, 0, grid=grid, room=room)
+    loc = np.array([rng.uniform(2, room[0] - 2), rng.uniform(2, room[1] - 2), rng.uniform(0.8, room[2] - 0.8)])
+    pts, aux = synth.make_scan(n_rows=128, seed=9000 + seed, n_cols=int(rng.choice([520, 777, 1024])), room=room, sensor_local=loc)
+    cfg = synth.enwide_config()
+    cfg.update(use_huber=int(rng.integers(0, 2)), reg_4_dof=int(rng.integers(0, 2)), num_corres_points=int(rng.choice([5, 5, 8])),
+               max_corres_distance=float(rng.choice([0.5, 1.0])))
+    mode = int(rng.choice([7, 19, 27]))
+    gm, rm = capi.VoxelMap(ctx, mode=mode), ref_cpu.Map(mode=mode)
+    for chunk in np.array_split(m, 3):
+        gm.insert(chunk)
+        rm.insert(chunk)
+    assert gm.stats()["n_points"] == rm.num_points
+    R = aux["R_W_L"] @ synth.so3_exp(np.deg2rad(rng.normal(0, 0.5, 3)))
+    t = aux["t_W_L"] + aux["R_W_L"] @ rng.normal(0, 0.04, 3)
+    gf = capi.ICPFactor(ctx, gm, pts, capi.make_reg_config(**cfg))
+    rf = ref_cpu.ICP(rm, pts, ref_cpu.make_config(**cfg))
+    assert len(pts) > 65536
+    for step in range(2):
+        got, ref = gf.linearize(R, t), rf.linearize(R, t)
+        assert_result_parity(got, ref, check_eigvec=False)
+        assert_state_parity(gf.state(), rf.state())
+        R, t = R @ synth.so3_exp(np.array([0.0, 0.0, 1.5e-3])), t + rng.normal(0, 0.02, 3)
+    gf.destroy()
+    gm.release()
+
+
+
+def test_non_finite_and_far_inputs_do_not_fault(ctx, small_world):
+    """NaN / Inf / absurdly far source points and poses: the reference computes NaNs and moves on; the device path must neither
+    fault nor hang, must keep every finite point's result intact, and must report the bad points as rejected."""
+    from mimosa_amd import capi
+
+    w = small_world
+    gm = capi.VoxelMap(ctx)
+    gm.insert(w["map_xyz"])
+    pts = w["pts"].copy()
+    n = len(pts)
+    bad = np.arange(0, n, 97)
+    vals = [np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, 1e-30]
+    for j, i in enumerate(bad):
+        pts["xyz"[j % 3]][i] = np.float32(vals[j % len(vals)])
+    rc = capi.make_reg_config(**w["cfg"])
+    gf, clean = capi.ICPFactor(ctx, gm, pts, rc), capi.ICPFactor(ctx, gm, np.delete(w["pts"], bad), rc)
+    g, c = gf.linearize(w["R"], w["t"]), clean.linearize(w["R"], w["t"])
+    st = gf.state()[0]
+    finite = np.isfinite(pts["x"]) & np.isfinite(pts["y"]) & np.isfinite(pts["z"]) & (np.abs(pts["x"]) < 1e6) & (np.abs(pts["y"]) < 1e6) & (np.abs(pts["z"]) < 1e6)
+    assert np.all(st[~finite] != 8)
+    assert np.array_equal(np.delete(st, bad), clean.state()[0])
+    assert g["status_hist"][8] == c["status_hist"][8]
+    assert np.allclose(g["H_ss"], c["H_ss"], rtol=1e-12, atol=0) and np.all(np.isfinite(g["H_ss"]))
+    # a NaN pose: everything is rejected or NaN, nothing faults, and the factor is usable afterwards
+    Rn = w["R"].copy()
+    Rn[0, 0] = np.nan
+    gf.linearize(Rn, w["t"])
+    gf.reset()
+    g2 = gf.linearize(w["R"], w["t"])
+    assert np.array_equal(g2["H_ss"], g["H_ss"])
+    # k-NN queries far outside the map / non-finite
+    q = np.array([[1e30, 0, 0], [np.nan, 0, 0], [np.inf, -np.inf, 0], [3e9, 3e9, 3e9], [0.1, 0.2, 0.3]])
+    _, _, found = gm.knn(q, 5)
+    assert list(found[:4]) == [0, 0, 0, 0]
+    for f in (gf, clean):
+        f.destroy()
+    gm.release()
