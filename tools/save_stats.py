@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Copy the newest rocprofv3 *_kernel_stats.csv under <dir> to <out.csv> with the kernel names shortened to the function
 name (rocPRIM's template names run to kilobytes)."""
-import csv, glob, re, sys
-f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv"))[-1]
+import csv, glob, os, re, sys
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv"), key=os.path.getmtime)  # gpurun_out/ accumulates: newest, not last by name
 w = csv.writer(open(sys.argv[2], "w"))
 w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
 for r in csv.DictReader(open(f)):
