@@ -394,7 +394,7 @@ typedef struct mh_photo_config {
   int32_t n_low_pass;
   int32_t brightness_window_size[2];    /* cv::Size(width, height) */
   float lidar_origin_to_beam_origin_mm;
-  int32_t rotate_patch_to_align_with_gradient; /* must be 0 (false in every shipped configuration) */
+  int32_t rotate_patch_to_align_with_gradient; /* photometric.cpp:659-684: new features sample the pattern rotated into their edge frame */
   const int32_t * patch_offsets;        /* edgelet_patch_offsets: n_patch_offsets pairs (du, dv); <= 64 */
   int32_t n_patch_offsets;
   int32_t use_robust_cost_function;

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <set>
 #include <vector>
 
 #include "math3.hpp"
@@ -340,6 +341,45 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   return MH_OK;
 }
 
+// photometric_utils.cpp:453-483 — the nearest free pixel (one of the 8 neighbours when the rounded one is taken)
+std::pair<int, int> snap_point(const std::pair<double, double> & p, std::set<std::pair<int, int>> & used)
+{
+  const int gx = static_cast<int>(std::round(p.first)), gy = static_cast<int>(std::round(p.second));
+  const std::pair<int, int> first{gx, gy};
+  if (used.insert(first).second) return first;
+  double best_d = std::numeric_limits<double>::max();
+  std::pair<int, int> best = first;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy) {
+      if (dx == 0 && dy == 0) continue;
+      const std::pair<int, int> alt{gx + dx, gy + dy};
+      if (used.count(alt)) continue;
+      const double ex = alt.first - p.first, ey = alt.second - p.second;
+      const double d = std::sqrt(ex * ex + ey * ey);
+      if (d < best_d) {
+        best_d = d;
+        best = alt;
+      }
+    }
+  used.insert(best);
+  return best;
+}
+
+// photometric_utils.cpp:485-518 — getGradientBasedLocations: the pattern in the (edge normal, edge tangent) frame of the
+// candidate, snapped to distinct pixels (rotate_patch_to_align_with_gradient, photometric.cpp:659-684)
+void gradient_based_locations(float gx, float gy, const std::vector<int32_t> & pattern, int32_t * out)
+{
+  const double norm = std::sqrt(gx * gx + gy * gy) + 1e-6;  // float products and float sqrt, as there
+  const double nx = -gy / norm, ny = gx / norm, tx = gx / norm, ty = gy / norm;
+  std::set<std::pair<int, int>> used;
+  for (size_t o = 0; o < pattern.size() / 2; ++o) {
+    const double x = pattern[2 * o], y = pattern[2 * o + 1];
+    const std::pair<int, int> g = snap_point({nx * x + tx * y, ny * x + ty * y}, used);
+    out[2 * o] = g.first;
+    out[2 * o + 1] = g.second;
+  }
+}
+
 int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3], const double * bias,
                          size_t n_dirs)
 {
@@ -405,7 +445,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_win + b_rec + rec_idx.size() * 4 + 256, ctx->stream, false));
     char * d = static_cast<char *>(ph->d_gather.p);
     MH_HIP(ctx, hipMemcpyAsync(d, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_cand, static_cast<const float *>(fr->d_intensity.p),
+    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_cand, false, static_cast<const float *>(fr->d_intensity.p),
                                         static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
                                         reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
                                         reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
@@ -416,9 +456,12 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   }
   // :575-625 scores of every candidate along every bias direction
   std::vector<std::vector<std::pair<double, int>>> scores(n_dirs, std::vector<std::pair<double, int>>(cand.size(), {0.0, 0}));
+  std::vector<float> grad_dir(2 * cand.size());
   for (size_t i = 0; i < cand.size(); ++i) {
     float ix, iy;
     patch_gradient_direction(&win[i * 49], 7, 3, 3, ix, iy);
+    grad_dir[2 * i] = ix;
+    grad_dir[2 * i + 1] = iy;
     const size_t ctr = i * per + m_off;
     if (rec_idx[ctr] < 0) continue;
     double P[6];
@@ -443,6 +486,35 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
         const int k = scores[b][i].second;
         if (std::find(selected.begin(), selected.end(), k) == selected.end()) selected.push_back(k);
       }
+  // rotate_patch_to_align_with_gradient (:659-684): every selected candidate samples its own rotated pattern — a second,
+  // per-candidate gather of just those (a handful of) candidates replaces the records of the fixed pattern
+  std::vector<size_t> rec_at(cand.size());  // where candidate k's patch records start
+  for (size_t k = 0; k < cand.size(); ++k) rec_at[k] = k * per;
+  if (c.rotate_patch_to_align_with_gradient && !selected.empty()) {
+    const int n_sel = static_cast<int>(selected.size());
+    std::vector<int32_t> uv(2 * static_cast<size_t>(n_sel) * (m_off + 1));
+    for (int j = 0; j < n_sel; ++j) {
+      const int k = selected[j];
+      gradient_based_locations(grad_dir[2 * k], grad_dir[2 * k + 1], ph->offsets, &uv[2 * static_cast<size_t>(j) * m_off]);
+      uv[2 * (static_cast<size_t>(n_sel) * m_off + j)] = cand[k].first;
+      uv[2 * (static_cast<size_t>(n_sel) * m_off + j) + 1] = cand[k].second;
+      rec_at[k] = static_cast<size_t>(j) * per;
+    }
+    rec.assign(static_cast<size_t>(n_sel) * per * 4, 0.f);
+    rec_idx.assign(static_cast<size_t>(n_sel) * per, -1);
+    const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (static_cast<size_t>(n_sel) * 49 * 4 + 255) & ~size_t(255),
+                 b_rec = (rec.size() * 4 + 255) & ~size_t(255);
+    MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_win + b_rec + rec_idx.size() * 4 + 256, ctx->stream, false));
+    char * d = static_cast<char *>(ph->d_gather.p);
+    MH_HIP(ctx, hipMemcpyAsync(d, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_sel, true, static_cast<const float *>(fr->d_intensity.p),
+                                        static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
+                                        reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
+                                        reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(rec.data(), d + b_uv + b_win, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(rec_idx.data(), d + b_uv + b_win + b_rec, rec_idx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   Pose TBL, TWB;
   std::memcpy(TBL.R, c.T_B_L_R, sizeof(TBL.R));
   std::memcpy(TBL.t, c.T_B_L_t, sizeof(TBL.t));
@@ -461,8 +533,9 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     ft.hdr.n_points = m;
     bool missing = false;
     for (int o = 0; o < m; ++o) {
-      const size_t at = static_cast<size_t>(k) * per + o;  // pixel (lx, ly) + patch offset o
-      if (rec_idx[at] < 0) {  // the reference indexes the cloud with -1 here (undefined behaviour); the eroded mask makes it unreachable
+      const size_t at = rec_at[k] + o;  // pixel (lx, ly) + patch offset o
+      if (rec_idx[at] < 0) {  // the reference indexes the cloud with -1 here (undefined behaviour); the eroded mask makes it
+                              // unreachable for the plain pattern, a rotated one can get there when erosion_buffer is small
         missing = true;
         break;
       }
@@ -521,8 +594,6 @@ int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out)
     if (cfg->rows < 2) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: at least two beams");
     if (cfg->n_patch_offsets < 2 || cfg->n_patch_offsets > mh::kPhotoMaxPatch || !cfg->patch_offsets)
       return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: 2..64 patch offsets");
-    if (cfg->rotate_patch_to_align_with_gradient)
-      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: rotate_patch_to_align_with_gradient is not supported (false in every shipped configuration)");
     if (cfg->remove_lines && (cfg->n_high_pass < 1 || cfg->n_low_pass < 1 || cfg->n_high_pass > mh::kPhotoMaxTaps || cfg->n_low_pass > mh::kPhotoMaxTaps ||
                               !(cfg->n_high_pass & 1) || !(cfg->n_low_pass & 1) || !cfg->high_pass_fir || !cfg->low_pass_fir))
       return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: FIR kernels must have an odd length <= 129");

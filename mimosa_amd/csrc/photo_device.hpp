@@ -92,8 +92,8 @@ hipError_t launch_photo_candidates(const uint8_t * grad, const uint8_t * mask, i
                                    uint32_t * n_out, hipStream_t stream);
 // per candidate c (centre uv[n_off + c]): win49[c] = the 7 x 7 intensity window, rec[c][o] = (x, y, z, intensity) and
 // rec_idx[c][o] = point index of the pixel centre + uv[o] (o < n_off) / the centre itself (o == n_off); -1 = no point
-hipError_t launch_photo_gather(const int2 * uv, int n_off, int n_cand, const float * I, const int32_t * idx, const mh_point32 * pts, int rows,
-                               int cols, float * win49, float4 * rec, int32_t * rec_idx, hipStream_t stream);
+hipError_t launch_photo_gather(const int2 * uv, int n_off, int n_cand, bool per_candidate, const float * I, const int32_t * idx,
+                               const mh_point32 * pts, int rows, int cols, float * win49, float4 * rec, int32_t * rec_idx, hipStream_t stream);
 
 // PhotometricFactor::linearize (photometric_factor.hpp:136-355): one wave per feature
 struct PhotoLinArgs

@@ -758,20 +758,23 @@ __global__ __launch_bounds__(kT) void photo_cand_scatter_kernel(const uint8_t * 
 
 // What the host-side selection needs of each candidate that survived the non-maximum suppression: the 7 x 7 intensity
 // window around it (cornerEigenValsAndVecs, O11), and for the patch pixels + the centre: point index, point, intensity.
-// uv: n_off patch offsets, then n_cand candidate centres.  One block per candidate.
-__global__ __launch_bounds__(128) void photo_gather_kernel(const int2 * uv, int n_off, int n_cand, const float * I, const int32_t * idx,
-                                                           const mh_point32 * pts, int rows, int cols, float * win49, float4 * rec, int32_t * rec_idx)
+// uv: n_off patch offsets, then n_cand candidate centres — or, per_candidate (rotate_patch_to_align_with_gradient: every
+// candidate has its own rotated pattern), n_cand x n_off offsets, then the centres.  One block per candidate.
+__global__ __launch_bounds__(128) void photo_gather_kernel(const int2 * uv, int n_off, int n_cand, int per_candidate, const float * I,
+                                                           const int32_t * idx, const mh_point32 * pts, int rows, int cols, float * win49,
+                                                           float4 * rec, int32_t * rec_idx)
 {
   const int c = blockIdx.x;
   if (c >= n_cand) return;
-  const int2 ctr = uv[n_off + c];
+  const int2 ctr = uv[(per_candidate ? n_cand * n_off : n_off) + c];
+  const int2 * offs = uv + (per_candidate ? c * n_off : 0);
   const int t = threadIdx.x;
   if (t < 49) {
     const int u = min(max(ctr.x + (t % 7) - 3, 0), cols - 1), v = min(max(ctr.y + (t / 7) - 3, 0), rows - 1);
     win49[static_cast<size_t>(c) * 49 + t] = I[static_cast<size_t>(v) * cols + u];
   }
   if (t <= n_off) {
-    const int u = ctr.x + (t < n_off ? uv[t].x : 0), v = ctr.y + (t < n_off ? uv[t].y : 0);
+    const int u = ctr.x + (t < n_off ? offs[t].x : 0), v = ctr.y + (t < n_off ? offs[t].y : 0);
     int32_t pi = -1;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (u >= 0 && u < cols && v >= 0 && v < rows) {
@@ -885,11 +888,12 @@ hipError_t launch_photo_candidates(const uint8_t * grad, const uint8_t * mask, i
   hipLaunchKernelGGL(photo_cand_scatter_kernel, g, dim3(kT), 0, stream, grad, mask, npx, thr, blk, out, n_out);
   return hipGetLastError();
 }
-hipError_t launch_photo_gather(const int2 * uv, int n_off, int n_cand, const float * I, const int32_t * idx, const mh_point32 * pts, int rows,
-                               int cols, float * win49, float4 * rec, int32_t * rec_idx, hipStream_t stream)
+hipError_t launch_photo_gather(const int2 * uv, int n_off, int n_cand, bool per_candidate, const float * I, const int32_t * idx,
+                               const mh_point32 * pts, int rows, int cols, float * win49, float4 * rec, int32_t * rec_idx, hipStream_t stream)
 {
   if (n_cand <= 0) return hipSuccess;
-  hipLaunchKernelGGL(photo_gather_kernel, dim3(n_cand), dim3(128), 0, stream, uv, n_off, n_cand, I, idx, pts, rows, cols, win49, rec, rec_idx);
+  hipLaunchKernelGGL(photo_gather_kernel, dim3(n_cand), dim3(128), 0, stream, uv, n_off, n_cand, per_candidate ? 1 : 0, I, idx, pts, rows, cols,
+                     win49, rec, rec_idx);
   return hipGetLastError();
 }
 hipError_t launch_photo_linearize(const PhotoLinArgs & a, hipStream_t stream)

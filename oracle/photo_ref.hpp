@@ -56,6 +56,7 @@
 #include <limits>
 #include <stdexcept>
 #include <utility>
+#include <set>
 #include <vector>
 
 #include "ref_cpu.hpp"
@@ -83,6 +84,7 @@ struct PhotoConfig
   int remove_lines = 1, filter_brightness = 1, gaussian_blur = 1, gaussian_blur_size = 3;
   float gradient_threshold = 20.f, max_dist_from_mean = 0.2f, max_dist_from_plane = 0.1f;
   int nma_radius = 10;
+  bool rotate_patch_to_align_with_gradient = false;  // photometric_config.hpp:61
   int num_features_detect = 60;
   float occlusion_range_diff_threshold = 0.1f;
   int max_feature_life_time = 30;
@@ -836,6 +838,49 @@ inline void fill_circle_zero(std::vector<uint8_t> & img, int rows, int cols, int
   }
 }
 
+// src/lidar/photometric_utils.cpp:453-483 — nearest free grid point (the 8 neighbours when the rounded one is taken)
+inline std::pair<int, int> snap_point(const std::pair<double, double> & p, std::set<std::pair<int, int>> & used)
+{
+  const int grid_x = static_cast<int>(std::round(p.first)), grid_y = static_cast<int>(std::round(p.second));
+  const std::pair<int, int> candidate{grid_x, grid_y};
+  if (used.find(candidate) == used.end()) {
+    used.insert(candidate);
+    return candidate;
+  }
+  double best_distance = std::numeric_limits<double>::max();
+  std::pair<int, int> best = candidate;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy) {
+      if (dx == 0 && dy == 0) continue;
+      const std::pair<int, int> alt{grid_x + dx, grid_y + dy};
+      if (used.find(alt) == used.end()) {
+        const double ddx = alt.first - p.first, ddy = alt.second - p.second;
+        const double dist = std::sqrt(ddx * ddx + ddy * ddy);
+        if (dist < best_distance) {
+          best_distance = dist;
+          best = alt;
+        }
+      }
+    }
+  used.insert(best);
+  return best;
+}
+
+// src/lidar/photometric_utils.cpp:485-518 — the patch pattern rotated into the (edge normal, edge tangent) frame and
+// snapped to distinct pixels
+inline std::vector<std::pair<int, int>> gradient_based_locations(float grad_x, float grad_y, const std::vector<std::pair<int, int>> & pattern)
+{
+  const double norm = std::sqrt(grad_x * grad_x + grad_y * grad_y) + 1e-6;  // float products, promoted by the sqrt
+  const double normal_x = -grad_y / norm, normal_y = grad_x / norm, tangent_x = grad_x / norm, tangent_y = grad_y / norm;
+  std::vector<std::pair<int, int>> snapped;
+  std::set<std::pair<int, int>> used;
+  for (const auto & p : pattern) {
+    const double x = static_cast<double>(p.first), y = static_cast<double>(p.second);
+    snapped.push_back(snap_point({normal_x * x + tangent_x * y, normal_y * x + tangent_y * y}, used));
+  }
+  return snapped;
+}
+
 // O11: centre value of cornerEigenValsAndVecs(roi(7 x 7), blockSize 5, ksize 3) -> gradient direction (i_x, i_y)
 inline void patch_gradient_direction(const std::vector<float> & I, int cols, int x, int y, int patch_size, float & ix, float & iy)
 {
@@ -964,13 +1009,28 @@ inline void detect_features(const PhotoConfig & c, const Frame & f, int num_to_d
     ft.life_time = 1;
     ft.center[0] = lx;
     ft.center[1] = ly;
-    // rotate_patch_to_align_with_gradient is false in every shipped configuration: the plain offsets are used (:659-661)
-    for (const auto & o : c.patch_offsets) {
+    std::vector<std::pair<int, int>> sampling_locations = c.patch_offsets;
+    if (c.rotate_patch_to_align_with_gradient) {  // :659-684 (false in every shipped configuration)
+      float ix, iy;
+      patch_gradient_direction(f.img_intensity, c.cols, lx, ly, c.patch_size, ix, iy);
+      sampling_locations = gradient_based_locations(ix, iy, c.patch_offsets);
+    }
+    bool missing = false;
+    for (const auto & o : sampling_locations) {
       const int u = lx + o.first, v = ly + o.second;
-      const Point32 & q = f.points_deskewed[f.img_idx[static_cast<size_t>(v) * c.cols + u]];
+      // A rotated pattern reaches up to 2 * sqrt(2) + 1 pixels further than the eroded mask vouches for when
+      // erosion_buffer is small: the reference then indexes the cloud with -1 (or reads outside the image) — undefined
+      // behaviour there, the candidate is skipped here and in the product.
+      const int pi = (u >= 0 && u < c.cols && v >= 0 && v < c.rows) ? f.img_idx[static_cast<size_t>(v) * c.cols + u] : -1;
+      if (pi < 0) {
+        missing = true;
+        break;
+      }
+      const Point32 & q = f.points_deskewed[pi];
       ft.Le_ps.push_back(T_map * V3{q.x, q.y, q.z});
       ft.intensities.push_back(f.img_intensity[static_cast<size_t>(v) * c.cols + u]);
     }
+    if (missing) continue;
     const size_t m = ft.Le_ps.size();
     V3 mean;
     for (const V3 & p : ft.Le_ps) mean = mean + p;

@@ -64,6 +64,7 @@ void * refphoto_create(const mh_photo_config * c)
   p.max_dist_from_mean = c->max_dist_from_mean;
   p.max_dist_from_plane = c->max_dist_from_plane;
   p.nma_radius = c->nma_radius;
+  p.rotate_patch_to_align_with_gradient = c->rotate_patch_to_align_with_gradient != 0;
   p.num_features_detect = c->num_features_detect;
   p.occlusion_range_diff_threshold = c->occlusion_range_diff_threshold;
   p.max_feature_life_time = c->max_feature_life_time;

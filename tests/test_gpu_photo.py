@@ -251,8 +251,40 @@ def test_ragged_inputs(ctx, frames):
         big = np.concatenate([f["raw"], f["raw"][:4000]])
         g.preprocess(big, big, f["unique_ns"], f["T_Le_Lt"])
     with pytest.raises(capi.MhError):
-        capi.Photo(ctx, dict(cfg, rotate_patch_to_align_with_gradient=1))
+        capi.Photo(ctx, dict(cfg, gaussian_blur_size=5))        # a deliberate limit
     g.destroy()
+
+
+@pytest.mark.parametrize("erosion_buffer", [10, 0])
+def test_rotated_patches(ctx, frames, erosion_buffer):
+    """rotate_patch_to_align_with_gradient (photometric.cpp:659-684, photometric_utils.cpp:453-518): every new feature samples
+    the pattern rotated into its edge frame and snapped to distinct pixels.  With erosion_buffer 0 a rotated pattern can reach
+    pixels the eroded mask does not vouch for: those candidates are skipped on both sides (the reference's behaviour is
+    undefined there)."""
+    from mimosa_amd import capi, synth, synth_photo as sp
+
+    cfg0, fr = frames
+    cfg = dict(cfg0, rotate_patch_to_align_with_gradient=1, erosion_buffer=erosion_buffer)
+    g, r = _both(ctx, cfg)
+    _pre(g, fr[0]), _pre(r, fr[0])
+    for P in (g, r):
+        P.detect(40, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    fa = g.features()
+    assert len(fa) >= 20
+    _same_features(fa, r.features())
+    plain, _ = _both(ctx, dict(cfg, rotate_patch_to_align_with_gradient=0))
+    _pre(plain, fr[0])
+    plain.detect(40, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    fp = plain.features()
+    n = min(len(fa), len(fp))
+    assert any(not np.array_equal(a["intensities"], b["intensities"]) for a, b in zip(fa[:n], fp[:n]))    # the patterns really moved
+    _pre(g, fr[1]), _pre(r, fr[1])
+    gf, rf = g.make_factor(), r.make_factor()
+    R, t = fr[1]["R_W_Be"] @ synth.so3_exp(np.array([0.002, -0.001, 0.003])), fr[1]["t_W_Be"] + np.array([0.02, -0.01, 0.01])
+    _assert_factor(gf.linearize(R, t), rf.linearize(R, t), gf.state(), rf.state())
+    gf.destroy()
+    g.destroy()
+    plain.destroy()
 
 
 def test_preprocess_from_resident_scan(ctx, frames):

@@ -30,7 +30,7 @@ def _case(seed):
         use_robust_cost_function=int(rng.integers(0, 2)), robust_cost_function=int(rng.integers(0, 2)),
         robust_cost_function_parameter=float(rng.choice([0.5, 1.345])), error_scale=float(rng.choice([1.0, 2.0])),
         max_error=float(rng.choice([0.3, 0.5075, 2.0])), sigma=float(rng.choice([0.1, 0.25])),
-        intensity_scale=float(rng.choice([0.25, 1.0])), brightness_window_size=(int(rng.choice([21, 41])), int(rng.choice([5, 7]))),
+        rotate_patch_to_align_with_gradient=int(rng.integers(0, 2)), intensity_scale=float(rng.choice([0.25, 1.0])), brightness_window_size=(int(rng.choice([21, 41])), int(rng.choice([5, 7]))),
     )
     cfg = sp.photo_config(rows=rows, cols=cols, patch=patch, **over)
     kw = dict(seed=synth.BASE_SEED + 500 + seed, v=tuple(rng.normal(0, 1.0, 3) * [1.5, 0.5, 0.1]), w=tuple(rng.normal(0, 0.3, 3) * [0.2, 0.2, 1.0]),
@@ -103,7 +103,7 @@ def test_random_photometric_pipeline(ctx, seed):
             if binary:
                 assert rel(gr["H_ba"], rr["H_ba"]) <= 1e-5 and rel(gr["H_aa"], rr["H_aa"]) <= 1e-5
         elif nH == 0:
-            assert np.linalg.norm(gr["H_bb"]) == 0
+            assert flat or np.linalg.norm(gr["H_bb"]) == 0
         else:
             assert flat     # a NaN in H: only ever from a constant patch
     if flat:                # the tracked sets may have parted ways
