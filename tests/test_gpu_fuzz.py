@@ -43,7 +43,7 @@ def _case(seed):
 # 225, 271, 356, 923: found by the wide sweep (MH_FUZZ_EXTRA=1500) — neighbourhoods whose two smallest covariance
 # eigenvalues are within 1-10 % of each other; 356 put one Valid point's normal 5 degrees off (H 3.5e-5 off) before
 # plane_eigen got its Rayleigh refinement.  238, 1303: 4-5 valid points in all, H singular
-@pytest.mark.parametrize("seed", list(range(14)) + [225, 238, 271, 356, 923, 1303] + _EXTRA(100))
+@pytest.mark.parametrize("seed", list(range(40)) + [225, 238, 271, 356, 923, 1303] + _EXTRA(100))
 def test_random_configuration(ctx, seed):
     from mimosa_amd import capi
     from oracle import ref_cpu
@@ -89,7 +89,7 @@ def _random_cloud(rng, n):
     return xyz.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(200))
+@pytest.mark.parametrize("seed", list(range(20)) + _EXTRA(200))
 def test_random_scan_frontend(ctx, seed):
     """prepareInput -> preprocess on random clouds and filter settings: same points, same order, same bits as the oracle."""
     from mimosa_amd import capi
@@ -128,7 +128,7 @@ def test_random_scan_frontend(ctx, seed):
     sc.destroy()
 
 
-@pytest.mark.parametrize("seed", list(range(5)) + _EXTRA(300))
+@pytest.mark.parametrize("seed", list(range(15)) + _EXTRA(300))
 def test_random_map_insert_sequences(ctx, seed):
     """iVox insert + LRU purge over random batch sequences (clusters that saturate voxels, duplicates, boundary points, tiny and
     large batches): getCloud — points AND order — equals the oracle's after every insert."""
@@ -151,7 +151,7 @@ def test_random_map_insert_sequences(ctx, seed):
     gm.release()
 
 
-@pytest.mark.parametrize("seed", list(range(4)) + _EXTRA(400))
+@pytest.mark.parametrize("seed", list(range(12)) + _EXTRA(400))
 def test_random_window_batches(ctx, seed):
     """mh_icp_linearize_batch over random windows — 1..9 factors, ragged sizes from empty to several thousand points, unary or
     binary, components on for a random subset — is bit-identical to the same factors linearized one call at a time, cold
@@ -194,7 +194,7 @@ def test_random_window_batches(ctx, seed):
     gm.release()
 
 
-@pytest.mark.parametrize("seed", [0] + _EXTRA(500))
+@pytest.mark.parametrize("seed", [0, 1, 2] + _EXTRA(500))
 def test_random_large_clouds(ctx, seed):
     """The 512-thread / multi-XCD regime (clouds of 66 k - 131 k points against rooms sampled with 0.1 - 1.5 M points): random
     room, density, sensor pose, pose error and registration options; cold + one partial re-association."""

@@ -1,5 +1,5 @@
 """-m gpu: randomised photometric pipelines against the oracle — image size, patch shape, filter chain switches, gradient
-threshold, suppression radius, robust cost, scene / motion / dropout seeds, pose error at the factor.  Six seeds by default;
+threshold, suppression radius, robust cost, scene / motion / dropout seeds, pose error at the factor.  Eighteen seeds by default (341 and 1024 are the flat-patch cases the sweep found);
 MH_FUZZ_EXTRA=N adds N more (a bug hunt on demand, like tests/test_gpu_fuzz.py)."""
 import os
 
@@ -39,7 +39,7 @@ def _case(seed):
     return cfg, fr, rng
 
 
-@pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(100))
+@pytest.mark.parametrize("seed", list(range(16)) + [341, 1024] + _EXTRA(100))
 def test_random_photometric_pipeline(ctx, seed):
     from mimosa_amd import capi, synth, synth_photo as sp
     from oracle import photo_ref

@@ -241,7 +241,7 @@ def _EXTRA(base):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(8)) + _EXTRA(100))
+@pytest.mark.parametrize("seed", list(range(24)) + _EXTRA(100))
 def test_random_record_layouts(ctx, seed):
     """The layout descriptor is general: the same sensor data re-packed into a record with the fields in a random order, at
     random (also unaligned) offsets and a random stride must give the result of the reference's typed code on the original."""
