@@ -1084,15 +1084,26 @@ int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9],
 
 namespace
 {
+// pinned landing block of a scan: [ScanCounters | kUniqueCached timestamps | one flag word]
+constexpr size_t kScanPinnedBytes = sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t) + 16;
+int scan_ensure_pinned(mh_scan * s)
+{
+  if (!s->h_c) {
+    void * p = nullptr;
+    MH_HIP(s->ctx, AllocCache::alloc_pinned(&p, kScanPinnedBytes));
+    s->h_c = static_cast<mh::ScanCounters *>(p);
+  }
+  return MH_OK;
+}
+uint32_t * scan_pinned_flag(mh_scan * s)
+{
+  return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s->h_c) + sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t));
+}
 int scan_fetch_counters(mh_scan * s, bool with_unique = false)
 {
   mh_ctx * ctx = s->ctx;
-  constexpr size_t kBytes = sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t);
-  if (!s->h_c) {
-    void * p = nullptr;
-    MH_HIP(ctx, AllocCache::alloc_pinned(&p, kBytes));
-    s->h_c = static_cast<mh::ScanCounters *>(p);
-  }
+  const int rcp = scan_ensure_pinned(s);
+  if (rcp != MH_OK) return rcp;
   MH_HIP(ctx, hipMemcpyAsync(s->h_c, s->d_counters.p, sizeof(s->c), hipMemcpyDeviceToHost, ctx->stream));
   size_t n_copy = 0;
   if (with_unique) {  // the distinct timestamps ride along: the caller asks for them next (IMU propagation), one wait instead of two
@@ -1216,23 +1227,28 @@ static int mh_scan_prepare_input_layout_impl(mh_scan * s, const void * raw, size
   const size_t m = n ? n : 1, n_blk = (m + 255) / 256;
   const size_t raw_bytes = (m * L->stride + 255) & ~size_t(255), tmp_bytes = organize ? m * sizeof(mh_ouster_point) : 0;
   MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));  // the canonical records
-  MH_HIP(ctx, s->d_sensor.reserve(raw_bytes + tmp_bytes + (organize ? n_blk * 128 * sizeof(uint32_t) : 0) + 256, ctx->stream, false));
-  MH_HIP(ctx, s->d_counters.reserve(sizeof(mh::ScanCounters), ctx->stream, false));
+  const size_t hist_bytes = organize ? (n_blk + 1) * 128 * sizeof(uint32_t) : 0;  // per-block ring counts + the ring starts
+  MH_HIP(ctx, s->d_sensor.reserve(raw_bytes + tmp_bytes + hist_bytes + 256, ctx->stream, false));
   char * base = static_cast<char *>(s->d_sensor.p);
   auto * tmp = reinterpret_cast<mh_ouster_point *>(base + raw_bytes);
   auto * hist = reinterpret_cast<uint32_t *>(base + raw_bytes + tmp_bytes);
-  uint32_t * bad_ring = reinterpret_cast<uint32_t *>(static_cast<char *>(s->d_counters.p) + offsetof(mh::ScanCounters, bad_coord));
-  MH_HIP(ctx, hipMemsetAsync(s->d_counters.p, 0, sizeof(mh::ScanCounters), ctx->stream));
+  uint32_t * bad_ring = reinterpret_cast<uint32_t *>(base + raw_bytes + tmp_bytes + hist_bytes);
+  const int rcp = scan_ensure_pinned(s);
+  if (rcp != MH_OK) return rcp;
+  MH_HIP(ctx, hipMemsetAsync(bad_ring, 0, sizeof(uint32_t), ctx->stream));
   if (n) MH_HIP(ctx, hipMemcpyAsync(base, raw, n * L->stride, hipMemcpyHostToDevice, ctx->stream));
   MH_HIP(ctx, mh::launch_decode_points(base, static_cast<uint32_t>(n), *L, width, height, transpose != 0, organize, header_ts,
                                        static_cast<mh_ouster_point *>(s->d_raw.p), tmp, hist, bad_ring, ctx->stream));
-  if (organize) {  // a ring number beyond the reference's 128-entry tables (undefined behaviour there) is refused
-    uint32_t bad = 0;
-    MH_HIP(ctx, hipMemcpyAsync(&bad, bad_ring, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (bad) return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": organize_by_ring with a ring number >= 128");
+  // the flag comes back with the counters of the filter pass: no synchronisation of its own (the placement kernel masks
+  // the ring number, so a bad one cannot write out of bounds before it is reported)
+  *scan_pinned_flag(s) = 0u;
+  MH_HIP(ctx, hipMemcpyAsync(scan_pinned_flag(s), bad_ring, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  const int rc = scan_prepare_common(s, static_cast<const mh_ouster_point *>(s->d_raw.p), true, n, cfg, info, who, true, L->ring_filter != 0);
+  if (rc == MH_OK && organize && *scan_pinned_flag(s)) {  // a ring number beyond the reference's 128-entry tables (undefined behaviour there)
+    s->prepared = false;
+    return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": organize_by_ring with a ring number >= 128");
   }
-  return scan_prepare_common(s, static_cast<const mh_ouster_point *>(s->d_raw.p), true, n, cfg, info, who, true, L->ring_filter != 0);
+  return rc;
 }
 int mh_scan_prepare_input_layout(mh_scan * s, const void * raw, size_t n, const mh_point_layout * layout, uint32_t width, uint32_t height,
                                  int transpose, int organize_by_ring, double header_ts, const mh_input_config * cfg, mh_scan_info * info)

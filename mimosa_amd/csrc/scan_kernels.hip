@@ -312,27 +312,45 @@ __global__ __launch_bounds__(kThreads) void ring_histogram_kernel(const mh_ouste
   __syncthreads();
   if (threadIdx.x < kRings) hist[static_cast<size_t>(blockIdx.x) * kRings + threadIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(kThreads) void ring_place_kernel(const mh_ouster_point * __restrict__ in, uint32_t n, const uint32_t * __restrict__ hist,
+// per-(block, ring) counts -> exclusive offsets in place over the blocks of a ring, and the ring's total in
+// hist[n_blk * kRings + r].  One wave per ring: every lane scans a contiguous run of blocks, a wave scan joins the runs.
+__global__ __launch_bounds__(64) void ring_offsets_kernel(uint32_t * hist, uint32_t n_blk)
+{
+  const uint32_t r = blockIdx.x, lane = threadIdx.x;
+  const uint32_t per = (n_blk + 63u) / 64u, b0 = lane * per, b1 = min(b0 + per, n_blk);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; ++b) sum += hist[static_cast<size_t>(b) * kRings + r];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d, 64));
+    if (static_cast<int>(lane) >= d) incl += up;
+  }
+  uint32_t run = incl - sum;  // blocks of the lanes before this one
+  for (uint32_t b = b0; b < b1; ++b) {
+    const uint32_t c = hist[static_cast<size_t>(b) * kRings + r];
+    hist[static_cast<size_t>(b) * kRings + r] = run;
+    run += c;
+  }
+  if (lane == 63u) hist[static_cast<size_t>(n_blk) * kRings + r] = incl;
+}
+__global__ __launch_bounds__(kThreads) void ring_place_kernel(const mh_ouster_point * __restrict__ in, uint32_t n, const uint32_t * __restrict__ offs,
                                                                mh_ouster_point * __restrict__ out)
 {
-  __shared__ uint32_t s_total[kRings], s_before[kRings], s_ring[kThreads];
-  if (threadIdx.x < kRings) {
-    uint32_t tot = 0, before = 0;
-    for (uint32_t b = 0; b < gridDim.x; ++b) {
-      const uint32_t c = hist[static_cast<size_t>(b) * kRings + threadIdx.x];
-      if (b < blockIdx.x) before += c;
-      tot += c;
-    }
-    s_total[threadIdx.x] = tot;
-    s_before[threadIdx.x] = before;
-  }
+  __shared__ uint32_t s_ring[kThreads], s_tot[kRings], s_base[kRings];
+  if (threadIdx.x < kRings) s_tot[threadIdx.x] = offs[static_cast<size_t>(gridDim.x) * kRings + threadIdx.x];
   const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
   const uint32_t ring = j < n ? (in[j].ring & (kRings - 1u)) : 0xFFFFFFFFu;
   s_ring[threadIdx.x] = ring;
   __syncthreads();
+  if (threadIdx.x < kRings) {  // where ring r starts: the totals of the rings before it (:221-227)
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < threadIdx.x; ++q) base += s_tot[q];
+    s_base[threadIdx.x] = base;
+  }
+  __syncthreads();
   if (j >= n) return;
-  uint32_t pos = s_before[ring];
-  for (uint32_t r = 0; r < ring; ++r) pos += s_total[r];
+  uint32_t pos = s_base[ring] + offs[static_cast<size_t>(blockIdx.x) * kRings + ring];
   for (uint32_t t = 0; t < threadIdx.x; ++t) pos += s_ring[t] == ring ? 1u : 0u;  // earlier records of this block, same ring
   out[pos] = in[j];
 }
@@ -560,6 +578,7 @@ hipError_t launch_decode_points(const void * raw, uint32_t n, const mh_point_lay
                      header_ts, organize_by_ring ? tmp : canon, bad_ring);
   if (organize_by_ring) {
     hipLaunchKernelGGL(ring_histogram_kernel, g, b, 0, stream, tmp, n, hist);
+    hipLaunchKernelGGL(ring_offsets_kernel, dim3(kRings), dim3(64), 0, stream, hist, g.x);
     hipLaunchKernelGGL(ring_place_kernel, g, b, 0, stream, tmp, n, hist, canon);
   }
   return hipGetLastError();
