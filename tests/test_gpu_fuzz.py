@@ -268,3 +268,55 @@ def test_non_finite_and_far_inputs_do_not_fault(ctx, small_world):
     for f in (gf, clean):
         f.destroy()
     gm.release()
+
+
+@pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(600))
+def test_random_map_generations_with_live_factors(ctx, seed):
+    """Geometric::updateMap's pattern under random schedules: copy (or fork) -> insert -> occasional LRU purge, while factors
+    built on EARLIER generations stay alive, are re-linearized, cloned and destroyed in random order, and old generations are
+    released as soon as the caller lets go of them.  Every factor must keep seeing exactly the generation it was built on
+    (the oracle does the same steps with deep copies)."""
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    m, pts, cfg, mode, R, t, rng = _case(seed)
+    leaf, md = cfg["target_ivox_map_leaf_size"], cfg["target_ivox_map_min_dist_in_voxel"]
+    horizon = int(rng.choice([2, 4, 1000]))
+    gm = capi.VoxelMap(ctx, leaf=leaf, min_dist=md, mode=mode, lru_horizon=horizon, lru_clear_cycle=2)
+    rm = ref_cpu.Map(leaf=leaf, min_dist=md, mode=mode, lru_horizon=horizon)
+    rm.set_lru_clear_cycle(2)
+    chunks = np.array_split(m[rng.permutation(len(m))], 8)
+    gm.insert(chunks[0]), rm.insert(chunks[0])
+    rc, rrc = capi.make_reg_config(**cfg), ref_cpu.make_config(**cfg)
+    live = []            # (hip factor, oracle factor)
+    thr = md / 4.0
+    for gen in range(1, 8):
+        op = rng.integers(0, 3)
+        if op == 0:      # a factor on the current generation
+            sub = np.ascontiguousarray(pts[rng.permutation(len(pts))[: int(rng.choice([64, 500, len(pts)]))]])
+            live.append((capi.ICPFactor(ctx, gm, sub, rc), ref_cpu.ICP(rm, sub, rrc)))
+        # the next generation: copy or fork, then insert — the old handle is released right away (factors keep it alive)
+        use_fork = bool(rng.integers(0, 2))
+        new_g = gm.fork() if use_fork else gm.copy()
+        new_r = rm.copy()
+        gm.release()
+        gm, rm = new_g, new_r
+        gm.insert(chunks[gen]), rm.insert(chunks[gen])
+        assert gm.stats()["n_points"] == rm.num_points
+        # every live factor, at a moved pose: sees its own generation
+        for gf, rf in live:
+            Rk = R @ synth.so3_exp(rng.normal(0, 1.0, 3) * thr / 5.0)
+            tk = t + rng.normal(0, 1.0, 3) * thr * rng.choice([0.3, 3.0])
+            assert_result_parity(gf.linearize(Rk, tk), rf.linearize(Rk, tk), check_eigvec=False)
+        if live and rng.integers(0, 2):          # drop one, clone another
+            gf, rf = live.pop(int(rng.integers(0, len(live))))
+            gf.destroy()
+        if live and rng.integers(0, 3) == 0:
+            gf, rf = live[int(rng.integers(0, len(live)))]
+            c = gf.clone()
+            gf.destroy()
+            live[[i for i, p in enumerate(live) if p[0] is gf][0]] = (c, rf)
+    assert np.array_equal(gm.get_cloud(), rm.export()[2])
+    for gf, _ in live:
+        gf.destroy()
+    gm.release()
