@@ -320,3 +320,48 @@ def test_random_map_generations_with_live_factors(ctx, seed):
     for gf, _ in live:
         gf.destroy()
     gm.release()
+
+
+def test_host_threads_with_their_own_contexts_share_a_map(ctx, small_world):
+    """Four host threads, each with its own context (stream), factor and scratch, linearize against ONE map concurrently —
+    synchronous calls, pipelined calls, factor creation / destruction in the loop.  Every result must be the bits a single
+    thread produces (the library's shared state: allocation cache, pinned rings, error slots)."""
+    import threading
+    from mimosa_amd import capi
+
+    w = small_world
+    gm = capi.VoxelMap(ctx)
+    gm.insert(w["map_xyz"])
+    rc = capi.make_reg_config(**w["cfg"])
+    subs = [np.ascontiguousarray(w["pts"][i::4]) for i in range(4)]
+    want = []
+    for i in range(4):
+        f = capi.ICPFactor(ctx, gm, subs[i], rc)
+        want.append((f.linearize(w["R"], w["t"]), f.linearize(w["R"], w["t"] + np.array([0.002, 0.0, 0.001]))))
+        f.destroy()
+    errors = []
+
+    def worker(i):
+        try:
+            c = capi.Context(0)
+            for rep in range(40 + len(_EXTRA(0))):
+                f = capi.ICPFactor(c, gm, subs[i], rc)
+                a = f.linearize(w["R"], w["t"])
+                outs = [f.linearize_async(w["R"], w["t"] + np.array([0.002, 0.0, 0.001])) for _ in range(2)]
+                f.wait()
+                for k in ("H_ss", "b_s", "f", "status_hist", "loc_trans_comp"):
+                    assert np.array_equal(a[k], want[i][0][k]), (i, rep, k)
+                    assert np.array_equal(outs[0].as_dict()[k], want[i][1][k]), (i, rep, k)
+                f.destroy()
+            c.destroy() if hasattr(c, "destroy") else None
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not any(x.is_alive() for x in th), "a worker hung"
+    assert not errors, errors[:3]
+    gm.release()

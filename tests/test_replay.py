@@ -107,3 +107,33 @@ def test_replay_hip_equals_oracle_random_sequences(ctx, seed):
     assert rh["n_keyframes"] == ro["n_keyframes"] and rh["photo_valid"] == ro["photo_valid"]
     for (Ra, ta), (Rb, tb) in zip(rh["poses_est"], ro["poses_est"]):
         assert np.max(np.abs(ta - tb)) < 1e-7 and np.max(np.abs(Ra - Rb)) < 1e-8
+
+
+@pytest.mark.gpu
+def test_concurrent_replays_on_separate_contexts(ctx):
+    """Three host threads, each running a whole replay (front end, photometric path, map generations, window batches) on its
+    own context at the same time: every one reproduces the single-threaded trajectory bit for bit."""
+    import threading
+    from mimosa_amd import capi
+
+    cfg = small_cfg(5)
+    scans = replay.make_scans(cfg)
+    ref = replay.run(cfg, replay.HipBackend(ctx, cfg), scans)
+    out, errors = [None] * 3, []
+
+    def worker(i):
+        try:
+            out[i] = replay.run(cfg, replay.HipBackend(capi.Context(0), cfg), scans)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=600)
+    assert not any(x.is_alive() for x in th) and not errors, errors[:2]
+    for r in out:
+        assert r["n_keyframes"] == ref["n_keyframes"] and r["photo_valid"] == ref["photo_valid"]
+        for (Ra, ta), (Rb, tb) in zip(r["poses_est"], ref["poses_est"]):
+            assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb)
