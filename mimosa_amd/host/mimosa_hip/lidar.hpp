@@ -68,10 +68,11 @@ struct GeometricConfig
 class Context
 {
 public:
-  explicit Context(int device = 0)
+  explicit Context(int device = 0) : device_(device)
   {
     if (mh_init(device, &ctx_) != MH_OK) throw std::runtime_error(std::string("mh_init: ") + mh_last_error(nullptr));
   }
+  int device() const { return device_; }
   ~Context() { mh_shutdown(ctx_); }
   Context(const Context &) = delete;
   Context & operator=(const Context &) = delete;
@@ -82,6 +83,7 @@ public:
   }
 
 private:
+  int device_ = 0;
   mh_ctx * ctx_ = nullptr;
 };
 

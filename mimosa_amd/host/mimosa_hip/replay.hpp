@@ -191,7 +191,11 @@ public:
     map_->set_neighbor_voxel_mode(cfg_.neighbor_voxel_mode);
     map_->set_min_dist_in_cell(cfg_.reg.target_ivox_map_min_dist_in_voxel);
     if (cfg_.photometric) {
-      photo_.reset(new Photometric(ctx_, cfg_.photo));
+      // its own context = its own HIP stream: the patch factor (60 waves, a 27 us latency chain) and the window's ICP batch
+      // (a few hundred waves) are independent work of one smoother iteration and run side by side instead of one behind
+      // the other; every hand-over between the two contexts happens at a call that synchronises anyway
+      photo_ctx_ = std::make_shared<lidar::Context>(ctx_->device());
+      photo_.reset(new Photometric(photo_ctx_, cfg_.photo));
       scan_.keepRaw(true);
     }
   }
@@ -397,6 +401,7 @@ private:
   Config cfg_;
   ScanFrontEnd scan_;
   IncrementalVoxelMapPCL::Ptr map_;
+  std::shared_ptr<lidar::Context> photo_ctx_;  // declared before photo_: destroyed after it
   std::unique_ptr<Photometric> photo_;
 };
 

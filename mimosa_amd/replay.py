@@ -190,7 +190,9 @@ class HipBackend:
         self.scan = capi.Scan(ctx)
         self.icfg = capi.make_input_config()
         self.I3, self.z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
-        self.photo = capi.Photo(ctx, cfg.photo) if cfg.photometric else None
+        # the photometric path on its own context (stream): see host/mimosa_hip/replay.hpp
+        self.photo_ctx = capi.Context(ctx.device) if cfg.photometric else None
+        self.photo = capi.Photo(self.photo_ctx, cfg.photo) if cfg.photometric else None
         if self.photo is not None:
             ctx.check(ctx.L.mh_scan_keep_raw(self.scan.h, 1))
 
