@@ -901,6 +901,8 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if isinstance(sharded, dict) and "error" in sharded:
+        os._exit(0)  # a peer may still sit in a collective of the failed leg: tearing the process group down could wait on it for ever
     for f in factors:
         f.destroy()
     gmap.release()
