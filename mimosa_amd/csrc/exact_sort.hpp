@@ -1,0 +1,207 @@
+// std::sort's result, computed on several host threads.
+//
+// Photometric::detectFeatures (src/lidar/photometric.cpp:556-560) sorts ~30 000 (gradient, pixel) pairs with a comparator
+// that looks at the 8-bit gradient only.  std::sort is not stable: which of several thousand equal-gradient pixels comes
+// first is decided by libstdc++'s introsort (median-of-three pivot moved to the front, unguarded Hoare partition, recursion
+// on the right part, a final insertion sort), and that order decides the greedy non-maximum suppression that follows — so
+// the feature set of the reference is only reproduced by running THAT algorithm on THAT sequence.  It is the largest single
+// item of a frame's feature bookkeeping (0.49 ms of 0.79 ms).
+//
+// The algorithm's structure allows more than one thread: after a partition step the two parts are disjoint and what happens
+// to each depends on its contents and the remaining depth budget alone.  This header restates the introsort loop (own code,
+// written from the algorithm's description: GCC's bits/stl_algo.h, std::__introsort_loop / __unguarded_partition_pivot /
+// __final_insertion_sort, unchanged since GCC 4.x apart from the pivot landing at `first`) and runs disjoint parts on
+// worker threads; the depth-exhausted fallback calls std::partial_sort(first, last, last), which IS the library's own heap
+// sort.  tests/cpp/exact_sort_check.cpp compares it element for element with std::sort on random, duplicate-heavy,
+// sorted, reversed and organ-pipe sequences; the photometric parity tests compare the features against an oracle that
+// calls std::sort.
+#pragma once
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstddef>
+#include <mutex>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace mh
+{
+namespace exact_sort
+{
+constexpr std::ptrdiff_t kThreshold = 16;  // _S_threshold
+
+inline long floor_log2(std::ptrdiff_t n)
+{
+  long l = 0;
+  while (n > 1) {
+    n >>= 1;
+    ++l;
+  }
+  return l;
+}
+
+template <class T, class Comp>
+inline void median_to_first(T * result, T * a, T * b, T * c, Comp comp)
+{
+  if (comp(*a, *b)) {
+    if (comp(*b, *c))
+      std::iter_swap(result, b);
+    else if (comp(*a, *c))
+      std::iter_swap(result, c);
+    else
+      std::iter_swap(result, a);
+  } else if (comp(*a, *c))
+    std::iter_swap(result, a);
+  else if (comp(*b, *c))
+    std::iter_swap(result, c);
+  else
+    std::iter_swap(result, b);
+}
+
+template <class T, class Comp>
+inline T * partition_pivot(T * first, T * last, Comp comp)
+{
+  T * mid = first + (last - first) / 2;
+  median_to_first(first, first + 1, mid, last - 1, comp);
+  T * pivot = first;
+  T * lo = first + 1;
+  T * hi = last;
+  while (true) {
+    while (comp(*lo, *pivot)) ++lo;
+    --hi;
+    while (comp(*pivot, *hi)) --hi;
+    if (!(lo < hi)) return lo;
+    std::iter_swap(lo, hi);
+    ++lo;
+  }
+}
+
+// the loop of std::sort on [first, last) with `depth` partition levels left; ranges of <= 16 elements stay unsorted
+template <class T, class Comp>
+inline void introsort_loop(T * first, T * last, long depth, Comp comp)
+{
+  while (last - first > kThreshold) {
+    if (depth == 0) {
+      std::partial_sort(first, last, last, comp);  // the library's heap sort, as std::sort itself falls back to
+      return;
+    }
+    --depth;
+    T * cut = partition_pivot(first, last, comp);
+    introsort_loop(cut, last, depth, comp);
+    last = cut;
+  }
+}
+
+template <class T, class Comp>
+inline void linear_insert_unguarded(T * last, Comp comp)
+{
+  T val = std::move(*last);
+  T * next = last - 1;
+  while (comp(val, *next)) {
+    *last = std::move(*next);
+    last = next;
+    --next;
+  }
+  *last = std::move(val);
+}
+
+template <class T, class Comp>
+inline void insertion_sort(T * first, T * last, Comp comp)
+{
+  if (first == last) return;
+  for (T * i = first + 1; i != last; ++i) {
+    if (comp(*i, *first)) {
+      T val = std::move(*i);
+      std::move_backward(first, i, i + 1);
+      *first = std::move(val);
+    } else {
+      linear_insert_unguarded(i, comp);
+    }
+  }
+}
+
+template <class T, class Comp>
+inline void final_insertion_sort(T * first, T * last, Comp comp)
+{
+  if (last - first > kThreshold) {
+    insertion_sort(first, first + kThreshold, comp);
+    for (T * i = first + kThreshold; i != last; ++i) linear_insert_unguarded(i, comp);
+  } else {
+    insertion_sort(first, last, comp);
+  }
+}
+
+// std::sort(first, last, comp), one thread
+template <class T, class Comp>
+inline void sort_sequential(T * first, T * last, Comp comp)
+{
+  if (first == last) return;
+  introsort_loop(first, last, floor_log2(last - first) * 2, comp);
+  final_insertion_sort(first, last, comp);
+}
+
+// std::sort(first, last, comp) with the partition tree spread over `threads` host threads (the caller is one of them).
+// Parts larger than `leaf` are split further by whoever takes them; smaller ones are finished in place.
+template <class T, class Comp>
+inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrdiff_t leaf = 4096)
+{
+  if (first == last) return;
+  if (threads < 2 || last - first <= 2 * leaf) {
+    sort_sequential(first, last, comp);
+    return;
+  }
+  struct Part
+  {
+    T * first;
+    T * last;
+    long depth;
+  };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Part> queue;
+  int busy = 0;  // parts being worked on: the tree is finished when the queue is empty and nobody is busy
+  queue.push_back({first, last, floor_log2(last - first) * 2});
+  auto worker = [&]() {
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      while (queue.empty() && busy > 0) cv.wait(lk);
+      if (queue.empty()) return;  // busy == 0: done
+      Part p = queue.back();
+      queue.pop_back();
+      ++busy;
+      lk.unlock();
+      // the introsort loop on this part: big right halves go to the queue instead of the call stack
+      while (p.last - p.first > kThreshold) {
+        if (p.last - p.first <= leaf) {
+          introsort_loop(p.first, p.last, p.depth, comp);
+          break;
+        }
+        if (p.depth == 0) {
+          std::partial_sort(p.first, p.last, p.last, comp);
+          break;
+        }
+        --p.depth;
+        T * cut = partition_pivot(p.first, p.last, comp);
+        if (p.last - cut > kThreshold) {
+          lk.lock();
+          queue.push_back({cut, p.last, p.depth});
+          lk.unlock();
+          cv.notify_one();
+        }
+        p.last = cut;
+      }
+      lk.lock();
+      --busy;
+      if (queue.empty() && busy == 0) cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto & t : pool) t.join();
+  final_insertion_sort(first, last, comp);
+}
+
+}  // namespace exact_sort
+}  // namespace mh

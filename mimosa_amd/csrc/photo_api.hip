@@ -12,11 +12,14 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <set>
+#include <thread>
 #include <vector>
 
+#include "exact_sort.hpp"
 #include "math3.hpp"
 #include "mh_internal.hpp"
 #include "photo_device.hpp"
@@ -72,6 +75,8 @@ struct mh_photo
   mh::PhotoCounters * d_counters = nullptr;
   float * h_int_out = nullptr;  // pinned staging of the corrected intensities
   size_t h_int_cap = 0;
+  char * h_stage = nullptr;     // pinned staging of detectFeatures' small transfers (candidate list, gather records)
+  size_t h_stage_cap = 0;
   PhotoFrame * frame = nullptr;
   std::vector<HostFeature> features;  // map_Le_features_
   uint32_t next_id = 0;               // monotonic_feature_id_
@@ -110,6 +115,7 @@ void photo_release(mh_photo * p)
     b->release();
   if (p->h_counters) (void)hipHostFree(p->h_counters);
   if (p->h_int_out) (void)hipHostFree(p->h_int_out);
+  if (p->h_stage) (void)hipHostFree(p->h_stage);
   delete p;
 }
 
@@ -341,6 +347,20 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   return MH_OK;
 }
 
+// grow-only pinned staging block of a photo object (pageable transfers go through the runtime's own staging, one extra
+// synchronisation each)
+int photo_stage(mh_photo * ph, size_t bytes)
+{
+  if (ph->h_stage_cap >= bytes) return MH_OK;
+  if (ph->h_stage) (void)hipHostFree(ph->h_stage);
+  ph->h_stage = nullptr;
+  ph->h_stage_cap = 0;
+  const size_t cap = (bytes + bytes / 2 + 4095) & ~size_t(4095);
+  MH_HIP(ph->ctx, hipHostMalloc(reinterpret_cast<void **>(&ph->h_stage), cap, hipHostMallocDefault));
+  ph->h_stage_cap = cap;
+  return MH_OK;
+}
+
 // photometric_utils.cpp:453-483 — the nearest free pixel (one of the 8 neighbours when the rounded one is taken)
 std::pair<int, int> snap_point(const std::pair<double, double> & p, std::set<std::pair<int, int>> & used)
 {
@@ -403,14 +423,22 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   uint32_t * d_list = static_cast<uint32_t *>(ph->d_cand.p), * d_blk = d_list + npx, * d_n = d_blk + n_blk;
   MH_HIP(ctx, mh::launch_photo_candidates(static_cast<const uint8_t *>(ph->d_grad.p), static_cast<const uint8_t *>(ph->d_detmask.p), npx,
                                           c.gradient_threshold, d_blk, d_list, d_n, ctx->stream));
-  uint32_t n_list = 0;
-  MH_HIP(ctx, hipMemcpyAsync(&n_list, d_n, sizeof(n_list), hipMemcpyDeviceToHost, ctx->stream));
+  // the count and a 64 K-entry prefix of the list come back together (one synchronisation; a longer list needs a second copy)
+  const size_t prefix = std::min<size_t>(static_cast<size_t>(npx), 65536);
+  {
+    const int rcs = photo_stage(ph, 256 + static_cast<size_t>(npx) * sizeof(uint32_t));
+    if (rcs != MH_OK) return rcs;
+  }
+  uint32_t * h_list = reinterpret_cast<uint32_t *>(ph->h_stage + 256);
+  MH_HIP(ctx, hipMemcpyAsync(ph->h_stage, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(h_list, d_list, prefix * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<uint32_t> gradients(n_list);
-  if (n_list) {
-    MH_HIP(ctx, hipMemcpyAsync(gradients.data(), d_list, n_list * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  const uint32_t n_list = *reinterpret_cast<const uint32_t *>(ph->h_stage);
+  if (n_list > prefix) {
+    MH_HIP(ctx, hipMemcpyAsync(h_list + prefix, d_list + prefix, (n_list - prefix) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  std::vector<uint32_t> gradients(h_list, h_list + n_list);
   // the detection mask is only ever asked about candidate pixels (set by construction): `alive` carries the circles
   std::vector<uint8_t> alive(static_cast<size_t>(npx), 1);
   for (const HostFeature & ft : ph->features)  // :526-530
@@ -421,7 +449,22 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
                   gradients.end());
   // :556-560 — std::sort with a comparator on the gradient only: the order of equal gradients is libstdc++'s (it depends
   // on the sequence of comparison outcomes alone, so sorting the packed words moves them exactly like the reference's pairs)
-  std::sort(gradients.begin(), gradients.end(), [](uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); });
+  // For a long list the same introsort runs on four host threads (exact_sort.hpp: same pivots, same partitions, same final
+  // insertion sort — element for element std::sort's result, tests/cpp/exact_sort_check.cpp); MH_SORT_THREADS=1 forces
+  // the plain library call.
+  {
+    auto by_gradient = [](uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); };
+    static const int sort_threads = [] {
+      const char * e = std::getenv("MH_SORT_THREADS");
+      const int hw = static_cast<int>(std::thread::hardware_concurrency());
+      const int want = e ? std::atoi(e) : 4;
+      return std::max(1, std::min(want, hw > 0 ? hw : 1));
+    }();
+    if (sort_threads > 1 && gradients.size() >= 16384)
+      mh::exact_sort::sort_parallel(gradients.data(), gradients.data() + gradients.size(), by_gradient, sort_threads);
+    else
+      std::sort(gradients.begin(), gradients.end(), by_gradient);
+  }
   std::vector<std::pair<int, int>> cand;
   for (const uint32_t g : gradients) {  // :565-571 non-maximum suppression
     const int px = static_cast<int>(g & 0xFFFFFFu);
@@ -431,9 +474,32 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   }
   // what the selection below reads, gathered on the device for the surviving candidates only
   const int m_off = c.n_patch_offsets, n_cand = static_cast<int>(cand.size()), per = m_off + 1;
-  std::vector<float> win(static_cast<size_t>(n_cand) * 49);
-  std::vector<float> rec(static_cast<size_t>(n_cand) * per * 4);
-  std::vector<int32_t> rec_idx(static_cast<size_t>(n_cand) * per);
+  std::vector<float> win, rec;
+  std::vector<int32_t> rec_idx;
+  // uv (offsets + centres, see photo_gather_kernel) goes up, the windows / patch records / point indices of `count` candidates
+  // come back: one upload, one kernel, ONE download, through the pinned staging block
+  auto gather = [&](const std::vector<int32_t> & uv, int count, bool per_candidate) -> int {
+    const size_t n_win = static_cast<size_t>(count) * 49, n_rec = static_cast<size_t>(count) * per * 4, n_idx = static_cast<size_t>(count) * per;
+    const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (n_win * 4 + 255) & ~size_t(255), b_rec = (n_rec * 4 + 255) & ~size_t(255);
+    const size_t b_out = b_win + b_rec + n_idx * 4;
+    MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_out + 256, ctx->stream, false));
+    const int rcs = photo_stage(ph, b_uv + b_out);
+    if (rcs != MH_OK) return rcs;
+    char * d = static_cast<char *>(ph->d_gather.p);
+    std::memcpy(ph->h_stage, uv.data(), uv.size() * 4);
+    MH_HIP(ctx, hipMemcpyAsync(d, ph->h_stage, uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, count, per_candidate, static_cast<const float *>(fr->d_intensity.p),
+                                        static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
+                                        reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
+                                        reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(ph->h_stage + b_uv, d + b_uv, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const char * h = ph->h_stage + b_uv;
+    win.assign(reinterpret_cast<const float *>(h), reinterpret_cast<const float *>(h) + n_win);
+    rec.assign(reinterpret_cast<const float *>(h + b_win), reinterpret_cast<const float *>(h + b_win) + n_rec);
+    rec_idx.assign(reinterpret_cast<const int32_t *>(h + b_win + b_rec), reinterpret_cast<const int32_t *>(h + b_win + b_rec) + n_idx);
+    return MH_OK;
+  };
   if (n_cand) {
     std::vector<int32_t> uv(2 * static_cast<size_t>(m_off + n_cand));
     std::memcpy(uv.data(), ph->offsets.data(), 2 * static_cast<size_t>(m_off) * sizeof(int32_t));
@@ -441,18 +507,8 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
       uv[2 * (m_off + i)] = cand[i].first;
       uv[2 * (m_off + i) + 1] = cand[i].second;
     }
-    const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (win.size() * 4 + 255) & ~size_t(255), b_rec = (rec.size() * 4 + 255) & ~size_t(255);
-    MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_win + b_rec + rec_idx.size() * 4 + 256, ctx->stream, false));
-    char * d = static_cast<char *>(ph->d_gather.p);
-    MH_HIP(ctx, hipMemcpyAsync(d, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_cand, false, static_cast<const float *>(fr->d_intensity.p),
-                                        static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
-                                        reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
-                                        reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(win.data(), d + b_uv, win.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(rec.data(), d + b_uv + b_win, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(rec_idx.data(), d + b_uv + b_win + b_rec, rec_idx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rcg = gather(uv, n_cand, false);
+    if (rcg != MH_OK) return rcg;
   }
   // :575-625 scores of every candidate along every bias direction
   std::vector<std::vector<std::pair<double, int>>> scores(n_dirs, std::vector<std::pair<double, int>>(cand.size(), {0.0, 0}));
@@ -479,12 +535,16 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   }
   for (size_t b = 0; b < n_dirs; ++b)
     std::sort(scores[b].begin(), scores[b].end(), [](const std::pair<double, int> & a, const std::pair<double, int> & bb) { return a.first > bb.first; });
-  std::vector<int> selected;  // :639-651 round-robin over the directions
+  std::vector<int> selected;  // :639-651 round-robin over the directions; "not selected yet" (a std::find there) is a flag here
+  std::vector<uint8_t> taken(cand.size(), 0);
   if (n_dirs)
     for (size_t i = 0; i < scores[0].size(); ++i)
       for (size_t b = 0; b < n_dirs; ++b) {
         const int k = scores[b][i].second;
-        if (std::find(selected.begin(), selected.end(), k) == selected.end()) selected.push_back(k);
+        if (!taken[static_cast<size_t>(k)]) {
+          taken[static_cast<size_t>(k)] = 1;
+          selected.push_back(k);
+        }
       }
   // rotate_patch_to_align_with_gradient (:659-684): every selected candidate samples its own rotated pattern — a second,
   // per-candidate gather of just those (a handful of) candidates replaces the records of the fixed pattern
@@ -500,20 +560,8 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
       uv[2 * (static_cast<size_t>(n_sel) * m_off + j) + 1] = cand[k].second;
       rec_at[k] = static_cast<size_t>(j) * per;
     }
-    rec.assign(static_cast<size_t>(n_sel) * per * 4, 0.f);
-    rec_idx.assign(static_cast<size_t>(n_sel) * per, -1);
-    const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (static_cast<size_t>(n_sel) * 49 * 4 + 255) & ~size_t(255),
-                 b_rec = (rec.size() * 4 + 255) & ~size_t(255);
-    MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_win + b_rec + rec_idx.size() * 4 + 256, ctx->stream, false));
-    char * d = static_cast<char *>(ph->d_gather.p);
-    MH_HIP(ctx, hipMemcpyAsync(d, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, n_sel, true, static_cast<const float *>(fr->d_intensity.p),
-                                        static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
-                                        reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
-                                        reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(rec.data(), d + b_uv + b_win, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(rec_idx.data(), d + b_uv + b_win + b_rec, rec_idx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rcg = gather(uv, n_sel, true);
+    if (rcg != MH_OK) return rcg;
   }
   Pose TBL, TWB;
   std::memcpy(TBL.R, c.T_B_L_R, sizeof(TBL.R));

@@ -60,3 +60,14 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for needle in ("ref_cpu", "numpy_ref", "import oracle", "from oracle", "libref_cpu"):
                     assert needle not in txt, (f, needle)
+
+
+def test_parallel_introsort_is_std_sort(tmp_path):
+    """mimosa_amd/csrc/exact_sort.hpp (detectFeatures' candidate sort on several host threads) leaves every sequence exactly
+    as this toolchain's std::sort does, tie order included (tests/cpp/exact_sort_check.cpp: 420 sequences)."""
+    import subprocess
+    exe = str(tmp_path / "exact_sort_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "exact_sort_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
