@@ -734,9 +734,10 @@ __device__ __forceinline__ void plane_eigen(const double a00, const double a01, 
     // So, for those lanes only: finish the Newton iteration (from below it can only reach the smallest root), then
     // Rayleigh refinement on the MATRIX — lambda = v'Av is second-order accurate in v, so every round squares the error —
     // which ends at the eps |A| / gap an iterative solver like Eigen's delivers.  The usual lane skips all of it.
-    const double S0 = c2 - w0, P0 = c1 - w0 * S0;
-    const double w1e = 0.5 * (S0 - sqrt(fmax(S0 * S0 - 4.0 * P0, 0.0)));
-    if (w1e - w0 < 0.25 * w1e) {
+    // "w1 - w0 < 25 % of w1", i.e. w1 < (4/3) w0, without extracting w1: w1, w2 are the roots of t^2 - S0 t + P0, so the test
+    // point t = (4/3) w0 lies at or above w1 iff the quadratic is <= 0 there or t is already past the roots' midpoint
+    const double S0 = c2 - w0, P0 = c1 - w0 * S0, tq = (4.0 / 3.0) * w0;
+    if (tq >= 0.5 * S0 || (tq - S0) * tq + P0 <= 0.0) {
       double prev = kDblMax;
 #pragma unroll 1
       for (int it = 0; it < 56; ++it) {
