@@ -296,8 +296,9 @@ def write_native_input(path, cfg: ReplayConfig, scans, rng_seed=7, mode=synth.EN
             w([sc["header_ts"]], np.float64)
 
 
-def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7):
-    """The same replay through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls."""
+def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible_device=None):
+    """The same replay through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls.
+    visible_device: run the driver with HIP_VISIBLE_DEVICES set to it (one replay per GPU of a node)."""
     import json
     import os
     import subprocess
@@ -305,7 +306,10 @@ def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7):
     exe = build.build_replay_native()
     path = os.path.join(workdir, "replay_input.bin")
     write_native_input(path, cfg, scans, rng_seed)
-    out = subprocess.run([exe, path, str(repeats)], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ)
+    if visible_device is not None:
+        env["HIP_VISIBLE_DEVICES"] = str(visible_device)
+    out = subprocess.run([exe, path, str(repeats)], capture_output=True, text=True, timeout=900, env=env)
     os.remove(path)
     if out.returncode != 0:
         raise RuntimeError("replay_native failed: " + out.stderr[-2000:])
