@@ -92,8 +92,25 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # MH_BENCH_DRYRUN=1 (tests only): several ranks on ONE GPU over gloo, to exercise the multi-rank control flow of this
+        # script on a one-GPU box (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+        dryrun = os.environ.get("MH_BENCH_DRYRUN") == "1"
+        if dryrun:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        _raw_all_reduce = dist.all_reduce
+
+        def _all_reduce(t, op=dist.ReduceOp.SUM, **kw):  # gloo: device tensors go through the host
+            if dist.get_backend() == "gloo" and t.is_cuda:
+                h = t.cpu()
+                _raw_all_reduce(h, op=op, **kw)
+                t.copy_(h)
+                return None
+            return _raw_all_reduce(t, op=op, **kw)
 
     from mimosa_amd import capi, synth
 
@@ -159,7 +176,7 @@ def main():
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        _all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     k3_ms = np.array([o.gpu_ms_linearize for o in outs if o.gpu_ms_linearize >= 0], dtype=np.float64)
@@ -608,7 +625,7 @@ def main():
             err = f"{type(exc).__name__}: {exc}"
         rates = torch.zeros(world, dtype=torch.float64, device="cuda")
         rates[rank] = my_rate
-        dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+        _all_reduce(rates, op=dist.ReduceOp.SUM)
         rl = [float(v) for v in rates.cpu()]
         rp_stats = {"mode": "one replay per GPU through replay_native (C++ host mirror), all ranks at the same time; scans 20, window 5, "
                             "6 update iterations, photometric on", "n_ranks": world,
@@ -669,7 +686,7 @@ def main():
         if dist is not None:
             import torch
             tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            _all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         conc = {"streams": args.concurrent_streams, "steps": ksteps,
                 "value": round(n_pts * ksteps * world / el / 1e6, 2), "ms_per_step": round(el / ksteps * 1e3, 5)}
@@ -891,12 +908,12 @@ def main():
                 torch.cuda.synchronize()
                 el = time.perf_counter() - a
                 tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                _all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
                 nloc = torch.tensor([float(first_s["n_local"]), float(sh.map.stats()["n_points"])], dtype=torch.float64, device="cuda")
                 nmax = nloc.clone()
-                dist.all_reduce(nloc, op=dist.ReduceOp.SUM)
-                dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+                _all_reduce(nloc, op=dist.ReduceOp.SUM)
+                _all_reduce(nmax, op=dist.ReduceOp.MAX)
                 result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
                                        f"(shard blocks of 8^3 voxels + one-voxel halo), cold linearize per step",
                            "n_ranks": world, "backend": dist.get_backend(), "steps": ksh,

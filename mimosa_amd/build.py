@@ -47,9 +47,47 @@ def _stale(out: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+class _BuildLock:
+    """One builder at a time across processes (the ranks of a torchrun job all import this package): an flock on a file next
+    to the outputs.  Whoever waited re-checks staleness afterwards and usually finds nothing left to do."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(LIBDIR, exist_ok=True)
+        self.f = open(os.path.join(LIBDIR, ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+def _run_to(cmd: list, out: str, verbose: bool = False):
+    """Run a compiler command whose output path is `out`, into a temporary name, then rename: a concurrent reader (or a
+    process that is executing the old file) never sees a half-written one."""
+    tmp = f"{out}.tmp.{os.getpid()}"
+    cmd = [tmp if c == out else c for c in cmd]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
     """timeline=True builds the diagnostic variant libmimosa_hip_timeline.so (-DMH_TIMELINE:
     per-wave s_memtime stamps + mh_icp_timeline); never loaded by the product path."""
+    with _BuildLock():
+        return _build_locked(force, verbose, timeline)
+
+
+def _build_locked(force: bool, verbose: bool, timeline: bool) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build_timeline" if timeline else "build")
     os.makedirs(objdir, exist_ok=True)
@@ -63,15 +101,11 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
                    "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] + (["-DMH_BALANCE"] if os.environ.get("MH_BALANCE") else []) if timeline else []), "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            _run_to(cmd, o, verbose)
     lib = LIB.replace(".so", "_timeline.so") if timeline else LIB
     if force or _stale(lib, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        _run_to(cmd, lib, verbose)
     return lib
 
 
@@ -82,9 +116,10 @@ def build_replay_native(force: bool = False) -> str:
     host = os.path.join(HERE, "host")
     src = os.path.join(host, "replay_main.cpp")
     deps = [src, lib] + [os.path.join(host, "mimosa_hip", h) for h in ("replay.hpp", "binio.hpp", "photometric.hpp", "lidar.hpp", "types.hpp")]
-    if force or _stale(exe, deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, src, "-o", exe,
-                               "-L", LIBDIR, "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
+    with _BuildLock():
+        if force or _stale(exe, deps):
+            _run_to(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, src, "-o", exe,
+                     "-L", LIBDIR, "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"], exe)
     return exe
 
 

@@ -55,3 +55,29 @@ def test_sharded_configs2_size_world2():
     """BASELINE configs[2] at full size on the one GPU of the box: 131 072-pt scan vs the ~50 M-pt map sharded over two ranks
     == the unsharded HIP factor on the full map."""
     _run_ranks("dist_gpu_worker3.py", 2, timeout=900)
+
+
+def test_bench_two_rank_control_flow_dry_run():
+    """bench.py under torch.distributed.run with TWO ranks — the launch line the driver uses for the scaling runs — on the one
+    GPU of the test box: MH_BENCH_DRYRUN=1 puts both ranks on device 0 over gloo (RCCL refuses two ranks on one device).  The
+    numbers mean nothing; what is checked is that every multi-rank leg runs to the end: replica timing with its max-over-ranks
+    reduction, one replay per rank, the map-sharded leg (whose status histogram must be the unsharded one) and ONE JSON line."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MH_BENCH_DRYRUN="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["sequence_replay"]["n_ranks"] == 2 and min(d["sequence_replay"]["scans_per_s_per_rank"]) > 0
+    sh = d["sharded"]
+    assert "error" not in sh, sh
+    assert sh["n_ranks"] == 2 and sh["scan_points_total"] == 131072 and sh["scan_points_max_per_rank"] < 131072
+    assert sum(sh["status_hist"]) == 131072 and sh["status_hist"][8] > 80000
