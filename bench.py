@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL / device-buffer sharing fail with hipIpcGetMemHandle: invalid
+# argument otherwise); the launch environment normally exports it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
