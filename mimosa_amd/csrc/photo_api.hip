@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <set>
 #include <thread>
@@ -96,6 +97,8 @@ struct mh_photo_factor
   void * d_out = nullptr;  // device address of h_out
   size_t out_bytes = 0;
   bool pending = false, pending_timed = false;  // a linearize is enqueued and not yet collected
+  DevBuf d_ticket;              // one counter: blocks of the linearize kernel that have finished
+  unsigned int seq_counter = 0, pending_seq = 0;  // completion number the pending call publishes (0: wait on the stream)
   std::vector<int32_t> statuses;
   std::vector<double> centers, partials, rows;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -983,6 +986,8 @@ static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::v
   if (rc == MH_OK) e = AllocCache::alloc_pinned(&f->h_out, f->out_bytes);
   if (rc == MH_OK && e == hipSuccess) e = hipHostGetDevicePointer(&f->d_out, f->h_out, 0);
   if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = f->d_ticket.reserve(64, ctx->stream, false);
+  if (rc == MH_OK && e == hipSuccess) e = hipMemsetAsync(f->d_ticket.p, 0, 64, ctx->stream);
   if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
   if (rc != MH_OK || e != hipSuccess) {
     mh_photo_factor_destroy(f);
@@ -1031,7 +1036,7 @@ void mh_photo_factor_destroy(mh_photo_factor * f)
   mh_ctx * ctx = f->photo->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_rows}) b->release(true);
+  for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_rows, &f->d_ticket}) b->release(true);
   if (f->h_out) AllocCache::free_pinned(f->h_out, f->out_bytes);
   for (auto & e : f->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1102,6 +1107,17 @@ static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], con
     a.status = reinterpret_cast<int32_t *>(a.partials + nf * mh::kPhotoPartial);
     a.rows_out = static_cast<double *>(f->d_rows.p);
     a.counters = f->photo->d_counters;
+    // the completion word sits behind the statuses in the mapped block (the block is sized with 64 spare bytes)
+    const size_t seq_off = ((2 * nf + nf * mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 7) & ~size_t(7);
+    a.seq = 0;
+    a.ticket = static_cast<unsigned int *>(f->d_ticket.p);
+    a.host_seq = reinterpret_cast<unsigned int *>(static_cast<char *>(f->d_out) + seq_off);
+    f->pending_seq = 0;
+    if (!timed && nf > 0) {  // (no kernel is launched for an empty factor)
+      if (++f->seq_counter == 0) ++f->seq_counter;
+      a.seq = f->pending_seq = f->seq_counter;
+      __atomic_store_n(reinterpret_cast<unsigned int *>(static_cast<char *>(f->h_out) + seq_off), 0u, __ATOMIC_RELEASE);  // re-arm
+    }
     f->photo->h_counters->project_throw = f->photo->h_counters->pose_missing = 0;
     if (timed && !f->ev[0]) {
       MH_HIP(ctx, hipEventCreate(&f->ev[0]));
@@ -1125,7 +1141,25 @@ static int photo_linearize_finish(mh_photo_factor * f, mh_photo_result * out)
   const bool timed = f->pending_timed;
   f->pending = false;
   {
-    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the end of the kernel makes its host writes visible
+    bool need_sync = f->pending_seq == 0;
+    if (!need_sync) {  // spin on the completion number the kernel's last block publishes (mh_icp_wait does the same)
+      const size_t seq_off = ((2 * nf + nf * mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 7) & ~size_t(7);
+      const volatile unsigned int * flag = reinterpret_cast<const volatile unsigned int *>(static_cast<const char *>(f->h_out) + seq_off);
+      timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != f->pending_seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u) {
+          timespec t1;
+          clock_gettime(CLOCK_MONOTONIC, &t1);
+          if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 20000000L) {  // 20 ms: fall back
+            need_sync = true;
+            break;
+          }
+        }
+      }
+    }
+    if (need_sync) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the end of the kernel makes its host writes visible
     const double * new_centers = static_cast<const double *>(f->h_out);
     f->partials.assign(new_centers + 2 * nf, new_centers + 2 * nf + nf * mh::kPhotoPartial);
     std::memcpy(f->statuses.data(), new_centers + 2 * nf + nf * mh::kPhotoPartial, nf * sizeof(int32_t));

@@ -116,6 +116,9 @@ struct PhotoLinArgs
   double * partials;     // n_features x kPhotoPartial: upper triangle of sum v v^T, v = [J_b(6) (, J_a(6)), e]
   double * rows_out;     // optional (parity tooling): n_features x kPhotoMaxPatch x 8 = {e, J_b[6], valid}
   PhotoCounters * counters;
+  unsigned int seq;        // != 0: the last block publishes it to *host_seq (mapped pinned) after everything else
+  unsigned int * ticket;   // device counter of finished blocks
+  unsigned int * host_seq;
 };
 hipError_t launch_photo_linearize(const PhotoLinArgs & a, hipStream_t stream);
 

@@ -470,7 +470,8 @@ __device__ __forceinline__ void mat3_vec(const double * R, double x, double y, d
 }
 
 constexpr int kFeatPerBlock = 4;
-__global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(const PhotoLinArgs a)
+// one wave = one feature; returns as soon as the feature's status is known
+__device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
 {
   const int lane = threadIdx.x & 63, f = blockIdx.x * kFeatPerBlock + (threadIdx.x >> 6);
   if (f >= a.n_features) return;  // whole waves
@@ -713,6 +714,25 @@ __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(con
       if (lane == 0) part[ent] = s;
       ++ent;
     }
+}
+
+__global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(const PhotoLinArgs a)
+{
+  photo_linearize_feature(a);
+  // Completion number for a host that spins on the mapped block instead of paying a stream synchronisation (as K4 does
+  // for the ICP factor): every block makes its host writes visible (system-scope fence), takes a ticket, the last one
+  // re-arms the ticket and publishes.
+  if (a.seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == gridDim.x - 1) {
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
