@@ -197,7 +197,12 @@ inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrd
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+  pool.reserve(static_cast<size_t>(threads));
+  try {
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+  } catch (...) {
+    // no more threads to be had: the ones that started and the caller finish the tree
+  }
   worker();
   for (auto & t : pool) t.join();
   final_insertion_sort(first, last, comp);
