@@ -470,7 +470,8 @@ int mh_photo_set_features(mh_photo * photo, const mh_photo_feature * features, s
                           const double * intensities, const double * psi);
 /* Photometric::detectFeatures (photometric.cpp:516-745) on the current frame: up to num_to_detect new features are
  * appended to the tracked ones.  T_W_Be = Values[frame key]; bias_directions: n_directions x 3 (the degenerate
- * directions Manager::postDefineUpdate passes, lidar/manager.cpp:568-581). */
+ * directions Manager::postDefineUpdate passes, lidar/manager.cpp:568-581).  The candidate sort (std::sort's exact result, tie order included)
+ * runs on up to four host threads of its own for the duration of the call (MH_SORT_THREADS=1: the plain library call). */
 int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3],
                              const double * bias_directions, size_t n_directions);
 /* Photometric::updateMap (photometric.cpp:396-514): feature bookkeeping from the factor's statuses (drop the
