@@ -815,6 +815,10 @@ def main():
             "kernel_ms_avg": round(float(k3_ms.mean()), 5),
             "kernel_ms_p95": round(float(np.percentile(k3_ms, 95)), 5),
             "localizability_kernel_ms_avg": round(float(k4_ms.mean()), 5),
+            "kernel_ms_back_to_back": round(elapsed_nocomp / max(args.steps, 1) * 1e3, 5) if not args.profile_mode else None,
+            "kernel_ms_back_to_back_note": "wall clock / steps of the pipelined pass with the component pass off (K3 launches back to back, "
+                                           "no event packets): an upper bound of K3's duration, the figure rocprofv3 reports; "
+                                           "kernel_ms_avg (HIP events around single launches) also contains the dispatch latency",
         },
         "sync_latency_ms": round(lat_ms, 4),
         "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
