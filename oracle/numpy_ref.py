@@ -322,6 +322,65 @@ def prepare_input(raw, range_min=0.2, range_max=100.0, intensity_min=0.0, intens
     return {"points_full": full, "geometric_idxs": geo, "unique_ns": unique_ns, "groups": groups, "last_point_ns": last}
 
 
+def prepare_input_typed(kind, raw, header_ts=0.0, width=None, height=1, transpose=False, organize=False, range_min=0.2, range_max=100.0,
+                        intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9, z_offset=0.0, create_full_res_pointcloud=True,
+                        point_skip_divisor=4, ring_skip_divisor=1):
+    """Manager::prepareInput<PointT> (src/lidar/manager.cpp:149-383) for the reference's nine point types, vectorised and
+    independent of oracle/ref_cpu.hpp: re-ordering by index arithmetic (transpose :177-203, stable bucket-by-ring :205-241),
+    masks instead of the `continue` chain, per-type time decoding (:285-304) in numpy float64 / float32.
+    raw: structured array with the type's own field names (x, y, z, intensity | reflectivity, t | timestamp | time, ring, tag)."""
+    n = len(raw)
+    width = n if width is None else width
+    order = np.arange(n)
+    if transpose and kind in ("rslidar", "velodyne_anybotics"):
+        # transposed[new_row * new_width + new_col] = cloud[new_col * width + new_row], new_width = height
+        j = np.arange(n)
+        order = (j % height) * width + (j // height)
+        width, height = height, width
+    raw = raw[order]
+    has_ring = kind not in ("livox", "livox_custom2", "ouster_odyssey")
+    if organize and height == 1 and has_ring:
+        raw = raw[np.argsort(raw["ring"].astype(np.int64), kind="stable")]
+    i = np.arange(n)
+    x, y, z = raw["x"].astype(np.float32), raw["y"].astype(np.float32), raw["z"].astype(np.float32)
+    stride = 1 if create_full_res_pointcloud else point_skip_divisor
+    with np.errstate(invalid="ignore", over="ignore"):
+        keep = (i % stride) == 0
+        keep &= ~(np.isnan(x) | np.isnan(y) | np.isnan(z))
+        if kind in ("livox", "livox_custom2"):                                         # :256-262
+            keep &= np.isin(raw["tag"] & 0x30, (0x00, 0x10))
+        if kind == "ouster_odyssey":                                                   # :265-271
+            refl = raw["reflectivity"]
+            keep &= ~((refl < np.float32(intensity_min)) | (refl > np.float32(intensity_max)))
+            inten = refl.astype(np.float32)
+        else:
+            inten = raw["intensity"].astype(np.float32)
+            keep &= ~(np.isnan(inten) | (inten < np.float32(intensity_min)) | (inten > np.float32(intensity_max)))
+        r2 = (x * x + y * y) + z * z
+        keep &= ~((r2 < np.float32(range_min) * np.float32(range_min)) | (r2 > np.float32(range_max) * np.float32(range_max)))
+        if kind in ("ouster", "ouster_odyssey", "ouster_r8", "livox_custom2"):
+            t_ns = raw["t"].astype(np.uint32)
+        else:
+            if kind in ("hesai", "rslidar"):
+                d = (raw["timestamp"].astype(np.float64) - np.float64(header_ts)) * 1e9
+            elif kind == "livox":
+                d = raw["timestamp"].astype(np.float64) - np.float64(header_ts) * 1e9
+            else:
+                d = raw["time"].astype(np.float32).astype(np.float64) * 1e9
+            # uint32_t t_ns = <double> on x86-64: truncate to a 64-bit integer, keep the low word
+            t_ns = (np.trunc(d).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+        keep &= ~(t_ns.astype(np.float32) > np.float32(ns_max))
+    sel = np.nonzero(keep)[0]
+    full = {"x": x[sel], "y": y[sel], "z": z[sel] + np.float32(z_offset), "intensity": inten[sel], "t": t_ns[sel],
+            "idx": sel.astype(np.uint32), "range": np.sqrt(r2[sel])}
+    geo_mask = (sel % point_skip_divisor) == 0
+    if kind not in ("livox", "livox_custom2", "velodyne_anybotics", "ouster_odyssey"):  # :321-332
+        geo_mask &= (raw["ring"][sel].astype(np.int64) % ring_skip_divisor) == 0
+    unique_ns = np.unique(t_ns[sel])
+    return {"points_full": full, "geometric_idxs": np.nonzero(geo_mask)[0], "unique_ns": unique_ns,
+            "last_point_ns": int(t_ns[sel].max()) if len(sel) else 0}
+
+
 def _so3_exp(w):
     th = float(np.linalg.norm(w))
     K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], float)

@@ -105,6 +105,33 @@ def test_typed_oracle_branches(kind):
     assert o["last_point_ns"] == full["t"].max()
 
 
+@pytest.mark.parametrize("kind", ref_cpu.POINT_KINDS)
+def test_typed_oracle_against_the_numpy_twin(kind):
+    """oracle/ref_cpu.hpp::prepare_input_typed (sequential, per-type structs) and oracle/numpy_ref.py::prepare_input_typed
+    (vectorised, index arithmetic) are two independent restatements of manager.cpp:149-383; they must agree bit for bit on
+    every point type, with and without the two re-orderings."""
+    from oracle import numpy_ref
+    cases = [dict(width=128, height=32), dict(organize=True)]
+    if kind in ("rslidar", "velodyne_anybotics"):
+        cases.append(dict(width=32, height=128, transpose=True))
+    for kw in (dict(), CFG, dict(create_full_res_pointcloud=0, point_skip_divisor=3, ring_skip_divisor=3)):
+        for order in cases:
+            raw = make_sensor_scan(kind, order="col" if (order.get("organize") or order.get("transpose")) else "row")
+            a = ref_cpu.prepare_input_typed(kind, raw, ref_cpu.make_input_config(**kw), header_ts=HEADER_TS, **order)
+            cfgd = dict(range_min=0.0, range_max=100.0, intensity_min=0.0, intensity_max=1.0e10, ns_max=1.0e9, z_offset=0.0,
+                        create_full_res_pointcloud=True, point_skip_divisor=1, ring_skip_divisor=1)
+            ic = ref_cpu.make_input_config(**kw)
+            for f in cfgd:
+                cfgd[f] = type(cfgd[f])(getattr(ic, f))
+            b = numpy_ref.prepare_input_typed(kind, raw, header_ts=HEADER_TS, **order, **cfgd)
+            pa = _as_points(a["points_full"])
+            assert len(pa) == len(b["points_full"]["x"]) > 0
+            for k in FIELDS:
+                assert np.array_equal(pa[k].view(np.uint32), np.ascontiguousarray(b["points_full"][k]).view(np.uint32)), (kind, order, k)
+            assert np.array_equal(a["geometric_idxs"], b["geometric_idxs"].astype(np.uint64))
+            assert np.array_equal(a["unique_ns"], b["unique_ns"]) and a["last_point_ns"] == b["last_point_ns"]
+
+
 def _check(ctx, kind, raw, kw, **order):
     from mimosa_amd import capi
     cfg = capi.make_input_config(**kw)
