@@ -301,3 +301,32 @@ def linearize(cfg, fr, features, R_b, t_b, R_a=None, t_a=None, VSVt=None):
     with np.errstate(invalid="ignore"):
         out.update(loc_rot_final=np.sqrt(wr), loc_trans_final=np.sqrt(wt), eigvec_rot=Er, eigvec_trans=Et)
     return out
+
+
+def gradient_based_locations(grad_x, grad_y, pattern):
+    """getGradientBasedLocations + snapPoint (src/lidar/photometric_utils.cpp:453-518), written independently of
+    oracle/photo_ref.hpp: the pattern rotated into the (edge normal, edge tangent) frame, every point snapped to the nearest
+    free pixel (round half away from zero; when taken, the nearest of the 8 neighbours in dx-major, dy-minor order)."""
+    gx, gy = np.float32(grad_x), np.float32(grad_y)
+    norm = float(np.sqrt(np.float32(gx * gx + gy * gy))) + 1e-6          # float products, float sqrt, then double
+    nx, ny, tx, ty = -float(gy) / norm, float(gx) / norm, float(gx) / norm, float(gy) / norm
+    used, out = set(), []
+    for px, py in pattern:
+        rx, ry = nx * float(px) + tx * float(py), ny * float(px) + ty * float(py)
+        g = (int(round_half_away(rx)), int(round_half_away(ry)))
+        if g in used:
+            best, best_d = g, float("inf")
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    if dx == 0 and dy == 0:
+                        continue
+                    alt = (g[0] + dx, g[1] + dy)
+                    if alt in used:
+                        continue
+                    d = float(np.sqrt((alt[0] - rx) ** 2 + (alt[1] - ry) ** 2))
+                    if d < best_d:
+                        best, best_d = alt, d
+            g = best
+        used.add(g)
+        out.append(g)
+    return np.array(out, np.int32)

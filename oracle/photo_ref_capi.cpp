@@ -87,6 +87,18 @@ void * refphoto_create(const mh_photo_config * c)
 }
 void refphoto_destroy(void * h) { delete static_cast<Handle *>(h); }
 
+// getGradientBasedLocations (photometric_utils.cpp:485-518) on its own, for the check against the numpy twin
+void refphoto_gradient_locations(float grad_x, float grad_y, const int32_t * pattern, int n, int32_t * out)
+{
+  std::vector<std::pair<int, int>> pat;
+  for (int i = 0; i < n; ++i) pat.emplace_back(pattern[2 * i], pattern[2 * i + 1]);
+  const auto loc = gradient_based_locations(grad_x, grad_y, pat);
+  for (int i = 0; i < n; ++i) {
+    out[2 * i] = loc[i].first;
+    out[2 * i + 1] = loc[i].second;
+  }
+}
+
 // returns 0 ok, 1 = the reference would have thrown
 int refphoto_preprocess(void * hv, const Point32 * raw, Point32 * desk, size_t n, const uint32_t * ns, const double * T, size_t ng)
 {

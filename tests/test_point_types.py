@@ -326,3 +326,25 @@ def test_random_record_layouts(ctx, seed):
     _same_points(sc.points(capi.Scan.FULL), _as_points(o["points_full"]))
     assert np.array_equal(sc.indices(0), o["geometric_idxs"].astype(np.uint32))
     sc.destroy()
+
+
+def test_rotated_patch_locations_against_the_numpy_twin():
+    """getGradientBasedLocations / snapPoint (photometric_utils.cpp:453-518): oracle/photo_ref.hpp vs oracle/numpy_photo.py
+    on random gradient directions (including exact multiples of 45 degrees, where rounding ties and collisions happen) for the
+    5 x 5, 8 x 8 and 3 x 3 patterns."""
+    import ctypes as C
+    from oracle import numpy_photo, ref_cpu as rc
+    from mimosa_amd import synth_photo as sp
+    L = rc.lib()
+    L.refphoto_gradient_locations.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(11)
+    for patch in (5, 8, 3):
+        pat = np.ascontiguousarray(sp.photo_config(patch=patch)["patch_offsets"], np.int32)
+        dirs = [(np.cos(a), np.sin(a)) for a in np.arange(0, 2 * np.pi, np.pi / 8)] + [tuple(rng.normal(0, 1, 2)) for _ in range(60)] + [(0.0, 0.0)]
+        for gx, gy in dirs:
+            out = np.zeros_like(pat)
+            L.refphoto_gradient_locations(C.c_float(gx), C.c_float(gy), pat.ctypes.data_as(C.c_void_p), len(pat), out.ctypes.data_as(C.c_void_p))
+            tw = numpy_photo.gradient_based_locations(gx, gy, pat)
+            assert np.array_equal(out, tw), (patch, gx, gy)
+            if gx or gy:                                             # (a zero gradient piles everything onto 9 pixels, there as here)
+                assert len({tuple(r) for r in out}) == len(out)
