@@ -97,7 +97,13 @@ def test_random_photometric_pipeline(ctx, seed):
             assert rel(ga[:, :, 1:7], ra[:, :, 1:7]) <= 1e-5 and rel(ga[:, :, 0], ra[:, :, 0]) <= 1e-5
         nH = np.linalg.norm(rr["H_bb"])
         if np.isfinite(nH) and np.all(np.isfinite(gr["H_bb"])) and nH > 0:
-            assert rel(gr["H_bb"], rr["H_bb"]) <= 1e-5 and np.linalg.norm(np.asarray(gr["b_b"]) - np.asarray(rr["b_b"])) <= 1e-5 * max(np.linalg.norm(rr["b_b"]), 1e-12 * nH)
+            assert rel(gr["H_bb"], rr["H_bb"]) <= 1e-5
+            # The unary factor returns b = VSVt J_I VSVt J_I^-1 b_I (photometric_factor.hpp:337-341): with one or two Valid
+            # features J_I = sum J'J is singular, its "inverse" is rounding noise times 1e16 and b is arbitrary in every
+            # implementation (found by the 6000-seed soak: H and f equal to 1e-13, b different).  b is compared when J_I
+            # (= H_bb here, VSVt being the identity) is invertible in double precision.
+            if binary or np.linalg.cond(np.asarray(rr["H_bb"], float).reshape(6, 6)) < 1e9:
+                assert np.linalg.norm(np.asarray(gr["b_b"]) - np.asarray(rr["b_b"])) <= 1e-5 * max(np.linalg.norm(rr["b_b"]), 1e-12 * nH)
             if not flat:
                 assert abs(gr["f"] - rr["f"]) <= 1e-5 * max(abs(rr["f"]), 1e-300)
             if binary:

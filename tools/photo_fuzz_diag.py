@@ -29,7 +29,10 @@ for it in range(2):
     args = (R, t, fr[0]["R_W_Be"], fr[0]["t_W_Be"]) if binary else (R, t)
     gr, rr = gf.linearize(*args), rf.linearize(*args)
     gs, rs = gf.state(), rf.state()
-    print("it", it, "hist", list(gr["status_hist"]), list(rr["status_hist"]))
+    print("it", it, "binary", binary, "hist", list(gr["status_hist"]), list(rr["status_hist"]))
+    for key in ("b_b", "f", "b_a"):
+        print("   ", key, "hip", np.asarray(gr[key]).ravel()[:6], "ref", np.asarray(rr[key]).ravel()[:6])
+    print("    H_bb diag hip", np.diag(np.asarray(gr["H_bb"]).reshape(6, 6)), "ref", np.diag(np.asarray(rr["H_bb"]).reshape(6, 6)))
     for f_ in np.nonzero(gs[0] != rs[0])[0]:
         print(" STATUS differs: feature", f_, gs[0][f_], rs[0][f_], "\n  hip res", gs[2][f_, :12, 0], "\n  ref res", rs[2][f_, :12, 0], "\n  hip J0", gs[2][f_, :3, 1:7], "\n  ref J0", rs[2][f_, :3, 1:7])
     d = np.abs(gs[2] - rs[2]).max(axis=2)
