@@ -970,25 +970,33 @@ static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::v
   for (int i = 0; i < 36; ++i) f->VSVt[i] = VSVt ? VSVt[i] : ((i % 7 == 0) ? 1.0 : 0.0);
   f->features = feats;
   const size_t nf = f->features.size();
-  std::vector<double> Le(nf * mh::kPhotoMaxPatch * 3, 0.0), ps(nf * mh::kPhotoMaxPatch, 0.0);
-  std::vector<int32_t> np(nf);
-  for (size_t i = 0; i < nf; ++i) {
-    const HostFeature & hf = f->features[i];
-    np[i] = hf.hdr.n_points;
-    std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
-    std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
+  // The factor's pinned block holds the kernel's outputs and, behind them, the staged inputs (patch points, psi, point
+  // counts): the uploads run from memory that lives as long as the factor, so creating a factor does not wait for them.
+  const size_t out_part = (nf * (2 + mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 64 + 255) & ~size_t(255);
+  const size_t b_Le = nf * mh::kPhotoMaxPatch * 3 * sizeof(double), b_ps = nf * mh::kPhotoMaxPatch * sizeof(double), b_np = nf * sizeof(int32_t);
+  f->out_bytes = (out_part + b_Le + b_ps + b_np + 64 + 4095) & ~size_t(4095);  // few size classes for the pinned cache
+  hipError_t e = AllocCache::alloc_pinned(&f->h_out, f->out_bytes);
+  int rc = MH_OK;
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&f->d_out, f->h_out, 0);
+  if (e == hipSuccess) {
+    char * stage = static_cast<char *>(f->h_out) + out_part;
+    double * Le = reinterpret_cast<double *>(stage);
+    double * ps = reinterpret_cast<double *>(stage + b_Le);
+    int32_t * np = reinterpret_cast<int32_t *>(stage + b_Le + b_ps);
+    std::memset(stage, 0, b_Le + b_ps + b_np);
+    for (size_t i = 0; i < nf; ++i) {
+      const HostFeature & hf = f->features[i];
+      np[i] = hf.hdr.n_points;
+      std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
+      std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
+    }
+    rc = upload(ctx, f->d_Le, Le, b_Le);
+    if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps, b_ps);
+    if (rc == MH_OK) rc = upload(ctx, f->d_npts, np, b_np);
   }
-  int rc = upload(ctx, f->d_Le, Le.data(), Le.size() * sizeof(double));
-  if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps.data(), ps.size() * sizeof(double));
-  if (rc == MH_OK) rc = upload(ctx, f->d_npts, np.data(), np.size() * sizeof(int32_t));
-  hipError_t e = hipSuccess;
-  f->out_bytes = (nf * (2 + mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 64 + 4095) & ~size_t(4095);  // few size classes for the pinned cache
-  if (rc == MH_OK) e = AllocCache::alloc_pinned(&f->h_out, f->out_bytes);
-  if (rc == MH_OK && e == hipSuccess) e = hipHostGetDevicePointer(&f->d_out, f->h_out, 0);
   if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
   if (rc == MH_OK && e == hipSuccess) e = f->d_ticket.reserve(64, ctx->stream, false);
   if (rc == MH_OK && e == hipSuccess) e = hipMemsetAsync(f->d_ticket.p, 0, 64, ctx->stream);
-  if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors go out of scope
   if (rc != MH_OK || e != hipSuccess) {
     mh_photo_factor_destroy(f);
     return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_factor_create");
