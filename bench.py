@@ -168,8 +168,10 @@ def main():
             done += nb
 
     # ---- warmup, then the timed region (per-kernel HIP events on the launch stream are on) ----
+    # every n-th call of a factor is bracketed; with few steps (per stream) n shrinks so that the timed region still holds one
+    event_every = max(1, min(args.event_every, args.steps // max(len(factors), 1)))
     for c in ctxs:
-        c.set_profiling(args.event_every)
+        c.set_profiling(event_every)
     run_steps(args.warmup)
     outs = []
     barrier()
@@ -811,7 +813,7 @@ def main():
             "bytes_per_point": round(b_pt, 1),
             "mean_candidates_per_query": round(mean_cq, 2),
             "kernel_timing": f"HIP events on the launch stream around {len(k3_ms)} of the {len(outs)} launches of the timed "
-                             f"region (every {args.event_every}th call of each factor)",
+                             f"region (every {event_every}th call of each factor)",
             "kernel_ms_avg": round(float(k3_ms.mean()), 5),
             "kernel_ms_p95": round(float(np.percentile(k3_ms, 95)), 5),
             "localizability_kernel_ms_avg": round(float(k4_ms.mean()), 5),
