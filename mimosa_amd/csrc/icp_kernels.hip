@@ -446,6 +446,9 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   }
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
   rem &= prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
+#ifdef MH_FAKE_SCAN_MASK  // tuning experiment only (wrong results): what the kernel would take if a lane scanned a subset of its voxels
+  rem &= MH_FAKE_SCAN_MASK;
+#endif
   uint32_t alive = rem;  // neighbour voxels never pruned: alive & ~rem (after the scan) = the voxels scanned
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
   const uint32_t amask_unpruned = amask & ~1u;
