@@ -976,7 +976,16 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         a.mean[3 * qi + 2] = mean[2];
         double w[3], v0[3];
         MH_STAMP_C2(a.dbg, 14);
+#ifdef MH_FAKE_NO_EIGEN  // timing-only bound experiment (wrong results): the plane fit without its eigen-decomposition
+        w[0] = c00 * ikm1 * 1e-3;
+        w[1] = c11 * ikm1;
+        w[2] = c22 * ikm1 + w[1];
+        v0[0] = 0.0;
+        v0[1] = 0.0;
+        v0[2] = 1.0;
+#else
         plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
+#endif
         MH_STAMP_C2(a.dbg, 15);
         if (!(w[0] == w[0]) || !(w[2] == w[2])) {
           st = MH_EIGEN_SOLVER_FAIL;  // NaN input: Eigen would report NoConvergence (:197)
@@ -1144,6 +1153,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
                   static_cast<double>(s_cnt[threadIdx.x - 128]));
 
   MH_STAMP(a.dbg, 5);
+#ifdef MH_FAKE_NO_TAIL  // timing-only bound experiment (wrong results): no ticket, no fold by the last block
+  return;
+#endif
   if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   MH_STAMP(a.dbg, 6);
 
@@ -1173,7 +1185,12 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         Hb[3 * r + c] = s_sum[ent_of(rr + o, cc + o)];
       }
     double loc[3], E[9];
+#ifdef MH_FAKE_NO_TAIL_EIGEN  // timing-only bound experiment (wrong results)
+    for (int i = 0; i < 3; ++i) loc[i] = Hb[4 * i];
+    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#else
     compute_localizability(Hb, loc, E);
+#endif
     for (int i = 0; i < 3; ++i) {
       if (o)
         MH_PUT(loc_trans_final[i], loc[i]);

@@ -14,6 +14,16 @@
 
 namespace mh
 {
+// 1 / sqrt(x): the device's reciprocal-square-root sequence (one refinement chain instead of a square root followed by a division)
+MH_HD double mh_rsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(x);
+#else
+  return 1.0 / std::sqrt(x);
+#endif
+}
+
 // Symmetric 3x3 eigen-decomposition, cyclic Jacobi in fp64.  A row-major (only the upper triangle
 // is read); on return w[0] <= w[1] <= w[2] and V (row-major) holds the eigenvectors in COLUMNS.
 // Branch-light and register-resident: every lane runs the same fixed sweep schedule, rotations
@@ -21,7 +31,7 @@ namespace mh
 // quadratically; 3x3 needs <= 5 sweeps for fp64 round-off (6 are run).  The sign of each
 // eigenvector is arbitrary (as it is in Eigen); the plane normal's sign is fixed afterwards by the
 // "normal faces the sensor" rule (geometric_factor.hpp:217-220).
-MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
+MH_HD void sym_eigen3_jacobi(const double A[9], double w[3], double V[9])
 {
   double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
@@ -31,9 +41,13 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
 
 #define MH_JACOBI_ROT(app, aqq, apq, apr, aqr, vp0, vq0, vp1, vq1, vp2, vq2) \
   if (fabs(apq) > tiny) {                                                     \
-    const double theta = (aqq - app) / (2.0 * apq);                           \
-    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
-    const double c = 1.0 / sqrt(tt * tt + 1.0);                               \
+    /* t = tan(rotation angle), the smaller root of t^2 + 2 theta t - 1 = 0 with theta = (aqq - app) / (2 apq), written   \
+       without theta: t = 2 apq sgn(d) / (|d| + sqrt(d^2 + 4 apq^2)), d = aqq - app — one square root and one division   \
+       (fp64 divisions and square roots are ~100-cycle dependent sequences on the device, and this runs on a single lane   \
+       in the serial tail of K3: 3 divisions + 2 square roots per rotation cost 3.7 us per linearize) */                  \
+    const double dd = aqq - app;                                              \
+    const double tt = (dd >= 0 ? 2.0 : -2.0) * apq / (fabs(dd) + sqrt(dd * dd + 4.0 * apq * apq)); \
+    const double c = mh_rsqrt(tt * tt + 1.0);                                 \
     const double s = tt * c;                                                  \
     app -= tt * apq;                                                          \
     aqq += tt * apq;                                                          \
@@ -76,6 +90,115 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
   V[0] = v00; V[1] = v01; V[2] = v02;
   V[3] = v10; V[4] = v11; V[5] = v12;
   V[6] = v20; V[7] = v21; V[8] = v22;
+}
+
+// The same decomposition without iterating, for the serial tail of K3 (one lane decomposes H_rr, another H_tt, while every
+// other wave of the machine has finished: the Jacobi sweeps above are ~12 rotations of dependent fp64 division / square-root
+// sequences, 3.5 us of a 38 us kernel).  Eigenvalues by the trigonometric form of the characteristic cubic on the scaled,
+// shifted matrix; the eigenvector of the best-separated eigenvalue from the largest cross product of two rows of A - w I, the
+// second from the 2 x 2 problem in its orthogonal complement, the third as their cross product (the construction of Eberly,
+// "A robust eigensolver for 3 x 3 symmetric matrices"); one Rayleigh-quotient step per eigenvalue afterwards.  The result is
+// VERIFIED — |A v - w v| against 1e-13 |A|, eigenvalue order — and anything that does not pass (clustered eigenvalues) goes
+// through the Jacobi sweeps instead, so the accuracy is Jacobi's either way.
+MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
+{
+  const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
+  const double mx = fmax(fmax(fabs(a00), fabs(a11)), fmax(fmax(fabs(a22), fabs(a01)), fmax(fabs(a02), fabs(a12))));
+  bool ok = mx > 0.0 && mx < 1e300;
+  if (ok) {
+    const double inv = 1.0 / mx;
+    const double b00 = a00 * inv, b01 = a01 * inv, b02 = a02 * inv, b11 = a11 * inv, b12 = a12 * inv, b22 = a22 * inv;
+    const double norm = b01 * b01 + b02 * b02 + b12 * b12;
+    const double q = (b00 + b11 + b22) / 3.0;
+    const double c00 = b00 - q, c11 = b11 - q, c22 = b22 - q;
+    const double p = sqrt((c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * norm) / 6.0);
+    ok = p > 1e-8;  // (nearly) a multiple of the identity: let the sweeps decide
+    double e0 = 0, e1 = 0, e2 = 0;
+    if (ok) {
+      const double ip = 1.0 / p;
+      const double d00 = c00 * ip, d01 = b01 * ip, d02 = b02 * ip, d11 = c11 * ip, d12 = b12 * ip, d22 = c22 * ip;
+      double half_det = 0.5 * (d00 * (d11 * d22 - d12 * d12) - d01 * (d01 * d22 - d12 * d02) + d02 * (d01 * d12 - d11 * d02));
+      half_det = fmin(fmax(half_det, -1.0), 1.0);
+      const double angle = acos(half_det) / 3.0;
+      const double two_thirds_pi = 2.09439510239319549;
+      const double beta2 = 2.0 * cos(angle), beta0 = 2.0 * cos(angle + two_thirds_pi), beta1 = -(beta0 + beta2);
+      e0 = q + p * beta0;
+      e1 = q + p * beta1;
+      e2 = q + p * beta2;
+      // eigenvectors (of the scaled matrix b): start with the eigenvalue that stands alone
+      auto evec_first = [&](double ev, double (&v)[3]) {
+        const double m00 = b00 - ev, m11 = b11 - ev, m22 = b22 - ev;
+        const double x0 = b01 * b12 - b02 * m11, y0 = b02 * b01 - m00 * b12, z0 = m00 * m11 - b01 * b01;
+        const double x1 = b01 * m22 - b02 * b12, y1 = b02 * b02 - m00 * m22, z1 = m00 * b12 - b01 * b02;
+        const double x2 = m11 * m22 - b12 * b12, y2 = b12 * b02 - b01 * m22, z2 = b01 * b12 - m11 * b02;
+        const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+        double vx = x0, vy = y0, vz = z0, nn = n0;
+        if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+        if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+        const double r = nn > 0.0 ? mh_rsqrt(nn) : 0.0;
+        v[0] = vx * r; v[1] = vy * r; v[2] = vz * r;
+        return nn > 0.0;
+      };
+      auto evec_second = [&](const double (&v0)[3], double ev, double (&v)[3]) {
+        // orthonormal complement {U, W} of v0
+        double U[3], W[3];
+        if (fabs(v0[0]) > fabs(v0[1])) {
+          const double r = mh_rsqrt(v0[0] * v0[0] + v0[2] * v0[2]);
+          U[0] = -v0[2] * r; U[1] = 0.0; U[2] = v0[0] * r;
+        } else {
+          const double r = mh_rsqrt(v0[1] * v0[1] + v0[2] * v0[2]);
+          U[0] = 0.0; U[1] = v0[2] * r; U[2] = -v0[1] * r;
+        }
+        W[0] = v0[1] * U[2] - v0[2] * U[1]; W[1] = v0[2] * U[0] - v0[0] * U[2]; W[2] = v0[0] * U[1] - v0[1] * U[0];
+        const double AU0 = b00 * U[0] + b01 * U[1] + b02 * U[2], AU1 = b01 * U[0] + b11 * U[1] + b12 * U[2], AU2 = b02 * U[0] + b12 * U[1] + b22 * U[2];
+        const double AW0 = b00 * W[0] + b01 * W[1] + b02 * W[2], AW1 = b01 * W[0] + b11 * W[1] + b12 * W[2], AW2 = b02 * W[0] + b12 * W[1] + b22 * W[2];
+        double m00 = U[0] * AU0 + U[1] * AU1 + U[2] * AU2 - ev, m01 = U[0] * AW0 + U[1] * AW1 + U[2] * AW2,
+               m11 = W[0] * AW0 + W[1] * AW1 + W[2] * AW2 - ev;
+        const double am00 = fabs(m00), am01 = fabs(m01), am11 = fabs(m11);
+        double cu, cw;  // v = cu U + cw W in the null space of [[m00, m01], [m01, m11]]
+        if (am00 >= am11) {
+          if (fmax(am00, am01) > 0.0) {
+            if (am00 >= am01) { const double t = m01 / m00; const double r = mh_rsqrt(1.0 + t * t); cu = t * r; cw = -r; }
+            else { const double t = m00 / m01; const double r = mh_rsqrt(1.0 + t * t); cu = r; cw = -t * r; }
+          } else { cu = 1.0; cw = 0.0; }
+        } else {
+          if (fmax(am11, am01) > 0.0) {
+            if (am11 >= am01) { const double t = m01 / m11; const double r = mh_rsqrt(1.0 + t * t); cu = -r; cw = t * r; }
+            else { const double t = m11 / m01; const double r = mh_rsqrt(1.0 + t * t); cu = -t * r; cw = r; }
+          } else { cu = 1.0; cw = 0.0; }
+        }
+        v[0] = cu * U[0] + cw * W[0]; v[1] = cu * U[1] + cw * W[1]; v[2] = cu * U[2] + cw * W[2];
+      };
+      double va[3], vb[3], vc[3];
+      if (half_det >= 0.0) {  // e2 stands alone (e0, e1 may be close)
+        ok = evec_first(e2, vc);
+        evec_second(vc, e1, vb);
+        va[0] = vb[1] * vc[2] - vb[2] * vc[1]; va[1] = vb[2] * vc[0] - vb[0] * vc[2]; va[2] = vb[0] * vc[1] - vb[1] * vc[0];
+      } else {                // e0 stands alone
+        ok = evec_first(e0, va);
+        evec_second(va, e1, vb);
+        vc[0] = va[1] * vb[2] - va[2] * vb[1]; vc[1] = va[2] * vb[0] - va[0] * vb[2]; vc[2] = va[0] * vb[1] - va[1] * vb[0];
+      }
+      // Rayleigh quotients on the unscaled matrix, then the check
+      auto rq = [&](const double (&v)[3], double & res) {
+        const double Av0 = a00 * v[0] + a01 * v[1] + a02 * v[2], Av1 = a01 * v[0] + a11 * v[1] + a12 * v[2], Av2 = a02 * v[0] + a12 * v[1] + a22 * v[2];
+        const double lam = v[0] * Av0 + v[1] * Av1 + v[2] * Av2;
+        const double r0 = Av0 - lam * v[0], r1 = Av1 - lam * v[1], r2 = Av2 - lam * v[2];
+        res = fmax(fabs(r0), fmax(fabs(r1), fabs(r2)));
+        return lam;
+      };
+      double ra, rb, rc;
+      const double la = rq(va, ra), lb = rq(vb, rb), lc = rq(vc, rc);
+      ok = ok && fmax(ra, fmax(rb, rc)) <= 1e-13 * mx && la <= lb && lb <= lc;
+      if (ok) {
+        w[0] = la; w[1] = lb; w[2] = lc;
+        V[0] = va[0]; V[1] = vb[0]; V[2] = vc[0];
+        V[3] = va[1]; V[4] = vb[1]; V[5] = vc[1];
+        V[6] = va[2]; V[7] = vb[2]; V[8] = vc[2];
+      }
+    }
+  }
+  if (!ok) sym_eigen3_jacobi(A, w, V);
 }
 
 // computeLocalizability, include/mimosa/utils.hpp:308-313: sqrt(eigenvalues) ascending + eigenvectors

@@ -71,3 +71,13 @@ def test_parallel_introsort_is_std_sort(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "exact_sort_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+def test_fast_eigen3_matches_jacobi(tmp_path):
+    """mh::sym_eigen3 (math3.hpp: trigonometric eigenvalues, cross-product eigenvectors, Rayleigh step, verified, Jacobi fallback)
+    vs the Jacobi sweeps on 400 000 random spectra: eigenvalues within 1e-12 |A|, residual |A v - w v| within 1e-12 |A|."""
+    import subprocess
+    exe = str(tmp_path / "eigen3_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "eigen3_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
