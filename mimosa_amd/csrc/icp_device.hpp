@@ -64,7 +64,8 @@ struct LocArgs
 {
   DeviceResult * host_result;  // mapped pinned host slot: the last block writes loc_comp / status_hist there (no D2H copy node)
   unsigned int seq;            // published to host_result->seq after everything else: the host may spin on it
-  const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = use result->eig_* from K3
+  const double * eig;          // 18 doubles: eig_rot (9) then eig_trans (9); null = derive them from result->sums (K3's Hessian sums)
+  int nv;                      // 7 (unary) or 13 (binary): row length of the v v^T triangle in result->sums
   const float4 * src;
   int n;
   int chunks_per_block;  // set by the launcher

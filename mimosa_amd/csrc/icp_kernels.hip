@@ -1174,36 +1174,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
   if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
   if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
-  if (threadIdx.x == 0 || threadIdx.x == 64) {
-    // computeLocalizability on the rot / trans 3x3 blocks of J_s^T J_s (:405-411), one wave each
-    auto ent_of = [](int r, int c) { return r * NV - r * (r - 1) / 2 + (c - r); };  // r <= c
-    const int o = threadIdx.x ? 3 : 0;
-    double Hb[9];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        const int rr = r < c ? r : c, cc = r < c ? c : r;
-        Hb[3 * r + c] = s_sum[ent_of(rr + o, cc + o)];
-      }
-    double loc[3], E[9];
-#ifdef MH_FAKE_NO_TAIL_EIGEN  // timing-only bound experiment (wrong results)
-    for (int i = 0; i < 3; ++i) loc[i] = Hb[4 * i];
-    for (int i = 0; i < 9; ++i) E[i] = (i % 4 == 0) ? 1.0 : 0.0;
-#else
-    compute_localizability(Hb, loc, E);
-#endif
-    for (int i = 0; i < 3; ++i) {
-      if (o)
-        MH_PUT(loc_trans_final[i], loc[i]);
-      else
-        MH_PUT(loc_rot_final[i], loc[i]);
-    }
-    for (int i = 0; i < 9; ++i) {
-      if (o)
-        MH_PUT(eig_trans[i], E[i]);
-      else
-        MH_PUT(eig_rot[i], E[i]);
-    }
-  }
+  // computeLocalizability of the rot / trans 3 x 3 blocks (:405-411) is NOT done here: two eigen-decompositions on one lane
+  // each cost 2.3 us of this serial tail while 255 CUs idle.  K4's workgroups derive the eigenbases they need from
+  // result->sums themselves (behind their per-point loads), the host epilogue derives the ones it reports (finish_result).
 #undef MH_PUT
   // No K4 behind this call (mh_icp_set_components(icp, 0)): this block's writes are the whole result, so the completion
   // number a spinning host waits for is published here — data first (system-scope fence by every writer), then the flag.
@@ -1300,16 +1273,37 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double v[6] = {0, 0, 0, 0, 0, 0};
   unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // the two eigenbases are requested up front, in the same round trip as the first per-point loads
+  // The first chunk's status, point and normal are requested first: one memory round trip, in flight while the
+  // eigenbases below are worked out (the pass is a handful of round trips long, nothing else).
+  const int i_first = block_id * a.chunks_per_block * TPB + static_cast<int>(threadIdx.x);
+  const int i_ld = i_first < a.n ? i_first : 0;
+  int st_next = a.n > 0 ? a.status[i_ld] : -1;
+  float4 sp_next = a.n > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
+  double n0_next = a.n > 0 ? a.normal[3 * i_ld] : 0.0, n1_next = a.n > 0 ? a.normal[3 * i_ld + 1] : 0.0, n2_next = a.n > 0 ? a.normal[3 * i_ld + 2] : 0.0;
+  // The two eigenbases: given (map-sharded factors: the basis of the GLOBAL Hessian), or derived here from the Hessian sums
+  // K3's last block left in result->sums — one lane per 3 x 3 block (computeLocalizability, utils.hpp:308-313), every
+  // workgroup for itself.  (In K3's serial tail they cost 2.3 us with 255 CUs idle.)
+  __shared__ double s_E[18];
+  if (a.eig) {
+    if (threadIdx.x < 18) s_E[threadIdx.x] = a.eig[threadIdx.x];
+  } else if (threadIdx.x == 0 || threadIdx.x == 64) {
+    const int NV = a.nv, o = threadIdx.x ? 3 : 0;
+    double Hb[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const int rr = (r < c ? r : c) + o, cc = (r < c ? c : r) + o;
+        Hb[3 * r + c] = a.result->sums[rr * NV - rr * (rr - 1) / 2 + (cc - rr)];
+      }
+    double loc[3], E[9];
+    compute_localizability(Hb, loc, E);
+    for (int q = 0; q < 9; ++q) s_E[(o ? 9 : 0) + q] = E[q];
+  }
+  __syncthreads();
   double er[9], et[9];
-  {
-    const double * Er = a.eig ? a.eig : a.result->eig_rot;
-    const double * Et = a.eig ? a.eig + 9 : a.result->eig_trans;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      er[q] = Er[q];
-      et[q] = Et[q];
-    }
+  for (int q = 0; q < 9; ++q) {
+    er[q] = s_E[q];
+    et[q] = s_E[9 + q];
   }
   // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
   // cost is the ticket + fold tail, which scales with the number of partial rows
@@ -1317,11 +1311,21 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   const int i = (block_id * a.chunks_per_block + ch) * TPB + threadIdx.x;
   int st = -1;
   if (i < a.n) {
-    // status, point and normal are requested together (one memory round trip instead of a dependent chain;
-    // the pass is a handful of round trips long, nothing else)
-    st = a.status[i];
-    const float4 sp = a.src[i];
-    const double n0 = a.normal[3 * i], n1 = a.normal[3 * i + 1], n2 = a.normal[3 * i + 2];
+    float4 sp;
+    double n0, n1, n2;
+    if (ch == 0) {
+      st = st_next;
+      sp = sp_next;
+      n0 = n0_next;
+      n1 = n1_next;
+      n2 = n2_next;
+    } else {
+      st = a.status[i];
+      sp = a.src[i];
+      n0 = a.normal[3 * i];
+      n1 = a.normal[3 * i + 1];
+      n2 = a.normal[3 * i + 2];
+    }
     if (st == MH_VALID) {
       const double px = sp.x, py = sp.y, pz = sp.z;
       const double ns0 = a.R[0] * n0 + (a.R[3] * n1 + a.R[6] * n2);

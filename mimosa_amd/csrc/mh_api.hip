@@ -129,15 +129,25 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
       out->b_t[r] = d.sums[ent(6 + r, 12)];
     }
   }
+  // computeLocalizability of the rot / trans blocks of J_s^T J_s (:405-411), here on the host from the Hessian sums: on the
+  // device it was two serial eigen-decompositions in K3's tail (2.3 us); K4 derives the bases it needs itself.
+  {
+    double Hr[9], Ht[9], er[9], et[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        Hr[3 * r + c] = d.sums[ent(r, c)];
+        Ht[3 * r + c] = d.sums[ent(3 + r, 3 + c)];
+      }
+    mh::compute_localizability(Hr, out->loc_rot_final, er);
+    mh::compute_localizability(Ht, out->loc_trans_final, et);
+    std::memcpy(out->eigvec_rot, er, sizeof(er));
+    std::memcpy(out->eigvec_trans, et, sizeof(et));
+  }
   for (int i = 0; i < 3; ++i) {
-    out->loc_rot_final[i] = d.loc_rot_final[i];
-    out->loc_trans_final[i] = d.loc_trans_final[i];
     // switched off (mh_icp_set_components): NaN, so that a caller who reads them anyway notices
     out->loc_trans_comp[i] = pc.components ? d.loc_comp[i] : std::numeric_limits<double>::quiet_NaN();
     out->loc_rot_comp[i] = pc.components ? d.loc_comp[3 + i] : std::numeric_limits<double>::quiet_NaN();
   }
-  std::memcpy(out->eigvec_rot, d.eig_rot, sizeof(double) * 9);
-  std::memcpy(out->eigvec_trans, d.eig_trans, sizeof(double) * 9);
 
   double Hrr[9], Hrt[9], Htr[9], Htt[9];
   for (int r = 0; r < 3; ++r)
@@ -624,6 +634,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   l.host_result = nullptr;  // set below once the slot is known
   l.seq = 0;
   l.eig = nullptr;
+  l.nv = icp->binary ? 13 : 7;
   l.n = a.n;
   l.chunks_per_block = 1;
   std::memcpy(l.R, a.R, sizeof(l.R));
@@ -950,6 +961,7 @@ static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9]
   l.host_result = icp->d_h_results;  // slot 0
   l.seq = 0xFFFFFFFFu;  // not waited on by flag: the call below synchronises the stream
   l.eig = static_cast<const double *>(icp->d_eig.p);
+  l.nv = icp->binary ? 13 : 7;
   l.src = static_cast<const float4 *>(icp->d_src.p);
   l.n = static_cast<int>(icp->n);
   std::memcpy(l.R, icp->split_R, sizeof(l.R));
@@ -1635,6 +1647,7 @@ static int mh_icp_linearize_finish_device_impl(mh_icp * icp, const double * d_gl
     l.host_result = nullptr;
     l.seq = 0;
     l.eig = static_cast<const double *>(icp->d_eig.p);
+    l.nv = 7;
     l.src = static_cast<const float4 *>(icp->d_src.p);
     l.n = static_cast<int>(icp->n);
     l.chunks_per_block = 1;
