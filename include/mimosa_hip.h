@@ -544,6 +544,58 @@ int mh_icp_linearize_finish_device(mh_icp * icp, const double * d_global_sums32,
  * the degeneracy branch (geometric_factor.hpp:405-428, 464-557) — applied once, to the global sums. */
 int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out);
 
+/* ---- native map-sharded factor: the exchange inside the library (RCCL over xGMI) ------------------------------------
+ * No reference counterpart (the reference is single-process): what it must preserve is that the sharded factor equals
+ * ICPFactor::linearize (include/mimosa/lidar/geometric_factor.hpp:231-562) point for point.  Same partition as above
+ * (shard blocks by XORVector3iHash, include/mimosa/lidar/utils.hpp:228-238; one-voxel halo stored by mh_map_insert_shard).
+ * One process per GPU; a linearize is ONE chain of enqueues — route kernels, ncclAllToAll of fixed-size per-peer segments
+ * [count | records], append, K3, ncclAllReduce of the Hessian sums, (K4 + ncclAllReduce when the components are on), publish —
+ * and one wait at its end: no count ever crosses the host, the factor's slot count lives on the device.  A segment that
+ * was too small (every rank reads the same maxima from the all-reduce vector) makes every rank repeat the call with larger
+ * segments.  With world == 1 and force_collectives == 0 the call is mh_icp_linearize.  librccl is resolved at run time
+ * (dlopen; a copy already in the process, e.g. PyTorch's, is used; MH_RCCL_LIB overrides). */
+typedef struct mh_shard_comm mh_shard_comm;
+typedef struct mh_shard_icp mh_shard_icp;
+#define MH_SHARD_UNIQUE_ID_BYTES 128
+typedef struct mh_shard_config {
+  int32_t block_log2;        /* shard blocks of 2^block_log2 voxels per axis (the map must have been built with the same value) */
+  int32_t force_collectives; /* run the full exchange protocol even with one rank (tests, overhead measurement) */
+} mh_shard_config;
+typedef struct mh_shard_stats {
+  uint64_t n_live, n_slots, slot_capacity, n_total; /* points held; slots in use incl. tombstones; capacity; points of all ranks */
+  uint32_t segment_records;   /* per-peer segment capacity the next call will use */
+  uint32_t last_max_movers;   /* max over ranks and destinations of the points that wanted to move in the last call */
+  uint32_t retries_total, retries_last, compactions_total;
+  uint32_t collectives_last;  /* collectives the last call entered */
+  int32_t world, rank, collective, linearize_count;
+} mh_shard_stats;
+/* ncclGetUniqueId: one rank creates it, the caller hands it to the others (any channel: a file, MPI, torch.distributed). */
+int mh_shard_unique_id(void * id128);
+/* ncclCommInitRank on ctx's device; collective over all ranks. */
+int mh_shard_comm_init_rccl(mh_ctx * ctx, const void * id128, int world, int rank, mh_shard_comm ** out);
+/* Test transport: `world` ranks inside ONE process (one host thread per rank, all on one device); out_array[world]. */
+int mh_shard_comm_init_local(int world, mh_shard_comm ** out_array);
+void mh_shard_comm_destroy(mh_shard_comm * comm);
+int mh_shard_comm_world(const mh_shard_comm * comm);
+int mh_shard_comm_rank(const mh_shard_comm * comm);
+const char * mh_shard_comm_backend(const mh_shard_comm * comm); /* "rccl" | "local" */
+/* ICPFactor ctor (geometric_factor.hpp:119-142) for this rank's share of the scan (any split; the first linearize routes
+ * every point to the owner of its centre voxel).  points: host buffer, or device buffer when points_on_device != 0.
+ * shard_map: this rank's shard (mh_map_insert_shard with the same world / rank / block_log2).  Collective. */
+int mh_shard_icp_create(mh_ctx * ctx, mh_shard_comm * comm, mh_map * shard_map, const mh_point32 * points, size_t n_local,
+                        int points_on_device, const mh_reg_config * cfg, int is_binary, const mh_shard_config * scfg, mh_shard_icp ** out);
+/* ICPFactor::linearize of the WHOLE scan against the WHOLE map: every rank gets the same global result (H, b, f,
+ * localizabilities, degeneracy info; 4-DoF / degeneracy projection applied once, on the global sums).  Collective; blocks. */
+int mh_shard_icp_linearize(mh_shard_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                           const double * t_tgt, const double g_unit[3], mh_icp_result * out);
+int mh_shard_icp_reset(mh_shard_icp * icp);                       /* as mh_icp_reset; points stay where they are */
+int mh_shard_icp_set_components(mh_shard_icp * icp, int enabled); /* as mh_icp_set_components; must agree on all ranks */
+/* Per-point state of the points this rank holds now (origin = first rank << 32 | index there); n_out alone may be asked for. */
+int mh_shard_icp_get_state(mh_shard_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals,
+                           size_t capacity, size_t * n_out);
+int mh_shard_icp_stats(const mh_shard_icp * icp, mh_shard_stats * out);
+void mh_shard_icp_destroy(mh_shard_icp * icp);
+
 #ifdef __cplusplus
 }
 #endif

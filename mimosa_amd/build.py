@@ -27,6 +27,7 @@ SOURCES = [
     ("map_kernels.hip", ["-ffp-contract=off"]),
     ("map_api.hip", []),
     ("shard_kernels.hip", []),
+    ("shard_api.hip", []),
     ("photo_kernels.hip", ["-ffp-contract=off"]),
     ("photo_api.hip", []),
 ]
@@ -87,24 +88,48 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         return _build_locked(force, verbose, timeline)
 
 
+def _deps_of(depfile: str) -> list[str] | None:
+    """Prerequisites recorded by the compiler (-MMD) at the last build of an object; None when there is no record."""
+    try:
+        txt = open(depfile).read()
+    except OSError:
+        return None
+    txt = txt.replace("\\\n", " ")
+    if ":" not in txt:
+        return None
+    return [d for d in txt.split(":", 1)[1].split() if d]
+
+
 def _build_locked(force: bool, verbose: bool, timeline: bool) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build_timeline" if timeline else "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
+        d = o + ".d"
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra",
+        # an object is rebuilt when one of the files the compiler actually read for it changed (its -MMD record); without
+        # a record, when the source or any header of the package changed
+        deps = _deps_of(d)
+        if deps is not None and not all(os.path.exists(x) for x in deps):
+            deps = None
+        if force or _stale(o, deps if deps is not None else [s] + hdrs):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-MMD", "-MF", d,
                    "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] + (["-DMH_BALANCE"] if os.environ.get("MH_BALANCE") else []) if timeline else []), "-c", s, "-o", o]
-            _run_to(cmd, o, verbose)
+            jobs.append((cmd, o))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for f in [ex.submit(_run_to, cmd, o, verbose) for cmd, o in jobs]:
+                f.result()
     lib = LIB.replace(".so", "_timeline.so") if timeline else LIB
     if force or _stale(lib, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"]
         _run_to(cmd, lib, verbose)
     return lib
 

@@ -29,6 +29,9 @@ EXPORTS = [
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
+    "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
+    "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
+    "mh_shard_icp_stats", "mh_shard_icp_destroy",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
     "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_linearize_async", "mh_photo_factor_wait", "mh_photo_factor_get_state", "mh_photo_factor_size",
@@ -97,6 +100,23 @@ class IcpResult(C.Structure):
         for k in ("eigvec_trans", "eigvec_rot", "degen_eigvec_rot", "degen_eigvec_trans"):
             d[k] = d[k].reshape(3, 3)
         return d
+
+
+class ShardConfig(C.Structure):
+    _fields_ = [("block_log2", C.c_int32), ("force_collectives", C.c_int32)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("n_live", C.c_uint64), ("n_slots", C.c_uint64), ("slot_capacity", C.c_uint64), ("n_total", C.c_uint64),
+                ("segment_records", C.c_uint32), ("last_max_movers", C.c_uint32), ("retries_total", C.c_uint32), ("retries_last", C.c_uint32),
+                ("compactions_total", C.c_uint32), ("collectives_last", C.c_uint32),
+                ("world", C.c_int32), ("rank", C.c_int32), ("collective", C.c_int32), ("linearize_count", C.c_int32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+SHARD_UNIQUE_ID_BYTES = 128
 
 
 class InputConfig(C.Structure):
@@ -363,6 +383,23 @@ def load(build_if_missing: bool = True):
     L.mh_icp_linearize_begin_device.argtypes = [vp, vp, vp, vp, vp]
     L.mh_icp_linearize_finish_device.argtypes = [vp, vp, vp]
     L.mh_icp_global_epilogue.argtypes = [vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_shard_unique_id.argtypes = [vp]
+    L.mh_shard_comm_init_rccl.argtypes = [vp, vp, i32, i32, pvp]
+    L.mh_shard_comm_init_local.argtypes = [i32, pvp]
+    L.mh_shard_comm_destroy.argtypes = [vp]
+    L.mh_shard_comm_destroy.restype = None
+    L.mh_shard_comm_world.argtypes = [vp]
+    L.mh_shard_comm_rank.argtypes = [vp]
+    L.mh_shard_comm_backend.argtypes = [vp]
+    L.mh_shard_comm_backend.restype = C.c_char_p
+    L.mh_shard_icp_create.argtypes = [vp, vp, vp, vp, sz, i32, C.POINTER(RegConfig), i32, C.POINTER(ShardConfig), pvp]
+    L.mh_shard_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_shard_icp_reset.argtypes = [vp]
+    L.mh_shard_icp_set_components.argtypes = [vp, C.c_int]
+    L.mh_shard_icp_get_state.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.mh_shard_icp_stats.argtypes = [vp, C.POINTER(ShardStats)]
+    L.mh_shard_icp_destroy.argtypes = [vp]
+    L.mh_shard_icp_destroy.restype = None
     L.mh_photo_create.argtypes = [vp, C.POINTER(PhotoConfig), pvp]
     L.mh_photo_destroy.argtypes = [vp]
     L.mh_photo_destroy.restype = None
@@ -719,6 +756,124 @@ class ICPFactor:
             self.destroy()
         except Exception:
             pass
+
+
+class ShardComm:
+    """mh_shard_comm: the communicator of the native map-sharded factor.  rccl(): one process per GPU, the 128-byte
+    ncclUniqueId travels through whatever channel the caller has (torch.distributed in bench.py); local(): `world` ranks inside
+    this process, one host thread each (tests on a one-GPU box)."""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = load()
+        buf = C.create_string_buffer(SHARD_UNIQUE_ID_BYTES)
+        rc = L.mh_shard_unique_id(buf)
+        if rc != MH_OK:
+            raise MhError(rc, (L.mh_last_error(None) or b"").decode())
+        return buf.raw
+
+    @staticmethod
+    def rccl(ctx: "Context", unique_id: bytes, world: int, rank: int) -> "ShardComm":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), SHARD_UNIQUE_ID_BYTES)
+        ctx.check(ctx.L.mh_shard_comm_init_rccl(ctx.h, buf, world, rank, C.byref(h)))
+        return ShardComm(ctx.L, h)
+
+    @staticmethod
+    def local(world: int) -> list:
+        L = load()
+        arr = (C.c_void_p * world)()
+        rc = L.mh_shard_comm_init_local(world, arr)
+        if rc != MH_OK:
+            raise MhError(rc, (L.mh_last_error(None) or b"").decode())
+        return [ShardComm(L, C.c_void_p(arr[r])) for r in range(world)]
+
+    @property
+    def world(self):
+        return int(self.L.mh_shard_comm_world(self.h))
+
+    @property
+    def rank(self):
+        return int(self.L.mh_shard_comm_rank(self.h))
+
+    @property
+    def backend(self):
+        return self.L.mh_shard_comm_backend(self.h).decode()
+
+    def destroy(self):
+        if self.h:
+            self.L.mh_shard_comm_destroy(self.h)
+            self.h = None
+
+
+class ShardedICPFactor:
+    """mh_shard_icp: this rank's part of a scan-to-map factor whose map is sharded across GPUs; linearize() is collective
+    and returns the GLOBAL result on every rank."""
+
+    def __init__(self, ctx: Context, comm: ShardComm, shard_map: VoxelMap, pts, cfg: RegConfig, binary=False, block_log2=3, force_collectives=False,
+                 d_points_ptr=None, n_device=0):
+        self.ctx, self.L, self.comm, self.map = ctx, ctx.L, comm, shard_map
+        ctx._children += 1
+        sc = ShardConfig(block_log2, int(bool(force_collectives)))
+        h = C.c_void_p()
+        if d_points_ptr is not None:
+            ctx.check(self.L.mh_shard_icp_create(ctx.h, comm.h, shard_map.h, C.c_void_p(d_points_ptr), n_device, 1, C.byref(cfg), int(binary), C.byref(sc), C.byref(h)))
+        else:
+            pts = np.ascontiguousarray(pts)
+            assert pts.dtype.itemsize == 32
+            ctx.check(self.L.mh_shard_icp_create(ctx.h, comm.h, shard_map.h, _p(pts), len(pts), 0, C.byref(cfg), int(binary), C.byref(sc), C.byref(h)))
+        self.h = h
+
+    def linearize(self, R, t, g_unit=(0.0, 0.0, -1.0), R_tgt=None, t_tgt=None) -> dict:
+        out = IcpResult()
+        R, t, g = _f64(R), _f64(t), _f64(g_unit)
+        Rt = _f64(R_tgt) if R_tgt is not None else None
+        tt = _f64(t_tgt) if t_tgt is not None else None
+        self.ctx.check(self.L.mh_shard_icp_linearize(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
+        return out.as_dict()
+
+    def reset(self):
+        self.ctx.check(self.L.mh_shard_icp_reset(self.h))
+
+    def set_components(self, enabled: bool):
+        self.ctx.check(self.L.mh_shard_icp_set_components(self.h, int(bool(enabled))))
+
+    def stats(self) -> dict:
+        s = ShardStats()
+        self.ctx.check(self.L.mh_shard_icp_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def state(self):
+        """(origin, status, mean, normal) of the points this rank holds now."""
+        n = C.c_size_t()
+        self.ctx.check(self.L.mh_shard_icp_get_state(self.h, None, None, None, None, 0, C.byref(n)))
+        n = int(n.value)
+        origin, st = np.empty(n, np.uint64), np.empty(n, np.int32)
+        mean, nrm = np.empty((n, 3)), np.empty((n, 3))
+        m = C.c_size_t()
+        self.ctx.check(self.L.mh_shard_icp_get_state(self.h, _p(origin), _p(st), _p(mean), _p(nrm), n, C.byref(m)))
+        assert int(m.value) == n
+        return origin, st, mean, nrm
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.mh_shard_icp_destroy(self.h)
+            self.h = None
+            self.ctx._child_released()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def map_insert_shard(ctx: Context, vmap: VoxelMap, xyz, world: int, rank: int, block_log2: int = 3):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    ctx.check(ctx.L.mh_map_insert_shard(vmap.h, _p(xyz), len(xyz), 3, world, rank, block_log2))
 
 
 class _PhotoBase:

@@ -58,7 +58,13 @@ struct IcpArgs
   unsigned int seq;          // != 0: no K4 follows (components switched off) — the last block publishes the completion number itself
   unsigned long long * dbg;  // MH_TIMELINE diagnostic build only, else null
   int reps;                  // MH_TIMELINE only: repeat the per-point section (warm-cache experiment)
+  // map-sharded factors (shard_api.hip): the number of point slots lives on the device (arrivals are appended by a
+  // kernel of the same stream, the host only knows an upper bound `n` that sizes the grid); slots whose status carries
+  // kShardSkip (points that left for another rank, or could not be sent yet) are passed over untouched
+  const uint32_t * n_dev = nullptr;    // null: n is exact
+  double * shard_out = nullptr;        // non-null: the last block also writes the NENT sums + 4 counters here (all-reduce input)
 };
+constexpr int32_t kShardSkip = 0x100;  // status flag bit: not this rank's point in this call
 
 struct LocArgs
 {
@@ -75,6 +81,9 @@ struct LocArgs
   double * partials;
   unsigned int * ticket;
   DeviceResult * result;
+  const uint32_t * n_dev = nullptr;  // as IcpArgs::n_dev
+  const double * sums = nullptr;     // null: result->sums; map-sharded factors: the all-reduced (global) Hessian sums
+  double * shard_out = nullptr;      // non-null: the last block also writes 6 component sums + 9 histogram counts here (16 doubles)
 };
 
 int linearize_grid(int n);

@@ -891,7 +891,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   for (int j = 0; j < NV; ++j) row[j] = 0.0;
 
   const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
-  if (qi < a.n) {
+  const int n_pts = a.n_dev ? static_cast<int>(*a.n_dev) : a.n;
+  if (qi < n_pts) {
     const float4 sp = a.src[qi];
     const double px = sp.x, py = sp.y, pz = sp.z;
     // 1. q = R p + t (geometric_factor.hpp:276-277)
@@ -909,8 +910,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       qd2 = a.q_da[3 * qi + 2];
       st = a.status[qi];
     }
+    const bool gone = (st & kShardSkip) != 0;  // map-sharded factors only: another rank's point in this call
     const double ddx = q0 - qd0, ddy = q1 - qd1, ddz = q2 - qd2;
-    const bool update = sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
+    const bool update = !gone && sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
 
     double mean[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
     bool go = false;
@@ -1031,7 +1033,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       }
     } else {
       // :308-317 — reuse the cached plane only if the previous pass got past the plane gates
-      if (st > MH_CORRES_PLANE_INVALID) {
+      if (!gone && st > MH_CORRES_PLANE_INVALID) {
         mean[0] = a.mean[3 * qi + 0];
         mean[1] = a.mean[3 * qi + 1];
         mean[2] = a.mean[3 * qi + 2];
@@ -1086,7 +1088,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         st = MH_VALID;
       }
     }
-    a.status[qi] = st;
+    if (!gone) a.status[qi] = st;
   }
   {
     // k-NN counters: one LDS atomic per wave and counter (uniform control flow: every lane is active here)
@@ -1174,6 +1176,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
   if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
   if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
+  if (a.shard_out && threadIdx.x < NENT + 4) a.shard_out[threadIdx.x] = s_sum[threadIdx.x];  // what the shards all-reduce
   // computeLocalizability of the rot / trans 3 x 3 blocks (:405-411) is NOT done here: two eigen-decompositions on one lane
   // each cost 2.3 us of this serial tail while 255 CUs idle.  K4's workgroups derive the eigenbases they need from
   // result->sums themselves (behind their per-point loads), the host epilogue derives the ones it reports (finish_result).
@@ -1275,11 +1278,12 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // The first chunk's status, point and normal are requested first: one memory round trip, in flight while the
   // eigenbases below are worked out (the pass is a handful of round trips long, nothing else).
+  const int n_pts = a.n_dev ? static_cast<int>(*a.n_dev) : a.n;
   const int i_first = block_id * a.chunks_per_block * TPB + static_cast<int>(threadIdx.x);
-  const int i_ld = i_first < a.n ? i_first : 0;
-  int st_next = a.n > 0 ? a.status[i_ld] : -1;
-  float4 sp_next = a.n > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
-  double n0_next = a.n > 0 ? a.normal[3 * i_ld] : 0.0, n1_next = a.n > 0 ? a.normal[3 * i_ld + 1] : 0.0, n2_next = a.n > 0 ? a.normal[3 * i_ld + 2] : 0.0;
+  const int i_ld = i_first < n_pts ? i_first : 0;
+  int st_next = n_pts > 0 ? a.status[i_ld] : -1;
+  float4 sp_next = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
+  double n0_next = n_pts > 0 ? a.normal[3 * i_ld] : 0.0, n1_next = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0, n2_next = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
   // The two eigenbases: given (map-sharded factors: the basis of the GLOBAL Hessian), or derived here from the Hessian sums
   // K3's last block left in result->sums — one lane per 3 x 3 block (computeLocalizability, utils.hpp:308-313), every
   // workgroup for itself.  (In K3's serial tail they cost 2.3 us with 255 CUs idle.)
@@ -1288,11 +1292,12 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     if (threadIdx.x < 18) s_E[threadIdx.x] = a.eig[threadIdx.x];
   } else if (threadIdx.x == 0 || threadIdx.x == 64) {
     const int NV = a.nv, o = threadIdx.x ? 3 : 0;
+    const double * sums = a.sums ? a.sums : a.result->sums;
     double Hb[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
         const int rr = (r < c ? r : c) + o, cc = (r < c ? c : r) + o;
-        Hb[3 * r + c] = a.result->sums[rr * NV - rr * (rr - 1) / 2 + (cc - rr)];
+        Hb[3 * r + c] = sums[rr * NV - rr * (rr - 1) / 2 + (cc - rr)];
       }
     double loc[3], E[9];
     compute_localizability(Hb, loc, E);
@@ -1310,7 +1315,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   for (int ch = 0; ch < a.chunks_per_block; ++ch) {
   const int i = (block_id * a.chunks_per_block + ch) * TPB + threadIdx.x;
   int st = -1;
-  if (i < a.n) {
+  if (i < n_pts) {
     float4 sp;
     double n0, n1, n2;
     if (ch == 0) {
@@ -1373,6 +1378,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
+  if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
   // this kernel's outputs also go to the caller's mapped pinned host slot, straight from the LDS sums (K3's
   // last block already wrote its part there); the end of the kernel makes them visible to the host
   if (a.host_result) {

@@ -26,51 +26,6 @@
 #include "shard_device.hpp"
 #include "voxel_map.hpp"
 
-struct PendingCall
-{
-  mh_icp_result * out;
-  double R[9];     // delta rotation (for reg_4_dof's local_z)
-  double gz[3];    // global_z = -g_unit
-  int parity;
-  int linearize_count;
-  unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
-  bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
-  hipEvent_t ev[3];
-};
-
-struct mh_icp
-{
-  mh_ctx * ctx;
-  mh_map * map;
-  size_t n;
-  mh_reg_config cfg;
-  bool binary;
-  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm, d_eig;
-  bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
-  double split_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // delta rotation of an open mh_icp_linearize_begin
-  bool split_open = false;
-  mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly
-  mh::DeviceResult * d_h_results = nullptr;  // its device-side address
-  PendingCall pending[kMaxPending];
-  int n_pending = 0;
-  int parity = 0;
-  bool cold = true;
-  bool components = true;  // mh_icp_set_components: run K4 (component localizabilities + status histogram) in every linearize
-  int linearize_count = 0;
-  hipEvent_t events[kMaxPending][3];
-  bool events_ready = false;
-  unsigned int seq_counter = 0;
-  // map-sharded use (mh_icp_shard_*): points migrate between ranks with their association state
-  bool no_order = false;  // keep the caller's point order (no Morton re-ordering)
-  DevBuf d_origin, x_src, x_qda, x_mean, x_normal, x_status, x_origin;  // origin ids; the second set of arrays pack compacts into
-  DevBuf s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_counts, s_temp, d_sums;
-  uint32_t * h_counts = nullptr;  // pinned
-  bool origin_ready = false, plan_open = false;
-  uint32_t n_movers = 0;
-  int shard_world = 0, shard_rank = 0, shard_log2 = 3;
-  bool dev_split_open = false;
-};
-
 namespace
 {
 void pose_inverse_compose(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t)
@@ -339,7 +294,8 @@ extern "C" {
 static int icp_alloc(mh_icp * icp)
 {
   mh_ctx * ctx = icp->ctx;
-  const size_t n = icp->n ? icp->n : 1;
+  const size_t nn = icp->cap_n > icp->n ? icp->cap_n : icp->n;  // map-sharded factors reserve room for arrivals
+  const size_t n = nn ? nn : 1;
   MH_HIP(ctx, icp->d_src.reserve(n * sizeof(float4), ctx->stream, false));
   MH_HIP(ctx, icp->d_qda.reserve(n * 3 * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, icp->d_mean.reserve(n * 3 * sizeof(double), ctx->stream, false));
@@ -418,7 +374,7 @@ static int icp_init_source(mh_icp * icp, const mh_point32 * source, const mh_poi
 
 // source: host cloud (d_source == nullptr) or a cloud already on the device (source == nullptr)
 static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_point32 * d_source, size_t n,
-                             const mh_reg_config * cfg, int is_binary, mh_icp ** out, bool no_order = false)
+                             const mh_reg_config * cfg, int is_binary, mh_icp ** out, bool no_order = false, size_t capacity = 0)
 {
   *out = nullptr;
   // A map may be shared read-only by factors of several contexts (= HIP streams) of the SAME device:
@@ -437,6 +393,7 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   icp->cfg = *cfg;
   icp->binary = is_binary != 0;
   icp->no_order = no_order;
+  icp->cap_n = capacity > n ? capacity : n;
   int rc = icp_alloc(icp);
   if (rc != MH_OK) {
     mh_icp_destroy(icp);
@@ -1709,3 +1666,24 @@ int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double l
 }
 
 }  // extern "C"
+
+// ---- internals shared with shard_api.hip (declared in mh_internal.hpp) ---------------------------------------------
+namespace mhi
+{
+void pose_delta(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t)
+{
+  pose_inverse_compose(Rs, ts, Rt, tt, R, t);
+}
+void finish(const mh_icp * icp, const mh::DeviceResult & d, const PendingCall & pc, mh_icp_result * out) { finish_result(icp, d, pc, out); }
+int icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_point32 * d_source, size_t n, size_t capacity,
+               const mh_reg_config * cfg, int is_binary, mh_icp ** out, bool no_order)
+{
+  return icp_create_common(ctx, map, source, d_source, n, cfg, is_binary, out, no_order, capacity);
+}
+int prepare(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, const double g_unit[3],
+            mh_icp_result * out, bool want_flag, mh::IcpArgs & a, mh::LocArgs & l)
+{
+  bool timed = false;
+  return linearize_prepare(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, want_flag, false, a, l, timed);
+}
+}  // namespace mhi

@@ -341,3 +341,62 @@ inline mh::MapView map_view(const mh_map * m)
   v.mode_idx = m->n_off == 1 ? 0 : (m->n_off == 7 ? 1 : (m->n_off == 19 ? 2 : 3));
   return v;
 }
+
+// ---- ICP factor handle (mh_api.hip; shared with shard_api.hip) --------------------------------------------------
+struct PendingCall
+{
+  mh_icp_result * out;
+  double R[9];     // delta rotation (for reg_4_dof's local_z)
+  double gz[3];    // global_z = -g_unit
+  int parity;
+  int linearize_count;
+  unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
+  bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
+  hipEvent_t ev[3];
+};
+
+struct mh_icp
+{
+  mh_ctx * ctx;
+  mh_map * map;
+  size_t n;
+  mh_reg_config cfg;
+  bool binary;
+  DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm, d_eig;
+  bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
+  double split_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // delta rotation of an open mh_icp_linearize_begin
+  bool split_open = false;
+  mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly
+  mh::DeviceResult * d_h_results = nullptr;  // its device-side address
+  PendingCall pending[kMaxPending];
+  int n_pending = 0;
+  int parity = 0;
+  bool cold = true;
+  bool components = true;  // mh_icp_set_components: run K4 (component localizabilities + status histogram) in every linearize
+  int linearize_count = 0;
+  hipEvent_t events[kMaxPending][3];
+  bool events_ready = false;
+  unsigned int seq_counter = 0;
+  // map-sharded use (mh_icp_shard_*): points migrate between ranks with their association state
+  bool no_order = false;  // keep the caller's point order (no Morton re-ordering)
+  size_t cap_n = 0;       // per-point arrays are sized for this many points (>= n): room for arrivals of the sharded path
+  DevBuf d_origin, x_src, x_qda, x_mean, x_normal, x_status, x_origin;  // origin ids; the second set of arrays pack compacts into
+  DevBuf s_keys_a, s_keys_b, s_idx_a, s_idx_b, s_counts, s_temp, d_sums;
+  uint32_t * h_counts = nullptr;  // pinned
+  bool origin_ready = false, plan_open = false;
+  uint32_t n_movers = 0;
+  int shard_world = 0, shard_rank = 0, shard_log2 = 3;
+  bool dev_split_open = false;
+};
+
+// mh_api.hip internals used by shard_api.hip
+namespace mhi
+{
+void pose_delta(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t);
+void finish(const mh_icp * icp, const mh::DeviceResult & d, const PendingCall & pc, mh_icp_result * out);
+int icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_point32 * d_source, size_t n, size_t capacity,
+               const mh_reg_config * cfg, int is_binary, mh_icp ** out, bool no_order);
+// argument blocks of one linearize call in pending slot n_pending (claimed); no launch
+int prepare(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, const double g_unit[3],
+            mh_icp_result * out, bool want_flag, mh::IcpArgs & a, mh::LocArgs & l);
+}  // namespace mhi

@@ -36,6 +36,56 @@ struct ShardRecord
 };
 static_assert(sizeof(ShardRecord) == 112, "ShardRecord layout");
 
+// ---- native sharded factor (shard_api.hip): slots, tombstones, fixed-capacity exchange ------------------------------
+// A sharded factor's per-point arrays are SLOTS: a point that leaves for another rank becomes a tombstone (origin == kShardTomb,
+// status == -1, which carries kShardSkip), arrivals are appended behind the last slot.  Nothing about the exchange is
+// known to the host in advance: every rank sends every peer one fixed-size segment — a 16-byte header with the record
+// count, then up to `cap` records — so the collective needs no counts, and the slot count of the factor lives on the
+// device (ping-pong entries: the kernels of call c read [c & 1] and write [(c + 1) & 1]).
+constexpr unsigned long long kShardTomb = ~0ull;
+constexpr int kShardMaxWorld = 64;
+constexpr int kShardSums = 104;                          // all-reduce vector: 95 sums / counters of a binary factor, padded
+constexpr int kShardArLen = kShardSums + kShardMaxWorld;  // ... + one slot per rank (each rank fills its own): max movers per destination
+struct ShardState
+{
+  uint32_t n_slots[2];  // slots in use, tombstones included
+  uint32_t n_live[2];   // points this rank holds
+  uint32_t sent_total;  // records that left in the current call
+  uint32_t max_total;   // max over destinations of the points that WANT to leave (may exceed the segment capacity)
+  uint32_t error;       // bit 0: arrivals beyond the slot capacity were dropped
+  uint32_t pad;
+};
+struct ShardHdr
+{
+  uint32_t sent, total, pad0, pad1;  // records in this segment; points bound for this peer (> sent: capacity overflow)
+};
+static_assert(sizeof(ShardHdr) == 16, "segment header");
+// what the last kernel of a collective call leaves in mapped pinned host memory
+struct ShardPublish
+{
+  double ar[kShardArLen];  // all-reduced sums, counters, per-rank mover maxima
+  double loc[16];          // all-reduced component localizabilities + status histogram
+  uint32_t n_slots, n_live, error, max_total;
+  uint32_t seq, pad[3];
+};
+__host__ __device__ inline size_t shard_segment_bytes(uint32_t cap) { return sizeof(ShardHdr) + static_cast<size_t>(cap) * 112; }
+
+hipError_t launch_shard_state_init(ShardState * st, uint32_t n, hipStream_t stream);
+// owner of every live slot at this pose -> dest[] (0xFF: stays / tombstone), per-block per-destination counts; then the
+// movers' records into the per-peer segments in slot order (stable), tombstones behind them; the last block writes the
+// segment headers, the state's sent / max counters and this rank's slot of the all-reduce vector
+hipError_t launch_shard_route(const ShardPose & P, const ShardArrays & a, ShardState * st, int cur, uint32_t n_bound, double inv_leaf, uint32_t world,
+                              uint32_t rank, int log2, uint8_t * dest, uint32_t * hist, uint32_t cap, char * send, double * ar_slots, hipStream_t stream);
+// arrivals of all peers appended behind the last slot, in (peer, record) order; writes the next ping-pong entries
+hipError_t launch_shard_append(const ShardArrays & a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv, uint32_t slot_capacity,
+                               hipStream_t stream);
+// stable compaction of the live slots into `out` (tombstones dropped); both ping-pong entries become n_live
+hipError_t launch_shard_compact(const ShardArrays & in, const ShardArrays & out, ShardState * st, int cur, uint32_t n_bound, uint32_t * flags, uint32_t * pos,
+                                void * temp, size_t temp_bytes, hipStream_t stream);
+// forget every data association (== freshly constructed factor state) of the points held; tombstones stay
+hipError_t launch_shard_reset(const ShardArrays & a, const ShardState * st, int cur, uint32_t n_bound, hipStream_t stream);
+hipError_t launch_shard_publish(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq, hipStream_t stream);
+
 size_t shard_temp_bytes(size_t n);
 hipError_t launch_shard_filter(const float * xyz, uint32_t n, uint32_t stride, double inv_leaf, uint32_t world, uint32_t rank, int log2,
                                uint32_t * flags, uint32_t * pos, float * out, uint32_t * n_out, void * temp, size_t temp_bytes, hipStream_t stream);

@@ -166,7 +166,268 @@ __global__ void shard_pack_loc_kernel(const DeviceResult * r, double * out16)
   if (i >= 6 && i < 15) out16[i] = static_cast<double>(r->status_hist[i - 6]);
   if (i == 15) out16[15] = 0.0;
 }
+
+// ---- native sharded factor: slots, tombstones, fixed-capacity segments (shard_device.hpp) ----------------------------
+__global__ void shard_state_init_kernel(ShardState * st, uint32_t n)
+{
+  if (threadIdx.x == 0) {
+    st->n_slots[0] = st->n_slots[1] = n;
+    st->n_live[0] = st->n_live[1] = n;
+    st->sent_total = st->max_total = st->error = st->pad = 0u;
+  }
+}
+
+// Pass 1 of the routing: destination of every live slot (0xFF: stays, tombstone or past the end) and the block's count
+// per destination.  A slot that could not be sent in the previous call (segment overflow) loses its skip flag here and is
+// looked at afresh.
+__global__ __launch_bounds__(kT) void shard_route_count_kernel(const ShardPose P, const ShardArrays a, const ShardState * st, int cur, double inv_leaf,
+                                                                uint32_t world, uint32_t rank, int log2, uint8_t * dest, uint32_t * hist)
+{
+  __shared__ uint32_t s_h[kShardMaxWorld];
+  if (threadIdx.x < kShardMaxWorld) s_h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t n = st->n_slots[cur];
+  const uint32_t i = blockIdx.x * kT + threadIdx.x;
+  uint32_t d = 0xFFu;
+  if (i < n && a.origin[i] != kShardTomb) {
+    const int32_t s = a.status[i];
+    if (s & kShardSkip) a.status[i] = s & ~kShardSkip;
+    const float4 sp = a.src[i];
+    const double px = sp.x, py = sp.y, pz = sp.z;
+    const double q0 = (P.R[0] * px + (P.R[1] * py + P.R[2] * pz)) + P.t[0];
+    const double q1 = (P.R[3] * px + (P.R[4] * py + P.R[5] * pz)) + P.t[1];
+    const double q2 = (P.R[6] * px + (P.R[7] * py + P.R[8] * pz)) + P.t[2];
+    const uint32_t o = owner_of_block(fast_floor(q0 * inv_leaf) >> log2, fast_floor(q1 * inv_leaf) >> log2, fast_floor(q2 * inv_leaf) >> log2, world);
+    if (o != rank) {
+      d = o;
+      atomicAdd(&s_h[o], 1u);
+    }
+  }
+  dest[i] = static_cast<uint8_t>(d);
+  __syncthreads();
+  if (threadIdx.x < world) hist[static_cast<size_t>(blockIdx.x) * world + threadIdx.x] = s_h[threadIdx.x];
+}
+
+// Pass 2: position of every mover inside its destination's segment = movers of earlier blocks + earlier movers of this
+// block (slot order: stable, so the arrival order — and with it every sum — is reproducible run to run).
+__global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardArrays a, ShardState * st, uint32_t world, uint32_t rank, const uint8_t * dest,
+                                                               const uint32_t * hist, uint32_t cap, char * send, double * ar_slots)
+{
+  constexpr int NW = kT / 64;
+  __shared__ uint32_t s_base[kShardMaxWorld];
+  __shared__ uint32_t s_wc[NW][kShardMaxWorld];
+  if (threadIdx.x < kShardMaxWorld) {
+    s_base[threadIdx.x] = 0u;
+    for (int w = 0; w < NW; ++w) s_wc[w][threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kT)
+    for (uint32_t d = 0; d < world; ++d) {
+      const uint32_t c = hist[static_cast<size_t>(b) * world + d];
+      if (c) atomicAdd(&s_base[d], c);
+    }
+  const uint32_t i = blockIdx.x * kT + threadIdx.x;
+  const uint32_t d = dest[i];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t my_rank = 0u;
+  {
+    unsigned long long todo = __ballot(d != 0xFFu);
+    while (todo) {
+      const int l0 = __builtin_ctzll(todo);
+      const uint32_t d0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(d), l0));
+      const unsigned long long m = __ballot(d == d0);
+      if (d == d0) my_rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+      if (static_cast<int>(lane) == l0) s_wc[wv][d0] = static_cast<uint32_t>(__popcll(m));
+      todo &= ~m;
+    }
+  }
+  __syncthreads();
+  if (d != 0xFFu) {
+    uint32_t pos = s_base[d] + my_rank;
+    for (uint32_t w = 0; w < wv; ++w) pos += s_wc[w][d];
+    if (pos < cap) {
+      ShardRecord r;
+      r.src = a.src[i];
+      for (int k = 0; k < 3; ++k) {
+        r.q_da[k] = a.q_da[3 * static_cast<size_t>(i) + k];
+        r.mean[k] = a.mean[3 * static_cast<size_t>(i) + k];
+        r.normal[k] = a.normal[3 * static_cast<size_t>(i) + k];
+      }
+      r.status = a.status[i];
+      r.pad = 0;
+      r.origin = a.origin[i];
+      *reinterpret_cast<ShardRecord *>(send + static_cast<size_t>(d) * shard_segment_bytes(cap) + sizeof(ShardHdr) + static_cast<size_t>(pos) * sizeof(ShardRecord)) = r;
+      a.origin[i] = kShardTomb;
+      a.status[i] = -1;  // carries kShardSkip
+    } else {
+      a.status[i] |= kShardSkip;  // the segment is full: stays here unprocessed, the caller repeats the call with larger segments
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    __syncthreads();
+    __shared__ uint32_t s_tot[kShardMaxWorld];
+    if (threadIdx.x < kShardMaxWorld) {
+      uint32_t t = 0u;
+      if (threadIdx.x < world) {
+        t = s_base[threadIdx.x];
+        for (int w = 0; w < NW; ++w) t += s_wc[w][threadIdx.x];
+        ShardHdr h;
+        h.sent = t < cap ? t : cap;
+        h.total = t;
+        h.pad0 = h.pad1 = 0u;
+        *reinterpret_cast<ShardHdr *>(send + static_cast<size_t>(threadIdx.x) * shard_segment_bytes(cap)) = h;
+      }
+      s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t sent = 0u, mx = 0u;
+      for (uint32_t r = 0; r < world; ++r) {
+        sent += s_tot[r] < cap ? s_tot[r] : cap;
+        mx = s_tot[r] > mx ? s_tot[r] : mx;
+      }
+      st->sent_total = sent;
+      st->max_total = mx;
+    }
+    if (threadIdx.x < kShardMaxWorld) {
+      uint32_t mx = 0u;
+      for (uint32_t r = 0; r < world; ++r) mx = s_tot[r] > mx ? s_tot[r] : mx;
+      ar_slots[threadIdx.x] = threadIdx.x == rank ? static_cast<double>(mx) : 0.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kT) void shard_append_kernel(const ShardArrays a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv,
+                                                           uint32_t slot_capacity)
+{
+  const size_t seg = shard_segment_bytes(cap);
+  const uint32_t t = blockIdx.x * kT + threadIdx.x;
+  const uint32_t peer = t / cap, j = t - peer * cap;
+  const uint32_t n0 = st->n_slots[cur];
+  if (peer < world) {
+    uint32_t before = 0u;
+    for (uint32_t p = 0; p < peer; ++p) before += reinterpret_cast<const ShardHdr *>(recv + p * seg)->sent;
+    const uint32_t cnt = reinterpret_cast<const ShardHdr *>(recv + peer * seg)->sent;
+    const size_t d = static_cast<size_t>(n0) + before + j;
+    if (j < cnt && d < slot_capacity) {
+      const ShardRecord r = *reinterpret_cast<const ShardRecord *>(recv + peer * seg + sizeof(ShardHdr) + static_cast<size_t>(j) * sizeof(ShardRecord));
+      a.src[d] = r.src;
+      for (int k = 0; k < 3; ++k) {
+        a.q_da[3 * d + k] = r.q_da[k];
+        a.mean[3 * d + k] = r.mean[k];
+        a.normal[3 * d + k] = r.normal[k];
+      }
+      a.status[d] = r.status;
+      a.origin[d] = r.origin;
+    }
+  }
+  if (t == 0) {
+    uint32_t total = 0u;
+    for (uint32_t p = 0; p < world; ++p) total += reinterpret_cast<const ShardHdr *>(recv + p * seg)->sent;
+    const uint32_t room = slot_capacity - n0;
+    const uint32_t taken = total < room ? total : room;
+    if (taken < total) st->error |= 1u;
+    st->n_slots[cur ^ 1] = n0 + taken;
+    st->n_live[cur ^ 1] = st->n_live[cur] - st->sent_total + taken;
+  }
+}
+
+__global__ __launch_bounds__(kT) void shard_live_flags_kernel(const ShardArrays a, const ShardState * st, int cur, uint32_t n_bound, uint32_t * flags)
+{
+  const uint32_t n = st->n_slots[cur];
+  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n_bound; i += gridDim.x * kT) flags[i] = (i < n && a.origin[i] != kShardTomb) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kT) void shard_compact_slots_kernel(const ShardArrays in, const ShardArrays out, ShardState * st, uint32_t n_bound, const uint32_t * flags,
+                                                                  const uint32_t * pos)
+{
+  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n_bound; i += gridDim.x * kT) {
+    if (flags[i]) {
+      const size_t d = pos[i];
+      out.src[d] = in.src[i];
+      for (int k = 0; k < 3; ++k) {
+        out.q_da[3 * d + k] = in.q_da[3 * static_cast<size_t>(i) + k];
+        out.mean[3 * d + k] = in.mean[3 * static_cast<size_t>(i) + k];
+        out.normal[3 * d + k] = in.normal[3 * static_cast<size_t>(i) + k];
+      }
+      out.status[d] = in.status[i];
+      out.origin[d] = in.origin[i];
+    }
+    if (i == n_bound - 1) {
+      const uint32_t live = pos[i] + flags[i];
+      st->n_slots[0] = st->n_slots[1] = live;
+      st->n_live[0] = st->n_live[1] = live;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kT) void shard_reset_kernel(const ShardArrays a, const ShardState * st, int cur, uint32_t n_bound)
+{
+  const uint32_t n = st->n_slots[cur];
+  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n_bound && i < n; i += gridDim.x * kT) {
+    if (a.origin[i] == kShardTomb) continue;
+    a.status[i] = 0;
+    for (int k = 0; k < 3; ++k) a.q_da[3 * static_cast<size_t>(i) + k] = a.mean[3 * static_cast<size_t>(i) + k] = a.normal[3 * static_cast<size_t>(i) + k] = 0.0;
+  }
+}
+
+__global__ void shard_publish_kernel(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq)
+{
+  const int t = threadIdx.x;
+  if (t < kShardArLen) host->ar[t] = ar[t];
+  if (t < 16) host->loc[t] = loc ? loc[t] : 0.0;
+  if (t == 0) {
+    host->n_slots = st->n_slots[next];
+    host->n_live = st->n_live[next];
+    host->error = st->error;
+    host->max_total = st->max_total;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 }  // namespace
+
+hipError_t launch_shard_state_init(ShardState * st, uint32_t n, hipStream_t stream)
+{
+  hipLaunchKernelGGL(shard_state_init_kernel, dim3(1), dim3(64), 0, stream, st, n);
+  return hipGetLastError();
+}
+hipError_t launch_shard_route(const ShardPose & P, const ShardArrays & a, ShardState * st, int cur, uint32_t n_bound, double inv_leaf, uint32_t world,
+                              uint32_t rank, int log2, uint8_t * dest, uint32_t * hist, uint32_t cap, char * send, double * ar_slots, hipStream_t stream)
+{
+  const uint32_t nblk = n_bound ? (n_bound + kT - 1) / kT : 1u;  // at least one block: the headers must be written
+  hipLaunchKernelGGL(shard_route_count_kernel, dim3(nblk), dim3(kT), 0, stream, P, a, st, cur, inv_leaf, world, rank, log2, dest, hist);
+  hipLaunchKernelGGL(shard_route_pack_kernel, dim3(nblk), dim3(kT), 0, stream, a, st, world, rank, dest, hist, cap, send, ar_slots);
+  return hipGetLastError();
+}
+hipError_t launch_shard_append(const ShardArrays & a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv, uint32_t slot_capacity,
+                               hipStream_t stream)
+{
+  const uint32_t threads = world * cap;
+  hipLaunchKernelGGL(shard_append_kernel, dim3((threads + kT - 1) / kT), dim3(kT), 0, stream, a, st, cur, world, cap, recv, slot_capacity);
+  return hipGetLastError();
+}
+hipError_t launch_shard_compact(const ShardArrays & in, const ShardArrays & out, ShardState * st, int cur, uint32_t n_bound, uint32_t * flags, uint32_t * pos,
+                                void * temp, size_t temp_bytes, hipStream_t stream)
+{
+  if (!n_bound) return hipSuccess;
+  hipLaunchKernelGGL(shard_live_flags_kernel, dim3(grid_for(n_bound)), dim3(kT), 0, stream, in, st, cur, n_bound, flags);
+  size_t tb = temp_bytes;
+  const hipError_t e = rocprim::exclusive_scan(temp, tb, flags, pos, 0u, static_cast<size_t>(n_bound), rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(shard_compact_slots_kernel, dim3(grid_for(n_bound)), dim3(kT), 0, stream, in, out, st, n_bound, flags, pos);
+  return hipGetLastError();
+}
+hipError_t launch_shard_reset(const ShardArrays & a, const ShardState * st, int cur, uint32_t n_bound, hipStream_t stream)
+{
+  if (n_bound) hipLaunchKernelGGL(shard_reset_kernel, dim3(grid_for(n_bound)), dim3(kT), 0, stream, a, st, cur, n_bound);
+  return hipGetLastError();
+}
+hipError_t launch_shard_publish(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq, hipStream_t stream)
+{
+  hipLaunchKernelGGL(shard_publish_kernel, dim3(1), dim3(192), 0, stream, ar, loc, st, next, host, seq);
+  return hipGetLastError();
+}
 
 size_t shard_temp_bytes(size_t n)
 {

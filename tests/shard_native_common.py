@@ -1,0 +1,127 @@
+"""Shared body of the native map-sharded factor tests (mh_shard_*): every rank builds its map shard with mh_map_insert_shard,
+takes a share of the scan, and linearizes over a pose sequence; every rank's GLOBAL result must equal the unsharded oracle
+and the state of the points it holds must equal the oracle's state of those points."""
+import threading
+
+import numpy as np
+
+POSE_STEPS = [
+    (np.zeros(3), np.array([0.004, 0.003, -0.002])),
+    (np.array([0.0, 0.0, 0.012]), np.array([0.06, -0.05, 0.02])),
+    (np.array([0.004, -0.003, 0.02]), np.array([-0.09, 0.11, 0.03])),
+    (np.zeros(3), np.zeros(3)),
+    (np.zeros(3), np.zeros(3)),
+]
+
+
+def default_case(cfg_over=None, binary=False):
+    from mimosa_amd import synth
+    room = np.array([20.0, 14.0, 3.0])
+    map_xyz = synth.make_room(4321, 0, 0, room=room)
+    scan, aux = synth.make_scan(n_rows=32, seed=99, n_cols=128, room=room, sensor_local=np.array([9.3, 6.6, 1.2]))
+    R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    cfg = dict(synth.enwide_config(), **(cfg_over or {}))
+    poses = [(R, t)]
+    for w, d in POSE_STEPS:
+        poses.append((poses[0][0] @ synth.so3_exp(w), poses[0][1] + d))
+    tgt = None
+    if binary:
+        Rt = synth.so3_exp(np.array([0.01, -0.02, 0.015]))
+        tt = np.array([0.2, -0.1, 0.05])
+        tgt = (Rt, tt)
+        poses = [(Rt @ Rk, Rt @ tk + tt) for Rk, tk in poses]   # delta = T_tgt^-1 T_src stays what the unary case uses
+    return dict(map_chunks=np.array_split(map_xyz, 3), scan=scan, cfg=cfg, poses=poses, tgt=tgt, binary=binary)
+
+
+def oracle_results(case):
+    """The unsharded oracle over the pose sequence: per pose (result, status, mean, normal)."""
+    from oracle import ref_cpu
+    M = ref_cpu.Map()
+    for c in case["map_chunks"]:
+        M.insert(c)
+    F = ref_cpu.ICP(M, case["scan"], ref_cpu.make_config(**case["cfg"]), binary=case["binary"]) if case["binary"] else ref_cpu.ICP(M, case["scan"], ref_cpu.make_config(**case["cfg"]))
+    out = []
+    for Rk, tk in case["poses"]:
+        res = F.linearize(Rk, tk, R_tgt=case["tgt"][0], t_tgt=case["tgt"][1]) if case["binary"] else F.linearize(Rk, tk)
+        rs, rm, rn, _ = F.da_state()
+        out.append((res, rs.copy(), rm.copy(), rn.copy()))
+    return out, M.num_points
+
+
+def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components_off_from=None, log=None):
+    """One rank of the native path over the whole pose sequence."""
+    from mimosa_amd import capi, synth
+    from parity import assert_result_parity, assert_state_parity
+    rank, world = comm.rank, comm.world
+    cfg = case["cfg"]
+    kw = dict(leaf=cfg["target_ivox_map_leaf_size"], min_dist=cfg["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+              mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    vmap = capi.VoxelMap(ctx, **kw)
+    for c in case["map_chunks"]:
+        capi.map_insert_shard(ctx, vmap, c, world, rank, block_log2)
+    f = capi.ShardedICPFactor(ctx, comm, vmap, case["scan"][split[rank]], capi.make_reg_config(**cfg), binary=case["binary"], block_log2=block_log2,
+                              force_collectives=force)
+    moved = []
+    for k, (Rk, tk) in enumerate(case["poses"]):
+        if components_off_from is not None and k == components_off_from:
+            f.set_components(False)
+        got = f.linearize(Rk, tk, R_tgt=case["tgt"][0], t_tgt=case["tgt"][1]) if case["binary"] else f.linearize(Rk, tk)
+        ref = refs[k][0]
+        if components_off_from is not None and k >= components_off_from:
+            assert np.all(np.isnan(got["loc_trans_comp"])) and np.all(got["status_hist"] == -1)
+            got = dict(got, loc_trans_comp=ref["loc_trans_comp"], loc_rot_comp=ref["loc_rot_comp"], status_hist=np.asarray(ref["status_hist"]))
+        assert_result_parity(got, ref, binary=case["binary"])
+        st = f.stats()
+        moved.append(st["last_max_movers"])
+        origin, s, mean, nrm = f.state()
+        glob = np.array([split[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin], np.int64)
+        _, rs, rm, rn = refs[k]
+        if len(glob):
+            assert_state_parity((s, mean, nrm), (rs[glob], rm[glob], rn[glob]))
+        assert st["n_live"] == len(origin)
+        if log is not None:
+            log.append((rank, k, st))
+    stats = vmap.stats()
+    final = f.stats()
+    f.destroy()
+    vmap.release()
+    return dict(moved=moved, map_points=stats["n_points"], stats=final)
+
+
+def run_local_world(world, case=None, block_log2=3, uneven=False, components_off_from=None):
+    """`world` ranks as threads of this process over the in-process transport (one context = one stream per rank)."""
+    from mimosa_amd import capi
+    case = case or default_case()
+    refs, n_map = oracle_results(case)
+    n = len(case["scan"])
+    if uneven:
+        rng = np.random.default_rng(world)
+        cuts = np.sort(rng.integers(0, n + 1, world - 1))
+        split = np.split(np.arange(n), cuts)
+    else:
+        split = np.array_split(np.arange(n), world)
+    comms = capi.ShardComm.local(world)
+    ctxs = [capi.Context(0) for _ in range(world)]
+    results, errors = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            results[r] = run_rank(comms[r], ctxs[r], case, refs, split, block_log2=block_log2, force=(world == 1), components_off_from=components_off_from)
+        except BaseException as e:  # noqa: BLE001 — reported by the main thread
+            errors[r] = e
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    alive = [t.is_alive() for t in threads]
+    for r, e in enumerate(errors):
+        if e is not None:
+            raise AssertionError(f"rank {r}: {type(e).__name__}: {e}") from e
+    assert not any(alive), f"ranks still running (a collective was not entered by all): {alive}"
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.close()
+    return results, n_map

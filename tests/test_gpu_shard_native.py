@@ -1,0 +1,82 @@
+"""-m gpu: the native map-sharded factor (mh_shard_*, mimosa_amd/csrc/shard_api.hip) — the exchange inside the library.
+World > 1 runs over the in-process transport (ranks = threads on the one GPU of the box): the whole protocol — routing,
+fixed-size segments, tombstones, device-side slot counts, all-reduced sums, retries on overflow, compaction — against the
+unsharded oracle.  World 1 over RCCL (the only size a one-GPU box offers to RCCL) runs in a fresh process with the full
+protocol forced."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_native_sharded_equals_unsharded_oracle(world):
+    import shard_native_common as C
+    results, n_map = C.run_local_world(world)
+    for r, res in enumerate(results):
+        st = res["stats"]
+        assert st["world"] == world and st["rank"] == r and st["collective"] == 1
+        if world > 1:
+            assert 0 < res["map_points"] < n_map        # a real shard (with halo), not the whole map
+            assert res["moved"][0] > 0                   # the cold call routes points
+            assert res["moved"][-1] == 0                 # the last pose repeats the one before: nothing moves
+    # every call but retries is 1 all-to-all + 2 all-reduces (components on)
+    assert results[0]["stats"]["collectives_last"] == 3
+
+
+def test_native_sharded_uneven_shares_and_components_off():
+    import shard_native_common as C
+    results, _ = C.run_local_world(3, uneven=True, components_off_from=2)
+    assert results[0]["stats"]["collectives_last"] == 2   # no K4, no second all-reduce
+
+
+def test_native_sharded_small_blocks_and_4dof():
+    import shard_native_common as C
+    C.run_local_world(2, case=C.default_case(dict(reg_4_dof=1)), block_log2=2)
+
+
+def test_native_sharded_binary_factor():
+    import shard_native_common as C
+    C.run_local_world(2, case=C.default_case(binary=True))
+
+
+def test_native_sharded_segment_overflow_retries():
+    """A pose jump of metres after the segments have shrunk to their minimum: far more points change owner than a segment
+    holds, every rank repeats the call with larger segments, and the result is still the unsharded one."""
+    import shard_native_common as C
+    from mimosa_amd import synth
+    case = C.default_case()
+    R0, t0 = case["poses"][0]
+    case["poses"] = [(R0, t0), (R0, t0), (R0, t0), (R0 @ synth.so3_exp(np.array([0, 0, 0.3])), t0 + np.array([0.4, -0.3, 0.0])), (R0, t0)]
+    results, _ = C.run_local_world(2, case=case)
+    assert results[0]["stats"]["retries_total"] >= 1
+
+
+def test_native_world1_is_the_plain_factor(ctx, small_world):
+    from mimosa_amd import capi
+    w = small_world
+    comm = capi.ShardComm.local(1)[0]
+    vmap = capi.VoxelMap(ctx)
+    capi.map_insert_shard(ctx, vmap, w["map_xyz"], 1, 0)
+    rc = capi.make_reg_config(**w["cfg"])
+    f = capi.ShardedICPFactor(ctx, comm, vmap, w["pts"], rc)
+    g = capi.ICPFactor(ctx, vmap, w["pts"], rc)
+    a, b = f.linearize(w["R"], w["t"]), g.linearize(w["R"], w["t"])
+    assert np.array_equal(a["H_ss"], b["H_ss"]) and np.array_equal(a["b_s"], b["b_s"]) and a["f"] == b["f"]
+    st = f.stats()
+    assert st["collective"] == 0 and st["collectives_last"] == 0 and st["n_live"] == len(w["pts"])
+    f.destroy()
+    g.destroy()
+    vmap.release()
+    comm.destroy()
+
+
+def test_native_world1_over_rccl_full_protocol():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_native_rccl_worker.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
