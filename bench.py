@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--shard-rooms", type=str, default="auto",
                     help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
                          "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
-    ap.add_argument("--sharded", action="store_true", help="run the map-sharded leg at --gpus 1 too (world 1 over RCCL)")
+    ap.add_argument("--sharded", action="store_true", help="(kept for old command lines: the map-sharded leg now runs by default, at --gpus 1 too)")
+    ap.add_argument("--shard-block-log2", type=int, default=3, help="shard blocks of 2^n voxels per axis (3: 4 m cubes at the 0.5 m leaf)")
     return ap.parse_args()
 
 
@@ -86,13 +87,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if args.sharded and "MASTER_ADDR" not in os.environ:  # plain `python bench.py --sharded`: a one-rank RCCL group
-        import socket
-        sk = socket.socket()
-        sk.bind(("127.0.0.1", 0))
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-        sk.close()
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ or args.sharded:  # under torch.distributed.run
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ:  # under torch.distributed.run
         import torch
         import torch.distributed as dist
 
@@ -878,70 +873,154 @@ def main():
             "status_hist_equal": bool(np.array_equal(last["status_hist"], res4["status_hist"])),
         }
 
-    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node (mimosa_amd/dist.py): every
-    # rank stores the blocks it owns + a one-voxel halo, points are routed to the owner of their centre voxel with their
-    # association state (all-to-all over RCCL / xGMI), the Hessian sums and component localizabilities are all-reduced.  Reported
-    # NEXT TO the replica figure (`value`); all ranks take part.
+    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node.  The NATIVE path
+    # (mimosa_amd/csrc/shard_api.hip, mh_shard_*): every rank stores the blocks it owns + a one-voxel halo, a linearize is one
+    # chain of enqueues — route kernels, ncclAllToAll of fixed-size segments over xGMI, append, K3, ncclAllReduce of the Hessian
+    # sums (+ K4 and a second all-reduce when the components are on), publish — and ONE wait.  Reported NEXT TO the replica
+    # figure (`value`); all ranks take part.  With one rank the leg also runs by default: the sharded factor without
+    # collectives (nothing to exchange: the call IS mh_icp_linearize) and the FULL protocol forced over RCCL.
     sharded = None
-    if dist is not None and (world > 1 or args.sharded) and args.shard_rooms != "none":
+    if args.shard_rooms != "none" and not args.profile_mode:
         # The leg runs under a deadline in a worker thread: a failure or a stuck collective in it must not cost the
         # job its JSON line (the replica figure above is complete at this point).
         import threading
         box = {}
+        dry = os.environ.get("MH_BENCH_DRYRUN") == "1"
 
-        def _sharded_leg():
-            try:
-                torch.cuda.set_device(local_rank)
-                from mimosa_amd import dist as mdist
-                sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else "4x5")
-                snx, sny = (int(v) for v in sr.lower().split("x"))
-                sctx = mdist.context_on_torch_stream(local_rank)
-                dev = torch.device("cuda", local_rank)
-                sh = mdist.ShardedICPDevice(dist.group.WORLD, sctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), dev)
-                t0s = time.time()
-                sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), leaf=cfgd["target_ivox_map_leaf_size"],
-                             min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
-                             lru_horizon=synth.ENWIDE_LRU_HORIZON)
-                build_s = time.time() - t0s
-                spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
-                sh.set_scan(np.array_split(spts, world)[rank])
-                first_s = sh.linearize(R, t)                                         # routes the points to their owners
-                ksh, wsh = max(20, args.steps // 4), 5
-                def _sh_steps(k):
-                    for _ in range(k):
-                        sctx.check(sctx.L.mh_icp_reset(sh.fh))
-                        sh.linearize(R, t)
-                _sh_steps(wsh)
-                dist.barrier()
-                torch.cuda.synchronize()
-                a = time.perf_counter()
-                _sh_steps(ksh)
-                dist.barrier()
-                torch.cuda.synchronize()
-                el = time.perf_counter() - a
+        def _timed(fn, k, pre=None):
+            """k calls, barrier + device sync on both sides, max over ranks: seconds per call"""
+            def sync():
+                sctx.synchronize()
+                if dist is not None:
+                    dist.barrier()
+            for _ in range(3):
+                if pre:
+                    pre()
+                fn()
+            sync()
+            a = time.perf_counter()
+            for _ in range(k):
+                if pre:
+                    pre()
+                fn()
+            sync()
+            el = time.perf_counter() - a
+            if dist is not None and world > 1:
+                import torch
                 tt = torch.tensor([el], dtype=torch.float64, device="cuda")
                 _all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
-                nloc = torch.tensor([float(first_s["n_local"]), float(sh.map.stats()["n_points"])], dtype=torch.float64, device="cuda")
-                nmax = nloc.clone()
-                _all_reduce(nloc, op=dist.ReduceOp.SUM)
-                _all_reduce(nmax, op=dist.ReduceOp.MAX)
+            return el / k
+
+        def _native_leg(force, vmap, comm, spts, ksh):
+            f = capi.ShardedICPFactor(sctx, comm, vmap, np.array_split(spts, world)[rank], capi.make_reg_config(**cfgd), block_log2=args.shard_block_log2,
+                                      force_collectives=force)
+            a0 = time.perf_counter()
+            first_s = f.linearize(R, t)                                          # cold + routes every point to its owner
+            first_ms = (time.perf_counter() - a0) * 1e3
+            st0 = f.stats()
+            for _ in range(100):  # the scan was generated on the host just before: let the clocks come back up
+                f.linearize(R, t)
+            cold = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
+            warm = _timed(lambda: f.linearize(R, t), ksh)
+            f.set_components(False)
+            cold_nc = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
+            warm_nc = _timed(lambda: f.linearize(R, t), ksh)
+            kk = [0]
+            movers = []
+
+            def walk():  # a Gauss-Newton-sized pose step per call: points near block faces change owner
+                kk[0] += 1
+                f.linearize(R @ synth.so3_exp(np.array([0.0, 0.0, 0.0005 * kk[0]])), t + np.array([0.004, 0.002, 0.0]) * kk[0])
+                movers.append(f.stats()["last_max_movers"])
+            walk_nc = _timed(walk, ksh)
+            st = f.stats()
+            f.destroy()
+            return {"first_linearize_ms": round(first_ms, 4), "first_max_movers_per_destination": st0["last_max_movers"],
+                    "ms_per_cold_linearize": round(cold * 1e3, 4), "ms_per_warm_linearize": round(warm * 1e3, 4),
+                    "ms_per_cold_linearize_without_components": round(cold_nc * 1e3, 4), "ms_per_warm_linearize_without_components": round(warm_nc * 1e3, 4),
+                    "ms_per_walking_pose_linearize_without_components": round(walk_nc * 1e3, 4),
+                    "walking_pose_max_movers_per_destination": int(max(movers)) if movers else 0,
+                    "value": round(len(spts) / cold / 1e6, 2), "points_held": st["n_live"], "slots": st["n_slots"], "segment_records": st["segment_records"],
+                    "retries": st["retries_total"], "compactions": st["compactions_total"], "collectives_per_linearize": st["collectives_last"],
+                    "status_hist": [int(v) for v in first_s["status_hist"]]}
+
+        def _sharded_leg():
+            try:
+                if dist is not None:
+                    import torch
+                    torch.cuda.set_device(local_rank)
+                sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else ("4x5" if world > 1 else args.rooms))
+                snx, sny = (int(v) for v in sr.lower().split("x"))
+                spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
+                ksh = max(20, args.steps // 4)
+                mkw = dict(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+                           mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+                if dry and world > 1:
+                    # tests only: several ranks on ONE GPU — RCCL refuses that, so the caller-driven form of the protocol
+                    # (mimosa_amd/dist.py over gloo) stands in; the native path at world > 1 is covered by the in-process
+                    # transport in tests/test_gpu_shard_native.py
+                    import torch
+                    from mimosa_amd import dist as mdist
+                    lctx = mdist.context_on_torch_stream(local_rank)
+                    sh = mdist.ShardedICPDevice(dist.group.WORLD, lctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), torch.device("cuda", local_rank))
+                    sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), **mkw)
+                    sh.set_scan(np.array_split(spts, world)[rank])
+                    first_s = sh.linearize(R, t)
+                    nloc = torch.tensor([float(first_s["n_local"])], dtype=torch.float64, device="cuda")
+                    nmax = nloc.clone()
+                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
+                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
+                    box["result"] = {"n_ranks": world, "backend": "gloo (dry run, caller-driven protocol)", "scan_points_total": int(nloc[0].item()),
+                                     "scan_points_max_per_rank": int(nmax[0].item()), "status_hist": [int(v) for v in first_s["status_hist"]]}
+                    sh.close()
+                    return
+                # the communicator: rank 0 draws the ncclUniqueId, torch.distributed (already up for the replica leg) carries it
+                uid = capi.ShardComm.unique_id() if rank == 0 else None
+                if dist is not None and world > 1:
+                    obj = [uid]
+                    dist.broadcast_object_list(obj, src=0)
+                    uid = obj[0]
+                comm = capi.ShardComm.rccl(sctx, uid, world, rank)
+                t0s = time.time()
+                if world == 1 and sr == args.rooms:
+                    vmap, own_map = gmap, False                                    # one rank's shard IS the map
+                else:
+                    vmap, own_map = capi.VoxelMap(sctx, **mkw), True
+                    for _, _, xyz in synth.make_map_rooms(snx, sny):
+                        capi.map_insert_shard(sctx, vmap, xyz, world, rank, args.shard_block_log2)
+                build_s = time.time() - t0s
+                mstats = vmap.stats()
+                res = _native_leg(False, vmap, comm, spts, ksh)
                 result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
-                                       f"(shard blocks of 8^3 voxels + one-voxel halo), cold linearize per step",
-                           "n_ranks": world, "backend": dist.get_backend(), "steps": ksh,
-                           "ms_per_linearize": round(el / ksh * 1e3, 4), "value": round(len(spts) * ksh / el / 1e6, 2), "unit": "Mpts/s",
-                           "scan_points_total": int(nloc[0].item()), "scan_points_max_per_rank": int(nmax[0].item()),
-                           "map_points_stored_total": int(nloc[1].item()), "map_points_max_per_rank": int(nmax[1].item()),
-                           "map_build_s": round(build_s, 2), "status_hist": [int(v) for v in first_s["status_hist"]],
-                           "collectives_per_linearize": "all_to_all(counts) + [all_to_all(records) when points change owner] + all_reduce(32 f64) + all_reduce(16 f64)",
-                           "note": "one scan is latency-bound when sharded (a few thousand points per rank and four collectives per linearize): "
-                                   "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode"}
-                sh.close()
+                                       f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
+                           "n_ranks": comm.world, "backend": comm.backend, "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
+                           "map_build_s": round(build_s, 2), **res}
+                if world == 1:
+                    result["full_protocol_forced"] = _native_leg(True, vmap, comm, spts, ksh)
+                    result["full_protocol_forced"]["note"] = ("one rank, every step of the exchange protocol executed anyway: route kernels, ncclAllToAll of the segments to itself, "
+                                                              "append, K3 on device-side counts, ncclAllReduce(s), publish")
+                    result["scan_points_total"] = result["scan_points_max_per_rank"] = res["points_held"]
+                    result["map_points_stored_total"] = result["map_points_max_per_rank"] = int(mstats["n_points"])
+                else:
+                    import torch
+                    nloc = torch.tensor([float(res["points_held"]), float(mstats["n_points"])], dtype=torch.float64, device="cuda")
+                    nmax = nloc.clone()
+                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
+                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
+                    result.update(scan_points_total=int(nloc[0].item()), scan_points_max_per_rank=int(nmax[0].item()),
+                                  map_points_stored_total=int(nloc[1].item()), map_points_max_per_rank=int(nmax[1].item()))
+                result["note"] = ("one scan is latency-bound when sharded (a few thousand points per rank behind one all-to-all and one or two all-reduces): "
+                                  "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode.  "
+                                  + ("No xGMI figure exists yet: a one-GPU box cannot run RCCL with more than one rank." if world == 1 else ""))
+                comm.destroy()
+                if own_map:
+                    vmap.release()
                 box["result"] = result
             except Exception as exc:  # noqa: BLE001 - reported in the line
                 box["error"] = f"{type(exc).__name__}: {exc}"
 
-        import torch
+        sctx = capi.Context(local_rank)
         th = threading.Thread(target=_sharded_leg, daemon=True)
         th.start()
         th.join(args.shard_timeout)
@@ -953,6 +1032,8 @@ def main():
                 os.write(real_stdout, (json.dumps(line) + "\n").encode())
             os._exit(0)  # the worker may sit in a collective for ever: no clean-up is possible
         sharded = box.get("result") or {"error": box.get("error", "unknown"), "n_ranks": world}
+        if "error" not in sharded:
+            sctx.close()
     line["sharded"] = sharded
 
     if rank == 0:
