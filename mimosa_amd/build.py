@@ -141,9 +141,10 @@ def build_replay_native(force: bool = False) -> str:
     host = os.path.join(HERE, "host")
     src = os.path.join(host, "replay_main.cpp")
     deps = [src, lib] + [os.path.join(host, "mimosa_hip", h) for h in ("replay.hpp", "binio.hpp", "photometric.hpp", "lidar.hpp", "types.hpp")]
+    deps += [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(host, "gtsam_sig")) for f in fs]
     with _BuildLock():
         if force or _stale(exe, deps):
-            _run_to(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, src, "-o", exe,
+            _run_to(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, "-I", os.path.join(host, "gtsam_sig"), src, "-o", exe,
                      "-L", LIBDIR, "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"], exe)
     return exe
 

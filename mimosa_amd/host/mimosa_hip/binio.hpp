@@ -18,17 +18,23 @@ inline std::vector<T> read_vec(std::ifstream & f)
   uint64_t n = 0;
   f.read(reinterpret_cast<char *>(&n), 8);
   if (!f) throw std::runtime_error("binio: truncated input");
+  {
+    // the length is file-supplied: it may not promise more than the file still holds
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    if (here < 0 || end < here || n > static_cast<uint64_t>(end - here) / sizeof(T)) throw std::runtime_error("binio: vector length exceeds the file");
+  }
   std::vector<T> v(n);
   f.read(reinterpret_cast<char *>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
   if (!f) throw std::runtime_error("binio: truncated input");
   return v;
 }
-inline Pose3 pose_from(const double * p)
+inline Pose3 pose_from(const std::vector<double> & p, size_t offset = 0)  // 12 doubles: R row-major, t
 {
-  Pose3 T;
-  for (int i = 0; i < 9; ++i) T.R[i] = p[i];
-  for (int i = 0; i < 3; ++i) T.t[i] = p[9 + i];
-  return T;
+  if (p.size() < offset + 12) throw std::runtime_error("binio: a pose needs 12 doubles");
+  return pose3(p.data() + offset, p.data() + offset + 9);
 }
 // the photometric block: 18 ints, 13 doubles, pixel shifts, beam angles, two FIR kernels, patch offsets, T_B_L
 inline lidar::PhotometricConfig read_photo_config(std::ifstream & f)
@@ -75,7 +81,7 @@ inline lidar::PhotometricConfig read_photo_config(std::ifstream & f)
   cfg.edgelet_patch_offsets.clear();
   for (size_t i = 0; i + 1 < offs.size(); i += 2) cfg.edgelet_patch_offsets.emplace_back(offs[i], offs[i + 1]);
   const auto TBL = read_vec<double>(f);
-  cfg.T_B_L = pose_from(TBL.data());
+  cfg.T_B_L = pose_from(TBL);
   return cfg;
 }
 }  // namespace binio

@@ -53,7 +53,7 @@ inline RegistrationConfig defaultRegistrationConfig()
 struct GeometricConfig
 {
   bool enabled = true;
-  Pose3 T_B_L = Pose3::Identity();
+  Pose3 T_B_L = Pose3();
   int point_skip_divisor = 1;
   int ring_skip_divisor = 1;
   float map_keyframe_trans_thresh = 0.1f;
@@ -141,20 +141,21 @@ public:
   void insertBodyCloud(mh_scan * scan, const Pose3 & T_W_Be)
   {
     ensure();
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
-    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
-    ctx_->check(mh_map_insert_from_scan(map_, scan, R, t), "mh_map_insert_from_scan");
+    float Rt[12];
+    toFloat12(T_W_Be, Rt);
+    ctx_->check(mh_map_insert_from_scan(map_, scan, Rt, Rt + 9), "mh_map_insert_from_scan");
   }
   // incremental_voxel_map.cpp:26-32: true iff k neighbours were found; coordinates instead of ids
   bool knn_search(const V3D & point, const size_t k, std::vector<V3D> & neighbours, std::vector<double> & sq_dists)
   {
     ensure();
-    neighbours.assign(k, V3D{});
+    neighbours.assign(k, V3D());
     sq_dists.assign(k, 0.0);
     int32_t found = 0;
-    ctx_->check(mh_map_knn(map_, point.data(), 1, static_cast<int>(k), neighbours[0].data(), sq_dists.data(), &found),
-                "mh_map_knn");
+    const A3 q = toArray(point);
+    std::vector<double> nb(3 * k);
+    ctx_->check(mh_map_knn(map_, q.data(), 1, static_cast<int>(k), nb.data(), sq_dists.data(), &found), "mh_map_knn");
+    for (size_t i = 0; i < k; ++i) neighbours[i] = vector3(&nb[3 * i]);
     return static_cast<size_t>(found) == k;
   }
   PointCloud getCloud()  // incremental_voxel_map.cpp:34-38
@@ -365,10 +366,7 @@ public:
   {
     if (T_Le_Lt.size() != unique_ns_.size()) throw std::runtime_error("deskewPoints: one pose per unique timestamp");
     std::vector<float> Rt12(12 * T_Le_Lt.size());
-    for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
-      for (int i = 0; i < 9; ++i) Rt12[12 * g + i] = static_cast<float>(T_Le_Lt[g].R[i]);
-      for (int i = 0; i < 3; ++i) Rt12[12 * g + 9 + i] = static_cast<float>(T_Le_Lt[g].t[i]);
-    }
+    for (size_t g = 0; g < T_Le_Lt.size(); ++g) toFloat12(T_Le_Lt[g], &Rt12[12 * g]);
     ctx_->check(mh_scan_deskew(scan_, Rt12.data(), T_Le_Lt.size()), "mh_scan_deskew");
   }
   // which: 0 points_full_, 1 Be_cloud_, 2 sm_Be_cloud_ds_
@@ -392,6 +390,18 @@ private:
   double corrected_ts_ = 0;
 };
 
+// The GaussianFactor ICPFactor::linearize returns: gtsam::HessianFactor(keys()[0], H, -b, f) (geometric_factor.hpp:559-560),
+// binary HessianFactor(k0, k1, H_ss, H_st, -b_s, H_tt, -b_t, f) (:459-462), from the C ABI's row-major result.
+inline std::shared_ptr<HessianFactor> hessianFrom(const KeyVector & keys, bool binary, const mh_icp_result & r)
+{
+  gtsam::Vector g1(6);
+  for (int i = 0; i < 6; ++i) g1(i) = -r.b_s[i];
+  if (!binary) return std::make_shared<HessianFactor>(keys[0], matrix6(r.H_ss), g1, r.f);
+  gtsam::Vector g2(6);
+  for (int i = 0; i < 6; ++i) g2(i) = -r.b_t[i];
+  return std::make_shared<HessianFactor>(keys[0], keys[1], matrix6(r.H_ss), matrix6(r.H_st), g1, matrix6(r.H_tt), g2, r.f);
+}
+
 class ICPFactor : public NonlinearFactor
 {
 public:
@@ -411,20 +421,20 @@ public:
   // unary: key_source is T_W_B, the cloud is registered to the map frame (:119-129)
   ICPFactor(const Key key_source, IncrementalVoxelMapPCL::Ptr ivox_target, const PointCloud & cloud_source,
             const RegistrationConfig & config)
-  : NonlinearFactor({key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
+  : NonlinearFactor(KeyVector{key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
   {
     create(cloud_source, config);
   }
   // binary (:131-142)
   ICPFactor(const Key key_source, const Key key_target, IncrementalVoxelMapPCL::Ptr ivox_target,
             const PointCloud & cloud_source, const RegistrationConfig & config)
-  : NonlinearFactor({key_source, key_target}), is_binary_(true), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
+  : NonlinearFactor(KeyVector{key_source, key_target}), is_binary_(true), ivox_target_(std::move(ivox_target)), n_(cloud_source.size())
   {
     create(cloud_source, config);
   }
   // unary, source cloud = the scan front end's sm_Be_cloud_ds_, taken from device memory
   ICPFactor(const Key key_source, IncrementalVoxelMapPCL::Ptr ivox_target, ScanFrontEnd & scan, const RegistrationConfig & config)
-  : NonlinearFactor({key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(scan.info().n_downsampled)
+  : NonlinearFactor(KeyVector{key_source}), is_binary_(false), ivox_target_(std::move(ivox_target)), n_(scan.info().n_downsampled)
   {
     std::memset(&last_, 0, sizeof(last_));
     ctx().check(mh_icp_create_from_scan(ctx().get(), ivox_target_->underlying(), scan.underlying(), &config, 0, &icp_),
@@ -446,11 +456,13 @@ public:
 
   std::shared_ptr<GaussianFactor> linearize(const Values & c) const override  // :231-562
   {
-    const Pose3 & Ts = c.atPose3(keys()[0]);
-    const Pose3 * Tt = is_binary_ ? &c.atPose3(keys()[1]) : nullptr;
+    // :247-257 — T_W_S = c.at<Pose3>(keys()[0]), T_W_T for the binary factor, global_z from c.at<Unit3>(G(0)) (read unconditionally)
+    const PoseRM Ts = rowMajor(c.at<Pose3>(keys()[0]));
+    PoseRM Tt{};
+    if (is_binary_) Tt = rowMajor(c.at<Pose3>(keys()[1]));
+    const A3 g = toArray(c.at<Unit3>(G(0)).unitVector());
     mh_icp_result r;
-    ctx().check(mh_icp_linearize(icp_, Ts.R.data(), Ts.t.data(), Tt ? Tt->R.data() : nullptr, Tt ? Tt->t.data() : nullptr,
-                                 c.gravityUnit().data(), &r),
+    ctx().check(mh_icp_linearize(icp_, Ts.R.data(), Ts.t.data(), is_binary_ ? Tt.R.data() : nullptr, is_binary_ ? Tt.t.data() : nullptr, g.data(), &r),
                 "mh_icp_linearize");
     last_ = r;
     return toHessian(r);
@@ -471,15 +483,16 @@ public:
       const ICPFactor & f = *factors[i];
       if (f.is_binary_ != binary) throw std::runtime_error("ICPFactor::linearizeBatch: unary and binary factors mixed");
       h[i] = f.icp_;
-      const Pose3 & Ts = c.atPose3(f.keys()[0]);
+      const PoseRM Ts = rowMajor(c.at<Pose3>(f.keys()[0]));
       std::memcpy(&Rs[9 * i], Ts.R.data(), 72);
       std::memcpy(&ts[3 * i], Ts.t.data(), 24);
       if (binary) {
-        const Pose3 & Tt = c.atPose3(f.keys()[1]);
+        const PoseRM Tt = rowMajor(c.at<Pose3>(f.keys()[1]));
         std::memcpy(&Rt[9 * i], Tt.R.data(), 72);
         std::memcpy(&tt[3 * i], Tt.t.data(), 24);
       }
-      std::memcpy(&g[3 * i], c.gravityUnit().data(), 24);
+      const A3 gu = toArray(c.at<Unit3>(G(0)).unitVector());
+      std::memcpy(&g[3 * i], gu.data(), 24);
     }
     std::vector<mh_icp_result> r(n);
     factors[0]->ctx().check(mh_icp_linearize_batch(h.data(), n, Rs.data(), ts.data(), binary ? Rt.data() : nullptr,
@@ -503,32 +516,36 @@ public:
   }
   std::vector<V3D> getCorresMeansTarget() const
   {
+    std::vector<double> v(3 * n_);
+    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, v.data(), nullptr), "mh_icp_get_state");
     std::vector<V3D> m(n_);
-    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, m[0].data(), nullptr), "mh_icp_get_state");
+    for (size_t i = 0; i < n_; ++i) m[i] = vector3(&v[3 * i]);
     return m;
   }
   std::vector<V3D> getCorresNormalsTarget() const
   {
+    std::vector<double> v(3 * n_);
+    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, nullptr, v.data()), "mh_icp_get_state");
     std::vector<V3D> m(n_);
-    if (n_) ctx().check(mh_icp_get_state(icp_, nullptr, nullptr, m[0].data()), "mh_icp_get_state");
+    for (size_t i = 0; i < n_; ++i) m[i] = vector3(&v[3 * i]);
     return m;
   }
   void getLocalizabilities(V3D & trans_comp, V3D & rot_comp, V3D & trans_final, V3D & rot_final, M33 & eigenvectors_trans,
                            M33 & eigenvectors_rot)
   {
-    std::memcpy(trans_comp.data(), last_.loc_trans_comp, 24);
-    std::memcpy(rot_comp.data(), last_.loc_rot_comp, 24);
-    std::memcpy(trans_final.data(), last_.loc_trans_final, 24);
-    std::memcpy(rot_final.data(), last_.loc_rot_final, 24);
-    std::memcpy(eigenvectors_trans.data(), last_.eigvec_trans, 72);
-    std::memcpy(eigenvectors_rot.data(), last_.eigvec_rot, 72);
+    trans_comp = vector3(last_.loc_trans_comp);
+    rot_comp = vector3(last_.loc_rot_comp);
+    trans_final = vector3(last_.loc_trans_final);
+    rot_final = vector3(last_.loc_rot_final);
+    eigenvectors_trans = matrix3(last_.eigvec_trans);
+    eigenvectors_rot = matrix3(last_.eigvec_rot);
   }
   void getDegenInfo(V3D & rot, M33 & eigenvectors_rot, V3D & trans, M33 & eigenvectors_trans)
   {
-    std::memcpy(rot.data(), last_.degen_rot, 24);
-    std::memcpy(eigenvectors_rot.data(), last_.degen_eigvec_rot, 72);
-    std::memcpy(trans.data(), last_.degen_trans, 24);
-    std::memcpy(eigenvectors_trans.data(), last_.degen_eigvec_trans, 72);
+    rot = vector3(last_.degen_rot);
+    eigenvectors_rot = matrix3(last_.degen_eigvec_rot);
+    trans = vector3(last_.degen_trans);
+    eigenvectors_trans = matrix3(last_.degen_eigvec_trans);
   }
   int getLinearizeCount() const { return last_.linearize_count; }
   const mh_icp_result & lastResult() const { return last_; }  // incl. the status histogram of geometric.cpp:280-323
@@ -536,23 +553,13 @@ public:
 private:
   std::shared_ptr<HessianFactor> toHessian(const mh_icp_result & r) const
   {
-    auto h = std::make_shared<HessianFactor>();
-    h->keys = keys();
-    std::memcpy(h->G11.data(), r.H_ss, sizeof(r.H_ss));
-    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_s[i];  // HessianFactor(key, H, -b, f), :559-560
-    h->f = r.f;
-    if (is_binary_) {  // :460-462
-      std::memcpy(h->G12.data(), r.H_st, sizeof(r.H_st));
-      std::memcpy(h->G22.data(), r.H_tt, sizeof(r.H_tt));
-      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_t[i];
-    }
-    return h;
+    return hessianFrom(keys(), is_binary_, r);
   }
   struct CloneTag
   {
   };
   ICPFactor(const ICPFactor & o, CloneTag)
-  : NonlinearFactor(o.keys()), is_binary_(o.is_binary_), ivox_target_(o.ivox_target_), n_(o.n_), last_(o.last_)
+  : NonlinearFactor(KeyVector(o.keys())), is_binary_(o.is_binary_), ivox_target_(o.ivox_target_), n_(o.n_), last_(o.last_)
   {
     ctx().check(mh_icp_clone(o.icp_, &icp_), "mh_icp_clone");
   }
@@ -607,11 +614,10 @@ public:
     Be_cloud_.clear();
     Be_cloud_.reserve(idxs.size());
     for (const size_t idx : idxs) Be_cloud_.push_back(points_deskewed[idx]);
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(config.T_B_L.R[i]);
-    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(config.T_B_L.t[i]);
+    float Rt[12];
+    toFloat12(config.T_B_L, Rt);
     if (!Be_cloud_.empty())
-      ctx_->check(mh_transform_f32(ctx_->get(), Be_cloud_.data(), Be_cloud_.size(), R, t), "mh_transform_f32");
+      ctx_->check(mh_transform_f32(ctx_->get(), Be_cloud_.data(), Be_cloud_.size(), Rt, Rt + 9), "mh_transform_f32");
     downsample(Be_cloud_, sm_Be_cloud_ds_, config.scan_to_map.source_voxel_grid_filter_leaf_size, 20,
                config.scan_to_map.source_voxel_grid_min_dist_in_voxel);
     device_scan_ = nullptr;
@@ -625,10 +631,9 @@ public:
   {
     if (!config.enabled) return;
     ts_ = ts;
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(config.T_B_L.R[i]);
-    for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(config.T_B_L.t[i]);
-    ctx_->check(mh_scan_preprocess_geometric(scan.underlying(), R, t, config.scan_to_map.source_voxel_grid_filter_leaf_size,
+    float Rt[12];
+    toFloat12(config.T_B_L, Rt);
+    ctx_->check(mh_scan_preprocess_geometric(scan.underlying(), Rt, Rt + 9, config.scan_to_map.source_voxel_grid_filter_leaf_size,
                                              20, config.scan_to_map.source_voxel_grid_min_dist_in_voxel, &scan.mutableInfo()),
                 "mh_scan_preprocess_geometric");
     Be_cloud_.clear();
@@ -650,17 +655,17 @@ public:
     V3D tc, rc, tf, rf;
     M33 et, er;
     factor_->getLocalizabilities(tc, rc, tf, rf, et, er);
-    eigenvectors_block_matrix.fill(0.0);
+    eigenvectors_block_matrix.setZero();
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
-        eigenvectors_block_matrix[6 * r + c] = er[3 * r + c];
-        eigenvectors_block_matrix[6 * (3 + r) + 3 + c] = et[3 * r + c];
+        eigenvectors_block_matrix(r, c) = er(r, c);
+        eigenvectors_block_matrix(3 + r, 3 + c) = et(r, c);
       }
     for (int i = 0; i < 3; ++i) {  // :218-228
-      degen_directions[i] = rc[i] < config.scan_to_map.degen_thresh_rot;
-      degen_directions[3 + i] = tc[i] < config.scan_to_map.degen_thresh_trans;
-      debug_.degen_rot_bool[i] = degen_directions[i] != 0;
-      debug_.degen_trans_bool[i] = degen_directions[3 + i] != 0;
+      degen_directions(i) = rc(i) < config.scan_to_map.degen_thresh_rot;
+      degen_directions(3 + i) = tc(i) < config.scan_to_map.degen_thresh_trans;
+      debug_.degen_rot_bool[i] = degen_directions(i) != 0;
+      debug_.degen_trans_bool[i] = degen_directions(3 + i) != 0;
     }
     debug_.localizability_trans_comp = tc;
     debug_.localizability_rot_comp = rc;
@@ -678,31 +683,27 @@ public:
   {
     if (!config.enabled) return;
     if (factor_) debug_.n_linearize_calls = factor_->getLinearizeCount();
-    const Pose3 & T_W_Be = values.atPose3(key);
+    const Pose3 T_W_Be = values.at<Pose3>(key);
     bool update_map = true;
     if (!map_poses_.empty()) {
       float min_diff_trans = std::numeric_limits<float>::max();
       size_t min_diff_index = 0;
       for (size_t i = 0; i < map_poses_.size(); ++i) {
-        const V3D & a = map_poses_[i].t;
-        const float d = static_cast<float>(std::sqrt((a[0] - T_W_Be.t[0]) * (a[0] - T_W_Be.t[0]) +
-                                                     (a[1] - T_W_Be.t[1]) * (a[1] - T_W_Be.t[1]) +
-                                                     (a[2] - T_W_Be.t[2]) * (a[2] - T_W_Be.t[2])));
+        const Point3 & a = map_poses_[i].translation();
+        const Point3 & b = T_W_Be.translation();
+        const float d = static_cast<float>(std::sqrt((a(0) - b(0)) * (a(0) - b(0)) + (a(1) - b(1)) * (a(1) - b(1)) + (a(2) - b(2)) * (a(2) - b(2))));
         if (d < min_diff_trans) {
           min_diff_trans = d;
           min_diff_index = i;
         }
       }
       // rot_diff = R_B_L^-1 * between(R_kf, R_now) * R_B_L, yaw-pitch-roll magnitudes (:454-458)
-      Pose3 RBL;
-      RBL.R = config.T_B_L.R;
-      Pose3 Rk, Rn;
-      Rk.R = map_poses_[min_diff_index].R;
-      Rn.R = T_W_Be.R;
-      const Pose3 d = RBL.inverse() * (Rk.inverse() * Rn) * RBL;
-      const double yaw = std::atan2(d.R[3], d.R[0]);
-      const double pitch = std::atan2(-d.R[6], std::sqrt(d.R[7] * d.R[7] + d.R[8] * d.R[8]));
-      const double roll = std::atan2(d.R[7], d.R[8]);
+      const Rot3 & RBL = config.T_B_L.rotation();
+      const Rot3 dR = RBL.inverse() * map_poses_[min_diff_index].rotation().between(T_W_Be.rotation()) * RBL;
+      const M33 d = dR.matrix();  // Rot3::ypr() spelled out
+      const double yaw = std::atan2(d(1, 0), d(0, 0));
+      const double pitch = std::atan2(-d(2, 0), std::sqrt(d(2, 1) * d(2, 1) + d(2, 2) * d(2, 2)));
+      const double roll = std::atan2(d(2, 1), d(2, 2));
       const double ypr_max = std::max(std::fabs(yaw), std::max(std::fabs(pitch), std::fabs(roll)));
       if (min_diff_trans > config.map_keyframe_trans_thresh)
         update_map = true;
@@ -723,10 +724,9 @@ public:
       ivox_map_->insertBodyCloud(device_scan_->underlying(), T_W_Be);  // transform + insert on the device
     } else {
       PointCloud W = Be_cloud_;
-      float R[9], t[3];
-      for (int i = 0; i < 9; ++i) R[i] = static_cast<float>(T_W_Be.R[i]);
-      for (int i = 0; i < 3; ++i) t[i] = static_cast<float>(T_W_Be.t[i]);
-      if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), R, t), "mh_transform_f32");
+      float Rt[12];
+      toFloat12(T_W_Be, Rt);
+      if (!W.empty()) ctx_->check(mh_transform_f32(ctx_->get(), W.data(), W.size(), Rt, Rt + 9), "mh_transform_f32");
       ivox_map_->insert(W);
     }
     map_poses_.push_back(T_W_Be);
@@ -808,33 +808,7 @@ private:
 // Output: T_Le_Lt per distinct timestamp, exactly the constant-acceleration / constant-rate extrapolation of
 // :478-489 followed by T_Le_W * T_W_Bt * T_B_S (:493-497).  Timestamps after the last IMU sample get no pose
 // (the reference's vector simply ends there).
-struct NavState
-{
-  Pose3 pose;
-  V3D velocity{0, 0, 0};
-};
-
-inline M33 so3Expmap(const V3D & w)  // gtsam::Rot3::Expmap (Rodrigues)
-{
-  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
-  const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-  double A, B;
-  if (th < 1e-10) {
-    A = 1.0 - th2 / 6.0;
-    B = 0.5 - th2 / 24.0;
-  } else {
-    A = std::sin(th) / th;
-    B = (1.0 - std::cos(th)) / th2;
-  }
-  M33 R{1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double kk = 0;
-      for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
-      R[3 * i + j] += A * K[3 * i + j] + B * kk;
-    }
-  return R;
-}
+using gtsam::NavState;
 
 inline std::vector<Pose3> computeDeskewPoses(const std::vector<double> & imu_t, const std::vector<V3D> & imu_acc,
                                              const std::vector<V3D> & imu_gyro, const std::vector<NavState> & nav,
@@ -850,29 +824,29 @@ inline std::vector<Pose3> computeDeskewPoses(const std::vector<double> & imu_t, 
   size_t u = 0;
   for (size_t c = 0; c + 1 < imu_t.size(); ++c) {  // curr = c, next = c + 1 (:459-466)
     const NavState & curr = nav[c];
+    const A9 Rc = rowMajor(curr.pose().rotation().matrix());
+    const A3 pc = toArray(curr.pose().translation()), vc = toArray(curr.velocity());
     while (u < unique_ns.size()) {
       const double ts = header_ts + unique_ns[u] * 1.0e-9;  // globalTs, manager.hpp:94
       if (ts > imu_t[c + 1]) break;
       const double dt = ts - imu_t[c];
-      V3D acc, omega;
+      double acc[3], omega[3];
       for (int i = 0; i < 3; ++i) {
-        acc[i] = imu_acc[c][i] - bias_acc[i];     // ConstantBias::correctAccelerometer
-        omega[i] = imu_gyro[c][i] - bias_gyro[i];  // ::correctGyroscope
+        acc[i] = imu_acc[c](i) - bias_acc(i);     // ConstantBias::correctAccelerometer
+        omega[i] = imu_gyro[c](i) - bias_gyro(i);  // ::correctGyroscope
       }
-      Pose3 T;
-      const M33 E = so3Expmap({omega[0] * dt, omega[1] * dt, omega[2] * dt});
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-          T.R[3 * i + j] = curr.pose.R[3 * i] * E[j] + curr.pose.R[3 * i + 1] * E[3 + j] + curr.pose.R[3 * i + 2] * E[6 + j];
+      // :478-489  R = R_c Exp(omega dt),  p = p_c + v dt + 1/2 R_c a dt^2 + 1/2 g_hat |g| dt^2
+      const Rot3 R = curr.pose().rotation() * Rot3::Expmap(V3D(omega[0] * dt, omega[1] * dt, omega[2] * dt));
+      double p[3];
       for (int i = 0; i < 3; ++i) {
-        const double Ra = curr.pose.R[3 * i] * acc[0] + curr.pose.R[3 * i + 1] * acc[1] + curr.pose.R[3 * i + 2] * acc[2];
-        T.t[i] = curr.pose.t[i] + curr.velocity[i] * dt + 0.5 * Ra * dt * dt + 0.5 * gravity_unit[i] * gravity_norm * dt * dt;
+        const double Ra = Rc[3 * i] * acc[0] + Rc[3 * i + 1] * acc[1] + Rc[3 * i + 2] * acc[2];
+        p[i] = pc[i] + vc[i] * dt + 0.5 * Ra * dt * dt + 0.5 * gravity_unit(i) * gravity_norm * dt * dt;
       }
-      T_W_Bts.push_back(T);
+      T_W_Bts.push_back(Pose3(R, Point3(p[0], p[1], p[2])));
       ++u;
     }
   }
-  const Pose3 T_Le_W = T_B_S.inverse() * nav.back().pose.inverse();  // propagated state = T_W_Be (:492-493)
+  const Pose3 T_Le_W = T_B_S.inverse() * nav.back().pose().inverse();  // propagated state = T_W_Be (:492-493)
   std::vector<Pose3> out;
   out.reserve(T_W_Bts.size());
   for (const Pose3 & T : T_W_Bts) out.push_back(T_Le_W * T * T_B_S);
@@ -887,17 +861,11 @@ inline void deskewPoints(const Context & ctx, PointCloud & points_full, const st
 {
   if (unique_ns.size() != T_Le_Lt.size()) throw std::runtime_error("deskewPoints: one pose per unique timestamp");
   std::vector<float> Rt12(12 * T_Le_Lt.size());
-  for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
-    for (int i = 0; i < 9; ++i) Rt12[12 * g + i] = static_cast<float>(T_Le_Lt[g].R[i]);
-    for (int i = 0; i < 3; ++i) Rt12[12 * g + 9 + i] = static_cast<float>(T_Le_Lt[g].t[i]);
-  }
-  float Rb[9], tb[3];
-  if (T_B_L) {
-    for (int i = 0; i < 9; ++i) Rb[i] = static_cast<float>(T_B_L->R[i]);
-    for (int i = 0; i < 3; ++i) tb[i] = static_cast<float>(T_B_L->t[i]);
-  }
+  for (size_t g = 0; g < T_Le_Lt.size(); ++g) toFloat12(T_Le_Lt[g], &Rt12[12 * g]);
+  float Rb[12];
+  if (T_B_L) toFloat12(*T_B_L, Rb);
   ctx.check(mh_deskew(ctx.get(), points_full.data(), points_full.size(), unique_ns.data(), Rt12.data(), unique_ns.size(),
-                      T_B_L ? Rb : nullptr, T_B_L ? tb : nullptr),
+                      T_B_L ? Rb : nullptr, T_B_L ? Rb + 9 : nullptr),
             "mh_deskew");
 }
 

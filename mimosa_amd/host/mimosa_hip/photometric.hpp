@@ -27,7 +27,7 @@ struct PhotometricConfig
   bool enabled = true;
   bool destagger = true;
   std::vector<int> pixel_shift_by_row = {};
-  Pose3 T_B_L = Pose3::Identity();
+  Pose3 T_B_L = Pose3();
   size_t rows = 128;
   size_t cols = 512;
   float range_min = 0.1f;
@@ -73,7 +73,7 @@ struct Feature
   uint32_t id = 0;
   int life_time = 0;
   std::array<double, 2> center{0, 0};
-  V3D normal{0, 0, 0};
+  V3D normal = V3D(0, 0, 0);
   double mean_intensity = 0, sigma_intensity = 0;
   std::vector<V3D> Le_ps;
   std::vector<double> intensities, psi_intensities;
@@ -111,10 +111,12 @@ public:
 
   std::shared_ptr<GaussianFactor> linearize(const Values & c) const override  // :136-355
   {
-    const Pose3 & Tb = c.atPose3(keys()[0]);
-    const Pose3 * Ta = is_binary_ ? &c.atPose3(keys()[1]) : nullptr;
+    // :145-149 — T_W_Bb = c.at<Pose3>(keys()[0]) (and T_W_Ba for the binary factor)
+    const PoseRM Tb = rowMajor(c.at<Pose3>(keys()[0]));
+    PoseRM Ta{};
+    if (is_binary_) Ta = rowMajor(c.at<Pose3>(keys()[1]));
     mh_photo_result r;
-    ctx_->check(mh_photo_factor_linearize(f_, Tb.R.data(), Tb.t.data(), Ta ? Ta->R.data() : nullptr, Ta ? Ta->t.data() : nullptr, &r),
+    ctx_->check(mh_photo_factor_linearize(f_, Tb.R.data(), Tb.t.data(), is_binary_ ? Ta.R.data() : nullptr, is_binary_ ? Ta.t.data() : nullptr, &r),
                 "mh_photo_factor_linearize");
     return toHessian(r);
   }
@@ -122,9 +124,10 @@ public:
   // linearize() split in two so that the smoother can queue it next to ICPFactor::linearizeBatch on the same stream
   void linearizeAsync(const Values & c) const
   {
-    const Pose3 & Tb = c.atPose3(keys()[0]);
-    const Pose3 * Ta = is_binary_ ? &c.atPose3(keys()[1]) : nullptr;
-    ctx_->check(mh_photo_factor_linearize_async(f_, Tb.R.data(), Tb.t.data(), Ta ? Ta->R.data() : nullptr, Ta ? Ta->t.data() : nullptr),
+    const PoseRM Tb = rowMajor(c.at<Pose3>(keys()[0]));
+    PoseRM Ta{};
+    if (is_binary_) Ta = rowMajor(c.at<Pose3>(keys()[1]));
+    ctx_->check(mh_photo_factor_linearize_async(f_, Tb.R.data(), Tb.t.data(), is_binary_ ? Ta.R.data() : nullptr, is_binary_ ? Ta.t.data() : nullptr),
                 "mh_photo_factor_linearize_async");
   }
   std::shared_ptr<GaussianFactor> collect() const
@@ -152,10 +155,10 @@ public:
   }
   void getLocalizabilities(V3D & trans_final, V3D & rot_final, M33 & eigenvectors_trans, M33 & eigenvectors_rot) const  // :51-59
   {
-    std::memcpy(trans_final.data(), last_.loc_trans_final, 24);
-    std::memcpy(rot_final.data(), last_.loc_rot_final, 24);
-    std::memcpy(eigenvectors_trans.data(), last_.eigvec_trans, 72);
-    std::memcpy(eigenvectors_rot.data(), last_.eigvec_rot, 72);
+    trans_final = vector3(last_.loc_trans_final);
+    rot_final = vector3(last_.loc_rot_final);
+    eigenvectors_trans = matrix3(last_.eigvec_trans);
+    eigenvectors_rot = matrix3(last_.eigvec_rot);
   }
   const mh_photo_result & lastResult() const { return last_; }
   mh_photo_factor * underlying() const { return f_; }
@@ -168,20 +171,15 @@ private:
       throw std::runtime_error("PhotometricFactor::linearize: " + std::to_string(r.n_exceptions) +
                                " feature(s) hit a condition the reference throws on");
     last_ = r;
-    auto h = std::make_shared<HessianFactor>();
-    h->keys = keys();
-    std::memcpy(h->G11.data(), r.H_bb, sizeof(r.H_bb));
-    for (int i = 0; i < 6; ++i) h->g1[i] = -r.b_b[i];  // HessianFactor(key, H_bb, -b_b, f), :332-353
-    h->f = r.f;
-    if (is_binary_) {
-      std::memcpy(h->G12.data(), r.H_ba, sizeof(r.H_ba));
-      std::memcpy(h->G22.data(), r.H_aa, sizeof(r.H_aa));
-      for (int i = 0; i < 6; ++i) h->g2[i] = -r.b_a[i];
-    }
-    return h;
+    gtsam::Vector gb(6);
+    for (int i = 0; i < 6; ++i) gb(i) = -r.b_b[i];
+    if (!is_binary_) return std::make_shared<HessianFactor>(keys()[0], matrix6(r.H_bb), gb, r.f);  // HessianFactor(key, H_bb, -b_b, f), :332-353
+    gtsam::Vector ga(6);
+    for (int i = 0; i < 6; ++i) ga(i) = -r.b_a[i];
+    return std::make_shared<HessianFactor>(keys()[0], keys()[1], matrix6(r.H_bb), matrix6(r.H_ba), gb, matrix6(r.H_aa), ga, r.f);
   }
-  PhotometricFactor(std::shared_ptr<Context> ctx, std::vector<Key> keys, bool is_binary)
-  : NonlinearFactor(std::move(keys)), ctx_(std::move(ctx)), is_binary_(is_binary)
+  PhotometricFactor(std::shared_ptr<Context> ctx, const KeyVector & keys, bool is_binary)
+  : NonlinearFactor(keys), ctx_(std::move(ctx)), is_binary_(is_binary)
   {
     std::memset(&last_, 0, sizeof(last_));
   }
@@ -260,8 +258,9 @@ public:
     c.error_scale = config.error_scale;
     c.max_error = config.max_error;
     c.sigma = config.sigma;
-    std::memcpy(c.T_B_L_R, config.T_B_L.R.data(), sizeof(c.T_B_L_R));
-    std::memcpy(c.T_B_L_t, config.T_B_L.t.data(), sizeof(c.T_B_L_t));
+    const PoseRM TBL = rowMajor(config.T_B_L);
+    std::memcpy(c.T_B_L_R, TBL.R.data(), sizeof(c.T_B_L_R));
+    std::memcpy(c.T_B_L_t, TBL.t.data(), sizeof(c.T_B_L_t));
     c.static_mask = config.static_mask.empty() ? nullptr : config.static_mask.data();
     ctx_->check(mh_photo_create(ctx_->get(), &c, &photo_), "mh_photo_create");  // copies every table
   }
@@ -291,8 +290,9 @@ public:
     if (!config.enabled) return;
     std::vector<double> T(12 * T_Le_Lt.size());
     for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
-      std::memcpy(&T[12 * g], T_Le_Lt[g].R.data(), 72);
-      std::memcpy(&T[12 * g + 9], T_Le_Lt[g].t.data(), 24);
+      const PoseRM p = rowMajor(T_Le_Lt[g]);
+      std::memcpy(&T[12 * g], p.R.data(), 72);
+      std::memcpy(&T[12 * g + 9], p.t.data(), 24);
     }
     ctx_->check(mh_photo_preprocess_scan(photo_, scan.underlying(), T.data(), T_Le_Lt.size()), "mh_photo_preprocess_scan");
     ts_ = ts;
@@ -302,22 +302,22 @@ public:
   // photometric.cpp:373-394: unary factor on the current frame from the tracked features; V S V^T restricts it to the
   // directions `selection` keeps (the geometric factor's degenerate ones, lidar/manager.cpp:568-581)
   void getFactors(const Values &, NonlinearFactorGraph & graph, const M66 & eigenvectors_block_matrix = identity66(),
-                  const V6D & selection = V6D{1, 1, 1, 1, 1, 1})
+                  const V6D & selection = ones6())
   {
     if (!config.enabled) return;
     size_t nf = 0, np = 0;
     ctx_->check(mh_photo_num_features(photo_, &nf, &np), "mh_photo_num_features");
     debug_.n_features_tracked = nf;
     if (!nf) return;
-    M66 VSVt{};
+    double VSVt[36];  // row-major for the C ABI
     for (int i = 0; i < 6; ++i)
       for (int j = 0; j < 6; ++j) {
         double s = 0;
-        for (int k = 0; k < 6; ++k) s += eigenvectors_block_matrix[6 * i + k] * selection[k] * eigenvectors_block_matrix[6 * j + k];
+        for (int k = 0; k < 6; ++k) s += eigenvectors_block_matrix(i, k) * selection(k) * eigenvectors_block_matrix(j, k);
         VSVt[6 * i + j] = s;
       }
-    photometric_factor_.reset(new PhotometricFactor(ctx_, {key_}, false));
-    ctx_->check(mh_photo_factor_create(photo_, VSVt.data(), 0, &photometric_factor_->f_), "mh_photo_factor_create");
+    photometric_factor_.reset(new PhotometricFactor(ctx_, KeyVector{key_}, false));
+    ctx_->check(mh_photo_factor_create(photo_, VSVt, 0, &photometric_factor_->f_), "mh_photo_factor_create");
     debug_.n_features_in_factor = nf;
     graph.add(photometric_factor_);
   }
@@ -326,11 +326,14 @@ public:
   void updateMap(const Values & values, const std::vector<V3D> & bias_directions = {})
   {
     if (!config.enabled) return;
-    const Pose3 & T_W_Be = values.atPose3(key_);
+    const PoseRM T_W_Be = rowMajor(values.at<Pose3>(key_));
+    std::vector<double> bias(3 * bias_directions.size());
+    for (size_t i = 0; i < bias_directions.size(); ++i)
+      for (int k = 0; k < 3; ++k) bias[3 * i + k] = bias_directions[i](k);
     if (photometric_factor_)
       for (int i = 0; i < 9; ++i) debug_.n_status[i] = photometric_factor_->lastResult().status_hist[i];
     ctx_->check(mh_photo_update_map(photo_, photometric_factor_ ? photometric_factor_->underlying() : nullptr, T_W_Be.R.data(),
-                                    T_W_Be.t.data(), bias_directions.empty() ? nullptr : bias_directions[0].data(), bias_directions.size()),
+                                    T_W_Be.t.data(), bias.empty() ? nullptr : bias.data(), bias_directions.size()),
                 "mh_photo_update_map");
     photometric_factor_.reset();  // the factor stays alive in the graph that holds it
   }
@@ -349,11 +352,11 @@ public:
       f.id = h[i].id;
       f.life_time = h[i].life_time;
       f.center = {h[i].center[0], h[i].center[1]};
-      f.normal = {h[i].normal[0], h[i].normal[1], h[i].normal[2]};
+      f.normal = V3D(h[i].normal[0], h[i].normal[1], h[i].normal[2]);
       f.mean_intensity = h[i].mean_intensity;
       f.sigma_intensity = h[i].sigma_intensity;
       for (int k = 0; k < h[i].n_points; ++k, ++o) {
-        f.Le_ps.push_back({Le[3 * o], Le[3 * o + 1], Le[3 * o + 2]});
+        f.Le_ps.push_back(V3D(Le[3 * o], Le[3 * o + 1], Le[3 * o + 2]));
         f.intensities.push_back(in[o]);
         f.psi_intensities.push_back(psi[o]);
       }
@@ -372,11 +375,12 @@ public:
   const PhotometricFactor::Ptr & factor() const { return photometric_factor_; }
   mh_photo * underlying() { return photo_; }
 
-  static M66 identity66()
+  static M66 identity66() { return M66::Identity(); }
+  static V6D ones6()
   {
-    M66 I{};
-    for (int i = 0; i < 6; ++i) I[7 * i] = 1.0;
-    return I;
+    V6D v;
+    for (int i = 0; i < 6; ++i) v(i) = 1.0;
+    return v;
   }
 
 private:
@@ -386,8 +390,9 @@ private:
     T.resize(12 * m.size());
     for (size_t g = 0; g < m.size(); ++g) {
       ns[g] = m[g].first;
-      std::memcpy(&T[12 * g], m[g].second.R.data(), 72);
-      std::memcpy(&T[12 * g + 9], m[g].second.t.data(), 24);
+      const PoseRM p = rowMajor(m[g].second);
+      std::memcpy(&T[12 * g], p.R.data(), 72);
+      std::memcpy(&T[12 * g + 9], p.t.data(), 24);
     }
   }
   std::shared_ptr<Context> ctx_;

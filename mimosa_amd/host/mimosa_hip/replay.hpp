@@ -27,20 +27,52 @@ using lidar::Photometric;
 using lidar::PhotometricFactor;
 using lidar::ScanFrontEnd;
 
-inline M33 matmul(const M33 & a, const M33 & b)
+// The harness's own arithmetic runs on plain row-major arrays (bit for bit what mimosa_amd/replay.py computes with numpy);
+// gtsam::Pose3 / Values / HessianFactor appear where the mirror's classes are called, as they would in the reference.
+using A36 = std::array<double, 36>;
+struct RT
 {
-  M33 c{};
+  A9 R{1, 0, 0, 0, 1, 0, 0, 0, 1};
+  A3 t{0, 0, 0};
+};
+inline Pose3 toPose3(const RT & T) { return pose3(T.R.data(), T.t.data()); }
+inline A9 so3Expmap(const A3 & w)  // gtsam::Rot3::Expmap (Rodrigues)
+{
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+  const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double A, B;
+  if (th < 1e-10) {
+    A = 1.0 - th2 / 6.0;
+    B = 0.5 - th2 / 24.0;
+  } else {
+    A = std::sin(th) / th;
+    B = (1.0 - std::cos(th)) / th2;
+  }
+  A9 R{1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double kk = 0;
+      for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
+      R[3 * i + j] += A * K[3 * i + j] + B * kk;
+    }
+  return R;
+}
+
+
+inline A9 matmul(const A9 & a, const A9 & b)
+{
+  A9 c{};
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
   return c;
 }
-inline M33 transpose(const M33 & a) { return {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; }
-inline V3D matvec(const M33 & a, const V3D & v)
+inline A9 transpose(const A9 & a) { return {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}; }
+inline A3 matvec(const A9 & a, const A3 & v)
 {
   return {a[0] * v[0] + a[1] * v[1] + a[2] * v[2], a[3] * v[0] + a[4] * v[1] + a[5] * v[2], a[6] * v[0] + a[7] * v[1] + a[8] * v[2]};
 }
-inline M33 hat(const V3D & v) { return {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}; }
-inline V3D so3Log(const M33 & R)
+inline A9 hat(const A3 & v) { return {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}; }
+inline A3 so3Log(const A9 & R)
 {
   double c = (R[0] + R[4] + R[8] - 1.0) / 2.0;
   c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
@@ -49,25 +81,25 @@ inline V3D so3Log(const M33 & R)
   return {(R[7] - R[5]) * s, (R[2] - R[6]) * s, (R[3] - R[1]) * s};
 }
 // T <- T * Exp(xi), first order in the translation
-inline void retract(Pose3 & T, const double * xi)
+inline void retract(RT & T, const double * xi)
 {
-  const V3D d = matvec(T.R, {xi[3], xi[4], xi[5]});
-  T.R = matmul(T.R, lidar::so3Expmap({xi[0], xi[1], xi[2]}));
+  const A3 d = matvec(T.R, {xi[3], xi[4], xi[5]});
+  T.R = matmul(T.R, so3Expmap({xi[0], xi[1], xi[2]}));
   for (int i = 0; i < 3; ++i) T.t[i] += d[i];
 }
-inline Pose3 between(const Pose3 & a, const Pose3 & b)
+inline RT between(const RT & a, const RT & b)
 {
-  Pose3 r;
-  const M33 Rt = transpose(a.R);
+  RT r;
+  const A9 Rt = transpose(a.R);
   r.R = matmul(Rt, b.R);
   r.t = matvec(Rt, {b.t[0] - a.t[0], b.t[1] - a.t[1], b.t[2] - a.t[2]});
   return r;
 }
 // Ad(R, t) in (rotation, translation) tangent order
-inline M66 adjoint(const M33 & R, const V3D & t)
+inline A36 adjoint(const A9 & R, const A3 & t)
 {
-  M66 A{};
-  const M33 hR = matmul(hat(t), R);
+  A36 A{};
+  const A9 hR = matmul(hat(t), R);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
       A[6 * i + j] = R[3 * i + j];
@@ -107,19 +139,19 @@ inline std::vector<double> solve(std::vector<double> A, std::vector<double> b)
 struct ImuSamples
 {
   std::vector<double> ts;
-  std::vector<V3D> gyro, acc;
+  std::vector<A3> gyro, acc;
 };
 struct State
 {
-  Pose3 T;
-  V3D vel{0, 0, 0};
+  RT T;
+  A3 vel{0, 0, 0};
 };
 
 // Manager::deskewPoints' host part (src/lidar/manager.cpp:455-499): states at the IMU sample times by integrating sample
 // to sample, then constant-acc / omega extrapolation to every distinct timestamp.  `s0` = state at the first sample.
 // Returns T_W_Bt per timestamp; `last` = state at the last sample.
-inline std::vector<Pose3> propagate(const State & s0, const ImuSamples & imu, const double header_ts, const std::vector<uint32_t> & unique_ns,
-                                    const V3D & gravity, State & last)
+inline std::vector<RT> propagate(const State & s0, const ImuSamples & imu, const double header_ts, const std::vector<uint32_t> & unique_ns,
+                                    const A3 & gravity, State & last)
 {
   const size_t m = imu.ts.size();
   if (m < 2) throw std::runtime_error("Preintegration not possible as there are less than 2 measurements P1");  // :442-446
@@ -127,23 +159,23 @@ inline std::vector<Pose3> propagate(const State & s0, const ImuSamples & imu, co
   st[0] = s0;
   for (size_t c = 0; c + 1 < m; ++c) {
     const double d = imu.ts[c + 1] - imu.ts[c];
-    const V3D Ra = matvec(st[c].T.R, imu.acc[c]);
-    const V3D aw{Ra[0] + gravity[0], Ra[1] + gravity[1], Ra[2] + gravity[2]};
-    st[c + 1].T.R = matmul(st[c].T.R, lidar::so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d}));
+    const A3 Ra = matvec(st[c].T.R, imu.acc[c]);
+    const A3 aw{Ra[0] + gravity[0], Ra[1] + gravity[1], Ra[2] + gravity[2]};
+    st[c + 1].T.R = matmul(st[c].T.R, so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d}));
     for (int i = 0; i < 3; ++i) {
       st[c + 1].T.t[i] = st[c].T.t[i] + st[c].vel[i] * d + 0.5 * aw[i] * d * d;
       st[c + 1].vel[i] = st[c].vel[i] + aw[i] * d;
     }
   }
-  std::vector<Pose3> out(unique_ns.size());
+  std::vector<RT> out(unique_ns.size());
   size_t c = 0;
   for (size_t u = 0; u < unique_ns.size(); ++u) {
     const double tq = header_ts + unique_ns[u] * 1.0e-9;
     while (c + 2 < m && imu.ts[c + 1] < tq) ++c;  // interval with ts[c] < tq <= ts[c + 1] (:470-476)
     const double d = tq - imu.ts[c];
-    const M33 E = lidar::so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d});
+    const A9 E = so3Expmap({imu.gyro[c][0] * d, imu.gyro[c][1] * d, imu.gyro[c][2] * d});
     out[u].R = matmul(st[c].T.R, E);
-    const V3D Ra = matvec(st[c].T.R, imu.acc[c]);
+    const A3 Ra = matvec(st[c].T.R, imu.acc[c]);
     for (int i = 0; i < 3; ++i) out[u].t[i] = st[c].T.t[i] + st[c].vel[i] * d + 0.5 * Ra[i] * d * d + 0.5 * gravity[i] * d * d;
   }
   last = st[m - 1];
@@ -157,7 +189,7 @@ struct Config
   double between_sigma_rot = 2e-3, between_sigma_trans = 1e-2;
   double keyframe_trans_thresh = 1.0, keyframe_rot_thresh_deg = 20.0;
   bool photometric = true;
-  V3D gravity{0.0, 0.0, -9.81};
+  A3 gravity{0.0, 0.0, -9.81};
   lidar::RegistrationConfig reg = lidar::defaultRegistrationConfig();
   lidar::ManagerInputConfig input = lidar::defaultManagerInputConfig();
   size_t neighbor_voxel_mode = 19;
@@ -174,7 +206,7 @@ struct ScanInput
 
 struct Result
 {
-  std::vector<Pose3> poses;
+  std::vector<RT> poses;
   std::vector<int> photo_valid;
   std::vector<std::vector<double>> costs;
   int n_keyframes = 0;
@@ -210,13 +242,13 @@ public:
     struct Live
     {
       size_t k;
-      Pose3 T;
+      RT T;
       ICPFactor::Ptr f;
       bool has_Z;
-      Pose3 Z;
+      RT Z;
     };
     std::deque<Live> win;
-    std::vector<Pose3> kf_poses;
+    std::vector<RT> kf_poses;
     State prev = state0;
     bool have_prev = false;
     const double wr = 1.0 / (cfg_.between_sigma_rot * cfg_.between_sigma_rot), wt = 1.0 / (cfg_.between_sigma_trans * cfg_.between_sigma_trans);
@@ -229,19 +261,21 @@ public:
       scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
       const auto a1 = clk::now();
       State pred;
-      const std::vector<Pose3> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
+      const std::vector<RT> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
       std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
       {
-        const M33 Rt = transpose(pred.T.R);
+        const A9 Rt = transpose(pred.T.R);
         for (size_t g = 0; g < T_W_Bt.size(); ++g) {
-          T_Le_Lt[g].R = matmul(Rt, T_W_Bt[g].R);
-          T_Le_Lt[g].t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
+          RT d;
+          d.R = matmul(Rt, T_W_Bt[g].R);
+          d.t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
+          T_Le_Lt[g] = toPose3(d);
         }
       }
       const auto a2 = clk::now();
       scan_.deskewPoints(T_Le_Lt);
-      const Key X = static_cast<Key>(k);
-      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, X);
+      const Key Xk = X(k);
+      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
       ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
                                                cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
                   "mh_scan_preprocess_geometric");
@@ -249,14 +283,14 @@ public:
       Live lv;
       lv.k = k;
       lv.T = pred.T;
-      lv.f = std::make_shared<ICPFactor>(X, map_, scan_, cfg_.reg);
+      lv.f = std::make_shared<ICPFactor>(Xk, map_, scan_, cfg_.reg);
       lv.f->computeComponents(false);  // the loop below only takes H, b, f
       lv.has_Z = have_prev;
       if (have_prev) lv.Z = between(prev.T, pred.T);
       Values values;
       NonlinearFactorGraph photo_graph;
       if (photo_) {
-        values.insert(X, pred.T);
+        values.insert(Xk, toPose3(pred.T));
         photo_->getFactors(values, photo_graph);  // no factor while nothing is tracked (photometric.cpp:381)
       }
       PhotometricFactor::Ptr pf = photo_ ? photo_->factor() : nullptr;
@@ -269,9 +303,10 @@ public:
       for (int it = 0; it < cfg_.update_iters; ++it) {
         std::vector<ICPFactor::Ptr> factors(nW);
         Values v;
+        v.insert(G(0), Unit3(0.0, 0.0, -1.0));  // the gravity direction ICPFactor::linearize reads (geometric_factor.hpp:257)
         for (size_t i = 0; i < nW; ++i) {
           factors[i] = win[i].f;
-          v.insert(static_cast<Key>(win[i].k), win[i].T);
+          v.insert(X(win[i].k), toPose3(win[i].T));
         }
         if (pf) pf->linearizeAsync(v);  // queued ahead of the window: one wait for both
         const auto lin = ICPFactor::linearizeBatch(factors, v);
@@ -279,37 +314,41 @@ public:
         double cost = 0.0;
         for (size_t i = 0; i < nW; ++i) {
           const auto & h = *std::static_pointer_cast<HessianFactor>(lin[i]);
+          const gtsam::Matrix Gi = h.information();
+          const gtsam::Vector gi = h.linearTerm();
           for (int r = 0; r < 6; ++r) {
-            for (int c = 0; c < 6; ++c) A[(6 * i + r) * dim + 6 * i + c] += h.G11[6 * r + c];
-            g[6 * i + r] += -h.g1[r];  // the HessianFactor carries -b
+            for (int c = 0; c < 6; ++c) A[(6 * i + r) * dim + 6 * i + c] += Gi(r, c);
+            g[6 * i + r] += -gi(r);  // the HessianFactor carries -b
           }
-          cost += h.f;
+          cost += h.constantTerm();
         }
         if (pf) {
           const auto hp = std::static_pointer_cast<HessianFactor>(pf->collect());
           bool finite = pf->lastResult().status_hist[8] > 0;
-          for (int q = 0; q < 36 && finite; ++q) finite = std::isfinite(hp->G11[q]);
-          for (int q = 0; q < 6 && finite; ++q) finite = std::isfinite(hp->g1[q]);
+          const gtsam::Matrix Gp = hp->information();
+          const gtsam::Vector gp = hp->linearTerm();
+          for (int q = 0; q < 36 && finite; ++q) finite = std::isfinite(Gp(q / 6, q % 6));
+          for (int q = 0; q < 6 && finite; ++q) finite = std::isfinite(gp(q));
           if (finite) {
             const size_t o = 6 * (nW - 1);
             for (int r = 0; r < 6; ++r) {
-              for (int c = 0; c < 6; ++c) A[(o + r) * dim + o + c] += hp->G11[6 * r + c];
-              g[o + r] += -hp->g1[r];
+              for (int c = 0; c < 6; ++c) A[(o + r) * dim + o + c] += Gp(r, c);
+              g[o + r] += -gp(r);
             }
-            cost += hp->f;
+            cost += hp->constantTerm();
           }
         }
         for (size_t i = 1; i < nW; ++i) {
           if (!win[i].has_Z) continue;
-          const Pose3 ab = between(win[i - 1].T, win[i].T);
-          const M33 Rzt = transpose(win[i].Z.R);
-          const M33 Re = matmul(Rzt, ab.R);
-          const V3D te = matvec(Rzt, {ab.t[0] - win[i].Z.t[0], ab.t[1] - win[i].Z.t[1], ab.t[2] - win[i].Z.t[2]});  // Z^-1 * between
-          const V3D lr = so3Log(Re);
+          const RT ab = between(win[i - 1].T, win[i].T);
+          const A9 Rzt = transpose(win[i].Z.R);
+          const A9 Re = matmul(Rzt, ab.R);
+          const A3 te = matvec(Rzt, {ab.t[0] - win[i].Z.t[0], ab.t[1] - win[i].Z.t[1], ab.t[2] - win[i].Z.t[2]});  // Z^-1 * between
+          const A3 lr = so3Log(Re);
           const double r[6] = {lr[0], lr[1], lr[2], te[0], te[1], te[2]};
-          const M33 Rabt = transpose(ab.R);
-          const V3D tinv = matvec(Rabt, {-ab.t[0], -ab.t[1], -ab.t[2]});
-          const M66 Ad = adjoint(Rabt, tinv);  // J_a = -Ad(between^-1), J_b = I
+          const A9 Rabt = transpose(ab.R);
+          const A3 tinv = matvec(Rabt, {-ab.t[0], -ab.t[1], -ab.t[2]});
+          const A36 Ad = adjoint(Rabt, tinv);  // J_a = -Ad(between^-1), J_b = I
           // A += J^T W J, g += J^T W r over the two 6-blocks (a = i - 1, b = i)
           const size_t oa = 6 * (i - 1), ob = 6 * i;
           for (int p = 0; p < 6; ++p)
@@ -346,7 +385,7 @@ public:
       }
       res.costs.push_back(fs);
       const auto a5 = clk::now();
-      const Pose3 T = win.back().T;
+      const RT T = win.back().T;
       // ---- Geometric::updateMap's keyframe test (geometric.cpp:445-478)
       bool is_kf = true;
       if (!kf_poses.empty()) {
@@ -360,19 +399,19 @@ public:
             j = i;
           }
         }
-        const M33 d = matmul(transpose(kf_poses[j].R), T.R);
+        const A9 d = matmul(transpose(kf_poses[j].R), T.R);
         const double yaw = std::atan2(d[3], d[0]), pitch = std::atan2(-d[6], std::hypot(d[7], d[8])), roll = std::atan2(d[7], d[8]);
         const double ypr = std::max(std::fabs(yaw), std::max(std::fabs(pitch), std::fabs(roll)));
         is_kf = best > cfg_.keyframe_trans_thresh || ypr > cfg_.keyframe_rot_thresh_deg * 0.017453293;
       }
       if (is_kf) {
         map_ = map_->fork();  // copy-then-insert (geometric.cpp:494-495): live factors keep the map they were built on
-        map_->insertBodyCloud(scan_.underlying(), T);
+        map_->insertBodyCloud(scan_.underlying(), toPose3(T));
         kf_poses.push_back(T);
         ++res.n_keyframes;
       }
       if (photo_) {
-        values.update(X, T);
+        values.update(Xk, toPose3(T));
         if (pf) {
           (void)pf->linearize(values);  // statuses / centres at the final pose feed the bookkeeping
           res.photo_valid.push_back(pf->lastResult().status_hist[8]);

@@ -1,16 +1,30 @@
-// Minimal value types for the host mirror of the reference's LiDAR classes.
+// Value types of the host mirror: GTSAM's own.
 //
-// The reference's ICPFactor is a gtsam::NonlinearFactor and returns a gtsam::HessianFactor
-// (include/mimosa/lidar/geometric_factor.hpp:25, :459-462, :559-560).  GTSAM is not available in this
-// build environment, so the mirror is written against this small interface whose names and
-// signatures follow GTSAM's: compile with -DMIMOSA_HIP_WITH_GTSAM and provide the aliases below from
-// <gtsam/...> to drop the classes into a real factor graph.
+// The reference's ICPFactor is a gtsam::NonlinearFactor that reads c.at<gtsam::Pose3>(key) / c.at<gtsam::Unit3>(G(0)) and
+// returns a gtsam::HessianFactor (include/mimosa/lidar/geometric_factor.hpp:25, :247-257, :459-462, :559-560); its V3D / M33 /
+// M66 / V6D are Eigen typedefs (include/mimosa/utils.hpp).  The mirror is written against exactly those headers and
+// signatures — there is no #ifdef and no second code path.  What <gtsam/...> resolves to is decided by the include path:
+// a GTSAM installation in a deployment, or host/gtsam_sig (a signature stub: same paths, namespaces and member
+// signatures, just enough behaviour for the tests) in this build environment, where GTSAM and Eigen are absent.
+//
+// The C ABI underneath speaks plain row-major double arrays; the helpers at the end convert (element-wise: Eigen matrices
+// are column-major, nothing here relies on a memory layout).
 #pragma once
+
+#include <gtsam/base/Matrix.h>
+#include <gtsam/base/Vector.h>
+#include <gtsam/geometry/Pose3.h>
+#include <gtsam/geometry/Unit3.h>
+#include <gtsam/inference/Symbol.h>
+#include <gtsam/linear/HessianFactor.h>
+#include <gtsam/navigation/NavState.h>
+#include <gtsam/nonlinear/NonlinearFactor.h>
+#include <gtsam/nonlinear/NonlinearFactorGraph.h>
+#include <gtsam/nonlinear/Values.h>
 
 #include <array>
 #include <cmath>
 #include <cstdint>
-#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -18,94 +32,66 @@
 
 namespace mimosa_hip
 {
-using Key = std::uint64_t;
-using V3D = std::array<double, 3>;
-using M33 = std::array<double, 9>;   // row-major
-using M66 = std::array<double, 36>;  // row-major
-using V6D = std::array<double, 6>;
+using gtsam::GaussianFactor;
+using gtsam::HessianFactor;
+using gtsam::Key;
+using gtsam::KeyVector;
+using gtsam::NonlinearFactor;
+using gtsam::NonlinearFactorGraph;
+using gtsam::Point3;
+using gtsam::Pose3;
+using gtsam::Rot3;
+using gtsam::Unit3;
+using gtsam::Values;
+using gtsam::symbol_shorthand::G;  // the gravity direction lives under G(0) (geometric_factor.hpp:257)
+using gtsam::symbol_shorthand::X;
 
-// gtsam::Pose3 subset (rotation matrix + translation)
-struct Pose3
+// include/mimosa/utils.hpp: V3D = Eigen::Vector3d, M33 = Eigen::Matrix3d, M66, V6D
+using V3D = gtsam::Vector3;
+using M33 = gtsam::Matrix3;
+using M66 = gtsam::Matrix6;
+using V6D = gtsam::Vector6;
+
+// ---- plain row-major arrays <-> GTSAM / Eigen values (the C ABI's side of the boundary) ------------------------------
+using A3 = std::array<double, 3>;
+using A9 = std::array<double, 9>;  // row-major 3 x 3
+
+inline A9 rowMajor(const gtsam::Matrix3 & M)
 {
-  M33 R{1, 0, 0, 0, 1, 0, 0, 0, 1};
-  V3D t{0, 0, 0};
-  static Pose3 Identity() { return Pose3(); }
-  Pose3 inverse() const
-  {
-    Pose3 r;
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) r.R[3 * i + j] = R[3 * j + i];
-    for (int i = 0; i < 3; ++i) r.t[i] = -(r.R[3 * i] * t[0] + r.R[3 * i + 1] * t[1] + r.R[3 * i + 2] * t[2]);
-    return r;
-  }
-  Pose3 operator*(const Pose3 & o) const
-  {
-    Pose3 r;
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        r.R[3 * i + j] = R[3 * i] * o.R[j] + R[3 * i + 1] * o.R[3 + j] + R[3 * i + 2] * o.R[6 + j];
-    for (int i = 0; i < 3; ++i) r.t[i] = t[i] + R[3 * i] * o.t[0] + R[3 * i + 1] * o.t[1] + R[3 * i + 2] * o.t[2];
-    return r;
-  }
-  const V3D & translation() const { return t; }
-  const M33 & rotation() const { return R; }
-};
-
-// gtsam::Values subset: poses by key + the gravity direction Unit3 stored under G(0)
-// (linearize reads it unconditionally, geometric_factor.hpp:257)
-class Values
+  A9 a;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) a[3 * r + c] = M(r, c);
+  return a;
+}
+inline A3 toArray(const gtsam::Vector3 & v) { return A3{v(0), v(1), v(2)}; }
+inline M33 matrix3(const double * rm)
 {
-public:
-  void insert(Key k, const Pose3 & p) { poses_[k] = p; }
-  void update(Key k, const Pose3 & p) { poses_[k] = p; }
-  const Pose3 & atPose3(Key k) const
-  {
-    auto it = poses_.find(k);
-    if (it == poses_.end()) throw std::out_of_range("Values: no Pose3 for key");
-    return it->second;
-  }
-  void setGravity(const V3D & unit) { g_ = unit; }
-  const V3D & gravityUnit() const { return g_; }
-
-private:
-  std::map<Key, Pose3> poses_;
-  V3D g_{0, 0, -1};
-};
-
-// gtsam::HessianFactor as ICPFactor constructs it: unary (key, G, g, f) or binary
-// (k1, k2, G11, G12, g1, G22, g2, f); error = 0.5 x'Gx - x'g + 0.5 f
-struct GaussianFactor
+  M33 M;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) M(r, c) = rm[3 * r + c];
+  return M;
+}
+inline V3D vector3(const double * v) { return V3D(v[0], v[1], v[2]); }
+inline M66 matrix6(const double * rm)
 {
-  virtual ~GaussianFactor() = default;
-};
-struct HessianFactor : GaussianFactor
+  M66 M;
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) M(r, c) = rm[6 * r + c];
+  return M;
+}
+// a pose as the C ABI takes it: R row-major, t
+struct PoseRM
 {
-  std::vector<Key> keys;
-  M66 G11{}, G12{}, G22{};
-  V6D g1{}, g2{};
-  double f = 0.0;
+  A9 R;
+  A3 t;
 };
-
-class NonlinearFactor
+inline PoseRM rowMajor(const Pose3 & T) { return PoseRM{rowMajor(T.rotation().matrix()), toArray(T.translation())}; }
+inline Pose3 pose3(const double * R_rm, const double * t) { return Pose3(Rot3(matrix3(R_rm)), Point3(t[0], t[1], t[2])); }
+inline void toFloat12(const Pose3 & T, float * Rt12)  // {R row-major 9, t 3} in float: mh_deskew / mh_transform_f32
 {
-public:
-  using shared_ptr = std::shared_ptr<NonlinearFactor>;
-  explicit NonlinearFactor(std::vector<Key> keys) : keys_(std::move(keys)) {}
-  virtual ~NonlinearFactor() = default;
-  const std::vector<Key> & keys() const { return keys_; }
-  virtual std::shared_ptr<GaussianFactor> linearize(const Values & c) const = 0;
-  virtual shared_ptr clone() const = 0;
-  virtual size_t dim() const = 0;
-  virtual double error(const Values & c) const = 0;
-
-private:
-  std::vector<Key> keys_;
-};
-
-struct NonlinearFactorGraph
-{
-  std::vector<NonlinearFactor::shared_ptr> factors;
-  void add(const NonlinearFactor::shared_ptr & f) { factors.push_back(f); }
-};
+  const PoseRM p = rowMajor(T);
+  for (int i = 0; i < 9; ++i) Rt12[i] = static_cast<float>(p.R[i]);
+  for (int i = 0; i < 3; ++i) Rt12[9 + i] = static_cast<float>(p.t[i]);
+}
 
 }  // namespace mimosa_hip

@@ -40,7 +40,7 @@ int main(int argc, char ** argv)
     std::memcpy(&cfg.input, inpb.data(), sizeof(cfg.input));
     if (cfg.photometric) cfg.photo = binio::read_photo_config(f);
     const auto bias = read_vec<double>(f);
-    for (size_t i = 0; i + 2 < bias.size(); i += 3) cfg.bias_directions.push_back({bias[i], bias[i + 1], bias[i + 2]});
+    for (size_t i = 0; i + 2 < bias.size(); i += 3) cfg.bias_directions.push_back(V3D(bias[i], bias[i + 1], bias[i + 2]));
     const auto seed = read_vec<float>(f);
     const auto s0 = read_vec<double>(f);  // R (9), t (3), velocity (3): the state at the first IMU sample of the first sweep
     const auto nsc = read_vec<int32_t>(f);
@@ -56,7 +56,9 @@ int main(int argc, char ** argv)
       sc.header_ts = read_vec<double>(f).at(0);
     }
     replay::State st0;
-    st0.T = binio::pose_from(s0.data());
+    if (s0.size() < 15) throw std::runtime_error("the initial state needs 15 doubles");
+    for (int i = 0; i < 9; ++i) st0.T.R[i] = s0[i];
+    for (int i = 0; i < 3; ++i) st0.T.t[i] = s0[9 + i];
     st0.vel = {s0[12], s0[13], s0[14]};
     auto ctx = std::make_shared<lidar::Context>(0);
     replay::Result r;

@@ -30,25 +30,19 @@ int main(int argc, char ** argv)
   std::vector<V3D> acc(imu_t.size()), gyro(imu_t.size());
   std::vector<NavState> nav(imu_t.size());
   for (size_t j = 0; j < imu_t.size(); ++j) {
-    for (int i = 0; i < 3; ++i) {
-      acc[j][i] = meas[6 * j + i];
-      gyro[j][i] = meas[6 * j + 3 + i];
-      nav[j].pose.t[i] = navd[15 * j + 9 + i];
-      nav[j].velocity[i] = navd[15 * j + 12 + i];
-    }
-    for (int i = 0; i < 9; ++i) nav[j].pose.R[i] = navd[15 * j + i];
+    acc[j] = vector3(&meas[6 * j]);
+    gyro[j] = vector3(&meas[6 * j + 3]);
+    nav[j] = NavState(pose3(&navd[15 * j], &navd[15 * j + 9]), vector3(&navd[15 * j + 12]));
   }
-  Pose3 T_B_S;
-  for (int i = 0; i < 9; ++i) T_B_S.R[i] = misc[11 + i];
-  for (int i = 0; i < 3; ++i) T_B_S.t[i] = misc[20 + i];
+  const Pose3 T_B_S = pose3(&misc[11], &misc[20]);
   try {
-    const auto poses = computeDeskewPoses(imu_t, acc, gyro, nav, {misc[0], misc[1], misc[2]}, {misc[3], misc[4], misc[5]},
-                                          {misc[6], misc[7], misc[8]}, misc[9], uns, misc[10], T_B_S);
+    const auto poses = computeDeskewPoses(imu_t, acc, gyro, nav, vector3(&misc[0]), vector3(&misc[3]), vector3(&misc[6]), misc[9], uns, misc[10], T_B_S);
     std::printf("[");
     for (size_t g = 0; g < poses.size(); ++g) {
       std::printf("%s[", g ? ",\n" : "");
-      for (int i = 0; i < 9; ++i) std::printf("%.17g, ", poses[g].R[i]);
-      for (int i = 0; i < 3; ++i) std::printf("%.17g%s", poses[g].t[i], i < 2 ? ", " : "");
+      const PoseRM p = rowMajor(poses[g]);
+      for (int i = 0; i < 9; ++i) std::printf("%.17g, ", p.R[i]);
+      for (int i = 0; i < 3; ++i) std::printf("%.17g%s", p.t[i], i < 2 ? ", " : "");
       std::printf("]");
     }
     std::printf("]\n");

@@ -4,6 +4,7 @@
 // on inputs written by tests/test_gpu_host_cpp.py, and prints the results as JSON for comparison with
 // the oracle.  Input file: little-endian, see read_* below.
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -21,12 +22,28 @@ static std::vector<T> read_vec(std::ifstream & f)
   f.read(reinterpret_cast<char *>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
   return v;
 }
-static Pose3 pose_from(const double * p)
+static Pose3 pose_from(const double * p) { return pose3(p, p + 9); }
+// what a GTSAM consumer reads off the returned factor
+struct Flat
 {
-  Pose3 T;
-  for (int i = 0; i < 9; ++i) T.R[i] = p[i];
-  for (int i = 0; i < 3; ++i) T.t[i] = p[9 + i];
-  return T;
+  double H[36], g[6], f;
+  bool operator==(const Flat & o) const { return !std::memcmp(this, &o, sizeof(Flat)); }
+};
+static Flat flat(const HessianFactor & h)
+{
+  Flat o;
+  const gtsam::Matrix G = h.information();
+  const gtsam::Vector g = h.linearTerm();
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c < 6; ++c) o.H[6 * r + c] = G(r, c);
+    o.g[r] = g(r);
+  }
+  o.f = h.constantTerm();
+  return o;
+}
+static void dump(const char * name, const V3D & v, bool last = false)
+{
+  std::printf("\"%s\": [%.17g, %.17g, %.17g]%s\n", name, v(0), v(1), v(2), last ? "" : ",");
 }
 static void dump(const char * name, const double * v, int n, bool last = false)
 {
@@ -37,16 +54,18 @@ static void dump(const char * name, const double * v, int n, bool last = false)
 static void dump_factor(const char * tag, const Geometric & g, const HessianFactor & h, const V6D & degen)
 {
   std::printf("\"%s\": {\n", tag);
-  dump("H", h.G11.data(), 36);
-  dump("g", h.g1.data(), 6);
-  std::printf("\"f\": %.17g,\n", h.f);
+  const Flat fl = flat(h);
+  dump("H", fl.H, 36);
+  dump("g", fl.g, 6);
+  std::printf("\"f\": %.17g,\n", fl.f);
   std::printf("\"n_ds\": %zu,\n", g.debug().n_points_in_sm_ds);
   std::printf("\"status_hist\": [");
   for (int i = 0; i < 9; ++i) std::printf("%d%s", g.debug().n_status[i], i < 8 ? ", " : "");
   std::printf("],\n");
-  dump("loc_trans_comp", g.debug().localizability_trans_comp.data(), 3);
-  dump("loc_rot_comp", g.debug().localizability_rot_comp.data(), 3);
-  dump("degen_directions", degen.data(), 6, true);
+  dump("loc_trans_comp", g.debug().localizability_trans_comp);
+  dump("loc_rot_comp", g.debug().localizability_rot_comp);
+  const double dd[6] = {degen(0), degen(1), degen(2), degen(3), degen(4), degen(5)};
+  dump("degen_directions", dd, 6, true);
   std::printf("}");
 }
 
@@ -89,22 +108,23 @@ int main(int argc, char ** argv)
       if (scan[i].idx % static_cast<uint32_t>(cfg.point_skip_divisor) == 0) idxs.push_back(i);
     geo.preprocess(scan, idxs, 0.0);
 
-    const Key X0 = 1;
+    const Key X0 = X(1);
     Values values;
     values.insert(X0, pose_from(&misc[12]));
+    values.insert(G(0), Unit3(0.0, 0.0, -1.0));  // the gravity direction linearize() reads unconditionally (geometric_factor.hpp:257)
     NonlinearFactorGraph graph;
     M66 evecs;
     V6D degen;
     geo.getFactors(X0, values, graph, evecs, degen);
     std::printf("{\n");
-    auto h1 = std::static_pointer_cast<HessianFactor>(graph.factors[0]->linearize(values));  // relinearize: cache path
+    auto h1 = std::static_pointer_cast<HessianFactor>(graph.at(0)->linearize(values));  // relinearize: cache path
     dump_factor("first", geo, *h1, degen);
     std::printf(",\n\"linearize_count\": %d,\n", geo.factor()->getLinearizeCount());
 
     // clone keeps working independently (ISAM2 clones factors)
-    auto cl = graph.factors[0]->clone();
+    auto cl = graph.at(0)->clone();
     auto hc = std::static_pointer_cast<HessianFactor>(cl->linearize(values));
-    std::printf("\"clone_f\": %.17g,\n", hc->f);
+    std::printf("\"clone_f\": %.17g,\n", hc->constantTerm());
 
     geo.updateMap(X0, values);  // first keyframe is forced; map becomes a copy + this scan
     std::printf("\"map_updated\": %d,\n", geo.debug().map_updated ? 1 : 0);
@@ -113,7 +133,7 @@ int main(int argc, char ** argv)
     values.update(X0, pose_from(&misc[24]));
     NonlinearFactorGraph graph2;
     geo.getFactors(X0, values, graph2, evecs, degen);
-    auto h2 = std::static_pointer_cast<HessianFactor>(graph2.factors[0]->linearize(values));
+    auto h2 = std::static_pointer_cast<HessianFactor>(graph2.at(0)->linearize(values));
     dump_factor("second", geo, *h2, degen);
     geo.updateMap(X0, values);  // too close to the first keyframe: no update
     std::printf(",\n\"map_updated_2\": %d,\n", geo.debug().map_updated ? 1 : 0);
@@ -134,14 +154,14 @@ int main(int argc, char ** argv)
       values.update(X0, pose_from(&misc[12]));
       NonlinearFactorGraph graph3;
       geo2.getFactors(X0, values, graph3, evecs, degen);
-      auto h3 = std::static_pointer_cast<HessianFactor>(graph3.factors[0]->linearize(values));
+      auto h3 = std::static_pointer_cast<HessianFactor>(graph3.at(0)->linearize(values));
       dump_factor("first_device_frontend", geo2, *h3, degen);
       // the window in one pass: the device factor and a clone of it at two poses ≡ their own linearize calls
       std::vector<ICPFactor::Ptr> window{geo2.factor(), std::static_pointer_cast<ICPFactor>(geo2.factor()->clone())};
       const auto hb = ICPFactor::linearizeBatch(window, values);
       const auto hs = std::static_pointer_cast<HessianFactor>(window[1]->linearize(values));
       const auto hb1 = std::static_pointer_cast<HessianFactor>(hb[1]);
-      std::printf(",\n\"batch_equal\": %d", (hb1->G11 == hs->G11 && hb1->g1 == hs->g1 && hb1->f == hs->f) ? 1 : 0);
+      std::printf(",\n\"batch_equal\": %d", (flat(*hb1) == flat(*hs)) ? 1 : 0);
       geo2.updateMap(X0, values);  // Be_cloud_ never left the device: transform + insert there
       std::printf(",\n\"map_points_after_device\": %zu", geo2.map()->getCloud().size());
       std::printf(",\n\"corrected_ts\": %.9f\n}\n", fe.correctedTs());

@@ -28,7 +28,7 @@ int main(int argc, char ** argv)
   const PhotometricConfig cfg = binio::read_photo_config(f);
   const auto bias = read_vec<double>(f);
   std::vector<V3D> bias_directions;
-  for (size_t i = 0; i + 2 < bias.size(); i += 3) bias_directions.push_back({bias[i], bias[i + 1], bias[i + 2]});
+  for (size_t i = 0; i + 2 < bias.size(); i += 3) bias_directions.push_back(V3D(bias[i], bias[i + 1], bias[i + 2]));
   try {
     auto ctx = std::make_shared<Context>(0);
     Photometric photo(ctx, cfg);
@@ -41,31 +41,44 @@ int main(int argc, char ** argv)
       const auto T = read_vec<double>(f);
       const auto pose = read_vec<double>(f);
       std::vector<std::pair<uint32_t, Pose3>> interp(ns.size());
-      for (size_t g = 0; g < ns.size(); ++g) interp[g] = {ns[g], pose_from(&T[12 * g])};
-      const Key X = static_cast<Key>(10 + k);
-      values.insert(X, pose_from(pose.data()));
-      photo.preprocess(raw, desk, interp, 0.1 * k, X);
+      for (size_t g = 0; g < ns.size(); ++g) interp[g] = {ns[g], pose3(&T[12 * g], &T[12 * g + 9])};
+      const Key Xk = X(10 + k);
+      values.insert(Xk, pose3(pose.data(), pose.data() + 9));
+      photo.preprocess(raw, desk, interp, 0.1 * k, Xk);
       double isum = 0;  // corrected intensities were written back into the deskewed cloud (photometric.cpp:307-314)
       for (const Point & p : desk) isum += p.intensity;
       std::printf("\"intensity_sum_%d\": %.17g,\n", k, isum);
       NonlinearFactorGraph graph;
       photo.getFactors(values, graph);  // frame 0: no features yet -> no factor (photometric.cpp:381)
-      std::printf("\"n_factors_%d\": %zu,\n", k, graph.factors.size());
-      if (!graph.factors.empty()) {
-        auto h = std::static_pointer_cast<HessianFactor>(graph.factors[0]->linearize(values));
-        dump("H", h->G11.data(), 36);
-        dump("g", h->g1.data(), 6);
-        std::printf("\"f\": %.17g,\n", h->f);
+      std::printf("\"n_factors_%d\": %zu,\n", k, graph.size());
+      if (!graph.empty()) {
+        auto h = std::static_pointer_cast<HessianFactor>(graph.at(0)->linearize(values));
+        double H36[36], g6[6];
+        auto flat = [](const HessianFactor & hf, double * Hm, double * gv) {
+          const gtsam::Matrix G = hf.information();
+          const gtsam::Vector g = hf.linearTerm();
+          for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < 6; ++c) Hm[6 * r + c] = G(r, c);
+            gv[r] = g(r);
+          }
+        };
+        flat(*h, H36, g6);
+        dump("H", H36, 36);
+        dump("g", g6, 6);
+        std::printf("\"f\": %.17g,\n", h->constantTerm());
         std::printf("\"status_hist\": [");
         for (int i = 0; i < 9; ++i) std::printf("%d%s", photo.factor()->lastResult().status_hist[i], i < 8 ? ", " : "");
         std::printf("],\n");
         V3D tf, rf;
         M33 et, er;
         photo.factor()->getLocalizabilities(tf, rf, et, er);
-        dump("loc_trans_final", tf.data(), 3);
-        auto cl = graph.factors[0]->clone();  // ISAM2 clones factors
+        const double tf3[3] = {tf(0), tf(1), tf(2)};
+        dump("loc_trans_final", tf3, 3);
+        auto cl = graph.at(0)->clone();  // ISAM2 clones factors
         auto hc = std::static_pointer_cast<HessianFactor>(cl->linearize(values));
-        std::printf("\"clone_equal\": %d,\n", (hc->G11 == h->G11 && hc->g1 == h->g1 && hc->f == h->f) ? 1 : 0);
+        double Hc[36], gc[6];
+        flat(*hc, Hc, gc);
+        std::printf("\"clone_equal\": %d,\n", (!std::memcmp(Hc, H36, sizeof(Hc)) && !std::memcmp(gc, g6, sizeof(gc)) && hc->constantTerm() == h->constantTerm()) ? 1 : 0);
         int valid = 0;
         for (const auto s : photo.factor()->getStatuses()) valid += s == PhotometricFactor::RejectStatus::Valid;
         std::printf("\"n_valid\": %d,\n", valid);

@@ -21,7 +21,7 @@ def _exe():
     src = os.path.join(ROOT, "tests", "cpp", "deskew_poses.cpp")
     hdr = os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", "lidar.hpp")
     if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(exe):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, src, "-o", exe,
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, "-I", os.path.join(ROOT, "mimosa_amd", "host", "gtsam_sig"), src, "-o", exe,
                                "-L", os.path.dirname(lib), "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
     return exe
 

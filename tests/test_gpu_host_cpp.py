@@ -18,10 +18,12 @@ def build_exe(name="host_pipeline"):
     lib = build.build()
     exe = os.path.join(os.path.dirname(lib), name)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    hdrs = [os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", h) for h in ("lidar.hpp", "photometric.hpp", "types.hpp")]
+    hdrs = [os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", h) for h in ("lidar.hpp", "photometric.hpp", "types.hpp", "sharded.hpp", "binio.hpp")]
+    sig = os.path.join(ROOT, "mimosa_amd", "host", "gtsam_sig")
+    hdrs += [os.path.join(dp, f) for dp, _, fs in os.walk(sig) for f in fs]
     if not os.path.exists(exe) or max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(exe):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, src, "-o", exe,
-                               "-L", os.path.dirname(lib), "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", ROOT, "-I", os.path.join(ROOT, "mimosa_amd", "host", "gtsam_sig"), src, "-o", exe,
+                               "-L", os.path.dirname(lib), "-lmimosa_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return exe
 
 
@@ -30,6 +32,18 @@ def test_host_layer_compiles():
     assert os.path.exists(build_exe())
     assert os.path.exists(build_exe("photo_pipeline"))
     assert os.path.exists(build_exe("point_types"))
+    assert os.path.exists(build_exe("sharded_pipeline"))
+
+
+def test_host_mirror_is_written_against_gtsam_headers():
+    """The mirror includes <gtsam/...> and uses GTSAM's own spellings; what those headers are is an include-path matter
+    (host/gtsam_sig here, a GTSAM installation in a deployment): no #ifdef, no second code path."""
+    host = os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip")
+    src = "".join(open(os.path.join(host, h)).read() for h in os.listdir(host))
+    assert "#include <gtsam/nonlinear/NonlinearFactor.h>" in src and "#include <gtsam/linear/HessianFactor.h>" in src
+    assert "c.at<Pose3>(keys()[0])" in src and "c.at<Unit3>(G(0)).unitVector()" in src      # geometric_factor.hpp:247-257
+    assert "std::make_shared<HessianFactor>(keys[0], matrix6(r.H_ss), g1, r.f)" in src          # :559-560
+    assert "MIMOSA_HIP_WITH_GTSAM" not in src and "atPose3" not in src and "gravityUnit" not in src
 
 
 def _pose12(R, t):
@@ -219,3 +233,43 @@ def _same_but_padding(got, want):
     a = np.frombuffer(got, synth.POINT_DTYPE)
     b = np.frombuffer(np.ascontiguousarray(want).tobytes(), synth.POINT_DTYPE)
     return all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in ("x", "y", "z", "intensity", "t", "idx", "range"))
+
+
+def _write_sharded_input(path):
+    from mimosa_amd import synth
+    room = np.array([20.0, 14.0, 3.0])
+    map_xyz = synth.make_room(4321, 0, 0, room=room)
+    scan, aux = synth.make_scan(n_rows=32, seed=99, n_cols=128, room=room, sensor_local=np.array([9.3, 6.6, 1.2]))
+    R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    steps = [(np.zeros(3), np.zeros(3)), (np.zeros(3), np.array([0.004, 0.003, -0.002])), (np.array([0.0, 0.0, 0.012]), np.array([0.06, -0.05, 0.02])),
+             (np.array([0.004, -0.003, 0.02]), np.array([-0.09, 0.11, 0.03]))]
+    poses = np.concatenate([_pose12(R @ synth.so3_exp(w), t + d) for w, d in steps])
+    with open(path, "wb") as f:
+        for arr, n in ((map_xyz.astype(np.float32), map_xyz.size), (scan, len(scan)), (poses, poses.size)):
+            f.write(struct.pack("<Q", n))
+            f.write(np.ascontiguousarray(arr).tobytes())
+    return map_xyz, scan, (R, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("local", "1"), ("local", "3"), ("rccl",)])
+def test_sharded_host_mirror(tmp_path, mode):
+    """ShardCommunicator / ShardedVoxelMap / ShardedICPFactor through gtsam::Values and gtsam::HessianFactor: every rank's
+    global result equals the unsharded ICPFactor's on the full map (and the oracle's)."""
+    from mimosa_amd import synth
+    from oracle import ref_cpu
+    exe = build_exe("sharded_pipeline")
+    inp = tmp_path / "sh.bin"
+    map_xyz, scan, (R, t) = _write_sharded_input(inp)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    out = subprocess.run([exe, str(inp), *mode], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout[out.stdout.index("{"):])
+    assert d["worst_rel"] <= 1e-12 and d["hist_equal"] == 1 and d["ranks_equal"] == 1, d
+    assert d["collective"] == 1 and d["collectives_last"] == 3
+    assert d["backend"] == ("rccl" if mode[0] == "rccl" else "local")
+    assert sum(d["points_held"]) == len(scan)
+    M = ref_cpu.Map()
+    M.insert(map_xyz)
+    ref = ref_cpu.ICP(M, scan, ref_cpu.make_config(**synth.enwide_config())).linearize(R, t)
+    assert abs(d["H00"] - ref["H_ss"][0, 0]) <= 1e-9 * abs(ref["H_ss"][0, 0]) and abs(d["f"] - ref["f"]) <= 1e-9 * abs(ref["f"])
