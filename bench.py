@@ -54,15 +54,54 @@ def parse():
                     help="HIP events bracket the kernels of every n-th linearize call of the timed region "
                          "(an event record costs ~4 us of stream time; 1 = every call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="skip the two self-profiling rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--shard-timeout", type=float, default=240.0,
                     help="seconds the sharded leg may take before the line is printed without it")
     ap.add_argument("--shard-rooms", type=str, default="auto",
                     help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
                          "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
+    ap.add_argument("--hostile-rooms", type=str, default="2x5", help="rooms of the hostile second workload (mimosa_amd/synth_hostile.py); none = skip it and the moving-pose leg")
+    ap.add_argument("--hostile-poses", type=int, default=5, help="past scans per room the hostile map is built from")
     ap.add_argument("--sharded", action="store_true", help="(kept for old command lines: the map-sharded leg now runs by default, at --gpus 1 too)")
     ap.add_argument("--shard-block-log2", type=int, default=3, help="shard blocks of 2^n voxels per axis (3: 4 m cubes at the 0.5 m leaf)")
     return ap.parse_args()
+
+
+def measure_traffic(args):
+    """(bytes per K3 launch, note) from two rocprofv3 --pmc passes of this script in --profile-mode, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mh_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "40",
+               "--warmup", "5", "--profile-mode", "--no-measure-traffic", "--rooms", args.rooms, "--rows", str(args.rows)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    kn = r.get("Kernel_Name", "")
+                    if "icp_linearize_kernel" in kn and "batch" not in kn and r.get("Counter_Name") == ctr:
+                        vals.append(float(r["Counter_Value"]))
+            if len(vals) < 10:
+                return None, f"the {ctr} pass produced {len(vals)} samples"
+            got[ctr] = float(np.mean(vals[5:]))   # the first launches include the map's first touch
+        except Exception as exc:  # noqa: BLE001
+            return None, f"the {ctr} pass failed: {type(exc).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+    note = (f"measured IN THIS RUN: two rocprofv3 --kernel-trace --pmc passes of this script (--profile-mode, 40 steps), FETCH_SIZE {got['FETCH_SIZE']:.0f} KB and "
+            f"WRITE_SIZE {got['WRITE_SIZE']:.0f} KB per launch; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    return traffic, note
 
 
 def build_world(rank: int, rooms: str, rows: int):
@@ -701,15 +740,29 @@ def main():
     k3_avg_s = float(k3_ms.mean()) * 1e-3
     achieved_gbs = n_pts * b_pt / k3_avg_s / 1e9
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
-    # committed summary of the separate rocprofv3 --pmc passes is reported (profiles/latest_pmc.json)
+    # HBM traffic of the dominant kernel.  PMC counters cannot be collected inside this process, so the run profiles ITSELF:
+    # two separate `rocprofv3 --kernel-trace --pmc <one counter>` passes of this script in --profile-mode (the warm-up and the
+    # timed region only), FETCH_SIZE and WRITE_SIZE each in its own pass as MI355X_MICROARCH.md prescribes; bytes per launch =
+    # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950; uncalibrated for 16-byte
+    # scattered gathers, so the read side is an upper bound).  Without a profiler on the box the committed summary is used ONLY
+    # if it was taken from the kernel source of this tree (hash of icp_kernels.hip); a stale one is reported as null, loudly.
     traffic, traffic_note = None, None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        traffic = int((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024)
-        traffic_note = "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from " + pm["source"] + " @ " + str(pm.get("commit", "round 1"))
-    except Exception:
-        pass
+    if not args.profile_mode and world == 1 and rank == 0 and not args.no_measure_traffic:
+        traffic, traffic_note = measure_traffic(args)
+    if traffic is None:
+        why = traffic_note
+        try:
+            import hashlib
+            pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+            src_hash = hashlib.sha256(open(os.path.join(ROOT, "mimosa_amd", "csrc", "icp_kernels.hip"), "rb").read()).hexdigest()[:16]
+            if pm.get("kernel_source_sha16") == src_hash:
+                traffic = int((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024)
+                traffic_note = "NOT measured in this run (" + str(why) + "); committed summary of the same kernel source: " + pm["source"] + " @ " + str(pm.get("commit"))
+            else:
+                traffic_note = ("NOT measured in this run (" + str(why) + ") and profiles/latest_pmc.json was taken from another version of icp_kernels.hip (" +
+                                str(pm.get("kernel_source_sha16")) + " != " + src_hash + "): no traffic figure")
+        except Exception as exc:  # noqa: BLE001
+            traffic_note = f"NOT measured in this run ({why}); no usable committed summary ({type(exc).__name__})"
 
     # Compulsory lower bound of SURVEY.md §8(d): every touched voxel bucket read ONCE — N x 16 (source) + V_touched x 336
     # (16-B slot + 320-B bucket) + N x 64 (state out); V_touched = distinct occupied voxels in the 19-neighbourhoods of
@@ -758,6 +811,105 @@ def main():
                  "frac": round(len(ps) * bs / (float(np.mean(k3s[5:])) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         fs.destroy()
 
+    # ---- second workloads: (a) a MOVING pose — S scans cast a step apart along a path, one factor each,
+    # cold linearizes round-robin, so the touched map region changes with every step instead of staying resident in L2 /
+    # MALL; (b) the HOSTILE world of mimosa_amd/synth_hostile.py — map = union of past ray-cast scans (1 / r^2 density,
+    # voxels at the 20-point cap next to sparse ones, clutter, thin structures), every RejectStatus branch populated.
+    def _round_robin(fs, poses, k):
+        """k cold linearizes dealt round-robin to the factors `fs` (all on `ctx`), <= INFLIGHT in flight each: seconds per step"""
+        def go(kk):
+            done = 0
+            while done < kk:
+                nb = min(INFLIGHT * len(fs), kk - done)
+                for i in range(nb):
+                    j = (done + i) % len(fs)
+                    fs[j].reset()
+                    fs[j].linearize_async(*poses[j])
+                for f in fs:
+                    f.wait()
+                done += nb
+        go(max(8, 2 * len(fs)))
+        ctx.synchronize()
+        a = time.perf_counter()
+        go(k)
+        ctx.synchronize()
+        return (time.perf_counter() - a) / k
+
+    moving, hostile = None, None
+    if not args.profile_mode and world == 1 and args.hostile_rooms != "none":
+        try:
+            from mimosa_amd import synth_hostile as sh
+            rcfg_ = capi.make_reg_config(**cfgd)
+            ksec = max(40, args.steps // 2)
+            # (a) grid world, moving pose: the sensor advances 0.6 m per scan
+            nmv = 8
+            mv_f, mv_p = [], []
+            for i in range(nmv):
+                loc = synth.SENSOR_LOCAL + np.array([0.6 * i, 0.25 * (i % 3), 0.0])
+                pi_, ai_ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 300 + i, sensor_local=loc, yaw=synth.SENSOR_YAW + 0.05 * i)
+                mv_f.append(capi.ICPFactor(ctx, gmap, pi_, rcfg_))
+                mv_p.append(synth.query_pose(ai_["R_W_L"], ai_["t_W_L"]))
+            same = _round_robin(mv_f[:1], mv_p[:1], ksec)
+            mv = _round_robin(mv_f, mv_p, ksec)
+            moving = {"workload": f"{nmv} scans cast 0.6 m apart along a path in the configs[1] map, one factor each, cold linearizes round-robin on one stream: "
+                                  "the touched map region changes every step",
+                      "value": round(n_pts / mv / 1e6, 2), "ms_per_step": round(mv * 1e3, 5),
+                      "same_pose_value": round(n_pts / same / 1e6, 2), "same_pose_ms_per_step": round(same * 1e3, 5), "unit": "Mpts/s"}
+            for f in mv_f:
+                f.destroy()
+            # (b) hostile world
+            hnx, hny = (int(v) for v in args.hostile_rooms.lower().split("x"))
+            t0h = time.time()
+            hmap = capi.VoxelMap(ctx, leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
+                                 max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+            past = []
+            for _, _, _, hits in sh.make_map_scans(hnx, hny, args.hostile_poses, workers=min(64, os.cpu_count() or 1)):
+                hmap.insert(hits)
+                past.append(hits)
+            hstats = hmap.stats()
+            fill = sh.voxel_fill_stats(hmap.get_cloud(), cfgd["target_ivox_map_leaf_size"], synth.MAX_PTS_PER_VOXEL)
+            hs_f, hs_p = [], []
+            for i in range(nmv):
+                hp_, ha_ = sh.make_query_scan(0.37 + 0.0095 * i, n_rows=args.rows)     # 0.6 m apart along the corridor
+                hs_f.append(capi.ICPFactor(ctx, hmap, hp_, rcfg_))
+                hs_p.append(synth.query_pose(ha_["R_W_L"], ha_["t_W_L"]))
+            hbuild = time.time() - t0h
+            hres = hs_f[0].linearize(*hs_p[0])
+            h_same = _round_robin(hs_f[:1], hs_p[:1], ksec)
+            h_mv = _round_robin(hs_f, hs_p, ksec)
+            hs_f[0].reset()
+            ctx.synchronize()
+            a = time.perf_counter()
+            hs_f[0].linearize(*hs_p[0])
+            h_sync = time.perf_counter() - a
+            hostile = {"workload": f"the {n_pts}-pt OS0-128 scan of a cluttered room vs a {hstats['n_points']}-pt map = the union of {len(past)} past ray-cast scans "
+                                   f"({hnx}x{hny} rooms x {args.hostile_poses} poses, one insert each): 1/r^2 density, saturated and sparse voxels, plates, poles",
+                       "value": round(n_pts / h_same / 1e6, 2), "ms_per_step": round(h_same * 1e3, 5), "unit": "Mpts/s",
+                       "moving_pose_value": round(n_pts / h_mv / 1e6, 2), "moving_pose_ms_per_step": round(h_mv * 1e3, 5),
+                       "sync_latency_ms": round(h_sync * 1e3, 4),
+                       "map_points": int(hstats["n_points"]), "map_voxels": int(hstats["n_voxels"]), "points_inserted": int(sum(len(h_) for h_ in past)),
+                       "voxel_fill": {k_: round(v_, 4) if isinstance(v_, float) else v_ for k_, v_ in fill.items()},
+                       "mean_candidates": round(float(hres["mean_candidates"]), 2), "mean_scanned_after_pruning": round(float(hres["mean_scanned"]), 2),
+                       "exact_fallback_queries": int(hres["n_exact_fallback"]), "status_hist": [int(v) for v in hres["status_hist"]],
+                       "world_build_s": round(hbuild, 1)}
+            if not args.no_cpu_baseline:
+                from oracle import ref_cpu
+                hrm = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+                                  mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+                for hits in past:
+                    hrm.insert(hits)
+                hq, _ = sh.make_query_scan(0.37, n_rows=args.rows)
+                secs_h, href = ref_cpu.time_cold(hrm, hq, ref_cpu.make_config(**cfgd), hs_p[0][0], hs_p[0][1], n_threads=4, iters=3)
+                hostile["parity_vs_oracle"] = {"H_rel": float(np.linalg.norm(hres["H_ss"] - href["H_ss"]) / np.linalg.norm(href["H_ss"])),
+                                               "f_rel": abs(hres["f"] - href["f"]) / abs(href["f"]),
+                                               "status_hist_equal": bool(np.array_equal(hres["status_hist"], href["status_hist"]))}
+                hostile["cpu_oracle_4_threads_mpts_s"] = round(n_pts / float(np.median(secs_h[1:])) / 1e6, 3)
+            for f in hs_f:
+                f.destroy()
+            hmap.release()
+        except Exception as exc:  # noqa: BLE001 - reported in the line
+            hostile = {"error": f"{type(exc).__name__}: {exc}"}
+
     line = {
         "metric": "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU",
         "value": round(value, 3),
@@ -800,6 +952,7 @@ def main():
             "compulsory_bytes": comp_bytes,
             "voxels_touched": v_touched,
             "frac_compulsory": round(comp_bytes / k3_avg_s / 1e9 / HBM_PEAK_GBS, 4) if comp_bytes else None,
+            "frac_of_compulsory_at_measured_copy_peak": round(comp_bytes / (HBM_COPY_GBS * 1e9) / k3_avg_s, 4) if comp_bytes else None,
             "frac_note": "frac = gather-model bytes (no reuse credited, SURVEY.md 8(d)) / kernel time / 8 TB/s: a work-equivalent figure, NOT "
                          "HBM bandwidth — the touched map lives in L2 / Infinity Cache; hbm_measured_* is the PMC traffic, frac_compulsory the "
                          "read-every-bucket-once bound.  The kernel is bound by dependent latency and L1 request rate, see DESIGN.md",
@@ -827,6 +980,8 @@ def main():
         "scan_frontend": fe_stats,
         "sequence_replay": rp_stats,
         "relinearize_window": win_stats,
+        "moving_pose": moving,
+        "hostile_world": hostile,
         "photometric": ph_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,

@@ -28,6 +28,11 @@ extern "C" {
 #endif
 
 #define MH_ABI_VERSION 1
+#if defined(__GNUC__) && !defined(MH_BUILDING_LIBRARY)
+#define MH_DEPRECATED(msg) __attribute__((deprecated(msg)))
+#else
+#define MH_DEPRECATED(msg)
+#endif
 
 typedef enum mh_status {
   MH_OK = 0,
@@ -207,13 +212,13 @@ int mh_map_insert_from_scan(mh_map * map, const mh_scan * scan, const float R_W_
 /* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by Geometric::updateMap's
  * copy-then-insert (geometric.cpp:494): device to device, both maps stay writable. */
 int mh_map_copy(const mh_map * map, mh_map ** out);
-/* Round-1 name of the cheap copy; identical to mh_map_copy now that every copy is device-to-device. */
-int mh_map_fork(mh_map * map, mh_map ** out);
+/* DEPRECATED (ABI version 1 only; removed with the next MH_ABI_VERSION): round-1 name of mh_map_copy — use mh_map_copy. */
+int mh_map_fork(mh_map * map, mh_map ** out) MH_DEPRECATED("use mh_map_copy");
 /* shared_ptr semantics: factors retain the map they were built with. */
 int mh_map_retain(mh_map * map);
 void mh_map_release(mh_map * map);
-/* No-op (the device arrays ARE the map); kept for callers of the round-1 interface. */
-int mh_map_sync(mh_map * map);
+/* DEPRECATED (ABI version 1 only; removed with the next MH_ABI_VERSION): a no-op since the device arrays ARE the map. */
+int mh_map_sync(mh_map * map) MH_DEPRECATED("no longer needed");
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out);
 /* IncrementalVoxelMapPCL::getCloud (incremental_voxel_map.cpp:34-38): all points in voxel order.
  * xyz may be NULL to query the size; returns the number of points through n_out. */
@@ -251,10 +256,11 @@ int mh_icp_wait(mh_icp * icp);
 /* Every live ICPFactor of the sliding window re-linearized in ONE pass: what graph::Manager::defineNoLock's
  * smoother_->update() + additional_update_iterations (src/graph/manager.cpp:585-588) make GTSAM do one factor at
  * a time.  icps[f] is linearized at (R_src + 9 f, t_src + 3 f[, R_tgt + 9 f, t_tgt + 3 f], g_unit + 3 f) into out[f];
- * results are bit-identical to n_factors separate mh_icp_linearize calls.  One K3 launch and one K4 launch cover
- * all factors (two of each when clouds of up to 65 536 points and larger ones are mixed).  All factors must belong to one context, have no call in flight, and agree on unary/binary, on
- * num_corres_points == 5 and on the map's neighbour mode (MH_ERR_UNSUPPORTED otherwise); at most 64 per call.
- * R_tgt / t_tgt may be NULL for unary factors.  Blocks until every result is on the host. */
+ * results are bit-identical to n_factors separate mh_icp_linearize calls.  Factors that share a kernel instantiation —
+ * workgroup size (clouds of up to 65 536 points / larger ones), num_corres_points == 5 or not, the map's neighbour mode,
+ * unary / binary — form one launch group: one K3 launch and one K4 launch per group, so a window of like factors (the usual
+ * case) is one launch pair and any mix is accepted.  All factors must belong to one context and have no call in flight;
+ * at most 64 per call.  R_tgt / t_tgt may be NULL when no factor is binary.  Blocks until every result is on the host. */
 int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out);
 /* Two-phase form for a factor whose map is sharded across GPUs (no reference counterpart; the

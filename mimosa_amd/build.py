@@ -120,7 +120,7 @@ def _build_locked(force: bool, verbose: bool, timeline: bool) -> str:
         if deps is not None and not all(os.path.exists(x) for x in deps):
             deps = None
         if force or _stale(o, deps if deps is not None else [s] + hdrs):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-MMD", "-MF", d,
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-DMH_BUILDING_LIBRARY", "-MMD", "-MF", d,
                    "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] + (["-DMH_BALANCE"] if os.environ.get("MH_BALANCE") else []) if timeline else []), "-c", s, "-o", o]
             jobs.append((cmd, o))
     if jobs:

@@ -269,7 +269,17 @@ struct ScanCursor
     const uint32_t e = list[o_cur * lds_stride];  // off the cursor's dependency chain
     ScanStage st;
     st.ofs = lut4[o_cur];
-    st.quad = qbuckets[(e >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1))];
+    uint32_t qidx = (e >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1));
+#ifdef MH_DEAD_COALESCE
+    {
+      // a dead stage (this lane has no quad left while others of the wave still scan) loads quad 0 of voxel 0: every dead lane
+      // the SAME 16 bytes, one L1 transaction for all of them instead of one each.  Opaque to the compiler (a select on the
+      // index makes it sink the LDS read of `e` into a branch).
+      const uint32_t lm = 0u - static_cast<uint32_t>(live);
+      asm volatile("v_and_b32 %0, %0, %1" : "+v"(qidx) : "v"(lm));
+    }
+#endif
+    st.quad = qbuckets[qidx];
     st.meta = (static_cast<uint32_t>(o_cur) << 6) | ((live ? (e & 31u) : 0u) << 11) | (qd << 16);
     ++qd;
     return st;
@@ -1379,6 +1389,14 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
   if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
+  // the eigenbases THIS pass projected on are what the caller is told (the host's own decomposition of the same sums may
+  // pick another basis of a clustered eigenspace: no FMA there, other branches of sym_eigen3)
+  if (threadIdx.x >= 32 && threadIdx.x < 50) {
+    const int q = threadIdx.x - 32;
+    double * dst = q < 9 ? &a.result->eig_rot[q] : &a.result->eig_trans[q - 9];
+    *dst = s_E[q];
+    if (a.host_result) *(q < 9 ? &a.host_result->eig_rot[q] : &a.host_result->eig_trans[q - 9]) = s_E[q];
+  }
   // this kernel's outputs also go to the caller's mapped pinned host slot, straight from the LDS sums (K3's
   // last block already wrote its part there); the end of the kernel makes them visible to the host
   if (a.host_result) {

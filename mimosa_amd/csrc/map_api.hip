@@ -179,11 +179,14 @@ int purge_lru(mh_map * m)
   if (rc == MH_OK && e == hipSuccess) e = mh::launch_map_claim_blocks(dst, 0, keep, ctx->stream);
   if (rc == MH_OK && e == hipSuccess) rc = fetch_state(m);
   if (rc != MH_OK || e != hipSuccess) {
+    // the fresh arrays and the table are half written and the counters already name the compacted map: there is no way back
+    // to the old state from here.  The map is marked unusable instead of being left to answer from garbage ids.
     (void)hipStreamSynchronize(ctx->stream);
     ob.release();
     oq.release();
     ov.release();
     ol.release();
+    m->poisoned = true;
     return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_map_insert: LRU purge");
   }
   m->n_blocks = m->h_state->n_blocks;
@@ -193,10 +196,19 @@ int purge_lru(mh_map * m)
   ov.release();
   ol.release();
   rc = ensure_blocks(m, m->n_blocks, 0);
-  if (rc != MH_OK) return rc;
+  if (rc != MH_OK) {
+    m->poisoned = true;  // voxels without their cell words
+    return rc;
+  }
   dst = arrays_of(m);
-  MH_HIP(ctx, mh::launch_map_write_words(dst, 0, keep, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    hipError_t e2 = mh::launch_map_write_words(dst, 0, keep, ctx->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess) {
+      m->poisoned = true;
+      return hip_fail(ctx, e2, "mh_map_insert: LRU purge (cell words)");
+    }
+  }
   m->purges++;
   return MH_OK;
 }
@@ -207,6 +219,7 @@ int insert_device(mh_map * m, const float * d_src, size_t n, size_t stride, cons
 {
   mh_ctx * ctx = m->ctx;
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_insert: batch too large");
+  if (m->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_insert: the map is inconsistent after a failed mutation");
   // Factors of other contexts (HIP streams) may be reading this map: the arrays are modified in place and may be
   // reallocated, so the whole device is drained first (microseconds when idle).
   MH_HIP(ctx, hipDeviceSynchronize());
@@ -295,6 +308,7 @@ int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out)
     const int md = cfg->neighbor_voxel_mode;
     if (md != 1 && md != 7 && md != 19 && md != 27) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: neighbor_voxel_mode must be 1, 7, 19 or 27");
     if (cfg->lru_clear_cycle < 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_clear_cycle must be >= 1");
+    if (cfg->lru_horizon < 0) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_horizon must be >= 0");
     MH_HIP(ctx, hipSetDevice(ctx->device));
     mh_map * m = nullptr;
     int rc = map_alloc(ctx, *cfg, &m);
@@ -428,6 +442,7 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
   *out = nullptr;
   mh_ctx * ctx = src->ctx;
   return guarded(ctx, "mh_map_copy", [&]() -> int {
+    if (src->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_copy: the map is inconsistent after a failed mutation");
     MH_HIP(ctx, hipSetDevice(ctx->device));
     mh_map * m = nullptr;
     int rc = map_alloc(ctx, src->cfg, &m);
@@ -511,6 +526,7 @@ int mh_map_get_cloud(const mh_map * cmap, float * xyz, size_t capacity_points, s
   mh_map * map = const_cast<mh_map *>(cmap);  // scratch buffers only
   mh_ctx * ctx = map->ctx;
   return guarded(ctx, "mh_map_get_cloud", [&]() -> int {
+    if (map->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_get_cloud: the map is inconsistent after a failed mutation");
     *n_out = static_cast<size_t>(map->n_points);
     if (!xyz || map->n_points == 0) return MH_OK;
     MH_HIP(ctx, hipSetDevice(ctx->device));
@@ -536,6 +552,7 @@ int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * p
   mh_ctx * ctx = map->ctx;
   return guarded(ctx, "mh_map_knn", [&]() -> int {
     if (k < 1 || k > 8) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_knn: k must be in 1..8");
+    if (map->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_knn: the map is inconsistent after a failed mutation");
     MH_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) return MH_OK;
     DevTemp<double> d_q, d_p, d_s;

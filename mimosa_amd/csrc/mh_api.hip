@@ -95,8 +95,12 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
       }
     mh::compute_localizability(Hr, out->loc_rot_final, er);
     mh::compute_localizability(Ht, out->loc_trans_final, et);
-    std::memcpy(out->eigvec_rot, er, sizeof(er));
-    std::memcpy(out->eigvec_trans, et, sizeof(et));
+    // With the component pass on, the eigenvectors reported are the ones K4 projected on (it derives them on the device from
+    // the same sums; with clustered eigenvalues the host's decomposition may return a differently rotated basis of the same
+    // eigenspace, and loc_*_comp — thresholded at 0.5 per direction — belongs to K4's).  Eigenvalues do not depend on that.
+    const bool from_k4 = pc.components && icp->n > 0 && pc.seq_has_basis;
+    std::memcpy(out->eigvec_rot, from_k4 ? d.eig_rot : er, sizeof(er));
+    std::memcpy(out->eigvec_trans, from_k4 ? d.eig_trans : et, sizeof(et));
   }
   for (int i = 0; i < 3; ++i) {
     // switched off (mh_icp_set_components): NaN, so that a caller who reads them anyway notices
@@ -197,7 +201,7 @@ static int mh_init_impl(int device, mh_ctx ** out)
     hipDeviceProp_t prop;
     MH_HIP(nullptr, hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-      return fail(nullptr, MH_ERR_NO_DEVICE, std::string("mh_init: device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+      return fail(nullptr, MH_ERR_UNSUPPORTED, std::string("mh_init: device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
   }
   MH_HIP(nullptr, hipSetDevice(device));
   mh_ctx * ctx = new (std::nothrow) mh_ctx;
@@ -206,7 +210,7 @@ static int mh_init_impl(int device, mh_ctx ** out)
   MH_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[0]));
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[1]));
-  AllocCache::contexts()++;
+  AllocCache::context_created(device);
   *out = ctx;
   return MH_OK;
 }
@@ -230,10 +234,7 @@ void mh_shutdown(mh_ctx * ctx)
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   const int dev = ctx->device;
   delete ctx;
-  if (--AllocCache::contexts() <= 0) {  // the last context is gone: hand the cached device / pinned blocks back
-    AllocCache::contexts() = 0;
-    AllocCache::trim(dev);
-  }
+  AllocCache::context_destroyed(dev);  // the device's last context: its cached blocks (and, with no context left anywhere, the pinned ones) go back
 }
 
 static int mh_set_profiling_impl(mh_ctx * ctx, int on)
@@ -244,7 +245,7 @@ static int mh_set_profiling_impl(mh_ctx * ctx, int on)
 }
 int mh_set_profiling(mh_ctx * ctx, int on)
 {
-  return guarded(nullptr, "mh_set_profiling", [&]() -> int { return mh_set_profiling_impl(ctx, on); });
+  return guarded(ctx, "mh_set_profiling", [&]() -> int { return mh_set_profiling_impl(ctx, on); });
 }
 
 void * mh_stream(mh_ctx * ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
@@ -258,7 +259,7 @@ static int mh_synchronize_impl(mh_ctx * ctx)
 }
 int mh_synchronize(mh_ctx * ctx)
 {
-  return guarded(nullptr, "mh_synchronize", [&]() -> int { return mh_synchronize_impl(ctx); });
+  return guarded(ctx, "mh_synchronize", [&]() -> int { return mh_synchronize_impl(ctx); });
 }
 
 static int mh_timer_begin_impl(mh_ctx * ctx)
@@ -270,7 +271,7 @@ static int mh_timer_begin_impl(mh_ctx * ctx)
 }
 int mh_timer_begin(mh_ctx * ctx)
 {
-  return guarded(nullptr, "mh_timer_begin", [&]() -> int { return mh_timer_begin_impl(ctx); });
+  return guarded(ctx, "mh_timer_begin", [&]() -> int { return mh_timer_begin_impl(ctx); });
 }
 
 static int mh_timer_end_impl(mh_ctx * ctx, float * ms)
@@ -284,7 +285,7 @@ static int mh_timer_end_impl(mh_ctx * ctx, float * ms)
 }
 int mh_timer_end(mh_ctx * ctx, float * ms)
 {
-  return guarded(nullptr, "mh_timer_end", [&]() -> int { return mh_timer_end_impl(ctx, ms); });
+  return guarded(ctx, "mh_timer_end", [&]() -> int { return mh_timer_end_impl(ctx, ms); });
 }
 
 }  // extern "C"
@@ -380,6 +381,7 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   // A map may be shared read-only by factors of several contexts (= HIP streams) of the SAME device:
   // uploads are host-synchronised on the map's own stream before any factor kernel is enqueued.
   if (map->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_create: map lives on another device");
+  if (map->poisoned) return fail(ctx, MH_ERR_HIP, "mh_icp_create: the map is inconsistent after a failed mutation");
   if (cfg->num_corres_points < 2 || cfg->num_corres_points > 8)
     return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: num_corres_points must be in 2..8");
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: cloud too large");
@@ -418,7 +420,7 @@ static int mh_icp_create_impl(mh_ctx * ctx, mh_map * map, const mh_point32 * sou
 int mh_icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, size_t n, const mh_reg_config * cfg,
                   int is_binary, mh_icp ** out)
 {
-  return guarded(nullptr, "mh_icp_create", [&]() -> int { return mh_icp_create_impl(ctx, map, source, n, cfg, is_binary, out); });
+  return guarded(ctx, "mh_icp_create", [&]() -> int { return mh_icp_create_impl(ctx, map, source, n, cfg, is_binary, out); });
 }
 
 static int mh_icp_clone_impl(const mh_icp * src, mh_icp ** out)
@@ -466,7 +468,7 @@ static int mh_icp_clone_impl(const mh_icp * src, mh_icp ** out)
 }
 int mh_icp_clone(const mh_icp * src, mh_icp ** out)
 {
-  return guarded(nullptr, "mh_icp_clone", [&]() -> int { return mh_icp_clone_impl(src, out); });
+  return guarded(src ? src->ctx : nullptr, "mh_icp_clone", [&]() -> int { return mh_icp_clone_impl(src, out); });
 }
 
 void mh_icp_destroy(mh_icp * icp)
@@ -523,7 +525,7 @@ static int mh_icp_reset_impl(mh_icp * icp)
 }
 int mh_icp_reset(mh_icp * icp)
 {
-  return guarded(nullptr, "mh_icp_reset", [&]() -> int { return mh_icp_reset_impl(icp); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_reset", [&]() -> int { return mh_icp_reset_impl(icp); });
 }
 
 static int mh_icp_set_components_impl(mh_icp * icp, int enabled)
@@ -535,8 +537,38 @@ static int mh_icp_set_components_impl(mh_icp * icp, int enabled)
 }
 int mh_icp_set_components(mh_icp * icp, int enabled)
 {
-  return guarded(nullptr, "mh_icp_set_components", [&]() -> int { return mh_icp_set_components_impl(icp, enabled); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_set_components", [&]() -> int { return mh_icp_set_components_impl(icp, enabled); });
 }
+
+// What linearize_prepare changes on the handle before anything is enqueued: put back unless the launches went through (a
+// recoverable failure — an allocation, a launch error — must not leave a never-linearized factor looking warm, or a pending
+// slot claimed for ever).
+struct LinearizeTxn
+{
+  mh_icp * icp;
+  bool cold = true, committed = false;
+  int count = 0, pending = 0;
+  explicit LinearizeTxn(mh_icp * i) : icp(i)
+  {
+    if (icp) {
+      cold = icp->cold;
+      count = icp->linearize_count;
+      pending = icp->n_pending;
+    }
+  }
+  LinearizeTxn(LinearizeTxn && o) noexcept : icp(o.icp), cold(o.cold), committed(o.committed), count(o.count), pending(o.pending) { o.icp = nullptr; }
+  LinearizeTxn(const LinearizeTxn &) = delete;
+  LinearizeTxn & operator=(const LinearizeTxn &) = delete;
+  void commit() { committed = true; }
+  ~LinearizeTxn()
+  {
+    if (icp && !committed) {
+      icp->cold = cold;
+      icp->linearize_count = count;
+      icp->n_pending = pending;
+    }
+  }
+};
 
 // Argument blocks of one linearize call of `icp` in pending slot n_pending (which it claims): everything of
 // linearize_enqueue except the launches.  want_flag: the last kernel publishes a completion sequence number to the
@@ -616,6 +648,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   }
   pc.seq = 0;
   pc.components = icp->components;
+  pc.seq_has_basis = false;  // set by the callers whose K4 writes its eigenbases into this call's result slot
   a.seq = 0;
   if (a.n > 0) {
     a.host_result = l.host_result = icp->d_h_results + slot;
@@ -636,6 +669,7 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   mh::IcpArgs a;
   mh::LocArgs l;
   bool timed = false;
+  LinearizeTxn txn(icp);
   const int rc = linearize_prepare(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, want_flag, true, a, l, timed);
   if (rc != MH_OK) return rc;
   mh_ctx * ctx = icp->ctx;
@@ -646,7 +680,10 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     if (!pc.components) a.seq = l.seq;  // K3 is the call's last kernel: it publishes the completion number
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
-    if (pc.components) MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+    if (pc.components) {
+      MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
+      pc.seq_has_basis = true;
+    }
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   } else {
     if (timed) {
@@ -657,6 +694,7 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
                                ctx->stream));
   }
+  txn.commit();
   return MH_OK;
 }
 
@@ -668,7 +706,7 @@ static int mh_icp_linearize_async_impl(mh_icp * icp, const double R_src[9], cons
 int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                            const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
-  return guarded(nullptr, "mh_icp_linearize_async", [&]() -> int { return mh_icp_linearize_async_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_async", [&]() -> int { return mh_icp_linearize_async_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
 }
 
 static int mh_icp_wait_impl(mh_icp * icp)
@@ -717,7 +755,7 @@ static int mh_icp_wait_impl(mh_icp * icp)
 }
 int mh_icp_wait(mh_icp * icp)
 {
-  return guarded(nullptr, "mh_icp_wait", [&]() -> int { return mh_icp_wait_impl(icp); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_wait", [&]() -> int { return mh_icp_wait_impl(icp); });
 }
 
 static int mh_icp_linearize_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
@@ -730,7 +768,7 @@ static int mh_icp_linearize_impl(mh_icp * icp, const double R_src[9], const doub
 int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                      const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
-  return guarded(nullptr, "mh_icp_linearize", [&]() -> int { return mh_icp_linearize_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize", [&]() -> int { return mh_icp_linearize_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
 }
 
 // ---- all live factors of the sliding window in two launches ------------------------------------------------
@@ -747,58 +785,65 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
   for (size_t f = 0; f < n_factors; ++f)
     if (!icps[f]) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: NULL factor");
   mh_ctx * ctx = icps[0]->ctx;
-  const bool binary = icps[0]->binary;
-  const bool k5 = icps[0]->cfg.num_corres_points == 5;
-  const int n_off = icps[0]->map->n_off;
-  size_t max_n = 0;
   for (size_t f = 0; f < n_factors; ++f) {
     const mh_icp * c = icps[f];
     if (c->ctx != ctx) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: factors of different contexts");
     if (c->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: a factor has calls in flight");
-    if (c->binary != binary || (c->cfg.num_corres_points == 5) != k5 || c->map->n_off != n_off)
-      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_linearize_batch: factors must agree on unary/binary, k == 5 and the neighbour mode");
-    if (binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: binary factors need target poses");
+    if (c->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: binary factors need target poses");
     for (size_t g = 0; g < f; ++g)
       if (icps[g] == c) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: the same factor twice");
-    max_n = c->n > max_n ? c->n : max_n;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
-  // staging: [IcpArgs x 64 | LocArgs x 64 | start x 2 x 65], host-pinned + a device copy the kernels read.  Factors
-  // are grouped by the workgroup size their cloud gets in a single call (256 threads up to 65 536 points, 512 above),
-  // one launch pair per non-empty group, so every factor reduces in exactly the order of a separate call.
+  // Launch groups: the factors that share a kernel instantiation — workgroup size (256 threads up to 65 536 points, 512
+  // above: so every factor reduces in exactly the order of a separate call), k == 5 or the generic k <= 8 path, neighbour
+  // mode, unary / binary.  One K3b (+ one K4b) launch per non-empty group; a window of like factors — the usual case — is
+  // one group.  Staging: [IcpArgs x 64 | LocArgs x 64 | grid prefixes], host-pinned + a device copy the kernels read.
+  struct Group
+  {
+    int tpb, k, n_off;
+    bool binary;
+    std::vector<size_t> members;
+    int first = 0, grid = 0;
+  };
+  std::vector<Group> groups;
+  for (size_t f = 0; f < n_factors; ++f) {
+    const mh_icp * c = icps[f];
+    if (c->n == 0) continue;
+    const int tpb = mh::batch_tpb(static_cast<int>(c->n)), k = c->cfg.num_corres_points == 5 ? 5 : 8, n_off = c->map->n_off;
+    Group * g = nullptr;
+    for (Group & q : groups)
+      if (q.tpb == tpb && q.k == k && q.n_off == n_off && q.binary == c->binary) g = &q;
+    if (!g) {
+      groups.push_back(Group{tpb, k, n_off, c->binary, {}, 0, 0});
+      g = &groups.back();
+    }
+    g->members.push_back(f);
+  }
   const size_t ab = sizeof(mh::IcpArgs) * kMaxBatch, lb = sizeof(mh::LocArgs) * kMaxBatch, sb = sizeof(int) * 2 * (kMaxBatch + 1);
   const size_t total = ((ab + lb + sb + 255) & ~size_t(255)) + 256;
   if (!ctx->h_batch) MH_HIP(ctx, hipHostMalloc(&ctx->h_batch, total, hipHostMallocDefault));
   if (!ctx->d_batch) MH_HIP(ctx, hipMalloc(&ctx->d_batch, total));
   auto * h_a = reinterpret_cast<mh::IcpArgs *>(ctx->h_batch);
   auto * h_l = reinterpret_cast<mh::LocArgs *>(static_cast<char *>(ctx->h_batch) + ab);
-  int * h_s = reinterpret_cast<int *>(static_cast<char *>(ctx->h_batch) + ab + lb);
-  (void)max_n;
-  int group_first[2] = {0, 0}, group_n[2] = {0, 0}, group_grid[2] = {0, 0}, group_tpb[2] = {256, 512};
+  int * h_s = reinterpret_cast<int *>(static_cast<char *>(ctx->h_batch) + ab + lb);  // group g's prefix starts at h_s[first + g]
   size_t slot_of[kMaxBatch];
   {
-    size_t pos = 0;
-    for (int g = 0; g < 2; ++g) {
-      group_first[g] = static_cast<int>(pos);
-      for (size_t f = 0; f < n_factors; ++f) {
-        const size_t nf = icps[f]->n;
-        if (nf == 0 || mh::batch_tpb(static_cast<int>(nf)) != group_tpb[g]) continue;
-        slot_of[f] = pos++;
-        group_n[g]++;
-      }
+    int pos = 0;
+    for (Group & g : groups) {
+      g.first = pos;
+      for (size_t f : g.members) slot_of[f] = static_cast<size_t>(pos++);
     }
   }
-  int * h_start[2] = {h_s, h_s + (kMaxBatch + 1)};
+  std::vector<LinearizeTxn> txns;  // every factor's handle goes back to what it was unless ALL launches went through
+  txns.reserve(n_factors);
   for (size_t f = 0; f < n_factors; ++f) {
     bool timed = false;
     mh::IcpArgs a;
     mh::LocArgs l;
+    txns.emplace_back(icps[f]);
     const int rc = linearize_prepare(icps[f], R_src + 9 * f, t_src + 3 * f, R_tgt ? R_tgt + 9 * f : nullptr,
                                      t_tgt ? t_tgt + 3 * f : nullptr, g_unit + 3 * f, out + f, true, false, a, l, timed);
-    if (rc != MH_OK) {
-      for (size_t g = 0; g < f; ++g) icps[g]->n_pending = 0;
-      return rc;
-    }
+    if (rc != MH_OK) return rc;
     if (icps[f]->n == 0) {
       std::memset(&icps[f]->h_results[0], 0, sizeof(mh::DeviceResult));
       continue;
@@ -813,56 +858,63 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
   if (!any_components)
     for (size_t f = 0; f < n_factors; ++f)
       if (icps[f]->n) h_a[slot_of[f]].seq = h_l[slot_of[f]].seq;
-  for (int g = 0; g < 2; ++g) {
-    // prefix of the group's grids, in slot order
+  bool inline_args = true;
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    Group & g = groups[gi];
+    int * start = h_s + g.first + static_cast<int>(gi);  // prefix of the group's grids, in slot order
     int acc = 0;
-    for (int i = 0; i < group_n[g]; ++i) {
-      h_start[g][i] = acc;
-      acc += mh::batch_grid(h_a[group_first[g] + i].n, group_tpb[g]);
+    for (size_t i = 0; i < g.members.size(); ++i) {
+      start[i] = acc;
+      acc += mh::batch_grid(h_a[g.first + static_cast<int>(i)].n, g.tpb);
     }
-    h_start[g][group_n[g]] = acc;
-    group_grid[g] = acc;
+    start[g.members.size()] = acc;
+    g.grid = acc;
+    inline_args = inline_args && static_cast<int>(g.members.size()) <= mh::kBatchInline;
   }
-  if (group_grid[0] + group_grid[1] > 0) {
-    const int k = k5 ? 5 : 8;
-    const bool inline_args = group_n[0] <= mh::kBatchInline && group_n[1] <= mh::kBatchInline;
+  if (!groups.empty()) {
     if (inline_args) {
       // small window: the argument blocks ride in the kernel-argument segment, nothing is copied before the launches
-      for (int g = 0; g < 2; ++g) {
-        if (!group_grid[g]) continue;
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group & g = groups[gi];
+        const int * start = h_s + g.first + static_cast<int>(gi);
         mh::BatchInline<mh::IcpArgs> blk;
-        std::memset(&blk, 0, sizeof(blk));
-        for (int i = 0; i < group_n[g]; ++i) blk.a[i] = h_a[group_first[g] + i];
-        for (int i = 0; i <= group_n[g]; ++i) blk.start[i] = h_start[g][i];
-        blk.n = group_n[g];
-        MH_HIP(ctx, mh::launch_linearize_batch_inline(blk, group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
+        std::memset(static_cast<void *>(&blk), 0, sizeof(blk));
+        for (size_t i = 0; i < g.members.size(); ++i) blk.a[i] = h_a[g.first + static_cast<int>(i)];
+        for (size_t i = 0; i <= g.members.size(); ++i) blk.start[i] = start[i];
+        blk.n = static_cast<int>(g.members.size());
+        MH_HIP(ctx, mh::launch_linearize_batch_inline(blk, g.grid, g.tpb, g.k, g.n_off, g.binary, ctx->stream));
       }
-      for (int g = 0; g < 2 && any_components; ++g) {
-        if (!group_grid[g]) continue;
+      for (size_t gi = 0; gi < groups.size() && any_components; ++gi) {
+        const Group & g = groups[gi];
+        const int * start = h_s + g.first + static_cast<int>(gi);
         mh::BatchInline<mh::LocArgs> blk;
-        std::memset(&blk, 0, sizeof(blk));
-        for (int i = 0; i < group_n[g]; ++i) blk.a[i] = h_l[group_first[g] + i];
-        for (int i = 0; i <= group_n[g]; ++i) blk.start[i] = h_start[g][i];
-        blk.n = group_n[g];
-        MH_HIP(ctx, mh::launch_localizability_batch_inline(blk, group_grid[g], group_tpb[g], ctx->stream));
+        std::memset(static_cast<void *>(&blk), 0, sizeof(blk));
+        for (size_t i = 0; i < g.members.size(); ++i) blk.a[i] = h_l[g.first + static_cast<int>(i)];
+        for (size_t i = 0; i <= g.members.size(); ++i) blk.start[i] = start[i];
+        blk.n = static_cast<int>(g.members.size());
+        MH_HIP(ctx, mh::launch_localizability_batch_inline(blk, g.grid, g.tpb, ctx->stream));
       }
     } else {
       char * d = static_cast<char *>(ctx->d_batch);
       MH_HIP(ctx, hipMemcpyAsync(d, ctx->h_batch, ab + lb + sb, hipMemcpyHostToDevice, ctx->stream));
-      for (int g = 0; g < 2; ++g) {
-        if (!group_grid[g]) continue;
-        const auto * da = reinterpret_cast<const mh::IcpArgs *>(d) + group_first[g];
-        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
-        MH_HIP(ctx, mh::launch_linearize_batch(da, ds, group_n[g], group_grid[g], group_tpb[g], k, n_off, binary, ctx->stream));
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group & g = groups[gi];
+        const auto * da = reinterpret_cast<const mh::IcpArgs *>(d) + g.first;
+        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g.first + static_cast<int>(gi);
+        MH_HIP(ctx, mh::launch_linearize_batch(da, ds, static_cast<int>(g.members.size()), g.grid, g.tpb, g.k, g.n_off, g.binary, ctx->stream));
       }
-      for (int g = 0; g < 2 && any_components; ++g) {
-        if (!group_grid[g]) continue;
-        const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + group_first[g];
-        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g * (kMaxBatch + 1);
-        MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, group_n[g], group_grid[g], group_tpb[g], ctx->stream));
+      for (size_t gi = 0; gi < groups.size() && any_components; ++gi) {
+        const Group & g = groups[gi];
+        const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + g.first;
+        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g.first + static_cast<int>(gi);
+        MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, static_cast<int>(g.members.size()), g.grid, g.tpb, ctx->stream));
       }
     }
   }
+  if (any_components)
+    for (size_t f = 0; f < n_factors; ++f)
+      if (icps[f]->n && icps[f]->components) icps[f]->pending[0].seq_has_basis = true;  // K4b wrote the bases it used
+  for (LinearizeTxn & t : txns) t.commit();
   int rc_all = MH_OK;
   for (size_t f = 0; f < n_factors; ++f) {
     if (icps[f]->n == 0) icps[f]->pending[0].seq = 0;  // nothing was launched for it: falls back to a stream sync
@@ -874,7 +926,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
 int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out)
 {
-  return guarded(nullptr, "mh_icp_linearize_batch", [&]() -> int { return mh_icp_linearize_batch_impl(icps, n_factors, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
+  return guarded((icps && n_factors && icps[0]) ? icps[0]->ctx : nullptr, "mh_icp_linearize_batch", [&]() -> int { return mh_icp_linearize_batch_impl(icps, n_factors, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
 }
 
 // ---- two-phase form for map-sharded factors (mimosa_amd/dist.py): the Hessian sums of all shards are
@@ -893,7 +945,7 @@ static int mh_icp_linearize_begin_impl(mh_icp * icp, const double R_src[9], cons
 int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                            const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
 {
-  return guarded(nullptr, "mh_icp_linearize_begin", [&]() -> int { return mh_icp_linearize_begin_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_begin", [&]() -> int { return mh_icp_linearize_begin_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial); });
 }
 
 static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
@@ -941,7 +993,7 @@ static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9]
 int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
                             double loc_rot_comp[3], int32_t status_hist[9])
 {
-  return guarded(nullptr, "mh_icp_linearize_finish", [&]() -> int { return mh_icp_linearize_finish_impl(icp, eigvec_rot, eigvec_trans, loc_trans_comp, loc_rot_comp, status_hist); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_finish", [&]() -> int { return mh_icp_linearize_finish_impl(icp, eigvec_rot, eigvec_trans, loc_trans_comp, loc_rot_comp, status_hist); });
 }
 
 static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * means, double * normals)
@@ -980,7 +1032,7 @@ static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * 
 }
 int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals)
 {
-  return guarded(nullptr, "mh_icp_get_state", [&]() -> int { return mh_icp_get_state_impl(icp, status, means, normals); });
+  return guarded(icp ? icp->ctx : nullptr, "mh_icp_get_state", [&]() -> int { return mh_icp_get_state_impl(icp, status, means, normals); });
 }
 
 // ---- deskew / transforms -----------------------------------------------------------------------
@@ -1019,7 +1071,7 @@ static int mh_deskew_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32
 int mh_deskew(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32_t * unique_ns, const float * Rt12, size_t n_groups,
               const float * R_B_L, const float * t_B_L)
 {
-  return guarded(nullptr, "mh_deskew", [&]() -> int { return mh_deskew_impl(ctx, pts, n, unique_ns, Rt12, n_groups, R_B_L, t_B_L); });
+  return guarded(ctx, "mh_deskew", [&]() -> int { return mh_deskew_impl(ctx, pts, n, unique_ns, Rt12, n_groups, R_B_L, t_B_L); });
 }
 
 static int mh_transform_f32_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
@@ -1044,7 +1096,7 @@ static int mh_transform_f32_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const
 }
 int mh_transform_f32(mh_ctx * ctx, mh_point32 * pts, size_t n, const float R[9], const float t[3])
 {
-  return guarded(nullptr, "mh_transform_f32", [&]() -> int { return mh_transform_f32_impl(ctx, pts, n, R, t); });
+  return guarded(ctx, "mh_transform_f32", [&]() -> int { return mh_transform_f32_impl(ctx, pts, n, R, t); });
 }
 
 }  // extern "C"
@@ -1113,7 +1165,7 @@ static int mh_scan_create_impl(mh_ctx * ctx, mh_scan ** out)
 }
 int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
 {
-  return guarded(nullptr, "mh_scan_create", [&]() -> int { return mh_scan_create_impl(ctx, out); });
+  return guarded(ctx, "mh_scan_create", [&]() -> int { return mh_scan_create_impl(ctx, out); });
 }
 
 void mh_scan_destroy(mh_scan * s)
@@ -1166,7 +1218,7 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
 }
 int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
 {
-  return guarded(nullptr, "mh_scan_prepare_input",
+  return guarded(s ? s->ctx : nullptr, "mh_scan_prepare_input",
                  [&]() -> int { return scan_prepare_common(s, raw, false, n, cfg, info, "mh_scan_prepare_input"); });
 }
 // Manager::prepareInput<PointT> for any of the reference's point types: decode into canonical records on the device, then
@@ -1222,13 +1274,13 @@ static int mh_scan_prepare_input_layout_impl(mh_scan * s, const void * raw, size
 int mh_scan_prepare_input_layout(mh_scan * s, const void * raw, size_t n, const mh_point_layout * layout, uint32_t width, uint32_t height,
                                  int transpose, int organize_by_ring, double header_ts, const mh_input_config * cfg, mh_scan_info * info)
 {
-  return guarded(nullptr, "mh_scan_prepare_input_layout", [&]() -> int {
+  return guarded(s ? s->ctx : nullptr, "mh_scan_prepare_input_layout", [&]() -> int {
     return mh_scan_prepare_input_layout_impl(s, raw, n, layout, width, height, transpose, organize_by_ring, header_ts, cfg, info);
   });
 }
 int mh_scan_prepare_input_device(mh_scan * s, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg, mh_scan_info * info)
 {
-  return guarded(nullptr, "mh_scan_prepare_input_device",
+  return guarded(s ? s->ctx : nullptr, "mh_scan_prepare_input_device",
                  [&]() -> int { return scan_prepare_common(s, d_raw, true, n, cfg, info, "mh_scan_prepare_input_device"); });
 }
 
@@ -1251,7 +1303,7 @@ static int mh_scan_get_unique_ns_impl(const mh_scan * s, uint32_t * out, size_t 
 }
 int mh_scan_get_unique_ns(const mh_scan * s, uint32_t * out, size_t capacity, size_t * n_out)
 {
-  return guarded(nullptr, "mh_scan_get_unique_ns", [&]() -> int { return mh_scan_get_unique_ns_impl(s, out, capacity, n_out); });
+  return guarded(s ? s->ctx : nullptr, "mh_scan_get_unique_ns", [&]() -> int { return mh_scan_get_unique_ns_impl(s, out, capacity, n_out); });
 }
 
 static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
@@ -1278,7 +1330,7 @@ static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
 }
 int mh_scan_deskew(mh_scan * s, const float * Rt12, size_t n_groups)
 {
-  return guarded(nullptr, "mh_scan_deskew", [&]() -> int { return mh_scan_deskew_impl(s, Rt12, n_groups); });
+  return guarded(s ? s->ctx : nullptr, "mh_scan_deskew", [&]() -> int { return mh_scan_deskew_impl(s, Rt12, n_groups); });
 }
 
 static int mh_scan_preprocess_geometric_impl(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
@@ -1316,7 +1368,7 @@ static int mh_scan_preprocess_geometric_impl(mh_scan * s, const float R_B_L[9], 
 int mh_scan_preprocess_geometric(mh_scan * s, const float R_B_L[9], const float t_B_L[3], double leaf_size,
                                  int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info)
 {
-  return guarded(nullptr, "mh_scan_preprocess_geometric", [&]() -> int { return mh_scan_preprocess_geometric_impl(s, R_B_L, t_B_L, leaf_size, max_points_per_voxel, min_dist_in_voxel, info); });
+  return guarded(s ? s->ctx : nullptr, "mh_scan_preprocess_geometric", [&]() -> int { return mh_scan_preprocess_geometric_impl(s, R_B_L, t_B_L, leaf_size, max_points_per_voxel, min_dist_in_voxel, info); });
 }
 
 static int mh_scan_get_points_impl(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
@@ -1336,7 +1388,7 @@ static int mh_scan_get_points_impl(const mh_scan * s, int which, mh_point32 * ou
 }
 int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t capacity, size_t * n_out)
 {
-  return guarded(nullptr, "mh_scan_get_points", [&]() -> int { return mh_scan_get_points_impl(s, which, out, capacity, n_out); });
+  return guarded(s ? s->ctx : nullptr, "mh_scan_get_points", [&]() -> int { return mh_scan_get_points_impl(s, which, out, capacity, n_out); });
 }
 
 static int mh_scan_get_indices_impl(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
@@ -1356,7 +1408,7 @@ static int mh_scan_get_indices_impl(const mh_scan * s, int which, uint32_t * out
 }
 int mh_scan_get_indices(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
 {
-  return guarded(nullptr, "mh_scan_get_indices", [&]() -> int { return mh_scan_get_indices_impl(s, which, out, capacity, n_out); });
+  return guarded(s ? s->ctx : nullptr, "mh_scan_get_indices", [&]() -> int { return mh_scan_get_indices_impl(s, which, out, capacity, n_out); });
 }
 
 static int mh_icp_create_from_scan_impl(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
@@ -1374,7 +1426,7 @@ static int mh_icp_create_from_scan_impl(mh_ctx * ctx, mh_map * map, const mh_sca
 int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const mh_reg_config * cfg, int is_binary,
                             mh_icp ** out)
 {
-  return guarded(nullptr, "mh_icp_create_from_scan", [&]() -> int { return mh_icp_create_from_scan_impl(ctx, map, s, cfg, is_binary, out); });
+  return guarded(ctx, "mh_icp_create_from_scan", [&]() -> int { return mh_icp_create_from_scan_impl(ctx, map, s, cfg, is_binary, out); });
 }
 
 }  // extern "C"
@@ -1573,6 +1625,7 @@ static int mh_icp_linearize_begin_device_impl(mh_icp * icp, const double R_src[9
   mh::IcpArgs a;
   mh::LocArgs l;
   bool timed = false;
+  LinearizeTxn txn(icp);
   const int rc = linearize_prepare(icp, R_src, t_src, nullptr, nullptr, g_unit, &scratch, false, false, a, l, timed);
   if (rc != MH_OK) return rc;
   a.host_result = nullptr;  // results stay on the device
@@ -1583,6 +1636,7 @@ static int mh_icp_linearize_begin_device_impl(mh_icp * icp, const double R_src[9
   MH_HIP(ctx, mh::launch_shard_pack_sums(static_cast<const mh::DeviceResult *>(icp->d_result.p), d_sums32, ctx->stream));
   std::memcpy(icp->split_R, icp->pending[0].R, sizeof(icp->split_R));
   icp->dev_split_open = true;
+  txn.commit();
   return MH_OK;
 }
 int mh_icp_linearize_begin_device(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32)

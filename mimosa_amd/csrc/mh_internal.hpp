@@ -163,6 +163,25 @@ public:
     (void)hipHostFree(p);
   }
   // mh_shutdown of the last context of a device: give the cached blocks of that device back to the runtime
+  // context bookkeeping (mh_init / mh_shutdown): per device, under the cache mutex
+  static void context_created(int dev)
+  {
+    std::lock_guard<std::mutex> g(mu());
+    contexts_of()[dev]++;
+  }
+  // true when this was the device's last context (its cached blocks go back to the runtime; the pinned ones when no context
+  // is left on any device)
+  static void context_destroyed(int dev)
+  {
+    bool last_of_device = false;
+    {
+      std::lock_guard<std::mutex> g(mu());
+      int & n = contexts_of()[dev];
+      if (n > 0) --n;
+      last_of_device = n == 0;
+    }
+    if (last_of_device) trim(dev);
+  }
   static void trim(int dev)
   {
     std::vector<void *> dead, dead_pinned;
@@ -174,7 +193,9 @@ public:
           kv.second.clear();
         }
       cached_bytes()[dev] = 0;
-      if (contexts() == 0)
+      int total = 0;
+      for (const auto & kv : contexts_of()) total += kv.second;
+      if (total == 0)
         for (auto & kv : pinned()) {
           dead_pinned.insert(dead_pinned.end(), kv.second.begin(), kv.second.end());
           kv.second.clear();
@@ -183,13 +204,13 @@ public:
     for (void * p : dead) (void)hipFree(p);
     for (void * p : dead_pinned) (void)hipHostFree(p);
   }
-  static int & contexts()
-  {
-    static int n = 0;
-    return n;
-  }
 
 private:
+  static std::unordered_map<int, int> & contexts_of()
+  {
+    static std::unordered_map<int, int> m;
+    return m;
+  }
   struct Block
   {
     size_t cls;
@@ -326,6 +347,7 @@ struct mh_map
   int64_t inserts = 0, upload_bytes = 0, purges = 0;
   int n_off = 0;
   int8_t off[27][3];
+  bool poisoned = false;  // a mutation failed half way (LRU purge): the device arrays and the counters disagree; every later call fails
 };
 
 inline mh::MapView map_view(const mh_map * m)
@@ -352,6 +374,7 @@ struct PendingCall
   int linearize_count;
   unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
   bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
+  bool seq_has_basis = false;  // ... and wrote the eigenbases it projected on into the call's result slot
   hipEvent_t ev[3];
 };
 

@@ -641,7 +641,13 @@ int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out)
   *out = nullptr;
   return guarded(ctx, "mh_photo_create", [&]() -> int {
     if (cfg->rows < 1 || cfg->cols < 16 || cfg->cols > 4096) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: rows >= 1, 16 <= cols <= 4096");
+    // feature candidates are packed as pixel | gradient << 24 (photo_kernels.hip: photo_cand_scatter): 2^24 pixels at most
+    if (cfg->rows > 4096 || static_cast<int64_t>(cfg->rows) * cfg->cols > (int64_t(1) << 24))
+      return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: rows <= 4096 and rows * cols <= 2^24");
     if (!cfg->pixel_shift_by_row || !cfg->beam_altitude_angles) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: NULL table");
+    for (int r = 0; r < cfg->rows; ++r)
+      if (cfg->pixel_shift_by_row[r] <= -cfg->cols || cfg->pixel_shift_by_row[r] >= cfg->cols)
+        return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: |pixel_shift_by_row| must be below cols");
     if (cfg->rows < 2) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: at least two beams");
     if (cfg->n_patch_offsets < 2 || cfg->n_patch_offsets > mh::kPhotoMaxPatch || !cfg->patch_offsets)
       return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: 2..64 patch offsets");

@@ -36,7 +36,8 @@ __device__ __forceinline__ void idx_to_pixel(const PhotoModel & m, uint32_t idx,
 {
   v = static_cast<int>(idx / static_cast<uint32_t>(m.cols));
   const int c = static_cast<int>(idx % static_cast<uint32_t>(m.cols));
-  u = m.destagger ? (c + m.pixel_shift[v]) % m.cols : c;
+  const int sh = (c + m.pixel_shift[v]) % m.cols;  // shifts may be negative (the real OS0-128 table is 31, 10, -10, -30 ...)
+  u = m.destagger ? (sh < 0 ? sh + m.cols : sh) : c;
 }
 
 __device__ __forceinline__ float prep(float v, float scale, float gamma)

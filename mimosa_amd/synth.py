@@ -9,14 +9,17 @@ surfaces sampled on a 0.16 m jittered grid (+-0.005 m in-plane) with Gaussian no
 sigma = 0.02 m (a perfectly planar map is rejected wholesale by the reference:
 geometric_factor.hpp:202-206).  One room ~ 0.5 M points.
 
-Scan: OS0-128 model, 128 beams (+45.9 .. -45.9 deg, uniform — the real table in
-config/enwide/os_enwide.json is near-uniform), 1024 columns, column c fired at c * 97_656 ns,
-beam origin 27.67 mm off the axis, range noise sigma = 0.02 m; row-major point order
-(idx = row * 1024 + col), exactly 131 072 points (every ray hits the room).
+Scan: OS0-128 model with the sensor's own beam tables (mimosa_amd/os0_128.py = config/enwide/os_enwide.json: 128
+beam altitude angles +45.9 .. -45.9 deg, slightly non-uniform; the four-beam azimuth stagger as pixel_shift_by_row),
+1024 columns, column c fired at c * 97_656 ns, beam origin 27.67 mm off the axis, range noise sigma = 0.02 m; row-major
+STAGGERED point order as the driver publishes it (idx = row * 1024 + col; measurement (row, col) looks along the
+azimuth of destaggered column (col + shift[row]) % 1024), exactly 131 072 points (every ray hits the room).
 """
 from __future__ import annotations
 
 import numpy as np
+
+from . import os0_128
 
 ROOM = np.array([74.0, 55.0, 18.0])
 WALL = 1.0
@@ -150,8 +153,8 @@ def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
     """
     room = np.asarray(room, dtype=np.float64)
     R_end, t_end = rot_z(yaw), room_origin(0, 0) + np.asarray(sensor_local)
-    full = np.linspace(45.9, -45.9, 128)
-    alt = np.deg2rad(full[:: 128 // n_rows][:n_rows])
+    alt = np.deg2rad(os0_128.altitude_angles(n_rows))
+    shift = os0_128.pixel_shifts(n_rows, n_cols).astype(np.int64)  # the beams of a column are staggered in azimuth
     az = -2.0 * np.pi * (np.arange(n_cols) / n_cols)  # Ouster spins clockwise seen from above
     t_ns = (np.arange(n_cols) * COL_NS * (N_COLS // n_cols)).astype(np.uint32)
     t_end_ns = float(t_ns[-1])
@@ -159,7 +162,8 @@ def make_scan(n_rows: int = 128, seed: int = BASE_SEED + 1, skew: bool = False,
     rows, cols = np.meshgrid(np.arange(n_rows), np.arange(n_cols), indexing="ij")
     rows, cols = rows.ravel(), cols.ravel()
     ca, sa = np.cos(alt[rows]), np.sin(alt[rows])
-    cz, sz = np.cos(az[cols]), np.sin(az[cols])
+    look = (cols + shift[rows]) % n_cols  # destaggered column = the azimuth this measurement looks along
+    cz, sz = np.cos(az[look]), np.sin(az[look])
     d_s = np.stack([ca * cz, ca * sz, sa], axis=1)  # beam direction, sensor frame
     o_s = np.stack([BEAM_ORIGIN_M * cz, BEAM_ORIGIN_M * sz, np.zeros_like(cz)], axis=1)
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import synth
+from . import os0_128, synth
 
 ROOM = np.array([24.0, 18.0, 6.0])
 SENSOR_LOCAL = np.array([9.3, 6.6, 1.8])
@@ -42,14 +42,14 @@ def photo_config(rows: int = 128, cols: int = 1024, patch: int = 5, **over) -> d
         offs = [(du, dv) for dv in range(-half, half) for du in range(-half, half)]          # 8 x 8: -4 .. 3
     d = dict(
         rows=rows, cols=cols, destagger=1,
-        pixel_shift_by_row=np.tile(np.array([64, 43, 23, 3]) * cols // 1024, rows // 4 + 1)[:rows].astype(np.int32),
-        beam_altitude_angles=np.linspace(45.9, -45.9, rows).astype(np.float32),
+        pixel_shift_by_row=os0_128.pixel_shifts(rows, cols),                        # the sensor's own tables (config/enwide/os_enwide.json)
+        beam_altitude_angles=os0_128.altitude_angles(rows).astype(np.float32),
         range_min=0.5, range_max=30.0, erosion_buffer=10, patch_size=5, margin_size=10,
         intensity_scale=0.25, intensity_gamma=1.0, remove_lines=1, filter_brightness=1, gaussian_blur=1, gaussian_blur_size=3,
         gradient_threshold=10.0, max_dist_from_mean=3.0, max_dist_from_plane=0.5, nma_radius=11, num_features_detect=60,
         occlusion_range_diff_threshold=0.2, max_feature_life_time=1000,
         high_pass_fir=_fir(33, 0.12, True), low_pass_fir=_fir(33, 0.04, False), brightness_window_size=(41, 7),
-        lidar_origin_to_beam_origin_mm=27.67, rotate_patch_to_align_with_gradient=0,
+        lidar_origin_to_beam_origin_mm=os0_128.LIDAR_ORIGIN_TO_BEAM_ORIGIN_MM, rotate_patch_to_align_with_gradient=0,
         patch_offsets=np.array(offs, np.int32),
         use_robust_cost_function=0, robust_cost_function=0, robust_cost_function_parameter=1.345, error_scale=1.0,
         max_error=0.5075, sigma=0.25, T_B_L_R=T_B_L_R, T_B_L_t=T_B_L_t, static_mask=None,

@@ -144,8 +144,15 @@ _CORE = ("H_ss", "b_s", "f", "loc_trans_final", "loc_rot_final", "eigvec_rot", "
 
 
 def _core_same(a, b):
+    """bit-identical, except the eigenvectors of H_rr / H_tt: with the component pass ON the library reports the bases K4
+    projected on (derived on the device), with it OFF the host epilogue's decomposition of the same sums — the same
+    eigenvectors to rounding (modulo sign), not necessarily to the bit"""
+    from parity import eigvec_equal_mod_sign
     for k in _CORE:
-        assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+        if k in ("eigvec_rot", "eigvec_trans"):
+            assert eigvec_equal_mod_sign(a[k], b[k], tol=1e-9), k
+        else:
+            assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
 
 
 def test_components_switched_off_changes_nothing_else(ctx, room_world):
@@ -179,7 +186,7 @@ def test_components_switched_off_changes_nothing_else(ctx, room_world):
     fa[0].wait()
     for a, b in zip(outs, want):
         a = a.as_dict()
-        for k in ("H_ss", "b_s", "f", "loc_trans_final", "eigvec_rot"):
+        for k in ("H_ss", "b_s", "f", "loc_trans_final"):
             assert np.array_equal(a[k], b[k]), k
         assert np.all(np.isnan(a["loc_trans_comp"]))
     # a clone inherits the switch; switching it on brings the components back
@@ -208,3 +215,44 @@ def test_components_switched_off_changes_nothing_else(ctx, room_world):
     for f in fa + fb:
         f.destroy()
     gm.release()
+
+
+def test_batch_of_unlike_factors(ctx, small_world):
+    """Any mix in one call: k = 5 and k = 4, neighbour modes 19 and 7 (two maps), unary and binary — one launch group per
+    kernel instantiation, every factor still bit-identical to its own mh_icp_linearize and equal to the oracle."""
+    from mimosa_amd import capi, synth
+    from oracle import ref_cpu
+
+    w = small_world
+    pts = w["pts"]
+    specs = [dict(k=5, mode=19, binary=False), dict(k=4, mode=19, binary=False), dict(k=5, mode=7, binary=False), dict(k=5, mode=19, binary=True),
+             dict(k=8, mode=7, binary=True), dict(k=5, mode=19, binary=False)]
+    maps = {}
+    for mode in (19, 7):
+        gm, rm = capi.VoxelMap(ctx, mode=mode), ref_cpu.Map(mode=mode)
+        gm.insert(w["map_xyz"])
+        rm.insert(w["map_xyz"])
+        maps[mode] = (gm, rm)
+    Rt, tt = synth.so3_exp(np.array([0.002, 0.001, -0.003])), np.array([0.02, -0.01, 0.005])
+    fa, fb, fr, Rs, ts = [], [], [], [], []
+    for i, sp in enumerate(specs):
+        cfgd = dict(w["cfg"], num_corres_points=sp["k"])
+        gm, rm = maps[sp["mode"]]
+        sub = pts[i::len(specs)]
+        fa.append(capi.ICPFactor(ctx, gm, sub, capi.make_reg_config(**cfgd), binary=sp["binary"]))
+        fb.append(capi.ICPFactor(ctx, gm, sub, capi.make_reg_config(**cfgd), binary=sp["binary"]))
+        fr.append(ref_cpu.ICP(rm, sub, ref_cpu.make_config(**cfgd), binary=sp["binary"]))
+        R = w["R"] @ synth.so3_exp(np.array([0.001 * i, -0.0007 * i, 0.002 * i]))
+        t = w["t"] + np.array([0.01 * i, -0.004 * i, 0.002 * i])
+        Rs.append(Rt @ R)   # every factor gets the target pose; the unary ones ignore it
+        ts.append(Rt @ t + tt)
+    for rnd in range(2):   # cold, then through the data-association caches
+        got = capi.linearize_batch(fa, Rs, ts, R_tgts=[Rt] * len(specs), t_tgts=[tt] * len(specs))
+        for i, sp in enumerate(specs):
+            kw = dict(R_tgt=Rt, t_tgt=tt) if sp["binary"] else {}
+            _same(got[i], fb[i].linearize(Rs[i], ts[i], **kw))
+            assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i], **kw), binary=sp["binary"])
+    for f in fa + fb:
+        f.destroy()
+    for gm, _ in maps.values():
+        gm.release()

@@ -252,8 +252,12 @@ def test_non_finite_and_far_inputs_do_not_fault(ctx, small_world):
     finite = np.isfinite(pts["x"]) & np.isfinite(pts["y"]) & np.isfinite(pts["z"]) & (np.abs(pts["x"]) < 1e6) & (np.abs(pts["y"]) < 1e6) & (np.abs(pts["z"]) < 1e6)
     assert np.all(st[~finite] != 8)
     assert np.array_equal(np.delete(st, bad), clean.state()[0])
-    assert g["status_hist"][8] == c["status_hist"][8]
-    assert np.allclose(g["H_ss"], c["H_ss"], rtol=1e-12, atol=0) and np.all(np.isfinite(g["H_ss"]))
+    # (a coordinate replaced by 1e-30 leaves a finite point that may well register: it counts, and contributes to H)
+    extra = st[bad] == 8
+    assert g["status_hist"][8] == c["status_hist"][8] + int(extra.sum())
+    assert np.all(np.isfinite(g["H_ss"]))
+    if not extra.any():
+        assert np.allclose(g["H_ss"], c["H_ss"], rtol=1e-12, atol=0)
     # a NaN pose: everything is rejected or NaN, nothing faults, and the factor is usable afterwards
     Rn = w["R"].copy()
     Rn[0, 0] = np.nan

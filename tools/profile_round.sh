@@ -7,7 +7,7 @@ TAG=${MH_ROUND:-rXX}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 200 --warmup 20 --profile-mode"
+CMD="python $R/bench.py --steps 200 --warmup 20 --profile-mode --no-measure-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 i=0
 for pass in \
@@ -48,7 +48,9 @@ json.dump({'counters':out,'resources':res,'commit':os.environ.get('MH_COMMIT','?
 k3=[k for k in out if 'linearize_kernel' in k and 'batch' not in k]
 if k3:
     c=out[k3[0]]
-    json.dump({'kernel':k3[0],'FETCH_SIZE_KB':c.get('FETCH_SIZE'),'WRITE_SIZE_KB':c.get('WRITE_SIZE'),'TCC_EA0_RDREQ':c.get('TCC_EA0_RDREQ_sum'),
+    import hashlib
+    ksha=hashlib.sha256(open('$R/mimosa_amd/csrc/icp_kernels.hip','rb').read()).hexdigest()[:16]
+    json.dump({'kernel':k3[0],'kernel_source_sha16':ksha,'FETCH_SIZE_KB':c.get('FETCH_SIZE'),'WRITE_SIZE_KB':c.get('WRITE_SIZE'),'TCC_EA0_RDREQ':c.get('TCC_EA0_RDREQ_sum'),
                'commit':os.environ.get('MH_COMMIT','?'),'round':'$TAG',
                'source':'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 200 --warmup 20 --profile-mode (tools/profile_round.sh)',
                'note':'FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 (MI355X_MICROARCH.md HBM section): doubled as the guide prescribes for 128-B requests tallied at 64 B; uncalibrated for 16-B scattered gathers, so the read side is an upper bound'},

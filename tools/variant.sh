@@ -8,5 +8,5 @@ python -m mimosa_amd.build > /dev/null
 mkdir -p $R/mimosa_amd/lib/variants $R/mimosa_amd/build/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter "$@" -c $R/mimosa_amd/csrc/icp_kernels.hip -o $R/mimosa_amd/build/variants/icp_$tag.o
 objs=$(ls $R/mimosa_amd/build/*.o | grep -v icp_kernels.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/mimosa_amd/lib/variants/$tag.so $objs $R/mimosa_amd/build/variants/icp_$tag.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/mimosa_amd/lib/variants/$tag.so $objs $R/mimosa_amd/build/variants/icp_$tag.o -ldl
 echo $R/mimosa_amd/lib/variants/$tag.so
