@@ -15,7 +15,7 @@
 #include <chrono>
 #include <deque>
 
-#include "photometric.hpp"
+#include "manager.hpp"
 
 namespace mimosa_hip
 {
@@ -213,91 +213,50 @@ struct Result
   double seconds = 0, stage[5] = {0, 0, 0, 0, 0};  // front_end, imu, factor_create, optimise, update_map
 };
 
-class FixedLagReplay
+// The stand-in for GTSAM / ISAM2 (out of scope): a dense Gauss-Newton over the `window` most recent poses — unary ICP Hessian
+// factors (every live one re-linearized per iteration through ICPFactor::linearizeBatch, what smoother_->update +
+// additional_update_iterations do, src/graph/manager.cpp:585-588), the photometric factor on the newest pose, between
+// factors from the IMU propagation, a prior on the oldest pose.  Shared by FixedLagReplay and by the graph-manager stand-in
+// that lidar::Manager is driven with (ManagerReplay below).
+class WindowSmoother
 {
 public:
-  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx)
+  struct Live
   {
-    map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, cfg_.reg.target_ivox_map_leaf_size);
-    map_->set_lru_horizon(lru_horizon);
-    map_->set_neighbor_voxel_mode(cfg_.neighbor_voxel_mode);
-    map_->set_min_dist_in_cell(cfg_.reg.target_ivox_map_min_dist_in_voxel);
-    if (cfg_.photometric) {
-      // its own context = its own HIP stream: the patch factor (60 waves, a 27 us latency chain) and the window's ICP batch
-      // (a few hundred waves) are independent work of one smoother iteration and run side by side instead of one behind
-      // the other; every hand-over between the two contexts happens at a call that synchronises anyway
-      photo_ctx_ = std::make_shared<lidar::Context>(ctx_->device());
-      photo_.reset(new Photometric(photo_ctx_, cfg_.photo));
-      scan_.keepRaw(true);
+    size_t k;
+    RT T;
+    ICPFactor::Ptr f;
+    bool has_Z;
+    RT Z;
+  };
+  WindowSmoother(int window, int update_iters, double between_sigma_rot, double between_sigma_trans)
+  : window_(window), update_iters_(update_iters)
+  {
+    const double wr = 1.0 / (between_sigma_rot * between_sigma_rot), wt = 1.0 / (between_sigma_trans * between_sigma_trans);
+    for (int i = 0; i < 3; ++i) {
+      Wb_[i] = wr;
+      Wb_[3 + i] = wt;
     }
   }
-  void seedMap(const float * xyz, size_t n) { map_->insert(xyz, n); }
-
-  // state0: the state at the first IMU sample of the first sweep (the caller's first guess)
-  Result run(const std::vector<ScanInput> & scans, const State & state0)
+  void push(const Live & lv)
   {
-    using clk = std::chrono::steady_clock;
-    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    Result res;
-    struct Live
+    if (!pushed_) {
+      first_k_ = lv.k;  // the first pose the smoother ever sees: its prior stays loose until the window slides past it
+      pushed_ = true;
+    }
+    win.push_back(lv);
+    if (static_cast<int>(win.size()) > window_) win.pop_front();
+  }
+  const RT & newest() const { return win.back().T; }
+  void clear() { win.clear(); }
+  // update_iters Gauss-Newton iterations at scan k; returns the cost before each iteration
+  std::vector<double> optimise(const size_t k, const PhotometricFactor::Ptr & pf)
+  {
+    const double * Wb = Wb_;
+    const struct
     {
-      size_t k;
-      RT T;
-      ICPFactor::Ptr f;
-      bool has_Z;
-      RT Z;
-    };
-    std::deque<Live> win;
-    std::vector<RT> kf_poses;
-    State prev = state0;
-    bool have_prev = false;
-    const double wr = 1.0 / (cfg_.between_sigma_rot * cfg_.between_sigma_rot), wt = 1.0 / (cfg_.between_sigma_trans * cfg_.between_sigma_trans);
-    const double Wb[6] = {wr, wr, wr, wt, wt, wt};
-    const float I3f[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3f[3] = {0, 0, 0};
-    const auto t_begin = clk::now();
-    for (size_t k = 0; k < scans.size(); ++k) {
-      const ScanInput & sc = scans[k];
-      const auto a0 = clk::now();
-      scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
-      const auto a1 = clk::now();
-      State pred;
-      const std::vector<RT> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
-      std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
-      {
-        const A9 Rt = transpose(pred.T.R);
-        for (size_t g = 0; g < T_W_Bt.size(); ++g) {
-          RT d;
-          d.R = matmul(Rt, T_W_Bt[g].R);
-          d.t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
-          T_Le_Lt[g] = toPose3(d);
-        }
-      }
-      const auto a2 = clk::now();
-      scan_.deskewPoints(T_Le_Lt);
-      const Key Xk = X(k);
-      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
-      ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
-                                               cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
-                  "mh_scan_preprocess_geometric");
-      const auto a3 = clk::now();
-      Live lv;
-      lv.k = k;
-      lv.T = pred.T;
-      lv.f = std::make_shared<ICPFactor>(Xk, map_, scan_, cfg_.reg);
-      lv.f->computeComponents(false);  // the loop below only takes H, b, f
-      lv.has_Z = have_prev;
-      if (have_prev) lv.Z = between(prev.T, pred.T);
-      Values values;
-      NonlinearFactorGraph photo_graph;
-      if (photo_) {
-        values.insert(Xk, toPose3(pred.T));
-        photo_->getFactors(values, photo_graph);  // no factor while nothing is tracked (photometric.cpp:381)
-      }
-      PhotometricFactor::Ptr pf = photo_ ? photo_->factor() : nullptr;
-      win.push_back(lv);
-      if (static_cast<int>(win.size()) > cfg_.window) win.pop_front();
-      const auto a4 = clk::now();
-      // ---- smoother update: every live factor re-linearized per iteration ----------------------------------------
+      int window, update_iters;
+    } cfg_{window_, update_iters_};
       const size_t nW = win.size(), dim = 6 * nW;
       std::vector<double> fs;
       for (int it = 0; it < cfg_.update_iters; ++it) {
@@ -369,7 +328,7 @@ public:
           }
         }
         // what marginalisation leaves on the oldest pose; loose while that pose has never been optimised
-        const bool loose = win[0].k == 0 && static_cast<int>(k) < cfg_.window;
+        const bool loose = win[0].k == first_k_ && static_cast<int>(k - first_k_) < cfg_.window;
         const double sr = loose ? 0.017453292519943295 : 1e-4, st = loose ? 0.1 : 1e-4;
         for (int p = 0; p < 3; ++p) {
           A[p * dim + p] += 1.0 / (sr * sr);
@@ -383,6 +342,93 @@ public:
         for (size_t i = 0; i < nW; ++i) retract(win[i].T, &xi[6 * i]);
         fs.push_back(cost);
       }
+    return fs;
+  }
+  std::deque<Live> win;
+
+private:
+  int window_, update_iters_;
+  double Wb_[6];
+  size_t first_k_ = 0;
+  bool pushed_ = false;
+};
+
+class FixedLagReplay
+{
+public:
+  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx)
+  {
+    map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, cfg_.reg.target_ivox_map_leaf_size);
+    map_->set_lru_horizon(lru_horizon);
+    map_->set_neighbor_voxel_mode(cfg_.neighbor_voxel_mode);
+    map_->set_min_dist_in_cell(cfg_.reg.target_ivox_map_min_dist_in_voxel);
+    if (cfg_.photometric) {
+      // its own context = its own HIP stream: the patch factor (60 waves, a 27 us latency chain) and the window's ICP batch
+      // (a few hundred waves) are independent work of one smoother iteration and run side by side instead of one behind
+      // the other; every hand-over between the two contexts happens at a call that synchronises anyway
+      photo_ctx_ = std::make_shared<lidar::Context>(ctx_->device());
+      photo_.reset(new Photometric(photo_ctx_, cfg_.photo));
+      scan_.keepRaw(true);
+    }
+  }
+  void seedMap(const float * xyz, size_t n) { map_->insert(xyz, n); }
+
+  // state0: the state at the first IMU sample of the first sweep (the caller's first guess)
+  Result run(const std::vector<ScanInput> & scans, const State & state0)
+  {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    Result res;
+    using Live = WindowSmoother::Live;
+    WindowSmoother smoother(cfg_.window, cfg_.update_iters, cfg_.between_sigma_rot, cfg_.between_sigma_trans);
+    std::deque<Live> & win = smoother.win;
+    std::vector<RT> kf_poses;
+    State prev = state0;
+    bool have_prev = false;
+    const float I3f[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3f[3] = {0, 0, 0};
+    const auto t_begin = clk::now();
+    for (size_t k = 0; k < scans.size(); ++k) {
+      const ScanInput & sc = scans[k];
+      const auto a0 = clk::now();
+      scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
+      const auto a1 = clk::now();
+      State pred;
+      const std::vector<RT> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
+      std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
+      {
+        const A9 Rt = transpose(pred.T.R);
+        for (size_t g = 0; g < T_W_Bt.size(); ++g) {
+          RT d;
+          d.R = matmul(Rt, T_W_Bt[g].R);
+          d.t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
+          T_Le_Lt[g] = toPose3(d);
+        }
+      }
+      const auto a2 = clk::now();
+      scan_.deskewPoints(T_Le_Lt);
+      const Key Xk = X(k);
+      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+      ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
+                                               cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
+                  "mh_scan_preprocess_geometric");
+      const auto a3 = clk::now();
+      Live lv;
+      lv.k = k;
+      lv.T = pred.T;
+      lv.f = std::make_shared<ICPFactor>(Xk, map_, scan_, cfg_.reg);
+      lv.f->computeComponents(false);  // the loop below only takes H, b, f
+      lv.has_Z = have_prev;
+      if (have_prev) lv.Z = between(prev.T, pred.T);
+      Values values;
+      NonlinearFactorGraph photo_graph;
+      if (photo_) {
+        values.insert(Xk, toPose3(pred.T));
+        photo_->getFactors(values, photo_graph);  // no factor while nothing is tracked (photometric.cpp:381)
+      }
+      PhotometricFactor::Ptr pf = photo_ ? photo_->factor() : nullptr;
+      smoother.push(lv);
+      const auto a4 = clk::now();
+      const std::vector<double> fs = smoother.optimise(k, pf);
       res.costs.push_back(fs);
       const auto a5 = clk::now();
       const RT T = win.back().T;
@@ -442,6 +488,200 @@ private:
   IncrementalVoxelMapPCL::Ptr map_;
   std::shared_ptr<lidar::Context> photo_ctx_;  // declared before photo_: destroyed after it
   std::unique_ptr<Photometric> photo_;
+};
+
+// ---- the same sequence through lidar::Manager::callback (manager.hpp) -------------------------------------------------
+// Stand-ins for what the reference's Manager talks to and this build leaves to GTSAM: the IMU side integrates the scan's
+// samples with constant acceleration / rate per sample (the arithmetic of propagate() above), the graph side keeps the
+// fixed-lag window of WindowSmoother.  Reference semantics, which differ from FixedLagReplay in one place: the FIRST cloud
+// initialises (its pose is the graph's initial pose, it is not registered, manager.cpp:111-121) — so the initial state handed
+// in should be a good one.
+class SampleImu : public imu::ManagerInterface
+{
+public:
+  explicit SampleImu(const A3 & gravity) : g_(gravity) {}
+  void load(const ImuSamples * s) { cur_samples_ = s; }
+  void getInterpolatedMeasurements(const double, const double, ImuBuffer & out, const bool) override
+  {
+    out.clear();
+    for (size_t j = 0; j < cur_samples_->ts.size(); ++j) {
+      V6D m;
+      for (int i = 0; i < 3; ++i) {
+        m(i) = cur_samples_->acc[j][i];
+        m(3 + i) = cur_samples_->gyro[j][i];
+      }
+      out.emplace_back(cur_samples_->ts[j], m);
+    }
+  }
+  double gravityNorm() const override { return std::sqrt(g_[0] * g_[0] + g_[1] * g_[1] + g_[2] * g_[2]); }
+  void resetIntegrationAndSetBias(const mimosa_hip::State & state) override
+  {
+    const PoseRM p = rowMajor(state.navState().pose());
+    st_.T.R = p.R;
+    st_.T.t = p.t;
+    st_.vel = toArray(state.navState().velocity());
+  }
+  void integrateMeasurement(const V3D & acc, const V3D & gyro, const double d) override
+  {
+    const A3 Ra = matvec(st_.T.R, toArray(acc));
+    const A3 aw{Ra[0] + g_[0], Ra[1] + g_[1], Ra[2] + g_[2]};
+    const A9 Rn = matmul(st_.T.R, so3Expmap({gyro(0) * d, gyro(1) * d, gyro(2) * d}));
+    for (int i = 0; i < 3; ++i) {
+      st_.T.t[i] = st_.T.t[i] + st_.vel[i] * d + 0.5 * aw[i] * d * d;
+      st_.vel[i] = st_.vel[i] + aw[i] * d;
+    }
+    st_.T.R = Rn;
+  }
+  gtsam::NavState predict(const mimosa_hip::State &) override { return gtsam::NavState(toPose3(st_.T), V3D(st_.vel[0], st_.vel[1], st_.vel[2])); }
+  const State & integrated() const { return st_; }
+  Unit3 gravityUnit() const
+  {
+    const double n = gravityNorm();
+    return Unit3(g_[0] / n, g_[1] / n, g_[2] / n);
+  }
+
+private:
+  A3 g_;
+  const ImuSamples * cur_samples_ = nullptr;
+  State st_;
+};
+
+class WindowGraph : public graph::ManagerInterface
+{
+public:
+  WindowGraph(const Config & cfg, SampleImu & imu, const State & state0)
+  : cfg_(cfg), imu_(imu), smoother_(cfg.window, cfg.update_iters, cfg.between_sigma_rot, cfg.between_sigma_trans), prev_(state0)
+  {
+  }
+  void beginScan(const ScanInput & sc) { cur_ = &sc; }
+  // the state "up to" the cloud's header stamp: the last optimised pose with the propagated velocity (first cloud: the caller's)
+  void getStateUpto(const double, mimosa_hip::State & state) override
+  {
+    state.update(X(have_prev_ ? k_ : 0), cur_->imu.ts.front(), gtsam::NavState(toPose3(prev_.T), V3D(prev_.vel[0], prev_.vel[1], prev_.vel[2])), V3D(0, 0, 0),
+                 V3D(0, 0, 0), imu_.gravityUnit());
+  }
+  graph::DeclarationResult declare(const double, size_t & new_key, const bool use_to_init) override
+  {
+    // the graph predicts the new state from its own IMU factor: the same integration the LiDAR manager runs for deskewing
+    propagate(prev_, cur_->imu, cur_->header_ts, {}, cfg_.gravity, pred_);
+    if (!have_prev_) {
+      if (!use_to_init) return graph::DeclarationResult::FAILURE_CANNOT_INIT_ON_MODALITY;
+      new_key = k_ = 0;
+      return graph::DeclarationResult::SUCCESS_INITIALIZED;
+    }
+    new_key = ++k_;
+    return graph::DeclarationResult::SUCCESS_NORMAL;
+  }
+  Pose3 getPoseAt(const size_t) override { return toPose3(pred_.T); }
+  Values getCurrentOptimizedValues() override
+  {
+    Values v;
+    v.insert(G(0), imu_.gravityUnit());
+    return v;
+  }
+  // smoother_->update(): the new ICP factor joins the window, every live one is re-linearized per iteration
+  void define(const NonlinearFactorGraph & new_factors, Values & optimized_values, const graph::DeclarationResult) override
+  {
+    WindowSmoother::Live lv;
+    lv.k = k_;
+    lv.T = pred_.T;
+    lv.has_Z = have_prev_;
+    if (have_prev_) lv.Z = between(prev_.T, pred_.T);
+    PhotometricFactor::Ptr pf;
+    for (const auto & f : new_factors) {
+      if (auto icp = std::dynamic_pointer_cast<ICPFactor>(f)) lv.f = icp;
+      if (auto ph = std::dynamic_pointer_cast<PhotometricFactor>(f)) pf = ph;
+    }
+    if (!lv.f) throw std::runtime_error("WindowGraph::define: no ICPFactor among the new factors");
+    smoother_.push(lv);
+    costs.push_back(smoother_.optimise(k_, pf));
+    for (const auto & l : smoother_.win) optimized_values.insert_or_assign(X(l.k), toPose3(l.T));
+    finish(smoother_.newest());
+  }
+  // the first cloud is not optimised: its pose becomes the previous state as it is
+  void initialised() { finish(pred_.T); }
+  std::vector<std::vector<double>> costs;
+
+private:
+  void finish(const RT & T)
+  {
+    prev_.vel = matvec(T.R, matvec(transpose(pred_.T.R), pred_.vel));  // the propagated velocity, carried into the corrected attitude
+    prev_.T = T;
+    have_prev_ = true;
+  }
+  Config cfg_;
+  SampleImu & imu_;
+  WindowSmoother smoother_;
+  State prev_, pred_;
+  const ScanInput * cur_ = nullptr;
+  size_t k_ = 0;
+  bool have_prev_ = false;
+};
+
+class ManagerReplay
+{
+public:
+  ManagerReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), imu_(cfg.gravity)
+  {
+    lidar::ManagerConfig mc;
+    mc.range_min = cfg.input.range_min;
+    mc.range_max = cfg.input.range_max;
+    mc.intensity_min = cfg.input.intensity_min;
+    mc.intensity_max = cfg.input.intensity_max;
+    mc.ns_max = cfg.input.ns_max;
+    mc.z_offset = cfg.input.z_offset;
+    mc.create_full_res_pointcloud = cfg.input.create_full_res_pointcloud != 0;
+    gc_.point_skip_divisor = cfg.input.point_skip_divisor;
+    gc_.ring_skip_divisor = cfg.input.ring_skip_divisor;
+    gc_.map_keyframe_trans_thresh = static_cast<float>(cfg.keyframe_trans_thresh);
+    gc_.map_keyframe_rot_thresh_deg = static_cast<float>(cfg.keyframe_rot_thresh_deg);
+    gc_.initial_clouds_to_force_map_update = 0;
+    gc_.lru_horizon = lru_horizon;
+    gc_.neighbor_voxel_mode = cfg.neighbor_voxel_mode;
+    gc_.scan_to_map = cfg.reg;
+    mc_ = mc;
+    pc_ = cfg.photo;
+    pc_.enabled = cfg.photometric;
+    if (cfg.photometric) photo_ctx_ = std::make_shared<lidar::Context>(ctx_->device());
+  }
+  Result run(const std::vector<ScanInput> & scans, const State & state0, const float * seed_xyz = nullptr, size_t n_seed = 0)
+  {
+    using clk = std::chrono::steady_clock;
+    WindowGraph graph(cfg_, imu_, state0);
+    lidar::Manager manager(ctx_, mc_, gc_, pc_, graph, imu_, photo_ctx_);
+    if (n_seed) manager.geometric().map()->insert(seed_xyz, n_seed);
+    Result res;
+    const auto t0 = clk::now();
+    for (size_t k = 0; k < scans.size(); ++k) {
+      imu_.load(&scans[k].imu);
+      graph.beginScan(scans[k]);
+      manager.callback(scans[k].raw.data(), scans[k].raw.size(), scans[k].header_ts);
+      if (k == 0) graph.initialised();
+      const PoseRM p = rowMajor(manager.lastPose());
+      RT T;
+      T.R = p.R;
+      T.t = p.t;
+      res.poses.push_back(T);
+      res.n_keyframes += manager.geometric().debug().map_updated ? 1 : 0;
+      if (manager.photometric().debug().n_features_in_factor) res.photo_valid.push_back(manager.photometric().debug().n_status[8]);
+      res.stage[0] += (manager.debug().t_deskew + manager.debug().t_preprocess_geo_photo) * 1e-3;
+      res.stage[2] += manager.debug().t_factor_prep * 1e-3;
+      res.stage[3] += manager.debug().t_define * 1e-3;
+      res.stage[4] += manager.debug().t_post_define_update * 1e-3;
+    }
+    res.costs = graph.costs;
+    res.seconds = std::chrono::duration<double>(clk::now() - t0).count();
+    return res;
+  }
+
+private:
+  std::shared_ptr<lidar::Context> ctx_;
+  Config cfg_;
+  SampleImu imu_;
+  lidar::ManagerConfig mc_;
+  lidar::GeometricConfig gc_;
+  lidar::PhotometricConfig pc_;
+  std::shared_ptr<lidar::Context> photo_ctx_;
 };
 
 }  // namespace replay

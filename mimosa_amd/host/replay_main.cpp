@@ -13,10 +13,11 @@ using binio::read_vec;
 int main(int argc, char ** argv)
 {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: replay_native <input.bin> [repeats]\n");
+    std::fprintf(stderr, "usage: replay_native <input.bin> [repeats] [manager]\n");
     return 2;
   }
   const int repeats = argc > 2 ? std::atoi(argv[2]) : 1;
+  const bool through_manager = argc > 3 && std::string(argv[3]) == "manager";  // the same sequence through lidar::Manager::callback
   try {
     std::ifstream f(argv[1], std::ios::binary);
     if (!f) throw std::runtime_error("cannot open the input file");
@@ -63,9 +64,14 @@ int main(int argc, char ** argv)
     auto ctx = std::make_shared<lidar::Context>(0);
     replay::Result r;
     for (int rep = 0; rep < repeats; ++rep) {
-      replay::FixedLagReplay run(ctx, cfg, static_cast<size_t>(I[4]));
-      run.seedMap(seed.data(), seed.size() / 3);
-      r = run.run(scans, st0);
+      if (through_manager) {
+        replay::ManagerReplay run(ctx, cfg, static_cast<size_t>(I[4]));
+        r = run.run(scans, st0, seed.data(), seed.size() / 3);
+      } else {
+        replay::FixedLagReplay run(ctx, cfg, static_cast<size_t>(I[4]));
+        run.seedMap(seed.data(), seed.size() / 3);
+        r = run.run(scans, st0);
+      }
     }
     std::printf("{\"scans\": %zu, \"seconds\": %.9f, \"scans_per_s\": %.3f, \"n_keyframes\": %d,\n", scans.size(), r.seconds,
                 static_cast<double>(scans.size()) / r.seconds, r.n_keyframes);
@@ -74,7 +80,7 @@ int main(int argc, char ** argv)
     std::printf("\"photo_valid\": [");
     for (size_t i = 0; i < r.photo_valid.size(); ++i) std::printf("%d%s", r.photo_valid[i], i + 1 < r.photo_valid.size() ? ", " : "");
     std::printf("],\n\"first_costs\": [");
-    for (size_t i = 0; i < r.costs.at(0).size(); ++i) std::printf("%.17g%s", r.costs[0][i], i + 1 < r.costs[0].size() ? ", " : "");
+    for (size_t i = 0; !r.costs.empty() && i < r.costs.at(0).size(); ++i) std::printf("%.17g%s", r.costs[0][i], i + 1 < r.costs[0].size() ? ", " : "");
     std::printf("],\n\"poses\": [");
     for (size_t k = 0; k < r.poses.size(); ++k) {
       std::printf("[");
