@@ -638,8 +638,21 @@ def main():
             rp_stats["native"] = {"scans_per_s": round(rn["scans_per_s"], 1), "keyframes": rn["n_keyframes"],
                                   "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rn["stage_s"].items()},
                                   "max_abs_translation_difference_to_the_python_harness_m": dpos,
-                                  "note": "replay_native (mimosa_amd/host/replay_main.cpp): the same loop in C++ over the host mirror, "
-                                          "second pass over the sequence (allocations warm)"}
+                                  "note": "replay_native (mimosa_amd/host/replay_main.cpp): the same loop in C++ over the host mirror, PIPELINED across "
+                                          "scans (the next cloud staged on a copy stream, the photometric map update on a worker thread beside the next "
+                                          "scan's geometric path); second pass over the sequence (allocations warm).  The per-stage times are the main "
+                                          "thread's (overlapped work is not in them)"}
+            with tempfile.TemporaryDirectory() as td:
+                rs = replay.run_native(rcfg, rscans, td, repeats=2, sequential=True)
+            rp_stats["native"]["sequential"] = {"scans_per_s": round(rs["scans_per_s"], 1),
+                                                "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rs["stage_s"].items()},
+                                                "trajectory_identical_to_pipelined": bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                                                                                              for a, b in zip(rs["poses_est"], rn["poses_est"])))}
+            with tempfile.TemporaryDirectory() as td:
+                rm_ = replay.run_native(rcfg, rscans, td, repeats=2, through_manager=True)
+            rp_stats["native"]["through_lidar_manager"] = {"scans_per_s": round(rm_["scans_per_s"], 1),
+                                                           "note": "the same sequence through lidar::Manager::callback (host/mimosa_hip/manager.hpp): the reference's call order "
+                                                                   "incl. Geometric::getFactors' own first linearize with the component pass; the first cloud initialises"}
         except Exception as exc:  # noqa: BLE001 - reported, the Python figure above stands
             rp_stats["native"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:

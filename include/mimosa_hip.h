@@ -349,6 +349,13 @@ int mh_scan_prepare_input_layout(mh_scan * scan, const void * raw, size_t n, con
  * wants the figure without the PCIe upload): d_raw must stay valid and unchanged until the call returns. */
 int mh_scan_prepare_input_device(mh_scan * scan, const mh_ouster_point * d_raw, size_t n, const mh_input_config * cfg,
                                  mh_scan_info * info);
+/* Pipelined input.  mh_scan_prefetch stages the NEXT cloud while another scan is being processed: raw[n] is copied into the
+ * handle's pinned staging buffer and the host-to-device copy is enqueued on a copy stream of the handle's own; it returns as
+ * soon as the caller's buffer may go away.  It may be called from another host thread than the one that runs the pipeline,
+ * on a handle no other call is using at that moment.  mh_scan_prepare_input_prefetched is mh_scan_prepare_input on the staged
+ * cloud: the context stream waits for the copy on the device, the host does not. */
+int mh_scan_prefetch(mh_scan * scan, const mh_ouster_point * raw, size_t n);
+int mh_scan_prepare_input_prefetched(mh_scan * scan, const mh_input_config * cfg, mh_scan_info * info);
 /* unique_ns_ (lidar/manager.cpp:344-368), ascending; the caller's IMU propagation needs them on the host. */
 int mh_scan_get_unique_ns(const mh_scan * scan, uint32_t * out, size_t capacity, size_t * n_out);
 /* Manager::deskewPoints' per-point part (lidar/manager.cpp:496-509) on points_full_, in place:

@@ -145,7 +145,7 @@ def build_replay_native(force: bool = False) -> str:
     with _BuildLock():
         if force or _stale(exe, deps):
             _run_to(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.dirname(HERE), "-I", host, "-I", os.path.join(host, "gtsam_sig"), src, "-o", exe,
-                     "-L", LIBDIR, "-lmimosa_hip", "-Wl,-rpath,$ORIGIN"], exe)
+                     "-L", LIBDIR, "-lmimosa_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"], exe)
     return exe
 
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
     "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_set_components", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
-    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_prepare_input_layout", "mh_scan_get_unique_ns", "mh_scan_deskew",
+    "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_prefetch", "mh_scan_prepare_input_prefetched", "mh_scan_prepare_input_layout", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
@@ -367,6 +367,8 @@ def load(build_if_missing: bool = True):
     L.mh_scan_prepare_input_layout.argtypes = [vp, vp, sz, C.POINTER(PointLayout), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double,
                                                C.POINTER(InputConfig), C.POINTER(ScanInfo)]
     L.mh_scan_prepare_input_device.argtypes = [vp, vp, sz, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
+    L.mh_scan_prefetch.argtypes = [vp, vp, sz]
+    L.mh_scan_prepare_input_prefetched.argtypes = [vp, C.POINTER(InputConfig), C.POINTER(ScanInfo)]
     L.mh_scan_get_unique_ns.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.mh_scan_deskew.argtypes = [vp, vp, sz]
     L.mh_scan_preprocess_geometric.argtypes = [vp, vp, vp, C.c_double, i32, C.c_double, C.POINTER(ScanInfo)]
@@ -598,6 +600,17 @@ class Scan:
         info = ScanInfo()
         self.ctx.check(self.L.mh_scan_prepare_input_layout(self.h, _p(raw), n, C.byref(layout), width, height, int(transpose),
                                                            int(organize_by_ring), header_ts, C.byref(cfg), C.byref(info)))
+        return info.as_dict()
+
+    def prefetch(self, raw):
+        """stage the next cloud: pinned copy + host-to-device copy on the handle's copy stream (returns before the copy is done)"""
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype.itemsize == 32
+        self.ctx.check(self.L.mh_scan_prefetch(self.h, _p(raw), len(raw)))
+
+    def prepare_input_prefetched(self, cfg: InputConfig) -> dict:
+        info = ScanInfo()
+        self.ctx.check(self.L.mh_scan_prepare_input_prefetched(self.h, C.byref(cfg), C.byref(info)))
         return info.as_dict()
 
     def prepare_input_device(self, d_raw_ptr: int, n: int, cfg: InputConfig) -> dict:

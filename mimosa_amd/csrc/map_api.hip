@@ -221,8 +221,9 @@ int insert_device(mh_map * m, const float * d_src, size_t n, size_t stride, cons
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_insert: batch too large");
   if (m->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_insert: the map is inconsistent after a failed mutation");
   // Factors of other contexts (HIP streams) may be reading this map: the arrays are modified in place and may be
-  // reallocated, so the whole device is drained first (microseconds when idle).
-  MH_HIP(ctx, hipDeviceSynchronize());
+  // reallocated, so the streams of the contexts that hold factors on it are waited for first (none in the usual
+  // copy-then-insert: the fresh copy has no factor yet).
+  MH_HIP(ctx, map_wait_readers(m));
   if (n) {
     int rc = ensure_scratch(m, n);
     if (rc != MH_OK) return rc;
@@ -309,7 +310,7 @@ int mh_map_create(mh_ctx * ctx, const mh_map_config * cfg, mh_map ** out)
     if (md != 1 && md != 7 && md != 19 && md != 27) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: neighbor_voxel_mode must be 1, 7, 19 or 27");
     if (cfg->lru_clear_cycle < 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_clear_cycle must be >= 1");
     if (cfg->lru_horizon < 0) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_create: lru_horizon must be >= 0");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     mh_map * m = nullptr;
     int rc = map_alloc(ctx, *cfg, &m);
     if (rc != MH_OK) return rc;
@@ -364,7 +365,7 @@ int mh_map_insert(mh_map * map, const float * xyz, size_t n, size_t stride_float
   mh_ctx * ctx = map->ctx;
   return guarded(ctx, "mh_map_insert", [&]() -> int {
     if (stride_floats < 3) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert: stride_floats must be >= 3");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     if (n) {
       const int rc = stage_batch(map, xyz, n, stride_floats);
       if (rc != MH_OK) return rc;
@@ -384,7 +385,7 @@ int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride
     if (stride_floats < 3) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard: stride_floats must be >= 3");
     if (world < 1 || world > 64 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 10)
       return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard: world in 1..64, 0 <= rank < world, block_log2 in 0..10");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     size_t kept = 0;
     if (n) {
       if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_insert_shard: batch too large");
@@ -413,7 +414,7 @@ int mh_map_insert_device(mh_map * map, const void * d_points, size_t n, size_t s
   return guarded(ctx, "mh_map_insert_device", [&]() -> int {
     if (stride_floats < 3) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_device: stride_floats must be >= 3");
     if ((R == nullptr) != (t == nullptr)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_device: R and t go together");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     const float * d_rt = nullptr;
     if (R) {
       float rt[12];
@@ -443,7 +444,7 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
   mh_ctx * ctx = src->ctx;
   return guarded(ctx, "mh_map_copy", [&]() -> int {
     if (src->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_copy: the map is inconsistent after a failed mutation");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     mh_map * m = nullptr;
     int rc = map_alloc(ctx, src->cfg, &m);
     if (rc != MH_OK) return rc;
@@ -494,8 +495,8 @@ void mh_map_release(mh_map * map)
 {
   if (!map) return;
   if (map->refs.fetch_sub(1) == 1) {
-    (void)hipSetDevice(map->ctx->device);
-    (void)hipDeviceSynchronize();
+    (void)mh_enter(map->ctx);
+    (void)hipStreamSynchronize(map->ctx->stream);  // the last factor is gone (each waited for its own stream): only the map's own work can be in flight
     map_free(map);
   }
 }
@@ -529,7 +530,7 @@ int mh_map_get_cloud(const mh_map * cmap, float * xyz, size_t capacity_points, s
     if (map->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_get_cloud: the map is inconsistent after a failed mutation");
     *n_out = static_cast<size_t>(map->n_points);
     if (!xyz || map->n_points == 0) return MH_OK;
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     const uint32_t nv = map->n_voxels;
     const size_t np = static_cast<size_t>(map->n_points);
     MH_HIP(ctx, map->s_flags.reserve(nv * sizeof(uint32_t), ctx->stream, false));
@@ -553,7 +554,7 @@ int mh_map_knn(mh_map * map, const double * queries, size_t n, int k, double * p
   return guarded(ctx, "mh_map_knn", [&]() -> int {
     if (k < 1 || k > 8) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_knn: k must be in 1..8");
     if (map->poisoned) return fail(ctx, MH_ERR_HIP, "mh_map_knn: the map is inconsistent after a failed mutation");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     if (n == 0) return MH_OK;
     DevTemp<double> d_q, d_p, d_s;
     DevTemp<int32_t> d_f;

@@ -222,7 +222,7 @@ int mh_init(int device, mh_ctx ** out)
 void mh_shutdown(mh_ctx * ctx)
 {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  (void)mh_enter(ctx);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -232,6 +232,10 @@ void mh_shutdown(mh_ctx * ctx)
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   if (ctx->d_batch) (void)hipFree(ctx->d_batch);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
   const int dev = ctx->device;
   delete ctx;
   AllocCache::context_destroyed(dev);  // the device's last context: its cached blocks (and, with no context left anywhere, the pinned ones) go back
@@ -253,7 +257,7 @@ void * mh_stream(mh_ctx * ctx) { return ctx ? static_cast<void *>(ctx->stream) :
 static int mh_synchronize_impl(mh_ctx * ctx)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_synchronize: ctx is NULL");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
 }
@@ -265,7 +269,7 @@ int mh_synchronize(mh_ctx * ctx)
 static int mh_timer_begin_impl(mh_ctx * ctx)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_timer_begin: ctx is NULL");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   MH_HIP(ctx, hipEventRecord(ctx->timer[0], ctx->stream));
   return MH_OK;
 }
@@ -277,7 +281,7 @@ int mh_timer_begin(mh_ctx * ctx)
 static int mh_timer_end_impl(mh_ctx * ctx, float * ms)
 {
   if (!ctx || !ms) return fail(ctx, MH_ERR_INVALID_ARG, "mh_timer_end: NULL argument");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   MH_HIP(ctx, hipEventRecord(ctx->timer[1], ctx->stream));
   MH_HIP(ctx, hipEventSynchronize(ctx->timer[1]));
   MH_HIP(ctx, hipEventElapsedTime(ms, ctx->timer[0], ctx->timer[1]));
@@ -385,12 +389,13 @@ static int icp_create_common(mh_ctx * ctx, mh_map * map, const mh_point32 * sour
   if (cfg->num_corres_points < 2 || cfg->num_corres_points > 8)
     return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: num_corres_points must be in 2..8");
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_create: cloud too large");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   mh_icp * icp = new (std::nothrow) mh_icp;
   if (!icp) return fail(ctx, MH_ERR_OOM, "mh_icp_create: host allocation failed");
   icp->ctx = ctx;
   icp->map = map;
   mh_map_retain(map);
+  map_add_reader(map, ctx);
   icp->n = n;
   icp->cfg = *cfg;
   icp->binary = is_binary != 0;
@@ -429,12 +434,13 @@ static int mh_icp_clone_impl(const mh_icp * src, mh_icp ** out)
   *out = nullptr;
   mh_ctx * ctx = src->ctx;
   if (src->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_clone: source has linearize calls in flight");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   mh_icp * icp = new (std::nothrow) mh_icp;
   if (!icp) return fail(ctx, MH_ERR_OOM, "mh_icp_clone: host allocation failed");
   icp->ctx = ctx;
   icp->map = src->map;
   mh_map_retain(icp->map);
+  map_add_reader(icp->map, ctx);
   icp->n = src->n;
   icp->cfg = src->cfg;
   icp->binary = src->binary;
@@ -474,7 +480,7 @@ int mh_icp_clone(const mh_icp * src, mh_icp ** out)
 void mh_icp_destroy(mh_icp * icp)
 {
   if (!icp) return;
-  (void)hipSetDevice(icp->ctx->device);
+  (void)mh_enter(icp->ctx);
   (void)hipStreamSynchronize(icp->ctx->stream);
   icp->d_src.release(true);
   icp->d_qda.release(true);
@@ -495,7 +501,10 @@ void mh_icp_destroy(mh_icp * icp)
   if (icp->events_ready)
     for (auto & ev : icp->events)
       for (auto & e : ev) (void)hipEventDestroy(e);
-  if (icp->map) mh_map_release(icp->map);
+  if (icp->map) {
+    map_remove_reader(icp->map, icp->ctx);
+    mh_map_release(icp->map);
+  }
   delete icp;
 }
 
@@ -510,7 +519,7 @@ int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_word
   const size_t words = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 16;
   *n_words = words;
   if (capacity_words < words) return MH_ERR_INVALID_ARG;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MH_HIP(ctx, hipMemcpy(out, icp->d_dbg.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return MH_OK;
@@ -583,7 +592,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   mh_ctx * ctx = icp->ctx;
   if (icp->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize: binary factor needs the target pose");
   if (icp->n_pending >= kMaxPending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_async: too many calls in flight");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   if (ctx->profiling && !icp->events_ready) {
     for (auto & ev : icp->events)
       for (auto & e : ev) MH_HIP(ctx, hipEventCreate(&e));
@@ -713,7 +722,7 @@ static int mh_icp_wait_impl(mh_icp * icp)
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
   mh_ctx * ctx = icp->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   // Each call's last kernel publishes its sequence number to the mapped host slot after the results: spin on
   // it instead of paying the runtime's stream-synchronisation latency.  Fall back to the stream when something
   // was not launched, is being timed by events, or does not show up within the spin budget.
@@ -793,7 +802,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     for (size_t g = 0; g < f; ++g)
       if (icps[g] == c) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: the same factor twice");
   }
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   // Launch groups: the factors that share a kernel instantiation — workgroup size (256 threads up to 65 536 points, 512
   // above: so every factor reduces in exactly the order of a separate call), k == 5 or the generic k <= 8 path, neighbour
   // mode, unary / binary.  One K3b (+ one K4b) launch per non-empty group; a window of like factors — the usual case — is
@@ -956,7 +965,7 @@ static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9]
   mh_ctx * ctx = icp->ctx;
   if (!icp->split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish: no mh_icp_linearize_begin before");
   icp->split_open = false;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   for (int i = 0; i < 3; ++i) loc_trans_comp[i] = loc_rot_comp[i] = 0.0;
   if (status_hist) std::memset(status_hist, 0, 9 * sizeof(int32_t));
   if (icp->n == 0) return MH_OK;
@@ -1000,7 +1009,7 @@ static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * 
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_get_state: icp is NULL");
   mh_ctx * ctx = icp->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = icp->n;
   if (n == 0) return MH_OK;
   if (icp->cold) {  // fresh factor / after mh_icp_reset: commonConstructor()'s zeros (geometric_factor.hpp:144-156)
@@ -1043,7 +1052,7 @@ static int mh_deskew_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const uint32
     return fail(ctx, MH_ERR_INVALID_ARG, "mh_deskew: NULL argument");
   if ((R_B_L == nullptr) != (t_B_L == nullptr)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_deskew: R_B_L and t_B_L go together");
   if (n == 0) return MH_OK;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   DevTemp<mh_point32> d_pts;
   DevTemp<uint32_t> d_ns;
   DevTemp<float> d_rt, d_body;
@@ -1078,7 +1087,7 @@ static int mh_transform_f32_impl(mh_ctx * ctx, mh_point32 * pts, size_t n, const
 {
   if (!ctx || (!pts && n) || !R || !t) return fail(ctx, MH_ERR_INVALID_ARG, "mh_transform_f32: NULL argument");
   if (n == 0) return MH_OK;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   DevTemp<mh_point32> d_pts;
   DevTemp<float> d_rt;
   float rt[12];
@@ -1171,13 +1180,18 @@ int mh_scan_create(mh_ctx * ctx, mh_scan ** out)
 void mh_scan_destroy(mh_scan * s)
 {
   if (!s) return;
-  (void)hipSetDevice(s->ctx->device);
+  (void)mh_enter(s->ctx);
   (void)hipStreamSynchronize(s->ctx->stream);
   s->d_full_raw.release(true);
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
                      &s->d_rt, &s->d_prep, &s->d_vox, &s->d_sensor})
     b->release(true);
   AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t));
+  if (s->copy_done) {
+    (void)hipEventSynchronize(s->copy_done);  // a staged upload may still be reading the staging buffer
+    (void)hipEventDestroy(s->copy_done);
+  }
+  if (s->h_stage) AllocCache::free_pinned(s->h_stage, s->h_stage_cap);
   delete s;
 }
 
@@ -1189,7 +1203,7 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
   if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, std::string(who) + ": cloud too large");
   if (cfg->point_skip_divisor < 1 || cfg->ring_skip_divisor < 1)
     return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": skip divisors must be >= 1");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   s->prepared = s->preprocessed = s->raw_valid = false;
   s->n_unique_cached = 0;
   s->n_in = n;
@@ -1221,6 +1235,63 @@ int mh_scan_prepare_input(mh_scan * s, const mh_ouster_point * raw, size_t n, co
   return guarded(s ? s->ctx : nullptr, "mh_scan_prepare_input",
                  [&]() -> int { return scan_prepare_common(s, raw, false, n, cfg, info, "mh_scan_prepare_input"); });
 }
+// Pipelined input: the NEXT cloud is staged (pinned buffer, host-to-device copy on the handle's own copy stream) while another
+// scan is being processed; mh_scan_prepare_input_prefetched then makes the context stream wait for the copy on the device.
+static int mh_scan_prefetch_impl(mh_scan * s, const mh_ouster_point * raw, size_t n)
+{
+  if (!s || (!raw && n)) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_prefetch: NULL argument");
+  mh_ctx * ctx = s->ctx;
+  if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_prefetch: cloud too large");
+  MH_HIP(ctx, mh_enter(ctx));
+  hipStream_t copy_stream = nullptr;
+  {
+    std::lock_guard<std::mutex> g(ctx->copy_mu);
+    if (!ctx->copy_stream) MH_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    copy_stream = ctx->copy_stream;
+  }
+  if (!s->copy_done) MH_HIP(ctx, hipEventCreateWithFlags(&s->copy_done, hipEventDisableTiming));
+  g_mh_stream = copy_stream;  // what this call allocates / frees is ordered by the copy stream
+  const size_t bytes = (n ? n : 1) * sizeof(mh_ouster_point);
+  if (bytes > s->h_stage_cap) {
+    // pinned staging comes from the process-wide cache in 1 MiB classes (pinning 4 MiB costs ~2 ms: a front end that lives for
+    // one sequence must not pay it again)
+    MH_HIP(ctx, hipStreamSynchronize(copy_stream));  // an earlier copy may still read the old staging buffer
+    if (s->h_stage) AllocCache::free_pinned(s->h_stage, s->h_stage_cap);
+    s->h_stage = nullptr;
+    s->h_stage_cap = 0;
+    const size_t cap = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    MH_HIP(ctx, AllocCache::alloc_pinned(&s->h_stage, cap));
+    s->h_stage_cap = cap;
+  }
+  s->prefetch_valid = false;
+  MH_HIP(ctx, hipStreamSynchronize(copy_stream));  // the previous cloud staged here has left the buffer
+  MH_HIP(ctx, s->d_raw.reserve(bytes, copy_stream, false));
+  if (n) {
+    std::memcpy(s->h_stage, raw, n * sizeof(mh_ouster_point));
+    MH_HIP(ctx, hipMemcpyAsync(s->d_raw.p, s->h_stage, n * sizeof(mh_ouster_point), hipMemcpyHostToDevice, copy_stream));
+  }
+  MH_HIP(ctx, hipEventRecord(s->copy_done, copy_stream));
+  s->n_prefetched = n;
+  s->prefetch_valid = true;
+  return MH_OK;
+}
+int mh_scan_prefetch(mh_scan * s, const mh_ouster_point * raw, size_t n)
+{
+  return guarded(s ? s->ctx : nullptr, "mh_scan_prefetch", [&]() -> int { return mh_scan_prefetch_impl(s, raw, n); });
+}
+int mh_scan_prepare_input_prefetched(mh_scan * s, const mh_input_config * cfg, mh_scan_info * info)
+{
+  return guarded(s ? s->ctx : nullptr, "mh_scan_prepare_input_prefetched", [&]() -> int {
+    if (!s || !cfg) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_prepare_input_prefetched: NULL argument");
+    mh_ctx * ctx = s->ctx;
+    if (!s->prefetch_valid) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_prepare_input_prefetched: no mh_scan_prefetch before");
+    MH_HIP(ctx, mh_enter(ctx));
+    MH_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->copy_done, 0));  // on the device: the host does not wait for the copy
+    s->prefetch_valid = false;
+    return scan_prepare_common(s, static_cast<const mh_ouster_point *>(s->d_raw.p), true, s->n_prefetched, cfg, info, "mh_scan_prepare_input_prefetched");
+  });
+}
+
 // Manager::prepareInput<PointT> for any of the reference's point types: decode into canonical records on the device, then
 // the same filter / compaction / timestamp kernels as the PointOuster path.
 static int mh_scan_prepare_input_layout_impl(mh_scan * s, const void * raw, size_t n, const mh_point_layout * L, uint32_t width, uint32_t height,
@@ -1244,7 +1315,7 @@ static int mh_scan_prepare_input_layout_impl(mh_scan * s, const void * raw, size
   // :205-210 only an unorganised cloud is re-ordered, and only for the point types that carry a ring (compiled out for
   // PointLivox, PointLivoxFromCustom2 and PointOusterOdyssey there: the flag is ignored, not an error)
   const bool organize = organize_by_ring != 0 && height_after == 1 && L->ring_kind != MH_RING_NONE;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t m = n ? n : 1, n_blk = (m + 255) / 256;
   const size_t raw_bytes = (m * L->stride + 255) & ~size_t(255), tmp_bytes = organize ? m * sizeof(mh_ouster_point) : 0;
   MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));  // the canonical records
@@ -1296,7 +1367,7 @@ static int mh_scan_get_unique_ns_impl(const mh_scan * s, uint32_t * out, size_t 
     std::memcpy(out, s->h_c + 1, *n_out * sizeof(uint32_t));
     return MH_OK;
   }
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, s->d_unique.p, *n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
@@ -1313,7 +1384,7 @@ static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
   if (!s->prepared) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_deskew: no mh_scan_prepare_input before");
   if (n_groups != s->c.n_unique_ns) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_deskew: one pose per unique timestamp");
   if (s->c.n_full == 0) return MH_OK;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   if (s->keep_raw && !s->raw_valid) {  // points_raw_ = points_full_ before deskewing (lidar/manager.cpp:376-380)
     MH_HIP(ctx, s->d_full_raw.reserve(s->c.n_full * sizeof(mh_point32), ctx->stream, false));
     MH_HIP(ctx, hipMemcpyAsync(s->d_full_raw.p, s->d_full.p, s->c.n_full * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1342,7 +1413,7 @@ static int mh_scan_preprocess_geometric_impl(mh_scan * s, const float R_B_L[9], 
   if (!(leaf_size > 0.0)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_preprocess_geometric: leaf_size must be > 0");
   if (max_points_per_voxel < 1 || max_points_per_voxel > mh::kBucketStride)
     return fail(ctx, MH_ERR_UNSUPPORTED, "mh_scan_preprocess_geometric: max_points_per_voxel must be in 1..20");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = s->c.n_geometric, m = n ? n : 1;
   s->n_body = n;
   MH_HIP(ctx, s->d_body.reserve(m * sizeof(mh_point32), ctx->stream, false));
@@ -1381,7 +1452,7 @@ static int mh_scan_get_points_impl(const mh_scan * s, int which, mh_point32 * ou
   *n_out = which == 0 ? s->c.n_full : (which == 1 ? s->n_body : s->c.n_downsampled);
   if (!out) return MH_OK;
   if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_points: buffer too small");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, b.p, *n_out * sizeof(mh_point32), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
@@ -1401,7 +1472,7 @@ static int mh_scan_get_indices_impl(const mh_scan * s, int which, uint32_t * out
   *n_out = which == 0 ? s->c.n_geometric : s->c.n_downsampled;
   if (!out) return MH_OK;
   if (capacity < *n_out) return fail(ctx, MH_ERR_INVALID_ARG, "mh_scan_get_indices: buffer too small");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   if (*n_out) MH_HIP(ctx, hipMemcpyAsync(out, b.p, *n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
@@ -1503,7 +1574,7 @@ static int mh_icp_shard_plan_impl(mh_icp * icp, const double R_src[9], const dou
   if (icp->binary) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: unary factors only");
   if (icp->ordered) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: create the factor with mh_icp_create_from_device (caller's point order)");
   if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: calls in flight");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = icp->n, k = n ? n : 1;
   if (!icp->origin_ready) {
     MH_HIP(ctx, icp->d_origin.reserve(k * sizeof(unsigned long long), ctx->stream, false));
@@ -1550,7 +1621,7 @@ static int mh_icp_shard_pack_impl(mh_icp * icp, void * d_send)
   icp->plan_open = false;
   if (icp->n_movers == 0) return MH_OK;  // nothing leaves: the arrays stay as they are
   if (!d_send) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: d_send is NULL");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = icp->n;
   int rc = shard_reserve(icp, n, true, false);
   if (rc != MH_OK) return rc;
@@ -1579,7 +1650,7 @@ static int mh_icp_shard_unpack_impl(mh_icp * icp, const void * d_recv, size_t n_
   if (!icp->origin_ready) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_unpack: no mh_icp_shard_plan before");
   if (n_recv == 0) return MH_OK;
   if (icp->n + n_recv > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_unpack: cloud too large");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const int rc = shard_reserve(icp, icp->n + n_recv, false, true);
   if (rc != MH_OK) return rc;
   MH_HIP(ctx, mh::launch_shard_unpack(shard_arrays(icp, false), static_cast<uint32_t>(icp->n), static_cast<const mh::ShardRecord *>(d_recv),
@@ -1597,7 +1668,7 @@ static int mh_icp_shard_get_state_impl(mh_icp * icp, uint64_t * origin, int32_t 
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_get_state: icp is NULL");
   mh_ctx * ctx = icp->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = icp->n;
   if (n == 0) return MH_OK;
   if (origin) {
@@ -1650,7 +1721,7 @@ static int mh_icp_linearize_finish_device_impl(mh_icp * icp, const double * d_gl
   if (!icp || !d_global_sums32 || !d_loc16) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: NULL argument");
   mh_ctx * ctx = icp->ctx;
   if (!icp->dev_split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: no mh_icp_linearize_begin_device before");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   MH_HIP(ctx, icp->d_eig.reserve(18 * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, mh::launch_shard_eig(d_global_sums32, static_cast<double *>(icp->d_eig.p), ctx->stream));
   if (icp->n > 0) {

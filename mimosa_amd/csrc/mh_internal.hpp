@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/mimosa_hip.h"
@@ -37,7 +38,18 @@ struct mh_ctx
   void * d_batch = nullptr;  // ... and the device copy the batched kernels read
   void * d_scratch = nullptr;  // stream-ordered scratch of factor creation (source ordering): reused, never freed per call
   size_t d_scratch_cap = 0;
+  hipStream_t copy_stream = nullptr;  // mh_scan_prefetch: uploads beside the compute stream (created on first use: an HSA queue costs ~1 ms)
+  std::mutex copy_mu;
 };
+
+// The stream of the context the calling thread is working for (set by mh_enter at every entry point): what the allocation
+// cache orders its hand-overs by.
+inline thread_local hipStream_t g_mh_stream = nullptr;
+inline hipError_t mh_enter(const mh_ctx * ctx)
+{
+  g_mh_stream = ctx->stream;
+  return hipSetDevice(ctx->device);
+}
 
 inline int fail(const mh_ctx * ctx, int code, const std::string & msg)
 {
@@ -73,9 +85,12 @@ inline int guarded(const mh_ctx * ctx, const char * what, E && body)
 // Device / pinned-host allocation cache.  A scan creates a factor (a dozen device buffers, a pinned result
 // ring, sort temporaries) and destroys it a few hundred milliseconds later; hipMalloc / hipFree / hipHostMalloc
 // cost 10-200 us each and hipFree synchronises the device.  Freed blocks of 4 KiB .. 64 MiB are kept per
-// (device, rounded size) and handed out again; the cache holds at most kMaxCachedBytes per device.  A cached
-// free still drains the device first (hipDeviceSynchronize: microseconds when idle), because callers rely on
-// hipFree's implicit "nobody is using this any more".
+// (device, rounded size) and handed out again; the cache holds at most kMaxCachedBytes per device.
+// Hand-over is STREAM-ORDERED, there is no device-wide drain: a block freed while its last user may still be running
+// carries an event recorded on the freeing thread's stream (g_mh_stream: every piece of work on the block was enqueued there
+// before the free); whoever takes the block next on the same stream simply queues behind, on another stream waits for the
+// event on the device.  (Round 2 drained the whole device per free, which stalled the photometric stream behind the
+// geometric one and vice versa.)
 class AllocCache
 {
 public:
@@ -85,13 +100,38 @@ public:
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (cls) {
-      std::lock_guard<std::mutex> g(mu());
-      auto & v = free_list()[key(dev, cls)];
-      if (!v.empty()) {
-        *out = v.back();
-        v.pop_back();
-        cached_bytes()[dev] -= cls;
-        live()[*out] = Block{cls, dev};
+      Cached c{};
+      bool hit = false;
+      {
+        std::lock_guard<std::mutex> g(mu());
+        auto & v = free_list()[key(dev, cls)];
+        if (!v.empty()) {
+          // prefer a block nobody can still be using, or one whose last use was ordered on THIS stream: taking another
+          // stream's block makes this stream wait (on the device) for that stream to get there
+          size_t pick = v.size() - 1;
+          for (size_t i = v.size(); i-- > 0;)
+            if (!v[i].ev || v[i].stream == g_mh_stream) {
+              pick = i;
+              break;
+            }
+          c = v[pick];
+          v[pick] = v.back();
+          v.pop_back();
+          cached_bytes()[dev] -= cls;
+          live()[c.p] = Block{cls, dev};
+          hit = true;
+        }
+      }
+      if (hit) {
+        if (c.ev) {
+          if (!g_mh_stream)
+            (void)hipEventSynchronize(c.ev);
+          else if (c.stream != g_mh_stream)
+            (void)hipStreamWaitEvent(g_mh_stream, c.ev, 0);
+          std::lock_guard<std::mutex> g(mu());
+          event_pool().push_back(c.ev);
+        }
+        *out = c.p;
         return hipSuccess;
       }
     }
@@ -103,7 +143,7 @@ public:
     return e;
   }
   // drained: the caller has already waited for every stream that ever touched the block (a factor's or a scan's own
-  // buffers after a synchronisation of their context's stream): no device-wide drain is needed before reuse
+  // buffers after a synchronisation of their context's stream): it can be handed out at once
   static void free(void * p, bool drained = false)
   {
     if (!p) return;
@@ -117,21 +157,39 @@ public:
       }
     }
     if (b.cls) {
-      // in-flight work may still read / write the block: drain ITS device before it can be handed out again — outside
-      // the lock, on the device the block was allocated on (not whatever device is current at free time)
+      Cached c{p, nullptr, nullptr};
       if (!drained) {
-        int cur = 0;
-        (void)hipGetDevice(&cur);
-        if (cur != b.dev) (void)hipSetDevice(b.dev);
-        (void)hipDeviceSynchronize();
-        if (cur != b.dev) (void)hipSetDevice(cur);
+        if (g_mh_stream) {
+          {
+            std::lock_guard<std::mutex> g(mu());
+            if (!event_pool().empty()) {
+              c.ev = event_pool().back();
+              event_pool().pop_back();
+            }
+          }
+          if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+          if (c.ev && hipEventRecord(c.ev, g_mh_stream) == hipSuccess) {
+            c.stream = g_mh_stream;
+          } else {
+            if (c.ev) (void)hipEventDestroy(c.ev);
+            c.ev = nullptr;
+          }
+        }
+        if (!c.ev) {  // no stream known for this thread: the old way, on the block's own device
+          int cur = 0;
+          (void)hipGetDevice(&cur);
+          if (cur != b.dev) (void)hipSetDevice(b.dev);
+          (void)hipDeviceSynchronize();
+          if (cur != b.dev) (void)hipSetDevice(cur);
+        }
       }
       std::lock_guard<std::mutex> g(mu());
       if (cached_bytes()[b.dev] + b.cls <= kMaxCachedBytes) {
-        free_list()[key(b.dev, b.cls)].push_back(p);
+        free_list()[key(b.dev, b.cls)].push_back(c);
         cached_bytes()[b.dev] += b.cls;
         return;
       }
+      if (c.ev) event_pool().push_back(c.ev);  // (the block itself goes back to the runtime below: hipFree waits for the device)
     }
     (void)hipFree(p);
   }
@@ -189,7 +247,10 @@ public:
       std::lock_guard<std::mutex> g(mu());
       for (auto & kv : free_list())
         if (static_cast<int>(kv.first >> 56) == dev) {
-          dead.insert(dead.end(), kv.second.begin(), kv.second.end());
+          for (const Cached & c : kv.second) {
+            dead.push_back(c.p);
+            if (c.ev) event_pool().push_back(c.ev);
+          }
           kv.second.clear();
         }
       cached_bytes()[dev] = 0;
@@ -216,6 +277,17 @@ private:
     size_t cls;
     int dev;
   };
+  struct Cached
+  {
+    void * p;
+    hipStream_t stream;  // where the free was ordered; null with ev == null: nobody is using the block
+    hipEvent_t ev;
+  };
+  static std::vector<hipEvent_t> & event_pool()
+  {
+    static std::vector<hipEvent_t> v;
+    return v;
+  }
   static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
   static size_t size_class(size_t bytes)
   {
@@ -230,9 +302,9 @@ private:
     static std::mutex m;
     return m;
   }
-  static std::unordered_map<uint64_t, std::vector<void *>> & free_list()
+  static std::unordered_map<uint64_t, std::vector<Cached>> & free_list()
   {
-    static std::unordered_map<uint64_t, std::vector<void *>> m;
+    static std::unordered_map<uint64_t, std::vector<Cached>> m;
     return m;
   }
   static std::unordered_map<void *, Block> & live()
@@ -324,6 +396,11 @@ struct mh_scan
   mh::ScanCounters c{};
   size_t n_in = 0, n_body = 0;
   bool prepared = false, preprocessed = false;
+  // mh_scan_prefetch: the NEXT cloud staged (pinned buffer -> d_raw on a copy stream of its own) while another scan is processed
+  hipEvent_t copy_done = nullptr;
+  void * h_stage = nullptr;
+  size_t h_stage_cap = 0, n_prefetched = 0;
+  bool prefetch_valid = false;
 };
 
 // IncrementalVoxelMapPCL counterpart: the device-resident voxel map (map_device.hpp / map_kernels.hip).  The device
@@ -347,8 +424,44 @@ struct mh_map
   int64_t inserts = 0, upload_bytes = 0, purges = 0;
   int n_off = 0;
   int8_t off[27][3];
+  // contexts (= HIP streams) that hold factors on this map: a mutation waits for THEIR streams, not for the whole device
+  std::mutex readers_mu;
+  std::vector<std::pair<mh_ctx *, int>> readers;
   bool poisoned = false;  // a mutation failed half way (LRU purge): the device arrays and the counters disagree; every later call fails
 };
+
+inline void map_add_reader(mh_map * m, mh_ctx * c)
+{
+  std::lock_guard<std::mutex> g(m->readers_mu);
+  for (auto & r : m->readers)
+    if (r.first == c) {
+      ++r.second;
+      return;
+    }
+  m->readers.emplace_back(c, 1);
+}
+inline void map_remove_reader(mh_map * m, mh_ctx * c)
+{
+  std::lock_guard<std::mutex> g(m->readers_mu);
+  for (auto & r : m->readers)
+    if (r.first == c && r.second > 0) --r.second;
+}
+// Before a mutation: wait for the streams of the OTHER contexts that hold factors on this map (their kernels may be reading
+// it); work on the map's own stream is ordered by the stream.  (Round 2 drained the whole device here.)
+inline hipError_t map_wait_readers(mh_map * m)
+{
+  std::vector<hipStream_t> streams;
+  {
+    std::lock_guard<std::mutex> g(m->readers_mu);
+    for (const auto & r : m->readers)
+      if (r.second > 0 && r.first != m->ctx) streams.push_back(r.first->stream);
+  }
+  for (hipStream_t st : streams) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 inline mh::MapView map_view(const mh_map * m)
 {

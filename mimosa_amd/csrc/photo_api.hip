@@ -45,7 +45,7 @@ void frame_release(PhotoFrame * f)
 {
   if (!f) return;
   if (f->refs.fetch_sub(1) == 1) {
-    (void)hipSetDevice(f->ctx->device);
+    (void)mh_enter(f->ctx);
     (void)hipStreamSynchronize(f->ctx->stream);
     f->release_buffers();
     delete f;
@@ -110,7 +110,7 @@ void photo_release(mh_photo * p)
 {
   if (!p) return;
   if (p->refs.fetch_sub(1) != 1) return;
-  (void)hipSetDevice(p->ctx->device);
+  (void)mh_enter(p->ctx);
   (void)hipStreamSynchronize(p->ctx->stream);
   frame_release(p->frame);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
@@ -661,7 +661,7 @@ int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out)
     const int ek = cfg->patch_size + cfg->erosion_buffer;
     if (ek < 1 || ek > 33) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_photo_create: patch_size + erosion_buffer must be in 1..33");
     if (!(cfg->range_min < cfg->range_max)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_create: range_min < range_max");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     mh_photo * p = new mh_photo;
     p->ctx = ctx;
     p->cfg = *cfg;
@@ -757,7 +757,7 @@ int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_poin
   return guarded(ctx, "mh_photo_preprocess", [&]() -> int {
     if (n > static_cast<size_t>(photo->cfg.rows) * photo->cfg.cols)
       return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess: number of points exceeds the image size (photometric.cpp:103-110)");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     PhotoFrame * fr = new PhotoFrame;
     fr->ctx = ctx;
     const size_t pb = (n ? n : 1) * sizeof(mh_point32);
@@ -798,7 +798,7 @@ int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_
     const size_t n = scan->c.n_full;
     if (n > static_cast<size_t>(photo->cfg.rows) * photo->cfg.cols)
       return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: number of points exceeds the image size");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     if (scan->ctx != ctx) MH_HIP(ctx, hipStreamSynchronize(scan->ctx->stream));
     PhotoFrame * fr = new PhotoFrame;
     fr->ctx = ctx;
@@ -836,7 +836,7 @@ int mh_photo_get_image(mh_photo * photo, int which, void * out, size_t capacity_
   return guarded(ctx, "mh_photo_get_image", [&]() -> int {
     PhotoFrame * fr = photo->frame;
     if (!fr) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_get_image: no frame");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     const size_t npx = static_cast<size_t>(fr->rows) * fr->cols;
     const void * src = nullptr;
     size_t bytes = 0;
@@ -926,7 +926,7 @@ int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R
   if (!photo || !R_W_Be || !t_W_Be || (n_directions && !bias_directions))
     return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_detect_features: NULL argument");
   return guarded(photo->ctx, "mh_photo_detect_features", [&]() -> int {
-    MH_HIP(photo->ctx, hipSetDevice(photo->ctx->device));
+    MH_HIP(photo->ctx, mh_enter(photo->ctx));
     return detect_features_impl(photo, num_to_detect, R_W_Be, t_W_Be, bias_directions, n_directions);
   });
 }
@@ -937,7 +937,7 @@ int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double
   if (!photo || !R_W_Be || !t_W_Be || (n_directions && !bias_directions))
     return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_update_map: NULL argument");
   return guarded(photo->ctx, "mh_photo_update_map", [&]() -> int {
-    MH_HIP(photo->ctx, hipSetDevice(photo->ctx->device));
+    MH_HIP(photo->ctx, mh_enter(photo->ctx));
     if (factor) {  // photometric.cpp:402-494
       if (factor->photo != photo) return fail(photo->ctx, MH_ERR_INVALID_ARG, "mh_photo_update_map: the factor belongs to another mh_photo");
       if (factor->statuses.size() != photo->features.size())
@@ -966,7 +966,7 @@ static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::v
                               bool binary, mh_photo_factor ** out)
 {
   mh_ctx * ctx = photo->ctx;
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   mh_photo_factor * f = new mh_photo_factor;
   f->photo = photo;
   photo->refs.fetch_add(1);
@@ -1048,7 +1048,7 @@ void mh_photo_factor_destroy(mh_photo_factor * f)
 {
   if (!f) return;
   mh_ctx * ctx = f->photo->ctx;
-  (void)hipSetDevice(ctx->device);
+  (void)mh_enter(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf * b : {&f->d_Le, &f->d_psi, &f->d_npts, &f->d_rows, &f->d_ticket}) b->release(true);
   if (f->h_out) AllocCache::free_pinned(f->h_out, f->out_bytes);
@@ -1067,7 +1067,7 @@ static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], con
   const bool timed = ctx->profiling > 0;
   {
     if (f->binary && (!R_a || !t_a)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_factor_linearize: the binary factor needs T_a");
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     const mh_photo_config & c = f->photo->cfg;
     const size_t nf = f->features.size();
     Pose Tb, Ta, TBL;
@@ -1283,7 +1283,7 @@ int mh_photo_factor_get_state(const mh_photo_factor * f, int32_t * statuses, dou
   if (statuses) std::memcpy(statuses, f->statuses.data(), nf * sizeof(int32_t));
   if (centers) std::memcpy(centers, f->centers.data(), 2 * nf * sizeof(double));
   if (rows) {
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     MH_HIP(ctx, hipMemcpy(rows, f->d_rows.p, nf * mh::kPhotoMaxPatch * 8 * sizeof(double), hipMemcpyDeviceToHost));
   }
   return MH_OK;

@@ -312,7 +312,7 @@ int mh_shard_comm_init_rccl(mh_ctx * ctx, const void * id128, int world, int ran
       return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_comm_init_rccl: world in 1..64, 0 <= rank < world");
     RcclApi & api = rccl();
     if (!api.lib || !api.err.empty()) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_shard_comm_init_rccl: " + api.err);
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     mh_shard_comm * c = new mh_shard_comm;
     c->world = world;
     c->rank = rank;
@@ -378,7 +378,7 @@ void mh_shard_icp_destroy(mh_shard_icp * S)
 {
   if (!S) return;
   if (S->ctx) {
-    (void)hipSetDevice(S->ctx->device);
+    (void)mh_enter(S->ctx);
     (void)hipStreamSynchronize(S->ctx->stream);
   }
   for (DevBuf * b : {&S->d_dest, &S->d_hist, &S->d_send, &S->d_recv, &S->d_ar, &S->d_loc, &S->d_flags, &S->d_pos, &S->d_temp}) b->release(true);
@@ -397,7 +397,7 @@ static int shard_icp_create_impl(mh_ctx * ctx, mh_shard_comm * comm, mh_map * ma
   if (log2 < 0 || log2 > 10) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_create: block_log2 in 0..10");
   if (n_local > 0x1fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_shard_icp_create: cloud too large");
   if (comm->is_rccl && comm->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_create: communicator lives on another device");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   mh_shard_icp * S = new mh_shard_icp;
   S->ctx = ctx;
   S->comm = comm;
@@ -489,7 +489,7 @@ static int shard_icp_linearize_impl(mh_shard_icp * S, const double R_src[9], con
   }
   if (icp->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_linearize: binary factor needs the target pose");
   if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_linearize: calls in flight");
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const uint32_t world = static_cast<uint32_t>(comm->world), rank = static_cast<uint32_t>(comm->rank);
   const long long coll0 = comm->n_all_to_all + comm->n_all_reduce;
   mh::ShardPose P;
@@ -601,7 +601,7 @@ int mh_shard_icp_reset(mh_shard_icp * S)
     if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_reset: NULL argument");
     if (!S->collective) return mh_icp_reset(S->icp);
     mh_ctx * ctx = S->ctx;
-    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, mh_enter(ctx));
     MH_HIP(ctx, mh::launch_shard_reset(arrays_of(S->icp, false), S->d_state, S->cur, S->n_slots, ctx->stream));
     return MH_OK;
   });
@@ -626,7 +626,7 @@ static int shard_icp_get_state_impl(mh_shard_icp * S, uint64_t * origin, int32_t
       for (size_t i = 0; i < S->n_live; ++i) origin[i] = (static_cast<uint64_t>(S->comm->rank) << 32) | i;
     return mh_icp_get_state(icp, status, means, normals);
   }
-  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, mh_enter(ctx));
   const size_t n = S->n_slots;
   std::vector<uint64_t> o(n);
   std::vector<int32_t> st(n);

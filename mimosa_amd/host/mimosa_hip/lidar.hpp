@@ -338,6 +338,18 @@ public:
     size_t m = 0;
     ctx_->check(mh_scan_get_unique_ns(scan_, unique_ns_.data(), unique_ns_.size(), &m), "mh_scan_get_unique_ns");
   }
+  // Pipelined input: prefetch() stages the NEXT cloud (pinned copy + host-to-device copy on this front end's own copy stream)
+  // while another ScanFrontEnd is being processed — it may run on another host thread; prepareInputPrefetched() is
+  // prepareInput on the staged cloud (the device waits for the copy, the host does not).
+  void prefetch(const PointOuster * raw, size_t n) { ctx_->check(mh_scan_prefetch(scan_, raw, n), "mh_scan_prefetch"); }
+  void prepareInputPrefetched(const ManagerInputConfig & cfg, const double header_ts)
+  {
+    ctx_->check(mh_scan_prepare_input_prefetched(scan_, &cfg, &info_), "mh_scan_prepare_input_prefetched");
+    corrected_ts_ = header_ts + info_.last_point_ns * 1.0e-9;
+    unique_ns_.resize(info_.n_unique_ns);
+    size_t m = 0;
+    ctx_->check(mh_scan_get_unique_ns(scan_, unique_ns_.data(), unique_ns_.size(), &m), "mh_scan_get_unique_ns");
+  }
   // Manager::prepareInput<PointT> for any of the reference's point types (the sensor's own records go to the device).
   // transpose_pointcloud is honoured for PointRslidar / PointVelodyneAnybotics only, as in the reference (:177-203).
   template <typename PointT>

@@ -13,7 +13,11 @@
 #pragma once
 
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "manager.hpp"
 
@@ -189,6 +193,11 @@ struct Config
   double between_sigma_rot = 2e-3, between_sigma_trans = 1e-2;
   double keyframe_trans_thresh = 1.0, keyframe_rot_thresh_deg = 20.0;
   bool photometric = true;
+  // FixedLagReplay: overlap what does not depend on each other across scans — the next cloud's staging (pinned copy +
+  // upload on a copy stream) and the photometric map update of scan k (feature detection: a host-side selection over
+  // device-compacted candidates, on the photometric context's own stream) run on two worker threads beside the geometric
+  // path of scan k + 1.  Same calls on the same handles in the same order per handle: the trajectory does not change by a bit.
+  bool pipeline = true;
   A3 gravity{0.0, 0.0, -9.81};
   lidar::RegistrationConfig reg = lidar::defaultRegistrationConfig();
   lidar::ManagerInputConfig input = lidar::defaultManagerInputConfig();
@@ -211,6 +220,79 @@ struct Result
   std::vector<std::vector<double>> costs;
   int n_keyframes = 0;
   double seconds = 0, stage[5] = {0, 0, 0, 0, 0};  // front_end, imu, factor_create, optimise, update_map
+  // finer split of the main thread's time: stage_wait, prepare, deskew, geo_preprocess, icp_create, photo_wait, photo_preprocess,
+  // photo_factor, optimise, keyframe_map, photo_final_linearize, photo_update_or_submit
+  double detail[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double worker[4] = {0, 0, 0, 0};  // stager: start latency, duration; photometric worker: start latency, duration (summed over the scans)
+};
+
+// One host thread that runs the jobs it is given in order (the pipelined replay's helpers).
+class Worker
+{
+public:
+  Worker() : th_([this] { loop(); }) {}
+  ~Worker()
+  {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void submit(std::function<void()> job)
+  {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      jobs_.push_back(std::move(job));
+      ++pending_;
+    }
+    cv_.notify_all();
+  }
+  // blocks until every submitted job has run; rethrows the first exception a job ended with
+  void wait()
+  {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    if (error_) {
+      std::exception_ptr e = error_;
+      error_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+
+private:
+  void loop()
+  {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+        if (jobs_.empty()) return;
+        job = std::move(jobs_.front());
+        jobs_.pop_front();
+      }
+      try {
+        job();
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        --pending_;
+      }
+      done_cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<std::function<void()>> jobs_;
+  int pending_ = 0;
+  bool stop_ = false;
+  std::exception_ptr error_;
+  std::thread th_;
 };
 
 // The stand-in for GTSAM / ISAM2 (out of scope): a dense Gauss-Newton over the `window` most recent poses — unary ICP Hessian
@@ -356,7 +438,7 @@ private:
 class FixedLagReplay
 {
 public:
-  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx)
+  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx), scan_b_(ctx)
   {
     map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, cfg_.reg.target_ivox_map_leaf_size);
     map_->set_lru_horizon(lru_horizon);
@@ -369,6 +451,7 @@ public:
       photo_ctx_ = std::make_shared<lidar::Context>(ctx_->device());
       photo_.reset(new Photometric(photo_ctx_, cfg_.photo));
       scan_.keepRaw(true);
+      scan_b_.keepRaw(true);
     }
   }
   void seedMap(const float * xyz, size_t n) { map_->insert(xyz, n); }
@@ -386,11 +469,40 @@ public:
     State prev = state0;
     bool have_prev = false;
     const float I3f[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3f[3] = {0, 0, 0};
+    // Pipelined (cfg_.pipeline): `stager` copies cloud k + 1 into the idle front end's pinned buffer and starts its upload while
+    // scan k is processed; `photo_worker` runs Photometric::updateMap of scan k (feature detection on the photometric context's
+    // stream) beside the geometric path of scan k + 1, which joins it right before it needs the photometric frame itself.
+    ScanFrontEnd * bufs[2] = {&scan_, &scan_b_};
+    std::unique_ptr<Worker> stager, photo_worker;
+    if (cfg_.pipeline) {
+      stager.reset(new Worker);
+      if (photo_) photo_worker.reset(new Worker);
+      if (!scans.empty()) stager->submit([&scans, bufs] { bufs[0]->prefetch(scans[0].raw.data(), scans[0].raw.size()); });
+    }
     const auto t_begin = clk::now();
     for (size_t k = 0; k < scans.size(); ++k) {
       const ScanInput & sc = scans[k];
+      ScanFrontEnd & scan_ = cfg_.pipeline ? *bufs[k & 1] : this->scan_;
       const auto a0 = clk::now();
-      scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
+      if (cfg_.pipeline) {
+        stager->wait();  // cloud k sits in this front end's staging buffer, its upload is on the copy stream
+        res.detail[0] += secs(a0, clk::now());
+        scan_.prepareInputPrefetched(cfg_.input, sc.header_ts);
+        if (k + 1 < scans.size()) {
+          const ScanInput * nx = &scans[k + 1];
+          ScanFrontEnd * nb = bufs[(k + 1) & 1];
+          const auto ts = clk::now();
+          double * wk = res.worker;
+          stager->submit([nx, nb, ts, wk] {
+            const auto t0 = clk::now();
+            nb->prefetch(nx->raw.data(), nx->raw.size());
+            wk[0] += std::chrono::duration<double>(t0 - ts).count();
+            wk[1] += std::chrono::duration<double>(clk::now() - t0).count();
+          });
+        }
+      } else {
+        scan_.prepareInput(sc.raw.data(), sc.raw.size(), cfg_.input, sc.header_ts);
+      }
       const auto a1 = clk::now();
       State pred;
       const std::vector<RT> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
@@ -406,24 +518,41 @@ public:
       }
       const auto a2 = clk::now();
       scan_.deskewPoints(T_Le_Lt);
+      const auto b0 = clk::now();
+      res.detail[2] += secs(a2, b0);
       const Key Xk = X(k);
-      if (photo_) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+      // (the photometric frame is built AFTER the geometric pre-processing and the ICP factor when pipelined: those do not
+      // need it, and the previous scan's photometric map update may still be running on the frame before)
+      if (photo_ && !cfg_.pipeline) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
       ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
                                                cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
                   "mh_scan_preprocess_geometric");
       const auto a3 = clk::now();
+      res.detail[3] += secs(b0, a3);
       Live lv;
       lv.k = k;
       lv.T = pred.T;
       lv.f = std::make_shared<ICPFactor>(Xk, map_, scan_, cfg_.reg);
       lv.f->computeComponents(false);  // the loop below only takes H, b, f
+      const auto b1 = clk::now();
+      res.detail[4] += secs(a3, b1);
       lv.has_Z = have_prev;
       if (have_prev) lv.Z = between(prev.T, pred.T);
       Values values;
       NonlinearFactorGraph photo_graph;
       if (photo_) {
+        const auto c0 = clk::now();
+        if (cfg_.pipeline) {
+          photo_worker->wait();  // Photometric::updateMap of scan k - 1
+          const auto c1 = clk::now();
+          res.detail[5] += secs(c0, c1);
+          photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+          res.detail[6] += secs(c1, clk::now());
+        }
+        const auto c2 = clk::now();
         values.insert(Xk, toPose3(pred.T));
         photo_->getFactors(values, photo_graph);  // no factor while nothing is tracked (photometric.cpp:381)
+        res.detail[7] += secs(c2, clk::now());
       }
       PhotometricFactor::Ptr pf = photo_ ? photo_->factor() : nullptr;
       smoother.push(lv);
@@ -456,15 +585,35 @@ public:
         kf_poses.push_back(T);
         ++res.n_keyframes;
       }
+      const auto d0 = clk::now();
+      res.detail[9] += secs(a5, d0);
       if (photo_) {
         values.update(Xk, toPose3(T));
         if (pf) {
           (void)pf->linearize(values);  // statuses / centres at the final pose feed the bookkeeping
           res.photo_valid.push_back(pf->lastResult().status_hist[8]);
         }
-        photo_->updateMap(values, cfg_.bias_directions);
+        const auto d1 = clk::now();
+        res.detail[10] += secs(d0, d1);
+        if (cfg_.pipeline) {
+          Photometric * ph = photo_.get();
+          const std::vector<V3D> * bias = &cfg_.bias_directions;
+          const auto ts = clk::now();
+          double * wk = res.worker;
+          photo_worker->submit([ph, values, bias, ts, wk] {
+            const auto t0 = clk::now();
+            ph->updateMap(values, *bias);
+            wk[2] += std::chrono::duration<double>(t0 - ts).count();
+            wk[3] += std::chrono::duration<double>(clk::now() - t0).count();
+          });
+        } else {
+          photo_->updateMap(values, cfg_.bias_directions);
+        }
       }
       const auto a6 = clk::now();
+      res.detail[1] += secs(a0, a1);
+      res.detail[8] += secs(a4, a5);
+      res.detail[11] += secs(d0, a6);
       res.stage[0] += secs(a0, a1) + secs(a2, a3);
       res.stage[1] += secs(a1, a2);
       res.stage[2] += secs(a3, a4);
@@ -476,6 +625,7 @@ public:
       prev.vel = matvec(T.R, matvec(transpose(pred.T.R), pred.vel));
       have_prev = true;
     }
+    if (photo_worker) photo_worker->wait();
     win.clear();
     res.seconds = secs(t_begin, clk::now());
     return res;
@@ -484,7 +634,7 @@ public:
 private:
   std::shared_ptr<lidar::Context> ctx_;
   Config cfg_;
-  ScanFrontEnd scan_;
+  ScanFrontEnd scan_, scan_b_;  // double-buffered: scan k + 1 is staged into the one scan k is not using
   IncrementalVoxelMapPCL::Ptr map_;
   std::shared_ptr<lidar::Context> photo_ctx_;  // declared before photo_: destroyed after it
   std::unique_ptr<Photometric> photo_;

@@ -13,11 +13,12 @@ using binio::read_vec;
 int main(int argc, char ** argv)
 {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: replay_native <input.bin> [repeats] [manager]\n");
+    std::fprintf(stderr, "usage: replay_native <input.bin> [repeats] [manager | sequential]\n");
     return 2;
   }
   const int repeats = argc > 2 ? std::atoi(argv[2]) : 1;
   const bool through_manager = argc > 3 && std::string(argv[3]) == "manager";  // the same sequence through lidar::Manager::callback
+  const bool sequential = argc > 3 && std::string(argv[3]) == "sequential";   // FixedLagReplay without the cross-scan overlap
   try {
     std::ifstream f(argv[1], std::ios::binary);
     if (!f) throw std::runtime_error("cannot open the input file");
@@ -40,6 +41,7 @@ int main(int argc, char ** argv)
     std::memcpy(&cfg.reg, regb.data(), sizeof(cfg.reg));
     std::memcpy(&cfg.input, inpb.data(), sizeof(cfg.input));
     if (cfg.photometric) cfg.photo = binio::read_photo_config(f);
+    cfg.pipeline = !sequential;
     const auto bias = read_vec<double>(f);
     for (size_t i = 0; i + 2 < bias.size(); i += 3) cfg.bias_directions.push_back(V3D(bias[i], bias[i + 1], bias[i + 2]));
     const auto seed = read_vec<float>(f);
@@ -77,6 +79,14 @@ int main(int argc, char ** argv)
                 static_cast<double>(scans.size()) / r.seconds, r.n_keyframes);
     std::printf("\"stage_s\": {\"front_end\": %.9f, \"imu\": %.9f, \"factor_create\": %.9f, \"optimise\": %.9f, \"update_map\": %.9f},\n",
                 r.stage[0], r.stage[1], r.stage[2], r.stage[3], r.stage[4]);
+    {
+      const char * names[12] = {"stage_wait", "prepare_incl_stage_wait", "deskew", "geo_preprocess", "icp_create", "photo_wait", "photo_preprocess", "photo_factor",
+                                "optimise", "keyframe_map", "photo_final_linearize", "photo_tail_incl_final_linearize"};
+      std::printf("\"detail_s\": {");
+      for (int i = 0; i < 12; ++i) std::printf("\"%s\": %.9f, ", names[i], r.detail[i]);
+      std::printf("\"stager_start_latency\": %.9f, \"stager_prefetch\": %.9f, \"photo_worker_start_latency\": %.9f, \"photo_worker_update_map\": %.9f},\n", r.worker[0],
+                  r.worker[1], r.worker[2], r.worker[3]);
+    }
     std::printf("\"photo_valid\": [");
     for (size_t i = 0; i < r.photo_valid.size(); ++i) std::printf("%d%s", r.photo_valid[i], i + 1 < r.photo_valid.size() ? ", " : "");
     std::printf("],\n\"first_costs\": [");

@@ -296,7 +296,7 @@ def write_native_input(path, cfg: ReplayConfig, scans, rng_seed=7, mode=synth.EN
             w([sc["header_ts"]], np.float64)
 
 
-def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible_device=None, through_manager=False):
+def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible_device=None, through_manager=False, sequential=False):
     """The same replay through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls.
     visible_device: run the driver with HIP_VISIBLE_DEVICES set to it (one replay per GPU of a node).
     through_manager: every scan goes through lidar::Manager::callback (host/mimosa_hip/manager.hpp: the reference's method
@@ -311,7 +311,7 @@ def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible
     env = dict(os.environ)
     if visible_device is not None:
         env["HIP_VISIBLE_DEVICES"] = str(visible_device)
-    out = subprocess.run([exe, path, str(repeats)] + (["manager"] if through_manager else []), capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run([exe, path, str(repeats)] + (["manager"] if through_manager else (["sequential"] if sequential else [])), capture_output=True, text=True, timeout=900, env=env)
     os.remove(path)
     if out.returncode != 0:
         raise RuntimeError("replay_native failed: " + out.stderr[-2000:])

@@ -85,6 +85,39 @@ def test_native_replay_equals_python_replay(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_replay_full_size_hip_equals_oracle(ctx, tmp_path):
+    """BASELINE configs[4] at the bench's size inside the suite: 20 scans of 128 x 1024, window 5, 6 update iterations,
+    photometric on — the HIP loop (Python harness over the C ABI), the native pipelined loop and the oracle loop produce the
+    same keyframes, the same tracked features and the same trajectory."""
+    cfg = replay.ReplayConfig(n_scans=20, rows=128)
+    scans = replay.make_scans(cfg)
+    ro = replay.run(cfg, OracleBackend(cfg), scans)
+    rh = replay.run(cfg, replay.HipBackend(ctx, cfg), scans)
+    rn = replay.run_native(cfg, scans, str(tmp_path))
+    assert len(ro["poses_est"]) == 20 and ro["n_keyframes"] >= 2
+    assert rh["n_keyframes"] == ro["n_keyframes"] == rn["n_keyframes"] and rh["photo_valid"] == ro["photo_valid"] == rn["photo_valid"]
+    for (Ra, ta), (Rb, tb), (Rc, tc) in zip(rh["poses_est"], ro["poses_est"], rn["poses_est"]):
+        assert np.max(np.abs(ta - tb)) < 1e-7 and np.max(np.abs(Ra - Rb)) < 1e-8
+        assert np.max(np.abs(tc - tb)) < 1e-6 and np.max(np.abs(Rc - Rb)) < 1e-7
+    assert max(rh["trans_err"]) < 0.004 and max(rh["rot_err_deg"]) < 0.02
+
+
+@pytest.mark.gpu
+def test_pipelined_native_replay_is_the_sequential_one_bit_for_bit(tmp_path):
+    """replay_native overlaps across scans by default (next cloud staged on a copy stream by one worker thread, the photometric
+    map update of scan k on another beside the geometric path of scan k + 1); `sequential` runs the calls one after the other.
+    Same calls on the same handles in the same order per handle: identical trajectories, keyframes, tracked features — to the bit."""
+    cfg = small_cfg(8)
+    scans = replay.make_scans(cfg)
+    rp = replay.run_native(cfg, scans, str(tmp_path), repeats=2)
+    rs = replay.run_native(cfg, scans, str(tmp_path), repeats=2, sequential=True)
+    assert rp["n_keyframes"] == rs["n_keyframes"] and rp["photo_valid"] == rs["photo_valid"]
+    assert rp["first_costs"] == rs["first_costs"]
+    for (Ra, ta), (Rb, tb) in zip(rp["poses_est"], rs["poses_est"]):
+        assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+
+
+@pytest.mark.gpu
 def test_native_replay_through_the_manager_mirror(ctx, tmp_path):
     """The sequence through lidar::Manager::callback (host/mimosa_hip/manager.hpp: callback -> prepareInput -> declare ->
     deskewPoints -> preprocess -> getFactors -> define -> postDefineUpdate, the reference's call order, with stand-ins behind the
