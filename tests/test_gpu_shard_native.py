@@ -80,3 +80,42 @@ def test_native_world1_is_the_plain_factor(ctx, small_world):
 def test_native_world1_over_rccl_full_protocol():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_native_rccl_worker.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def _EXTRA(base):
+    return [base + i for i in range(int(os.environ.get("MH_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(100))
+def test_native_sharded_random_configurations(seed):
+    """Random room, map density, registration options (Huber, 4-DoF, degeneracy projection, gates), world size, block size,
+    uneven (also empty) scan shares, unary / binary, and a pose walk from millimetres to decimetres with the component pass
+    toggled: every rank's global result and the state of the points it holds equal the unsharded oracle."""
+    import shard_native_common as C
+    from mimosa_amd import synth
+
+    rng = np.random.default_rng(99000 + seed)
+    room = np.array([rng.uniform(8, 30), rng.uniform(6, 20), rng.uniform(2.5, 4)])
+    grid = float(rng.choice([0.11, 0.16, 0.3]))
+    map_xyz = synth.make_room(6000 + seed, 0, 0, grid=grid, room=room)
+    loc = np.array([rng.uniform(1.5, room[0] - 1.5), rng.uniform(1.5, room[1] - 1.5), rng.uniform(0.8, room[2] - 0.8)])
+    scan, aux = synth.make_scan(n_rows=int(rng.choice([16, 32])), seed=7000 + seed, n_cols=int(rng.choice([64, 128])), room=room, sensor_local=loc)
+    R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+    binary = bool(rng.integers(0, 2))
+    cfg = dict(synth.enwide_config(), use_huber=int(rng.integers(0, 2)), reg_4_dof=int(rng.integers(0, 2)) if not binary else 0,
+               project_on_degneneracy=int(rng.integers(0, 2)) if not binary else 0, degen_thresh_trans=float(rng.choice([15.0, 40.0, 1e9])),
+               max_corres_distance=float(rng.choice([0.5, 1.0])), plane_validity_distance=float(rng.choice([0.04, 0.07, 0.2])))
+    poses = [(R, t)]
+    for _ in range(4):
+        scale = float(rng.choice([0.002, 0.03, 0.15, 0.6]))
+        Rk, tk = poses[-1]
+        poses.append((Rk @ synth.so3_exp(rng.normal(0, 1.0, 3) * scale / 5.0), tk + rng.normal(0, 1.0, 3) * scale))
+    tgt = None
+    if binary:
+        Rt, tt = synth.so3_exp(rng.normal(0, 0.02, 3)), rng.normal(0, 0.2, 3)
+        tgt = (Rt, tt)
+        poses = [(Rt @ Rk, Rt @ tk + tt) for Rk, tk in poses]
+    case = dict(map_chunks=np.array_split(map_xyz, int(rng.integers(1, 5))), scan=scan, cfg=cfg, poses=poses, tgt=tgt, binary=binary)
+    world = int(rng.choice([2, 3, 4, 5]))
+    C.run_local_world(world, case=case, block_log2=int(rng.choice([2, 3, 4])), uneven=True,
+                      components_off_from=int(rng.integers(1, 5)) if rng.integers(0, 2) else None, check_eigvec=False)
