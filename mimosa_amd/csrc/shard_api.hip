@@ -31,6 +31,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +59,7 @@ struct RcclApi
   decltype(&ncclAllToAll) AllToAll = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
   std::string err;
 };
 RcclApi & rccl()
@@ -88,6 +91,7 @@ RcclApi & rccl()
     MH_SYM(AllToAll, "ncclAllToAll")
     MH_SYM(GetErrorString, "ncclGetErrorString")
     MH_SYM(GetVersion, "ncclGetVersion")
+    api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(api.lib, "ncclCommGetAsyncError"));
 #undef MH_SYM
   });
   return api;
@@ -104,17 +108,25 @@ struct LocalGroup
   int refs = 0;
   std::vector<const char *> send_ptr;
   std::vector<std::vector<double>> ar_host;
-  void barrier()
+  bool broken = false;  // a rank gave up waiting: every later barrier fails at once instead of hanging the others
+  // false: a peer did not arrive within the time limit (it failed, or a collective was not entered by all ranks)
+  bool barrier()
   {
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const unsigned long long g = gen;
     if (++arrived == world) {
       arrived = 0;
       ++gen;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return gen != g; });
+      return true;
     }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; }) || broken) {
+      broken = true;
+      cv.notify_all();
+      return false;
+    }
+    return true;
   }
 };
 }  // namespace
@@ -129,6 +141,12 @@ struct mh_shard_comm
   std::string err;
   long long n_all_to_all = 0, n_all_reduce = 0;
 
+  int peer_missing()
+  {
+    err = "in-process group: a rank did not reach the collective within 120 s";
+    g_mh_err = err;
+    return MH_ERR_HIP;
+  }
   int nccl_fail(ncclResult_t r, const char * what)
   {
     err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
@@ -145,13 +163,13 @@ struct mh_shard_comm
     }
     if (hipStreamSynchronize(stream) != hipSuccess) return MH_ERR_HIP;
     grp->send_ptr[rank] = static_cast<const char *>(send);
-    grp->barrier();
+    if (!grp->barrier()) return peer_missing();
     hipError_t e = hipSuccess;
     for (int p = 0; p < world && e == hipSuccess; ++p)
       e = hipMemcpyAsync(static_cast<char *>(recv) + static_cast<size_t>(p) * bytes, grp->send_ptr[p] + static_cast<size_t>(rank) * bytes, bytes,
                          hipMemcpyDeviceToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    grp->barrier();  // nobody refills a send buffer a peer is still reading
+    if (!grp->barrier()) return peer_missing();  // nobody refills a send buffer a peer is still reading
     return e == hipSuccess ? MH_OK : MH_ERR_HIP;
   }
   int all_reduce(double * buf, size_t n, hipStream_t stream)
@@ -165,11 +183,11 @@ struct mh_shard_comm
     mine.resize(n);
     if (hipMemcpyAsync(mine.data(), buf, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) return MH_ERR_HIP;
     if (hipStreamSynchronize(stream) != hipSuccess) return MH_ERR_HIP;
-    grp->barrier();
+    if (!grp->barrier()) return peer_missing();
     std::vector<double> sum(n, 0.0);
     for (int p = 0; p < world; ++p)  // rank order on every rank: identical bits everywhere
       for (size_t i = 0; i < n; ++i) sum[i] += grp->ar_host[p][i];
-    grp->barrier();
+    if (!grp->barrier()) return peer_missing();
     if (hipMemcpyAsync(buf, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) return MH_ERR_HIP;
     return hipStreamSynchronize(stream) == hipSuccess ? MH_OK : MH_ERR_HIP;
   }
@@ -193,6 +211,7 @@ struct mh_shard_icp
   uint32_t seg_cap = 0, seg_cap_max = 0;
   uint64_t n_total = 0;
   unsigned int seq = 0;
+  bool broken = false;  // a collective call failed half way (records sent, slots tombstoned): the factor's state is not to be trusted
   mh_shard_stats stats{};
 };
 
@@ -218,19 +237,31 @@ uint32_t pow2_at_least(uint32_t v)
 int wait_publish(mh_shard_icp * S, unsigned int seq)
 {
   mh_ctx * ctx = S->ctx;
+  mh_shard_comm * comm = S->comm;
   const volatile unsigned int * flag = &S->h_pub->seq;
   timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
     __builtin_ia32_pause();
-    if ((spins & 1023u) == 1023u) {
-      timespec t1;
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 50000000L) {  // 50 ms: let the runtime wait
-        MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        break;
+    if ((spins & 1023u) != 1023u) continue;
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) < 50000000L) continue;
+    // 50 ms: something is slow (a first call's channel set-up) or wrong (a peer is gone).  Stop burning the core; poll the
+    // stream and, over RCCL, the communicator's asynchronous error state, so that a dead peer is an error and not a hang
+    for (;;) {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) MH_HIP(ctx, q);
+      if (comm->is_rccl && rccl().CommGetAsyncError) {
+        ncclResult_t async = ncclSuccess;
+        const ncclResult_t r = rccl().CommGetAsyncError(comm->nccl, &async);
+        if (r != ncclSuccess) return comm->nccl_fail(r, "ncclCommGetAsyncError");
+        if (async != ncclSuccess && async != ncclInProgress) return comm->nccl_fail(async, "a collective failed asynchronously");
       }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+    break;
   }
   return MH_OK;
 }
@@ -489,6 +520,16 @@ static int shard_icp_linearize_impl(mh_shard_icp * S, const double R_src[9], con
   }
   if (icp->binary && (!R_tgt || !t_tgt)) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_linearize: binary factor needs the target pose");
   if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_linearize: calls in flight");
+  if (S->broken) return fail(ctx, MH_ERR_HIP, "mh_shard_icp_linearize: an earlier call on this factor failed half way; create a new factor");
+  struct Guard  // anything that leaves this function other than by success has left points in flight or tombstoned
+  {
+    mh_shard_icp * s;
+    bool ok = false;
+    ~Guard()
+    {
+      if (!ok) s->broken = true;
+    }
+  } guard{S};
   MH_HIP(ctx, mh_enter(ctx));
   const uint32_t world = static_cast<uint32_t>(comm->world), rank = static_cast<uint32_t>(comm->rank);
   const long long coll0 = comm->n_all_to_all + comm->n_all_reduce;
@@ -587,6 +628,7 @@ static int shard_icp_linearize_impl(mh_shard_icp * S, const double R_src[9], con
     break;
   }
   S->stats.collectives_last = static_cast<uint32_t>(comm->n_all_to_all + comm->n_all_reduce - coll0);
+  guard.ok = true;
   return MH_OK;
 }
 int mh_shard_icp_linearize(mh_shard_icp * S, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, const double g_unit[3],

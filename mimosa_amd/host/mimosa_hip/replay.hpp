@@ -684,7 +684,7 @@ public:
   }
   gtsam::NavState predict(const mimosa_hip::State &) override { return gtsam::NavState(toPose3(st_.T), V3D(st_.vel[0], st_.vel[1], st_.vel[2])); }
   const State & integrated() const { return st_; }
-  Unit3 gravityUnit() const
+  Unit3 gravityDirection() const
   {
     const double n = gravityNorm();
     return Unit3(g_[0] / n, g_[1] / n, g_[2] / n);
@@ -708,7 +708,7 @@ public:
   void getStateUpto(const double, mimosa_hip::State & state) override
   {
     state.update(X(have_prev_ ? k_ : 0), cur_->imu.ts.front(), gtsam::NavState(toPose3(prev_.T), V3D(prev_.vel[0], prev_.vel[1], prev_.vel[2])), V3D(0, 0, 0),
-                 V3D(0, 0, 0), imu_.gravityUnit());
+                 V3D(0, 0, 0), imu_.gravityDirection());
   }
   graph::DeclarationResult declare(const double, size_t & new_key, const bool use_to_init) override
   {
@@ -726,7 +726,7 @@ public:
   Values getCurrentOptimizedValues() override
   {
     Values v;
-    v.insert(G(0), imu_.gravityUnit());
+    v.insert(G(0), imu_.gravityDirection());
     return v;
   }
   // smoother_->update(): the new ICP factor joins the window, every live one is re-linearized per iteration

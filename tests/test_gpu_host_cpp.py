@@ -18,7 +18,7 @@ def build_exe(name="host_pipeline"):
     lib = build.build()
     exe = os.path.join(os.path.dirname(lib), name)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    hdrs = [os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", h) for h in ("lidar.hpp", "photometric.hpp", "types.hpp", "sharded.hpp", "binio.hpp")]
+    hdrs = [os.path.join(ROOT, "mimosa_amd", "host", "mimosa_hip", h) for h in ("lidar.hpp", "photometric.hpp", "types.hpp", "sharded.hpp", "binio.hpp", "manager.hpp")]
     sig = os.path.join(ROOT, "mimosa_amd", "host", "gtsam_sig")
     hdrs += [os.path.join(dp, f) for dp, _, fs in os.walk(sig) for f in fs]
     if not os.path.exists(exe) or max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(exe):
@@ -33,6 +33,7 @@ def test_host_layer_compiles():
     assert os.path.exists(build_exe("photo_pipeline"))
     assert os.path.exists(build_exe("point_types"))
     assert os.path.exists(build_exe("sharded_pipeline"))
+    assert os.path.exists(build_exe("manager_types"))    # lidar::Manager::callback<PointT> for all nine sensor point types
 
 
 def test_host_mirror_is_written_against_gtsam_headers():
@@ -273,3 +274,12 @@ def test_sharded_host_mirror(tmp_path, mode):
     M.insert(map_xyz)
     ref = ref_cpu.ICP(M, scan, ref_cpu.make_config(**synth.enwide_config())).linearize(R, t)
     assert abs(d["H00"] - ref["H_ss"][0, 0]) <= 1e-9 * abs(ref["H_ss"][0, 0]) and abs(d["f"] - ref["f"]) <= 1e-9 * abs(ref["f"])
+
+
+@pytest.mark.gpu
+def test_manager_callback_for_every_point_type():
+    """lidar::Manager::callback<PointT> runs prepareInput for each of the nine sensor point types (64 zero records each: all
+    points filtered) and honours a FAILURE_* declaration result by skipping the message (sensor_manager_base.hpp:208-260)."""
+    exe = build_exe("manager_types")
+    out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and json.loads(out.stdout)["ok"] == 1, out.stderr[-2000:]
