@@ -36,6 +36,23 @@
 #ifndef MH_PIPE
 #define MH_PIPE 4  // quads in flight per lane in the neighbour scan (knn_query)
 #endif
+// Work sharing inside a workgroup (knn_query, "share") — an EXPERIMENT, compiled out by default: a lane that still has
+// MH_SHARE_MIN_VOX neighbour voxels to enter after MH_SHARE_TRIP trips of the scan posts MH_SHARE_HELPERS of every
+// (MH_SHARE_HELPERS + 1) of them as jobs in LDS; waves of the same workgroup whose own scans are over claim and scan them.
+// Correct (the GPU parity suites pass with -DMH_SHARE=1) and 4 us SLOWER on configs[1] (42.0 vs 38.0 us; DESIGN.md §3,
+// "Round 3, second attempt"): kept so that the measurement can be repeated (tools/variant.sh share -DMH_SHARE=1).
+#ifndef MH_SHARE
+#define MH_SHARE 0
+#endif
+#ifndef MH_SHARE_TRIP
+#define MH_SHARE_TRIP 4
+#endif
+#ifndef MH_SHARE_MIN_VOX
+#define MH_SHARE_MIN_VOX 3
+#endif
+#ifndef MH_SHARE_HELPERS
+#define MH_SHARE_HELPERS 3
+#endif
 #include "map_device.hpp"
 #include "math3.hpp"
 
@@ -291,12 +308,13 @@ struct ScanCursor
 // affected).  boxd[] = squared box distances in grid units; the bound undoes the 10-bit key truncation (<= 2^-13
 // relative on d^2) and adds the coarse-tier error err_g; no k-th key yet = keep everything.
 template <int K, int KK, int NOFF>
-__device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], const float (&boxd)[NOFF], int k, float err_g)
+__device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], const float (&boxd)[NOFF], int k, float err_g,
+                                                    uint32_t kth_given = 0xFFFFFFFFu)
 {
-  uint32_t kth = 0xFFFFFFFFu;
+  uint32_t kth = kth_given;  // a k-th key proven elsewhere (the owner of a shared job at the time it posted it)
 #pragma unroll
   for (int i = 0; i < K; ++i)
-    if (i == k - 1) kth = ck[i];
+    if (i == k - 1) kth = min(kth, ck[i]);
   const float kv = __uint_as_float(kth & ~0x3FFu) * (1.0f + 2.5e-4f);
   const float r_up = sqrtf(kv) * (1.0f + 2e-6f) + err_g;
   const float b_up = kth != 0xFFFFFFFFu ? r_up * r_up : 3.0e38f;
@@ -304,6 +322,73 @@ __device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], co
 #pragma unroll
   for (int b = 1; b < NOFF; ++b) keep &= boxd[b] > b_up ? ~(1u << b) : ~0u;
   return keep;
+}
+
+// Squared distances (grid units) from q (qg = its position inside the centre voxel, grid units) to the boxes of the
+// neighbour voxels in scan order; the gaps to the faces of the centre voxel are shrunk by a margin that also covers a
+// stored point sitting ~1 ulp outside its nominal box.
+template <int NOFF>
+__device__ __forceinline__ void box_dists(const float qg0, const float qg1, const float qg2, float (&boxd)[NOFF])
+{
+  constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
+  constexpr float kQ = static_cast<float>(1 << kQuantBits);
+  const float marg = 1e-2f;
+  const float gxm = fmaxf(qg0 - marg, 0.f), gxp = fmaxf(kQ - qg0 - marg, 0.f);
+  const float gym = fmaxf(qg1 - marg, 0.f), gyp = fmaxf(kQ - qg1 - marg, 0.f);
+  const float gzm = fmaxf(qg2 - marg, 0.f), gzp = fmaxf(kQ - qg2 - marg, 0.f);
+  const float g2x[3] = {gxm * gxm, 0.f, gxp * gxp}, g2y[3] = {gym * gym, 0.f, gyp * gyp}, g2z[3] = {gzm * gzm, 0.f, gzp * gzp};
+#pragma unroll
+  for (int b = 0; b < NOFF; ++b) {
+    const uint32_t ent = kScan.ent[row][b];
+    boxd[b] = g2x[ent & 3u] + g2y[(ent >> 2) & 3u] + g2z[(ent >> 4) & 3u];
+  }
+}
+
+// One trip of the neighbour scan: the kPipe quads in flight are merged into the top-KK, each stage is refilled from the
+// cursor first.  Returns the number of live quads this lane consumed.
+template <int KK, int NOFF>
+__device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage (&stage)[MH_PIPE], uint32_t (&ck)[KK], const KeyConsts & kc,
+                                              const uint32_t * list, int lds_stride, const float4 * lut4, const uint4 * qbuckets,
+                                              const float cx0, const float cy1, const float cz2, uint32_t & n_scanned)
+{
+  uint32_t live_quads = 0u;
+#pragma unroll
+  for (int u = 0; u < MH_PIPE; ++u) {
+    const ScanStage st = stage[u];
+    stage[u] = cur.advance(list, lds_stride, lut4, qbuckets);  // refill this stage
+    const uint32_t cnt_ = (st.meta >> 11) & 31u, s0_ = ((st.meta >> 16) & 7u) * 4u;
+    n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
+    live_quads += cnt_ ? 1u : 0u;
+    merge_quad<KK>(ck, kc, st.quad, st.ofs.x + cx0, cy1 - st.ofs.y, st.ofs.z + cz2, ((st.meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
+  }
+  return live_quads;
+}
+
+// ---- work sharing inside a workgroup ("share") ---------------------------------------------------------------------
+// LDS: word 0 = job slots handed out so far; from word 4 on, kShareJobWords per job:
+//   [0] state: 0 free, 1 posted, 2 claimed, 3 done
+//   posted:  [1..3] qg (f32 bits), [4] the owner's k-th key when it posted, [5] mask of the scan positions to enter,
+//            [6..9] quads per voxel (the owner's qc0 / qc1), [10] the owner's thread index (its LDS list column)
+//   done:    [1..KK] the job's sorted top-KK keys (KK <= 8), [9] candidates scanned, [10] scan positions entered
+// Every job is resolved by exactly one party: a helper's compare-and-swap 1 -> 2, or the owner's own (it takes back what
+// nobody claimed once its own share is done).  A helper never waits; an owner waits only for jobs a helper holds: no cycle.
+constexpr int kShareJobWords = 12;
+constexpr int kShareHdrWords = 4;
+__host__ __device__ constexpr int share_jobs(int tpb) { return tpb / 2; }
+__host__ __device__ constexpr int share_words(int tpb) { return MH_SHARE ? kShareHdrWords + share_jobs(tpb) * kShareJobWords : 4; }
+
+[[maybe_unused]] __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t * p)
+{
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+[[maybe_unused]] __device__ __forceinline__ void lds_store_release(uint32_t * p, uint32_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+[[maybe_unused]] __device__ __forceinline__ bool lds_claim(uint32_t * p)  // 1 -> 2
+{
+  uint32_t expect = 1u;
+  return __hip_atomic_compare_exchange_strong(p, &expect, 2u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
@@ -326,13 +411,14 @@ __device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], co
 // budget) exceeds the exact k-th distance no non-survivor can belong to the answer; otherwise the wave re-runs
 // KnnResult::push for that lane over the scanned voxels (counted in n_exact_fallback).  Either way the selection is
 // bit-identical to the reference.
-template <int K, int NOFF>
+template <int K, int NOFF, bool SHARE = false>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
-                                              unsigned long long * dbg = nullptr)
+                                              unsigned long long * dbg = nullptr, uint32_t * share = nullptr)
 {
   (void)dbg;
+  (void)share;
   fell_back = false;
   constexpr int KK = K + 3 + (K > 5 ? 1 : 0);  // survivors: 8 for k = 5, 12 for the generic k <= 8 path
   constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
@@ -407,7 +493,6 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // packed 3 x 10-bit copy of the buckets: ONE 16-byte load brings four candidates (the kernel is bound
   // by per-lane L1 requests, not bytes).  A decoded coordinate is the middle of its quantisation cell:
   // |error| <= 0.5 g per axis, so |r_coarse - r| <= 0.87 g + f32 round-off; kErrG covers it.
-  constexpr float kQ = static_cast<float>(1 << kQuantBits);
   constexpr float kErrG = 0.9f;
   const double leaf_d = 1.0 / map.inv_leaf;
   const double g_d = leaf_d / static_cast<double>(1 << kQuantBits);
@@ -440,20 +525,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // k-th distance cannot hold a top-k point (strictly farther, so not even ties are affected).  The
   // squared box distances stay in registers: the scan re-applies the test as its bound tightens.
   float boxd[NOFF];
-  {
-    // gaps from q to the faces of its centre voxel, shrunk by a margin that also covers a stored
-    // point sitting ~1 ulp outside its nominal box
-    const float marg = 1e-2f;
-    const float gxm = fmaxf(qg0 - marg, 0.f), gxp = fmaxf(kQ - qg0 - marg, 0.f);
-    const float gym = fmaxf(qg1 - marg, 0.f), gyp = fmaxf(kQ - qg1 - marg, 0.f);
-    const float gzm = fmaxf(qg2 - marg, 0.f), gzp = fmaxf(kQ - qg2 - marg, 0.f);
-    const float g2x[3] = {gxm * gxm, 0.f, gxp * gxp}, g2y[3] = {gym * gym, 0.f, gyp * gyp}, g2z[3] = {gzm * gzm, 0.f, gzp * gzp};
-#pragma unroll
-    for (int b = 0; b < NOFF; ++b) {
-      const uint32_t ent = kScan.ent[row][b];
-      boxd[b] = g2x[ent & 3u] + g2y[(ent >> 2) & 3u] + g2z[(ent >> 4) & 3u];
-    }
-  }
+  box_dists<NOFF>(qg0, qg1, qg2, boxd);
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
   rem &= prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
 #ifdef MH_FAKE_SCAN_MASK  // tuning experiment only (wrong results): what the kernel would take if a lane scanned a subset of its voxels
@@ -471,10 +543,17 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // wave loops while any lane still has a live quad in flight; after the first and second trip the
   // tightened bound prunes the voxels not entered yet (what matters for lanes whose centre voxel held
   // fewer than k points: their first bound is infinite).
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+  unsigned long long share_stats = 0ull;  // per wave: jobs posted | taken back | done by helpers | done for others | help rounds
+  uint32_t st_posted = 0u, st_back = 0u, st_helped = 0u, st_rounds = 0u;
+#endif
+  uint32_t extra_scanned = 0u;  // share: scan positions a helper entered for this lane
+  uint32_t donated = 0u;        // share: scan positions posted as jobs and not (yet) taken back
   {
     constexpr int kPipe = MH_PIPE;
     const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
     const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
+    const uint32_t lane_ = threadIdx.x & 63u;
     ScanCursor<NOFF> cur;
     cur.rem = rem;
     cur.qc0 = qc0;
@@ -483,10 +562,105 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #pragma unroll
     for (int u = 0; u < kPipe; ++u) stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
-    uint32_t trips = 0;
+    uint32_t trips = 0, myq = 0;
 #endif
+    constexpr int HS = MH_SHARE_HELPERS;
+    uint32_t job_base = 0u, job_pending = 0u, job_await = 0u;  // this lane's jobs: first slot, not resolved yet, held by a helper
     for (int trip = 0;; ++trip) {
-      if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) break;  // a dead stage 0 means dead stages 1..3
+      if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) {  // a dead stage 0 means dead stages 1..3
+        if (SHARE && __any(static_cast<int>(job_pending))) {
+          // this wave's own shares are done: every lane takes back the first of its jobs that nobody has claimed
+          bool took = false;
+          const uint32_t keep_now = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
+          alive &= keep_now;
+#pragma unroll
+          for (int p = 0; p < HS; ++p) {
+            if (!took && ((job_pending >> p) & 1u)) {
+              job_pending &= ~(1u << p);
+              uint32_t * rec = share + kShareHdrWords + (job_base + static_cast<uint32_t>(p)) * kShareJobWords;
+              if (lds_claim(rec)) {
+                const uint32_t part = rec[5];
+                cur.rem |= part & keep_now;  // the bound has tightened since the job was posted
+                donated &= ~part;
+                took = true;
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+                ++st_back;
+#endif
+              } else {
+                job_await |= 1u << p;
+              }
+            }
+          }
+          if (__any(took)) {
+#pragma unroll
+            for (int u = 0; u < kPipe; ++u) stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);
+            continue;
+          }
+        }
+        break;
+      }
+#ifdef MH_FAKE_TRIP_CAP  // tuning experiment only (wrong results): what the kernel would take if no wave ran more trips than this
+      if (trip >= MH_FAKE_TRIP_CAP) break;
+#endif
+      if constexpr (SHARE) {
+        if (trip == MH_SHARE_TRIP) {
+          // lanes with many voxels still to enter keep every (HS+1)-th of them and post the others as HS jobs
+          const int jobs_max = share_jobs(lds_stride);
+          const bool want = __popc(cur.rem) >= MH_SHARE_MIN_VOX;
+          const uint64_t wm = __ballot(want);
+          if (wm) {
+            const int leader = __builtin_ctzll(wm);
+            uint32_t base = 0u;
+            if (static_cast<int>(lane_) == leader)
+              base = __hip_atomic_fetch_add(share, static_cast<uint32_t>(__popcll(wm)) * HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = lane_get(base, leader) + static_cast<uint32_t>(__popcll(wm & ((1ull << lane_) - 1ull))) * HS;
+            if (want && base + HS <= static_cast<uint32_t>(jobs_max)) {
+              uint32_t part[HS + 1];
+#pragma unroll
+              for (int p = 0; p <= HS; ++p) part[p] = 0u;
+              uint32_t cnt = 0u;
+#pragma unroll
+              for (int b = 1; b < NOFF; ++b) {
+                const uint32_t bit = cur.rem & (1u << b);
+#pragma unroll
+                for (int p = 0; p <= HS; ++p) part[p] |= (cnt == static_cast<uint32_t>(p)) ? bit : 0u;
+                cnt = bit ? (cnt == HS ? 0u : cnt + 1u) : cnt;
+              }
+              uint32_t kth = 0xFFFFFFFFu;
+#pragma unroll
+              for (int i = 0; i < K; ++i)
+                if (i == k - 1) kth = ck[i];
+#pragma unroll
+              for (int p = 1; p <= HS; ++p) {
+                uint32_t * rec = share + kShareHdrWords + (base + static_cast<uint32_t>(p - 1)) * kShareJobWords;
+                rec[1] = __float_as_uint(qg0);
+                rec[2] = __float_as_uint(qg1);
+                rec[3] = __float_as_uint(qg2);
+                rec[4] = kth;
+                rec[5] = part[p];
+                rec[6] = static_cast<uint32_t>(qc0);
+                rec[7] = static_cast<uint32_t>(qc0 >> 32);
+                rec[8] = static_cast<uint32_t>(qc1);
+                rec[9] = static_cast<uint32_t>(qc1 >> 32);
+                rec[10] = threadIdx.x;
+                donated |= part[p];
+              }
+#pragma unroll
+              for (int p = 1; p <= HS; ++p)
+                lds_store_release(share + kShareHdrWords + (base + static_cast<uint32_t>(p - 1)) * kShareJobWords, part[p] ? 1u : 3u);
+              // (an empty part is "done" at once: its record reads as a result nobody wrote — handled at the merge)
+              cur.rem = part[0];
+              job_base = base;
+              job_pending = 0u;
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+              st_posted = HS;
+#endif
+#pragma unroll
+              for (int p = 1; p <= HS; ++p) job_pending |= part[p] ? (1u << (p - 1)) : 0u;
+            }
+          }
+        }
+      }
       if (MH_PRUNE_TRIPS) {
         const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
         cur.rem &= keep;
@@ -494,21 +668,114 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       }
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
       ++trips;
+      myq +=
 #endif
-#pragma unroll
-      for (int u = 0; u < kPipe; ++u) {
-        const ScanStage st = stage[u];
-        stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);  // refill this stage
-        const uint32_t cnt_ = (st.meta >> 11) & 31u, s0_ = ((st.meta >> 16) & 7u) * 4u;
-        n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
-        merge_quad<KK>(ck, kc, st.quad, st.ofs.x + cx0, cy1 - st.ofs.y, st.ofs.z + cz2, ((st.meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
-      }
+        scan_trip<KK, NOFF>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
     }
     rem = cur.rem;
+#ifdef MH_FAKE_MID_BARRIER  // tuning experiment only (hangs unless every wave of the block gets here): what a block-wide
+    __builtin_amdgcn_s_barrier();  // exchange point between the scan and the plane fit would cost by aligning the waves
+#endif
+    if constexpr (SHARE) {
+      // ---- help: claim posted jobs of this workgroup and scan them (own scan state stays in registers) ----
+      const int jobs_max = share_jobs(lds_stride);
+      for (;;) {
+        const uint32_t n_posted = min(lane_get(lds_load_acquire(share), static_cast<int>(__builtin_ctzll(__ballot(1)))), static_cast<uint32_t>(jobs_max));
+        if (n_posted == 0u) break;
+        int jc = -1;
+        for (uint32_t j = lane_; j < n_posted && jc < 0; j += 64u) {
+          uint32_t * rec = share + kShareHdrWords + j * kShareJobWords;
+          if (lds_load_acquire(rec) == 1u && lds_claim(rec)) jc = static_cast<int>(j);
+        }
+        if (!__any(jc >= 0)) break;
+        const bool hj = jc >= 0;
 #if defined(MH_TIMELINE) && defined(MH_BALANCE)
+        st_helped += hj ? 1u : 0u;
+        ++st_rounds;
+#endif
+        uint32_t * rec = share + kShareHdrWords + static_cast<uint32_t>(hj ? jc : 0) * kShareJobWords;
+        const float h0 = __uint_as_float(rec[1]), h1 = __uint_as_float(rec[2]), h2 = __uint_as_float(rec[3]);
+        const uint32_t kth_owner = hj ? rec[4] : 0xFFFFFFFFu;
+        const uint32_t * hlist = hj ? (list - threadIdx.x + rec[10]) : list;
+        ScanCursor<NOFF> hc;
+        hc.rem = hj ? rec[5] : 0u;
+        hc.qc0 = static_cast<uint64_t>(rec[6]) | (static_cast<uint64_t>(rec[7]) << 32);
+        hc.qc1 = static_cast<uint64_t>(rec[8]) | (static_cast<uint64_t>(rec[9]) << 32);
+        float hbox[NOFF];
+        box_dists<NOFF>(h0, h1, h2, hbox);
+        uint32_t hk[KK];
+#pragma unroll
+        for (int i = 0; i < KK; ++i) hk[i] = 0xFFFFFFFFu;
+        hc.rem &= prune_keep_mask<K, KK, NOFF>(hk, hbox, k, kErrG, kth_owner);
+        uint32_t h_alive = hc.rem, h_scanned = 0u;
+        const float hx0 = 0.5f - h0, hy1 = 8192.0f - 0.5f + h1, hz2 = 0.5f - h2;
+#pragma unroll
+        for (int u = 0; u < kPipe; ++u) stage[u] = hc.advance(hlist, lds_stride, lut4, map.qbuckets);
+        for (int trip = 0;; ++trip) {
+          if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) break;
+          if (MH_PRUNE_TRIPS) {
+            const uint32_t keep = prune_keep_mask<K, KK, NOFF>(hk, hbox, k, kErrG, kth_owner);
+            hc.rem &= keep;
+            h_alive &= keep;
+          }
+          scan_trip<KK, NOFF>(hc, stage, hk, kc, hlist, lds_stride, lut4, map.qbuckets, hx0, hy1, hz2, h_scanned);
+        }
+        if (hj) {
+#pragma unroll
+          for (int i = 0; i < KK; ++i)
+            if (i < 8) rec[1 + i] = hk[i];
+          rec[9] = h_scanned;
+          rec[10] = h_alive & ~hc.rem;
+          lds_store_release(rec, 3u);
+        }
+      }
+      // ---- collect the jobs helpers did for this lane ----
+#pragma unroll
+      for (int p = 0; p < HS; ++p) {
+        if ((job_await >> p) & 1u) {
+          uint32_t * rec = share + kShareHdrWords + (job_base + static_cast<uint32_t>(p)) * kShareJobWords;
+          while (lds_load_acquire(rec) != 3u) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            uint32_t t = rec[1 + c];
+#pragma unroll
+            for (int i = 0; i < KK - 1; ++i) {
+              const uint32_t lo = min(ck[i], t);
+              t = max(ck[i], t);
+              ck[i] = lo;
+            }
+            ck[KK - 1] = min(ck[KK - 1], t);
+          }
+          n_scanned += rec[9];
+          extra_scanned |= rec[10];
+          donated &= ~rec[10];
+        }
+      }
+    }
+#if defined(MH_TIMELINE) && defined(MH_BALANCE)
+    {
+      uint32_t a_ = st_posted, b_ = st_back, c_ = static_cast<uint32_t>(__popc(job_await)), d_ = st_helped;
+      for (int d = 32; d > 0; d >>= 1) {
+        a_ += __shfl_xor(a_, d);
+        b_ += __shfl_xor(b_, d);
+        c_ += __shfl_xor(c_, d);
+        d_ += __shfl_xor(d_, d);
+      }
+      share_stats = (static_cast<unsigned long long>(min(a_, 255u)) << 16) | (static_cast<unsigned long long>(min(b_, 255u)) << 24) |
+                    (static_cast<unsigned long long>(min(c_, 255u)) << 32) | (static_cast<unsigned long long>(min(d_, 255u)) << 40) |
+                    (static_cast<unsigned long long>(min(st_rounds, 255u)) << 48);
+    }
     if (dbg && (threadIdx.x & 63) == 0) {
       unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
       w_[14] = 4u * trips;  // quad steps the wave executed
+    }
+    {  // lanes of this wave that scanned more than 8 / 12 / 16 / 24 neighbour quads (8 bits each above bit 16)
+      const unsigned long long h = (static_cast<unsigned long long>(__popcll(__ballot(myq > 8u))) << 16) |
+                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 12u))) << 24) |
+                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 16u))) << 32) |
+                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 24u))) << 40);
+      if (dbg && (threadIdx.x & 63) == 0)
+        dbg[(static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + 14] |= h;
     }
 #endif
   }
@@ -519,7 +786,9 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   const uint64_t act = __ballot(1);
   const uint32_t nact = static_cast<uint32_t>(__popcll(act));
   const uint32_t rank = static_cast<uint32_t>(__popcll(act & ((1ull << lane) - 1ull)));
-  const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem);  // centre + every neighbour voxel the cursor entered
+  // centre + every neighbour voxel the cursor entered (+ what helpers entered for this lane; what was handed to a helper
+  // and pruned by it was never entered)
+  const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem & ~donated) | extra_scanned;
   MH_STAMP(dbg, 2);
 
   // ---- exact tier: re-rank the survivors in fp64 by (distance, traversal rank) -------------------
@@ -589,7 +858,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     }
     if ((threadIdx.x & 63) == 0) {
       unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
-      w_[13] = sn;  // ~quads scanned by the wave's lanes (centre included)
+      w_[13] = sn | share_stats;  // ~quads scanned by the wave's lanes (centre included); share counters above bit 16
       w_[15] = static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
     }
   }
@@ -877,7 +1146,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
   __shared__ unsigned int s_cnt[4];  // n_knn, n_cand, exact-fallback count, candidates actually scanned
   __shared__ uint32_t s_scan[kScanLutWords];
+  __shared__ uint32_t s_share[share_words(TPB)];  // work sharing of the neighbour scan (knn_query)
   __shared__ bool s_last;
+  constexpr bool kShare = MH_SHARE && K == 5;  // the fast path's top-8; the generic k <= 8 path keeps 12 survivors
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [TPB][ROWW]
@@ -885,6 +1156,10 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
 
   const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  if constexpr (kShare) {
+    if (threadIdx.x == 0) s_share[0] = 0u;
+    if (static_cast<int>(threadIdx.x) < share_jobs(TPB)) s_share[kShareHdrWords + threadIdx.x * kShareJobWords] = 0u;
+  }
   fill_scan_lut<NOFF>(s_scan);
   __syncthreads();
 
@@ -894,7 +1169,15 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
 #ifdef MH_TIMELINE
   // diagnostic: repeat the per-point section (MH_REPS env) so the last pass runs with warm caches
   for (int rep = 0; rep < a.reps; ++rep) {
-  if (rep > 0 && threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  if (rep > 0) {
+    __syncthreads();
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+    if constexpr (kShare) {
+      if (threadIdx.x == 0) s_share[0] = 0u;
+      if (static_cast<int>(threadIdx.x) < share_jobs(TPB)) s_share[kShareHdrWords + threadIdx.x * kShareJobWords] = 0u;
+    }
+    __syncthreads();
+  }
 #endif
   MH_STAMP(a.dbg, 0);
 #pragma unroll
@@ -936,7 +1219,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       double dk;
       bool fell_back;
       uint32_t n_scanned;
-      const uint32_t n_cand = knn_query<K, NOFF>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg);
+      const uint32_t n_cand = knn_query<K, NOFF, kShare>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
       did_fall = fell_back;

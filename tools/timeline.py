@@ -59,7 +59,17 @@ stat("   C.1 exact tier (2->12)", T[:, 12] - T[:, 2])
 stat("   C.2 proof+plane+residual+stores (12->3)", T[:, 3] - T[:, 12])
 stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
 if os.environ.get("MH_BALANCE"):  # build with MH_BALANCE=1 python -m mimosa_amd.build --timeline --force
-  q_sum, steps = T[:, 13].astype(float), T[:, 14].astype(float)
+  q_sum, steps = (T[:, 13] & 0xFFFF).astype(float), (T[:, 14] & 0xFFFF).astype(float)
+  sh = np.stack([(T[:, 13] >> s) & 0xFF for s in (16, 24, 32, 40, 48)], 1)      # share: posted, taken back, done by helpers, done for others, rounds
+  print("share: jobs posted", int(sh[:, 0].sum()), " taken back by their owner", int(sh[:, 1].sum()), " done by helpers", int(sh[:, 2].sum()),
+        " (claimed", int(sh[:, 3].sum()), ") waves that posted", int((sh[:, 0] > 0).sum()), " waves that helped", int((sh[:, 3] > 0).sum()),
+        " help rounds max", int(sh[:, 4].max()))
+  heavy = np.stack([(T[:, 14] >> s) & 0xFF for s in (16, 24, 32, 40)], 1)   # lanes with > 8 / 12 / 16 / 24 neighbour quads
+  print("lanes per wave with > 8 / 12 / 16 / 24 neighbour quads: mean", heavy.mean(0).round(2), " p95", np.percentile(heavy, 95, 0), " max", heavy.max(0))
+  for lo, hi in ((0, 12), (12, 16), (16, 20), (20, 24), (24, 28), (28, 40)):
+    sel = (steps > lo) & (steps <= hi)
+    if sel.any():
+      print(f"  waves with {lo:2d} < quad steps <= {hi:2d}: {int(sel.sum()):5d}   their lanes > 8 / 12 / 16 / 24: mean {heavy[sel].mean(0).round(1)}  max {heavy[sel].max(0)}")
   print(f"scan lane balance: mean quads/lane (centre incl.) {q_sum.mean()/64:.2f}, mean neighbour quad steps per wave {steps.mean():.2f}, "
         f"p95 {np.percentile(steps,95):.0f}, max {steps.max():.0f}")
   i_sum, i_max = (T[:, 15] & 0xFFFFFFFF).astype(float), (T[:, 15] >> 32).astype(float)
