@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <new>
@@ -79,6 +80,7 @@ struct mh_photo
   char * h_stage = nullptr;     // pinned staging of detectFeatures' small transfers (candidate list, gather records)
   size_t h_stage_cap = 0;
   PhotoFrame * frame = nullptr;
+  PhotoFrame * next_frame = nullptr;  // built by mh_photo_preprocess_scan_begin, current after mh_photo_preprocess_commit
   std::vector<HostFeature> features;  // map_Le_features_
   uint32_t next_id = 0;               // monotonic_feature_id_
 };
@@ -113,6 +115,7 @@ void photo_release(mh_photo * p)
   (void)mh_enter(p->ctx);
   (void)hipStreamSynchronize(p->ctx->stream);
   frame_release(p->frame);
+  frame_release(p->next_frame);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
                      &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather})
     b->release();
@@ -409,6 +412,16 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   if (num_to_detect <= 0) return MH_OK;  // photometric.cpp:522
   mh_ctx * ctx = ph->ctx;
   PhotoFrame * fr = ph->frame;
+  // MH_DETECT_TRACE=1: wall time of the stages of this call on stderr (tools/detect_time.py)
+  static const bool trace = std::getenv("MH_DETECT_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t_prev = std::chrono::steady_clock::now();
+  double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    t_stage[i] += std::chrono::duration<double, std::micro>(now - t_prev).count();
+    t_prev = now;
+  };
   if (!fr) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_detect_features: no frame (call mh_photo_preprocess first)");
   const mh_photo_config & c = ph->cfg;
   const int rows = c.rows, cols = c.cols, npx = rows * cols;
@@ -441,6 +454,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     MH_HIP(ctx, hipMemcpyAsync(h_list + prefix, d_list + prefix, (n_list - prefix) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  lap(0);  // device: gradient, erosion, compaction; list read-back
   std::vector<uint32_t> gradients(h_list, h_list + n_list);
   // the detection mask is only ever asked about candidate pixels (set by construction): `alive` carries the circles
   std::vector<uint8_t> alive(static_cast<size_t>(npx), 1);
@@ -455,6 +469,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   // For a long list the same introsort runs on four host threads (exact_sort.hpp: same pivots, same partitions, same final
   // insertion sort — element for element std::sort's result, tests/cpp/exact_sort_check.cpp); MH_SORT_THREADS=1 forces
   // the plain library call.
+  lap(1);  // circles of the tracked features, filter
   {
     auto by_gradient = [](uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); };
     static const int sort_threads = [] {
@@ -468,6 +483,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     else
       std::sort(gradients.begin(), gradients.end(), by_gradient);
   }
+  lap(2);  // sort
   std::vector<std::pair<int, int>> cand;
   for (const uint32_t g : gradients) {  // :565-571 non-maximum suppression
     const int px = static_cast<int>(g & 0xFFFFFFu);
@@ -475,6 +491,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     cand.emplace_back(px % cols, px / cols);
     fill_circle_zero(alive, rows, cols, px % cols, px / cols, c.nma_radius);
   }
+  lap(3);  // non-maximum suppression
   // what the selection below reads, gathered on the device for the surviving candidates only
   const int m_off = c.n_patch_offsets, n_cand = static_cast<int>(cand.size()), per = m_off + 1;
   std::vector<float> win, rec;
@@ -513,6 +530,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     const int rcg = gather(uv, n_cand, false);
     if (rcg != MH_OK) return rcg;
   }
+  lap(4);  // gather round trip
   // :575-625 scores of every candidate along every bias direction
   std::vector<std::vector<std::pair<double, int>>> scores(n_dirs, std::vector<std::pair<double, int>>(cand.size(), {0.0, 0}));
   std::vector<float> grad_dir(2 * cand.size());
@@ -566,6 +584,7 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     const int rcg = gather(uv, n_sel, true);
     if (rcg != MH_OK) return rcg;
   }
+  lap(5);  // scores, per-direction sorts, round-robin selection
   Pose TBL, TWB;
   std::memcpy(TBL.R, c.T_B_L_R, sizeof(TBL.R));
   std::memcpy(TBL.t, c.T_B_L_t, sizeof(TBL.t));
@@ -629,6 +648,10 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     num_added++;
     if (num_added >= num_to_detect) break;
   }
+  lap(6);  // feature construction
+  if (trace)
+    std::fprintf(stderr, "detect_features: device+readback %.0f  filter %.0f  sort %.0f  nms %.0f  gather %.0f  select %.0f  build %.0f us  (%zu candidates, %zu after nms, %d added)\n",
+                 t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6], gradients.size(), cand.size(), num_added);
   return MH_OK;
 }
 }  // namespace
@@ -723,7 +746,7 @@ int mh_scan_keep_raw(mh_scan * scan, int keep)
   return MH_OK;
 }
 
-static int photo_finish_preprocess(mh_photo * photo, PhotoFrame * fr, mh_point32 * host_desk, size_t n)
+static int photo_finish_preprocess(mh_photo * photo, PhotoFrame * fr, mh_point32 * host_desk, size_t n, bool commit = true)
 {
   mh_ctx * ctx = photo->ctx;
   // corrected intensities back into the caller's cloud (:307-314)
@@ -743,8 +766,13 @@ static int photo_finish_preprocess(mh_photo * photo, PhotoFrame * fr, mh_point32
     return fail(ctx, MH_ERR_INVALID_ARG,
                 "mh_photo_preprocess: project(): invalid x coordinate for a deskewed point (the reference throws, photometric_utils.cpp:90-97)");
   }
-  frame_release(photo->frame);
-  photo->frame = fr;
+  if (commit) {
+    frame_release(photo->frame);
+    photo->frame = fr;
+  } else {
+    frame_release(photo->next_frame);  // a frame that was begun and never committed
+    photo->next_frame = fr;
+  }
   return MH_OK;
 }
 
@@ -785,7 +813,7 @@ int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_poin
   });
 }
 
-int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups)
+static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups, bool commit)
 {
   if (!photo || !scan || (n_groups && !T_Le_Lt))
     return fail(photo ? photo->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: NULL argument");
@@ -825,7 +853,26 @@ int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_
                                                         static_cast<float *>(fr->d_dy.p), static_cast<const int32_t *>(fr->d_idx.p),
                                                         static_cast<mh_point32 *>(scan->d_full.p), nullptr, photo->cfg.rows, photo->cfg.cols,
                                                         ctx->stream));
-    return photo_finish_preprocess(photo, fr, nullptr, n);
+    return photo_finish_preprocess(photo, fr, nullptr, n, commit);
+  });
+}
+int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups)
+{
+  return photo_preprocess_scan(photo, scan, T_Le_Lt, n_groups, true);
+}
+int mh_photo_preprocess_scan_begin(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups)
+{
+  return photo_preprocess_scan(photo, scan, T_Le_Lt, n_groups, false);
+}
+int mh_photo_preprocess_commit(mh_photo * photo)
+{
+  if (!photo) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_preprocess_commit: NULL argument");
+  return guarded(photo->ctx, "mh_photo_preprocess_commit", [&]() -> int {
+    if (!photo->next_frame) return fail(photo->ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_commit: no frame was begun (mh_photo_preprocess_scan_begin)");
+    frame_release(photo->frame);
+    photo->frame = photo->next_frame;
+    photo->next_frame = nullptr;
+    return MH_OK;
   });
 }
 

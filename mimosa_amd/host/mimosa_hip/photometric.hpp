@@ -298,6 +298,26 @@ public:
     ts_ = ts;
     key_ = key;
   }
+  // The same in two steps for a pipelined caller (replay.hpp): preprocessBegin builds the frame while another thread may
+  // still run updateMap of the previous scan on this object; preprocessCommit (after that update has returned) makes it current.
+  void preprocessBegin(ScanFrontEnd & scan, const std::vector<Pose3> & T_Le_Lt)
+  {
+    if (!config.enabled) return;
+    std::vector<double> T(12 * T_Le_Lt.size());
+    for (size_t g = 0; g < T_Le_Lt.size(); ++g) {
+      const PoseRM p = rowMajor(T_Le_Lt[g]);
+      std::memcpy(&T[12 * g], p.R.data(), 72);
+      std::memcpy(&T[12 * g + 9], p.t.data(), 24);
+    }
+    ctx_->check(mh_photo_preprocess_scan_begin(photo_, scan.underlying(), T.data(), T_Le_Lt.size()), "mh_photo_preprocess_scan_begin");
+  }
+  void preprocessCommit(const double ts, const Key key)
+  {
+    if (!config.enabled) return;
+    ctx_->check(mh_photo_preprocess_commit(photo_), "mh_photo_preprocess_commit");
+    ts_ = ts;
+    key_ = key;
+  }
 
   // photometric.cpp:373-394: unary factor on the current frame from the tracked features; V S V^T restricts it to the
   // directions `selection` keeps (the geometric factor's degenerate ones, lidar/manager.cpp:568-581)

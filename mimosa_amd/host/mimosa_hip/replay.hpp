@@ -541,13 +541,16 @@ public:
       Values values;
       NonlinearFactorGraph photo_graph;
       if (photo_) {
-        const auto c0 = clk::now();
         if (cfg_.pipeline) {
-          photo_worker->wait();  // Photometric::updateMap of scan k - 1
+          // the frame of scan k is BUILT while the worker may still be inside updateMap of scan k - 1 (it reads the frame
+          // and the tracked features of k - 1; building touches neither) and becomes current once that update has returned
+          const auto c0 = clk::now();
+          photo_->preprocessBegin(scan_, T_Le_Lt);
           const auto c1 = clk::now();
-          res.detail[5] += secs(c0, c1);
-          photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
-          res.detail[6] += secs(c1, clk::now());
+          res.detail[6] += secs(c0, c1);
+          photo_worker->wait();  // Photometric::updateMap of scan k - 1
+          photo_->preprocessCommit(sc.header_ts, Xk);
+          res.detail[5] += secs(c1, clk::now());
         }
         const auto c2 = clk::now();
         values.insert(Xk, toPose3(pred.T));

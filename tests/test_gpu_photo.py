@@ -320,6 +320,76 @@ def test_preprocess_from_resident_scan(ctx, frames):
     sc.destroy()
 
 
+def _resident_scan(ctx, cfg, f):
+    from mimosa_amd import capi, synth
+
+    raw = np.zeros(len(f["raw"]), dtype=synth.OUSTER_DTYPE)
+    for k in ("x", "y", "z", "intensity", "t"):
+        raw[k] = f["raw"][k]
+    full = np.zeros(cfg["rows"] * cfg["cols"], dtype=synth.OUSTER_DTYPE)
+    full["x"] = np.nan
+    full[f["raw"]["idx"]] = raw
+    full["ring"] = (np.arange(len(full)) // cfg["cols"]).astype(np.uint16)
+    sc = capi.Scan(ctx)
+    ctx.check(ctx.L.mh_scan_keep_raw(sc.h, 1))
+    sc.prepare_input(full, capi.make_input_config(range_min=0.0, range_max=1000.0))
+    sel = np.searchsorted(f["unique_ns"], sc.unique_ns())
+    sc.deskew(f["T_Le_Lt"][sel].astype(np.float32))
+    return sc, f["T_Le_Lt"][sel]
+
+
+def test_preprocess_begin_commit_beside_update_map(ctx, frames):
+    """mh_photo_preprocess_scan_begin / _commit: the frame of scan k is built (on another host thread's time) while
+    mh_photo_update_map of scan k - 1 runs on the same object, and becomes current afterwards — features, images and the
+    factor must be the bits of the plain sequence preprocess(k-1), update_map(k-1), preprocess(k)."""
+    import threading
+    from mimosa_amd import capi
+    from mimosa_amd import synth_photo as sp
+
+    cfg, fr = frames
+    sc0, T0 = _resident_scan(ctx, cfg, fr[0])
+    sc1, T1 = _resident_scan(ctx, cfg, fr[1])
+    plain, piped = capi.Photo(ctx, cfg), capi.Photo(ctx, cfg)
+    plain.preprocess_scan(sc0, T0)
+    plain.detect(60, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+    plain.preprocess_scan(sc1, T1)
+    want = plain.features()
+    with pytest.raises(capi.MhError):
+        piped.preprocess_commit()                       # nothing begun
+    for rep in range(3):                                # the overlap is a matter of timing: a few rounds
+        sc0b, _ = _resident_scan(ctx, cfg, fr[0])       # (fresh scans: preprocess writes the corrected intensities into them)
+        sc1b, _ = _resident_scan(ctx, cfg, fr[1])
+        piped.set_features([])
+        piped.preprocess_scan(sc0b, T0)
+        errors = []
+
+        def update():
+            try:
+                piped.detect(60, fr[0]["R_W_Be"], fr[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        th = threading.Thread(target=update)
+        th.start()
+        piped.preprocess_scan_begin(sc1b, T1)          # beside the detection on frame 0
+        th.join()
+        assert not errors, errors
+        piped.preprocess_commit()
+        got = piped.features()
+        assert len(got) == len(want) > 0
+        for a, b in zip(got, want):
+            for k in a:
+                if k != "id":                                        # ids keep counting across the rounds
+                    assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        for name in ("range", "mask", "idx", "intensity", "dx", "dy", "yaw", "proj_idx"):
+            assert np.array_equal(plain.image(name), piped.image(name)), name
+        assert sc1.points(0).tobytes() == sc1b.points(0).tobytes()
+        sc0b.destroy()
+        sc1b.destroy()
+    for o in (plain, piped, sc0, sc1):
+        o.destroy()
+
+
 def test_hip_matches_golden_fixture(ctx):
     """The committed fixture (generated by the independent numpy restatement) pins the HIP path as it pins the oracle."""
     from mimosa_amd import capi
