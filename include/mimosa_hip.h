@@ -500,6 +500,10 @@ int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R
  * factor may be NULL (no factor was built for this frame). */
 int mh_photo_update_map(mh_photo * photo, mh_photo_factor * factor, const double R_W_Be[9], const double t_W_Be[3],
                         const double * bias_directions, size_t n_directions);
+/* Optional: enqueues the part of the next mh_photo_detect_features / mh_photo_update_map that depends on the current frame
+ * alone (gradient magnitude, detection mask, candidate compaction, read-back of the candidate list) and returns without
+ * waiting; the next detection on this frame then only waits for those copies.  Results are the same with or without it. */
+int mh_photo_detect_prefetch(mh_photo * photo);
 /* PhotometricFactor ctor (photometric_factor.hpp:86-124) from the current frame and the tracked features (copied).
  * VSVt: 6x6 row-major = V S V^T of Photometric::getFactors (photometric.cpp:373-394), NULL = identity; ignored for
  * the binary form. */

@@ -32,7 +32,7 @@ EXPORTS = [
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
     "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
     "mh_shard_icp_stats", "mh_shard_icp_destroy",
-    "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_get_image",
+    "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
     "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_linearize_async", "mh_photo_factor_wait", "mh_photo_factor_get_state", "mh_photo_factor_size",
 ]
@@ -410,6 +410,7 @@ def load(build_if_missing: bool = True):
     L.mh_photo_preprocess_scan.argtypes = [vp, vp, vp, sz]
     L.mh_photo_preprocess_scan_begin.argtypes = [vp, vp, vp, sz]
     L.mh_photo_preprocess_commit.argtypes = [vp]
+    L.mh_photo_detect_prefetch.argtypes = [vp]
     L.mh_photo_get_image.argtypes = [vp, i32, vp, sz]
     L.mh_photo_num_features.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
     L.mh_photo_get_features.argtypes = [vp, vp, vp, vp, vp]
@@ -961,6 +962,9 @@ class Photo(_PhotoBase):
 
     def preprocess_commit(self):
         self.ctx.check(self.L.mh_photo_preprocess_commit(self.h))
+
+    def detect_prefetch(self):
+        self.ctx.check(self.L.mh_photo_detect_prefetch(self.h))
 
     def image(self, name):
         which, dt, k = PHOTO_IMAGES[name]

@@ -141,10 +141,86 @@ inline void sort_sequential(T * first, T * last, Comp comp)
   final_insertion_sort(first, last, comp);
 }
 
-// std::sort(first, last, comp) with the partition tree spread over `threads` host threads (the caller is one of them).
-// Parts larger than `leaf` are split further by whoever takes them; smaller ones are finished in place.
+// A few host threads that stay around between sorts (starting three threads costs ~60 us, a fifth of the sort they are
+// started for).  One job at a time: a caller that finds the pool busy sorts on its own thread.
+class Pool
+{
+public:
+  explicit Pool(int helpers)
+  {
+    try {
+      for (int t = 0; t < helpers; ++t) threads_.emplace_back([this] { loop(); });
+    } catch (...) {
+      // fewer helpers than asked for: the caller and the ones that started do the work
+    }
+  }
+  ~Pool()
+  {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto & t : threads_) t.join();
+  }
+  Pool(const Pool &) = delete;
+  Pool & operator=(const Pool &) = delete;
+  int helpers() const { return static_cast<int>(threads_.size()); }
+  // runs `fn` on every helper and on the caller, returns when all have returned; false (nothing run) when the pool is busy
+  template <class Fn>
+  bool run(Fn & fn)
+  {
+    std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+    if (!job.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      call_ = [](void * f) { (*static_cast<Fn *>(f))(); };
+      arg_ = &fn;
+      pending_ = helpers();
+      ++generation_;
+    }
+    cv_.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    return true;
+  }
+
+private:
+  void loop()
+  {
+    unsigned long seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return quit_ || generation_ != seen; });
+      if (quit_) return;
+      seen = generation_;
+      void (*call)(void *) = call_;
+      void * arg = arg_;
+      lk.unlock();
+      call(arg);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;
+  void (*call_)(void *) = nullptr;
+  void * arg_ = nullptr;
+  int pending_ = 0;
+  unsigned long generation_ = 0;
+  bool quit_ = false;
+};
+
+// std::sort(first, last, comp) with the partition tree spread over `threads` host threads (the caller is one of them;
+// the others come from `pool` when one is given and free, else they are started for this call).
+// Parts larger than `leaf` are split further by whoever takes them; smaller ones are finished in place — including their
+// share of the final insertion sort: a partition cut is a border no element crosses in that pass (everything right of it is
+// not before anything left of it, so the backward scan of an insertion stops there at the latest), hence the pass over the
+// whole array equals the passes over the parts, whoever runs them.
 template <class T, class Comp>
-inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrdiff_t leaf = 4096)
+inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrdiff_t leaf = 4096, Pool * pool = nullptr)
 {
   if (first == last) return;
   if (threads < 2 || last - first <= 2 * leaf) {
@@ -172,6 +248,7 @@ inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrd
       ++busy;
       lk.unlock();
       // the introsort loop on this part: big right halves go to the queue instead of the call stack
+      bool sorted = false;
       while (p.last - p.first > kThreshold) {
         if (p.last - p.first <= leaf) {
           introsort_loop(p.first, p.last, p.depth, comp);
@@ -179,6 +256,7 @@ inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrd
         }
         if (p.depth == 0) {
           std::partial_sort(p.first, p.last, p.last, comp);
+          sorted = true;  // nothing left for the insertion pass to move
           break;
         }
         --p.depth;
@@ -188,24 +266,27 @@ inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrd
           queue.push_back({cut, p.last, p.depth});
           lk.unlock();
           cv.notify_one();
+        } else {
+          insertion_sort(cut, p.last, comp);  // a right part the loop leaves to the final pass
         }
         p.last = cut;
       }
+      if (!sorted) insertion_sort(p.first, p.last, comp);
       lk.lock();
       --busy;
       if (queue.empty() && busy == 0) cv.notify_all();
     }
   };
-  std::vector<std::thread> pool;
-  pool.reserve(static_cast<size_t>(threads));
+  if (pool && pool->helpers() > 0 && pool->run(worker)) return;
+  std::vector<std::thread> spawned;
+  spawned.reserve(static_cast<size_t>(threads));
   try {
-    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    for (int t = 1; t < threads; ++t) spawned.emplace_back(worker);
   } catch (...) {
     // no more threads to be had: the ones that started and the caller finish the tree
   }
   worker();
-  for (auto & t : pool) t.join();
-  final_insertion_sort(first, last, comp);
+  for (auto & t : spawned) t.join();
 }
 
 }  // namespace exact_sort

@@ -81,6 +81,8 @@ struct mh_photo
   size_t h_stage_cap = 0;
   PhotoFrame * frame = nullptr;
   PhotoFrame * next_frame = nullptr;  // built by mh_photo_preprocess_scan_begin, current after mh_photo_preprocess_commit
+  PhotoFrame * cand_frame = nullptr;  // mh_photo_detect_prefetch: the frame whose candidate list is on its way to h_stage (a reference)
+  hipEvent_t cand_ev = nullptr;       // ... recorded behind the copies
   std::vector<HostFeature> features;  // map_Le_features_
   uint32_t next_id = 0;               // monotonic_feature_id_
 };
@@ -116,6 +118,8 @@ void photo_release(mh_photo * p)
   (void)hipStreamSynchronize(p->ctx->stream);
   frame_release(p->frame);
   frame_release(p->next_frame);
+  frame_release(p->cand_frame);
+  if (p->cand_ev) (void)hipEventDestroy(p->cand_ev);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
                      &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather})
     b->release();
@@ -406,6 +410,38 @@ void gradient_based_locations(float gx, float gy, const std::vector<int32_t> & p
   }
 }
 
+// The part of detectFeatures that depends on the frame alone (photometric.cpp:524-555 before the per-feature circles):
+// gradient magnitude, detection mask = erode(img_mask & mask_margin_), candidate pixels (mask != 0, gradient > threshold)
+// compacted in row-major order; the count and a 64 K-entry prefix of the list are on their way to h_stage when this returns
+// (~100 KB come back instead of the gradient / mask / intensity / index planes and the cloud, 5.3 MB).
+int detect_enqueue_candidates(mh_photo * ph, PhotoFrame * fr)
+{
+  mh_ctx * ctx = ph->ctx;
+  const mh_photo_config & c = ph->cfg;
+  const int rows = c.rows, cols = c.cols, npx = rows * cols;
+  MH_HIP(ctx, ph->d_grad.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, ph->d_detmask.reserve(npx, ctx->stream, false));
+  MH_HIP(ctx, mh::launch_photo_grad(static_cast<const float *>(fr->d_dx.p), static_cast<const float *>(fr->d_dy.p),
+                                    static_cast<uint8_t *>(ph->d_grad.p), npx, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(fr->d_mask.p), nullptr, c.margin_size, static_cast<uint8_t *>(ph->d_detmask.p),
+                                     rows, cols, c.patch_size + c.erosion_buffer, ctx->stream));
+  const int n_blk = (npx + 255) / 256;
+  MH_HIP(ctx, ph->d_cand.reserve((static_cast<size_t>(npx) + n_blk + 4) * sizeof(uint32_t), ctx->stream, false));
+  uint32_t * d_list = static_cast<uint32_t *>(ph->d_cand.p), * d_blk = d_list + npx, * d_n = d_blk + n_blk;
+  MH_HIP(ctx, mh::launch_photo_candidates(static_cast<const uint8_t *>(ph->d_grad.p), static_cast<const uint8_t *>(ph->d_detmask.p), npx,
+                                          c.gradient_threshold, d_blk, d_list, d_n, ctx->stream));
+  // the count and a prefix of the list come back together (one wait; a longer list needs a second copy)
+  const size_t prefix = std::min<size_t>(static_cast<size_t>(npx), 65536);
+  {
+    const int rcs = photo_stage(ph, 256 + static_cast<size_t>(npx) * sizeof(uint32_t));
+    if (rcs != MH_OK) return rcs;
+  }
+  uint32_t * h_list = reinterpret_cast<uint32_t *>(ph->h_stage + 256);
+  MH_HIP(ctx, hipMemcpyAsync(ph->h_stage, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(h_list, d_list, prefix * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  return MH_OK;
+}
+
 int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9], const double t_W_Be[3], const double * bias,
                          size_t n_dirs)
 {
@@ -425,33 +461,22 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   if (!fr) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_detect_features: no frame (call mh_photo_preprocess first)");
   const mh_photo_config & c = ph->cfg;
   const int rows = c.rows, cols = c.cols, npx = rows * cols;
-  // per-pixel part on the device: gradient magnitude, detection mask = erode(img_mask & mask_margin_)
-  MH_HIP(ctx, ph->d_grad.reserve(npx, ctx->stream, false));
-  MH_HIP(ctx, ph->d_detmask.reserve(npx, ctx->stream, false));
-  MH_HIP(ctx, mh::launch_photo_grad(static_cast<const float *>(fr->d_dx.p), static_cast<const float *>(fr->d_dy.p),
-                                    static_cast<uint8_t *>(ph->d_grad.p), npx, ctx->stream));
-  MH_HIP(ctx, mh::launch_photo_erode(static_cast<const uint8_t *>(fr->d_mask.p), nullptr, c.margin_size, static_cast<uint8_t *>(ph->d_detmask.p),
-                                     rows, cols, c.patch_size + c.erosion_buffer, ctx->stream));
-  // candidate pixels (mask != 0, gradient > threshold) compacted on the device in row-major order: ~100 KB come back
-  // instead of the gradient / mask / intensity / index planes and the cloud (5.3 MB)
-  const int n_blk = (npx + 255) / 256;
-  MH_HIP(ctx, ph->d_cand.reserve((static_cast<size_t>(npx) + n_blk + 4) * sizeof(uint32_t), ctx->stream, false));
-  uint32_t * d_list = static_cast<uint32_t *>(ph->d_cand.p), * d_blk = d_list + npx, * d_n = d_blk + n_blk;
-  MH_HIP(ctx, mh::launch_photo_candidates(static_cast<const uint8_t *>(ph->d_grad.p), static_cast<const uint8_t *>(ph->d_detmask.p), npx,
-                                          c.gradient_threshold, d_blk, d_list, d_n, ctx->stream));
-  // the count and a 64 K-entry prefix of the list come back together (one synchronisation; a longer list needs a second copy)
   const size_t prefix = std::min<size_t>(static_cast<size_t>(npx), 65536);
-  {
-    const int rcs = photo_stage(ph, 256 + static_cast<size_t>(npx) * sizeof(uint32_t));
-    if (rcs != MH_OK) return rcs;
+  if (ph->cand_frame == fr) {
+    // mh_photo_detect_prefetch enqueued this frame's candidate pass earlier: only its copies are waited for
+    MH_HIP(ctx, hipEventSynchronize(ph->cand_ev));
+  } else {
+    const int rcq = detect_enqueue_candidates(ph, fr);
+    if (rcq != MH_OK) return rcq;
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  frame_release(ph->cand_frame);
+  ph->cand_frame = nullptr;
   uint32_t * h_list = reinterpret_cast<uint32_t *>(ph->h_stage + 256);
-  MH_HIP(ctx, hipMemcpyAsync(ph->h_stage, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(h_list, d_list, prefix * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t n_list = *reinterpret_cast<const uint32_t *>(ph->h_stage);
   if (n_list > prefix) {
-    MH_HIP(ctx, hipMemcpyAsync(h_list + prefix, d_list + prefix, (n_list - prefix) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t * d_all = static_cast<const uint32_t *>(ph->d_cand.p);
+    MH_HIP(ctx, hipMemcpyAsync(h_list + prefix, d_all + prefix, (n_list - prefix) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   lap(0);  // device: gradient, erosion, compaction; list read-back
@@ -478,9 +503,10 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
       const int want = e ? std::atoi(e) : 4;
       return std::max(1, std::min(want, hw > 0 ? hw : 1));
     }();
-    if (sort_threads > 1 && gradients.size() >= 16384)
-      mh::exact_sort::sort_parallel(gradients.data(), gradients.data() + gradients.size(), by_gradient, sort_threads);
-    else
+    if (sort_threads > 1 && gradients.size() >= 16384) {
+      static mh::exact_sort::Pool pool(sort_threads - 1);  // helpers that stay around between frames (joined at exit)
+      mh::exact_sort::sort_parallel(gradients.data(), gradients.data() + gradients.size(), by_gradient, sort_threads, 4096, &pool);
+    } else
       std::sort(gradients.begin(), gradients.end(), by_gradient);
   }
   lap(2);  // sort
@@ -975,6 +1001,29 @@ int mh_photo_detect_features(mh_photo * photo, int num_to_detect, const double R
   return guarded(photo->ctx, "mh_photo_detect_features", [&]() -> int {
     MH_HIP(photo->ctx, mh_enter(photo->ctx));
     return detect_features_impl(photo, num_to_detect, R_W_Be, t_W_Be, bias_directions, n_directions);
+  });
+}
+
+int mh_photo_detect_prefetch(mh_photo * photo)
+{
+  if (!photo) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_detect_prefetch: NULL argument");
+  return guarded(photo->ctx, "mh_photo_detect_prefetch", [&]() -> int {
+    mh_ctx * ctx = photo->ctx;
+    if (!photo->frame) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_detect_prefetch: no frame (call mh_photo_preprocess first)");
+    MH_HIP(ctx, mh_enter(ctx));
+    if (photo->cand_frame == photo->frame) return MH_OK;
+    if (photo->cand_frame) {  // a prefetch nobody consumed: its copies must have landed before h_stage is written again
+      MH_HIP(ctx, hipEventSynchronize(photo->cand_ev));
+      frame_release(photo->cand_frame);
+      photo->cand_frame = nullptr;
+    }
+    if (!photo->cand_ev) MH_HIP(ctx, hipEventCreateWithFlags(&photo->cand_ev, hipEventDisableTiming));
+    const int rc = detect_enqueue_candidates(photo, photo->frame);
+    if (rc != MH_OK) return rc;
+    MH_HIP(ctx, hipEventRecord(photo->cand_ev, ctx->stream));
+    photo->cand_frame = photo->frame;
+    photo->cand_frame->refs.fetch_add(1);
+    return MH_OK;
   });
 }
 

@@ -318,6 +318,12 @@ public:
     ts_ = ts;
     key_ = key;
   }
+  // the frame-only part of the next updateMap (candidate pixels), enqueued now so that it runs beside the optimisation
+  void detectPrefetch()
+  {
+    if (!config.enabled) return;
+    ctx_->check(mh_photo_detect_prefetch(photo_), "mh_photo_detect_prefetch");
+  }
 
   // photometric.cpp:373-394: unary factor on the current frame from the tracked features; V S V^T restricts it to the
   // directions `selection` keeps (the geometric factor's degenerate ones, lidar/manager.cpp:568-581)

@@ -550,6 +550,7 @@ public:
           res.detail[6] += secs(c0, c1);
           photo_worker->wait();  // Photometric::updateMap of scan k - 1
           photo_->preprocessCommit(sc.header_ts, Xk);
+          photo_->detectPrefetch();  // candidate pixels of frame k: on the device while the smoother iterates
           res.detail[5] += secs(c1, clk::now());
         }
         const auto c2 = clk::now();

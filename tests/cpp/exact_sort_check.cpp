@@ -16,6 +16,7 @@ int main()
   auto by_gradient = [](uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); };  // photo_api.hip's comparator
   long cases = 0;
   double t_std = 0, t_par = 0;
+  mh::exact_sort::Pool pool(3);  // every other case runs on the persistent helpers
   for (int rep = 0; rep < 400; ++rep) {
     const size_t n = rep < 40 ? static_cast<size_t>(rep) : (rep % 7 == 0 ? 30000 + rng() % 40000 : rng() % 9000);
     const int distinct = 1 + static_cast<int>(rng() % (rep % 3 == 0 ? 3 : 246));  // few keys: thousands of ties
@@ -39,7 +40,7 @@ int main()
     auto t1 = std::chrono::steady_clock::now();
     mh::exact_sort::sort_sequential(b.data(), b.data() + b.size(), by_gradient);
     auto t2 = std::chrono::steady_clock::now();
-    mh::exact_sort::sort_parallel(c.data(), c.data() + c.size(), by_gradient, 2 + rep % 5, rep % 2 ? 4096 : 600);
+    mh::exact_sort::sort_parallel(c.data(), c.data() + c.size(), by_gradient, 2 + rep % 5, rep % 2 ? 4096 : 600, rep % 4 < 2 ? &pool : nullptr);
     auto t3 = std::chrono::steady_clock::now();
     if (n >= 30000) {
       t_std += std::chrono::duration<double, std::micro>(t1 - t0).count();
@@ -62,7 +63,7 @@ int main()
     std::vector<uint32_t> a = v, b = v, c = v;
     std::sort(a.begin(), a.end());
     mh::exact_sort::sort_sequential(b.data(), b.data() + n, std::less<uint32_t>());
-    mh::exact_sort::sort_parallel(c.data(), c.data() + n, std::less<uint32_t>(), 4, 512);
+    mh::exact_sort::sort_parallel(c.data(), c.data() + n, std::less<uint32_t>(), 4, 512, rep % 3 ? &pool : nullptr);
     if (a != b || a != c) {
       std::printf("MISMATCH (plain) rep %d\n", rep);
       return 1;

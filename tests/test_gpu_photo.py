@@ -361,6 +361,10 @@ def test_preprocess_begin_commit_beside_update_map(ctx, frames):
         sc1b, _ = _resident_scan(ctx, cfg, fr[1])
         piped.set_features([])
         piped.preprocess_scan(sc0b, T0)
+        if rep:                                         # the frame-only part of the detection enqueued ahead of it
+            piped.detect_prefetch()
+            if rep == 2:
+                piped.detect_prefetch()                 # twice is once
         errors = []
 
         def update():
