@@ -1192,6 +1192,11 @@ void mh_scan_destroy(mh_scan * s)
     (void)hipEventDestroy(s->copy_done);
   }
   if (s->h_stage) AllocCache::free_pinned(s->h_stage, s->h_stage_cap);
+  if (s->rt_done) {
+    (void)hipEventSynchronize(s->rt_done);
+    (void)hipEventDestroy(s->rt_done);
+  }
+  if (s->h_rt) AllocCache::free_pinned(s->h_rt, s->h_rt_cap);
   delete s;
 }
 
@@ -1391,11 +1396,27 @@ static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
     s->raw_valid = true;
   }
   MH_HIP(ctx, s->d_rt.reserve((n_groups + 1) * 12 * sizeof(float), ctx->stream, false));
-  MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, Rt12, n_groups * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  {
+    // the poses leave the caller's buffer here, on the host: pinned block -> device in stream order, no wait
+    const size_t bytes = n_groups * 12 * sizeof(float);
+    if (s->rt_done) MH_HIP(ctx, hipEventSynchronize(s->rt_done));  // the previous call's copy out of the block (long done)
+    if (bytes > s->h_rt_cap) {
+      size_t cap = size_t(64) << 10;
+      while (cap < bytes) cap <<= 1;
+      if (s->h_rt) AllocCache::free_pinned(s->h_rt, s->h_rt_cap);
+      s->h_rt = nullptr;
+      s->h_rt_cap = 0;
+      MH_HIP(ctx, AllocCache::alloc_pinned(&s->h_rt, cap));
+      s->h_rt_cap = cap;
+    }
+    if (!s->rt_done) MH_HIP(ctx, hipEventCreateWithFlags(&s->rt_done, hipEventDisableTiming));
+    std::memcpy(s->h_rt, Rt12, bytes);
+    MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, s->h_rt, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipEventRecord(s->rt_done, ctx->stream));
+  }
   MH_HIP(ctx, mh::launch_deskew(static_cast<mh_point32 *>(s->d_full.p), static_cast<int>(s->c.n_full),
                                 static_cast<const uint32_t *>(s->d_unique.p), static_cast<const float *>(s->d_rt.p),
                                 static_cast<int>(n_groups), nullptr, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // Rt12 is the caller's buffer
   s->preprocessed = false;
   return MH_OK;
 }

@@ -444,6 +444,11 @@ struct mh_scan
   void * h_stage = nullptr;
   size_t h_stage_cap = 0, n_prefetched = 0;
   bool prefetch_valid = false;
+  // mh_scan_deskew: the poses travel through a pinned block of the scan's own, so the call neither touches the caller's
+  // (pageable) buffer from the stream nor waits for it
+  void * h_rt = nullptr;
+  size_t h_rt_cap = 0;
+  hipEvent_t rt_done = nullptr;
 };
 
 // IncrementalVoxelMapPCL counterpart: the device-resident voxel map (map_device.hpp / map_kernels.hip).  The device
