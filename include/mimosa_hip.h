@@ -469,12 +469,15 @@ int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_poin
  * points_deskewed = its points_full_ now (corrected intensities are written there). */
 int mh_scan_keep_raw(mh_scan * scan, int keep);
 int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups);
-/* The same in two steps, for a caller that pipelines scans: _begin builds the frame of scan k WITHOUT making it current —
- * it touches none of the state mh_photo_update_map / mh_photo_detect_features use (tracked features, current frame, their
- * scratch), so one host thread may run it while another is still inside mh_photo_update_map of scan k - 1 on the same object
- * (the only concurrent pair that is allowed; both enqueue on the object's context stream); _commit makes the begun frame
- * current (after that update has returned).  mh_photo_preprocess_scan == _begin + _commit.  A begun frame that is never
- * committed is dropped by the next _begin or by mh_photo_destroy. */
+/* The same in two steps, for a caller that pipelines scans: _begin ENQUEUES the frame of scan k without making it current and
+ * without waiting for anything (it queues behind the scan's deskew on the device, reads the scan, does not write it) — it touches
+ * none of the state mh_photo_update_map / mh_photo_detect_features use (tracked features, current frame, their scratch), so one
+ * host thread may run it while another is still inside mh_photo_update_map of scan k - 1 on the same object (the only concurrent
+ * pair that is allowed; both enqueue on the object's context stream); _commit (after that update has returned) waits for the
+ * frame, reports what _begin's kernels found (the project() error), writes the corrected intensities into the scan's cloud —
+ * `scan` must still be alive and must not have been prepared again — and makes the frame current.
+ * mh_photo_preprocess_scan == _begin + _commit.  A begun frame that is never committed is dropped by the next _begin or by
+ * mh_photo_destroy. */
 int mh_photo_preprocess_scan_begin(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups);
 int mh_photo_preprocess_commit(mh_photo * photo);
 /* One image of the current frame, rows * cols elements.  which: 0 img_intensity (float), 1 img_range (float),

@@ -81,8 +81,25 @@ __global__ __launch_bounds__(kThreads) void pack_xyz_kernel(const float4 * pts, 
 }
 
 int grid_for(int n) { return max(1, min((n + kThreads - 1) / kThreads, 2048)); }
+// Device-to-device copy of 16-byte words as a kernel: stream-ordered like any launch.  (hipMemcpyAsync device-to-device goes
+// through the runtime's copy path; in the pipelined replay — a second thread uploading 4 MiB on a copy stream at the same time —
+// that call was seen to BLOCK the calling thread for 0.4 ms in about a third of the processes.)
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4 * __restrict__ src, uint4 * __restrict__ dst, size_t n16)
+{
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
 }  // namespace
 
+hipError_t launch_copy16(const void * src, void * dst, size_t bytes, hipStream_t stream)
+{
+  const size_t n16 = bytes / 16;  // callers copy whole 16-byte records (mh_point32 = 32 bytes)
+  if (!n16) return hipSuccess;
+  const size_t blocks = (n16 + 255) / 256;
+  hipLaunchKernelGGL(copy16_kernel, dim3(static_cast<unsigned int>(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream,
+                     static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+  return hipGetLastError();
+}
 
 hipError_t launch_deskew(mh_point32 * pts, int n, const uint32_t * unique_ns, const float * Rt12, int n_groups,
                          const float * body_Rt12, hipStream_t stream)

@@ -131,5 +131,6 @@ hipError_t launch_deskew(mh_point32 * pts, int n, const uint32_t * unique_ns, co
                          const float * body_Rt12, hipStream_t stream);
 hipError_t launch_transform(mh_point32 * pts, int n, const float * Rt12, hipStream_t stream);
 hipError_t launch_pack_xyz(const mh_point32 * pts, int n, float4 * xyz, hipStream_t stream);
+hipError_t launch_copy16(const void * src, void * dst, size_t bytes, hipStream_t stream);  // bytes: a multiple of 16
 
 }  // namespace mh

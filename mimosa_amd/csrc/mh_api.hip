@@ -1392,10 +1392,10 @@ static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
   MH_HIP(ctx, mh_enter(ctx));
   if (s->keep_raw && !s->raw_valid) {  // points_raw_ = points_full_ before deskewing (lidar/manager.cpp:376-380)
     MH_HIP(ctx, s->d_full_raw.reserve(s->c.n_full * sizeof(mh_point32), ctx->stream, false));
-    MH_HIP(ctx, hipMemcpyAsync(s->d_full_raw.p, s->d_full.p, s->c.n_full * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream));
+    MH_HIP(ctx, mh::launch_copy16(s->d_full.p, s->d_full_raw.p, s->c.n_full * sizeof(mh_point32), ctx->stream));
     s->raw_valid = true;
   }
-  MH_HIP(ctx, s->d_rt.reserve((n_groups + 1) * 12 * sizeof(float), ctx->stream, false));
+  MH_HIP(ctx, s->d_rt.reserve((n_groups + 1) * 12 * sizeof(float) + 16, ctx->stream, false));
   {
     // the poses leave the caller's buffer here, on the host: pinned block -> device in stream order, no wait
     const size_t bytes = n_groups * 12 * sizeof(float);
@@ -1411,7 +1411,11 @@ static int mh_scan_deskew_impl(mh_scan * s, const float * Rt12, size_t n_groups)
     }
     if (!s->rt_done) MH_HIP(ctx, hipEventCreateWithFlags(&s->rt_done, hipEventDisableTiming));
     std::memcpy(s->h_rt, Rt12, bytes);
-    MH_HIP(ctx, hipMemcpyAsync(s->d_rt.p, s->h_rt, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // a copy KERNEL reading the mapped block, not hipMemcpyAsync: a small host-to-device copy call was seen to block its caller
+    // for 0.1-0.4 ms whenever another thread's 4 MiB upload (mh_scan_prefetch of the next cloud) was in flight
+    void * d_src = nullptr;
+    MH_HIP(ctx, hipHostGetDevicePointer(&d_src, s->h_rt, 0));
+    MH_HIP(ctx, mh::launch_copy16(d_src, s->d_rt.p, (bytes + 15) & ~size_t(15), ctx->stream));
     MH_HIP(ctx, hipEventRecord(s->rt_done, ctx->stream));
   }
   MH_HIP(ctx, mh::launch_deskew(static_cast<mh_point32 *>(s->d_full.p), static_cast<int>(s->c.n_full),

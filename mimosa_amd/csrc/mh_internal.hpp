@@ -3,6 +3,9 @@
 // the boundary.
 #pragma once
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -148,7 +151,12 @@ public:
         return hipSuccess;
       }
     }
+    static const bool trace = std::getenv("MH_ALLOC_TRACE") != nullptr;  // every trip to the runtime, with its cost, on stderr
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, cls ? cls : bytes);
+    if (trace)
+      std::fprintf(stderr, "AllocCache: hipMalloc(%zu) %.0f us (stream %p)\n", cls ? cls : bytes,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), static_cast<void *>(g_mh_stream));
     if (e != hipSuccess && cls) {
       // out of memory: a cached block that is still in flight on another stream is better than none
       (void)hipGetLastError();

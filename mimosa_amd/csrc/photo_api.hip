@@ -35,10 +35,14 @@ struct PhotoFrame  // include/mimosa/lidar/photometric_utils.hpp:42-92, shared_p
   int rows = 0, cols = 0, n_poses = 0;
   size_t n_points = 0;
   DevBuf d_points, d_intensity, d_range, d_dx, d_dy, d_mask, d_idx, d_proj, d_yaw, d_pose_ns, d_pose_Rt;
+  void * h_pose = nullptr;  // pinned: the pose table and its timestamps on their way to the device (no pageable copy, no wait)
+  size_t h_pose_cap = 0;
   void release_buffers()
   {
     for (DevBuf * b : {&d_points, &d_intensity, &d_range, &d_dx, &d_dy, &d_mask, &d_idx, &d_proj, &d_yaw, &d_pose_ns, &d_pose_Rt})
       b->release();
+    if (h_pose) AllocCache::free_pinned(h_pose, h_pose_cap);
+    h_pose = nullptr;
   }
 };
 
@@ -81,6 +85,9 @@ struct mh_photo
   size_t h_stage_cap = 0;
   PhotoFrame * frame = nullptr;
   PhotoFrame * next_frame = nullptr;  // built by mh_photo_preprocess_scan_begin, current after mh_photo_preprocess_commit
+  mh_scan * next_scan = nullptr;      // ... the scan it was built from (its cloud receives the corrected intensities at the commit)
+  hipEvent_t next_ev = nullptr;       // ... recorded behind its last kernel
+  hipEvent_t scan_ev = nullptr;       // cross-stream order with the scan's context (device-side waits, no host wait)
   PhotoFrame * cand_frame = nullptr;  // mh_photo_detect_prefetch: the frame whose candidate list is on its way to h_stage (a reference)
   hipEvent_t cand_ev = nullptr;       // ... recorded behind the copies
   std::vector<HostFeature> features;  // map_Le_features_
@@ -120,6 +127,8 @@ void photo_release(mh_photo * p)
   frame_release(p->next_frame);
   frame_release(p->cand_frame);
   if (p->cand_ev) (void)hipEventDestroy(p->cand_ev);
+  if (p->next_ev) (void)hipEventDestroy(p->next_ev);
+  if (p->scan_ev) (void)hipEventDestroy(p->scan_ev);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
                      &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather})
     b->release();
@@ -287,6 +296,17 @@ int upload(mh_ctx * ctx, DevBuf & b, const void * src, size_t bytes)
   if (bytes) MH_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return MH_OK;
 }
+// The same out of a pinned block of this library (readable up to the next multiple of 16 bytes), as a copy KERNEL: a small
+// hipMemcpyAsync can block its caller behind another thread's big upload (mh_scan_deskew has the measurement).
+int upload_pinned(mh_ctx * ctx, DevBuf & b, const void * pinned_src, size_t bytes)
+{
+  MH_HIP(ctx, b.reserve(bytes + 16, ctx->stream, false));
+  if (!bytes) return MH_OK;
+  void * d_src = nullptr;
+  MH_HIP(ctx, hipHostGetDevicePointer(&d_src, const_cast<void *>(pinned_src), 0));
+  MH_HIP(ctx, mh::launch_copy16(d_src, b.p, (bytes + 15) & ~size_t(15), ctx->stream));
+  return MH_OK;
+}
 
 // The device part of preprocess on points already resident (d_raw / frame->d_points), then the pose table.
 int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, size_t n, const uint32_t * unique_ns,
@@ -304,10 +324,25 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   MH_HIP(ctx, ph->d_mask_raw.reserve(npx, ctx->stream, false));
   MH_HIP(ctx, ph->d_yaw_valid.reserve(npx, ctx->stream, false));
   MH_HIP(ctx, ph->d_int_out.reserve((n ? n : 1) * sizeof(float), ctx->stream, false));
-  int rc = upload(ctx, fr->d_pose_ns, unique_ns, n_groups * sizeof(uint32_t));
-  if (rc != MH_OK) return rc;
-  rc = upload(ctx, fr->d_pose_Rt, T_Le_Lt, n_groups * 12 * sizeof(double));
-  if (rc != MH_OK) return rc;
+  {
+    const size_t b_ns = (n_groups * sizeof(uint32_t) + 255) & ~size_t(255), b_rt = n_groups * 12 * sizeof(double);
+    size_t cap = size_t(64) << 10;
+    while (cap < b_ns + b_rt) cap <<= 1;
+    MH_HIP(ctx, AllocCache::alloc_pinned(&fr->h_pose, cap));
+    fr->h_pose_cap = cap;
+    char * h = static_cast<char *>(fr->h_pose);
+    if (n_groups) {
+      std::memcpy(h, unique_ns, n_groups * sizeof(uint32_t));
+      std::memcpy(h + b_ns, T_Le_Lt, b_rt);
+    }
+    // copy kernels reading the mapped block (see mh_scan_deskew: a small hipMemcpyAsync can block behind another thread's upload)
+    void * d_src = nullptr;
+    MH_HIP(ctx, hipHostGetDevicePointer(&d_src, h, 0));
+    MH_HIP(ctx, fr->d_pose_ns.reserve(b_ns + 16, ctx->stream, false));
+    MH_HIP(ctx, fr->d_pose_Rt.reserve(b_rt + 16, ctx->stream, false));
+    MH_HIP(ctx, mh::launch_copy16(d_src, fr->d_pose_ns.p, b_ns, ctx->stream));
+    MH_HIP(ctx, mh::launch_copy16(static_cast<char *>(d_src) + b_ns, fr->d_pose_Rt.p, (b_rt + 15) & ~size_t(15), ctx->stream));
+  }
   fr->n_poses = static_cast<int>(n_groups);
   fr->rows = rows;
   fr->cols = cols;
@@ -436,9 +471,16 @@ int detect_enqueue_candidates(mh_photo * ph, PhotoFrame * fr)
     const int rcs = photo_stage(ph, 256 + static_cast<size_t>(npx) * sizeof(uint32_t));
     if (rcs != MH_OK) return rcs;
   }
-  uint32_t * h_list = reinterpret_cast<uint32_t *>(ph->h_stage + 256);
-  MH_HIP(ctx, hipMemcpyAsync(ph->h_stage, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(h_list, d_list, prefix * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  // copy KERNELS writing the pinned block (small hipMemcpyAsync calls can block their caller behind another thread's upload,
+  // see mh_scan_deskew)
+  void * hd = nullptr;
+  MH_HIP(ctx, hipHostGetDevicePointer(&hd, ph->h_stage, 0));
+  {
+    // d_n's 16-byte neighbourhood lands at the start of the block; the reader picks the word at the same offset
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_n) & ~uintptr_t(15);
+    MH_HIP(ctx, mh::launch_copy16(reinterpret_cast<const void *>(a), hd, 16, ctx->stream));
+    MH_HIP(ctx, mh::launch_copy16(d_list, static_cast<char *>(hd) + 256, (prefix * sizeof(uint32_t) + 15) & ~size_t(15), ctx->stream));
+  }
   return MH_OK;
 }
 
@@ -473,7 +515,11 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
   frame_release(ph->cand_frame);
   ph->cand_frame = nullptr;
   uint32_t * h_list = reinterpret_cast<uint32_t *>(ph->h_stage + 256);
-  const uint32_t n_list = *reinterpret_cast<const uint32_t *>(ph->h_stage);
+  const uint32_t n_list = [&] {  // the count's 16-byte neighbourhood was copied: same offset inside it
+    const int n_blk_ = (npx + 255) / 256;
+    const uintptr_t dn = reinterpret_cast<uintptr_t>(static_cast<uint32_t *>(ph->d_cand.p) + npx + n_blk_);
+    return reinterpret_cast<const uint32_t *>(ph->h_stage)[(dn & 15u) / 4];
+  }();
   if (n_list > prefix) {
     const uint32_t * d_all = static_cast<const uint32_t *>(ph->d_cand.p);
     MH_HIP(ctx, hipMemcpyAsync(h_list + prefix, d_all + prefix, (n_list - prefix) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -529,16 +575,24 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     const size_t b_uv = (uv.size() * 4 + 255) & ~size_t(255), b_win = (n_win * 4 + 255) & ~size_t(255), b_rec = (n_rec * 4 + 255) & ~size_t(255);
     const size_t b_out = b_win + b_rec + n_idx * 4;
     MH_HIP(ctx, ph->d_gather.reserve(b_uv + b_out + 256, ctx->stream, false));
-    const int rcs = photo_stage(ph, b_uv + b_out);
+    const int rcs = photo_stage(ph, b_uv + b_out + 16);
     if (rcs != MH_OK) return rcs;
     char * d = static_cast<char *>(ph->d_gather.p);
     std::memcpy(ph->h_stage, uv.data(), uv.size() * 4);
-    MH_HIP(ctx, hipMemcpyAsync(d, ph->h_stage, uv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+      void * d_src = nullptr;  // (a copy kernel, see upload_pinned; b_uv is a multiple of 256 on both sides)
+      MH_HIP(ctx, hipHostGetDevicePointer(&d_src, ph->h_stage, 0));
+      MH_HIP(ctx, mh::launch_copy16(d_src, d, (uv.size() * 4 + 15) & ~size_t(15), ctx->stream));
+    }
     MH_HIP(ctx, mh::launch_photo_gather(reinterpret_cast<const int2 *>(d), m_off, count, per_candidate, static_cast<const float *>(fr->d_intensity.p),
                                         static_cast<const int32_t *>(fr->d_idx.p), static_cast<const mh_point32 *>(fr->d_points.p), rows, cols,
                                         reinterpret_cast<float *>(d + b_uv), reinterpret_cast<float4 *>(d + b_uv + b_win),
                                         reinterpret_cast<int32_t *>(d + b_uv + b_win + b_rec), ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(ph->h_stage + b_uv, d + b_uv, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    {
+      void * hd = nullptr;  // (a copy kernel writing the pinned block, see detect_enqueue_candidates)
+      MH_HIP(ctx, hipHostGetDevicePointer(&hd, ph->h_stage, 0));
+      MH_HIP(ctx, mh::launch_copy16(d + b_uv, static_cast<char *>(hd) + b_uv, (b_out + 15) & ~size_t(15), ctx->stream));
+    }
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const char * h = ph->h_stage + b_uv;
     win.assign(reinterpret_cast<const float *>(h), reinterpret_cast<const float *>(h) + n_win);
@@ -839,6 +893,22 @@ int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_poin
   });
 }
 
+// corrected intensities into the scan's resident cloud (:307-314), ordered before whatever the scan's own stream does next
+static int photo_writeback_scan(mh_photo * photo, PhotoFrame * fr, mh_scan * scan)
+{
+  mh_ctx * ctx = photo->ctx;
+  if (!scan->c.n_full) return MH_OK;
+  MH_HIP(ctx, mh::launch_photo_sobel_writeback(static_cast<const float *>(fr->d_intensity.p), static_cast<float *>(fr->d_dx.p),
+                                               static_cast<float *>(fr->d_dy.p), static_cast<const int32_t *>(fr->d_idx.p),
+                                               static_cast<mh_point32 *>(scan->d_full.p), nullptr, photo->cfg.rows, photo->cfg.cols, ctx->stream));
+  if (scan->ctx != ctx) {
+    if (!photo->scan_ev) MH_HIP(ctx, hipEventCreateWithFlags(&photo->scan_ev, hipEventDisableTiming));
+    MH_HIP(ctx, hipEventRecord(photo->scan_ev, ctx->stream));
+    MH_HIP(ctx, hipStreamWaitEvent(scan->ctx->stream, photo->scan_ev, 0));
+  }
+  return MH_OK;
+}
+
 static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups, bool commit)
 {
   if (!photo || !scan || (n_groups && !T_Le_Lt))
@@ -853,11 +923,15 @@ static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double 
     if (n > static_cast<size_t>(photo->cfg.rows) * photo->cfg.cols)
       return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_scan: number of points exceeds the image size");
     MH_HIP(ctx, mh_enter(ctx));
-    if (scan->ctx != ctx) MH_HIP(ctx, hipStreamSynchronize(scan->ctx->stream));
+    if (scan->ctx != ctx) {  // the scan's deskew may still be running on its own stream: this stream queues behind it
+      if (!photo->scan_ev) MH_HIP(ctx, hipEventCreateWithFlags(&photo->scan_ev, hipEventDisableTiming));
+      MH_HIP(ctx, hipEventRecord(photo->scan_ev, scan->ctx->stream));
+      MH_HIP(ctx, hipStreamWaitEvent(ctx->stream, photo->scan_ev, 0));
+    }
     PhotoFrame * fr = new PhotoFrame;
     fr->ctx = ctx;
     hipError_t e = fr->d_points.reserve((n ? n : 1) * sizeof(mh_point32), ctx->stream, false);
-    if (e == hipSuccess && n) e = hipMemcpyAsync(fr->d_points.p, scan->d_full.p, n * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = mh::launch_copy16(scan->d_full.p, fr->d_points.p, n * sizeof(mh_point32), ctx->stream);
     if (e != hipSuccess) {
       frame_release(fr);
       return hip_fail(ctx, e, "mh_photo_preprocess_scan: frame copy");
@@ -874,12 +948,21 @@ static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double 
       frame_release(fr);
       return rc;
     }
-    // corrected intensities into the scan's resident cloud
-    if (n) MH_HIP(ctx, mh::launch_photo_sobel_writeback(static_cast<const float *>(fr->d_intensity.p), static_cast<float *>(fr->d_dx.p),
-                                                        static_cast<float *>(fr->d_dy.p), static_cast<const int32_t *>(fr->d_idx.p),
-                                                        static_cast<mh_point32 *>(scan->d_full.p), nullptr, photo->cfg.rows, photo->cfg.cols,
-                                                        ctx->stream));
-    return photo_finish_preprocess(photo, fr, nullptr, n, commit);
+    if (!commit) {
+      // begin: nothing is waited for and the scan is not written; mh_photo_preprocess_commit does both
+      if (!photo->next_ev) MH_HIP(ctx, hipEventCreateWithFlags(&photo->next_ev, hipEventDisableTiming));
+      MH_HIP(ctx, hipEventRecord(photo->next_ev, ctx->stream));
+      frame_release(photo->next_frame);  // a frame that was begun and never committed
+      photo->next_frame = fr;
+      photo->next_scan = scan;
+      return MH_OK;
+    }
+    rc = photo_writeback_scan(photo, fr, scan);
+    if (rc != MH_OK) {
+      frame_release(fr);
+      return rc;
+    }
+    return photo_finish_preprocess(photo, fr, nullptr, n, true);
   });
 }
 int mh_photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double * T_Le_Lt, size_t n_groups)
@@ -894,10 +977,25 @@ int mh_photo_preprocess_commit(mh_photo * photo)
 {
   if (!photo) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_photo_preprocess_commit: NULL argument");
   return guarded(photo->ctx, "mh_photo_preprocess_commit", [&]() -> int {
-    if (!photo->next_frame) return fail(photo->ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_commit: no frame was begun (mh_photo_preprocess_scan_begin)");
-    frame_release(photo->frame);
-    photo->frame = photo->next_frame;
+    mh_ctx * ctx = photo->ctx;
+    if (!photo->next_frame) return fail(ctx, MH_ERR_INVALID_ARG, "mh_photo_preprocess_commit: no frame was begun (mh_photo_preprocess_scan_begin)");
+    MH_HIP(ctx, mh_enter(ctx));
+    MH_HIP(ctx, hipEventSynchronize(photo->next_ev));  // the frame's kernels (normally long done: they ran beside the caller's work)
+    PhotoFrame * fr = photo->next_frame;
     photo->next_frame = nullptr;
+    if (photo->h_counters->project_throw) {
+      frame_release(fr);
+      return fail(ctx, MH_ERR_INVALID_ARG,
+                  "mh_photo_preprocess: project(): invalid x coordinate for a deskewed point (the reference throws, photometric_utils.cpp:90-97)");
+    }
+    const int rc = photo_writeback_scan(photo, fr, photo->next_scan);
+    photo->next_scan = nullptr;
+    if (rc != MH_OK) {
+      frame_release(fr);
+      return rc;
+    }
+    frame_release(photo->frame);
+    photo->frame = fr;
     return MH_OK;
   });
 }
@@ -1092,9 +1190,9 @@ static int photo_factor_build(mh_photo * photo, PhotoFrame * frame, const std::v
       std::memcpy(&Le[i * mh::kPhotoMaxPatch * 3], hf.Le_ps.data(), hf.Le_ps.size() * sizeof(double));
       std::memcpy(&ps[i * mh::kPhotoMaxPatch], hf.psi.data(), hf.psi.size() * sizeof(double));
     }
-    rc = upload(ctx, f->d_Le, Le, b_Le);
-    if (rc == MH_OK) rc = upload(ctx, f->d_psi, ps, b_ps);
-    if (rc == MH_OK) rc = upload(ctx, f->d_npts, np, b_np);
+    rc = upload_pinned(ctx, f->d_Le, Le, b_Le);
+    if (rc == MH_OK) rc = upload_pinned(ctx, f->d_psi, ps, b_ps);
+    if (rc == MH_OK) rc = upload_pinned(ctx, f->d_npts, np, b_np);
   }
   if (rc == MH_OK && e == hipSuccess) e = f->d_rows.reserve(nf * mh::kPhotoMaxPatch * 8 * sizeof(double), ctx->stream, false);
   if (rc == MH_OK && e == hipSuccess) e = f->d_ticket.reserve(64, ctx->stream, false);

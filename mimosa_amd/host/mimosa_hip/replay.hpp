@@ -521,14 +521,22 @@ public:
       const auto b0 = clk::now();
       res.detail[2] += secs(a2, b0);
       const Key Xk = X(k);
-      // (the photometric frame is built AFTER the geometric pre-processing and the ICP factor when pipelined: those do not
-      // need it, and the previous scan's photometric map update may still be running on the frame before)
+      // Pipelined: the frame of scan k is ENQUEUED here (behind the deskew, on the photometric stream; the scan is only read)
+      // and runs beside the down-sampler and the ICP factor below, while the worker may still be inside updateMap of scan k - 1
+      // (it reads the frame and the tracked features of k - 1; building touches neither); it becomes current — and the scan's
+      // cloud receives the corrected intensities — at the commit, once that update has returned.
       if (photo_ && !cfg_.pipeline) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+      if (photo_ && cfg_.pipeline) {
+        const auto c0 = clk::now();
+        photo_->preprocessBegin(scan_, T_Le_Lt);
+        res.detail[6] += secs(c0, clk::now());
+      }
+      const auto b0g = clk::now();
       ctx_->check(mh_scan_preprocess_geometric(scan_.underlying(), I3f, z3f, cfg_.reg.source_voxel_grid_filter_leaf_size, 20,
                                                cfg_.reg.source_voxel_grid_min_dist_in_voxel, &scan_.mutableInfo()),
                   "mh_scan_preprocess_geometric");
       const auto a3 = clk::now();
-      res.detail[3] += secs(b0, a3);
+      res.detail[3] += secs(b0g, a3);
       Live lv;
       lv.k = k;
       lv.T = pred.T;
@@ -542,12 +550,7 @@ public:
       NonlinearFactorGraph photo_graph;
       if (photo_) {
         if (cfg_.pipeline) {
-          // the frame of scan k is BUILT while the worker may still be inside updateMap of scan k - 1 (it reads the frame
-          // and the tracked features of k - 1; building touches neither) and becomes current once that update has returned
-          const auto c0 = clk::now();
-          photo_->preprocessBegin(scan_, T_Le_Lt);
           const auto c1 = clk::now();
-          res.detail[6] += secs(c0, c1);
           photo_worker->wait();  // Photometric::updateMap of scan k - 1
           photo_->preprocessCommit(sc.header_ts, Xk);
           photo_->detectPrefetch();  // candidate pixels of frame k: on the device while the smoother iterates

@@ -304,6 +304,7 @@ def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible
     import json
     import os
     import subprocess
+    import sys
     from . import build
     exe = build.build_replay_native()
     path = os.path.join(workdir, "replay_input.bin")
@@ -315,6 +316,8 @@ def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible
     os.remove(path)
     if out.returncode != 0:
         raise RuntimeError("replay_native failed: " + out.stderr[-2000:])
+    if out.stderr and (os.environ.get("MH_ALLOC_TRACE") or os.environ.get("MH_DETECT_TRACE")):
+        sys.stderr.write(out.stderr)   # the library's diagnostic traces
     r = json.loads(out.stdout)
     r["poses_est"] = [(np.array(p[:9]).reshape(3, 3), np.array(p[9:])) for p in r.pop("poses")]
     return r
