@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -30,6 +31,10 @@ namespace mh
 namespace exact_sort
 {
 constexpr std::ptrdiff_t kThreshold = 16;  // _S_threshold
+#ifndef MH_LIST_PARTITION_MIN
+#define MH_LIST_PARTITION_MIN 1024
+#endif
+constexpr std::ptrdiff_t kListPartitionMin = MH_LIST_PARTITION_MIN;  // ranges at least this long are partitioned by partition_pivot_lists
 
 inline long floor_log2(std::ptrdiff_t n)
 {
@@ -77,6 +82,56 @@ inline T * partition_pivot(T * first, T * last, Comp comp)
   }
 }
 
+// The same partition — same swaps in the same order, same cut — without the data-dependent branches of the two scans (on
+// random 8-bit keys every second one is mispredicted): the scans only ever stop at "left stoppers" (!comp(x, pivot)) and
+// "right stoppers" (!comp(pivot, x)), so one branch-free pass lists both kinds of positions, and the algorithm's k-th swap is
+// (k-th left stopper from the left, k-th right stopper from the right) for as long as the former lies left of the latter: between
+// the two last swapped positions the array is still the original one, and the elements swapped INTO them are stoppers of the
+// right kind, which is where a scan ends when it finds no original stopper first — hence the cut below.
+// `idx` = scratch for 2 * (last - first) positions.
+template <class T, class Comp>
+inline T * partition_pivot_lists(T * first, T * last, Comp comp, uint32_t * idx)
+{
+  T * mid = first + (last - first) / 2;
+  median_to_first(first, first + 1, mid, last - 1, comp);
+  const T pivot = *first;
+  const uint32_t n = static_cast<uint32_t>(last - first);
+  uint32_t * A = idx;      // left stoppers, ascending positions (relative to first), from [1, n)
+  uint32_t * B = idx + n;  // right stoppers, ascending positions, from [0, n): position 0 (the pivot itself) is the sentinel
+  uint32_t na = 0, nb = 0;
+  B[nb++] = 0;
+  for (uint32_t p = 1; p < n; ++p) {
+    const T x = first[p];
+    A[na] = p;
+    na += comp(x, pivot) ? 0u : 1u;
+    B[nb] = p;
+    nb += comp(pivot, x) ? 0u : 1u;
+  }
+  // k-th right stopper from the right = B[nb - 1 - k]
+  uint32_t k = 0;
+  while (k < na && k < nb && A[k] < B[nb - 1 - k]) {
+    std::iter_swap(first + A[k], first + B[nb - 1 - k]);
+    ++k;
+  }
+  // the scan from the left ends at its next original stopper or, failing one before it, at the position of the last swap's
+  // right partner (which now holds a left stopper)
+  if (k == 0) return first + A[0];  // (exists: the median of three left an element that is not before the pivot)
+  const uint32_t prev_right = B[nb - k];
+  const uint32_t next_left = k < na ? A[k] : n;
+  return first + (next_left < prev_right ? next_left : prev_right);
+}
+
+// one partition step: the list form for long ranges (per-thread scratch), the scanning form for short ones
+template <class T, class Comp>
+inline T * partition_auto(T * first, T * last, Comp comp)
+{
+  if (last - first < kListPartitionMin) return partition_pivot(first, last, comp);
+  static thread_local std::vector<uint32_t> scratch;
+  const size_t need = 2 * static_cast<size_t>(last - first);
+  if (scratch.size() < need) scratch.resize(need);
+  return partition_pivot_lists(first, last, comp, scratch.data());
+}
+
 // the loop of std::sort on [first, last) with `depth` partition levels left; ranges of <= 16 elements stay unsorted
 template <class T, class Comp>
 inline void introsort_loop(T * first, T * last, long depth, Comp comp)
@@ -87,7 +142,7 @@ inline void introsort_loop(T * first, T * last, long depth, Comp comp)
       return;
     }
     --depth;
-    T * cut = partition_pivot(first, last, comp);
+    T * cut = partition_auto(first, last, comp);
     introsort_loop(cut, last, depth, comp);
     last = cut;
   }
@@ -260,7 +315,7 @@ inline void sort_parallel(T * first, T * last, Comp comp, int threads, std::ptrd
           break;
         }
         --p.depth;
-        T * cut = partition_pivot(p.first, p.last, comp);
+        T * cut = partition_auto(p.first, p.last, comp);
         if (p.last - cut > kThreshold) {
           lk.lock();
           queue.push_back({cut, p.last, p.depth});
