@@ -381,6 +381,15 @@ public:
     for (size_t g = 0; g < T_Le_Lt.size(); ++g) toFloat12(T_Le_Lt[g], &Rt12[12 * g]);
     ctx_->check(mh_scan_deskew(scan_, Rt12.data(), T_Le_Lt.size()), "mh_scan_deskew");
   }
+  // the same from n poses laid out as the C ABI takes them, in double: R row-major (9), then t (3) — a caller that forms the
+  // poses as plain arrays anyway (replay.hpp) skips the round trip through Pose3
+  void deskewPoints(const double * Rt12, const size_t n)
+  {
+    if (n != unique_ns_.size()) throw std::runtime_error("deskewPoints: one pose per unique timestamp");
+    std::vector<float> f(12 * n);
+    for (size_t i = 0; i < 12 * n; ++i) f[i] = static_cast<float>(Rt12[i]);
+    ctx_->check(mh_scan_deskew(scan_, f.data(), n), "mh_scan_deskew");
+  }
   // which: 0 points_full_, 1 Be_cloud_, 2 sm_Be_cloud_ds_
   PointCloud download(int which) const
   {

@@ -311,6 +311,11 @@ public:
     }
     ctx_->check(mh_photo_preprocess_scan_begin(photo_, scan.underlying(), T.data(), T_Le_Lt.size()), "mh_photo_preprocess_scan_begin");
   }
+  void preprocessBegin(ScanFrontEnd & scan, const double * Rt12, const size_t n)  // n x {R row-major, t}, as the C ABI takes them
+  {
+    if (!config.enabled) return;
+    ctx_->check(mh_photo_preprocess_scan_begin(photo_, scan.underlying(), Rt12, n), "mh_photo_preprocess_scan_begin");
+  }
   void preprocessCommit(const double ts, const Key key)
   {
     if (!config.enabled) return;

@@ -506,18 +506,20 @@ public:
       const auto a1 = clk::now();
       State pred;
       const std::vector<RT> T_W_Bt = propagate(prev, sc.imu, sc.header_ts, scan_.uniqueNs(), cfg_.gravity, pred);
-      std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
+      // pose of every column in the scan-end frame, laid out as the C ABI takes poses (R row-major, t): the deskew and the
+      // photometric frame read the same 12 doubles a Pose3 would hand back
+      std::vector<double> T_Le_Lt12(12 * T_W_Bt.size());
       {
         const A9 Rt = transpose(pred.T.R);
         for (size_t g = 0; g < T_W_Bt.size(); ++g) {
-          RT d;
-          d.R = matmul(Rt, T_W_Bt[g].R);
-          d.t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
-          T_Le_Lt[g] = toPose3(d);
+          const A9 R = matmul(Rt, T_W_Bt[g].R);
+          const A3 t = matvec(Rt, {T_W_Bt[g].t[0] - pred.T.t[0], T_W_Bt[g].t[1] - pred.T.t[1], T_W_Bt[g].t[2] - pred.T.t[2]});
+          std::memcpy(&T_Le_Lt12[12 * g], R.data(), 72);
+          std::memcpy(&T_Le_Lt12[12 * g + 9], t.data(), 24);
         }
       }
       const auto a2 = clk::now();
-      scan_.deskewPoints(T_Le_Lt);
+      scan_.deskewPoints(T_Le_Lt12.data(), T_W_Bt.size());
       const auto b0 = clk::now();
       res.detail[2] += secs(a2, b0);
       const Key Xk = X(k);
@@ -525,10 +527,14 @@ public:
       // and runs beside the down-sampler and the ICP factor below, while the worker may still be inside updateMap of scan k - 1
       // (it reads the frame and the tracked features of k - 1; building touches neither); it becomes current — and the scan's
       // cloud receives the corrected intensities — at the commit, once that update has returned.
-      if (photo_ && !cfg_.pipeline) photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+      if (photo_ && !cfg_.pipeline) {
+        std::vector<Pose3> T_Le_Lt(T_W_Bt.size());
+        for (size_t g = 0; g < T_W_Bt.size(); ++g) T_Le_Lt[g] = pose3(&T_Le_Lt12[12 * g], &T_Le_Lt12[12 * g + 9]);
+        photo_->preprocess(scan_, T_Le_Lt, sc.header_ts, Xk);
+      }
       if (photo_ && cfg_.pipeline) {
         const auto c0 = clk::now();
-        photo_->preprocessBegin(scan_, T_Le_Lt);
+        photo_->preprocessBegin(scan_, T_Le_Lt12.data(), T_W_Bt.size());
         res.detail[6] += secs(c0, clk::now());
       }
       const auto b0g = clk::now();
