@@ -394,6 +394,33 @@ def test_preprocess_begin_commit_beside_update_map(ctx, frames):
         o.destroy()
 
 
+def test_preprocess_begin_twice_and_left_pending(ctx, frames):
+    """A begun frame that is never committed is dropped by the next begin (the commit then installs the LATER one) and by
+    destroy; the scan's cloud is only written at the commit."""
+    from mimosa_amd import capi
+
+    cfg, fr = frames
+    sc0, T0 = _resident_scan(ctx, cfg, fr[0])
+    sc1, T1 = _resident_scan(ctx, cfg, fr[1])
+    ref1 = capi.Photo(ctx, cfg)
+    sc1r, _ = _resident_scan(ctx, cfg, fr[1])
+    ref1.preprocess_scan(sc1r, T1)
+    p = capi.Photo(ctx, cfg)
+    before = sc1.points(0).tobytes()
+    p.preprocess_scan_begin(sc0, T0)
+    p.preprocess_scan_begin(sc1, T1)                   # drops the frame of scan 0
+    assert sc1.points(0).tobytes() == before            # not written yet
+    p.preprocess_commit()
+    assert sc1.points(0).tobytes() == sc1r.points(0).tobytes()
+    for name in ("range", "mask", "idx", "intensity", "dx", "dy", "yaw", "proj_idx"):
+        assert np.array_equal(p.image(name), ref1.image(name)), name
+    with pytest.raises(capi.MhError):
+        p.preprocess_commit()                           # consumed
+    p.preprocess_scan_begin(sc0, T0)                    # left pending: destroy must cope
+    for o in (p, ref1, sc0, sc1, sc1r):
+        o.destroy()
+
+
 def test_hip_matches_golden_fixture(ctx):
     """The committed fixture (generated by the independent numpy restatement) pins the HIP path as it pins the oracle."""
     from mimosa_amd import capi
