@@ -359,7 +359,8 @@ int mh_scan_prepare_input_prefetched(mh_scan * scan, const mh_input_config * cfg
 /* unique_ns_ (lidar/manager.cpp:344-368), ascending; the caller's IMU propagation needs them on the host. */
 int mh_scan_get_unique_ns(const mh_scan * scan, uint32_t * out, size_t capacity, size_t * n_out);
 /* Manager::deskewPoints' per-point part (lidar/manager.cpp:496-509) on points_full_, in place:
- * Rt12[g] = pose (row-major R, then t, float) of the group with timestamp unique_ns[g]. */
+ * Rt12[g] = pose (row-major R, then t, float) of the group with timestamp unique_ns[g].  Rt12 is read before the call returns;
+ * the kernel itself is only ENQUEUED (every later call on the handle is ordered behind it on the context's stream). */
 int mh_scan_deskew(mh_scan * scan, const float * Rt12, size_t n_groups);
 /* Geometric::preprocess (geometric.cpp:128-183): Be_cloud_ = R_B_L * points_full_[geometric idx] + t_B_L
  * (f32), then Geometric::downsample (geometric.cpp:55-126) into sm_Be_cloud_ds_.  max_points_per_voxel <= 20
