@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "exact_sort.hpp"
 #include "math3.hpp"
 #include "mh_internal.hpp"
@@ -551,7 +553,9 @@ int detect_features_impl(mh_photo * ph, int num_to_detect, const double R_W_Be[9
     }();
     if (sort_threads > 1 && gradients.size() >= 16384) {
       static mh::exact_sort::Pool pool(sort_threads - 1);  // helpers that stay around between frames (joined at exit)
-      mh::exact_sort::sort_parallel(gradients.data(), gradients.data() + gradients.size(), by_gradient, sort_threads, 4096, &pool);
+      static const pid_t pool_owner = getpid();            // threads do not survive fork(): a child sorts with threads of its own
+      mh::exact_sort::sort_parallel(gradients.data(), gradients.data() + gradients.size(), by_gradient, sort_threads, 4096,
+                                    getpid() == pool_owner ? &pool : nullptr);
     } else
       std::sort(gradients.begin(), gradients.end(), by_gradient);
   }

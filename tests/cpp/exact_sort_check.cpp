@@ -52,6 +52,24 @@ int main()
     }
     ++cases;
   }
+  // one partition step, scanning form against list form: same array afterwards, same cut
+  for (int rep = 0; rep < 300; ++rep) {
+    const size_t n = 17 + rng() % (rep % 5 == 0 ? 40000 : 3000);
+    const int distinct = 1 + static_cast<int>(rng() % (rep % 3 == 0 ? 2 : 200));
+    std::vector<uint32_t> v(n);
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t key = rep % 7 == 0 ? static_cast<uint32_t>(i * distinct / n) : static_cast<uint32_t>(rng() % distinct);
+      v[i] = (std::min<uint32_t>(key, 255u) << 24) | static_cast<uint32_t>(i & 0xFFFFFFu);
+    }
+    std::vector<uint32_t> a = v, b = v, idx(2 * n);
+    const auto ca = mh::exact_sort::partition_pivot(a.data(), a.data() + n, by_gradient) - a.data();
+    const auto cb = mh::exact_sort::partition_pivot_lists(b.data(), b.data() + n, by_gradient, idx.data()) - b.data();
+    if (a != b || ca != cb) {
+      std::printf("MISMATCH (partition) rep %d n %zu distinct %d cut %ld vs %ld\n", rep, n, distinct, static_cast<long>(ca), static_cast<long>(cb));
+      return 1;
+    }
+    ++cases;
+  }
   // a full-word comparator (no ties) and a depth-exhausting input for the heap-sort branch: median-of-three killer
   for (int rep = 0; rep < 20; ++rep) {
     const size_t n = 5000 + 997 * rep;

@@ -64,7 +64,7 @@ def test_product_never_imports_the_oracle():
 
 def test_parallel_introsort_is_std_sort(tmp_path):
     """mimosa_amd/csrc/exact_sort.hpp (detectFeatures' candidate sort on several host threads) leaves every sequence exactly
-    as this toolchain's std::sort does, tie order included (tests/cpp/exact_sort_check.cpp: 420 sequences)."""
+    as this toolchain's std::sort does, tie order included (tests/cpp/exact_sort_check.cpp: 420 sequences + 300 single partition steps, scanning form against list form)."""
     import subprocess
     exe = str(tmp_path / "exact_sort_check")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-pthread",
