@@ -116,9 +116,12 @@ def run_local_world(world, case=None, block_log2=3, uneven=False, components_off
     for t in threads:
         t.join(timeout=600)
     alive = [t.is_alive() for t in threads]
-    for r, e in enumerate(errors):
-        if e is not None:
-            raise AssertionError(f"rank {r}: {type(e).__name__}: {e}") from e
+    # the rank that failed FIRST is the one to report: the others only notice that it never reached the next collective
+    order = sorted((r for r, e in enumerate(errors) if e is not None), key=lambda r: "did not reach the collective" in str(errors[r]))
+    if order:
+        r = order[0]
+        others = "; ".join(f"rank {q}: {type(errors[q]).__name__}: {str(errors[q])[:200]}" for q in order[1:])
+        raise AssertionError(f"rank {r}: {type(errors[r]).__name__}: {errors[r]}" + (f"  [then {others}]" if others else "")) from errors[r]
     assert not any(alive), f"ranks still running (a collective was not entered by all): {alive}"
     for c in comms:
         c.destroy()
