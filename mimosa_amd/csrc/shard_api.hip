@@ -109,19 +109,29 @@ struct LocalGroup
   std::vector<const char *> send_ptr;
   std::vector<std::vector<double>> ar_host;
   bool broken = false;  // a rank gave up waiting: every later barrier fails at once instead of hanging the others
+  std::vector<char> here;  // who stands at the current barrier
+  std::string missing;     // set by the rank that gave up: the ranks it was waiting for
   // false: a peer did not arrive within the time limit (it failed, or a collective was not entered by all ranks)
-  bool barrier()
+  bool barrier(int rank)
   {
     std::unique_lock<std::mutex> lk(mu);
     if (broken) return false;
+    if (here.size() != static_cast<size_t>(world)) here.assign(static_cast<size_t>(world), 0);
     const unsigned long long g = gen;
+    here[static_cast<size_t>(rank)] = 1;
     if (++arrived == world) {
       arrived = 0;
       ++gen;
+      std::fill(here.begin(), here.end(), 0);
       cv.notify_all();
       return true;
     }
     if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || broken; }) || broken) {
+      if (!broken) {
+        missing.clear();
+        for (int r = 0; r < world; ++r)
+          if (!here[static_cast<size_t>(r)]) missing += (missing.empty() ? "" : ", ") + std::to_string(r);
+      }
       broken = true;
       cv.notify_all();
       return false;
@@ -144,6 +154,10 @@ struct mh_shard_comm
   int peer_missing()
   {
     err = "in-process group: a rank did not reach the collective within 120 s";
+    {
+      std::lock_guard<std::mutex> g(grp->mu);
+      if (!grp->missing.empty()) err += " (rank " + std::to_string(rank) + " waited; missing: " + grp->missing + ")";
+    }
     g_mh_err = err;
     return MH_ERR_HIP;
   }
@@ -163,13 +177,13 @@ struct mh_shard_comm
     }
     if (hipStreamSynchronize(stream) != hipSuccess) return MH_ERR_HIP;
     grp->send_ptr[rank] = static_cast<const char *>(send);
-    if (!grp->barrier()) return peer_missing();
+    if (!grp->barrier(rank)) return peer_missing();
     hipError_t e = hipSuccess;
     for (int p = 0; p < world && e == hipSuccess; ++p)
       e = hipMemcpyAsync(static_cast<char *>(recv) + static_cast<size_t>(p) * bytes, grp->send_ptr[p] + static_cast<size_t>(rank) * bytes, bytes,
                          hipMemcpyDeviceToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (!grp->barrier()) return peer_missing();  // nobody refills a send buffer a peer is still reading
+    if (!grp->barrier(rank)) return peer_missing();  // nobody refills a send buffer a peer is still reading
     return e == hipSuccess ? MH_OK : MH_ERR_HIP;
   }
   int all_reduce(double * buf, size_t n, hipStream_t stream)
@@ -183,11 +197,11 @@ struct mh_shard_comm
     mine.resize(n);
     if (hipMemcpyAsync(mine.data(), buf, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) return MH_ERR_HIP;
     if (hipStreamSynchronize(stream) != hipSuccess) return MH_ERR_HIP;
-    if (!grp->barrier()) return peer_missing();
+    if (!grp->barrier(rank)) return peer_missing();
     std::vector<double> sum(n, 0.0);
     for (int p = 0; p < world; ++p)  // rank order on every rank: identical bits everywhere
       for (size_t i = 0; i < n; ++i) sum[i] += grp->ar_host[p][i];
-    if (!grp->barrier()) return peer_missing();
+    if (!grp->barrier(rank)) return peer_missing();
     if (hipMemcpyAsync(buf, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) return MH_ERR_HIP;
     return hipStreamSynchronize(stream) == hipSuccess ? MH_OK : MH_ERR_HIP;
   }
