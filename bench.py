@@ -905,6 +905,14 @@ def main():
                        "mean_candidates": round(float(hres["mean_candidates"]), 2), "mean_scanned_after_pruning": round(float(hres["mean_scanned"]), 2),
                        "exact_fallback_queries": int(hres["n_exact_fallback"]), "status_hist": [int(v) for v in hres["status_hist"]],
                        "world_build_s": round(hbuild, 1)}
+            try:
+                _h = np.asarray(sh.make_query_scan(0.37, n_rows=args.rows)[0])
+                _h = np.stack([_h["x"], _h["y"], _h["z"]], 1).astype(np.float64) if _h.dtype.names else np.asarray(_h, np.float64)[:, :3]
+                hq = _h @ np.asarray(hs_p[0][0], np.float64).T + np.asarray(hs_p[0][1], np.float64)
+                hostile["candidates_per_query"] = {k_: round(v_, 3) if isinstance(v_, float) else v_
+                                                   for k_, v_ in sh.candidate_stats(hmap.get_cloud(), hq, cfgd["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE).items()}
+            except Exception as e:  # noqa: BLE001
+                hostile["candidates_per_query"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu_baseline:
                 from oracle import ref_cpu
                 hrm = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
@@ -923,6 +931,17 @@ def main():
         except Exception as exc:  # noqa: BLE001 - reported in the line
             hostile = {"error": f"{type(exc).__name__}: {exc}"}
 
+    cand_stats = None
+    if rank == 0 and not args.profile_mode:
+        try:  # what the reference's k-NN scans per query on this world: the tail sets K3's slowest wave
+            from mimosa_amd import synth_hostile as _sh
+            _p = np.asarray(pts)
+            _p = np.stack([_p["x"], _p["y"], _p["z"]], 1).astype(np.float64) if _p.dtype.names else np.asarray(_p, np.float64)[:, :3]
+            qw = _p @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
+            cand_stats = {k_: round(v_, 3) if isinstance(v_, float) else v_
+                          for k_, v_ in _sh.candidate_stats(gmap.get_cloud(), qw, cfgd["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE).items()}
+        except Exception as e:  # noqa: BLE001 — a statistic, never the reason for a missing line
+            cand_stats = {"error": f"{type(e).__name__}: {e}"}
     line = {
         "metric": "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU",
         "value": round(value, 3),
@@ -949,6 +968,7 @@ def main():
                            "world (map points on a 0.16 m jittered grid: 5 neighbours often fall on one grid row); real scans will shift the valid fraction",
             "exact_fallback_queries": int(last["n_exact_fallback"]),
             "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2),
+            "candidates_per_query": cand_stats,
         },
         "roofline": {
             "bound": "hbm",

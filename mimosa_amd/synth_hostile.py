@@ -168,6 +168,35 @@ def make_query_scan(s: float = 0.37, rx: int = 0, ry: int = 0, seed: int = synth
     return pts, {"R_W_L": R, "t_W_L": t}
 
 
+def candidate_stats(map_xyz: np.ndarray, q_world: np.ndarray, leaf: float = 0.5, mode: int = 19) -> dict:
+    """What the reference's k-NN scans per query: map points (and 16-byte quads of four) in the occupied voxels of the
+    1 / 7 / 19 / 27-neighbourhood of the query's voxel (gtsam_points' offsets).  Percentiles over the queries — the tail
+    is what sets the dominant kernel's slowest wave."""
+    def key(v):
+        return (v[:, 0] + (1 << 20)) | ((v[:, 1] + (1 << 20)) << 21) | ((v[:, 2] + (1 << 20)) << 42)
+    def xyz(a):  # plain (n, >= 3) arrays and the library's point records alike
+        a = np.asarray(a)
+        return np.stack([a["x"], a["y"], a["z"]], 1).astype(np.float64) if a.dtype.names else np.asarray(a, np.float64)[:, :3]
+    map_xyz, q_world = xyz(map_xyz), xyz(q_world)
+    mv = np.floor(np.asarray(map_xyz, np.float64) / leaf).astype(np.int64)
+    keys, counts = np.unique(key(mv), return_counts=True)
+    qv = np.floor(np.asarray(q_world, np.float64) / leaf).astype(np.int64)
+    offs = [(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)
+            if abs(i) + abs(j) + abs(k) <= {1: 0, 7: 1, 19: 2, 27: 3}[mode]]
+    cand = np.zeros(len(qv), np.int64)
+    quads = np.zeros(len(qv), np.int64)
+    for o in offs:
+        kq = key(qv + np.array(o, np.int64))
+        at = np.minimum(np.searchsorted(keys, kq), len(keys) - 1)
+        c = np.where(keys[at] == kq, counts[at], 0)
+        cand += c
+        quads += (c + 3) // 4
+    pc = lambda x, q: float(np.percentile(x, q))
+    return dict(mean=float(cand.mean()), p50=pc(cand, 50), p90=pc(cand, 90), p99=pc(cand, 99), max=int(cand.max()),
+                quads_p50=pc(quads, 50), quads_p90=pc(quads, 90), quads_p99=pc(quads, 99), quads_max=int(quads.max()),
+                empty_centre_voxel_share=float((np.where(keys[np.minimum(np.searchsorted(keys, key(qv)), len(keys) - 1)] == key(qv), 1, 0) == 0).mean()))
+
+
 def voxel_fill_stats(map_xyz: np.ndarray, leaf: float = 0.5, cap: int = 20) -> dict:
     """How full the map's voxels are (from mh_map_get_cloud): points per occupied voxel and the share at the cap."""
     v = np.floor(np.asarray(map_xyz, np.float64) / leaf).astype(np.int64)
