@@ -111,31 +111,18 @@ public:
         if (!v.empty()) {
           // prefer a block nobody can still be using, or one whose last use was ordered on THIS stream: taking another
           // stream's block makes this stream wait (on the device) for that stream to get there
-          // ... so, failing that, one whose last user has already got past the free (the event has completed); only when
-          // every cached block of the class is still in flight on another stream is a fresh one taken from the runtime
-          // (each stream ends up with a working set of its own; a cross-stream wait stalled a 50 us call for 0.4 ms)
-          size_t pick = v.size();
+          size_t pick = v.size() - 1;
           for (size_t i = v.size(); i-- > 0;)
             if (!v[i].ev || v[i].stream == g_mh_stream) {
               pick = i;
               break;
             }
-          if (pick == v.size())
-            for (size_t i = v.size(); i-- > 0;)
-              if (hipEventQuery(v[i].ev) == hipSuccess) {
-                pick = i;
-                event_pool().push_back(v[i].ev);
-                v[i].ev = nullptr;
-                break;
-              }
-          if (pick != v.size()) {
-            c = v[pick];
-            v[pick] = v.back();
-            v.pop_back();
-            cached_bytes()[dev] -= cls;
-            live()[c.p] = Block{cls, dev};
-            hit = true;
-          }
+          c = v[pick];
+          v[pick] = v.back();
+          v.pop_back();
+          cached_bytes()[dev] -= cls;
+          live()[c.p] = Block{cls, dev};
+          hit = true;
         }
       }
       if (hit) {
