@@ -617,7 +617,27 @@ int mh_shard_icp_create(mh_ctx * ctx, mh_shard_comm * comm, mh_map * shard_map, 
  * localizabilities, degeneracy info; 4-DoF / degeneracy projection applied once, on the global sums).  Collective; blocks. */
 int mh_shard_icp_linearize(mh_shard_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                            const double * t_tgt, const double g_unit[3], mh_icp_result * out);
-int mh_shard_icp_reset(mh_shard_icp * icp);                       /* as mh_icp_reset; points stay where they are */
+/* Throughput forms.  The reference's second caller re-linearizes EVERY live ICPFactor per smoother update
+ * (src/graph/manager.cpp:585-588); the unsharded path answers that with mh_icp_linearize_async / _batch, these are the
+ * sharded counterparts.  A protocol ROUND carries any number of factors of one communicator and context: their movers
+ * interleaved per peer in ONE ncclAllToAll, one route / append / K3b (/ K4b) / publish launch each, ONE ncclAllReduce of
+ * n_factors x 168 doubles (+ one of n_factors x 16 when a factor's components are on).  _async / _batch_async only enqueue
+ * (up to 32 rounds in flight per communicator; a further one first completes the oldest); mh_shard_icp_wait completes
+ * every round in flight on the factor's communicator, in order, and fills their results — `out` must stay valid until
+ * then.  All of them are collective: every rank issues the same sequence of calls.  A call whose movers did not fit the
+ * per-peer segments is repeated (larger segments, same pose) at the next wait, or when its round leaves the ring — and
+ * the calls of that factor enqueued behind it are repeated behind its repeat, so results and association cache end as
+ * if the calls had run one after the other (the k-NN counters of repeated calls are statistics: a point may be counted
+ * by the attempt and by the repeat).
+ * Arrays are n_factors long: R_src[9 n], t_src[3 n], R_tgt / t_tgt (NULL without binary factors), g_unit[3 n], out[n]. */
+int mh_shard_icp_linearize_async(mh_shard_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
+                                 const double * t_tgt, const double g_unit[3], mh_icp_result * out);
+int mh_shard_icp_linearize_batch(mh_shard_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+                                 const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out); /* blocks */
+int mh_shard_icp_linearize_batch_async(mh_shard_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
+                                       const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out);
+int mh_shard_icp_wait(mh_shard_icp * icp);
+int mh_shard_icp_reset(mh_shard_icp * icp);                       /* as mh_icp_reset; points stay where they are; stream-ordered */
 int mh_shard_icp_set_components(mh_shard_icp * icp, int enabled); /* as mh_icp_set_components; must agree on all ranks */
 /* Per-point state of the points this rank holds now (origin = first rank << 32 | index there); n_out alone may be asked for. */
 int mh_shard_icp_get_state(mh_shard_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals,

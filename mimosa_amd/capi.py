@@ -30,7 +30,8 @@ EXPORTS = [
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
     "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
-    "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
+    "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
+    "mh_shard_icp_linearize_batch_async", "mh_shard_icp_wait", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
     "mh_shard_icp_stats", "mh_shard_icp_destroy",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
@@ -396,6 +397,10 @@ def load(build_if_missing: bool = True):
     L.mh_shard_comm_backend.restype = C.c_char_p
     L.mh_shard_icp_create.argtypes = [vp, vp, vp, vp, sz, i32, C.POINTER(RegConfig), i32, C.POINTER(ShardConfig), pvp]
     L.mh_shard_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_shard_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
+    L.mh_shard_icp_linearize_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
+    L.mh_shard_icp_linearize_batch_async.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
+    L.mh_shard_icp_wait.argtypes = [vp]
     L.mh_shard_icp_reset.argtypes = [vp]
     L.mh_shard_icp_set_components.argtypes = [vp, C.c_int]
     L.mh_shard_icp_get_state.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
@@ -851,6 +856,22 @@ class ShardedICPFactor:
         self.ctx.check(self.L.mh_shard_icp_linearize(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
         return out.as_dict()
 
+    def linearize_async(self, R, t, g_unit=(0.0, 0.0, -1.0), R_tgt=None, t_tgt=None) -> IcpResult:
+        """mh_shard_icp_linearize_async: enqueue only; the returned IcpResult is filled by wait() (collective, like linearize)."""
+        out = IcpResult()
+        R, t, g = _f64(R), _f64(t), _f64(g_unit)
+        Rt = _f64(R_tgt) if R_tgt is not None else None
+        tt = _f64(t_tgt) if t_tgt is not None else None
+        self.ctx.check(self.L.mh_shard_icp_linearize_async(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append(out)  # the library writes into it at wait()
+        return out
+
+    def wait(self):
+        """mh_shard_icp_wait: completes every round in flight on this factor's communicator."""
+        self.ctx.check(self.L.mh_shard_icp_wait(self.h))
+        self._pending = []
+
     def reset(self):
         self.ctx.check(self.L.mh_shard_icp_reset(self.h))
 
@@ -885,6 +906,41 @@ class ShardedICPFactor:
             self.destroy()
         except Exception:
             pass
+
+
+class _ShardBatchArgs:
+    """Marshalled arguments of a sharded batch call (kept alive until the results are in)."""
+
+    def __init__(self, factors, Rs, ts, g_units, R_tgts, t_tgts):
+        n = len(factors)
+        self.n = n
+        self.R = np.ascontiguousarray(np.asarray(Rs, np.float64).reshape(n, 9))
+        self.t = np.ascontiguousarray(np.asarray(ts, np.float64).reshape(n, 3))
+        self.g = np.ascontiguousarray(np.tile(np.array([0.0, 0.0, -1.0]), (n, 1)) if g_units is None else np.asarray(g_units, np.float64).reshape(n, 3))
+        self.Rt = None if R_tgts is None else np.ascontiguousarray(np.asarray(R_tgts, np.float64).reshape(n, 9))
+        self.tt = None if t_tgts is None else np.ascontiguousarray(np.asarray(t_tgts, np.float64).reshape(n, 3))
+        self.handles = (C.c_void_p * n)(*[f.h for f in factors])
+        self.out = (IcpResult * n)()
+
+    def args(self):
+        return (self.handles, self.n, _p(self.R), _p(self.t), _p(self.Rt), _p(self.tt), _p(self.g), self.out)
+
+    def results(self) -> list:
+        return [self.out[i].as_dict() for i in range(self.n)]
+
+
+def sharded_linearize_batch(factors, Rs, ts, g_units=None, R_tgts=None, t_tgts=None) -> list:
+    """mh_shard_icp_linearize_batch: the sharded factors of `factors` (one communicator) in ONE protocol round; blocks; collective."""
+    a = _ShardBatchArgs(factors, Rs, ts, g_units, R_tgts, t_tgts)
+    factors[0].ctx.check(factors[0].L.mh_shard_icp_linearize_batch(*a.args()))
+    return a.results()
+
+
+def sharded_linearize_batch_async(factors, Rs, ts, g_units=None, R_tgts=None, t_tgts=None) -> _ShardBatchArgs:
+    """mh_shard_icp_linearize_batch_async: enqueue one round; `.results()` of the returned object is valid after factors[0].wait()."""
+    a = _ShardBatchArgs(factors, Rs, ts, g_units, R_tgts, t_tgts)
+    factors[0].ctx.check(factors[0].L.mh_shard_icp_linearize_batch_async(*a.args()))
+    return a
 
 
 def map_insert_shard(ctx: Context, vmap: VoxelMap, xyz, world: int, rank: int, block_log2: int = 3):

@@ -109,9 +109,10 @@ struct BatchInline
   int n;
   char pad[256];  // load_uniform reads whole 256-byte chunks: keep the last block's read inside the segment
 };
+// shard: every factor of the launch is a map-sharded factor's (IcpArgs::n_dev / LocArgs::n_dev set) — the SHARD instantiation.
 hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int tpb, int k, int n_off, bool binary,
-                                         hipStream_t stream);
-hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream);
+                                         hipStream_t stream, bool shard = false);
+hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream, bool shard = false);
 hipError_t launch_map_knn(const MapView & map, const double * q, int n, int k, double * pts, double * sq,
                           int32_t * found, hipStream_t stream);
 

@@ -1126,7 +1126,10 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 // would occupy a fifth of the CUs with two waves per SIMD; at 256 every wave has a SIMD to itself.
 // block_id / n_blocks: this workgroup's index within ITS factor's (multiple-of-8) grid: the launch grid for the
 // single-factor kernel, the factor's segment of the launch grid for the batched one.
-template <int K, bool BINARY, int NOFF, int TPB>
+// SHARD: the launch of a map-sharded factor (shard_api.hip) — the slot count is read from the device, slots whose status
+// carries kShardSkip are passed over, the last block also writes its sums into the all-reduce vector.  The plain factor's
+// instantiation carries none of it (round 3 had it in the one kernel: +1 us on every unsharded launch).
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
@@ -1184,7 +1187,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   for (int j = 0; j < NV; ++j) row[j] = 0.0;
 
   const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
-  const int n_pts = a.n_dev ? static_cast<int>(*a.n_dev) : a.n;
+  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
   if (qi < n_pts) {
     const float4 sp = a.src[qi];
     const double px = sp.x, py = sp.y, pz = sp.z;
@@ -1203,7 +1206,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       qd2 = a.q_da[3 * qi + 2];
       st = a.status[qi];
     }
-    const bool gone = (st & kShardSkip) != 0;  // map-sharded factors only: another rank's point in this call
+    const bool gone = SHARD && (st & kShardSkip) != 0;  // map-sharded factors only: another rank's point in this call
     const double ddx = q0 - qd0, ddy = q1 - qd1, ddz = q2 - qd2;
     const bool update = !gone && sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
 
@@ -1469,7 +1472,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
   if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
   if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
-  if (a.shard_out && threadIdx.x < NENT + 4) a.shard_out[threadIdx.x] = s_sum[threadIdx.x];  // what the shards all-reduce
+  if constexpr (SHARD) {
+    if (a.shard_out && threadIdx.x < NENT + 4) a.shard_out[threadIdx.x] = s_sum[threadIdx.x];  // what the shards all-reduce
+  }
   // computeLocalizability of the rot / trans 3 x 3 blocks (:405-411) is NOT done here: two eigen-decompositions on one lane
   // each cost 2.3 us of this serial tail while 255 CUs idle.  K4's workgroups derive the eigenbases they need from
   // result->sums themselves (behind their per-point loads), the host epilogue derives the ones it reports (finish_result).
@@ -1484,10 +1489,10 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   MH_STAMP(a.dbg, 7);
 }
 
-template <int K, bool BINARY, int NOFF, int TPB>
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
 {
-  icp_linearize_body<K, BINARY, NOFF, TPB>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 
 // A kernel-argument block read from memory into SGPRs: lane i of the wave loads dword i (one or two coalesced
@@ -1535,12 +1540,12 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_kernel(const IcpArgs 
   const int f = batch_factor_of(start, n_factors, b);
   const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
   const IcpArgs a = load_uniform(args + f);
-  icp_linearize_body<K, BINARY, NOFF, TPB>(a, b - s0, s1 - s0);
+  icp_linearize_body<K, BINARY, NOFF, TPB, false>(a, b - s0, s1 - s0);
 }
 
 // The same with the argument blocks inside the kernel-argument segment.  They are read through the segment pointer:
 // indexing the by-value parameter itself with a runtime index makes the compiler copy the whole struct to scratch.
-template <int K, bool BINARY, int NOFF, int TPB>
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const BatchInline<IcpArgs> blk)
 {
   (void)blk;
@@ -1549,7 +1554,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
   const int f = batch_factor_of(p->start, p->n, b);
   const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
   const IcpArgs a = load_uniform(p->a + f);
-  icp_linearize_body<K, BINARY, NOFF, TPB>(a, b - s0, s1 - s0);
+  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD>(a, b - s0, s1 - s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1558,7 +1563,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
 // normal instead of storing two more per-point vectors.  6 sums by wave shuffles, 9 counts by
 // ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
 // ------------------------------------------------------------------------------------------------
-template <int TPB>
+template <int TPB, bool SHARD>
 __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NW = TPB / 64;
@@ -1571,7 +1576,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // The first chunk's status, point and normal are requested first: one memory round trip, in flight while the
   // eigenbases below are worked out (the pass is a handful of round trips long, nothing else).
-  const int n_pts = a.n_dev ? static_cast<int>(*a.n_dev) : a.n;
+  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
   const int i_first = block_id * a.chunks_per_block * TPB + static_cast<int>(threadIdx.x);
   const int i_ld = i_first < n_pts ? i_first : 0;
   int st_next = n_pts > 0 ? a.status[i_ld] : -1;
@@ -1585,7 +1590,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     if (threadIdx.x < 18) s_E[threadIdx.x] = a.eig[threadIdx.x];
   } else if (threadIdx.x == 0 || threadIdx.x == 64) {
     const int NV = a.nv, o = threadIdx.x ? 3 : 0;
-    const double * sums = a.sums ? a.sums : a.result->sums;
+    const double * sums = (SHARD && a.sums) ? a.sums : a.result->sums;
     double Hb[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
@@ -1671,7 +1676,9 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
-  if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
+  if constexpr (SHARD) {
+    if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
+  }
   // the eigenbases THIS pass projected on are what the caller is told (the host's own decomposition of the same sums may
   // pick another basis of a clustered eigenspace: no FMA there, other branches of sym_eigen3)
   if (threadIdx.x >= 32 && threadIdx.x < 50) {
@@ -1696,10 +1703,10 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   }
 }
 
-template <int TPB>
+template <int TPB, bool SHARD>
 __global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a)
 {
-  icp_localizability_body<TPB>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  icp_localizability_body<TPB, SHARD>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 template <int TPB>
 __global__ __launch_bounds__(TPB) void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
@@ -1708,10 +1715,10 @@ __global__ __launch_bounds__(TPB) void icp_localizability_batch_kernel(const Loc
   const int f = batch_factor_of(start, n_factors, b);
   const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
   const LocArgs a = load_uniform(args + f);
-  icp_localizability_body<TPB>(a, b - s0, s1 - s0);
+  icp_localizability_body<TPB, false>(a, b - s0, s1 - s0);
 }
 
-template <int TPB>
+template <int TPB, bool SHARD>
 __global__ __launch_bounds__(TPB) void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
 {
   (void)blk;
@@ -1720,7 +1727,7 @@ __global__ __launch_bounds__(TPB) void icp_localizability_batch_inline_kernel(co
   const int f = batch_factor_of(p->start, p->n, b);
   const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
   const LocArgs a = load_uniform(p->a + f);
-  icp_localizability_body<TPB>(a, b - s0, s1 - s0);
+  icp_localizability_body<TPB, SHARD>(a, b - s0, s1 - s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1789,29 +1796,37 @@ int linearize_grid(int n)
 constexpr int kLocChunksPerBlock = 1;  // measured: 1 vs 4 chunks per workgroup makes no difference (launch + round-trip bound)
 int localizability_grid(int n) { return (linearize_grid(n) + kLocChunksPerBlock - 1) / kLocChunksPerBlock; }
 
-template <int NOFF, int TPB>
+template <int NOFF, int TPB, bool SHARD>
 static void launch_linearize_nt(const IcpArgs & a, bool binary, hipStream_t stream)
 {
   const dim3 grid(linearize_grid(a.n)), block(TPB);
   if (a.k == 5) {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF, TPB>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF, TPB>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
   } else {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF, TPB>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF, TPB>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
   }
 }
 template <int NOFF>
 static void launch_linearize_n(const IcpArgs & a, bool binary, hipStream_t stream)
 {
-  if (linearize_tpb(a.n) == 256)
-    launch_linearize_nt<NOFF, 256>(a, binary, stream);
-  else
-    launch_linearize_nt<NOFF, kThreads>(a, binary, stream);
+  const bool shard = a.n_dev != nullptr;  // a map-sharded factor's launch (shard_api.hip): the SHARD instantiation
+  if (linearize_tpb(a.n) == 256) {
+    if (shard)
+      launch_linearize_nt<NOFF, 256, true>(a, binary, stream);
+    else
+      launch_linearize_nt<NOFF, 256, false>(a, binary, stream);
+  } else {
+    if (shard)
+      launch_linearize_nt<NOFF, kThreads, true>(a, binary, stream);
+    else
+      launch_linearize_nt<NOFF, kThreads, false>(a, binary, stream);
+  }
 }
 
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -1829,10 +1844,19 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
   a.chunks_per_block = kLocChunksPerBlock;
-  if (linearize_tpb(a.n) == 256)
-    hipLaunchKernelGGL(icp_localizability_kernel<256>, dim3(localizability_grid(a.n)), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL(icp_localizability_kernel<kThreads>, dim3(localizability_grid(a.n)), dim3(kThreads), 0, stream, a);
+  const dim3 grid(localizability_grid(a.n));
+  const bool shard = a.n_dev != nullptr;
+  if (linearize_tpb(a.n) == 256) {
+    if (shard)
+      hipLaunchKernelGGL((icp_localizability_kernel<256, true>), grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_localizability_kernel<256, false>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (shard)
+      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, true>), grid, dim3(kThreads), 0, stream, a);
+    else
+      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, false>), grid, dim3(kThreads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
@@ -1889,32 +1913,40 @@ hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_sta
   return hipGetLastError();
 }
 
-template <int NOFF, int TPB>
+// The inline form also serves the map-sharded factors' batch (shard_api.hip): shard = every argument block carries n_dev.
+template <int NOFF, int TPB, bool SHARD>
 static void launch_linearize_batch_inline_nt(const BatchInline<IcpArgs> & blk, int total_grid, int k, bool binary, hipStream_t stream)
 {
   const dim3 grid(total_grid), block(TPB);
   if (k == 5) {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, true, NOFF, TPB>), grid, block, 0, stream, blk);
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, true, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
     else
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, false, NOFF, TPB>), grid, block, 0, stream, blk);
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, false, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
   } else {
     if (binary)
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, true, NOFF, TPB>), grid, block, 0, stream, blk);
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, true, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
     else
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, false, NOFF, TPB>), grid, block, 0, stream, blk);
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, false, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
   }
 }
 
 hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int tpb, int k, int n_off, bool binary,
-                                         hipStream_t stream)
+                                         hipStream_t stream, bool shard)
 {
-#define MH_BATCH_TPB(NOFF)                                                                       \
-  do {                                                                                           \
-    if (tpb == 256)                                                                              \
-      launch_linearize_batch_inline_nt<NOFF, 256>(blk, total_grid, k, binary, stream);           \
-    else                                                                                         \
-      launch_linearize_batch_inline_nt<NOFF, kThreads>(blk, total_grid, k, binary, stream);      \
+#define MH_BATCH_TPB(NOFF)                                                                                  \
+  do {                                                                                                      \
+    if (tpb == 256) {                                                                                       \
+      if (shard)                                                                                            \
+        launch_linearize_batch_inline_nt<NOFF, 256, true>(blk, total_grid, k, binary, stream);              \
+      else                                                                                                  \
+        launch_linearize_batch_inline_nt<NOFF, 256, false>(blk, total_grid, k, binary, stream);             \
+    } else {                                                                                                \
+      if (shard)                                                                                            \
+        launch_linearize_batch_inline_nt<NOFF, kThreads, true>(blk, total_grid, k, binary, stream);         \
+      else                                                                                                  \
+        launch_linearize_batch_inline_nt<NOFF, kThreads, false>(blk, total_grid, k, binary, stream);        \
+    }                                                                                                       \
   } while (0)
   if (n_off <= 7)
     MH_BATCH_TPB(7);
@@ -1926,12 +1958,20 @@ hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int t
   return hipGetLastError();
 }
 
-hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream)
+hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream, bool shard)
 {
-  if (tpb == 256)
-    hipLaunchKernelGGL(icp_localizability_batch_inline_kernel<256>, dim3(total_grid), dim3(256), 0, stream, blk);
-  else
-    hipLaunchKernelGGL(icp_localizability_batch_inline_kernel<kThreads>, dim3(total_grid), dim3(kThreads), 0, stream, blk);
+  const dim3 grid(total_grid);
+  if (tpb == 256) {
+    if (shard)
+      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<256, true>), grid, dim3(256), 0, stream, blk);
+    else
+      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<256, false>), grid, dim3(256), 0, stream, blk);
+  } else {
+    if (shard)
+      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<kThreads, true>), grid, dim3(kThreads), 0, stream, blk);
+    else
+      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<kThreads, false>), grid, dim3(kThreads), 0, stream, blk);
+  }
   return hipGetLastError();
 }
 

@@ -94,8 +94,8 @@ MH_HD void sym_eigen3_jacobi(const double A[9], double w[3], double V[9])
 
 // The same decomposition without iterating, for the serial tail of K3 (one lane decomposes H_rr, another H_tt, while every
 // other wave of the machine has finished: the Jacobi sweeps above are ~12 rotations of dependent fp64 division / square-root
-// sequences, 3.5 us of a 38 us kernel).  Eigenvalues by the trigonometric form of the characteristic cubic on the scaled,
-// shifted matrix; the eigenvector of the best-separated eigenvalue from the largest cross product of two rows of A - w I, the
+// sequences, 3.5 us of a 38 us kernel).  Eigenvalues from the characteristic cubic of the scaled, shifted matrix (its
+// trigonometric form, evaluated by a six-step Newton iteration instead of acos / cos); the eigenvector of the best-separated eigenvalue from the largest cross product of two rows of A - w I, the
 // second from the 2 x 2 problem in its orthogonal complement, the third as their cross product (the construction of Eberly,
 // "A robust eigensolver for 3 x 3 symmetric matrices"); one Rayleigh-quotient step per eigenvalue afterwards.  The result is
 // VERIFIED — |A v - w v| against 1e-13 |A|, eigenvalue order — and anything that does not pass (clustered eigenvalues) goes
@@ -119,9 +119,24 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
       const double d00 = c00 * ip, d01 = b01 * ip, d02 = b02 * ip, d11 = c11 * ip, d12 = b12 * ip, d22 = c22 * ip;
       double half_det = 0.5 * (d00 * (d11 * d22 - d12 * d12) - d01 * (d01 * d22 - d12 * d02) + d02 * (d01 * d12 - d11 * d02));
       half_det = fmin(fmax(half_det, -1.0), 1.0);
-      const double angle = acos(half_det) / 3.0;
-      const double two_thirds_pi = 2.09439510239319549;
-      const double beta2 = 2.0 * cos(angle), beta0 = 2.0 * cos(angle + two_thirds_pi), beta1 = -(beta0 + beta2);
+      // The eigenvalues of the scaled, shifted matrix are the roots of g(x) = x^3 - 3 x - 2 half_det, i.e. 2 cos(theta / 3 +
+      // 2 pi k / 3) with cos(theta) = half_det.  An acos and two cos are ~250 dependent fp64 instructions EACH on the device
+      // (this runs on one lane, with a grid waiting: 2.5 us in round 3).  Instead: Newton on g for the root that stands
+      // alone — the largest (in [sqrt 3, 2]) when half_det >= 0, started at 2, the smallest (in [-2, -sqrt 3]) otherwise,
+      // started at -2: g is convex (concave) and monotone there, the iterates approach the root from outside without
+      // overshoot, g' >= 6, the root is simple for every half_det, and the error goes 0.27 -> 5e-2 -> 2e-3 -> 2e-6 -> 2e-12
+      // -> round-off: six steps.  The other two from the deflated quadratic x^2 + r x + (r^2 - 3).  (Accuracy does not rest
+      // on this: Rayleigh step + residual check below, Jacobi sweeps as the fallback.)
+      const double dd = 2.0 * half_det;
+      double br = half_det >= 0.0 ? 2.0 : -2.0;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const double b2 = br * br;
+        br -= ((b2 - 3.0) * br - dd) / (3.0 * b2 - 3.0);
+      }
+      const double sq = sqrt(fmax(12.0 - 3.0 * br * br, 0.0));
+      const double blo = 0.5 * (-br - sq), bhi = 0.5 * (-br + sq);
+      const double beta0 = half_det >= 0.0 ? blo : br, beta1 = half_det >= 0.0 ? bhi : blo, beta2 = half_det >= 0.0 ? br : bhi;
       e0 = q + p * beta0;
       e1 = q + p * beta1;
       e2 = q + p * beta2;

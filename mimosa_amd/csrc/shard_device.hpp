@@ -70,15 +70,57 @@ struct ShardPublish
 };
 __host__ __device__ inline size_t shard_segment_bytes(uint32_t cap) { return sizeof(ShardHdr) + static_cast<size_t>(cap) * 112; }
 
+// One factor of a protocol round, as the route / append kernels see it.  A round of several factors (the live factors of the
+// smoother window, src/graph/manager.cpp:585-588) shares ONE send and ONE receive buffer: peer p's block holds the factors'
+// segments one after the other, so `send` / `recv` point at this factor's segment inside peer 0's block and `peer_stride`
+// is the size of a whole peer block (= shard_segment_bytes(cap) for a round of one).
+struct ShardFactorArgs
+{
+  ShardPose P;
+  ShardArrays a;
+  ShardState * st;
+  double inv_leaf;
+  uint8_t * dest;     // per slot: destination rank, 0xFF = stays
+  uint32_t * hist;    // per 256-slot block and destination: movers
+  char * send;
+  const char * recv;
+  size_t peer_stride;
+  double * ar_slots;  // this factor's per-rank slots of the all-reduce vector (kShardSums ...)
+  uint32_t cap, slot_capacity;
+  int cur, log2;
+};
+constexpr int kShardBatchMax = 8;  // factors per batched launch (the argument blocks travel in the kernel-argument segment)
+struct ShardBatch
+{
+  ShardFactorArgs f[kShardBatchMax];
+  int route_start[kShardBatchMax + 1];   // exclusive prefix of the factors' route grids (256 slots per workgroup, >= 1 each)
+  int append_start[kShardBatchMax + 1];  // ... and of their append grids (world * cap threads)
+  int n;
+  uint32_t world, rank;
+};
+struct ShardPublishBatch
+{
+  const ShardState * st[kShardBatchMax];
+  int next[kShardBatchMax];
+  ShardPublish * host;  // n consecutive entries of the round's publish slot
+  const double * ar;    // n x kShardArLen
+  const double * loc;   // n x 16, or null
+  uint32_t seq;
+  int n;
+};
+
 hipError_t launch_shard_state_init(ShardState * st, uint32_t n, hipStream_t stream);
 // owner of every live slot at this pose -> dest[] (0xFF: stays / tombstone), per-block per-destination counts; then the
 // movers' records into the per-peer segments in slot order (stable), tombstones behind them; the last block writes the
 // segment headers, the state's sent / max counters and this rank's slot of the all-reduce vector
-hipError_t launch_shard_route(const ShardPose & P, const ShardArrays & a, ShardState * st, int cur, uint32_t n_bound, double inv_leaf, uint32_t world,
-                              uint32_t rank, int log2, uint8_t * dest, uint32_t * hist, uint32_t cap, char * send, double * ar_slots, hipStream_t stream);
+hipError_t launch_shard_route(const ShardFactorArgs & f, uint32_t n_bound, uint32_t world, uint32_t rank, hipStream_t stream);
 // arrivals of all peers appended behind the last slot, in (peer, record) order; writes the next ping-pong entries
-hipError_t launch_shard_append(const ShardArrays & a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv, uint32_t slot_capacity,
-                               hipStream_t stream);
+hipError_t launch_shard_append(const ShardFactorArgs & f, uint32_t world, hipStream_t stream);
+// the same for up to kShardBatchMax factors per launch; shard_batch_grids fills the two prefix tables from the slot bounds
+void shard_batch_grids(ShardBatch & b, const uint32_t * n_bound);
+hipError_t launch_shard_route_batch(const ShardBatch & b, hipStream_t stream);
+hipError_t launch_shard_append_batch(const ShardBatch & b, hipStream_t stream);
+hipError_t launch_shard_publish_batch(const ShardPublishBatch & b, hipStream_t stream);
 // stable compaction of the live slots into `out` (tombstones dropped); both ping-pong entries become n_live
 hipError_t launch_shard_compact(const ShardArrays & in, const ShardArrays & out, ShardState * st, int cur, uint32_t n_bound, uint32_t * flags, uint32_t * pos,
                                 void * temp, size_t temp_bytes, hipStream_t stream);

@@ -177,57 +177,62 @@ __global__ void shard_state_init_kernel(ShardState * st, uint32_t n)
   }
 }
 
+// ---- one factor of a protocol round (shard_device.hpp: ShardFactorArgs); the single-factor kernels and the batched ones
+// (all factors of a window in ONE launch each: route count, route pack, append, publish) run the same bodies --------------
 // Pass 1 of the routing: destination of every live slot (0xFF: stays, tombstone or past the end) and the block's count
 // per destination.  A slot that could not be sent in the previous call (segment overflow) loses its skip flag here and is
-// looked at afresh.
-__global__ __launch_bounds__(kT) void shard_route_count_kernel(const ShardPose P, const ShardArrays a, const ShardState * st, int cur, double inv_leaf,
-                                                                uint32_t world, uint32_t rank, int log2, uint8_t * dest, uint32_t * hist)
+// looked at afresh.  blk = this workgroup's index within the factor's grid.
+__device__ __forceinline__ void route_count_body(const ShardFactorArgs & f, const uint32_t world, const uint32_t rank, const uint32_t blk)
 {
   __shared__ uint32_t s_h[kShardMaxWorld];
   if (threadIdx.x < kShardMaxWorld) s_h[threadIdx.x] = 0u;
   __syncthreads();
-  const uint32_t n = st->n_slots[cur];
-  const uint32_t i = blockIdx.x * kT + threadIdx.x;
+  const ShardArrays & a = f.a;
+  const uint32_t n = f.st->n_slots[f.cur];
+  const uint32_t i = blk * kT + threadIdx.x;
   uint32_t d = 0xFFu;
   if (i < n && a.origin[i] != kShardTomb) {
     const int32_t s = a.status[i];
     if (s & kShardSkip) a.status[i] = s & ~kShardSkip;
     const float4 sp = a.src[i];
     const double px = sp.x, py = sp.y, pz = sp.z;
-    const double q0 = (P.R[0] * px + (P.R[1] * py + P.R[2] * pz)) + P.t[0];
-    const double q1 = (P.R[3] * px + (P.R[4] * py + P.R[5] * pz)) + P.t[1];
-    const double q2 = (P.R[6] * px + (P.R[7] * py + P.R[8] * pz)) + P.t[2];
-    const uint32_t o = owner_of_block(fast_floor(q0 * inv_leaf) >> log2, fast_floor(q1 * inv_leaf) >> log2, fast_floor(q2 * inv_leaf) >> log2, world);
+    const double q0 = (f.P.R[0] * px + (f.P.R[1] * py + f.P.R[2] * pz)) + f.P.t[0];
+    const double q1 = (f.P.R[3] * px + (f.P.R[4] * py + f.P.R[5] * pz)) + f.P.t[1];
+    const double q2 = (f.P.R[6] * px + (f.P.R[7] * py + f.P.R[8] * pz)) + f.P.t[2];
+    const uint32_t o = owner_of_block(fast_floor(q0 * f.inv_leaf) >> f.log2, fast_floor(q1 * f.inv_leaf) >> f.log2, fast_floor(q2 * f.inv_leaf) >> f.log2, world);
     if (o != rank) {
       d = o;
       atomicAdd(&s_h[o], 1u);
     }
   }
-  dest[i] = static_cast<uint8_t>(d);
+  f.dest[i] = static_cast<uint8_t>(d);
   __syncthreads();
-  if (threadIdx.x < world) hist[static_cast<size_t>(blockIdx.x) * world + threadIdx.x] = s_h[threadIdx.x];
+  if (threadIdx.x < world) f.hist[static_cast<size_t>(blk) * world + threadIdx.x] = s_h[threadIdx.x];
 }
 
 // Pass 2: position of every mover inside its destination's segment = movers of earlier blocks + earlier movers of this
-// block (slot order: stable, so the arrival order — and with it every sum — is reproducible run to run).
-__global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardArrays a, ShardState * st, uint32_t world, uint32_t rank, const uint8_t * dest,
-                                                               const uint32_t * hist, uint32_t cap, char * send, double * ar_slots)
+// block (slot order: stable, so the arrival order — and with it every sum — is reproducible run to run).  The segment of
+// destination d starts at send + d * peer_stride (a round of several factors interleaves their segments per peer).
+__device__ __forceinline__ void route_pack_body(const ShardFactorArgs & f, const uint32_t world, const uint32_t rank, const uint32_t blk, const uint32_t nblk)
 {
   constexpr int NW = kT / 64;
   __shared__ uint32_t s_base[kShardMaxWorld];
   __shared__ uint32_t s_wc[NW][kShardMaxWorld];
+  __shared__ uint32_t s_tot[kShardMaxWorld];
+  const ShardArrays & a = f.a;
+  const uint32_t cap = f.cap;
   if (threadIdx.x < kShardMaxWorld) {
     s_base[threadIdx.x] = 0u;
     for (int w = 0; w < NW; ++w) s_wc[w][threadIdx.x] = 0u;
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kT)
+  for (uint32_t b = threadIdx.x; b < blk; b += kT)
     for (uint32_t d = 0; d < world; ++d) {
-      const uint32_t c = hist[static_cast<size_t>(b) * world + d];
+      const uint32_t c = f.hist[static_cast<size_t>(b) * world + d];
       if (c) atomicAdd(&s_base[d], c);
     }
-  const uint32_t i = blockIdx.x * kT + threadIdx.x;
-  const uint32_t d = dest[i];
+  const uint32_t i = blk * kT + threadIdx.x;
+  const uint32_t d = f.dest[i];
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   uint32_t my_rank = 0u;
   {
@@ -256,16 +261,15 @@ __global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardArrays 
       r.status = a.status[i];
       r.pad = 0;
       r.origin = a.origin[i];
-      *reinterpret_cast<ShardRecord *>(send + static_cast<size_t>(d) * shard_segment_bytes(cap) + sizeof(ShardHdr) + static_cast<size_t>(pos) * sizeof(ShardRecord)) = r;
+      *reinterpret_cast<ShardRecord *>(f.send + static_cast<size_t>(d) * f.peer_stride + sizeof(ShardHdr) + static_cast<size_t>(pos) * sizeof(ShardRecord)) = r;
       a.origin[i] = kShardTomb;
       a.status[i] = -1;  // carries kShardSkip
     } else {
       a.status[i] |= kShardSkip;  // the segment is full: stays here unprocessed, the caller repeats the call with larger segments
     }
   }
-  if (blockIdx.x == gridDim.x - 1) {
+  if (blk == nblk - 1) {
     __syncthreads();
-    __shared__ uint32_t s_tot[kShardMaxWorld];
     if (threadIdx.x < kShardMaxWorld) {
       uint32_t t = 0u;
       if (threadIdx.x < world) {
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardArrays 
         h.sent = t < cap ? t : cap;
         h.total = t;
         h.pad0 = h.pad1 = 0u;
-        *reinterpret_cast<ShardHdr *>(send + static_cast<size_t>(threadIdx.x) * shard_segment_bytes(cap)) = h;
+        *reinterpret_cast<ShardHdr *>(f.send + static_cast<size_t>(threadIdx.x) * f.peer_stride) = h;
       }
       s_tot[threadIdx.x] = t;
     }
@@ -286,31 +290,32 @@ __global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardArrays 
         sent += s_tot[r] < cap ? s_tot[r] : cap;
         mx = s_tot[r] > mx ? s_tot[r] : mx;
       }
-      st->sent_total = sent;
-      st->max_total = mx;
+      f.st->sent_total = sent;
+      f.st->max_total = mx;
     }
     if (threadIdx.x < kShardMaxWorld) {
       uint32_t mx = 0u;
       for (uint32_t r = 0; r < world; ++r) mx = s_tot[r] > mx ? s_tot[r] : mx;
-      ar_slots[threadIdx.x] = threadIdx.x == rank ? static_cast<double>(mx) : 0.0;
+      f.ar_slots[threadIdx.x] = threadIdx.x == rank ? static_cast<double>(mx) : 0.0;
     }
   }
 }
 
-__global__ __launch_bounds__(kT) void shard_append_kernel(const ShardArrays a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv,
-                                                           uint32_t slot_capacity)
+// Arrivals of all peers appended behind the last slot in (peer, record) order; thread t of the factor's append grid takes
+// record t % cap of peer t / cap; thread 0 writes the next ping-pong entries of the slot / live counters.
+__device__ __forceinline__ void append_body(const ShardFactorArgs & f, const uint32_t world, const uint32_t t)
 {
-  const size_t seg = shard_segment_bytes(cap);
-  const uint32_t t = blockIdx.x * kT + threadIdx.x;
+  const ShardArrays & a = f.a;
+  const uint32_t cap = f.cap;
   const uint32_t peer = t / cap, j = t - peer * cap;
-  const uint32_t n0 = st->n_slots[cur];
+  const uint32_t n0 = f.st->n_slots[f.cur];
   if (peer < world) {
     uint32_t before = 0u;
-    for (uint32_t p = 0; p < peer; ++p) before += reinterpret_cast<const ShardHdr *>(recv + p * seg)->sent;
-    const uint32_t cnt = reinterpret_cast<const ShardHdr *>(recv + peer * seg)->sent;
+    for (uint32_t p = 0; p < peer; ++p) before += reinterpret_cast<const ShardHdr *>(f.recv + p * f.peer_stride)->sent;
+    const uint32_t cnt = reinterpret_cast<const ShardHdr *>(f.recv + peer * f.peer_stride)->sent;
     const size_t d = static_cast<size_t>(n0) + before + j;
-    if (j < cnt && d < slot_capacity) {
-      const ShardRecord r = *reinterpret_cast<const ShardRecord *>(recv + peer * seg + sizeof(ShardHdr) + static_cast<size_t>(j) * sizeof(ShardRecord));
+    if (j < cnt && d < f.slot_capacity) {
+      const ShardRecord r = *reinterpret_cast<const ShardRecord *>(f.recv + peer * f.peer_stride + sizeof(ShardHdr) + static_cast<size_t>(j) * sizeof(ShardRecord));
       a.src[d] = r.src;
       for (int k = 0; k < 3; ++k) {
         a.q_da[3 * d + k] = r.q_da[k];
@@ -323,13 +328,60 @@ __global__ __launch_bounds__(kT) void shard_append_kernel(const ShardArrays a, S
   }
   if (t == 0) {
     uint32_t total = 0u;
-    for (uint32_t p = 0; p < world; ++p) total += reinterpret_cast<const ShardHdr *>(recv + p * seg)->sent;
-    const uint32_t room = slot_capacity - n0;
+    for (uint32_t p = 0; p < world; ++p) total += reinterpret_cast<const ShardHdr *>(f.recv + p * f.peer_stride)->sent;
+    const uint32_t room = f.slot_capacity - n0;
     const uint32_t taken = total < room ? total : room;
-    if (taken < total) st->error |= 1u;
-    st->n_slots[cur ^ 1] = n0 + taken;
-    st->n_live[cur ^ 1] = st->n_live[cur] - st->sent_total + taken;
+    if (taken < total) f.st->error |= 1u;
+    f.st->n_slots[f.cur ^ 1] = n0 + taken;
+    f.st->n_live[f.cur ^ 1] = f.st->n_live[f.cur] - f.st->sent_total + taken;
   }
+}
+
+__global__ __launch_bounds__(kT) void shard_route_count_kernel(const ShardFactorArgs f, uint32_t world, uint32_t rank)
+{
+  route_count_body(f, world, rank, blockIdx.x);
+}
+__global__ __launch_bounds__(kT) void shard_route_pack_kernel(const ShardFactorArgs f, uint32_t world, uint32_t rank)
+{
+  route_pack_body(f, world, rank, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(kT) void shard_append_kernel(const ShardFactorArgs f, uint32_t world)
+{
+  append_body(f, world, blockIdx.x * kT + threadIdx.x);
+}
+
+// The batched forms: the argument blocks of up to kShardBatchMax factors ride in the kernel-argument segment (read through
+// the segment pointer with a wave-uniform index: scalar loads; indexing the by-value parameter would copy it to scratch);
+// a workgroup finds its factor in the prefix table of the per-factor grids.
+__device__ __forceinline__ int shard_batch_factor_of(const int * start, int n, int b)
+{
+  int f = 0;
+  for (int i = 1; i < n; ++i) f += (b >= start[i]) ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(f);
+}
+__global__ __launch_bounds__(kT) void shard_route_count_batch_kernel(const ShardBatch blk)
+{
+  (void)blk;
+  const auto * p = (const ShardBatch *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = shard_batch_factor_of(p->route_start, p->n, b);
+  route_count_body(p->f[f], p->world, p->rank, static_cast<uint32_t>(b - p->route_start[f]));
+}
+__global__ __launch_bounds__(kT) void shard_route_pack_batch_kernel(const ShardBatch blk)
+{
+  (void)blk;
+  const auto * p = (const ShardBatch *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = shard_batch_factor_of(p->route_start, p->n, b);
+  route_pack_body(p->f[f], p->world, p->rank, static_cast<uint32_t>(b - p->route_start[f]), static_cast<uint32_t>(p->route_start[f + 1] - p->route_start[f]));
+}
+__global__ __launch_bounds__(kT) void shard_append_batch_kernel(const ShardBatch blk)
+{
+  (void)blk;
+  const auto * p = (const ShardBatch *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = static_cast<int>(blockIdx.x);
+  const int f = shard_batch_factor_of(p->append_start, p->n, b);
+  append_body(p->f[f], p->world, static_cast<uint32_t>(b - p->append_start[f]) * kT + threadIdx.x);
 }
 
 __global__ __launch_bounds__(kT) void shard_live_flags_kernel(const ShardArrays a, const ShardState * st, int cur, uint32_t n_bound, uint32_t * flags)
@@ -370,7 +422,9 @@ __global__ __launch_bounds__(kT) void shard_reset_kernel(const ShardArrays a, co
   }
 }
 
-__global__ void shard_publish_kernel(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq)
+// One workgroup per factor of the round: the factor's slice of the all-reduced vectors, its counters, then ITS completion
+// flag (the host waits for every factor's flag of the round).
+__device__ __forceinline__ void publish_body(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq)
 {
   const int t = threadIdx.x;
   if (t < kShardArLen) host->ar[t] = ar[t];
@@ -385,6 +439,17 @@ __global__ void shard_publish_kernel(const double * ar, const double * loc, cons
   __syncthreads();
   if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void shard_publish_kernel(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq)
+{
+  publish_body(ar, loc, st, next, host, seq);
+}
+__global__ void shard_publish_batch_kernel(const ShardPublishBatch blk)
+{
+  (void)blk;
+  const auto * p = (const ShardPublishBatch *)__builtin_amdgcn_kernarg_segment_ptr();
+  const int f = static_cast<int>(blockIdx.x);
+  publish_body(p->ar + static_cast<size_t>(f) * kShardArLen, p->loc ? p->loc + static_cast<size_t>(f) * 16 : nullptr, p->st[f], p->next[f], p->host + f, p->seq);
+}
 }  // namespace
 
 hipError_t launch_shard_state_init(ShardState * st, uint32_t n, hipStream_t stream)
@@ -392,19 +457,41 @@ hipError_t launch_shard_state_init(ShardState * st, uint32_t n, hipStream_t stre
   hipLaunchKernelGGL(shard_state_init_kernel, dim3(1), dim3(64), 0, stream, st, n);
   return hipGetLastError();
 }
-hipError_t launch_shard_route(const ShardPose & P, const ShardArrays & a, ShardState * st, int cur, uint32_t n_bound, double inv_leaf, uint32_t world,
-                              uint32_t rank, int log2, uint8_t * dest, uint32_t * hist, uint32_t cap, char * send, double * ar_slots, hipStream_t stream)
+static uint32_t route_blocks(uint32_t n_bound) { return n_bound ? (n_bound + kT - 1) / kT : 1u; }  // at least one block: the headers must be written
+hipError_t launch_shard_route(const ShardFactorArgs & f, uint32_t n_bound, uint32_t world, uint32_t rank, hipStream_t stream)
 {
-  const uint32_t nblk = n_bound ? (n_bound + kT - 1) / kT : 1u;  // at least one block: the headers must be written
-  hipLaunchKernelGGL(shard_route_count_kernel, dim3(nblk), dim3(kT), 0, stream, P, a, st, cur, inv_leaf, world, rank, log2, dest, hist);
-  hipLaunchKernelGGL(shard_route_pack_kernel, dim3(nblk), dim3(kT), 0, stream, a, st, world, rank, dest, hist, cap, send, ar_slots);
+  const uint32_t nblk = route_blocks(n_bound);
+  hipLaunchKernelGGL(shard_route_count_kernel, dim3(nblk), dim3(kT), 0, stream, f, world, rank);
+  hipLaunchKernelGGL(shard_route_pack_kernel, dim3(nblk), dim3(kT), 0, stream, f, world, rank);
   return hipGetLastError();
 }
-hipError_t launch_shard_append(const ShardArrays & a, ShardState * st, int cur, uint32_t world, uint32_t cap, const char * recv, uint32_t slot_capacity,
-                               hipStream_t stream)
+hipError_t launch_shard_append(const ShardFactorArgs & f, uint32_t world, hipStream_t stream)
 {
-  const uint32_t threads = world * cap;
-  hipLaunchKernelGGL(shard_append_kernel, dim3((threads + kT - 1) / kT), dim3(kT), 0, stream, a, st, cur, world, cap, recv, slot_capacity);
+  const uint32_t threads = world * f.cap;
+  hipLaunchKernelGGL(shard_append_kernel, dim3((threads + kT - 1) / kT), dim3(kT), 0, stream, f, world);
+  return hipGetLastError();
+}
+void shard_batch_grids(ShardBatch & b, const uint32_t * n_bound)
+{
+  int r = 0, a = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.route_start[i] = r;
+    b.append_start[i] = a;
+    r += static_cast<int>(route_blocks(n_bound[i]));
+    a += static_cast<int>((b.world * b.f[i].cap + kT - 1) / kT);
+  }
+  b.route_start[b.n] = r;
+  b.append_start[b.n] = a;
+}
+hipError_t launch_shard_route_batch(const ShardBatch & b, hipStream_t stream)
+{
+  hipLaunchKernelGGL(shard_route_count_batch_kernel, dim3(b.route_start[b.n]), dim3(kT), 0, stream, b);
+  hipLaunchKernelGGL(shard_route_pack_batch_kernel, dim3(b.route_start[b.n]), dim3(kT), 0, stream, b);
+  return hipGetLastError();
+}
+hipError_t launch_shard_append_batch(const ShardBatch & b, hipStream_t stream)
+{
+  hipLaunchKernelGGL(shard_append_batch_kernel, dim3(b.append_start[b.n]), dim3(kT), 0, stream, b);
   return hipGetLastError();
 }
 hipError_t launch_shard_compact(const ShardArrays & in, const ShardArrays & out, ShardState * st, int cur, uint32_t n_bound, uint32_t * flags, uint32_t * pos,
@@ -426,6 +513,11 @@ hipError_t launch_shard_reset(const ShardArrays & a, const ShardState * st, int 
 hipError_t launch_shard_publish(const double * ar, const double * loc, const ShardState * st, int next, ShardPublish * host, uint32_t seq, hipStream_t stream)
 {
   hipLaunchKernelGGL(shard_publish_kernel, dim3(1), dim3(192), 0, stream, ar, loc, st, next, host, seq);
+  return hipGetLastError();
+}
+hipError_t launch_shard_publish_batch(const ShardPublishBatch & b, hipStream_t stream)
+{
+  hipLaunchKernelGGL(shard_publish_batch_kernel, dim3(b.n), dim3(192), 0, stream, b);
   return hipGetLastError();
 }
 

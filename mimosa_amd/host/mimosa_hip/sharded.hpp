@@ -229,6 +229,59 @@ public:
     impl_->last = r;
     return hessianFrom(keys(), is_binary_, r);
   }
+  // The throughput forms (graph::Manager re-linearizes every live factor per update, src/graph/manager.cpp:585-588).
+  // linearizeAsync only enqueues the factor's protocol round; wait() completes every round in flight on the communicator and
+  // returns this factor's last enqueued result.  Collective like linearize(); keep one call in flight per factor where the
+  // order of data-association cache updates matters (include/mimosa_hip.h).
+  void linearizeAsync(const Values & c) const
+  {
+    const PoseRM Ts = rowMajor(c.at<Pose3>(keys()[0]));
+    PoseRM Tt{};
+    if (is_binary_) Tt = rowMajor(c.at<Pose3>(keys()[1]));
+    const A3 g = toArray(c.at<Unit3>(G(0)).unitVector());
+    ctx().check(mh_shard_icp_linearize_async(impl_->icp, Ts.R.data(), Ts.t.data(), is_binary_ ? Tt.R.data() : nullptr, is_binary_ ? Tt.t.data() : nullptr, g.data(),
+                                             &impl_->last),
+                "mh_shard_icp_linearize_async");
+  }
+  std::shared_ptr<GaussianFactor> wait() const
+  {
+    ctx().check(mh_shard_icp_wait(impl_->icp), "mh_shard_icp_wait");
+    return hessianFrom(keys(), is_binary_, impl_->last);
+  }
+  // All factors of the window (one communicator) in ONE protocol round: one all-to-all carrying every factor's movers, one
+  // K3b / K4b launch pair per kernel instantiation, one all-reduce of n x 168 doubles.  Unary and binary factors may be mixed.
+  static std::vector<std::shared_ptr<GaussianFactor>> linearizeBatch(const std::vector<Ptr> & factors, const Values & c)
+  {
+    std::vector<std::shared_ptr<GaussianFactor>> out;
+    if (factors.empty()) return out;
+    const size_t n = factors.size();
+    bool any_binary = false;
+    for (const Ptr & f : factors) any_binary = any_binary || f->is_binary_;
+    std::vector<mh_shard_icp *> h(n);
+    std::vector<double> Rs(9 * n), ts(3 * n), Rt(any_binary ? 9 * n : 0), tt(any_binary ? 3 * n : 0), g(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+      const ShardedICPFactor & f = *factors[i];
+      h[i] = f.impl_->icp;
+      const PoseRM Ts = rowMajor(c.at<Pose3>(f.keys()[0]));
+      std::memcpy(&Rs[9 * i], Ts.R.data(), 72);
+      std::memcpy(&ts[3 * i], Ts.t.data(), 24);
+      if (f.is_binary_) {
+        const PoseRM Tt = rowMajor(c.at<Pose3>(f.keys()[1]));
+        std::memcpy(&Rt[9 * i], Tt.R.data(), 72);
+        std::memcpy(&tt[3 * i], Tt.t.data(), 24);
+      }
+      const A3 gu = toArray(c.at<Unit3>(G(0)).unitVector());
+      std::memcpy(&g[3 * i], gu.data(), 24);
+    }
+    std::vector<mh_icp_result> r(n);
+    factors[0]->ctx().check(mh_shard_icp_linearize_batch(h.data(), n, Rs.data(), ts.data(), any_binary ? Rt.data() : nullptr, any_binary ? tt.data() : nullptr, g.data(), r.data()),
+                            "mh_shard_icp_linearize_batch");
+    for (size_t i = 0; i < n; ++i) {
+      factors[i]->impl_->last = r[i];
+      out.push_back(hessianFrom(factors[i]->keys(), factors[i]->is_binary_, r[i]));
+    }
+    return out;
+  }
   void getLocalizabilities(V3D & trans_comp, V3D & rot_comp, V3D & trans_final, V3D & rot_final, M33 & eigenvectors_trans, M33 & eigenvectors_rot)
   {
     const mh_icp_result & l = impl_->last;

@@ -82,6 +82,16 @@ int main(int argc, char ** argv)
       want[k] = flat(*ref.linearize(v));
       for (int i = 0; i < 9; ++i) want_hist[k][i] = ref.lastResult().status_hist[i];
     }
+    // the throughput forms, in the order the ranks run them below: a window batch of the factor and a SECOND, fresh factor
+    // (key X(2)) at the last pose, then one enqueued call of the first factor collected by wait()
+    const Key X2 = X(2);
+    Values v_last;
+    v_last.insert(G(0), Unit3(0.0, 0.0, -1.0));
+    v_last.insert(X1, pose3(&poses12[12 * (n_poses - 1)], &poses12[12 * (n_poses - 1) + 9]));
+    v_last.insert(X2, pose3(&poses12[12 * (n_poses - 1)], &poses12[12 * (n_poses - 1) + 9]));
+    ICPFactor ref2(X2, full, scan, cfg.scan_to_map);
+    const Flat want_b1 = flat(*ref.linearize(v_last)), want_b2 = flat(*ref2.linearize(v_last)), want_async = flat(*ref.linearize(v_last));
+    std::vector<Flat> got_b1(world), got_b2(world), got_async(world);
     // the sharded factor: `world` ranks
     std::vector<std::shared_ptr<Context>> ctxs;
     for (int r = 0; r < world; ++r) ctxs.push_back(r == 0 ? ctx0 : std::make_shared<Context>(0));
@@ -109,6 +119,13 @@ int main(int argc, char ** argv)
           hist_ok[r][k] = !std::memcmp(fac.lastResult().status_hist, want_hist[k].data(), 9 * sizeof(int));
         }
         stats[r] = fac.stats();
+        auto fac_p = std::static_pointer_cast<ShardedICPFactor>(fac.clone());  // shares the device state with `fac`
+        auto fac2 = std::make_shared<ShardedICPFactor>(X2, shard, share, cfg.scan_to_map, mode == "rccl" || world == 1);
+        const auto both = ShardedICPFactor::linearizeBatch({fac_p, fac2}, v_last);
+        got_b1[r] = flat(*both[0]);
+        got_b2[r] = flat(*both[1]);
+        fac.linearizeAsync(v_last);
+        got_async[r] = flat(*fac.wait());
       } catch (const std::exception & e) {
         errors[r] = e.what();
       }
@@ -132,7 +149,21 @@ int main(int argc, char ** argv)
         hist_all &= hist_ok[r][k];
         ranks_equal &= !std::memcmp(&got[r][k], &got[0][k], sizeof(Flat));  // every rank holds the SAME global result, bit for bit
       }
-    std::printf("{\"mode\": \"%s\", \"world\": %d, \"backend\": \"%s\", \"n_poses\": %zu, \"worst_rel\": %.3g, \"hist_equal\": %d, \"ranks_equal\": %d,\n", mode.c_str(),
+    auto rel_of = [](const Flat & a, const Flat & b) {
+      double num = 0, den = 0;
+      for (int i = 0; i < 36; ++i) {
+        num += (a.H[i] - b.H[i]) * (a.H[i] - b.H[i]);
+        den += b.H[i] * b.H[i];
+      }
+      return std::max(std::sqrt(num / den), std::fabs(a.f - b.f) / std::fabs(b.f));
+    };
+    double worst_batch = 0, worst_async = 0;
+    for (int r = 0; r < world; ++r) {
+      worst_batch = std::max(worst_batch, std::max(rel_of(got_b1[r], want_b1), rel_of(got_b2[r], want_b2)));
+      worst_async = std::max(worst_async, rel_of(got_async[r], want_async));
+    }
+    std::printf("{\"batch_worst_rel\": %.3g, \"async_worst_rel\": %.3g, ", worst_batch, worst_async);
+    std::printf("\"mode\": \"%s\", \"world\": %d, \"backend\": \"%s\", \"n_poses\": %zu, \"worst_rel\": %.3g, \"hist_equal\": %d, \"ranks_equal\": %d,\n", mode.c_str(),
                 world, comms[0]->backend().c_str(), n_poses, worst, hist_all, ranks_equal);
     std::printf("\"collective\": %d, \"collectives_last\": %u, \"points_held\": [", stats[0].collective, stats[0].collectives_last);
     for (int r = 0; r < world; ++r) std::printf("%llu%s", static_cast<unsigned long long>(stats[r].n_live), r + 1 < world ? ", " : "");

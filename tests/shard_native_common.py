@@ -48,8 +48,10 @@ def oracle_results(case):
     return out, M.num_points
 
 
-def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components_off_from=None, log=None, check_eigvec=True):
-    """One rank of the native path over the whole pose sequence."""
+def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components_off_from=None, log=None, check_eigvec=True, mode="sync", sync_first=0, check_counters=True):
+    """One rank of the native path over the whole pose sequence.  mode: "sync" mh_shard_icp_linearize; "async" one
+    mh_shard_icp_linearize_async + mh_shard_icp_wait per pose; "pipelined" every pose (after the first `sync_first`) enqueued
+    before the one wait — the results must still be the sequential ones (one stream: the calls run in order)."""
     from mimosa_amd import capi, synth
     from parity import assert_result_parity, assert_state_parity
     rank, world = comm.rank, comm.world
@@ -62,10 +64,34 @@ def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components
     f = capi.ShardedICPFactor(ctx, comm, vmap, case["scan"][split[rank]], capi.make_reg_config(**cfg), binary=case["binary"], block_log2=block_log2,
                               force_collectives=force)
     moved = []
+    tkw = dict(R_tgt=case["tgt"][0], t_tgt=case["tgt"][1]) if case["binary"] else {}
+    if mode == "pipelined":
+        assert components_off_from is None
+        for k in range(sync_first):
+            assert_result_parity(f.linearize(*case["poses"][k], **tkw), refs[k][0], binary=case["binary"], check_eigvec=check_eigvec)
+        outs = [f.linearize_async(Rk, tk, **tkw) for Rk, tk in case["poses"][sync_first:]]
+        f.wait()
+        for k, o in enumerate(outs):
+            assert_result_parity(o.as_dict(), refs[sync_first + k][0], binary=case["binary"], check_eigvec=check_eigvec, check_counters=check_counters)
+        origin, s, mean, nrm = f.state()
+        glob = np.array([split[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin], np.int64)
+        _, rs, rm, rn = refs[-1]
+        if len(glob):
+            assert_state_parity((s, mean, nrm), (rs[glob], rm[glob], rn[glob]))
+        stats, final = vmap.stats(), f.stats()
+        assert final["n_live"] == len(origin)
+        f.destroy()
+        vmap.release()
+        return dict(moved=[final["last_max_movers"]], map_points=stats["n_points"], stats=final)
     for k, (Rk, tk) in enumerate(case["poses"]):
         if components_off_from is not None and k == components_off_from:
             f.set_components(False)
-        got = f.linearize(Rk, tk, R_tgt=case["tgt"][0], t_tgt=case["tgt"][1]) if case["binary"] else f.linearize(Rk, tk)
+        if mode == "async":
+            o = f.linearize_async(Rk, tk, **tkw)
+            f.wait()
+            got = o.as_dict()
+        else:
+            got = f.linearize(Rk, tk, **tkw)
         ref = refs[k][0]
         if components_off_from is not None and k >= components_off_from:
             assert np.all(np.isnan(got["loc_trans_comp"])) and np.all(got["status_hist"] == -1)
@@ -88,7 +114,121 @@ def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components
     return dict(moved=moved, map_points=stats["n_points"], stats=final)
 
 
-def run_local_world(world, case=None, block_log2=3, uneven=False, components_off_from=None, check_eigvec=True):
+def run_rank_batch(comm, ctx, cases, refs, splits, block_log2=3, force=False, components_off=(), check_eigvec=True, pipelined=False):
+    """One rank of a WINDOW of sharded factors (cases[i]: its own scan and pose sequence, all against cases[0]'s map): per
+    pose index one mh_shard_icp_linearize_batch over all factors (pipelined: every round enqueued, one wait); every factor's
+    global result and the state of the points this rank holds must equal that factor's unsharded oracle."""
+    from mimosa_amd import capi, synth
+    from parity import assert_result_parity, assert_state_parity
+    rank, world = comm.rank, comm.world
+    cfg = cases[0]["cfg"]
+    kw = dict(leaf=cfg["target_ivox_map_leaf_size"], min_dist=cfg["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+              mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    vmap = capi.VoxelMap(ctx, **kw)
+    for c in cases[0]["map_chunks"]:
+        capi.map_insert_shard(ctx, vmap, c, world, rank, block_log2)
+    fs = [capi.ShardedICPFactor(ctx, comm, vmap, c["scan"][sp[rank]], capi.make_reg_config(**c["cfg"]), binary=c["binary"], block_log2=block_log2, force_collectives=force)
+          for c, sp in zip(cases, splits)]
+    for i in components_off:
+        fs[i].set_components(False)
+    binary = any(c["binary"] for c in cases)
+    n_poses = len(cases[0]["poses"])
+
+    def args_of(k):
+        Rs = [c["poses"][k][0] for c in cases]
+        ts = [c["poses"][k][1] for c in cases]
+        kw2 = {}
+        if binary:
+            kw2 = dict(R_tgts=[c["tgt"][0] if c["binary"] else np.eye(3) for c in cases], t_tgts=[c["tgt"][1] if c["binary"] else np.zeros(3) for c in cases])
+        return Rs, ts, kw2
+
+    def check(k, gots):
+        for i, got in enumerate(gots):
+            ref = refs[i][k][0]
+            if i in components_off:
+                assert np.all(np.isnan(got["loc_trans_comp"])) and np.all(got["status_hist"] == -1)
+                got = dict(got, loc_trans_comp=ref["loc_trans_comp"], loc_rot_comp=ref["loc_rot_comp"], status_hist=np.asarray(ref["status_hist"]))
+            assert_result_parity(got, ref, binary=cases[i]["binary"], check_eigvec=check_eigvec)
+
+    def check_state(k):
+        for i, f in enumerate(fs):
+            origin, s, mean, nrm = f.state()
+            sp = splits[i]
+            glob = np.array([sp[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin], np.int64)
+            _, rs, rm, rn = refs[i][k]
+            if len(glob):
+                assert_state_parity((s, mean, nrm), (rs[glob], rm[glob], rn[glob]))
+
+    if pipelined:
+        pend = []
+        for k in range(n_poses):
+            Rs, ts, kw2 = args_of(k)
+            pend.append(capi.sharded_linearize_batch_async(fs, Rs, ts, **kw2))
+        fs[0].wait()
+        for k, a in enumerate(pend):
+            check(k, a.results())
+        check_state(n_poses - 1)
+    else:
+        for k in range(n_poses):
+            Rs, ts, kw2 = args_of(k)
+            check(k, capi.sharded_linearize_batch(fs, Rs, ts, **kw2))
+            check_state(k)
+    final = [f.stats() for f in fs]
+    for f in fs:
+        f.destroy()
+    vmap.release()
+    return dict(stats=final)
+
+
+def _run_threads(world, body_of_rank):
+    """`world` rank bodies as threads; the rank that failed FIRST is the one reported."""
+    results, errors = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            results[r] = body_of_rank(r)
+        except BaseException as e:  # noqa: BLE001 — reported by the main thread
+            errors[r] = e
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    alive = [t.is_alive() for t in threads]
+    order = sorted((r for r, e in enumerate(errors) if e is not None), key=lambda r: "did not reach the collective" in str(errors[r]))
+    if order:
+        r = order[0]
+        others = "; ".join(f"rank {q}: {type(errors[q]).__name__}: {str(errors[q])[:200]}" for q in order[1:])
+        raise AssertionError(f"rank {r}: {type(errors[r]).__name__}: {errors[r]}" + (f"  [then {others}]" if others else "")) from errors[r]
+    assert not any(alive), f"ranks still running (a collective was not entered by all): {alive}"
+    return results
+
+
+def run_local_world_batch(world, cases, block_log2=3, components_off=(), check_eigvec=True, pipelined=False, uneven=True):
+    """A window of sharded factors over the in-process transport (run_rank_batch on every rank)."""
+    from mimosa_amd import capi
+    refs = [oracle_results(dict(c, map_chunks=cases[0]["map_chunks"]))[0] for c in cases]
+    splits = []
+    for i, c in enumerate(cases):
+        n = len(c["scan"])
+        if uneven:
+            rng = np.random.default_rng(world + n + 17 * i)
+            splits.append(np.split(np.arange(n), np.sort(rng.integers(0, n + 1, world - 1))))
+        else:
+            splits.append(np.array_split(np.arange(n), world))
+    comms = capi.ShardComm.local(world)
+    ctxs = [capi.Context(0) for _ in range(world)]
+    results = _run_threads(world, lambda r: run_rank_batch(comms[r], ctxs[r], cases, refs, splits, block_log2=block_log2, force=(world == 1),
+                                                           components_off=components_off, check_eigvec=check_eigvec, pipelined=pipelined))
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.close()
+    return results
+
+
+def run_local_world(world, case=None, block_log2=3, uneven=False, components_off_from=None, check_eigvec=True, mode="sync", sync_first=0, check_counters=True):
     """`world` ranks as threads of this process over the in-process transport (one context = one stream per rank)."""
     from mimosa_amd import capi
     case = case or default_case()
@@ -106,7 +246,8 @@ def run_local_world(world, case=None, block_log2=3, uneven=False, components_off
 
     def body(r):
         try:
-            results[r] = run_rank(comms[r], ctxs[r], case, refs, split, block_log2=block_log2, force=(world == 1), components_off_from=components_off_from, check_eigvec=check_eigvec)
+            results[r] = run_rank(comms[r], ctxs[r], case, refs, split, block_log2=block_log2, force=(world == 1), components_off_from=components_off_from, check_eigvec=check_eigvec,
+                                  mode=mode, sync_first=sync_first, check_counters=check_counters)
         except BaseException as e:  # noqa: BLE001 — reported by the main thread
             errors[r] = e
 

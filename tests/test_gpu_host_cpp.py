@@ -267,6 +267,7 @@ def test_sharded_host_mirror(tmp_path, mode):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout[out.stdout.index("{"):])
     assert d["worst_rel"] <= 1e-12 and d["hist_equal"] == 1 and d["ranks_equal"] == 1, d
+    assert d["batch_worst_rel"] <= 1e-12 and d["async_worst_rel"] <= 1e-12, d   # ShardedICPFactor::linearizeBatch / linearizeAsync + wait
     assert d["collective"] == 1 and d["collectives_last"] == 3
     assert d["backend"] == ("rccl" if mode[0] == "rccl" else "local")
     assert sum(d["points_held"]) == len(scan)

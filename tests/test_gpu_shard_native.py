@@ -58,6 +58,76 @@ def test_native_sharded_segment_overflow_retries():
     assert results[0]["stats"]["retries_total"] >= 1
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_sharded_async_form_is_the_blocking_one(world):
+    """mh_shard_icp_linearize_async + mh_shard_icp_wait per pose: the same protocol round, the same results."""
+    import shard_native_common as C
+    C.run_local_world(world, mode="async")
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_native_sharded_pipelined_calls_are_the_sequential_ones(world):
+    """Every pose of the sequence enqueued before the one wait (6 rounds in flight): one stream, so the calls — and the
+    data-association cache they share — run in order; results and final state are the unsharded oracle's."""
+    import shard_native_common as C
+    C.run_local_world(world, mode="pipelined")
+
+
+def test_native_sharded_pipelined_overflow_is_repeated_at_the_wait():
+    """Three blocking calls shrink the segments to their minimum; then a pose jump of metres and the way back are enqueued
+    TOGETHER: both overflow, both are repeated (larger segments) at the wait, every rank in the same order."""
+    import shard_native_common as C
+    from mimosa_amd import synth
+    case = C.default_case()
+    R0, t0 = case["poses"][0]
+    case["poses"] = [(R0, t0), (R0, t0), (R0, t0), (R0 @ synth.so3_exp(np.array([0, 0, 0.3])), t0 + np.array([0.4, -0.3, 0.0])), (R0, t0)]
+    # (the k-NN counters of a call repeated BEHIND a later one are statistics: points it had counted re-associate in the repeat)
+    results, _ = C.run_local_world(2, case=case, mode="pipelined", sync_first=3, check_counters=False)
+    assert results[0]["stats"]["retries_total"] >= 1
+
+
+def _window_cases(n, binary_at=()):
+    import shard_native_common as C
+    from mimosa_amd import synth
+    base = C.default_case()
+    cases = []
+    for i in range(n):
+        c = C.default_case(binary=(i in binary_at))
+        room = np.array([20.0, 14.0, 3.0])
+        scan, aux = synth.make_scan(n_rows=[32, 16, 32, 8, 32][i % 5], seed=200 + i, n_cols=[128, 64, 96, 128, 32][i % 5], room=room,
+                                    sensor_local=np.array([9.3 - 0.7 * i, 6.6 + 0.4 * i, 1.2]))
+        R, t = synth.query_pose(aux["R_W_L"], aux["t_W_L"])
+        poses = [(R, t)] + [(R @ synth.so3_exp(w * (1 + 0.3 * i)), t + d * (1 + 0.2 * i)) for w, d in C.POSE_STEPS]
+        if c["binary"]:
+            Rt, tt = c["tgt"]
+            poses = [(Rt @ Rk, Rt @ tk + tt) for Rk, tk in poses]
+        cases.append(dict(c, scan=scan, poses=poses, map_chunks=base["map_chunks"]))
+    return cases
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_native_sharded_window_batch_equals_unsharded_oracle(world):
+    """mh_shard_icp_linearize_batch: five factors (different scans, sizes and pose walks) in ONE protocol round per pose —
+    one all-to-all, one all-reduce of 5 x 168 doubles (+ one of 5 x 16) — each equal to ITS unsharded oracle."""
+    import shard_native_common as C
+    results = C.run_local_world_batch(world, _window_cases(5))
+    for st in results[0]["stats"]:
+        assert st["collectives_last"] == 3
+
+
+def test_native_sharded_window_batch_mixed_kinds_and_components():
+    """Unary and binary factors in one round (two kernel instantiations), the component pass off for some of them."""
+    import shard_native_common as C
+    C.run_local_world_batch(2, _window_cases(4, binary_at=(1, 3)), components_off=(0, 3))
+
+
+def test_native_sharded_window_batch_of_ten_and_pipelined():
+    """More factors than one batched launch carries (8): two launches per stage, still one round; and the rounds of the whole
+    pose sequence in flight at once."""
+    import shard_native_common as C
+    C.run_local_world_batch(2, _window_cases(10), pipelined=True)
+
+
 def test_native_world1_is_the_plain_factor(ctx, small_world):
     from mimosa_amd import capi
     w = small_world
