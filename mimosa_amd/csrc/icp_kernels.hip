@@ -1206,7 +1206,22 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       qd2 = a.q_da[3 * qi + 2];
       st = a.status[qi];
     }
-    const bool gone = SHARD && (st & kShardSkip) != 0;  // map-sharded factors only: another rank's point in this call
+    bool gone = SHARD && (st & kShardSkip) != 0;  // map-sharded factors only: another rank's point in this call
+    if constexpr (SHARD) {
+      if (a.cold) {
+        // a sharded factor after mh_shard_icp_reset: the association state reads as zero (as above), but WHICH slots are this
+        // rank's is still in the status word — tombstones (-1) stay, a held-back mover (skip flag on a live status) is reset
+        // in place, since no pass of this call will touch it
+        const int raw = a.status[qi];
+        gone = (raw & kShardSkip) != 0;
+        if (gone && raw != -1) {
+          a.status[qi] = kShardSkip;
+          a.q_da[3 * qi + 0] = a.q_da[3 * qi + 1] = a.q_da[3 * qi + 2] = 0.0;
+          a.mean[3 * qi + 0] = a.mean[3 * qi + 1] = a.mean[3 * qi + 2] = 0.0;
+          a.normal[3 * qi + 0] = a.normal[3 * qi + 1] = a.normal[3 * qi + 2] = 0.0;
+        }
+      }
+    }
     const double ddx = q0 - qd0, ddy = q1 - qd1, ddz = q2 - qd2;
     const bool update = !gone && sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
 

@@ -198,6 +198,7 @@ struct mh_shard_comm
   unsigned int seq = 0;
   unsigned long long n_rounds = 0;   // rounds enqueued so far
   std::vector<ShardCall> repairs;    // calls whose segments overflowed, waiting to be repeated (settle_rounds)
+  std::vector<mh_shard_icp *> plain_pending;  // one rank, no protocol: the factors with mh_icp_linearize_async calls to collect
 
   int peer_missing()
   {
@@ -271,6 +272,7 @@ struct mh_shard_icp
   int cur = 0;
   uint32_t n_slots = 0, n_live = 0, slot_capacity = 0, slots_bound = 0;
   int inflight = 0;  // calls enqueued and not completed
+  bool cold_pending = false;  // mh_shard_icp_reset since the last enqueued call: the next one reads the association state as zero
   bool replay = false;  // a call overflowed its segments and waits to be repeated: the calls made after it are repeated behind it
   uint32_t seg_cap = 0, seg_cap_max = 0;
   uint64_t n_total = 0;
@@ -518,6 +520,8 @@ void mh_shard_icp_destroy(mh_shard_icp * S)
         if (c.S == S) c.S = nullptr;
     for (ShardCall & c : S->comm->repairs)
       if (c.S == S) c.S = nullptr;
+    auto & pend = S->comm->plain_pending;
+    pend.erase(std::remove(pend.begin(), pend.end(), S), pend.end());
   }
   for (DevBuf * b : {&S->d_dest, &S->d_hist, &S->d_ar, &S->d_flags, &S->d_pos, &S->d_temp}) b->release(true);
   if (S->d_state) AllocCache::free(S->d_state, true);
@@ -835,6 +839,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
   comm->ws_ctx = ctx;
   const uint32_t world = static_cast<uint32_t>(comm->world), rank = static_cast<uint32_t>(comm->rank);
   const unsigned long long index = comm->n_rounds;
+  const long long coll_before = comm->n_all_to_all + comm->n_all_reduce;
   if (index >= static_cast<unsigned long long>(kShardRing)) {
     const int rc = settle_rounds(comm, index - kShardRing);
     if (rc != MH_OK) return rc;
@@ -976,7 +981,8 @@ int enqueue_round(const RoundSpec * spec, size_t B)
     mh::IcpArgs & a = ia[f];
     mh::LocArgs & l = la[f];
     a.n_dev = l.n_dev = &S->d_state->n_slots[S->cur ^ 1];
-    a.cold = 0;
+    a.cold = S->cold_pending ? 1 : 0;  // (K3 still reads the status words: tombstones and held-back movers are marked there)
+    S->cold_pending = false;
     a.host_result = nullptr;
     a.seq = 0;
     a.shard_out = ar + f * mh::kShardArLen;
@@ -1086,6 +1092,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
     S->slots_bound = static_cast<uint32_t>(std::min<uint64_t>(S->slot_capacity, static_cast<uint64_t>(S->slots_bound) + round.calls[f].arrivals_bound));
     S->inflight++;
     S->icp->n = S->slots_bound;
+    S->stats.collectives_last = static_cast<uint32_t>(comm->n_all_to_all + comm->n_all_reduce - coll_before);  // (a blocking call adds its repeats')
   }
   comm->rounds.push_back(std::move(round));
   comm->n_rounds++;
@@ -1121,7 +1128,6 @@ int round_from_arrays(mh_shard_icp * const * Ss, size_t B, const double * R_src,
   for (size_t f = 0; f < B; ++f) {
     spec[f] = RoundSpec{Ss[f], R_src + 9 * f, t_src + 3 * f, R_tgt ? R_tgt + 9 * f : nullptr, t_tgt ? t_tgt + 3 * f : nullptr, g_unit + 3 * f, out + f};
     Ss[f]->stats.retries_last = 0;
-    Ss[f]->stats.collectives_last = 0;
   }
   return enqueue_round(spec.data(), B);
 }
@@ -1157,7 +1163,10 @@ int mh_shard_icp_linearize_async(mh_shard_icp * S, const double R_src[9], const 
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_linearize_async", [&]() -> int {
     const int rc = check_round(&S, S ? 1 : 0, R_src, t_src, R_tgt, t_tgt, g_unit, out, "mh_shard_icp_linearize_async");
     if (rc != MH_OK) return rc;
-    if (!S->collective) return mh_icp_linearize_async(S->icp, R_src, t_src, R_tgt, t_tgt, g_unit, out);
+    if (!S->collective) {
+      if (std::find(S->comm->plain_pending.begin(), S->comm->plain_pending.end(), S) == S->comm->plain_pending.end()) S->comm->plain_pending.push_back(S);
+      return mh_icp_linearize_async(S->icp, R_src, t_src, R_tgt, t_tgt, g_unit, out);
+    }
     return round_from_arrays(&S, 1, R_src, t_src, R_tgt, t_tgt, g_unit, out);
   });
 }
@@ -1170,6 +1179,8 @@ int mh_shard_icp_linearize_batch_async(mh_shard_icp * const * Ss, size_t n_facto
     if (rc != MH_OK) return rc;
     if (!Ss[0]->collective) {  // one rank, nothing to exchange: the plain factors, enqueued one behind the other
       for (size_t f = 0; f < n_factors; ++f) {
+        auto & pend = Ss[f]->comm->plain_pending;
+        if (std::find(pend.begin(), pend.end(), Ss[f]) == pend.end()) pend.push_back(Ss[f]);
         const int r2 = mh_icp_linearize_async(Ss[f]->icp, R_src + 9 * f, t_src + 3 * f, R_tgt ? R_tgt + 9 * f : nullptr, t_tgt ? t_tgt + 3 * f : nullptr, g_unit + 3 * f, out + f);
         if (r2 != MH_OK) return r2;
       }
@@ -1206,7 +1217,16 @@ int mh_shard_icp_wait(mh_shard_icp * S)
 {
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_wait", [&]() -> int {
     if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_wait: NULL argument");
-    if (!S->collective) return mh_icp_wait(S->icp);
+    if (!S->collective) {  // every factor of the communicator with enqueued calls, like the rounds of the collective form
+      int rc_all = mh_icp_wait(S->icp);
+      for (mh_shard_icp * q : S->comm->plain_pending)
+        if (q != S) {
+          const int rc = mh_icp_wait(q->icp);
+          if (rc != MH_OK) rc_all = rc;
+        }
+      S->comm->plain_pending.clear();
+      return rc_all;
+    }
     MH_HIP(S->ctx, mh_enter(S->ctx));
     return settle_rounds(S->comm, ~0ull);
   });
@@ -1219,8 +1239,12 @@ int mh_shard_icp_reset(mh_shard_icp * S)
     if (!S->collective) return mh_icp_reset(S->icp);
     mh_ctx * ctx = S->ctx;
     MH_HIP(ctx, mh_enter(ctx));
-    // stream-ordered behind the calls in flight: the kernel reads the slot count from the device, the grid covers the bound
-    MH_HIP(ctx, mh::launch_shard_reset(arrays_of(S->icp, false), S->d_state, S->cur, S->slots_bound, ctx->stream));
+    // No kernel: like mh_icp_reset, the next enqueued call treats the association state of every point as freshly
+    // constructed (K3's `cold` launch reads it as zero and writes it for every slot it processes; movers' records carry
+    // stale state that the receiving rank's cold K3 ignores the same way).  Ordered like a stream operation: it applies to
+    // the calls enqueued after it.
+    (void)ctx;
+    S->cold_pending = true;
     return MH_OK;
   });
 }

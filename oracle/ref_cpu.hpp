@@ -728,7 +728,7 @@ public:
 
     const size_t N = cloud_source_.size();
     const int nt = std::max(1, n_threads);
-    struct Acc
+    struct alignas(128) Acc  // one thread's sums: its own cache lines (unpadded, neighbouring threads shared a line — an artefact of this port)
     {
       double ss[36], st[36], tt[36], bs[6], bt[6], f;
       int64_t n_knn, n_cand;

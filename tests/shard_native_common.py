@@ -109,6 +109,17 @@ def run_rank(comm, ctx, case, refs, split, block_log2=3, force=False, components
             log.append((rank, k, st))
     stats = vmap.stats()
     final = f.stats()
+    if components_off_from is None:
+        # mh_shard_icp_reset: the next call is the FIRST call of a freshly constructed factor at that pose (refs[0]), wherever
+        # the points are by now
+        f.reset()
+        R0, t0 = case["poses"][0]
+        again = f.linearize(R0, t0, **tkw)
+        assert_result_parity(dict(again, linearize_count=refs[0][0]["linearize_count"]), refs[0][0], binary=case["binary"], check_eigvec=check_eigvec)
+        origin, s, mean, nrm = f.state()
+        glob = np.array([split[int(o >> np.uint64(32))][int(o & np.uint64(0xFFFFFFFF))] for o in origin], np.int64)
+        if len(glob):
+            assert_state_parity((s, mean, nrm), (refs[0][1][glob], refs[0][2][glob], refs[0][3][glob]))
     f.destroy()
     vmap.release()
     return dict(moved=moved, map_points=stats["n_points"], stats=final)
