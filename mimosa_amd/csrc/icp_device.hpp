@@ -37,6 +37,18 @@ struct DeviceResult
   unsigned int seq;  // host slot only: written LAST by K4 (system-scope release) = the call's sequence number
 };
 
+// Results of a plain (unsharded) factor reach the host as "flagged words": every double travels as ONE 16-byte store
+// {lo, seq, hi, seq} into mapped pinned memory, each 8-byte half carrying the call's sequence number, so the host knows a
+// value has arrived by looking at the value itself — no system-scope fence, no completion flag behind the data, no
+// ordering between stores needed (the idea of NCCL's LL protocol).  Layout of one call's slot (LlSlot): the 28 / 91 Hessian
+// sums + 4 counters, the two eigenbases K4 projected on, and K4's per-workgroup rows of 16 (6 component sums + 9 histogram
+// counts, two 32-bit counts per word), which the HOST folds in workgroup order — K4 has no ticket / last-block fold any more.
+constexpr int kLlSums = 96;   // >= 91 + 4
+constexpr int kLlEig = 32;    // 18 used
+constexpr int kLlRow = 12;    // 11 used: 6 component sums, then the 9 histogram counts in pairs (lo | hi << 32)
+constexpr int kLocChunks = 4; // consecutive chunks of TPB points per K4 workgroup (plain factors): a quarter of K3's workgroups => a quarter of the rows (8: 14 us instead of 10, measured)
+__host__ __device__ inline size_t ll_slot_words(int loc_grid_cap) { return static_cast<size_t>(kLlSums + kLlEig) + static_cast<size_t>(loc_grid_cap) * kLlRow; }
+
 struct IcpArgs
 {
   MapView map;
@@ -55,7 +67,10 @@ struct IcpArgs
   unsigned int * ticket;
   DeviceResult * result;
   DeviceResult * host_result;  // mapped pinned host slot (may be null): the last block writes its part there too
-  unsigned int seq;          // != 0: no K4 follows (components switched off) — the last block publishes the completion number itself
+  unsigned int seq;          // the call's sequence number (tags every flagged word of the call)
+  int tail;                  // plain factors: 1 = no K4 follows (components switched off) — ticket, fold by the last block, sums + counters
+                             // published as flagged words; 0 = K4 follows and folds the per-block rows itself: this kernel ends at its row
+  uint4 * ll;                // plain factors: the call's slot in mapped pinned memory (device address)
   unsigned long long * dbg;  // MH_TIMELINE diagnostic build only, else null
   int reps;                  // MH_TIMELINE only: repeat the per-point section (warm-cache experiment)
   // map-sharded factors (shard_api.hip): the number of point slots lives on the device (arrivals are appended by a
@@ -75,6 +90,8 @@ struct LocArgs
   const float4 * src;
   int n;
   int chunks_per_block;  // set by the launcher
+  int k3_blocks;         // plain factors: K3's workgroups of this factor = rows in `partials` that every K4 workgroup folds for itself
+  uint4 * ll;            // plain factors: the call's slot in mapped pinned memory
   double R[9];
   const double * normal;
   const int32_t * status;
@@ -87,13 +104,14 @@ struct LocArgs
 };
 
 int linearize_grid(int n);
-int localizability_grid(int n);
+int localizability_grid(int n, bool shard = false);
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream);
 hipError_t launch_localizability(const LocArgs & a, hipStream_t stream);
 // Batched form: d_args / d_start live in device-visible memory (n_factors argument blocks, n_factors + 1 grid
 // prefix entries); every factor's grid is batch_grid(n, tpb) with one tpb = batch_tpb(max n) for the whole batch.
 int batch_tpb(int max_n);
 int batch_grid(int n, int tpb);
+int batch_loc_grid(int n, int tpb, bool shard = false);
 hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb, int k,
                                   int n_off, bool binary, hipStream_t stream);
 hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,

@@ -1064,6 +1064,13 @@ __device__ __forceinline__ double load_partial(const double * p)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One double as a flagged word (icp_device.hpp): a single 16-byte store into mapped pinned memory.
+__device__ __forceinline__ void ll_store(uint4 * p, double v, unsigned int seq)
+{
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+  *p = make_uint4(static_cast<unsigned int>(b), seq, static_cast<unsigned int>(b >> 32), seq);
+}
+
 __device__ __forceinline__ bool arrive_is_last(unsigned int * ticket, unsigned int n_blocks, bool * s_last)
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own write-through stores
@@ -1081,10 +1088,10 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int * ticket, unsigned i
 // Deterministic parallel fold of the per-block partial rows by the last-arriving block: thread
 // (entry, lane-segment) sums blocks seg, seg+NSEG, ... with four independent accumulators (loads
 // stay in flight), segments are then combined in index order.  Result in s_out[0..n_ent).
-template <int EW, int TPB>  // entries rounded up: 32 (unary / K4) or 96 (binary); TPB threads per workgroup
+template <int EW, int TPB, bool PLAIN = false>  // entries rounded up: 32 (unary / K4) or 96 (binary); TPB threads per workgroup
 __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks, int n_ent, double * s_seg,
                                           double * s_out)
-{
+{  // PLAIN: the rows were written by an EARLIER kernel (plain stores, visible at the kernel boundary): ordinary cached loads
   constexpr int NSEG = TPB / EW;
   const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
   if (seg < NSEG && ent < n_ent) {
@@ -1098,7 +1105,8 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
         const int b = b0 + u * NSEG;
-        v[u] = load_partial(partials + static_cast<size_t>(b < n_blocks ? b : seg) * kPartialStride + ent);
+        const double * src = partials + static_cast<size_t>(b < n_blocks ? b : seg) * kPartialStride + ent;
+        v[u] = PLAIN ? *src : load_partial(src);
       }
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) acc += (b0 + u * NSEG < n_blocks) ? v[u] : 0.0;  // fixed order: deterministic
@@ -1453,53 +1461,61 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     }
   }
   __syncthreads();
+  // A plain factor whose K4 follows (a.tail == 0) ends here: the row is an ordinary store, K4's workgroups fold the rows
+  // themselves after the kernel boundary — no write-through, no ticket, no last-block fold (3 us of serial tail with 255
+  // CUs idle in round 3).  Otherwise (no K4 behind it, or a map-sharded factor, whose sums feed an all-reduce): rows
+  // write-through, ticket, fold by the last block.
+  const bool fold_here = SHARD || a.tail != 0;
   if (threadIdx.x < NENT) {
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < SEGS; ++g) s += s_aux[g * NENT + threadIdx.x];
-    store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x], s);
+    double * dst = &a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x];
+    if (fold_here)
+      store_partial(dst, s);
+    else
+      *dst = s;
   }
-  // the block's k-NN counters ride along as two more partial entries (exact in fp64): same-line
+  // the block's k-NN counters ride along as four more partial entries (exact in fp64): same-line
   // global atomics from every block would serialise at L2
-  if (threadIdx.x >= 128 && threadIdx.x < 132)
-    store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + NENT + (threadIdx.x - 128)],
-                  static_cast<double>(s_cnt[threadIdx.x - 128]));
+  if (threadIdx.x >= 128 && threadIdx.x < 132) {
+    double * dst = &a.partials[static_cast<size_t>(block_id) * kPartialStride + NENT + (threadIdx.x - 128)];
+    const double c = static_cast<double>(s_cnt[threadIdx.x - 128]);
+    if (fold_here)
+      store_partial(dst, c);
+    else
+      *dst = c;
+  }
 
   MH_STAMP(a.dbg, 5);
 #ifdef MH_FAKE_NO_TAIL  // timing-only bound experiment (wrong results): no ticket, no fold by the last block
   return;
 #endif
+  if (!fold_here) return;
   if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   MH_STAMP(a.dbg, 6);
 
   // ---- last block: fold the partial rows in fixed order, finalise --------------------------------
   double * s_sum = s_aux + (TPB / EW) * EW;
   fold_rows<EW, TPB>(a.partials, n_blocks, NENT + 4, s_aux, s_sum);
-  // Results go to the device struct (K4 reads the eigenbases there) AND straight to the caller's mapped
-  // pinned host slot: no D2H copy node, and K4's tail does not have to relay them.
+  if constexpr (SHARD) {
+    // Results go to the device struct (the caller-driven two-phase form reads them there) and, when given, to a mapped host slot
 #define MH_PUT(field, val)                          \
   do {                                              \
     a.result->field = (val);                        \
     if (a.host_result) a.host_result->field = (val); \
   } while (0)
-  if (threadIdx.x < NENT) MH_PUT(sums[threadIdx.x], s_sum[threadIdx.x]);
-  if (threadIdx.x == NENT) MH_PUT(n_knn, static_cast<unsigned long long>(s_sum[NENT]));
-  if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
-  if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
-  if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
-  if constexpr (SHARD) {
-    if (a.shard_out && threadIdx.x < NENT + 4) a.shard_out[threadIdx.x] = s_sum[threadIdx.x];  // what the shards all-reduce
-  }
-  // computeLocalizability of the rot / trans 3 x 3 blocks (:405-411) is NOT done here: two eigen-decompositions on one lane
-  // each cost 2.3 us of this serial tail while 255 CUs idle.  K4's workgroups derive the eigenbases they need from
-  // result->sums themselves (behind their per-point loads), the host epilogue derives the ones it reports (finish_result).
+    if (threadIdx.x < NENT) MH_PUT(sums[threadIdx.x], s_sum[threadIdx.x]);
+    if (threadIdx.x == NENT) MH_PUT(n_knn, static_cast<unsigned long long>(s_sum[NENT]));
+    if (threadIdx.x == NENT + 1) MH_PUT(n_cand, static_cast<unsigned long long>(s_sum[NENT + 1]));
+    if (threadIdx.x == NENT + 2) MH_PUT(n_fallback, static_cast<unsigned long long>(s_sum[NENT + 2]));
+    if (threadIdx.x == NENT + 3) MH_PUT(n_scanned, static_cast<unsigned long long>(s_sum[NENT + 3]));
 #undef MH_PUT
-  // No K4 behind this call (mh_icp_set_components(icp, 0)): this block's writes are the whole result, so the completion
-  // number a spinning host waits for is published here — data first (system-scope fence by every writer), then the flag.
-  if (a.seq && a.host_result) {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.shard_out && threadIdx.x < NENT + 4) a.shard_out[threadIdx.x] = s_sum[threadIdx.x];  // what the shards all-reduce
+  } else {
+    // this kernel is the whole call: sums + counters straight to the host as flagged words (computeLocalizability of the
+    // rot / trans blocks, :405-411, is the host epilogue's: finish_result)
+    if (threadIdx.x < NENT + 4) ll_store(a.ll + threadIdx.x, s_sum[threadIdx.x], a.seq);
   }
   MH_STAMP(a.dbg, 7);
 }
@@ -1583,29 +1599,55 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
 {
   constexpr int NW = TPB / 64;
   __shared__ double s_w[NW][16];
-  __shared__ double s_seg[(TPB / 32) * 32 + 32];
+  __shared__ double s_seg[TPB + 96 + 96];  // fold scratch: (TPB / EW) * EW segment sums + EW totals, EW = 32 or 96
   __shared__ bool s_last;
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double v[6] = {0, 0, 0, 0, 0, 0};
   unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // The first chunk's status, point and normal are requested first: one memory round trip, in flight while the
-  // eigenbases below are worked out (the pass is a handful of round trips long, nothing else).
+  // The pass is a handful of memory round trips long and nothing else, so everything that does not depend on the eigenbases
+  // happens BEFORE they are known: the status / point / normal of ALL of this workgroup's chunks are requested up front (one
+  // round trip, in flight while the Hessian rows are folded), and the unwhitened Jacobian directions of the Valid points
+  // (geometric_factor.hpp:343-352) are worked out while two lanes of the workgroup decompose H_rr and H_tt.
+  constexpr int CH = SHARD ? 1 : kLocChunks;  // == a.chunks_per_block (set by the launchers)
   const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
-  const int i_first = block_id * a.chunks_per_block * TPB + static_cast<int>(threadIdx.x);
-  const int i_ld = i_first < n_pts ? i_first : 0;
-  int st_next = n_pts > 0 ? a.status[i_ld] : -1;
-  float4 sp_next = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
-  double n0_next = n_pts > 0 ? a.normal[3 * i_ld] : 0.0, n1_next = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0, n2_next = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
-  // The two eigenbases: given (map-sharded factors: the basis of the GLOBAL Hessian), or derived here from the Hessian sums
-  // K3's last block left in result->sums — one lane per 3 x 3 block (computeLocalizability, utils.hpp:308-313), every
-  // workgroup for itself.  (In K3's serial tail they cost 2.3 us with 255 CUs idle.)
+  int st_c[CH];
+  float4 sp_c[CH];
+  double nx_c[CH], ny_c[CH], nz_c[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int i = (block_id * CH + ch) * TPB + static_cast<int>(threadIdx.x);
+    const int i_ld = i < n_pts ? i : 0;
+    st_c[ch] = n_pts > 0 ? a.status[i_ld] : -1;
+    sp_c[ch] = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
+    nx_c[ch] = n_pts > 0 ? a.normal[3 * i_ld] : 0.0;
+    ny_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0;
+    nz_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
+    if (i >= n_pts) st_c[ch] = -1;
+  }
+  // The Hessian sums the eigenbases come from.  Plain factor: K3 ended at its per-workgroup rows; EVERY workgroup of this
+  // kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed order of the old last-block
+  // fold — so every workgroup holds the same bits), workgroup 0 also publishes them.  Map-sharded factor: the all-reduced
+  // (global) sums are given.
+  const double * sums = nullptr;
+  double * s_h = s_seg + TPB;  // folded sums + counters (plain factors)
+  if constexpr (SHARD) {
+    sums = a.sums ? a.sums : a.result->sums;
+  } else {
+    const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
+    if (a.nv == 7)
+      fold_rows<32, TPB, true>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    else
+      fold_rows<96, TPB, true>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    sums = s_h;
+  }
+  // The two eigenbases: given (two-phase callers), or derived here — one lane per 3 x 3 block (computeLocalizability,
+  // utils.hpp:308-313), every workgroup for itself, on the LAST two waves (the others go on to their points).
   __shared__ double s_E[18];
   if (a.eig) {
     if (threadIdx.x < 18) s_E[threadIdx.x] = a.eig[threadIdx.x];
-  } else if (threadIdx.x == 0 || threadIdx.x == 64) {
-    const int NV = a.nv, o = threadIdx.x ? 3 : 0;
-    const double * sums = (SHARD && a.sums) ? a.sums : a.result->sums;
+  } else if (threadIdx.x == TPB - 64 || threadIdx.x == TPB - 128) {
+    const int NV = a.nv, o = threadIdx.x == TPB - 64 ? 3 : 0;
     double Hb[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
@@ -1616,6 +1658,29 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     compute_localizability(Hb, loc, E);
     for (int q = 0; q < 9; ++q) s_E[(o ? 9 : 0) + q] = E[q];
   }
+  // Jacobian directions of this thread's points (independent of the eigenbases)
+  double jr_c[CH][3], jt_c[CH][3];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const double px = sp_c[ch].x, py = sp_c[ch].y, pz = sp_c[ch].z;
+    const double ns0 = a.R[0] * nx_c[ch] + (a.R[3] * ny_c[ch] + a.R[6] * nz_c[ch]);
+    const double ns1 = a.R[1] * nx_c[ch] + (a.R[4] * ny_c[ch] + a.R[7] * nz_c[ch]);
+    const double ns2 = a.R[2] * nx_c[ch] + (a.R[5] * ny_c[ch] + a.R[8] * nz_c[ch]);
+    double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
+    const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
+    if (nr2 > 0.0) {  // Eigen normalized(): unchanged when the squared norm is zero
+      const double inv = 1.0 / sqrt(nr2);
+      r0 *= inv;
+      r1 *= inv;
+      r2 *= inv;
+    }
+    jr_c[ch][0] = r0;
+    jr_c[ch][1] = r1;
+    jr_c[ch][2] = r2;
+    jt_c[ch][0] = -ns0;
+    jt_c[ch][1] = -ns1;
+    jt_c[ch][2] = -ns2;
+  }
   __syncthreads();
   double er[9], et[9];
 #pragma unroll
@@ -1623,51 +1688,20 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     er[q] = s_E[q];
     et[q] = s_E[9 + q];
   }
-  // few, fat workgroups (a.chunks_per_block consecutive 512-point chunks each): the pass is short, so its
-  // cost is the ticket + fold tail, which scales with the number of partial rows
-  for (int ch = 0; ch < a.chunks_per_block; ++ch) {
-  const int i = (block_id * a.chunks_per_block + ch) * TPB + threadIdx.x;
-  int st = -1;
-  if (i < n_pts) {
-    float4 sp;
-    double n0, n1, n2;
-    if (ch == 0) {
-      st = st_next;
-      sp = sp_next;
-      n0 = n0_next;
-      n1 = n1_next;
-      n2 = n2_next;
-    } else {
-      st = a.status[i];
-      sp = a.src[i];
-      n0 = a.normal[3 * i];
-      n1 = a.normal[3 * i + 1];
-      n2 = a.normal[3 * i + 2];
-    }
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int st = st_c[ch];
     if (st == MH_VALID) {
-      const double px = sp.x, py = sp.y, pz = sp.z;
-      const double ns0 = a.R[0] * n0 + (a.R[3] * n1 + a.R[6] * n2);
-      const double ns1 = a.R[1] * n0 + (a.R[4] * n1 + a.R[7] * n2);
-      const double ns2 = a.R[2] * n0 + (a.R[5] * n1 + a.R[8] * n2);
-      double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
-      const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
-      if (nr2 > 0.0) {  // Eigen normalized(): unchanged when the squared norm is zero
-        const double inv = 1.0 / sqrt(nr2);
-        r0 *= inv;
-        r1 *= inv;
-        r2 *= inv;
-      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double tc = fabs((-ns0) * et[c] + ((-ns1) * et[3 + c] + (-ns2) * et[6 + c]));
-        const double rc = fabs(r0 * er[c] + (r1 * er[3 + c] + r2 * er[6 + c]));
+        const double tc = fabs(jt_c[ch][0] * et[c] + (jt_c[ch][1] * et[3 + c] + jt_c[ch][2] * et[6 + c]));
+        const double rc = fabs(jr_c[ch][0] * er[c] + (jr_c[ch][1] * er[3 + c] + jr_c[ch][2] * er[6 + c]));
         v[c] += tc >= 0.5 ? tc : 0.0;      // trans components
         v[3 + c] += rc >= 0.5 ? rc : 0.0;  // rot components
       }
     }
-  }
 #pragma unroll
-  for (int h = 0; h < 9; ++h) hist[h] += static_cast<unsigned int>(__popcll(__ballot(st == h)));
+    for (int h = 0; h < 9; ++h) hist[h] += static_cast<unsigned int>(__popcll(__ballot(st == h)));
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -1680,20 +1714,48 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   for (int h = 0; h < 9; ++h)
     if (lane == 0) s_w[wv][6 + h] = static_cast<double>(hist[h]);
   __syncthreads();
+  if constexpr (!SHARD) {
+    // The workgroup's row of 15 goes to the host as flagged words and the HOST folds the rows (in workgroup order:
+    // deterministic) — no partial-row store, ticket, fold or completion flag on the device.  Workgroup 0 adds what every
+    // workgroup computed identically: the Hessian sums + counters and the eigenbases this pass projected on.
+    uint4 * ll_rows = a.ll + (kLlSums + kLlEig) + static_cast<size_t>(block_id) * kLlRow;
+    if (threadIdx.x < 6) {
+      double s = 0.0;
+      for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
+      ll_store(ll_rows + threadIdx.x, s, a.seq);
+    } else if (threadIdx.x < 11) {  // histogram counts 2 (t - 6), 2 (t - 6) + 1 in one word
+      const int h0 = 2 * (static_cast<int>(threadIdx.x) - 6);
+      unsigned int c0 = 0u, c1 = 0u;
+      for (int w2 = 0; w2 < NW; ++w2) {
+        c0 += static_cast<unsigned int>(s_w[w2][6 + h0]);
+        if (h0 + 1 < 9) c1 += static_cast<unsigned int>(s_w[w2][6 + h0 + 1]);
+      }
+      ll_rows[threadIdx.x] = make_uint4(c0, a.seq, c1, a.seq);
+    }
+    if (block_id == 0) {
+      const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
+      if (threadIdx.x >= 64 && static_cast<int>(threadIdx.x) < 64 + n_ent) ll_store(a.ll + (threadIdx.x - 64), s_h[threadIdx.x - 64], a.seq);
+      if (threadIdx.x >= 192 && threadIdx.x < 192 + 18) ll_store(a.ll + kLlSums + (threadIdx.x - 192), s_E[threadIdx.x - 192], a.seq);
+    }
+    (void)n_blocks;
+    (void)s_last;
+    return;
+  } else {
   if (threadIdx.x < 15) {
     double s = 0.0;
     for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
     store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x], s);
   }
+#ifdef MH_FAKE_K4_NO_TAIL  // timing-only bound experiment (wrong results): no ticket, no fold by the last block
+  return;
+#endif
   if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   double * s_sum = s_seg + (TPB / 32) * 32;
   fold_rows<32, TPB>(a.partials, n_blocks, 15, s_seg, s_sum);
   if (threadIdx.x < 6) a.result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
   if (threadIdx.x >= 6 && threadIdx.x < 15)
     a.result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
-  if constexpr (SHARD) {
-    if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
-  }
+  if (a.shard_out && threadIdx.x < 16) a.shard_out[threadIdx.x] = threadIdx.x < 15 ? s_sum[threadIdx.x] : 0.0;
   // the eigenbases THIS pass projected on are what the caller is told (the host's own decomposition of the same sums may
   // pick another basis of a clustered eigenspace: no FMA there, other branches of sym_eigen3)
   if (threadIdx.x >= 32 && threadIdx.x < 50) {
@@ -1702,19 +1764,13 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     *dst = s_E[q];
     if (a.host_result) *(q < 9 ? &a.host_result->eig_rot[q] : &a.host_result->eig_trans[q - 9]) = s_E[q];
   }
-  // this kernel's outputs also go to the caller's mapped pinned host slot, straight from the LDS sums (K3's
-  // last block already wrote its part there); the end of the kernel makes them visible to the host
+  // two-phase callers (mh_icp_linearize_finish): this kernel's outputs also go to a mapped pinned host slot; the end of the
+  // kernel makes them visible to the host (they synchronise the stream)
   if (a.host_result) {
     if (threadIdx.x < 6) a.host_result->loc_comp[threadIdx.x] = s_sum[threadIdx.x];
     if (threadIdx.x >= 6 && threadIdx.x < 15)
       a.host_result->status_hist[threadIdx.x - 6] = static_cast<unsigned int>(s_sum[threadIdx.x]);
-    // completion flag for a host that spins on the slot instead of paying a stream synchronisation: data first
-    // (system-scope fence by every writer), then the sequence number with release semantics
-    if (a.seq) {  // synchronous callers only: the system-scope fence costs ~2 us of kernel time
-      __threadfence_system();
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&a.host_result->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+  }
   }
 }
 
@@ -1808,8 +1864,11 @@ int linearize_grid(int n)
   const int tpb = linearize_tpb(n);
   return (((n + tpb - 1) / tpb) + 7) & ~7;
 }
-constexpr int kLocChunksPerBlock = 1;  // measured: 1 vs 4 chunks per workgroup makes no difference (launch + round-trip bound)
-int localizability_grid(int n) { return (linearize_grid(n) + kLocChunksPerBlock - 1) / kLocChunksPerBlock; }
+// K4's workgroups take kLocChunks consecutive chunks of a plain factor (the kernel's time does not depend on it — launch +
+// round trips — but the host folds a quarter of the rows), one chunk each of a map-sharded factor (its rows are folded on
+// the device as before).
+static int loc_chunks(bool shard) { return shard ? 1 : kLocChunks; }
+int localizability_grid(int n, bool shard) { return (linearize_grid(n) + loc_chunks(shard) - 1) / loc_chunks(shard); }
 
 template <int NOFF, int TPB, bool SHARD>
 static void launch_linearize_nt(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -1858,9 +1917,9 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
 hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
-  a.chunks_per_block = kLocChunksPerBlock;
-  const dim3 grid(localizability_grid(a.n));
   const bool shard = a.n_dev != nullptr;
+  a.chunks_per_block = loc_chunks(shard);
+  const dim3 grid(localizability_grid(a.n, shard));
   if (linearize_tpb(a.n) == 256) {
     if (shard)
       hipLaunchKernelGGL((icp_localizability_kernel<256, true>), grid, dim3(256), 0, stream, a);
@@ -1878,6 +1937,7 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 // ---- batched launches: all factors share (k == 5 or not, binary, neighbour mode, TPB) ------------------------
 int batch_tpb(int max_n) { return linearize_tpb(max_n); }
 int batch_grid(int n, int tpb) { return (((n + tpb - 1) / tpb) + 7) & ~7; }
+int batch_loc_grid(int n, int tpb, bool shard) { return (batch_grid(n, tpb) + loc_chunks(shard) - 1) / loc_chunks(shard); }
 
 template <int NOFF, int TPB>
 static void launch_linearize_batch_nt(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int k,

@@ -308,7 +308,7 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_status.reserve(n * sizeof(int32_t), ctx->stream, false));
   const size_t max_grid = static_cast<size_t>(mh::linearize_grid(static_cast<int>(n)));
   MH_HIP(ctx, icp->d_partials.reserve(max_grid * mh::kPartialStride * sizeof(double), ctx->stream, false));
-  MH_HIP(ctx, icp->d_ticket.reserve(2 * sizeof(unsigned int), ctx->stream, false));
+  MH_HIP(ctx, icp->d_ticket.reserve(4 * sizeof(unsigned int), ctx->stream, false));  // K3's ticket, K4's ticket, the point count of the two-phase forms
   MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
 #ifdef MH_TIMELINE
   MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 16 * sizeof(unsigned long long), ctx->stream, false));
@@ -316,6 +316,13 @@ static int icp_alloc(mh_icp * icp)
 #endif
   MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending));
   MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_results), icp->h_results, 0));
+  // flagged-word slots: a recycled pinned block may hold another factor's words — harmless, sequence numbers are drawn from
+  // one process-wide counter (next_call_seq), so nothing stale ever carries the number of a call of this factor
+  // (row capacity in steps of 16 workgroups: factors of similar size — a scan's down-sampled cloud from one keyframe to the
+  // next — ask the pinned cache for the SAME size and get a recycled block instead of a fresh hipHostMalloc)
+  icp->ll_words = mh::ll_slot_words((mh::localizability_grid(static_cast<int>(n)) + 15) & ~15);
+  MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_ll), icp->ll_words * sizeof(uint4) * kMaxPending));
+  MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_ll), icp->h_ll, 0));
   return MH_OK;
 }
 
@@ -498,6 +505,7 @@ void mh_icp_destroy(mh_icp * icp)
     b->release(true);
   if (icp->h_counts) (void)hipHostFree(icp->h_counts);
   if (icp->h_results) AllocCache::free_pinned(icp->h_results, sizeof(mh::DeviceResult) * kMaxPending);
+  if (icp->h_ll) AllocCache::free_pinned(icp->h_ll, icp->ll_words * sizeof(uint4) * kMaxPending);
   if (icp->events_ready)
     for (auto & ev : icp->events)
       for (auto & e : ev) (void)hipEventDestroy(e);
@@ -579,6 +587,15 @@ struct LinearizeTxn
   }
 };
 
+// Sequence numbers of calls: process-wide, never 0 (what a fresh or recycled flagged-word slot cannot hold by accident).
+static unsigned int next_call_seq()
+{
+  static std::atomic<unsigned int> counter{0};
+  unsigned int v = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  if (v == 0u) v = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  return v;
+}
+
 // Argument blocks of one linearize call of `icp` in pending slot n_pending (which it claims): everything of
 // linearize_enqueue except the launches.  want_flag: the last kernel publishes a completion sequence number to the
 // host slot (mh_icp_wait then spins on it instead of synchronising the stream).  Worth it for one synchronous call,
@@ -657,15 +674,19 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   }
   pc.seq = 0;
   pc.components = icp->components;
-  pc.seq_has_basis = false;  // set by the callers whose K4 writes its eigenbases into this call's result slot
+  pc.seq_has_basis = false;  // set by the callers whose K4 publishes the eigenbases it projected on
+  pc.loc_blocks = 0;
+  pc.launched_k4 = false;
   a.seq = 0;
+  a.tail = 1;
+  a.ll = l.ll = nullptr;
+  l.k3_blocks = mh::linearize_grid(a.n);
+  (void)want_flag;  // every call is collected through its flagged words now: no completion flag to ask for
   if (a.n > 0) {
-    a.host_result = l.host_result = icp->d_h_results + slot;
-    if (want_flag) {
-      if (++icp->seq_counter == 0) ++icp->seq_counter;
-      pc.seq = l.seq = icp->seq_counter;
-      __atomic_store_n(&icp->h_results[slot].seq, 0u, __ATOMIC_RELEASE);  // re-arm the slot before anything is enqueued
-    }
+    // plain factors publish flagged words into the call's slot; the two-phase and sharded callers overwrite what they need
+    pc.seq = a.seq = l.seq = next_call_seq();
+    a.ll = l.ll = icp->d_h_ll + static_cast<size_t>(slot) * icp->ll_words;
+    pc.loc_blocks = mh::localizability_grid(a.n);
   }
   icp->n_pending++;
   icp->cold = false;
@@ -686,12 +707,13 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   PendingCall & pc = icp->pending[slot];
   if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
   if (a.n > 0) {
-    if (!pc.components) a.seq = l.seq;  // K3 is the call's last kernel: it publishes the completion number
+    a.tail = pc.components ? 0 : 1;  // K4 follows and folds K3's rows itself / K3 is the whole call: its last block folds and publishes
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     if (pc.components) {
       MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
       pc.seq_has_basis = true;
+      pc.launched_k4 = true;
     }
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   } else {
@@ -699,9 +721,7 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
       MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
       MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
     }
-    // nothing was launched: the (zero) device result is copied the plain way
-    MH_HIP(ctx, hipMemcpyAsync(&icp->h_results[slot], icp->d_result.p, sizeof(mh::DeviceResult), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    // nothing was launched (pc.seq == 0): the result of an empty cloud is all zero, assembled on the host
   }
   txn.commit();
   return MH_OK;
@@ -718,40 +738,127 @@ int mh_icp_linearize_async(mh_icp * icp, const double R_src[9], const double t_s
   return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_async", [&]() -> int { return mh_icp_linearize_async_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
 }
 
+// One flagged word (icp_device.hpp): two self-validating 8-byte halves {lo | seq << 32, hi | seq << 32}.
+static inline bool ll_read_bits(const uint4 * p, unsigned int seq, unsigned long long & bits)
+{
+  const auto * q = reinterpret_cast<const unsigned long long *>(p);
+  const unsigned long long a = __atomic_load_n(q, __ATOMIC_ACQUIRE), b = __atomic_load_n(q + 1, __ATOMIC_ACQUIRE);
+  if (static_cast<unsigned int>(a >> 32) != seq || static_cast<unsigned int>(b >> 32) != seq) return false;
+  bits = (a & 0xffffffffull) | (b << 32);
+  return true;
+}
+static inline bool ll_read(const uint4 * p, unsigned int seq, double & v)
+{
+  unsigned long long bits;
+  if (!ll_read_bits(p, seq, bits)) return false;
+  std::memcpy(&v, &bits, sizeof(v));
+  return true;
+}
+
+// Assemble a call's DeviceResult from its flagged words: sums + counters (from K4's workgroup 0, or from K3's last block when
+// no K4 ran), the eigenbases K4 projected on, and K4's per-workgroup rows folded HERE in workgroup order (deterministic).
+// spin_ns > 0: wait up to that long for words that have not arrived.  false = something is still missing.
+static bool collect_call(const mh_icp * icp, int slot, const PendingCall & pc, long spin_ns, mh::DeviceResult & d)
+{
+  std::memset(&d, 0, sizeof(d));
+  if (pc.seq == 0) return true;  // nothing was launched (empty cloud)
+  const uint4 * base = icp->h_ll + static_cast<size_t>(slot) * icp->ll_words;
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  unsigned spins = 0;
+  auto get = [&](const uint4 * p, double & v) {
+    while (!ll_read(p, pc.seq, v)) {
+      if (spin_ns <= 0) return false;
+      __builtin_ia32_pause();
+      if ((++spins & 1023u) == 0u) {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > spin_ns) return false;
+      }
+    }
+    return true;
+  };
+  const int nent = icp->binary ? 91 : 28;
+  double c4[4];
+  // the words that are written LAST first (K4's rows, when it ran): once they are here the rest usually is
+  if (pc.launched_k4) {
+    double acc[6] = {0};
+    unsigned long long hist[10] = {0};
+    const uint4 * rows = base + (mh::kLlSums + mh::kLlEig);
+    {
+      // wait for the first word; K4's workgroups end within a microsecond of each other, so by then (nearly) everything has
+      // landed: touch every cache line of the slot at once — the device wrote them over PCIe, each is a miss, and a dozen
+      // misses in flight cost what one does
+      double v0;
+      if (!get(rows, v0)) return false;
+      const char * lo = reinterpret_cast<const char *>(base);
+      const char * hi = reinterpret_cast<const char *>(rows + static_cast<size_t>(pc.loc_blocks) * mh::kLlRow);
+      for (const char * q = lo; q < hi; q += 64) __builtin_prefetch(q);
+    }
+    for (int b = 0; b < pc.loc_blocks; ++b) {
+      const uint4 * row = rows + static_cast<size_t>(b) * mh::kLlRow;
+      for (int i = 0; i < 6; ++i) {
+        double v;
+        if (!get(row + i, v)) return false;
+        acc[i] += v;
+      }
+      for (int i = 0; i < 5; ++i) {  // two 32-bit counts per word
+        double raw;
+        if (!get(row + 6 + i, raw)) return false;
+        unsigned long long bits;
+        std::memcpy(&bits, &raw, sizeof(bits));
+        hist[2 * i] += bits & 0xffffffffull;
+        hist[2 * i + 1] += bits >> 32;
+      }
+    }
+    for (int i = 0; i < 6; ++i) d.loc_comp[i] = acc[i];
+    for (int i = 0; i < 9; ++i) d.status_hist[i] = static_cast<unsigned int>(hist[i]);
+    for (int i = 0; i < 18; ++i) {
+      double v;
+      if (!get(base + mh::kLlSums + i, v)) return false;
+      (i < 9 ? d.eig_rot[i] : d.eig_trans[i - 9]) = v;
+    }
+  }
+  for (int i = 0; i < nent; ++i)
+    if (!get(base + i, d.sums[i])) return false;
+  for (int i = 0; i < 4; ++i)
+    if (!get(base + nent + i, c4[i])) return false;
+  d.n_knn = static_cast<unsigned long long>(c4[0]);
+  d.n_cand = static_cast<unsigned long long>(c4[1]);
+  d.n_fallback = static_cast<unsigned long long>(c4[2]);
+  d.n_scanned = static_cast<unsigned long long>(c4[3]);
+  return true;
+}
+
 static int mh_icp_wait_impl(mh_icp * icp)
 {
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
   mh_ctx * ctx = icp->ctx;
   MH_HIP(ctx, mh_enter(ctx));
-  // Each call's last kernel publishes its sequence number to the mapped host slot after the results: spin on
-  // it instead of paying the runtime's stream-synchronisation latency.  Fall back to the stream when something
-  // was not launched, is being timed by events, or does not show up within the spin budget.
-  bool need_sync = false;
-  for (int s = 0; s < icp->n_pending && !need_sync; ++s) {
-    const PendingCall & pc = icp->pending[s];
-    if (pc.seq == 0 || pc.ev[0]) {
-      need_sync = true;
-      break;
+  // Every value a call produces arrives in mapped pinned memory tagged with the call's sequence number: the host polls the
+  // values themselves instead of paying the runtime's stream-synchronisation latency (or a device-side completion flag
+  // behind a system-scope fence).  Calls timed by HIP events, and anything that does not show up within the spin budget,
+  // fall back to the stream.
+  bool synced = false;
+  for (int s = 0; s < icp->n_pending; ++s)
+    if (icp->pending[s].ev[0] && !synced) {
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      synced = true;
     }
-    const volatile unsigned int * flag = &icp->h_results[s].seq;
-    timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != pc.seq; ++spins) {
-      __builtin_ia32_pause();
-      if ((spins & 1023u) == 1023u) {
-        timespec t1;
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 20000000L) {  // 20 ms
-          need_sync = true;
-          break;
-        }
-      }
-    }
-  }
-  if (need_sync) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < icp->n_pending; ++s) {
     const PendingCall & pc = icp->pending[s];
-    finish_result(icp, icp->h_results[s], pc, pc.out);
+    mh::DeviceResult d;
+    if (!collect_call(icp, s, pc, synced ? 0L : 20000000L, d)) {  // 20 ms
+      if (!synced) {
+        MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        synced = true;
+      }
+      if (!collect_call(icp, s, pc, 2000000L, d)) {
+        icp->n_pending = 0;
+        return fail(ctx, MH_ERR_HIP, "mh_icp_wait: the stream drained without the call's results");
+      }
+    }
+    finish_result(icp, d, pc, pc.out);
     if (pc.ev[0]) {
       (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
       (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
@@ -812,7 +919,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     int tpb, k, n_off;
     bool binary;
     std::vector<size_t> members;
-    int first = 0, grid = 0;
+    int first = 0, grid = 0, grid4 = 0;
   };
   std::vector<Group> groups;
   for (size_t f = 0; f < n_factors; ++f) {
@@ -823,12 +930,12 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     for (Group & q : groups)
       if (q.tpb == tpb && q.k == k && q.n_off == n_off && q.binary == c->binary) g = &q;
     if (!g) {
-      groups.push_back(Group{tpb, k, n_off, c->binary, {}, 0, 0});
+      groups.push_back(Group{tpb, k, n_off, c->binary, {}, 0, 0, 0});
       g = &groups.back();
     }
     g->members.push_back(f);
   }
-  const size_t ab = sizeof(mh::IcpArgs) * kMaxBatch, lb = sizeof(mh::LocArgs) * kMaxBatch, sb = sizeof(int) * 2 * (kMaxBatch + 1);
+  const size_t ab = sizeof(mh::IcpArgs) * kMaxBatch, lb = sizeof(mh::LocArgs) * kMaxBatch, sb = sizeof(int) * 4 * (kMaxBatch + 1);  // two prefix tables (K3b, K4b), each up to factors + groups entries
   const size_t total = ((ab + lb + sb + 255) & ~size_t(255)) + 256;
   if (!ctx->h_batch) MH_HIP(ctx, hipHostMalloc(&ctx->h_batch, total, hipHostMallocDefault));
   if (!ctx->d_batch) MH_HIP(ctx, hipMalloc(&ctx->d_batch, total));
@@ -853,10 +960,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     const int rc = linearize_prepare(icps[f], R_src + 9 * f, t_src + 3 * f, R_tgt ? R_tgt + 9 * f : nullptr,
                                      t_tgt ? t_tgt + 3 * f : nullptr, g_unit + 3 * f, out + f, true, false, a, l, timed);
     if (rc != MH_OK) return rc;
-    if (icps[f]->n == 0) {
-      std::memset(&icps[f]->h_results[0], 0, sizeof(mh::DeviceResult));
-      continue;
-    }
+    if (icps[f]->n == 0) continue;  // (pc.seq == 0: an all-zero result is assembled at the wait)
     h_a[slot_of[f]] = a;
     h_l[slot_of[f]] = l;
   }
@@ -864,20 +968,29 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
   // them, geometric.cpp:205-214 is the only reader); a mixed batch runs it for all, the others report NaN all the same
   bool any_components = false;
   for (size_t f = 0; f < n_factors; ++f) any_components = any_components || (icps[f]->n && icps[f]->components);
-  if (!any_components)
-    for (size_t f = 0; f < n_factors; ++f)
-      if (icps[f]->n) h_a[slot_of[f]].seq = h_l[slot_of[f]].seq;
+  for (size_t f = 0; f < n_factors; ++f)
+    if (icps[f]->n) h_a[slot_of[f]].tail = any_components ? 0 : 1;  // K4b follows and folds the rows / K3b is the whole call
   bool inline_args = true;
+  int * h_s4 = h_s + 2 * (kMaxBatch + 1);  // the same prefixes for K4b's (smaller) per-factor grids
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     Group & g = groups[gi];
     int * start = h_s + g.first + static_cast<int>(gi);  // prefix of the group's grids, in slot order
-    int acc = 0;
+    int * start4 = h_s4 + g.first + static_cast<int>(gi);
+    int acc = 0, acc4 = 0;
     for (size_t i = 0; i < g.members.size(); ++i) {
+      const int slot = g.first + static_cast<int>(i);
       start[i] = acc;
-      acc += mh::batch_grid(h_a[g.first + static_cast<int>(i)].n, g.tpb);
+      start4[i] = acc4;
+      acc += mh::batch_grid(h_a[slot].n, g.tpb);
+      acc4 += mh::batch_loc_grid(h_a[slot].n, g.tpb);
+      h_l[slot].k3_blocks = mh::batch_grid(h_a[slot].n, g.tpb);
+      h_l[slot].chunks_per_block = mh::kLocChunks;
+      icps[g.members[i]]->pending[0].loc_blocks = mh::batch_loc_grid(h_a[slot].n, g.tpb);
     }
     start[g.members.size()] = acc;
+    start4[g.members.size()] = acc4;
     g.grid = acc;
+    g.grid4 = acc4;
     inline_args = inline_args && static_cast<int>(g.members.size()) <= mh::kBatchInline;
   }
   if (!groups.empty()) {
@@ -895,13 +1008,13 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
       }
       for (size_t gi = 0; gi < groups.size() && any_components; ++gi) {
         const Group & g = groups[gi];
-        const int * start = h_s + g.first + static_cast<int>(gi);
+        const int * start4 = h_s4 + g.first + static_cast<int>(gi);
         mh::BatchInline<mh::LocArgs> blk;
         std::memset(static_cast<void *>(&blk), 0, sizeof(blk));
         for (size_t i = 0; i < g.members.size(); ++i) blk.a[i] = h_l[g.first + static_cast<int>(i)];
-        for (size_t i = 0; i <= g.members.size(); ++i) blk.start[i] = start[i];
+        for (size_t i = 0; i <= g.members.size(); ++i) blk.start[i] = start4[i];
         blk.n = static_cast<int>(g.members.size());
-        MH_HIP(ctx, mh::launch_localizability_batch_inline(blk, g.grid, g.tpb, ctx->stream));
+        MH_HIP(ctx, mh::launch_localizability_batch_inline(blk, g.grid4, g.tpb, ctx->stream));
       }
     } else {
       char * d = static_cast<char *>(ctx->d_batch);
@@ -915,18 +1028,20 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
       for (size_t gi = 0; gi < groups.size() && any_components; ++gi) {
         const Group & g = groups[gi];
         const auto * dl = reinterpret_cast<const mh::LocArgs *>(d + ab) + g.first;
-        const int * ds = reinterpret_cast<const int *>(d + ab + lb) + g.first + static_cast<int>(gi);
-        MH_HIP(ctx, mh::launch_localizability_batch(dl, ds, static_cast<int>(g.members.size()), g.grid, g.tpb, ctx->stream));
+        const int * ds4 = reinterpret_cast<const int *>(d + ab + lb) + 2 * (kMaxBatch + 1) + g.first + static_cast<int>(gi);
+        MH_HIP(ctx, mh::launch_localizability_batch(dl, ds4, static_cast<int>(g.members.size()), g.grid4, g.tpb, ctx->stream));
       }
     }
   }
   if (any_components)
     for (size_t f = 0; f < n_factors; ++f)
-      if (icps[f]->n && icps[f]->components) icps[f]->pending[0].seq_has_basis = true;  // K4b wrote the bases it used
+      if (icps[f]->n) {
+        icps[f]->pending[0].launched_k4 = true;  // its sums come from K4b's workgroup 0
+        if (icps[f]->components) icps[f]->pending[0].seq_has_basis = true;  // ... and K4b published the bases it used
+      }
   for (LinearizeTxn & t : txns) t.commit();
   int rc_all = MH_OK;
   for (size_t f = 0; f < n_factors; ++f) {
-    if (icps[f]->n == 0) icps[f]->pending[0].seq = 0;  // nothing was launched for it: falls back to a stream sync
     const int rc = mh_icp_wait(icps[f]);
     if (rc != MH_OK) rc_all = rc;
   }
@@ -977,7 +1092,12 @@ static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9]
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // e18 is a stack buffer
   mh::LocArgs l;
   l.host_result = icp->d_h_results;  // slot 0
-  l.seq = 0xFFFFFFFFu;  // not waited on by flag: the call below synchronises the stream
+  l.seq = 0;
+  l.ll = nullptr;
+  l.k3_blocks = 0;
+  // the device-folding instantiation (the one the map-sharded factors use): it takes its point count from the device
+  MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), static_cast<int>(icp->n), 1, ctx->stream));
+  l.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
   l.eig = static_cast<const double *>(icp->d_eig.p);
   l.nv = icp->binary ? 13 : 7;
   l.src = static_cast<const float4 *>(icp->d_src.p);
@@ -1724,7 +1844,12 @@ static int mh_icp_linearize_begin_device_impl(mh_icp * icp, const double R_src[9
   LinearizeTxn txn(icp);
   const int rc = linearize_prepare(icp, R_src, t_src, nullptr, nullptr, g_unit, &scratch, false, false, a, l, timed);
   if (rc != MH_OK) return rc;
-  a.host_result = nullptr;  // results stay on the device
+  a.host_result = nullptr;  // results stay on the device: the device-folding instantiation (point count read from the device)
+  a.ll = nullptr;
+  if (a.n > 0) {
+    MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), a.n, 1, ctx->stream));
+    a.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
+  }
   if (a.n > 0)
     MH_HIP(ctx, mh::launch_linearize(a, false, ctx->stream));
   else
@@ -1753,6 +1878,10 @@ static int mh_icp_linearize_finish_device_impl(mh_icp * icp, const double * d_gl
     mh::LocArgs l;
     l.host_result = nullptr;
     l.seq = 0;
+    l.ll = nullptr;
+    l.k3_blocks = 0;
+    MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), static_cast<int>(icp->n), 1, ctx->stream));
+    l.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
     l.eig = static_cast<const double *>(icp->d_eig.p);
     l.nv = 7;
     l.src = static_cast<const float4 *>(icp->d_src.p);

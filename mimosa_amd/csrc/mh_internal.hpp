@@ -531,6 +531,8 @@ struct PendingCall
   unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
   bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
   bool seq_has_basis = false;  // ... and wrote the eigenbases it projected on into the call's result slot
+  int loc_blocks = 0;          // plain factors: K4's workgroups of this call = rows of flagged words the host folds
+  bool launched_k4 = false;    // plain factors: the call's sums come from K4's workgroup 0 (else from K3's last block)
   hipEvent_t ev[3];
 };
 
@@ -545,8 +547,11 @@ struct mh_icp
   bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
   double split_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // delta rotation of an open mh_icp_linearize_begin
   bool split_open = false;
-  mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly
+  mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly (two-phase callers)
   mh::DeviceResult * d_h_results = nullptr;  // its device-side address
+  uint4 * h_ll = nullptr;     // pinned, mapped ring of flagged-word slots (icp_device.hpp): what a plain call's kernels publish
+  uint4 * d_h_ll = nullptr;   // its device-side address
+  size_t ll_words = 0;        // 16-byte words per slot
   PendingCall pending[kMaxPending];
   int n_pending = 0;
   int parity = 0;
