@@ -62,6 +62,7 @@ def parse():
                     help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
                          "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
     ap.add_argument("--hostile-rooms", type=str, default="2x5", help="rooms of the hostile second workload (mimosa_amd/synth_hostile.py); none = skip it and the moving-pose leg")
+    ap.add_argument("--leaf1-rooms", type=str, default="4x5", help="rooms of the leaf-1.0 / min-dist-0.2 workload (config/hornbill/params.yaml:86-95); none = skip it")
     ap.add_argument("--hostile-poses", type=int, default=5, help="past scans per room the hostile map is built from")
     ap.add_argument("--sharded", action="store_true", help="(kept for old command lines: the map-sharded leg now runs by default, at --gpus 1 too)")
     ap.add_argument("--shard-block-log2", type=int, default=3, help="shard blocks of 2^n voxels per axis (3: 4 m cubes at the 0.5 m leaf)")
@@ -959,6 +960,80 @@ def main():
         except Exception as exc:  # noqa: BLE001 - reported in the line
             hostile = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # The parameter block most shipped configurations use (config/hornbill/params.yaml:86-95; euroc, lapwing, magpie, parrot
+    # alike): 1 m leaf, 0.2 m minimum distance.  The same scan against a >= 5 M-point map built with that block — voxels AT the
+    # 20-point cap, ~190 candidates per query (up to 380): the regime the box pruning and the proof check were not tuned on.
+    leaf1 = None
+    if not args.profile_mode and world == 1 and args.leaf1_rooms != "none":
+        try:
+            from mimosa_amd import synth_hostile as sh1
+            hcfg = synth.hornbill_config()
+            lnx, lny = (int(v) for v in args.leaf1_rooms.lower().split("x"))
+            t0l = time.time()
+            lmap = capi.VoxelMap(ctx, leaf=hcfg["target_ivox_map_leaf_size"], min_dist=hcfg["target_ivox_map_min_dist_in_voxel"],
+                                 max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+            lrooms = [xyz for _, _, xyz in synth.make_hornbill_rooms(lnx, lny)]
+            for xyz in lrooms:
+                lmap.insert(xyz)
+            lstats = lmap.stats()
+            lbuild = time.time() - t0l
+            lf = capi.ICPFactor(ctx, lmap, pts, capi.make_reg_config(**hcfg))
+            lres = lf.linearize(R, t)
+            ctx.set_profiling(1)
+            lk3, lk4 = [], []
+            for _ in range(24):
+                lf.reset()
+                rr_ = lf.linearize(R, t)
+                lk3.append(rr_["gpu_ms_linearize"])
+                lk4.append(rr_["gpu_ms_localizability"])
+            ctx.set_profiling(False)
+            l_step = _round_robin([lf], [(R, t)], max(40, args.steps // 2))
+            lsync = []
+            for _ in range(20):
+                lf.reset()
+                ctx.synchronize()
+                a = time.perf_counter()
+                lf.linearize(R, t)
+                lsync.append(time.perf_counter() - a)
+            lcloud = lmap.get_cloud()
+            lfill = sh1.voxel_fill_stats(lcloud, hcfg["target_ivox_map_leaf_size"], synth.MAX_PTS_PER_VOXEL)
+            _p1 = np.asarray(pts)
+            _p1 = np.stack([_p1["x"], _p1["y"], _p1["z"]], 1).astype(np.float64)
+            lq = _p1 @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
+            lcq = sh1.candidate_stats(lcloud, lq, hcfg["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE)
+            lk3_s = float(np.mean(lk3[4:])) * 1e-3
+            l_bpt = 384.0 + 16.0 * float(lres["mean_candidates"])
+            leaf1 = {"workload": f"the {n_pts}-pt OS0-128 scan vs a {lstats['n_points']}-pt map built with config/hornbill/params.yaml:86-95 (leaf 1.0 m, min-dist 0.2 m; "
+                                 f"{lnx}x{lny} rooms, walls sampled every {synth.HORNBILL_GRID} m), k = 5, mode 19, cold linearize per step",
+                     "value": round(n_pts / l_step / 1e6, 2), "ms_per_step": round(l_step * 1e3, 5), "unit": "Mpts/s",
+                     "sync_latency_ms": round(float(np.median(lsync)) * 1e3, 4),
+                     "kernel_ms_avg": round(float(np.mean(lk3[4:])), 5), "localizability_kernel_ms_avg": round(float(np.mean(lk4[4:])), 5),
+                     "map_points": int(lstats["n_points"]), "map_voxels": int(lstats["n_voxels"]),
+                     "voxel_fill": {k_: round(v_, 4) if isinstance(v_, float) else v_ for k_, v_ in lfill.items()},
+                     "share_of_voxels_at_cap": round(float(lfill["share_at_cap"]), 4),
+                     "candidates_per_query": {k_: round(v_, 3) if isinstance(v_, float) else v_ for k_, v_ in lcq.items()},
+                     "mean_candidates": round(float(lres["mean_candidates"]), 2), "mean_scanned_after_pruning": round(float(lres["mean_scanned"]), 2),
+                     "exact_fallback_queries": int(lres["n_exact_fallback"]), "status_hist": [int(v) for v in lres["status_hist"]],
+                     "roofline": {"bound": "hbm", "bytes_per_point": round(l_bpt, 1), "achieved": round(n_pts * l_bpt / lk3_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(n_pts * l_bpt / lk3_s / 1e9 / HBM_PEAK_GBS, 4),
+                                  "note": "the same gather model as the headline (384 + 16 C_q bytes per point, no reuse credited): a work-equivalent figure, see roofline.frac_note"},
+                     "world_build_s": round(lbuild, 1)}
+            if not args.no_cpu_baseline:
+                from oracle import ref_cpu
+                lrm = ref_cpu.Map(leaf=hcfg["target_ivox_map_leaf_size"], min_dist=hcfg["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+                                  mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+                for xyz in lrooms:
+                    lrm.insert(xyz)
+                secs_l, lref = ref_cpu.time_cold(lrm, pts, ref_cpu.make_config(**hcfg), R, t, n_threads=4, iters=3)
+                leaf1["parity_vs_oracle"] = {"H_rel": float(np.linalg.norm(lres["H_ss"] - lref["H_ss"]) / np.linalg.norm(lref["H_ss"])),
+                                             "f_rel": abs(lres["f"] - lref["f"]) / abs(lref["f"]),
+                                             "status_hist_equal": bool(np.array_equal(lres["status_hist"], lref["status_hist"]))}
+                leaf1["cpu_oracle_4_threads_mpts_s"] = round(n_pts / float(np.median(secs_l[1:])) / 1e6, 3)
+            lf.destroy()
+            lmap.release()
+        except Exception as exc:  # noqa: BLE001 - reported in the line
+            leaf1 = {"error": f"{type(exc).__name__}: {exc}"}
+
     cand_stats = None
     if rank == 0 and not args.profile_mode:
         try:  # what the reference's k-NN scans per query on this world: the tail sets K3's slowest wave
@@ -1055,6 +1130,7 @@ def main():
         "relinearize_window": win_stats,
         "moving_pose": moving,
         "hostile_world": hostile,
+        "leaf1_world": leaf1,
         "photometric": ph_stats,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,

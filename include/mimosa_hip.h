@@ -645,6 +645,12 @@ int mh_shard_icp_get_state(mh_shard_icp * icp, uint64_t * origin, int32_t * stat
 int mh_shard_icp_stats(const mh_shard_icp * icp, mh_shard_stats * out);
 void mh_shard_icp_destroy(mh_shard_icp * icp);
 
+/* ---- diagnostics -------------------------------------------------------------------------------------------------------
+ * With MH_ALLOC_CHECK=1 in the environment the device-allocation cache checks its hand-over rule (a block is re-used only
+ * behind everything that was enqueued on it): freed blocks are poisoned behind their last use, verified when they are handed
+ * out again.  blocks_verified / words_overwritten so far; MH_ERR_UNSUPPORTED when the check is off.  No reference counterpart. */
+int mh_alloc_check_stats(unsigned long long * blocks_verified, unsigned long long * words_overwritten);
+
 #ifdef __cplusplus
 }
 #endif

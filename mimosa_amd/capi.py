@@ -32,7 +32,7 @@ EXPORTS = [
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
     "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
     "mh_shard_icp_linearize_batch_async", "mh_shard_icp_wait", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
-    "mh_shard_icp_stats", "mh_shard_icp_destroy",
+    "mh_shard_icp_stats", "mh_shard_icp_destroy", "mh_alloc_check_stats",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
     "mh_photo_num_features", "mh_photo_get_features", "mh_photo_set_features", "mh_photo_detect_features", "mh_photo_update_map",
     "mh_photo_factor_create", "mh_photo_factor_clone", "mh_photo_factor_destroy", "mh_photo_factor_linearize", "mh_photo_factor_linearize_async", "mh_photo_factor_wait", "mh_photo_factor_get_state", "mh_photo_factor_size",
@@ -405,6 +405,7 @@ def load(build_if_missing: bool = True):
     L.mh_shard_icp_set_components.argtypes = [vp, C.c_int]
     L.mh_shard_icp_get_state.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.mh_shard_icp_stats.argtypes = [vp, C.POINTER(ShardStats)]
+    L.mh_alloc_check_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.mh_shard_icp_destroy.argtypes = [vp]
     L.mh_shard_icp_destroy.restype = None
     L.mh_photo_create.argtypes = [vp, C.POINTER(PhotoConfig), pvp]
@@ -941,6 +942,14 @@ def sharded_linearize_batch_async(factors, Rs, ts, g_units=None, R_tgts=None, t_
     a = _ShardBatchArgs(factors, Rs, ts, g_units, R_tgts, t_tgts)
     factors[0].ctx.check(factors[0].L.mh_shard_icp_linearize_batch_async(*a.args()))
     return a
+
+
+def alloc_check_stats():
+    """(blocks verified at hand-out, words found overwritten) of the allocation cache's MH_ALLOC_CHECK mode; None when it is off."""
+    a, b = C.c_ulonglong(), C.c_ulonglong()
+    if load().mh_alloc_check_stats(C.byref(a), C.byref(b)) != 0:
+        return None
+    return int(a.value), int(b.value)
 
 
 def map_insert_shard(ctx: Context, vmap: VoxelMap, xyz, world: int, rank: int, block_log2: int = 3):

@@ -1302,15 +1302,16 @@ void mh_scan_destroy(mh_scan * s)
   if (!s) return;
   (void)mh_enter(s->ctx);
   (void)hipStreamSynchronize(s->ctx->stream);
+  // a staged upload (mh_scan_prefetch, on the context's copy stream) may still be WRITING d_raw: it is not "drained" before
+  // that copy has finished
+  if (s->copy_done) (void)hipEventSynchronize(s->copy_done);
   s->d_full_raw.release(true);
   for (DevBuf * b : {&s->d_raw, &s->d_full, &s->d_geo_idx, &s->d_unique, &s->d_body, &s->d_ds, &s->d_kept_idx, &s->d_counters,
                      &s->d_rt, &s->d_prep, &s->d_vox, &s->d_sensor})
     b->release(true);
   AllocCache::free_pinned(s->h_c, sizeof(mh::ScanCounters) + mh_scan::kUniqueCached * sizeof(uint32_t));
-  if (s->copy_done) {
-    (void)hipEventSynchronize(s->copy_done);  // a staged upload may still be reading the staging buffer
-    (void)hipEventDestroy(s->copy_done);
-  }
+  if (s->copy_done) (void)hipEventDestroy(s->copy_done);
+  if (s->compute_mark) (void)hipEventDestroy(s->compute_mark);
   if (s->h_stage) AllocCache::free_pinned(s->h_stage, s->h_stage_cap);
   if (s->rt_done) {
     (void)hipEventSynchronize(s->rt_done);
@@ -1334,6 +1335,13 @@ static int scan_prepare_common(mh_scan * s, const mh_ouster_point * raw, bool ra
   s->n_in = n;
   s->n_body = 0;
   const size_t m = n ? n : 1;
+  if (!raw_on_device && s->copy_done) {
+    // a plain prepare behind a prefetch nobody consumed: the copy stream may still write d_raw — order this stream behind it,
+    // and the staged cloud is gone
+    MH_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->copy_done, 0));
+    s->prefetch_valid = false;
+    s->n_prefetched = 0;
+  }
   if (!raw_on_device) MH_HIP(ctx, s->d_raw.reserve(m * sizeof(mh_ouster_point), ctx->stream, false));
   MH_HIP(ctx, s->d_full.reserve(m * sizeof(mh_point32), ctx->stream, false));
   MH_HIP(ctx, s->d_geo_idx.reserve(m * sizeof(uint32_t), ctx->stream, false));
@@ -1375,6 +1383,12 @@ static int mh_scan_prefetch_impl(mh_scan * s, const mh_ouster_point * raw, size_
     copy_stream = ctx->copy_stream;
   }
   if (!s->copy_done) MH_HIP(ctx, hipEventCreateWithFlags(&s->copy_done, hipEventDisableTiming));
+  if (!s->compute_mark) MH_HIP(ctx, hipEventCreateWithFlags(&s->compute_mark, hipEventDisableTiming));
+  // d_raw is about to be overwritten (perhaps re-allocated) from the copy stream: everything the compute stream has enqueued
+  // on this scan so far may read it, so the copy stream queues behind that point.  (This is what makes "freed on the stream
+  // that last used it" — the allocation cache's hand-over rule — true for d_raw.)
+  MH_HIP(ctx, hipEventRecord(s->compute_mark, ctx->stream));
+  MH_HIP(ctx, hipStreamWaitEvent(copy_stream, s->compute_mark, 0));
   g_mh_stream = copy_stream;  // what this call allocates / frees is ordered by the copy stream
   const size_t bytes = (n ? n : 1) * sizeof(mh_ouster_point);
   if (bytes > s->h_stage_cap) {
@@ -1947,6 +1961,39 @@ int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double l
 }  // extern "C"
 
 // ---- internals shared with shard_api.hip (declared in mh_internal.hpp) ---------------------------------------------
+// MH_ALLOC_CHECK (mh_internal.hpp): words of a re-used cached block that are not the poison pattern any more
+namespace mh
+{
+namespace
+{
+__global__ void alloc_verify_kernel(const unsigned int * p, size_t n_words, unsigned long long * violations)
+{
+  unsigned long long bad = 0;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n_words; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    bad += p[i] != kAllocPoison ? 1ull : 0ull;
+  if (bad) atomicAdd_system(violations, bad);
+}
+}  // namespace
+hipError_t launch_alloc_verify(const void * p, size_t bytes, unsigned long long * violations, hipStream_t stream)
+{
+  unsigned long long * d_v = nullptr;
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&d_v), violations, 0) != hipSuccess) return hipErrorInvalidValue;
+  const size_t n = bytes / 4;
+  const int grid = static_cast<int>(std::min<size_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(alloc_verify_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, static_cast<const unsigned int *>(p), n, d_v);
+  return hipGetLastError();
+}
+}  // namespace mh
+
+extern "C" int mh_alloc_check_stats(unsigned long long * blocks_verified, unsigned long long * words_overwritten)
+{
+  if (!AllocCache::checking() || !AllocCache::check_counters()) return MH_ERR_UNSUPPORTED;
+  (void)hipDeviceSynchronize();
+  if (blocks_verified) *blocks_verified = AllocCache::check_counters()[0];
+  if (words_overwritten) *words_overwritten = AllocCache::check_counters()[1];
+  return MH_OK;
+}
+
 namespace mhi
 {
 void pose_delta(const double * Rs, const double * ts, const double * Rt, const double * tt, double * R, double * t)

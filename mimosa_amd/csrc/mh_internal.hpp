@@ -94,9 +94,40 @@ inline int guarded(const mh_ctx * ctx, const char * what, E && body)
 // before the free); whoever takes the block next on the same stream simply queues behind, on another stream waits for the
 // event on the device.  (Round 2 drained the whole device per free, which stalled the photometric stream behind the
 // geometric one and vice versa.)
+// MH_ALLOC_CHECK=1 (environment, diagnostic): the rule above is CHECKED.  Every block that goes back to the cache is
+// poisoned on the freeing stream (a fill behind everything that stream enqueued on it, in front of the release event), and
+// every cached block that is handed out again is verified on the taker's stream behind the event: a word that is not the
+// poison pattern any more was written by work that was NOT ordered in front of the free — a user on another stream the
+// freeing thread did not wait for.  Reads of that kind see the pattern and fail the parity suites.  Violations are counted
+// in mapped host memory (mh_alloc_check_stats) and reported when the last context of the process is shut down.
+namespace mh
+{
+hipError_t launch_alloc_verify(const void * p, size_t bytes, unsigned long long * violations, hipStream_t stream);  // mh_api.hip
+}
+constexpr unsigned int kAllocPoison = 0xA5C3A5C3u;
+
 class AllocCache
 {
 public:
+  static bool checking()
+  {
+    static const bool on = [] {
+      const char * e = std::getenv("MH_ALLOC_CHECK");
+      return e && *e && *e != '0';
+    }();
+    return on;
+  }
+  // [0] blocks verified at hand-out, [1] words found overwritten; mapped pinned (the verify kernel adds to [1])
+  static unsigned long long * check_counters()
+  {
+    static unsigned long long * c = [] {
+      void * p = nullptr;
+      if (hipHostMalloc(&p, 2 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return static_cast<unsigned long long *>(nullptr);
+      std::memset(p, 0, 2 * sizeof(unsigned long long));
+      return static_cast<unsigned long long *>(p);
+    }();
+    return c;
+  }
   static hipError_t alloc(void ** out, size_t bytes)
   {
     const size_t cls = size_class(bytes);
@@ -104,36 +135,8 @@ public:
     (void)hipGetDevice(&dev);
     if (cls) {
       Cached c{};
-      bool hit = false;
-      {
-        std::lock_guard<std::mutex> g(mu());
-        auto & v = free_list()[key(dev, cls)];
-        if (!v.empty()) {
-          // prefer a block nobody can still be using, or one whose last use was ordered on THIS stream: taking another
-          // stream's block makes this stream wait (on the device) for that stream to get there
-          size_t pick = v.size() - 1;
-          for (size_t i = v.size(); i-- > 0;)
-            if (!v[i].ev || v[i].stream == g_mh_stream) {
-              pick = i;
-              break;
-            }
-          c = v[pick];
-          v[pick] = v.back();
-          v.pop_back();
-          cached_bytes()[dev] -= cls;
-          live()[c.p] = Block{cls, dev};
-          hit = true;
-        }
-      }
-      if (hit) {
-        if (c.ev) {
-          if (!g_mh_stream)
-            (void)hipEventSynchronize(c.ev);
-          else if (c.stream != g_mh_stream)
-            (void)hipStreamWaitEvent(g_mh_stream, c.ev, 0);
-          std::lock_guard<std::mutex> g(mu());
-          event_pool().push_back(c.ev);
-        }
+      if (take(dev, cls, true, c)) {
+        hand_over(c, dev, cls);
         *out = c.p;
         return hipSuccess;
       }
@@ -148,27 +151,8 @@ public:
       // out of memory: a cached block that is still in flight on another stream is better than none
       (void)hipGetLastError();
       Cached c{};
-      bool hit = false;
-      {
-        std::lock_guard<std::mutex> g(mu());
-        auto & v = free_list()[key(dev, cls)];
-        if (!v.empty()) {
-          c = v.back();
-          v.pop_back();
-          cached_bytes()[dev] -= cls;
-          live()[c.p] = Block{cls, dev};
-          hit = true;
-        }
-      }
-      if (hit) {
-        if (c.ev) {
-          if (!g_mh_stream)
-            (void)hipEventSynchronize(c.ev);
-          else if (c.stream != g_mh_stream)
-            (void)hipStreamWaitEvent(g_mh_stream, c.ev, 0);
-          std::lock_guard<std::mutex> g(mu());
-          event_pool().push_back(c.ev);
-        }
+      if (take(dev, cls, false, c)) {
+        hand_over(c, dev, cls);
         *out = c.p;
         return hipSuccess;
       }
@@ -181,7 +165,8 @@ public:
     return e;
   }
   // drained: the caller has already waited for every stream that ever touched the block (a factor's or a scan's own
-  // buffers after a synchronisation of their context's stream): it can be handed out at once
+  // buffers after a synchronisation of their context's stream — and of the copy stream where one wrote them): it can be
+  // handed out at once
   static void free(void * p, bool drained = false)
   {
     if (!p) return;
@@ -195,14 +180,23 @@ public:
       }
     }
     if (b.cls) {
-      Cached c{p, nullptr, nullptr};
+      Cached c{p, nullptr, nullptr, false};
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      const bool same_dev = cur == b.dev;
+      if (checking() && same_dev && g_mh_stream) {
+        // poison behind the freeing stream's work on the block (for a drained block: behind nothing — it is idle)
+        c.poisoned = hipMemsetD32Async(p, static_cast<int>(kAllocPoison), b.cls / 4, g_mh_stream) == hipSuccess;
+        if (drained && c.poisoned) drained = false;  // the fill itself is in flight now: hand over behind an event
+      }
       if (!drained) {
-        if (g_mh_stream) {
+        if (g_mh_stream && same_dev) {  // (an event of one device cannot be recorded on a stream of another)
           {
             std::lock_guard<std::mutex> g(mu());
-            if (!event_pool().empty()) {
-              c.ev = event_pool().back();
-              event_pool().pop_back();
+            auto & pool = event_pool()[b.dev];
+            if (!pool.empty()) {
+              c.ev = pool.back();
+              pool.pop_back();
             }
           }
           if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
@@ -213,13 +207,7 @@ public:
             c.ev = nullptr;
           }
         }
-        if (!c.ev) {  // no stream known for this thread: the old way, on the block's own device
-          int cur = 0;
-          (void)hipGetDevice(&cur);
-          if (cur != b.dev) (void)hipSetDevice(b.dev);
-          (void)hipDeviceSynchronize();
-          if (cur != b.dev) (void)hipSetDevice(cur);
-        }
+        if (!c.ev) drain_device(b.dev);  // no stream known for this thread: the old way, on the block's own device
       }
       std::lock_guard<std::mutex> g(mu());
       if (cached_bytes()[b.dev] + b.cls <= kMaxCachedBytes) {
@@ -227,7 +215,7 @@ public:
         cached_bytes()[b.dev] += b.cls;
         return;
       }
-      if (c.ev) event_pool().push_back(c.ev);  // (the block itself goes back to the runtime below: hipFree waits for the device)
+      if (c.ev) event_pool()[b.dev].push_back(c.ev);  // (the block itself goes back to the runtime below: hipFree waits for the device)
     }
     (void)hipFree(p);
   }
@@ -258,15 +246,14 @@ public:
     }
     (void)hipHostFree(p);
   }
-  // mh_shutdown of the last context of a device: give the cached blocks of that device back to the runtime
   // context bookkeeping (mh_init / mh_shutdown): per device, under the cache mutex
   static void context_created(int dev)
   {
     std::lock_guard<std::mutex> g(mu());
     contexts_of()[dev]++;
   }
-  // true when this was the device's last context (its cached blocks go back to the runtime; the pinned ones when no context
-  // is left on any device)
+  // the device's last context gives its cached blocks back to the runtime (the pinned ones go when no context is left on any
+  // device)
   static void context_destroyed(int dev)
   {
     bool last_of_device = false;
@@ -281,20 +268,22 @@ public:
   static void trim(int dev)
   {
     std::vector<void *> dead, dead_pinned;
+    bool none_left = false;
     {
       std::lock_guard<std::mutex> g(mu());
       for (auto & kv : free_list())
         if (static_cast<int>(kv.first >> 56) == dev) {
           for (const Cached & c : kv.second) {
             dead.push_back(c.p);
-            if (c.ev) event_pool().push_back(c.ev);
+            if (c.ev) event_pool()[dev].push_back(c.ev);
           }
           kv.second.clear();
         }
       cached_bytes()[dev] = 0;
       int total = 0;
       for (const auto & kv : contexts_of()) total += kv.second;
-      if (total == 0)
+      none_left = total == 0;
+      if (none_left)
         for (auto & kv : pinned()) {
           dead_pinned.insert(dead_pinned.end(), kv.second.begin(), kv.second.end());
           kv.second.clear();
@@ -302,6 +291,11 @@ public:
     }
     for (void * p : dead) (void)hipFree(p);
     for (void * p : dead_pinned) (void)hipHostFree(p);
+    if (none_left && checking() && check_counters()) {
+      (void)hipDeviceSynchronize();
+      std::fprintf(stderr, "MH_ALLOC_CHECK: %llu cached blocks verified at hand-out, %llu overwritten words found\n", check_counters()[0], check_counters()[1]);
+      if (check_counters()[1]) std::abort();  // diagnostic mode: a process that broke the rule does not exit quietly
+    }
   }
 
 private:
@@ -320,10 +314,71 @@ private:
     void * p;
     hipStream_t stream;  // where the free was ordered; null with ev == null: nobody is using the block
     hipEvent_t ev;
+    bool poisoned;       // MH_ALLOC_CHECK: filled with kAllocPoison behind its last use
   };
-  static std::vector<hipEvent_t> & event_pool()
+  static void drain_device(int dev)
   {
-    static std::vector<hipEvent_t> v;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur != dev) (void)hipSetDevice(cur);
+  }
+  // a cached block of the class, preferring (prefer_idle) one nobody can still be using or whose last use was ordered on
+  // THIS stream: taking another stream's block makes this stream wait (on the device) for that stream to get there
+  static bool take(int dev, size_t cls, bool prefer_idle, Cached & c)
+  {
+    std::lock_guard<std::mutex> g(mu());
+    auto & v = free_list()[key(dev, cls)];
+    if (v.empty()) return false;
+    size_t pick = v.size() - 1;
+    if (prefer_idle)
+      for (size_t i = v.size(); i-- > 0;)
+        if (!v[i].ev || v[i].stream == g_mh_stream) {
+          pick = i;
+          break;
+        }
+    c = v[pick];
+    v[pick] = v.back();
+    v.pop_back();
+    cached_bytes()[dev] -= cls;
+    live()[c.p] = Block{cls, dev};
+    return true;
+  }
+  // order the taker behind the block's release; a wait that cannot be set up (a stale stream after mh_shutdown, an event the
+  // runtime rejects) falls back to draining the block's device — never hands the block out unordered
+  static void hand_over(Cached & c, int dev, size_t cls)
+  {
+    if (c.ev) {
+      hipError_t e = hipSuccess;
+      if (!g_mh_stream)
+        e = hipEventSynchronize(c.ev);
+      else if (c.stream != g_mh_stream)
+        e = hipStreamWaitEvent(g_mh_stream, c.ev, 0);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipEventSynchronize(c.ev) != hipSuccess) {
+          (void)hipGetLastError();
+          drain_device(dev);
+        }
+      }
+      std::lock_guard<std::mutex> g(mu());
+      event_pool()[dev].push_back(c.ev);
+      c.ev = nullptr;
+    }
+    if (c.poisoned && checking() && check_counters()) {
+      if (g_mh_stream) {
+        __atomic_fetch_add(&check_counters()[0], 1ull, __ATOMIC_RELAXED);
+        (void)mh::launch_alloc_verify(c.p, cls, check_counters() + 1, g_mh_stream);
+      }
+      c.poisoned = false;
+    }
+  }
+  // events are per DEVICE: one recorded on another device's stream fails, and every free would fall back to draining the
+  // device
+  static std::unordered_map<int, std::vector<hipEvent_t>> & event_pool()
+  {
+    static std::unordered_map<int, std::vector<hipEvent_t>> v;
     return v;
   }
   static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
@@ -436,6 +491,7 @@ struct mh_scan
   bool prepared = false, preprocessed = false;
   // mh_scan_prefetch: the NEXT cloud staged (pinned buffer -> d_raw on a copy stream of its own) while another scan is processed
   hipEvent_t copy_done = nullptr;
+  hipEvent_t compute_mark = nullptr;  // recorded on the compute stream at every prefetch: the copy stream queues behind it
   void * h_stage = nullptr;
   size_t h_stage_cap = 0, n_prefetched = 0;
   bool prefetch_valid = false;

@@ -256,6 +256,25 @@ def enwide_config() -> dict:
     )
 
 
+def hornbill_config() -> dict:
+    """scan_to_map block of config/hornbill/params.yaml:86-100 — the same in euroc, lapwing, magpie and parrot (five of the
+    reference's seven configurations): 1 m leaf, 0.2 m minimum distance.  ~25 points fit a planar 1 m voxel at that spacing,
+    so the voxels of a dense map sit AT the 20-point cap and a query's 19-neighbourhood holds up to 19 x 20 candidates."""
+    return dict(enwide_config(), source_voxel_grid_filter_leaf_size=1.0, source_voxel_grid_min_dist_in_voxel=0.2,
+                target_ivox_map_leaf_size=1.0, target_ivox_map_min_dist_in_voxel=0.2)
+
+
+HORNBILL_GRID = 0.1       # wall sampling of the leaf-1.0 world: dense enough that the greedy 0.2 m rule fills 98 % of the voxels to the cap
+HORNBILL_ROOMS = (4, 5)   # 20 rooms x ~254 k stored points = ~5.07 M points
+
+
+def make_hornbill_rooms(n_rx: int = HORNBILL_ROOMS[0], n_ry: int = HORNBILL_ROOMS[1], seed: int = BASE_SEED, grid: float = HORNBILL_GRID):
+    """Yield (rx, ry, float32 (n, 3)) per room of the leaf-1.0 world: the rooms of make_map_rooms, walls sampled every `grid` metres."""
+    for rx in range(n_rx):
+        for ry in range(n_ry):
+            yield rx, ry, make_room(seed, rx, ry, grid=grid)
+
+
 ENWIDE_NEIGHBOR_MODE = 19
 ENWIDE_LRU_HORIZON = 1000
 MAX_PTS_PER_VOXEL = 20

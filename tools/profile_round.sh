@@ -25,14 +25,18 @@ for pass in \
   timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$i -- $CMD > $OUT/pmc_$i.log 2>&1
 done
 python3 - <<PY
-import csv,glob,collections,json,os
+import csv,glob,collections,json,os,re
+def short(n):
+    n=n.split('(')[0]
+    m=re.search(r'(icp_\w+<[^>]*>|icp_\w+)',n)
+    return m.group(1) if m else n[-60:]
 out={}
 for d in sorted(glob.glob('$OUT/pmc_*/')):
     f=glob.glob(d+'*/*_counter_collection.csv')
     if not f: continue
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
-        acc[r['Kernel_Name'].split('(')[0][-44:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items():
         if 'icp_' in k:
             out.setdefault(k,{}).update({c:sum(x)/len(x) for c,x in v.items()})
@@ -41,7 +45,7 @@ tr=glob.glob('$OUT/stats/*/*_kernel_trace.csv')
 res={}
 if tr:
     for r in csv.DictReader(open(tr[0])):
-        n=r['Kernel_Name'].split('(')[0][-44:]
+        n=short(r['Kernel_Name'])
         if 'icp_' in n and n not in res:
             res[n]={k:r.get(k) for k in ('VGPR_Count','Accum_VGPR_Count','SGPR_Count','LDS_Block_Size','Scratch_Size','Workgroup_Size','Grid_Size')}
 json.dump({'counters':out,'resources':res,'commit':os.environ.get('MH_COMMIT','?'),'round':'$TAG'},open('$OUT/pmc_summary.json','w'),indent=1)
@@ -58,3 +62,6 @@ if k3:
 print(json.dumps(out,indent=1)[:6000])
 PY
 cat $OUT/stats/*/*_kernel_stats.csv | cut -c1-200
+# gpurun merges at most 64 MiB back: keep the summaries, the logs and the stats table, drop the raw per-dispatch tables
+mkdir -p $OUT/keep && cp $OUT/stats/*/*_kernel_stats.csv $OUT/keep/kernel_stats.csv 2>/dev/null
+rm -rf $OUT/pmc_*/ $OUT/stats
