@@ -36,7 +36,8 @@ struct PhotoFrame  // include/mimosa/lidar/photometric_utils.hpp:42-92, shared_p
   mh_ctx * ctx = nullptr;
   int rows = 0, cols = 0, n_poses = 0;
   size_t n_points = 0;
-  DevBuf d_points, d_intensity, d_range, d_dx, d_dy, d_mask, d_idx, d_proj, d_yaw, d_pose_ns, d_pose_Rt;
+  DevBuf d_points, d_intensity, d_range, d_dx, d_dy, d_mask, d_idx, d_proj, d_yaw, d_pose_ns, d_pose_Rt;  // (d_pose_Rt unused: the poses sit behind the timestamps in d_pose_ns)
+  size_t pose_rt_offset = 0;
   void * h_pose = nullptr;  // pinned: the pose table and its timestamps on their way to the device (no pageable copy, no wait)
   size_t h_pose_cap = 0;
   void release_buffers()
@@ -79,7 +80,9 @@ struct mh_photo
   DevBuf d_alt, d_shift, d_hp, d_lp, d_static;
   // per-frame scratch
   DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather;
-  mh::PhotoCounters * h_counters = nullptr;  // pinned, mapped
+  // pinned, mapped: [0] the preprocess kernels' counters (project() errors of a frame), [1] the factor kernels' — a factor
+  // linearize between mh_photo_preprocess_scan_begin and _commit must not erase or mix into the frame's count
+  mh::PhotoCounters * h_counters = nullptr;
   mh::PhotoCounters * d_counters = nullptr;
   float * h_int_out = nullptr;  // pinned staging of the corrected intensities
   size_t h_int_cap = 0;
@@ -326,6 +329,8 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   MH_HIP(ctx, ph->d_mask_raw.reserve(npx, ctx->stream, false));
   MH_HIP(ctx, ph->d_yaw_valid.reserve(npx, ctx->stream, false));
   MH_HIP(ctx, ph->d_int_out.reserve((n ? n : 1) * sizeof(float), ctx->stream, false));
+  const void * pose_src = nullptr;
+  size_t pose_bytes = 0;
   {
     const size_t b_ns = (n_groups * sizeof(uint32_t) + 255) & ~size_t(255), b_rt = n_groups * 12 * sizeof(double);
     size_t cap = size_t(64) << 10;
@@ -340,10 +345,11 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
     // copy kernels reading the mapped block (see mh_scan_deskew: a small hipMemcpyAsync can block behind another thread's upload)
     void * d_src = nullptr;
     MH_HIP(ctx, hipHostGetDevicePointer(&d_src, h, 0));
-    MH_HIP(ctx, fr->d_pose_ns.reserve(b_ns + 16, ctx->stream, false));
-    MH_HIP(ctx, fr->d_pose_Rt.reserve(b_rt + 16, ctx->stream, false));
-    MH_HIP(ctx, mh::launch_copy16(d_src, fr->d_pose_ns.p, b_ns, ctx->stream));
-    MH_HIP(ctx, mh::launch_copy16(static_cast<char *>(d_src) + b_ns, fr->d_pose_Rt.p, (b_rt + 15) & ~size_t(15), ctx->stream));
+    // one block [timestamps | poses] on the device as in the pinned buffer: ONE copy launch
+    MH_HIP(ctx, fr->d_pose_ns.reserve(b_ns + b_rt + 32, ctx->stream, false));
+    fr->pose_rt_offset = b_ns;
+    pose_src = d_src;
+    pose_bytes = b_ns + ((b_rt + 15) & ~size_t(15));  // copied by the frame-reset launch below
   }
   fr->n_poses = static_cast<int>(n_groups);
   fr->rows = rows;
@@ -354,21 +360,61 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   MH_HIP(ctx, mh::launch_photo_clear(npx, static_cast<int>(n), img_raw, static_cast<float *>(fr->d_range.p),
                                      static_cast<uint8_t *>(ph->d_mask_raw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
                                      static_cast<int32_t *>(fr->d_idx.p), static_cast<int32_t *>(fr->d_proj.p),
-                                     static_cast<float *>(ph->d_int_out.p), ctx->stream));
+                                     static_cast<float *>(ph->d_int_out.p), pose_src, fr->d_pose_ns.p, pose_bytes, ctx->stream));
   ph->h_counters->project_throw = ph->h_counters->pose_missing = 0;
   const int ni = static_cast<int>(n);
   MH_HIP(ctx, mh::launch_photo_scatter(m, d_raw, desk, ni, static_cast<float *>(fr->d_yaw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
                                        img_raw, static_cast<float *>(fr->d_range.p), static_cast<uint8_t *>(ph->d_mask_raw.p),
                                        static_cast<int32_t *>(fr->d_idx.p), ctx->stream));
-  MH_HIP(ctx, mh::launch_photo_yaw_fill(m, static_cast<float *>(fr->d_yaw.p), static_cast<const uint8_t *>(ph->d_yaw_valid.p), ctx->stream));
-  MH_HIP(ctx, mh::launch_photo_project(m, desk, ni, static_cast<const float *>(fr->d_yaw.p), static_cast<int32_t *>(fr->d_proj.p),
-                                       ph->d_counters, ctx->stream));
-  MH_HIP(ctx, mh::launch_photo_proj_finalize(npx, static_cast<int32_t *>(fr->d_proj.p), ctx->stream));
-  // filter chain (photometric.cpp:246-300)
+  // behind the scatter: the image chain (photometric.cpp:246-320), the mask erosion, the yaw table and the projection index in
+  // THREE multi-job launches (photo_kernels.hip, "Round 4": 13 launches -> 5), or the single-stage kernels when a filter is
+  // larger than the tiles were sized for (and with MH_PHOTO_UNFUSED=1, diagnostic)
   const mh_photo_config & c = ph->cfg;
   const float scale = static_cast<float>(static_cast<double>(c.intensity_scale)), gamma = c.intensity_gamma;
   float * ta = static_cast<float *>(ph->d_tmp_a.p);
   float * tb = static_cast<float *>(ph->d_tmp_b.p);
+  float * fin = static_cast<float *>(fr->d_intensity.p);
+  mh::PhotoChain pc;
+  pc.raw = img_raw;
+  pc.ta = ta;
+  pc.tb = tb;
+  pc.fin = fin;
+  pc.dx = static_cast<float *>(fr->d_dx.p);
+  pc.dy = static_cast<float *>(fr->d_dy.p);
+  pc.idx = static_cast<const int32_t *>(fr->d_idx.p);
+  pc.intensity_out = static_cast<float *>(ph->d_int_out.p);
+  pc.hp = static_cast<const float *>(ph->d_hp.p);
+  pc.lp = static_cast<const float *>(ph->d_lp.p);
+  pc.mask_raw = static_cast<const uint8_t *>(ph->d_mask_raw.p);
+  pc.static_mask = ph->static_mask.empty() ? nullptr : static_cast<const uint8_t *>(ph->d_static.p);
+  pc.mask_out = static_cast<uint8_t *>(fr->d_mask.p);
+  pc.yaw = static_cast<float *>(fr->d_yaw.p);
+  pc.yaw_valid = static_cast<const uint8_t *>(ph->d_yaw_valid.p);
+  pc.desk_points = desk;
+  pc.proj = static_cast<int32_t *>(fr->d_proj.p);
+  pc.counters = ph->d_counters;
+  pc.rows = rows;
+  pc.cols = cols;
+  pc.n_pts = ni;
+  pc.n_hp = c.n_high_pass;
+  pc.n_lp = c.n_low_pass;
+  pc.remove_lines = c.remove_lines ? 1 : 0;
+  pc.filter_brightness = c.filter_brightness ? 1 : 0;
+  pc.bw = c.brightness_window_size[0];
+  pc.bh = c.brightness_window_size[1];
+  pc.do_gauss = c.gaussian_blur ? 1 : 0;
+  pc.erode_k = c.patch_size + c.erosion_buffer;
+  pc.scale = scale;
+  pc.gamma = gamma;
+  static const bool unfused = std::getenv("MH_PHOTO_UNFUSED") != nullptr;
+  if (!unfused && mh::photo_stages_fit(pc)) {
+    MH_HIP(ctx, mh::launch_photo_stages(pc, m, ctx->stream));
+    return MH_OK;
+  }
+  MH_HIP(ctx, mh::launch_photo_yaw_fill(m, static_cast<float *>(fr->d_yaw.p), static_cast<const uint8_t *>(ph->d_yaw_valid.p), ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_project(m, desk, ni, static_cast<const float *>(fr->d_yaw.p), static_cast<int32_t *>(fr->d_proj.p),
+                                       ph->d_counters, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_proj_finalize(npx, static_cast<int32_t *>(fr->d_proj.p), ctx->stream));
   const float * cur;
   if (c.remove_lines) {
     MH_HIP(ctx, mh::launch_photo_vfir(img_raw, ta, rows, cols, static_cast<const float *>(ph->d_hp.p), c.n_high_pass, scale, gamma, ctx->stream));
@@ -383,7 +429,6 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
     MH_HIP(ctx, mh::launch_photo_brightness(cur, ta, rows, cols, c.brightness_window_size[0], c.brightness_window_size[1], ctx->stream));
     cur = ta;
   }
-  float * fin = static_cast<float *>(fr->d_intensity.p);
   MH_HIP(ctx, mh::launch_photo_gauss_trunc(cur, fin, rows, cols, c.gaussian_blur ? 1 : 0, ctx->stream));
   MH_HIP(ctx, mh::launch_photo_sobel_writeback(fin, static_cast<float *>(fr->d_dx.p), static_cast<float *>(fr->d_dy.p),
                                                static_cast<const int32_t *>(fr->d_idx.p), nullptr, static_cast<float *>(ph->d_int_out.p),
@@ -791,14 +836,14 @@ int mh_photo_create(mh_ctx * ctx, const mh_photo_config * cfg, mh_photo ** out)
     if (rc == MH_OK) rc = upload(ctx, p->d_lp, p->lp_f.data(), p->lp_f.size() * sizeof(float));
     if (rc == MH_OK) rc = upload(ctx, p->d_static, p->static_mask.data(), p->static_mask.size());
     hipError_t e = hipSuccess;
-    if (rc == MH_OK) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_counters), sizeof(mh::PhotoCounters), hipHostMallocMapped);
+    if (rc == MH_OK) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_counters), 2 * sizeof(mh::PhotoCounters), hipHostMallocMapped);
     if (rc == MH_OK && e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_counters), p->h_counters, 0);
     if (rc == MH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (rc != MH_OK || e != hipSuccess) {
       photo_release(p);
       return rc != MH_OK ? rc : hip_fail(ctx, e, "mh_photo_create");
     }
-    std::memset(p->h_counters, 0, sizeof(*p->h_counters));
+    std::memset(p->h_counters, 0, 2 * sizeof(*p->h_counters));
     // derived parameters (photometric_config.cpp:98-110); DEG2RAD is PCL's macro (x * 0.017453293)
     mh::PhotoModel & m = p->model;
     m.rows = cfg->rows;
@@ -1295,7 +1340,7 @@ static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], con
     a.frame.proj = static_cast<const int32_t *>(fr->d_proj.p);
     a.frame.yaw = static_cast<const float *>(fr->d_yaw.p);
     a.frame.pose_ns = static_cast<const uint32_t *>(fr->d_pose_ns.p);
-    a.frame.pose_Rt = static_cast<const double *>(fr->d_pose_Rt.p);
+    a.frame.pose_Rt = reinterpret_cast<const double *>(static_cast<const char *>(fr->d_pose_ns.p) + fr->pose_rt_offset);
     a.frame.n_poses = fr->n_poses;
     a.Le_ps = static_cast<const double *>(f->d_Le.p);
     a.psi_a = static_cast<const double *>(f->d_psi.p);
@@ -1318,7 +1363,7 @@ static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], con
     a.partials = a.centers + 2 * nf;
     a.status = reinterpret_cast<int32_t *>(a.partials + nf * mh::kPhotoPartial);
     a.rows_out = static_cast<double *>(f->d_rows.p);
-    a.counters = f->photo->d_counters;
+    a.counters = f->photo->d_counters + 1;
     // the completion word sits behind the statuses in the mapped block (the block is sized with 64 spare bytes)
     const size_t seq_off = ((2 * nf + nf * mh::kPhotoPartial) * sizeof(double) + nf * sizeof(int32_t) + 7) & ~size_t(7);
     a.seq = 0;
@@ -1330,7 +1375,7 @@ static int photo_linearize_enqueue(mh_photo_factor * f, const double R_b[9], con
       a.seq = f->pending_seq = f->seq_counter;
       __atomic_store_n(reinterpret_cast<unsigned int *>(static_cast<char *>(f->h_out) + seq_off), 0u, __ATOMIC_RELEASE);  // re-arm
     }
-    f->photo->h_counters->project_throw = f->photo->h_counters->pose_missing = 0;
+    f->photo->h_counters[1].project_throw = f->photo->h_counters[1].pose_missing = 0;
     if (timed && !f->ev[0]) {
       MH_HIP(ctx, hipEventCreate(&f->ev[0]));
       MH_HIP(ctx, hipEventCreate(&f->ev[1]));
@@ -1378,7 +1423,7 @@ static int photo_linearize_finish(mh_photo_factor * f, mh_photo_result * out)
     std::memset(out, 0, sizeof(*out));
     out->gpu_ms = -1.f;
     if (timed) (void)hipEventElapsedTime(&out->gpu_ms, f->ev[0], f->ev[1]);
-    out->n_exceptions = static_cast<int32_t>(f->photo->h_counters->project_throw + f->photo->h_counters->pose_missing);
+    out->n_exceptions = static_cast<int32_t>(f->photo->h_counters[1].project_throw + f->photo->h_counters[1].pose_missing);
     // accumulate the per-feature sums in feature order (the reference's serial loop, :157-330)
     const int NV = f->binary ? 13 : 7;
     auto ent = [NV](int r, int cc) {

@@ -58,8 +58,9 @@ struct PhotoCounters
 };
 
 // frame reset: intensity / range / masks 0, idx -1, proj_idx "empty", corrected-intensity staging NaN
+// (+ a second job in the same launch: copy_bytes (a multiple of 16) from a mapped pinned block to the device — the frame's pose table)
 hipError_t launch_photo_clear(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw, uint8_t * yaw_valid,
-                              int32_t * idx, int32_t * proj, float * int_out, hipStream_t stream);
+                              int32_t * idx, int32_t * proj, float * int_out, const void * copy_src, void * copy_dst, size_t copy_bytes, hipStream_t stream);
 // preprocess stage 1 (photometric.cpp:121-130, 204-217): yaw of the raw points, image fill from the deskewed ones
 hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
                                 uint8_t * yaw_valid, float * intensity, float * range, uint8_t * mask, int32_t * idx,
@@ -85,6 +86,33 @@ hipError_t launch_photo_sobel_writeback(const float * img, float * dx, float * d
 hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out, int rows, int cols,
                               int k, hipStream_t stream);
 // detectFeatures' per-pixel part (:524-540): gradient magnitude image
+// Photometric::preprocess behind the scatter — the image chain (photometric.cpp:246-320), the mask erosion (:349-371), the
+// yaw-table fill (:135-199) and the projection index (:218-244) — in three multi-job launches (photo_kernels.hip, "Round 4")
+struct PhotoChain
+{
+  const float * raw;
+  float * ta;
+  float * tb;
+  float * fin;
+  float * dx;
+  float * dy;
+  const int32_t * idx;
+  float * intensity_out;
+  const float * hp;
+  const float * lp;
+  const uint8_t * mask_raw;
+  const uint8_t * static_mask;
+  uint8_t * mask_out;
+  float * yaw;
+  const uint8_t * yaw_valid;
+  const mh_point32 * desk_points;
+  int32_t * proj;
+  PhotoCounters * counters;
+  int rows, cols, n_pts, n_hp, n_lp, remove_lines, filter_brightness, bw, bh, do_gauss, erode_k;
+  float scale, gamma;
+};
+bool photo_stages_fit(const PhotoChain & c);
+hipError_t launch_photo_stages(const PhotoChain & c, const PhotoModel & m, hipStream_t stream);
 hipError_t launch_photo_grad(const float * dx, const float * dy, uint8_t * grad, int n, hipStream_t stream);
 // (:541-555) pixels with mask != 0 and gradient > thr in row-major order: out[i] = px | grad << 24, *n_out = how many.
 // blk: (npx + 255) / 256 words of scratch.

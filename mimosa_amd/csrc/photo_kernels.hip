@@ -15,6 +15,8 @@
 // per feature, one lane per patch point, with wave shuffles for the NCC sums and the 28 / 91 Hessian sums.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "photo_device.hpp"
 
 namespace mh
@@ -51,8 +53,14 @@ __device__ __forceinline__ float prep(float v, float scale, float gamma)
 // frame reset: one launch instead of six memsets (each a ~4 us fill kernel of its own)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void photo_clear_kernel(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw,
-                                                          uint8_t * yaw_valid, int32_t * idx, int32_t * proj, float * int_out)
+                                                          uint8_t * yaw_valid, int32_t * idx, int32_t * proj, float * int_out, int n_clear_blocks,
+                                                          const uint4 * copy_src, uint4 * copy_dst, int n_copy16)
 {
+  if (static_cast<int>(blockIdx.x) >= n_clear_blocks) {  // second job of the launch: the frame's pose table from its mapped pinned block
+    for (int k = (static_cast<int>(blockIdx.x) - n_clear_blocks) * kT + static_cast<int>(threadIdx.x); k < n_copy16; k += (static_cast<int>(gridDim.x) - n_clear_blocks) * kT)
+      copy_dst[k] = copy_src[k];
+    return;
+  }
   const int i = blockIdx.x * kT + threadIdx.x;
   if (i < npx) {
     img_raw[i] = 0.f;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(kT) void photo_clear_kernel(int npx, int n_pts, flo
     yaw_valid[i] = 0;
     idx[i] = -1;
   }
-  for (int k = i; k < npx * kPhotoDup; k += gridDim.x * kT) proj[k] = kProjEmpty;
+  for (int k = i; k < npx * kPhotoDup; k += n_clear_blocks * kT) proj[k] = kProjEmpty;
   if (i < n_pts) int_out[i] = __uint_as_float(0xFFFFFFFFu);  // NaN = "this point owns no pixel"
 }
 
@@ -102,15 +110,20 @@ __global__ __launch_bounds__(kT) void photo_scatter_kernel(const PhotoModel m, c
 // preprocess stage 2: one workgroup per image row
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxCols = 4096;
-__global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, float * yaw, const uint8_t * yaw_valid)
+constexpr int kYawLdsWords = 3 * kMaxCols + 2 * 1024;  // s_yaw, s_prev, s_next, s_clast, s_cfirst (<= 1024 threads)
+// row v of the yaw table; `lds`: kYawLdsWords words; any workgroup size up to 1024
+__device__ __forceinline__ void yaw_fill_row(const PhotoModel & m, float * yaw, const uint8_t * yaw_valid, const int v, uint32_t * lds)
 {
-  __shared__ float s_yaw[kMaxCols];
-  __shared__ int s_prev[kMaxCols], s_next[kMaxCols];
-  __shared__ int s_clast[kT], s_cfirst[kT];
-  const int v = blockIdx.x, cols = m.cols;
+  float * s_yaw = reinterpret_cast<float *>(lds);
+  int * s_prev = reinterpret_cast<int *>(lds + kMaxCols);
+  int * s_next = reinterpret_cast<int *>(lds + 2 * kMaxCols);
+  int * s_clast = reinterpret_cast<int *>(lds + 3 * kMaxCols);
+  int * s_cfirst = s_clast + 1024;
+  const int nthr = static_cast<int>(blockDim.x);
+  const int cols = m.cols;
   float * yr = yaw + static_cast<size_t>(v) * cols;
   const uint8_t * vr = yaw_valid + static_cast<size_t>(v) * cols;
-  const int per = (cols + kT - 1) / kT, c0 = threadIdx.x * per, c1 = min(cols, c0 + per);
+  const int per = (cols + nthr - 1) / nthr, c0 = min(cols, static_cast<int>(threadIdx.x) * per), c1 = min(cols, c0 + per);
   int last = -1, first = -1;
   for (int u = c0; u < c1; ++u) {
     const bool ok = vr[u] != 0;
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, 
   __syncthreads();
   int carry_prev = -1, carry_next = -1;
   for (int t = static_cast<int>(threadIdx.x) - 1; t >= 0 && carry_prev < 0; --t) carry_prev = s_clast[t];
-  for (int t = threadIdx.x + 1; t < kT && carry_next < 0; ++t) carry_next = s_cfirst[t];
+  for (int t = threadIdx.x + 1; t < nthr && carry_next < 0; ++t) carry_next = s_cfirst[t];
   const double kPi = 3.14159265358979323846;
   for (int u = c0; u < c1; ++u) {
     if (vr[u]) continue;
@@ -150,6 +163,11 @@ __global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, 
     }
     yr[u] = out;
   }
+}
+__global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, float * yaw, const uint8_t * yaw_valid)
+{
+  __shared__ uint32_t s_lds[kYawLdsWords];
+  yaw_fill_row(m, yaw, yaw_valid, static_cast<int>(blockIdx.x), s_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,10 +225,9 @@ __device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * y
 // preprocess stage 3: project + proj_idx.  Slots 1..9 of a pixel hold its 9 smallest point indices in ascending
 // order, kept by a carry chain of atomicMin (the displaced larger value moves on to the next slot); the reference
 // appends in index order and stops at 9 (photometric.cpp:232-244) — the same set in the same order.
-__global__ __launch_bounds__(kT) void photo_project_kernel(const PhotoModel m, const mh_point32 * desk, int n, const float * yaw,
-                                                            int32_t * proj, PhotoCounters * counters)
+__device__ __forceinline__ void project_point(const PhotoModel & m, const mh_point32 * desk, int n, const float * yaw, int32_t * proj,
+                                              PhotoCounters * counters, const int i)
 {
-  const int i = blockIdx.x * kT + threadIdx.x;
   if (i >= n) return;
   const mh_point32 p = desk[i];
   if (p.range < m.range_min || p.range > m.range_max) return;
@@ -228,20 +245,32 @@ __global__ __launch_bounds__(kT) void photo_project_kernel(const PhotoModel m, c
     cur = max(old, cur);
   }
 }
-
-__global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, int32_t * proj)
+__global__ __launch_bounds__(kT) void photo_project_kernel(const PhotoModel m, const mh_point32 * desk, int n, const float * yaw,
+                                                            int32_t * proj, PhotoCounters * counters)
 {
-  const int px = blockIdx.x * kT + threadIdx.x;
+  project_point(m, desk, n, yaw, proj, counters, static_cast<int>(blockIdx.x * kT + threadIdx.x));
+}
+
+__device__ __forceinline__ void proj_finalize_px(int n_pixels, int32_t * proj, const int px)
+{
   if (px >= n_pixels) return;
   int32_t * slot = proj + static_cast<size_t>(px) * kPhotoDup;
+  int v[kPhotoDup];
+#pragma unroll
+  for (int s = 1; s < kPhotoDup; ++s) v[s] = slot[s];  // all requested together: one round trip, not nine dependent ones
   int cnt = 0;
+#pragma unroll
   for (int s = 1; s < kPhotoDup; ++s) {
-    if (slot[s] != kProjEmpty)
+    if (v[s] != kProjEmpty)
       ++cnt;
     else
       slot[s] = 0;
   }
   slot[0] = cnt;
+}
+__global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, int32_t * proj)
+{
+  proj_finalize_px(n_pixels, proj, static_cast<int>(blockIdx.x * kT + threadIdx.x));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -249,12 +278,13 @@ __global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, i
 // ------------------------------------------------------------------------------------------------
 // removeLines part 1 (:322-327): vertical correlation with the high-pass FIR.  Tile = 64 rows x 64 columns + halo.
 constexpr int kVT_R = 16, kVT_C = 64;  // 8 x 16 = 128 workgroups for a 128 x 1024 image
-__global__ __launch_bounds__(kT) void photo_vfir_kernel(const float * in, float * out, int rows, int cols, const float * taps,
-                                                         int n_taps, float scale, float gamma)
+constexpr int kVfirLdsWords = (kVT_R + kPhotoMaxTaps - 1) * kVT_C + kPhotoMaxTaps;
+__device__ __forceinline__ void vfir_tile(const float * in, float * out, int rows, int cols, const float * taps, int n_taps, float scale, float gamma,
+                                          const int bx, const int by, uint32_t * pool)
 {
-  __shared__ float s_tile[(kVT_R + kPhotoMaxTaps - 1) * kVT_C];
-  __shared__ float s_taps[kPhotoMaxTaps];
-  const int a = n_taps / 2, r0 = blockIdx.y * kVT_R, c0 = blockIdx.x * kVT_C, th = kVT_R + n_taps - 1;
+  float * s_tile = reinterpret_cast<float *>(pool);
+  float * s_taps = s_tile + (kVT_R + kPhotoMaxTaps - 1) * kVT_C;
+  const int a = n_taps / 2, r0 = by * kVT_R, c0 = bx * kVT_C, th = kVT_R + n_taps - 1;
   for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
   for (int e = threadIdx.x; e < th * kVT_C; e += kT) {
     const int ty = e / kVT_C, tx = e % kVT_C;
@@ -270,15 +300,22 @@ __global__ __launch_bounds__(kT) void photo_vfir_kernel(const float * in, float 
     out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = s;
   }
 }
+__global__ __launch_bounds__(kT) void photo_vfir_kernel(const float * in, float * out, int rows, int cols, const float * taps,
+                                                         int n_taps, float scale, float gamma)
+{
+  __shared__ uint32_t s_pool[kVfirLdsWords];
+  vfir_tile(in, out, rows, cols, taps, n_taps, scale, gamma, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), s_pool);
+}
 
 // removeLines part 2 (:328-336): horizontal low-pass of the high-passed image = the line artefacts; subtract, clip.
 constexpr int kHT_R = 8, kHT_C = 128;
-__global__ __launch_bounds__(kT) void photo_hfir_sub_kernel(const float * hp, const float * raw_in, float * out, int rows, int cols,
-                                                             const float * taps, int n_taps, float scale, float gamma)
+constexpr int kHfirLdsWords = kHT_R * (kHT_C + kPhotoMaxTaps - 1) + kPhotoMaxTaps;
+__device__ __forceinline__ void hfir_sub_tile(const float * hp, const float * raw_in, float * out, int rows, int cols, const float * taps, int n_taps,
+                                              float scale, float gamma, const int bx, const int by, uint32_t * pool)
 {
-  __shared__ float s_tile[kHT_R * (kHT_C + kPhotoMaxTaps - 1)];
-  __shared__ float s_taps[kPhotoMaxTaps];
-  const int a = n_taps / 2, r0 = blockIdx.y * kHT_R, c0 = blockIdx.x * kHT_C, tw = kHT_C + n_taps - 1;
+  float * s_tile = reinterpret_cast<float *>(pool);
+  float * s_taps = s_tile + kHT_R * (kHT_C + kPhotoMaxTaps - 1);
+  const int a = n_taps / 2, r0 = by * kHT_R, c0 = bx * kHT_C, tw = kHT_C + n_taps - 1;
   for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
   for (int e = threadIdx.x; e < kHT_R * tw; e += kT) {
     const int ty = e / tw, tx = e % tw;
@@ -295,6 +332,12 @@ __global__ __launch_bounds__(kT) void photo_hfir_sub_kernel(const float * hp, co
     const float v = prep(raw_in[px], scale, gamma) - s;
     out[px] = v < 0.f ? 0.f : v;
   }
+}
+__global__ __launch_bounds__(kT) void photo_hfir_sub_kernel(const float * hp, const float * raw_in, float * out, int rows, int cols,
+                                                             const float * taps, int n_taps, float scale, float gamma)
+{
+  __shared__ uint32_t s_pool[kHfirLdsWords];
+  hfir_sub_tile(hp, raw_in, out, rows, cols, taps, n_taps, scale, gamma, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), s_pool);
 }
 
 __global__ __launch_bounds__(kT) void photo_scale_kernel(const float * in, float * out, int n, float scale, float gamma)
@@ -382,12 +425,13 @@ __global__ __launch_bounds__(kT) void photo_sobel_writeback_kernel(const float *
 // erode with a k x k ones kernel, anchor k / 2 (O6).  in &= static_mask (and the margin rectangle when margin >= 0:
 // detectFeatures' `img_mask & mask_margin_`, photometric.cpp:524) before the erosion.
 constexpr int kET_R = 16, kET_C = 64, kEMaxK = 33;
-__global__ __launch_bounds__(kT) void photo_erode_kernel(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out,
-                                                          int rows, int cols, int k)
+constexpr int kErodeLdsWords = ((kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1) + (kET_R + kEMaxK - 1) * kET_C + 3) / 4;
+__device__ __forceinline__ void erode_tile(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out, int rows, int cols, int k,
+                                           const int bx, const int by, uint32_t * pool)
 {
-  __shared__ uint8_t s_raw[(kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1)];
-  __shared__ uint8_t s_row[(kET_R + kEMaxK - 1) * kET_C];
-  const int a = k / 2, r0 = blockIdx.y * kET_R, c0 = blockIdx.x * kET_C, tw = kET_C + k - 1, th = kET_R + k - 1;
+  uint8_t * s_raw = reinterpret_cast<uint8_t *>(pool);
+  uint8_t * s_row = s_raw + (kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1);
+  const int a = k / 2, r0 = by * kET_R, c0 = bx * kET_C, tw = kET_C + k - 1, th = kET_R + k - 1;
   for (int e = threadIdx.x; e < th * tw; e += kT) {
     const int ty = e / tw, tx = e % tw;
     const int y = r0 + ty - a, x = c0 + tx - a;
@@ -413,6 +457,189 @@ __global__ __launch_bounds__(kT) void photo_erode_kernel(const uint8_t * in, con
     uint8_t mn = 255;
     for (int j = 0; j < k; ++j) mn = min(mn, s_row[(ty + j) * kET_C + tx]);
     out[static_cast<size_t>(r0 + ty) * cols + c0 + tx] = mn;
+  }
+}
+__global__ __launch_bounds__(kT) void photo_erode_kernel(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out,
+                                                          int rows, int cols, int k)
+{
+  __shared__ uint32_t s_pool[kErodeLdsWords];
+  erode_tile(in, static_mask, margin, out, rows, cols, k, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), s_pool);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the preprocess chain in FIVE launches instead of thirteen.  A 128 x 1024 image is 512 KiB: every stage above is a
+// 3-10 us kernel and the chain was launch-bound (2 % of HBM peak).  Two things cut the launches without adding work:
+//   * stages that do not depend on each other share a launch (a workgroup finds its job by its index):
+//       stage A = vertical FIR tiles | mask-erosion tiles | yaw-table rows          (all need only the scattered image)
+//       stage B = horizontal FIR + subtract tiles | projection of the points        (the projection needs the yaw table)
+//       stage C = brightness + Gaussian + Sobel tiles | projection-index finalise
+//   * brightness, GaussianBlur 3 x 3 + TRUNC and Sobel + write-back run on ONE tile (16 x 64 outputs, a 2-pixel ring of
+//     brightness values around it in LDS): the stages' reach is 1 pixel each, so the ring costs 1.3x the brightness work.
+// (Tried first and rejected: the WHOLE chain on column strips with all rows in LDS — 32 workgroups with a 38-column halo per
+// side for the 33-tap and 41-wide filters: 132 us, three times the six launches it replaced.)  Every stage evaluates the
+// expression of its single-stage kernel in the same operation order: the images stay bit-identical to the oracle's.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFT_R = 16, kFT_C = 64;
+constexpr int kBgsLdsWords = (kFT_R + 4 + kBMaxH - 1) * (kFT_C + 4 + kBMaxW - 1) + 2 * (kFT_R + 4 + kBMaxH - 1) * (kFT_C + 4) + 2 * (kFT_R + 4) * (kFT_C + 4);
+// filterBrightness -> GaussianBlur + TRUNC -> Sobel + write-back for the output tile (bx, by).  Each stage of the reference
+// reflects ITS OWN input at the image border (BORDER_REFLECT_101 per filter): a neighbour outside the image is read at the
+// reflected position of the same plane, which lies inside the tile's ring; ring positions outside the image are never computed.
+__device__ __forceinline__ void bgs_tile(const float * in, float * fin, float * dx, float * dy, const int32_t * idx, mh_point32 * desk,
+                                         float * intensity_out, int rows, int cols, int filter_brightness, int w, int h, int do_gauss, const int bx,
+                                         const int by, uint32_t * pool)
+{
+  constexpr int DR = kFT_R + 4, DC = kFT_C + 4;
+  const int ax = filter_brightness ? w / 2 : 0, ay = filter_brightness ? h / 2 : 0;
+  const int r0 = by * kFT_R - 2, c0 = bx * kFT_C - 2;  // image position of ring position (0, 0)
+  const int tw = DC + 2 * ax, th = DR + 2 * ay;
+  float * s_raw = reinterpret_cast<float *>(pool);                                   // th x tw: input with the window halo
+  double * s_rs = reinterpret_cast<double *>(s_raw + (kFT_R + 4 + kBMaxH - 1) * (kFT_C + 4 + kBMaxW - 1));  // th x DC row sums
+  float * s_D = reinterpret_cast<float *>(s_rs + (kFT_R + 4 + kBMaxH - 1) * (kFT_C + 4));                   // DR x DC
+  float * s_T = s_D + DR * DC;                                                                               // DR x DC
+  const int nthr = static_cast<int>(blockDim.x), tid = static_cast<int>(threadIdx.x);
+  // (tw is a run-time value: the row of a flat index by a float reciprocal — exact for these sizes — instead of an integer division)
+  const float inv_tw = 1.0f / static_cast<float>(tw);
+  for (int e = tid; e < th * tw; e += nthr) {
+    int ty = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_tw);
+    int tx = e - ty * tw;
+    if (tx < 0) {
+      --ty;
+      tx += tw;
+    } else if (tx >= tw) {
+      ++ty;
+      tx -= tw;
+    }
+    s_raw[e] = in[static_cast<size_t>(reflect101(r0 + ty - ay, rows)) * cols + reflect101(c0 + tx - ax, cols)];
+  }
+  __syncthreads();
+  auto inside = [&](int ty, int tx) { return r0 + ty >= 0 && r0 + ty < rows && c0 + tx >= 0 && c0 + tx < cols; };
+  if (filter_brightness) {
+    for (int e = tid; e < th * DC; e += nthr) {
+      const int ty = e / DC, tx = e - ty * DC;
+      double s = 0;
+      const float * src = s_raw + ty * tw + tx;
+      for (int k = 0; k < w; ++k) s += static_cast<double>(src[k]);
+      s_rs[e] = s;
+    }
+    __syncthreads();
+    const double scl = 1.0 / (static_cast<double>(w) * static_cast<double>(h));
+    for (int e = tid; e < DR * DC; e += nthr) {
+      const int ty = e / DC, tx = e - ty * DC;
+      if (!inside(ty, tx)) continue;
+      double s = 0;
+      for (int k = 0; k < h; ++k) s += s_rs[(ty + k) * DC + tx];
+      const float b = static_cast<float>(s * scl) + 1.0f;
+      const float v = s_raw[(ty + ay) * tw + tx + ax];
+      s_D[e] = b != 0.f ? (v * 140.0f) / b : 0.f;
+    }
+  } else {
+    for (int e = tid; e < DR * DC; e += nthr) {
+      const int ty = e / DC, tx = e - ty * DC;
+      if (inside(ty, tx)) s_D[e] = s_raw[ty * tw + tx];
+    }
+  }
+  __syncthreads();
+  auto trow = [&](int y) { return reflect101(y, rows) - r0; };
+  auto tcol = [&](int x) { return reflect101(x, cols) - c0; };
+  // GaussianBlur 3 x 3: horizontal into s_T (all ring rows), vertical back into s_D (ring rows 1 .. DR - 2), TRUNC 255
+  for (int e = tid; e < DR * DC; e += nthr) {
+    const int ty = e / DC, tx = e - ty * DC;
+    if (!inside(ty, tx) || tx < 1 || tx >= DC - 1) continue;
+    const float l = s_D[ty * DC + tcol(c0 + tx - 1)], c = s_D[e], r = s_D[ty * DC + tcol(c0 + tx + 1)];
+    s_T[e] = do_gauss ? 0.5f * c + 0.25f * (l + r) : c;
+  }
+  __syncthreads();
+  for (int e = tid; e < DR * DC; e += nthr) {
+    const int ty = e / DC, tx = e - ty * DC;
+    if (!inside(ty, tx) || tx < 1 || tx >= DC - 1 || ty < 1 || ty >= DR - 1) continue;
+    const float u = s_T[trow(r0 + ty - 1) * DC + tx], c = s_T[e], d = s_T[trow(r0 + ty + 1) * DC + tx];
+    float v = do_gauss ? 0.5f * c + 0.25f * (u + d) : c;
+    v = v > 255.0f ? 255.0f : v;
+    s_D[e] = v;
+  }
+  __syncthreads();
+  // Sobel ksize 1, scale 0.5 + the corrected intensities back into the cloud
+  for (int e = tid; e < kFT_R * kFT_C; e += nthr) {
+    const int oy = e / kFT_C, ox = e - oy * kFT_C, ty = oy + 2, tx = ox + 2;
+    const int y = r0 + ty, x = c0 + tx;
+    if (y >= rows || x >= cols) continue;
+    const size_t px = static_cast<size_t>(y) * cols + x;
+    const float c = s_D[ty * DC + tx];
+    fin[px] = c;
+    dx[px] = (s_D[ty * DC + tcol(x + 1)] - s_D[ty * DC + tcol(x - 1)]) * 0.5f;
+    dy[px] = (s_D[trow(y + 1) * DC + tx] - s_D[trow(y - 1) * DC + tx]) * 0.5f;
+    const int i = idx[px];
+    if (i >= 0) {
+      if (desk) desk[i].intensity = c;
+      if (intensity_out) intensity_out[i] = c;
+    }
+  }
+}
+
+struct PhotoStageArgs  // one argument block for the three multi-job launches
+{
+  const float * raw;   // scattered intensity image
+  float * ta;          // high-passed image (stage A -> B)
+  float * tb;          // line-free image (stage B -> C), or prep(raw) when removeLines is off
+  float * fin;
+  float * dx;
+  float * dy;
+  const int32_t * idx;
+  float * intensity_out;
+  const float * hp;
+  const float * lp;
+  const uint8_t * mask_raw;
+  const uint8_t * static_mask;
+  uint8_t * mask_out;
+  float * yaw;
+  const uint8_t * yaw_valid;
+  const mh_point32 * desk;
+  int32_t * proj;
+  PhotoCounters * counters;
+  int rows, cols, n_pts, n_hp, n_lp, remove_lines, filter_brightness, bw, bh, do_gauss, erode_k;
+  float scale, gamma;
+  int n_job0, n_job1;  // workgroups of the launch's first / second job (the rest run the third)
+};
+constexpr int kStageALds = kYawLdsWords > kVfirLdsWords ? kYawLdsWords : kVfirLdsWords;
+__global__ __launch_bounds__(kT) void photo_stage_a_kernel(const PhotoStageArgs a, const PhotoModel m)
+{
+  __shared__ uint32_t s_pool[kStageALds > kErodeLdsWords ? kStageALds : kErodeLdsWords];
+  const int b = static_cast<int>(blockIdx.x);
+  if (b < a.n_job0) {  // vertical high-pass tiles (or the plain intensity scaling when removeLines is off)
+    if (a.remove_lines) {
+      const int gx = (a.cols + kVT_C - 1) / kVT_C;
+      vfir_tile(a.raw, a.ta, a.rows, a.cols, a.hp, a.n_hp, a.scale, a.gamma, b % gx, b / gx, s_pool);
+    } else {
+      const int i = b * kT + static_cast<int>(threadIdx.x);
+      if (i < a.rows * a.cols) a.tb[i] = prep(a.raw[i], a.scale, a.gamma);
+    }
+  } else if (b < a.n_job0 + a.n_job1) {  // mask erosion tiles
+    const int t = b - a.n_job0, gx = (a.cols + kET_C - 1) / kET_C;
+    erode_tile(a.mask_raw, a.static_mask, -1, a.mask_out, a.rows, a.cols, a.erode_k, t % gx, t / gx, s_pool);
+  } else {  // yaw-table rows
+    yaw_fill_row(m, a.yaw, a.yaw_valid, b - a.n_job0 - a.n_job1, s_pool);
+  }
+}
+__global__ __launch_bounds__(kT) void photo_stage_b_kernel(const PhotoStageArgs a, const PhotoModel m)
+{
+  __shared__ uint32_t s_pool[kHfirLdsWords];
+  const int b = static_cast<int>(blockIdx.x);
+  if (b < a.n_job0) {
+    const int gx = (a.cols + kHT_C - 1) / kHT_C;
+    hfir_sub_tile(a.ta, a.raw, a.tb, a.rows, a.cols, a.lp, a.n_lp, a.scale, a.gamma, b % gx, b / gx, s_pool);
+  } else {
+    project_point(m, a.desk, a.n_pts, a.yaw, a.proj, a.counters, (b - a.n_job0) * kT + static_cast<int>(threadIdx.x));
+  }
+}
+__global__ __launch_bounds__(kT) void photo_stage_c_kernel(const PhotoStageArgs a)
+{
+  __shared__ __attribute__((aligned(8))) uint32_t s_pool[kBgsLdsWords];
+  const int b = static_cast<int>(blockIdx.x);
+  if (b < a.n_job0) {
+    const int gx = (a.cols + kFT_C - 1) / kFT_C;
+    bgs_tile(a.tb, a.fin, a.dx, a.dy, a.idx, nullptr, a.intensity_out, a.rows, a.cols, a.filter_brightness, a.bw, a.bh, a.do_gauss, b % gx, b / gx, s_pool);
+  } else {
+    proj_finalize_px(a.rows * a.cols, a.proj, (b - a.n_job0) * kT + static_cast<int>(threadIdx.x));
   }
 }
 
@@ -821,10 +1048,12 @@ __global__ __launch_bounds__(128) void photo_gather_kernel(const int2 * uv, int 
 static inline dim3 g1(int n) { return dim3((n + kT - 1) / kT); }
 
 hipError_t launch_photo_clear(int npx, int n_pts, float * img_raw, float * range, uint8_t * mask_raw, uint8_t * yaw_valid,
-                              int32_t * idx, int32_t * proj, float * int_out, hipStream_t stream)
+                              int32_t * idx, int32_t * proj, float * int_out, const void * copy_src, void * copy_dst, size_t copy_bytes, hipStream_t stream)
 {
   const int n = npx > n_pts ? npx : n_pts;
-  hipLaunchKernelGGL(photo_clear_kernel, g1(n), dim3(kT), 0, stream, npx, n_pts, img_raw, range, mask_raw, yaw_valid, idx, proj, int_out);
+  const int nb = (n + kT - 1) / kT, n16 = static_cast<int>(copy_bytes / 16), ncopy = n16 ? (n16 + kT - 1) / kT : 0;
+  hipLaunchKernelGGL(photo_clear_kernel, dim3(nb + (ncopy > 16 ? 16 : ncopy)), dim3(kT), 0, stream, npx, n_pts, img_raw, range, mask_raw, yaw_valid, idx, proj, int_out, nb,
+                     static_cast<const uint4 *>(copy_src), static_cast<uint4 *>(copy_dst), n16);
   return hipGetLastError();
 }
 hipError_t launch_photo_scatter(const PhotoModel & m, const mh_point32 * raw, const mh_point32 * desk, int n, float * yaw,
@@ -896,6 +1125,66 @@ hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, i
   hipLaunchKernelGGL(photo_erode_kernel, grid, dim3(kT), 0, stream, in, static_mask, margin, out, rows, cols, k);
   return hipGetLastError();
 }
+// The preprocess chain behind the scatter in three multi-job launches (photo_stage_a/b/c_kernel).  false = a filter is
+// larger than the tiles were sized for: the caller runs the single-stage kernels.
+bool photo_stages_fit(const PhotoChain & c)
+{
+  if (c.n_hp > kPhotoMaxTaps || c.n_lp > kPhotoMaxTaps) return false;
+  if (c.filter_brightness && (c.bw > kBMaxW || c.bh > kBMaxH || c.bw < 1 || c.bh < 1)) return false;
+  if (c.erode_k < 1 || c.erode_k > kEMaxK) return false;
+  return c.cols <= kMaxCols && c.rows >= 2 && c.cols >= 2;
+}
+hipError_t launch_photo_stages(const PhotoChain & c, const PhotoModel & m, hipStream_t stream)
+{
+  PhotoStageArgs a;
+  a.raw = c.raw;
+  a.ta = c.ta;
+  a.tb = c.tb;
+  a.fin = c.fin;
+  a.dx = c.dx;
+  a.dy = c.dy;
+  a.idx = c.idx;
+  a.intensity_out = c.intensity_out;
+  a.hp = c.hp;
+  a.lp = c.lp;
+  a.mask_raw = c.mask_raw;
+  a.static_mask = c.static_mask;
+  a.mask_out = c.mask_out;
+  a.yaw = c.yaw;
+  a.yaw_valid = c.yaw_valid;
+  a.desk = c.desk_points;
+  a.proj = c.proj;
+  a.counters = c.counters;
+  a.rows = c.rows;
+  a.cols = c.cols;
+  a.n_pts = c.n_pts;
+  a.n_hp = c.n_hp;
+  a.n_lp = c.n_lp;
+  a.remove_lines = c.remove_lines;
+  a.filter_brightness = c.filter_brightness;
+  a.bw = c.bw;
+  a.bh = c.bh;
+  a.do_gauss = c.do_gauss;
+  a.erode_k = c.erode_k;
+  a.scale = c.scale;
+  a.gamma = c.gamma;
+  const int npx = c.rows * c.cols;
+  auto tiles = [&](int tr, int tc) { return ((c.cols + tc - 1) / tc) * ((c.rows + tr - 1) / tr); };
+  // A: vertical FIR (or scaling) | erosion | yaw rows
+  a.n_job0 = c.remove_lines ? tiles(kVT_R, kVT_C) : (npx + kT - 1) / kT;
+  a.n_job1 = tiles(kET_R, kET_C);
+  hipLaunchKernelGGL(photo_stage_a_kernel, dim3(a.n_job0 + a.n_job1 + m.rows), dim3(kT), 0, stream, a, m);
+  // B: horizontal FIR + subtract | projection
+  a.n_job0 = c.remove_lines ? tiles(kHT_R, kHT_C) : 0;
+  a.n_job1 = (c.n_pts + kT - 1) / kT;
+  if (a.n_job0 + a.n_job1 > 0) hipLaunchKernelGGL(photo_stage_b_kernel, dim3(a.n_job0 + a.n_job1), dim3(kT), 0, stream, a, m);
+  // C: brightness + Gaussian + Sobel + write-back | projection-index finalise
+  a.n_job0 = tiles(kFT_R, kFT_C);
+  a.n_job1 = (npx + kT - 1) / kT;
+  hipLaunchKernelGGL(photo_stage_c_kernel, dim3(a.n_job0 + a.n_job1), dim3(kT), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_photo_grad(const float * dx, const float * dy, uint8_t * grad, int n, hipStream_t stream)
 {
   hipLaunchKernelGGL(photo_grad_kernel, g1(n), dim3(kT), 0, stream, dx, dy, grad, n);

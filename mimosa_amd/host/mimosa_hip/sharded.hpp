@@ -44,15 +44,17 @@ public:
     return c;
   }
   // ... with the id passed from rank 0 to the others over a TCP socket (ranks of one node: host = 127.0.0.1).  Rank 0 listens
-  // on `port` until world - 1 peers have fetched the id.
+  // on `host`:`port` ONLY (not on every interface) until ranks 1 .. world - 1 have each fetched the id; a peer says who it is
+  // first ("MHID" + its rank), anything else — a stray connection, a rank twice — is dropped without costing a real rank its
+  // slot.
   static Ptr rcclOverTcp(const std::shared_ptr<Context> & ctx, int world, int rank, const std::string & host, int port, double timeout_s = 120.0)
   {
     std::array<char, MH_SHARD_UNIQUE_ID_BYTES> id{};
     if (rank == 0) {
       ctx->check(mh_shard_unique_id(id.data()), "mh_shard_unique_id");
-      if (world > 1) serveId(id, world - 1, port, timeout_s);
+      if (world > 1) serveId(id, world, host, port, timeout_s);
     } else {
-      fetchId(id, host, port, timeout_s);
+      fetchId(id, rank, host, port, timeout_s);
     }
     return rccl(ctx, id, world, rank);
   }
@@ -89,7 +91,7 @@ public:
 
 private:
   explicit ShardCommunicator(const std::shared_ptr<Context> & ctx) : ctx_(ctx) {}
-  static void serveId(const std::array<char, MH_SHARD_UNIQUE_ID_BYTES> & id, int peers, int port, double timeout_s)
+  static void serveId(const std::array<char, MH_SHARD_UNIQUE_ID_BYTES> & id, int world, const std::string & host, int port, double timeout_s)
   {
     const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
     if (ls < 0) throw std::runtime_error("ShardCommunicator: socket() failed");
@@ -97,31 +99,56 @@ private:
     ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     sockaddr_in a{};
     a.sin_family = AF_INET;
-    a.sin_addr.s_addr = htonl(INADDR_ANY);
     a.sin_port = htons(static_cast<uint16_t>(port));
-    if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, peers) != 0) {
+    if (::inet_pton(AF_INET, host.c_str(), &a.sin_addr) != 1) {
       ::close(ls);
-      throw std::runtime_error("ShardCommunicator: cannot listen on port " + std::to_string(port));
+      throw std::runtime_error("ShardCommunicator: MASTER_ADDR must be an IPv4 address");
     }
-    timeval tv{static_cast<time_t>(timeout_s), 0};
-    ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-    for (int p = 0; p < peers; ++p) {
-      const int s = ::accept(ls, nullptr, nullptr);
-      if (s < 0) {
+    if (::bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || ::listen(ls, world) != 0) {
+      ::close(ls);
+      throw std::runtime_error("ShardCommunicator: cannot listen on " + host + ":" + std::to_string(port));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<char> served(static_cast<size_t>(world), 0);
+    int left = world - 1;
+    while (left > 0) {
+      const double remaining = timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (remaining <= 0) {
         ::close(ls);
         throw std::runtime_error("ShardCommunicator: a peer did not fetch the communicator id in time");
       }
-      size_t off = 0;
-      while (off < id.size()) {
-        const ssize_t w = ::send(s, id.data() + off, id.size() - off, 0);
-        if (w <= 0) break;
-        off += static_cast<size_t>(w);
+      timeval tv{static_cast<time_t>(remaining), static_cast<suseconds_t>((remaining - static_cast<double>(static_cast<time_t>(remaining))) * 1e6)};
+      ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      const int s = ::accept(ls, nullptr, nullptr);
+      if (s < 0) continue;  // timed out or interrupted: the loop head decides
+      timeval hv{2, 0};     // a peer has two seconds to say who it is
+      ::setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &hv, sizeof(hv));
+      char hello[8] = {0};
+      size_t got = 0;
+      while (got < sizeof(hello)) {
+        const ssize_t r = ::recv(s, hello + got, sizeof(hello) - got, 0);
+        if (r <= 0) break;
+        got += static_cast<size_t>(r);
+      }
+      int32_t peer = -1;
+      if (got == sizeof(hello) && std::memcmp(hello, "MHID", 4) == 0) std::memcpy(&peer, hello + 4, 4);
+      if (peer >= 1 && peer < world && !served[static_cast<size_t>(peer)]) {
+        size_t off = 0;
+        while (off < id.size()) {
+          const ssize_t w = ::send(s, id.data() + off, id.size() - off, 0);
+          if (w <= 0) break;
+          off += static_cast<size_t>(w);
+        }
+        if (off == id.size()) {
+          served[static_cast<size_t>(peer)] = 1;
+          --left;
+        }
       }
       ::close(s);
     }
     ::close(ls);
   }
-  static void fetchId(std::array<char, MH_SHARD_UNIQUE_ID_BYTES> & id, const std::string & host, int port, double timeout_s)
+  static void fetchId(std::array<char, MH_SHARD_UNIQUE_ID_BYTES> & id, int rank, const std::string & host, int port, double timeout_s)
   {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -135,6 +162,10 @@ private:
         throw std::runtime_error("ShardCommunicator: MASTER_ADDR must be an IPv4 address");
       }
       if (::connect(s, reinterpret_cast<sockaddr *>(&a), sizeof(a)) == 0) {
+        char hello[8] = {'M', 'H', 'I', 'D', 0, 0, 0, 0};
+        const int32_t me = rank;
+        std::memcpy(hello + 4, &me, 4);
+        (void)::send(s, hello, sizeof(hello), 0);
         size_t off = 0;
         while (off < id.size()) {
           const ssize_t r = ::recv(s, id.data() + off, id.size() - off, 0);

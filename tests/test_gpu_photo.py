@@ -1,6 +1,9 @@
 """-m gpu: the photometric path (BASELINE configs[3]) — Photometric::preprocess, detectFeatures,
 updateMap and PhotometricFactor::linearize through the C ABI (mh_photo_*) against the CPU oracle (oracle/photo_ref.hpp)
 on identical synthetic frames: a 128 x 1024 staggered, skewed OS0-128-style scan of a textured room."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -431,3 +434,15 @@ def test_hip_matches_golden_fixture(ctx):
     F = check_against_golden(P, cfg, f0, f1, g, feats)
     F.destroy()
     P.destroy()
+
+
+def test_single_stage_kernels_still_match_the_oracle():
+    """Round 4 runs the image chain, the mask erosion and the yaw-table fill as ONE launch (photo_chain_kernel) where the
+    configuration fits its strip scheme; the single-stage kernels stay as the general path.  MH_PHOTO_UNFUSED=1 forces them:
+    the preprocess / golden / resident-scan tests of this file pass either way (a fresh process: the switch is read once)."""
+    import subprocess
+    env = dict(os.environ, MH_PHOTO_UNFUSED="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                          "preprocess_matches_oracle or golden_fixture or resident_scan or ragged"], capture_output=True, text=True, env=env, timeout=900,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
