@@ -1404,7 +1404,7 @@ def main():
                 # at N ranks that is N scans' worth of points per round, i.e. the per-GPU work of the replica mode (weak scaling)
                 nwin_s = max(world, 2)
                 clouds = [spts] + [synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + 1000 * i)[0] for i in range(1, nwin_s)]
-                thr = _throughput_forms(False, vmap, comm, clouds, max(20, args.steps), f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
+                thr = _throughput_forms(False, vmap, comm, clouds, args.steps, f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
                 result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
                                        f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
                            "n_ranks": comm.world, "backend": comm.backend, "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,

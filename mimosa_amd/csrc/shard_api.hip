@@ -199,6 +199,7 @@ struct mh_shard_comm
   unsigned long long n_rounds = 0;   // rounds enqueued so far
   std::vector<ShardCall> repairs;    // calls whose segments overflowed, waiting to be repeated (settle_rounds)
   std::vector<mh_shard_icp *> plain_pending;  // one rank, no protocol: the factors with mh_icp_linearize_async calls to collect
+  std::vector<mh_shard_icp *> factors;        // every live factor of this communicator (a communicator destroyed first orphans them)
 
   int peer_missing()
   {
@@ -488,6 +489,10 @@ void mh_shard_comm_destroy(mh_shard_comm * comm)
     for (DevBuf * b : {&comm->ws_send, &comm->ws_recv, &comm->ws_ar, &comm->ws_loc}) b->release(true);
     if (comm->h_ring) AllocCache::free_pinned(comm->h_ring, sizeof(mh::ShardPublish) * comm->ring_width * kShardRing);
   }
+  for (mh_shard_icp * S : comm->factors) {  // factors that outlive their communicator can only be destroyed
+    S->comm = nullptr;
+    S->broken = true;
+  }
   if (comm->is_rccl && comm->nccl) {
     (void)hipSetDevice(comm->device);
     (void)rccl().CommDestroy(comm->nccl);
@@ -513,6 +518,10 @@ void mh_shard_icp_destroy(mh_shard_icp * S)
   if (S->ctx) {
     (void)mh_enter(S->ctx);
     (void)hipStreamSynchronize(S->ctx->stream);
+  }
+  if (S->comm) {
+    auto & all = S->comm->factors;
+    all.erase(std::remove(all.begin(), all.end(), S), all.end());
   }
   if (S->comm) {  // calls nobody waited for: the rounds stay (other factors' results are in them), this factor's part is dropped
     for (ShardRound & r : S->comm->rounds)
@@ -542,6 +551,7 @@ static int shard_icp_create_impl(mh_ctx * ctx, mh_shard_comm * comm, mh_map * ma
   mh_shard_icp * S = new mh_shard_icp;
   S->ctx = ctx;
   S->comm = comm;
+  comm->factors.push_back(S);
   S->block_log2 = log2;
   S->collective = comm->world > 1 || (scfg && scfg->force_collectives);
   S->stats.world = comm->world;
@@ -1109,6 +1119,8 @@ int check_round(mh_shard_icp * const * Ss, size_t B, const double * R_src, const
   for (size_t f = 0; f < B; ++f)
     if (!Ss[f]) return fail(nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": NULL factor");
   mh_ctx * ctx = Ss[0]->ctx;
+  for (size_t f = 0; f < B; ++f)
+    if (!Ss[f]->comm) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": the factor's communicator was destroyed");
   for (size_t f = 0; f < B; ++f) {
     const mh_shard_icp * S = Ss[f];
     if (S->ctx != ctx || S->comm != Ss[0]->comm) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": factors of different contexts / communicators");
@@ -1217,6 +1229,7 @@ int mh_shard_icp_wait(mh_shard_icp * S)
 {
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_wait", [&]() -> int {
     if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_wait: NULL argument");
+    if (!S->comm) return fail(S->ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_wait: the factor's communicator was destroyed");
     if (!S->collective) {  // every factor of the communicator with enqueued calls, like the rounds of the collective form
       int rc_all = mh_icp_wait(S->icp);
       for (mh_shard_icp * q : S->comm->plain_pending)
@@ -1266,7 +1279,7 @@ static int shard_icp_get_state_impl(mh_shard_icp * S, uint64_t * origin, int32_t
   if (capacity < S->n_live) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_get_state: capacity too small");
   if (!S->collective) {
     if (origin)
-      for (size_t i = 0; i < S->n_live; ++i) origin[i] = (static_cast<uint64_t>(S->comm->rank) << 32) | i;
+      for (size_t i = 0; i < S->n_live; ++i) origin[i] = (static_cast<uint64_t>(S->stats.rank) << 32) | i;
     return mh_icp_get_state(icp, status, means, normals);
   }
   MH_HIP(ctx, mh_enter(ctx));
@@ -1308,8 +1321,8 @@ int mh_shard_icp_stats(const mh_shard_icp * S, mh_shard_stats * out)
   out->slot_capacity = S->slot_capacity;
   out->n_total = S->n_total;
   out->segment_records = S->seg_cap;
-  out->world = S->comm->world;
-  out->rank = S->comm->rank;
+  out->world = S->comm ? S->comm->world : S->stats.world;
+  out->rank = S->comm ? S->comm->rank : S->stats.rank;
   out->collective = S->collective ? 1 : 0;
   out->linearize_count = S->icp->linearize_count;
   return MH_OK;
