@@ -189,7 +189,7 @@ __device__ __forceinline__ double lane_get(double v, int l)
 // (one literal per VOP3), one v_and_or_b32 with register operands.
 struct KeyConsts
 {
-  uint32_t ymask, ymagic, kmask;
+  uint32_t ymask, ymagic, kmask, xmask, xmagic;
 };
 
 // Coarse key of one candidate: packed word w (3 x 10-bit voxel-relative coordinates), voxel offsets in grid units,
@@ -216,23 +216,61 @@ __device__ __forceinline__ void cmp_exch(uint32_t & a, uint32_t & b)
   a = lo;
 }
 
-// Four candidates (one 16-byte load) into the sorted top-KK.  KK == 8: sort the quad (5 compare-exchanges),
-// half-clean it against the upper half of the sorted top-8 (C[i] = min(ck[4+i], q[3-i]) keeps the 8 smallest of the
-// 12 as a bitonic sequence), bitonic-merge the 8 (12 compare-exchanges): 38 min/max ops instead of 4 x 15 for four
-// serial insertions.  Other KK (generic k <= 8 path): serial insertion.  mfy: y offset already folded with the 2^13
-// magic; pb: payload of the quad's slot 0; s0: first slot of the quad; cnt: points in the voxel.
+// Four candidates (one 16-byte load) into the sorted top-KK.  The scan is VALU-bound while both waves of a SIMD are in it
+// (~135 instructions per quad in round 3), so the arithmetic is written for instruction count:
+//   keys   two candidates per packed-f32 instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: same IEEE results as the scalar
+//          forms, same operation order dy^2 -> + dx^2 -> + dz^2), validity = slot index below `vcnt` (valid slots of THIS
+//          quad, 0..4, worked out once by the cursor)
+//   KK == 8  sort the quad (5 compare-exchanges); half-clean it against the sorted top-8 and run the first merge stage in
+//          one step: with ck[i] <= ck[4+i], min(ck[i], min(ck[4+i], q)) = min(ck[i], q) and max(ck[i], min(ck[4+i], q)) =
+//          med3(ck[i], ck[4+i], q) — 2 instructions per pair instead of 3; then the two remaining bitonic stages: 34
+//          min / max / med3 ops instead of 4 x 15 for four serial insertions.
+//   other KK (generic k <= 8 path): serial insertion.
+// mfy: y offset already folded with the 2^13 magic; pb: payload of the quad's slot 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f32x2 coarse_dist2(const KeyConsts & kc, uint32_t wa, uint32_t wb, float ofx, float mfy, float ofz)
+{
+  // x: its bit field (bits 0-9) OR-ed into the mantissa of 2^23 (ulp 1) and 2^23 subtracted again, exactly — one v_and_or
+  // and half a packed subtract instead of mask + convert
+  const f32x2 xm = {__uint_as_float((wa & kc.xmask) | kc.xmagic), __uint_as_float((wb & kc.xmask) | kc.xmagic)};
+  const f32x2 x = xm - 8388608.0f;
+  const f32x2 y = {__uint_as_float((wa & kc.ymask) | kc.ymagic), __uint_as_float((wb & kc.ymask) | kc.ymagic)};
+  // z: bits 20-29; a stored word has bits 30-31 clear (map_kernels.hip), an unused slot's key is discarded whatever it decodes to
+  const f32x2 z = {static_cast<float>(wa >> 20), static_cast<float>(wb >> 20)};
+  const f32x2 dx = x + ofx, dy = y - mfy, dz = z + ofz;
+  f32x2 d = dy * dy;
+  d = __builtin_elementwise_fma(dx, dx, d);
+  d = __builtin_elementwise_fma(dz, dz, d);
+  return d;
+}
 template <int KK>
 __device__ __forceinline__ void merge_quad(uint32_t (&ck)[KK], const KeyConsts & kc, const uint4 qw, float ofx, float mfy, float ofz,
-                                           uint32_t pb, uint32_t s0, uint32_t cnt)
+                                           uint32_t pb, uint32_t vcnt)
 {
-  uint32_t k0 = coarse_key(kc, qw.x, ofx, mfy, ofz, pb, s0 + 0u < cnt);
-  uint32_t k1 = coarse_key(kc, qw.y, ofx, mfy, ofz, pb | 1u, s0 + 1u < cnt);
-  uint32_t k2 = coarse_key(kc, qw.z, ofx, mfy, ofz, pb | 2u, s0 + 2u < cnt);
-  uint32_t k3 = coarse_key(kc, qw.w, ofx, mfy, ofz, pb | 3u, s0 + 3u < cnt);
+  const f32x2 da = coarse_dist2(kc, qw.x, qw.y, ofx, mfy, ofz), db = coarse_dist2(kc, qw.z, qw.w, ofx, mfy, ofz);
+  uint32_t k0 = (__float_as_uint(da.x) & kc.kmask) | pb;
+  uint32_t k1 = (__float_as_uint(da.y) & kc.kmask) | (pb | 1u);
+  uint32_t k2 = (__float_as_uint(db.x) & kc.kmask) | (pb | 2u);
+  uint32_t k3 = (__float_as_uint(db.y) & kc.kmask) | (pb | 3u);
+  k0 = vcnt > 0u ? k0 : 0xFFFFFFFFu;
+  k1 = vcnt > 1u ? k1 : 0xFFFFFFFFu;
+  k2 = vcnt > 2u ? k2 : 0xFFFFFFFFu;
+  k3 = vcnt > 3u ? k3 : 0xFFFFFFFFu;
   if constexpr (KK == 8) {
     cmp_exch(k0, k1); cmp_exch(k2, k3); cmp_exch(k0, k2); cmp_exch(k1, k3); cmp_exch(k1, k2);
-    ck[4] = min(ck[4], k3); ck[5] = min(ck[5], k2); ck[6] = min(ck[6], k1); ck[7] = min(ck[7], k0);
-    cmp_exch(ck[0], ck[4]); cmp_exch(ck[1], ck[5]); cmp_exch(ck[2], ck[6]); cmp_exch(ck[3], ck[7]);
+    const uint32_t q[4] = {k3, k2, k1, k0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t hi = med3_u32(ck[i], ck[4 + i], q[i]);
+      ck[i] = min(ck[i], q[i]);
+      ck[4 + i] = hi;
+    }
     cmp_exch(ck[0], ck[2]); cmp_exch(ck[1], ck[3]); cmp_exch(ck[4], ck[6]); cmp_exch(ck[5], ck[7]);
     cmp_exch(ck[0], ck[1]); cmp_exch(ck[2], ck[3]); cmp_exch(ck[4], ck[5]); cmp_exch(ck[6], ck[7]);
   } else {
@@ -262,7 +300,8 @@ struct ScanStage
 {
   uint4 quad;     // four packed candidates
   float4 ofs;     // voxel offset in grid units (x, y, z)
-  uint32_t meta;  // scan position << 6 | live point count << 11 | quad index << 16
+  uint32_t pb;    // payload of the quad's slot 0: scan position << 5 | first slot
+  uint32_t vcnt;  // valid slots of this quad: 0 (dead stage) .. 4
 };
 template <int NOFF>
 struct ScanCursor
@@ -282,7 +321,6 @@ struct ScanCursor
       nq_cur = static_cast<uint32_t>(qc0 >> (3 * o_cur)) & 7u;
     else
       nq_cur = static_cast<uint32_t>((o_cur < 21 ? qc0 : qc1) >> (3 * (o_cur < 21 ? o_cur : o_cur - 21))) & 7u;
-    const bool live = qd < nq_cur;
     const uint32_t e = list[o_cur * lds_stride];  // off the cursor's dependency chain
     ScanStage st;
     st.ofs = lut4[o_cur];
@@ -292,12 +330,22 @@ struct ScanCursor
       // a dead stage (this lane has no quad left while others of the wave still scan) loads quad 0 of voxel 0: every dead lane
       // the SAME 16 bytes, one L1 transaction for all of them instead of one each.  Opaque to the compiler (a select on the
       // index makes it sink the LDS read of `e` into a branch).
-      const uint32_t lm = 0u - static_cast<uint32_t>(live);
+      const uint32_t lm = 0u - static_cast<uint32_t>(qd < nq_cur);
       asm volatile("v_and_b32 %0, %0, %1" : "+v"(qidx) : "v"(lm));
     }
 #endif
+#ifdef MH_FAKE_SCAN_ADDR  // tuning experiment only (wrong results): every scan load reads quad 0 — the scan without its scattered line fills
+    {
+      uint32_t zero = 0u;
+      asm volatile("v_and_b32 %0, %0, %1" : "+v"(qidx) : "v"(zero));
+    }
+#endif
     st.quad = qbuckets[qidx];
-    st.meta = (static_cast<uint32_t>(o_cur) << 6) | ((live ? (e & 31u) : 0u) << 11) | (qd << 16);
+    // valid slots: the voxel's count minus the slots before this quad, clamped to 0..4 — a quad index at or past the
+    // voxel's last (an exhausted cursor keeps counting) gives 0 by itself: no liveness select
+    const uint32_t q4 = qd << 2;
+    st.vcnt = static_cast<uint32_t>(min(max(static_cast<int>(e & 31u) - static_cast<int>(q4), 0), 4));
+    st.pb = (static_cast<uint32_t>(o_cur) << 5) | q4;
     ++qd;
     return st;
   }
@@ -356,10 +404,9 @@ __device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage 
   for (int u = 0; u < MH_PIPE; ++u) {
     const ScanStage st = stage[u];
     stage[u] = cur.advance(list, lds_stride, lut4, qbuckets);  // refill this stage
-    const uint32_t cnt_ = (st.meta >> 11) & 31u, s0_ = ((st.meta >> 16) & 7u) * 4u;
-    n_scanned += static_cast<uint32_t>(min(max(static_cast<int>(cnt_) - static_cast<int>(s0_), 0), 4));
-    live_quads += cnt_ ? 1u : 0u;
-    merge_quad<KK>(ck, kc, st.quad, st.ofs.x + cx0, cy1 - st.ofs.y, st.ofs.z + cz2, ((st.meta >> 1) & 0x3E0u) | s0_, s0_, cnt_);
+    n_scanned += st.vcnt;
+    live_quads += st.vcnt ? 1u : 0u;
+    merge_quad<KK>(ck, kc, st.quad, st.ofs.x + cx0, cy1 - st.ofs.y, st.ofs.z + cz2, st.pb, st.vcnt);
   }
   return live_quads;
 }
@@ -502,8 +549,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint32_t ck[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
-  KeyConsts kc{0xFFC00u, 0x46000000u, ~0x3FFu};
-  asm volatile("" : "+v"(kc.ymask), "+v"(kc.ymagic), "+v"(kc.kmask));  // opaque: keeps them in registers
+  KeyConsts kc{0xFFC00u, 0x46000000u, ~0x3FFu, 0x3FFu, 0x4B000000u};
+  asm volatile("" : "+v"(kc.ymask), "+v"(kc.ymagic), "+v"(kc.kmask), "+v"(kc.xmask), "+v"(kc.xmagic));  // opaque: keeps them in registers
 
   // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
   n_scanned = 0;
@@ -517,7 +564,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     for (int u = 0; u < kBucketStride / 4; ++u) qw[u] = b[static_cast<uint32_t>(4 * u) < cc ? u : 0];  // all issued together
 #pragma unroll
     for (int u = 0; u < kBucketStride / 4; ++u) {
-      if (static_cast<uint32_t>(4 * u) < cc) merge_quad<KK>(ck, kc, qw[u], ofx, 8192.0f - ofy, ofz, static_cast<uint32_t>(4 * u), static_cast<uint32_t>(4 * u), cc);
+      if (static_cast<uint32_t>(4 * u) < cc) merge_quad<KK>(ck, kc, qw[u], ofx, 8192.0f - ofy, ofz, static_cast<uint32_t>(4 * u), min(cc - static_cast<uint32_t>(4 * u), 4u));
     }
   }
   MH_STAMP(dbg, 10);
@@ -567,7 +614,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     constexpr int HS = MH_SHARE_HELPERS;
     uint32_t job_base = 0u, job_pending = 0u, job_await = 0u;  // this lane's jobs: first slot, not resolved yet, held by a helper
     for (int trip = 0;; ++trip) {
-      if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) {  // a dead stage 0 means dead stages 1..3
+      if (!__any(static_cast<int>(stage[0].vcnt))) {  // a dead stage 0 means dead stages 1..3
         if (SHARE && __any(static_cast<int>(job_pending))) {
           // this wave's own shares are done: every lane takes back the first of its jobs that nobody has claimed
           bool took = false;
@@ -712,7 +759,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #pragma unroll
         for (int u = 0; u < kPipe; ++u) stage[u] = hc.advance(hlist, lds_stride, lut4, map.qbuckets);
         for (int trip = 0;; ++trip) {
-          if (!__any(static_cast<int>((stage[0].meta >> 11) & 31u))) break;
+          if (!__any(static_cast<int>(stage[0].vcnt))) break;
           if (MH_PRUNE_TRIPS) {
             const uint32_t keep = prune_keep_mask<K, KK, NOFF>(hk, hbox, k, kErrG, kth_owner);
             hc.rem &= keep;

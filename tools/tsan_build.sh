@@ -2,7 +2,7 @@
 # ThreadSanitizer pass over the HOST side of the library: every .hip file's host code compiled with
 # -fsanitize=thread (hipcc ignores the flag for the device code), the drivers of the host mirror with the same clang.
 #   tools/tsan_build.sh          (here, no GPU)   -> mimosa_amd/lib/tsan/{libmimosa_hip.so, replay_native, sharded_pipeline}
-#   tools/tsan_build.sh run      (GPU box)        -> gpurun_out/tsan_*.log
+#   tools/tsan_build.sh run      (GPU box)        -> gpurun_out/tsan_*.log   (take mimosa_amd/lib/tsan/ out of .gpurunignore first)
 # What TSAN cannot see: the HIP runtime is not instrumented, so ordering established ONLY through it (a stream
 # synchronisation between two host threads) is invisible, and device writes into mapped host memory are not events at all.
 set -u
