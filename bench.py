@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--profile-mode", action="store_true",
                     help="only the warm-up and the timed region (what rocprofv3 should see): no latency, "
                          "re-linearization, PCIe, concurrent or CPU-baseline legs")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="HIP events bracket the kernels of every n-th linearize call of the timed region "
                          "(an event record costs ~4 us of stream time; 1 = every call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,20 +175,6 @@ def main():
         f2.linearize(R, t)
         ctxs.append(c2)
         factors.append(f2)
-    # The several-scans-in-flight pass (value_concurrent) gets its contexts NOW, while this process has created no other
-    # HIP stream: HIP multiplexes a process's streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), and two busy streams that
-    # share a queue serialise.  Rounds 2 and 3 created these contexts after the photometric / replay legs had created theirs
-    # and measured 3.8 Gpts/s where round 1 (no such legs yet) had measured 5.0 — tools/conc_probe.py reproduces both from
-    # any commit by creating 0 or 1-2 contexts first (profiles/r04_concurrency_bisect.md).
-    conc_ctxs, conc_factors = [], []
-    if args.streams == 1 and args.concurrent_streams > 1 and not args.profile_mode:
-        for sidx in range(1, args.concurrent_streams):
-            c2 = capi.Context(local_rank)
-            p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + rank + 1000 * sidx)
-            f2 = capi.ICPFactor(c2, gmap, p2, capi.make_reg_config(**cfgd))
-            f2.linearize(R, t)
-            conc_ctxs.append(c2)
-            conc_factors.append(f2)
     stats = gmap.stats()
     setup_s = time.time() - t0
 
@@ -251,25 +237,28 @@ def main():
         for _ in range(4):
             block_s.append(timed_block(args.steps, outs))
 
+    # ---- several scans in flight: 4 contexts (one HIP stream each) sharing the map, in a process of their own ----
+    # HIP multiplexes a process's streams onto 4 hardware queues and two busy streams that share one serialise
+    # (profiles/r04_concurrency_bisect.md); this process's context holds a second stream (the component server's side
+    # stream), so four MORE contexts here would share queues (3.6-3.7 Gpts/s measured that way).  tools/conc_probe.py runs
+    # the same loop — cold linearizes dealt round-robin to the streams by one host thread, <= 32 in flight per stream — in a
+    # fresh process with one stream per context (MH_OVERLAP=0).
     conc = None
-    if conc_factors:
-        for c in ctxs:
-            c.set_profiling(False)
-        cf = factors + conc_factors
-        ksteps = args.steps * 2
-        run_steps(max(args.warmup, 8 * len(cf)), fs=cf)
-        cs = [timed_block(ksteps, fs=cf, sync_extra=conc_ctxs) for _ in range(5)]
-        med = float(np.median(cs))
-        conc = {"streams": len(cf), "steps": ksteps, "value": round(n_pts * ksteps * world / med / 1e6, 2), "ms_per_step": round(med / ksteps * 1e3, 5),
-                "blocks_ms_per_step": [round(v / ksteps * 1e3, 5) for v in cs],
-                "note": "median of 5 blocks; the contexts were created before any other leg created a HIP stream (more than 4 live streams "
-                        "per process share hardware queues: with 1-2 streams created first this figure reads 4.0 instead of 4.8-5.0 Gpts/s)"}
-        for f in conc_factors:
-            f.destroy()
-        for c in conc_ctxs:
-            c.close()
-        for c in ctxs:
-            c.set_profiling(event_every)
+    if args.streams == 1 and args.concurrent_streams > 1 and not args.profile_mode and world == 1:
+        import subprocess
+        env = dict(os.environ, MH_OVERLAP="0")
+        here = os.path.dirname(os.path.abspath(__file__))
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(here, "tools", "conc_probe.py"), "--streams", str(args.concurrent_streams),
+                                 "--steps", str(max(400, args.steps * 2))], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1]
+            pj = json.loads(line)
+            conc = {"streams": pj["streams"], "steps": pj["steps"], "value": pj["conc_mpts"], "ms_per_step": pj["conc_ms"],
+                    "single_stream_same_process_ms": pj["single_ms"], "one_host_thread_per_stream_mpts": pj["threads_mpts"],
+                    "note": "tools/conc_probe.py in a process of its own (best of 3 passes of this many steps): 4 contexts, one HIP stream each "
+                            "(MH_OVERLAP=0), sharing one map; see the comment in bench.py"}
+        except Exception as e:  # the figure is a side leg: say why it is missing
+            conc = {"error": f"{type(e).__name__}: {e}"}
 
     k3_ms = np.array([o.gpu_ms_linearize for o in outs if o.gpu_ms_linearize >= 0], dtype=np.float64)
     k4_ms = np.array([o.gpu_ms_localizability for o in outs if o.gpu_ms_localizability >= 0], dtype=np.float64)
@@ -774,7 +763,7 @@ def main():
 
     # Aggregate throughput with several independent scans in flight (own HIP streams, shared map): a single
     # 131 072-point scan can only put 2 waves on a SIMD, concurrent scans fill the machine.  Measured at the start of the run
-    # (`conc`, below the timed region): see the note where its contexts are created.
+    # (`conc`, below the timed region: measured in a process of its own).
     total_pts = n_pts * args.steps * world
     value = total_pts / elapsed / 1e6
     mean_cq = float(last["mean_candidates"])

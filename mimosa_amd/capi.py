@@ -18,7 +18,7 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 
 # every symbol include/mimosa_hip.h declares
 EXPORTS = [
-    "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
+    "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling", "mh_set_overlap",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
     "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
@@ -326,6 +326,7 @@ def load(build_if_missing: bool = True):
     L.mh_last_error.argtypes = [vp]
     L.mh_last_error.restype = C.c_char_p
     L.mh_set_profiling.argtypes = [vp, i32]
+    L.mh_set_overlap.argtypes = [vp, i32]
     L.mh_stream.argtypes = [vp]
     L.mh_stream.restype = vp
     L.mh_synchronize.argtypes = [vp]
@@ -469,6 +470,10 @@ class Context:
     def set_profiling(self, every):
         """0/False = off, n = HIP events around the kernels of every n-th linearize call (True = every call)."""
         self.check(self.L.mh_set_profiling(self.h, int(every)))
+
+    def set_overlap(self, on):
+        """K4 of pipelined linearize calls on a side stream of the context (default on); off = one stream per context."""
+        self.check(self.L.mh_set_overlap(self.h, int(bool(on))))
 
     def synchronize(self):
         self.check(self.L.mh_synchronize(self.h))

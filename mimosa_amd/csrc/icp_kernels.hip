@@ -192,22 +192,12 @@ struct KeyConsts
   uint32_t ymask, ymagic, kmask, xmask, xmagic;
 };
 
-// Coarse key of one candidate: packed word w (3 x 10-bit voxel-relative coordinates), voxel offsets in grid units,
-// payload (scan position << 5 | slot), validity.  y is decoded by OR-ing its bit field (bits 10-19) into the mantissa
-// of 2^13 (whose mantissa bit 10 weighs 1, ulp 2^-10): one v_and_or + one v_sub instead of extract + convert + add;
-// the caller folds the 2^13 into the per-voxel offset `mfy` (rounding <= 2^-11 grid units, inside the error budget).
-// The same trick on x (bits 0-9) would need 2^23, whose ulp of one whole grid unit would destroy the sub-grid offset.
-__device__ __forceinline__ uint32_t coarse_key(const KeyConsts & kc, uint32_t w, float ofx, float mfy, float ofz, uint32_t payload,
-                                               bool valid)
-{
-  const float dx = static_cast<float>(w & 1023u) + ofx;
-  const float dy = __uint_as_float((w & kc.ymask) | kc.ymagic) - mfy;
-  const float dz = static_cast<float>((w >> 20) & 1023u) + ofz;
-  const float d = dx * dx + dy * dy + dz * dz;
-  const uint32_t t = (__float_as_uint(d) & kc.kmask) | payload;
-  return valid ? t : 0xFFFFFFFFu;
-}
-
+// Coarse key of a candidate: packed word w (3 x 10-bit voxel-relative coordinates), voxel offsets in grid units, payload
+// (scan position << 5 | slot).  y is decoded by OR-ing its bit field (bits 10-19) into the mantissa of 2^13 (whose mantissa
+// bit 10 weighs 1, ulp 2^-10): one v_and_or + a subtract instead of extract + convert + add; the caller folds the 2^13 into
+// the per-voxel offset `mfy` (rounding <= 2^-11 grid units, inside the error budget).  x (bits 0-9) goes through the mantissa
+// of 2^23 the same way, but 2^23 — whose ulp is one whole grid unit — is subtracted again exactly before the sub-grid offset
+// is added (coarse_dist2 below).
 // compare-exchange: a <- min, b <- max
 __device__ __forceinline__ void cmp_exch(uint32_t & a, uint32_t & b)
 {
@@ -1135,17 +1125,19 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int * ticket, unsigned i
 // Deterministic parallel fold of the per-block partial rows by the last-arriving block: thread
 // (entry, lane-segment) sums blocks seg, seg+NSEG, ... with four independent accumulators (loads
 // stay in flight), segments are then combined in index order.  Result in s_out[0..n_ent).
-template <int EW, int TPB, bool PLAIN = false>  // entries rounded up: 32 (unary / K4) or 96 (binary); TPB threads per workgroup
+template <int EW, int TPB, bool PLAIN = false, int BATCH = 16>  // entries rounded up: 32 (unary / K4) or 96 (binary); TPB threads per workgroup
 __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks, int n_ent, double * s_seg,
                                           double * s_out)
 {  // PLAIN: the rows were written by an EARLIER kernel (plain stores, visible at the kernel boundary): ordinary cached loads
-  constexpr int NSEG = TPB / EW;
+  // The segmentation — and with it the order of the additions — is that of a 256-thread workgroup whatever TPB is: the same
+  // rows fold to the same bits in K3's own last block, in a 512-thread K4 and in the 256-thread K4 of a side-stream call.
+  constexpr int NSEG = (TPB < 256 ? TPB : 256) / EW;
   const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
   if (seg < NSEG && ent < n_ent) {
     // all of this thread's rows are requested before the first one is consumed: ONE memory round trip for
     // the usual <= 16 rows per thread (the fold is the serial tail of the kernel; four dependent rounds
     // of write-through loads cost ~4 us)
-    constexpr int kBatch = 16;
+    constexpr int kBatch = BATCH;  // (32: K4's 256 rows over 8 segments in one round trip, where the registers are there)
     double acc = 0.0;
     for (int b0 = seg; b0 < n_blocks; b0 += kBatch * NSEG) {
       double v[kBatch];
@@ -1172,6 +1164,33 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
 }
 
 }  // namespace
+
+// Unwhitened, normalised Jacobian directions of one point, as the component localizabilities project them
+// (geometric_factor.hpp:343-352, :434-457): n_s = R^T n, jr = (n_s x p) normalised (Eigen normalized(): unchanged when the
+// squared norm is zero), jt = -n_s.  One body for K3 (plain factors: it writes them into the call's record) and K4 (map-sharded
+// and two-phase callers: from the stored normals), so both produce the same bits.
+template <typename A>
+__device__ __forceinline__ void loc_directions(const A & a, const double nx, const double ny, const double nz, const double px,
+                                               const double py, const double pz, double (&jr)[3], double (&jt)[3])
+{
+  const double ns0 = a.R[0] * nx + (a.R[3] * ny + a.R[6] * nz);
+  const double ns1 = a.R[1] * nx + (a.R[4] * ny + a.R[7] * nz);
+  const double ns2 = a.R[2] * nx + (a.R[5] * ny + a.R[8] * nz);
+  double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
+  const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
+  if (nr2 > 0.0) {
+    const double inv = 1.0 / sqrt(nr2);
+    r0 *= inv;
+    r1 *= inv;
+    r2 *= inv;
+  }
+  jr[0] = r0;
+  jr[1] = r1;
+  jr[2] = r2;
+  jt[0] = -ns0;
+  jt[1] = -ns1;
+  jt[2] = -ns2;
+}
 
 // ------------------------------------------------------------------------------------------------
 // K3
@@ -1213,6 +1232,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
   const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
+  // side-stream bookkeeping (IcpArgs::sig): the counter this call's stores may have to wait for is requested now and looked
+  // at after the per-point section — its round trip is never waited for
+  [[maybe_unused]] bool k4_ok = true;
+  __shared__ int s_hold;
+  if constexpr (!SHARD) {
+    if (a.k4_wait && threadIdx.x < 64)
+      for (int b = static_cast<int>(threadIdx.x); b < a.k4_blocks; b += 64)
+        k4_ok = k4_ok && static_cast<int>(__hip_atomic_load(&a.sig4[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.k4_need) >= 0;
+    if (a.srv_posted && block_id == 0 && threadIdx.x == 0)  // announce the call to the component server (LocServerArgs)
+      __hip_atomic_store(a.srv_posted, a.srv_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
   if constexpr (kShare) {
     if (threadIdx.x == 0) s_share[0] = 0u;
@@ -1222,6 +1252,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   __syncthreads();
 
   double row[NV];
+  [[maybe_unused]] double rec_jr[3] = {0.0, 0.0, 0.0}, rec_jt[3] = {0.0, 0.0, 0.0};  // this point's entry of the call's record (IcpArgs::rec)
+  [[maybe_unused]] int rec_st = -1;
   uint32_t cnt_pack = 0u;  // this lane's k-NN counters, reduced per wave after the per-point section
   bool did_knn = false, did_fall = false;
 #ifdef MH_TIMELINE
@@ -1455,6 +1487,12 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       }
     }
     if (!gone) a.status[qi] = st;
+    if constexpr (!SHARD) {
+      if (a.rec) {
+        if (st == MH_VALID) loc_directions(a, nrm[0], nrm[1], nrm[2], px, py, pz, rec_jr, rec_jt);
+        rec_st = st;
+      }
+    }
   }
   {
     // k-NN counters: one LDS atomic per wave and counter (uniform control flow: every lane is active here)
@@ -1476,8 +1514,51 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   // 8. H += J^T J, b += J^T e, f += e^2 (:363-382) — LDS tile of rows (the k-NN arena is dead now),
   //    then every thread owns one (entry, segment) pair of the upper triangle of sum v v^T.
   MH_STAMP(a.dbg, 3);
+  if constexpr (!SHARD) {
+    if (a.k4_wait && threadIdx.x < 64) {
+      const bool all_ok = __all(static_cast<int>(k4_ok)) != 0;
+      if (threadIdx.x == 0) s_hold = all_ok ? 0 : 1;
+    }
+  }
   __syncthreads();
   MH_STAMP(a.dbg, 4);
+  if constexpr (!SHARD) {
+    if (a.k4_wait && s_hold) {  // (not seen in practice: the K4 in question ended a whole K3 ago)
+      if (threadIdx.x < 64) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (;;) {
+          bool ok = true;
+          for (int b = static_cast<int>(threadIdx.x); b < a.k4_blocks; b += 64)
+            ok = ok && static_cast<int>(__hip_atomic_load(&a.sig4[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.k4_need) >= 0;
+          if (__all(static_cast<int>(ok))) break;
+          if (__builtin_readcyclecounter() - t0 > 8000000000ull) break;  // (the server gave up: that call is lost anyway)
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      __syncthreads();
+    }
+    if (a.rec && qi < a.n) {
+      // the call's record: what K4 reads of this point.  Side-stream calls write it through (K4 may run on another XCD, with
+      // no kernel boundary in between)
+      const size_t rn = static_cast<size_t>(a.rec_n);
+      int32_t * rst = reinterpret_cast<int32_t *>(a.rec + 6 * rn);
+      if (a.side) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          store_partial(&a.rec[static_cast<size_t>(c) * rn + qi], rec_jr[c]);
+          store_partial(&a.rec[static_cast<size_t>(3 + c) * rn + qi], rec_jt[c]);
+        }
+        __hip_atomic_store(&rst[qi], rec_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          a.rec[static_cast<size_t>(c) * rn + qi] = rec_jr[c];
+          a.rec[static_cast<size_t>(3 + c) * rn + qi] = rec_jt[c];
+        }
+        rst[qi] = rec_st;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
   if (static_cast<int>(threadIdx.x) < (kTileRows - TPB) * ROWW) s_rows[TPB * ROWW + threadIdx.x] = 0.0;
@@ -1513,12 +1594,13 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   // CUs idle in round 3).  Otherwise (no K4 behind it, or a map-sharded factor, whose sums feed an all-reduce): rows
   // write-through, ticket, fold by the last block.
   const bool fold_here = SHARD || a.tail != 0;
+  const bool through = fold_here || (!SHARD && a.side);
   if (threadIdx.x < NENT) {
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < SEGS; ++g) s += s_aux[g * NENT + threadIdx.x];
     double * dst = &a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x];
-    if (fold_here)
+    if (through)
       store_partial(dst, s);
     else
       *dst = s;
@@ -1528,10 +1610,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   if (threadIdx.x >= 128 && threadIdx.x < 132) {
     double * dst = &a.partials[static_cast<size_t>(block_id) * kPartialStride + NENT + (threadIdx.x - 128)];
     const double c = static_cast<double>(s_cnt[threadIdx.x - 128]);
-    if (fold_here)
+    if (through)
       store_partial(dst, c);
     else
       *dst = c;
+  }
+  if constexpr (!SHARD) {
+    if (a.side) {  // sign off: this workgroup's record entries and row are in memory
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&a.sig[block_id], a.side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 
   MH_STAMP(a.dbg, 5);
@@ -1641,7 +1730,18 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
 // normal instead of storing two more per-point vectors.  6 sums by wave shuffles, 9 counts by
 // ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
 // ------------------------------------------------------------------------------------------------
-template <int TPB, bool SHARD>
+// A plain factor's K4 runs 256-thread workgroups whatever K3 ran (a 512-thread K3 class gets twice the chunks per workgroup:
+// the same 2048 points, the same grid): a K4 launched on the side stream (LocArgs::side) sits on its CUs while the next
+// call's K3 starts, and it must FIT beside a K3 workgroup — K3 holds 2 waves x 168 VGPRs of every SIMD's 512, a 512-thread K4
+// workgroup (2 waves x 128) does not fit next to that and K3 then runs on the CUs K4 left free, in two rounds (measured:
+// 52.9 us per step instead of 48.1); one wave per SIMD does.  Synchronous calls run the same configuration, so the two
+// forms agree to the bit.
+// (512 - 2 x 168 = 176 registers per lane are what K3 leaves of a SIMD's file)
+#define MH_LOC_VGPRS __attribute__((amdgpu_waves_per_eu(3, 8)))  // at most 168 registers per lane
+__host__ __device__ constexpr int loc_tpb(int tpb, bool shard) { return (!shard && tpb > 256) ? 256 : tpb; }
+__host__ __device__ constexpr int loc_ch(int tpb, bool shard) { return shard ? 1 : (tpb > 256 ? 2 * kLocChunks : kLocChunks); }
+
+template <int TPB, bool SHARD, int CH>
 __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NW = TPB / 64;
@@ -1656,22 +1756,66 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   // happens BEFORE they are known: the status / point / normal of ALL of this workgroup's chunks are requested up front (one
   // round trip, in flight while the Hessian rows are folded), and the unwhitened Jacobian directions of the Valid points
   // (geometric_factor.hpp:343-352) are worked out while two lanes of the workgroup decompose H_rr and H_tt.
-  constexpr int CH = SHARD ? 1 : kLocChunks;  // == a.chunks_per_block (set by the launchers)
-  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
+  // (a plain factor without a record: its component pass is switched off but a batch runs K4 for every member — nothing to
+  // read, the host reports NaN for it)
+  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : (a.rec ? a.n : 0);
+  bool side = false;
+  if constexpr (!SHARD) {
+    side = a.side != 0;
+    if (side) {
+      // this kernel was launched on the context's side stream with nothing between it and the K3 whose record it reads: wait
+      // until every workgroup of that K3 has signed off (LocArgs::sig).  The waves not polling sit at the barrier.
+      if (threadIdx.x < 64) {
+        for (;;) {
+          bool ok = true;
+          for (int b = static_cast<int>(threadIdx.x); b < a.k3_blocks; b += 64)
+            ok = ok && static_cast<int>(__hip_atomic_load(&a.sig[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.side) >= 0;
+          if (__all(static_cast<int>(ok))) break;
+          __builtin_amdgcn_s_sleep(100);  // ~2.7 us between looks
+        }
+      }
+      __syncthreads();
+    }
+  }
   int st_c[CH];
-  float4 sp_c[CH];
-  double nx_c[CH], ny_c[CH], nz_c[CH];
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
+  double jr_c[CH][3], jt_c[CH][3];
+  [[maybe_unused]] float4 sp_c[CH];
+  [[maybe_unused]] double nx_c[CH], ny_c[CH], nz_c[CH];
+  // (eight chunks per workgroup: the second half is requested further down)
+  constexpr int CH0 = CH > kLocChunks ? CH / 2 : CH;
+  auto load_chunk = [&](const int ch) {
     const int i = (block_id * CH + ch) * TPB + static_cast<int>(threadIdx.x);
     const int i_ld = i < n_pts ? i : 0;
-    st_c[ch] = n_pts > 0 ? a.status[i_ld] : -1;
-    sp_c[ch] = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
-    nx_c[ch] = n_pts > 0 ? a.normal[3 * i_ld] : 0.0;
-    ny_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0;
-    nz_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
+    if constexpr (SHARD) {
+      st_c[ch] = n_pts > 0 ? a.status[i_ld] : -1;
+      sp_c[ch] = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
+      nx_c[ch] = n_pts > 0 ? a.normal[3 * i_ld] : 0.0;
+      ny_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0;
+      nz_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
+    } else {
+      // plain factor: the call's record (K3 wrote the directions, zero unless Valid, and the status)
+      const size_t rn = static_cast<size_t>(a.rec_n);
+      const int32_t * rst = reinterpret_cast<const int32_t *>(a.rec + 6 * rn);
+      if (side) {  // written through by a kernel that may still be running on other XCDs: loads that see memory
+        st_c[ch] = n_pts > 0 ? __hip_atomic_load(&rst[i_ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          jr_c[ch][c] = n_pts > 0 ? load_partial(&a.rec[static_cast<size_t>(c) * rn + i_ld]) : 0.0;
+          jt_c[ch][c] = n_pts > 0 ? load_partial(&a.rec[static_cast<size_t>(3 + c) * rn + i_ld]) : 0.0;
+        }
+      } else {
+        st_c[ch] = n_pts > 0 ? rst[i_ld] : -1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          jr_c[ch][c] = n_pts > 0 ? a.rec[static_cast<size_t>(c) * rn + i_ld] : 0.0;
+          jt_c[ch][c] = n_pts > 0 ? a.rec[static_cast<size_t>(3 + c) * rn + i_ld] : 0.0;
+        }
+      }
+    }
     if (i >= n_pts) st_c[ch] = -1;
-  }
+  };
+#pragma unroll
+  for (int ch = 0; ch < CH0; ++ch) load_chunk(ch);
   // The Hessian sums the eigenbases come from.  Plain factor: K3 ended at its per-workgroup rows; EVERY workgroup of this
   // kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed order of the old last-block
   // fold — so every workgroup holds the same bits), workgroup 0 also publishes them.  Map-sharded factor: the all-reduced
@@ -1682,10 +1826,18 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     sums = a.sums ? a.sums : a.result->sums;
   } else {
     const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
-    if (a.nv == 7)
-      fold_rows<32, TPB, true>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-    else
-      fold_rows<96, TPB, true>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    constexpr int FB = 32;  // rows in flight per thread: 256 rows over 8 segments in one round trip
+    if (a.nv == 7) {
+      if (side)
+        fold_rows<32, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+      else
+        fold_rows<32, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    } else {
+      if (side)
+        fold_rows<96, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+      else
+        fold_rows<96, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    }
     sums = s_h;
   }
   // The two eigenbases: given (two-phase callers), or derived here — one lane per 3 x 3 block (computeLocalizability,
@@ -1705,28 +1857,17 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     compute_localizability(Hb, loc, E);
     for (int q = 0; q < 9; ++q) s_E[(o ? 9 : 0) + q] = E[q];
   }
-  // Jacobian directions of this thread's points (independent of the eigenbases)
-  double jr_c[CH][3], jt_c[CH][3];
+  // second half of the records (CH0 above): behind the eigen-decompositions in program order, so that their registers are
+  // not live inside them — the waves that decompose nothing get here at once, and their round trip hides behind the two that do
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    const double px = sp_c[ch].x, py = sp_c[ch].y, pz = sp_c[ch].z;
-    const double ns0 = a.R[0] * nx_c[ch] + (a.R[3] * ny_c[ch] + a.R[6] * nz_c[ch]);
-    const double ns1 = a.R[1] * nx_c[ch] + (a.R[4] * ny_c[ch] + a.R[7] * nz_c[ch]);
-    const double ns2 = a.R[2] * nx_c[ch] + (a.R[5] * ny_c[ch] + a.R[8] * nz_c[ch]);
-    double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
-    const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
-    if (nr2 > 0.0) {  // Eigen normalized(): unchanged when the squared norm is zero
-      const double inv = 1.0 / sqrt(nr2);
-      r0 *= inv;
-      r1 *= inv;
-      r2 *= inv;
-    }
-    jr_c[ch][0] = r0;
-    jr_c[ch][1] = r1;
-    jr_c[ch][2] = r2;
-    jt_c[ch][0] = -ns0;
-    jt_c[ch][1] = -ns1;
-    jt_c[ch][2] = -ns2;
+  for (int ch = CH0; ch < CH; ++ch) load_chunk(ch);
+  // Jacobian directions of this thread's points (independent of the eigenbases): map-sharded / two-phase callers work them
+  // out here from the stored normals, plain factors loaded them above
+  if constexpr (SHARD) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      loc_directions(a, nx_c[ch], ny_c[ch], nz_c[ch], static_cast<double>(sp_c[ch].x), static_cast<double>(sp_c[ch].y),
+                     static_cast<double>(sp_c[ch].z), jr_c[ch], jt_c[ch]);
   }
   __syncthreads();
   double er[9], et[9];
@@ -1786,6 +1927,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     }
     (void)n_blocks;
     (void)s_last;
+    if (side && threadIdx.x == 0) __hip_atomic_store(&a.sig4[block_id], a.side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every value read was used before the barrier above
     return;
   } else {
   if (threadIdx.x < 15) {
@@ -1821,23 +1963,23 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   }
 }
 
-template <int TPB, bool SHARD>
-__global__ __launch_bounds__(TPB) void icp_localizability_kernel(const LocArgs a)
+template <int TPB, bool SHARD>  // TPB: the class of the K3 launch (256 / 512 threads); this kernel runs loc_tpb(TPB, SHARD) threads
+__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) MH_LOC_VGPRS void icp_localizability_kernel(const LocArgs a)
 {
-  icp_localizability_body<TPB, SHARD>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD)>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 template <int TPB>
-__global__ __launch_bounds__(TPB) void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
+__global__ __launch_bounds__(loc_tpb(TPB, false)) MH_LOC_VGPRS void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
 {
   const int b = static_cast<int>(blockIdx.x);
   const int f = batch_factor_of(start, n_factors, b);
   const int s0 = __builtin_amdgcn_readfirstlane(start[f]), s1 = __builtin_amdgcn_readfirstlane(start[f + 1]);
   const LocArgs a = load_uniform(args + f);
-  icp_localizability_body<TPB, false>(a, b - s0, s1 - s0);
+  icp_localizability_body<loc_tpb(TPB, false), false, loc_ch(TPB, false)>(a, b - s0, s1 - s0);
 }
 
 template <int TPB, bool SHARD>
-__global__ __launch_bounds__(TPB) void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
+__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) MH_LOC_VGPRS void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
 {
   (void)blk;
   const auto * p = (const BatchInline<LocArgs> *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1845,7 +1987,53 @@ __global__ __launch_bounds__(TPB) void icp_localizability_batch_inline_kernel(co
   const int f = batch_factor_of(p->start, p->n, b);
   const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
   const LocArgs a = load_uniform(p->a + f);
-  icp_localizability_body<TPB, SHARD>(a, b - s0, s1 - s0);
+  icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD)>(a, b - s0, s1 - s0);
+}
+
+// The component server (icp_device.hpp: LocServerArgs): K4's body in a loop over the calls the context's K3s announce.
+__global__ __launch_bounds__(256) MH_LOC_VGPRS void icp_localizability_server_kernel(const LocServerArgs s)
+{
+  __shared__ int s_cmd;
+  for (unsigned int j = s.first;; ++j) {
+    if (threadIdx.x == 0) {
+      int cmd = 0;
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      for (unsigned int it = 1u;; ++it) {
+        const unsigned int p = __hip_atomic_load(s.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<int>(p - (j + 1u)) >= 0) {
+          cmd = 1;
+          break;
+        }
+        if ((it & 7u) == 0u) {  // (a read of host memory: every eighth round)
+          const unsigned int st = __hip_atomic_load(s.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (st != 0u && static_cast<int>(j - st) >= 0) {
+            cmd = 2;
+            break;
+          }
+          // nothing to serve and no word from the host for ~4 s of shader clock: give up rather than hold the device for ever
+          // (a host that died, a stream layout this kernel must not be used with); the host sees its calls unanswered
+          if (__builtin_readcyclecounter() - t0 > 8000000000ull) {
+            cmd = 2;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(60);
+      }
+      s_cmd = cmd;
+    }
+    __syncthreads();
+    const int cmd = s_cmd;
+    __syncthreads();
+    if (cmd == 2) break;
+    const LocArgs a = load_uniform(&s.ring[j % static_cast<unsigned int>(s.ring_n)].a);
+    for (int vb = static_cast<int>(blockIdx.x); vb < a.srv_blocks; vb += static_cast<int>(gridDim.x)) {
+      if (a.srv_class > 256)
+        icp_localizability_body<256, false, loc_ch(kThreads, false)>(a, vb, a.srv_blocks);
+      else
+        icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);
+      __syncthreads();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1906,6 +2094,7 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 #define MH_TPB_SPLIT 65536  // clouds up to this many points run 256-thread workgroups, larger ones 512
 #endif
 static int linearize_tpb(int n) { return n <= MH_TPB_SPLIT ? 256 : kThreads; }
+int linearize_class(int n) { return linearize_tpb(n); }
 int linearize_grid(int n)
 {
   const int tpb = linearize_tpb(n);
@@ -1961,6 +2150,13 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
   return hipGetLastError();
 }
 
+int loc_server_grid() { return 64; }
+hipError_t launch_loc_server(const LocServerArgs & s, hipStream_t stream)
+{
+  hipLaunchKernelGGL(icp_localizability_server_kernel, dim3(loc_server_grid()), dim3(256), 0, stream, s);
+  return hipGetLastError();
+}
+
 hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
@@ -1976,7 +2172,7 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
     if (shard)
       hipLaunchKernelGGL((icp_localizability_kernel<kThreads, true>), grid, dim3(kThreads), 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, false>), grid, dim3(kThreads), 0, stream, a);
+      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, false>), grid, dim3(loc_tpb(kThreads, false)), 0, stream, a);
   }
   return hipGetLastError();
 }
@@ -2030,7 +2226,7 @@ hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_sta
   if (tpb == 256)
     hipLaunchKernelGGL(icp_localizability_batch_kernel<256>, dim3(total_grid), dim3(256), 0, stream, d_args, d_start, n_factors);
   else
-    hipLaunchKernelGGL(icp_localizability_batch_kernel<kThreads>, dim3(total_grid), dim3(kThreads), 0, stream, d_args, d_start,
+    hipLaunchKernelGGL(icp_localizability_batch_kernel<kThreads>, dim3(total_grid), dim3(loc_tpb(kThreads, false)), 0, stream, d_args, d_start,
                        n_factors);
   return hipGetLastError();
 }
@@ -2092,7 +2288,7 @@ hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, 
     if (shard)
       hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<kThreads, true>), grid, dim3(kThreads), 0, stream, blk);
     else
-      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<kThreads, false>), grid, dim3(kThreads), 0, stream, blk);
+      hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<kThreads, false>), grid, dim3(loc_tpb(kThreads, false)), 0, stream, blk);
   }
   return hipGetLastError();
 }

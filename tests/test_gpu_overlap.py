@@ -1,0 +1,151 @@
+"""-m gpu: pipelined calls with the component pass (K4) on the context's side stream (mh_set_overlap, the default of
+mh_icp_linearize_async) against the same calls with every kernel on the context's stream, and against the oracle.
+
+K4 of call i runs beside K3 of call i + 1 of the SAME factor: K4 reads only the record K3 wrote for its call (two records and
+two sets of partial rows per factor, alternating).  The pose changes with every call, so a K4 that read the next call's record
+or rows — or the factor's association state, which the next K3 rewrites in place — would report another call's components."""
+import numpy as np
+import pytest
+
+from parity import assert_result_parity
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("H_ss", "b_s", "f", "status_hist", "loc_trans_comp", "loc_rot_comp", "loc_trans_final", "loc_rot_final", "eigvec_rot",
+        "eigvec_trans", "n_knn", "mean_candidates", "linearize_count")
+
+
+def _poses(world, n):
+    from mimosa_amd import synth
+    out = []
+    for j in range(n):
+        dR = synth.so3_exp(np.array([0.0004 * j, -0.0003 * j, 0.0011 * j]))
+        out.append((world["R"] @ dR, world["t"] + np.array([0.013 * j, -0.007 * j, 0.002 * (j % 3)])))
+    return out
+
+
+def _run(ctx, gm, world, poses, overlap, reset_each, sync_every=0):
+    from mimosa_amd import capi
+    ctx.set_overlap(overlap)
+    f = capi.ICPFactor(ctx, gm, world["pts"], capi.make_reg_config(**world["cfg"]))
+    outs = []
+    for j, (R, t) in enumerate(poses):
+        if reset_each:
+            f.reset()
+        if sync_every and j % sync_every == sync_every - 1:
+            f.wait()
+            outs.append(f.linearize(R, t))       # a synchronous call between pipelined ones (K4 on the context's stream)
+        else:
+            outs.append(f.linearize_async(R, t))
+    f.wait()
+    res = [o if isinstance(o, dict) else o.as_dict() for o in outs]
+    st = f.state()
+    f.destroy()
+    ctx.set_overlap(True)
+    return res, st
+
+
+@pytest.mark.parametrize("reset_each", [False, True])
+def test_side_stream_calls_equal_one_stream_calls_and_the_oracle(ctx, room_world, reset_each):
+    from mimosa_amd import capi
+    from oracle import ref_cpu
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(room_world["map_xyz"])
+    poses = _poses(room_world, 24)                     # 24 calls in flight: every record and row set is reused 12 times
+    on, st_on = _run(ctx, gm, room_world, poses, True, reset_each)
+    off, st_off = _run(ctx, gm, room_world, poses, False, reset_each)
+    for a, b in zip(on, off):
+        for k in KEYS:
+            assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+    for x, y in zip(st_on, st_off):
+        assert np.array_equal(x, y, equal_nan=True)
+    # the calls differ from each other (else the comparison above could not see a mixed-up record)
+    assert not np.array_equal(on[3]["loc_rot_comp"], on[4]["loc_rot_comp"]) or not np.array_equal(on[3]["status_hist"], on[4]["status_hist"])
+    # and the oracle agrees, call by call
+    rm = ref_cpu.Map()
+    rm.insert(room_world["map_xyz"])
+    fr = ref_cpu.ICP(rm, room_world["pts"], ref_cpu.make_config(**room_world["cfg"]))
+    for j, (R, t) in enumerate(poses[:6]):
+        if reset_each:
+            fr = ref_cpu.ICP(rm, room_world["pts"], ref_cpu.make_config(**room_world["cfg"]))
+        want = fr.linearize(R, t)
+        want["linearize_count"] = on[j]["linearize_count"]  # (a reset keeps the factor's call counter; the fresh oracle factor starts at 1)
+        assert_result_parity(on[j], want)
+    gm.release()
+
+
+def test_synchronous_calls_between_pipelined_ones(ctx, small_world):
+    """A blocking mh_icp_linearize every fourth call: its K3 must queue behind the side-stream K4 that read the record it reuses."""
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(small_world["map_xyz"])
+    poses = _poses(small_world, 16)
+    on, st_on = _run(ctx, gm, small_world, poses, True, False, sync_every=4)
+    off, st_off = _run(ctx, gm, small_world, poses, False, False, sync_every=4)
+    for a, b in zip(on, off):
+        for k in KEYS:
+            assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+    for x, y in zip(st_on, st_off):
+        assert np.array_equal(x, y, equal_nan=True)
+    gm.release()
+
+
+def test_factor_destroyed_with_calls_just_collected_and_components_toggled(ctx, small_world):
+    """Records go back to the allocation cache only behind the side stream's last K4 (MH_ALLOC_CHECK verifies the hand-over);
+    switching the component pass off between pipelined calls reuses row set 0 behind the K4 that read it."""
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(small_world["map_xyz"])
+    cfg = capi.make_reg_config(**small_world["cfg"])
+    poses = _poses(small_world, 6)
+    for rep in range(4):
+        f = capi.ICPFactor(ctx, gm, small_world["pts"], cfg)
+        g = capi.ICPFactor(ctx, gm, small_world["pts"], cfg)
+        outs = [f.linearize_async(R, t) for R, t in poses[:3]]
+        f.wait()                                   # (the switch is refused with calls in flight)
+        f.set_components(False)
+        outs += [f.linearize_async(R, t) for R, t in poses[3:]]
+        f.wait()
+        want = [g.linearize(R, t) for R, t in poses[:3]]
+        g.set_components(False)
+        want += [g.linearize(R, t) for R, t in poses[3:]]
+        for a, b in zip(outs, want):
+            a = a.as_dict()
+            for k in ("H_ss", "b_s", "f", "loc_trans_final", "loc_rot_final"):
+                assert np.array_equal(a[k], b[k]), k
+            assert np.array_equal(a["loc_rot_comp"], b["loc_rot_comp"], equal_nan=True)
+        f.destroy()
+        g.destroy()
+    gm.release()
+
+
+def test_full_size_side_stream_calls_equal_synchronous_calls(ctx, big_world):
+    """131 072 points: K3 runs 512-thread workgroups, the side-stream K4 256-thread ones (it has to fit beside the next K3) —
+    the sums, folded in the same order by either, must agree to the bit with synchronous calls (K4 on the context's stream)."""
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    for xyz in big_world["map_rooms"]:
+        gm.insert(xyz)
+    cfg = capi.make_reg_config(**big_world["cfg"])
+    poses = _poses(big_world, 8)
+    f, g = capi.ICPFactor(ctx, gm, big_world["pts"], cfg), capi.ICPFactor(ctx, gm, big_world["pts"], cfg)
+    outs = []
+    for R, t in poses:
+        f.reset()
+        outs.append(f.linearize_async(R, t))
+    f.wait()
+    for o, (R, t) in zip(outs, poses):
+        g.reset()
+        want, got = g.linearize(R, t), o.as_dict()
+        for k in KEYS:
+            if k != "linearize_count":
+                assert np.array_equal(np.asarray(got[k], float), np.asarray(want[k], float), equal_nan=True), k
+    for x, y in zip(f.state(), g.state()):
+        assert np.array_equal(x, y, equal_nan=True)
+    f.destroy()
+    g.destroy()
+    gm.release()
