@@ -185,10 +185,15 @@ const char * mh_last_error(const mh_ctx * ctx);
  * bracket the kernels of every n-th linearize call of a factor (each event record costs ~4 us of stream time,
  * so a throughput measurement samples).  Untimed calls report gpu_ms_* = -1. */
 int mh_set_profiling(mh_ctx * ctx, int every);
-/* mh_icp_linearize_async pipelining: 1 (default) = the component pass (K4) of a call runs on a side stream of the context
- * behind an event, so the context's stream goes from one call's K3 straight into the next call's — K4 reads only what K3
- * recorded for that call, so consecutive calls of ONE factor overlap as well; 0 = every kernel on the context's stream
- * (what several contexts sharing the device want: a process has 4 hardware queues).  Results are identical either way.
+/* mh_icp_linearize_async pipelining: 1 (default) = the component pass (K4) of a pipelined call is done by a component
+ * server, one long-running kernel on a side stream of the context that K3 signals through flag words in device memory (no
+ * dispatch, event or barrier packet per call), so the context's stream goes from one call's K3 straight into the next
+ * call's — K4 reads only what K3 recorded for that call, so consecutive calls of ONE factor overlap as well.  Only the first
+ * context of a process gets a side stream (MH_SIDE_CONTEXTS raises that), and only calls that follow another call still in
+ * flight use it; the server ends at the next mh_icp_wait / mh_synchronize / destroy, and by itself after ~4 s without
+ * work.  A caller that synchronises the DEVICE (hipDeviceSynchronize) with pipelined calls open must call mh_icp_wait or
+ * mh_synchronize first.  0 = every kernel on the context's stream (what several contexts sharing the device want: a
+ * process has 4 hardware queues).  Results are identical either way, bit for bit.
  * The reference has no counterpart: GTSAM calls ICPFactor::linearize (geometric_factor.hpp:231) one factor after the other. */
 int mh_set_overlap(mh_ctx * ctx, int on);
 /* hipStream_t of the context, for callers that want to order their own work / events on it. */

@@ -1206,6 +1206,9 @@ __device__ __forceinline__ void loc_directions(const A & a, const double nx, con
 template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
+#ifdef MH_K3_PRIO
+  __builtin_amdgcn_s_setprio(MH_K3_PRIO);
+#endif
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
   constexpr int SEGS = TPB / NENT;         // 18 / 5 point segments reduced in parallel
@@ -1994,6 +1997,9 @@ __global__ __launch_bounds__(loc_tpb(TPB, SHARD)) MH_LOC_VGPRS void icp_localiza
 __global__ __launch_bounds__(256) MH_LOC_VGPRS void icp_localizability_server_kernel(const LocServerArgs s)
 {
   __shared__ int s_cmd;
+#ifdef MH_SRV_PRIO
+  __builtin_amdgcn_s_setprio(MH_SRV_PRIO);
+#endif
   for (unsigned int j = s.first;; ++j) {
     if (threadIdx.x == 0) {
       int cmd = 0;
@@ -2150,7 +2156,10 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
   return hipGetLastError();
 }
 
-int loc_server_grid() { return 64; }
+#ifndef MH_SRV_GRID
+#define MH_SRV_GRID 64
+#endif
+int loc_server_grid() { return MH_SRV_GRID; }
 hipError_t launch_loc_server(const LocServerArgs & s, hipStream_t stream)
 {
   hipLaunchKernelGGL(icp_localizability_server_kernel, dim3(loc_server_grid()), dim3(256), 0, stream, s);

@@ -784,6 +784,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
 }
 
 // ---- the component server of a context (icp_device.hpp: LocServerArgs) ----------------------------------------------------
+constexpr std::chrono::milliseconds kSrvIdleRestart{500};  // see linearize_enqueue
 static unsigned int * srv_stop_word(mh_ctx * ctx)
 {
   return reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->h_srv) + sizeof(mh::LocServerSlot) * kSrvRing);
@@ -858,11 +859,17 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     // the streams — an event record + wait costs the compute stream more than the overlap buys (measured: 50.6 us per step
     // against 48.4 without the side stream) — K4 is simply launched and polls a device counter its K3 signs off on
     // (icp_device.hpp: IcpArgs::sig); the side stream runs its K4s in order, so only one of them ever waits on the device.
-    // A synchronous call, or one timed by events, keeps K4 on the compute stream.
+    // A synchronous call keeps K4 on the compute stream.  A pipelined call timed by events goes to the server like the others
+    // (its K3 is bracketed, its component pass has no launch of its own to bracket: gpu_ms_localizability = -1).
     // Only a caller that pipelines goes to the server — a call that follows another one still in flight on this context, or the
     // first call after a wait that collected several: a lone call gains nothing from it.
     if (ctx->calls_open > 0) ctx->pipelined = true;
-    bool side = ctx->overlap && !want_flag && !timed && pc.components && a.rec != nullptr && ctx->pipelined && side_slot(ctx);
+    // The server ends by itself after ~3.3 s (8e9 shader cycles) without work, unseen by the host.  A caller that left its
+    // pipeline alone for a while therefore gets a fresh one: the old server is told to end (it has, or does so now, after
+    // everything posted so far) and the launch further down waits for the side stream to drain before it clears the stop word.
+    // The host-side limit is far below the device's, so no call is ever announced to a server that has already gone.
+    if (ctx->srv_running && std::chrono::steady_clock::now() - ctx->srv_last_post > kSrvIdleRestart) srv_stop(ctx);
+    bool side = ctx->overlap && !want_flag && pc.components && a.rec != nullptr && ctx->pipelined && side_slot(ctx);
     // (a ring slot is free once the call that used it has been collected)
     if (side && !ctx->srv_open.empty() && ctx->srv_posted - *ctx->srv_open.begin() >= static_cast<unsigned int>(kSrvRing) - 1u) side = false;
     if (side) {
@@ -904,6 +911,7 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     if (side) {
       // K3 is in the stream and will announce call j: from here on the bookkeeping must say so
       const unsigned int j = ctx->srv_posted++;
+      ctx->srv_last_post = std::chrono::steady_clock::now();
       icp->side_calls = a.side;
       icp->rec_need[pc.rec_b] = a.side;
       icp->rec_blocks[pc.rec_b] = pc.loc_blocks;
@@ -933,7 +941,12 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
       pc.seq_has_basis = true;
       pc.launched_k4 = true;
     }
-    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+    if (timed) {
+      if (pc.srv_index >= 0)
+        pc.ev[2] = nullptr;  // served: nothing of K4 is on this stream
+      else
+        MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
+    }
   } else {
     if (timed) {
       MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
@@ -1100,7 +1113,10 @@ static int mh_icp_wait_impl(mh_icp * icp)
     finish_result(icp, d, pc, pc.out);
     if (pc.ev[0]) {
       (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
-      (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
+      if (pc.ev[2])
+        (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
+      else
+        pc.out->gpu_ms_localizability = -1.0f;  // done by the component server: no launch to bracket
     } else {
       pc.out->gpu_ms_linearize = pc.out->gpu_ms_localizability = -1.0f;  // this call was not timed
     }

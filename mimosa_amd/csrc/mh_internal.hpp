@@ -55,6 +55,7 @@ struct mh_ctx
   unsigned int * d_srv_posted = nullptr;
   unsigned int srv_posted = 0;       // calls handed to the server so far (= index of the next one)
   bool srv_running = false;
+  std::chrono::steady_clock::time_point srv_last_post{};  // host time of the last call handed to the server (mh_api.hip: kSrvIdleRestart)
   int calls_open = 0;                // linearize calls enqueued on this context and not collected yet
   bool pipelined = false;            // the caller has had several calls in flight (and has not gone back to one at a time)
   std::set<unsigned int> srv_open;   // calls posted and not yet collected by their factor's wait (ring slots in use)

@@ -149,3 +149,31 @@ def test_full_size_side_stream_calls_equal_synchronous_calls(ctx, big_world):
     f.destroy()
     g.destroy()
     gm.release()
+
+
+@pytest.mark.parametrize("pause_s", [0.7, 4.5])
+def test_pipeline_left_alone_then_resumed(ctx, small_world, pause_s):
+    """Pipelined calls, nothing for a while, more pipelined calls, all collected by ONE wait.  0.7 s: past the host-side limit
+    after which a resumed pipeline gets a fresh component server; 4.5 s: past the ~3.3 s after which an idle server ends by
+    itself — no call may be announced to a server that has gone (it would never be answered)."""
+    import time
+
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(small_world["map_xyz"])
+    cfg = capi.make_reg_config(**small_world["cfg"])
+    poses = _poses(small_world, 12)
+    f, g = capi.ICPFactor(ctx, gm, small_world["pts"], cfg), capi.ICPFactor(ctx, gm, small_world["pts"], cfg)
+    outs = [f.linearize_async(R, t) for R, t in poses[:6]]
+    time.sleep(pause_s)
+    outs += [f.linearize_async(R, t) for R, t in poses[6:]]
+    f.wait()
+    want = [g.linearize(R, t) for R, t in poses]
+    for a, b in zip(outs, want):
+        a = a.as_dict()
+        for k in KEYS:
+            assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+    f.destroy()
+    g.destroy()
+    gm.release()
