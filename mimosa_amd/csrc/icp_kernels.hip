@@ -1206,9 +1206,13 @@ __device__ __forceinline__ void loc_directions(const A & a, const double nx, con
 template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
-#ifdef MH_K3_PRIO
-  __builtin_amdgcn_s_setprio(MH_K3_PRIO);
+  // K3's waves issue ahead of the component server's (icp_localizability_server_kernel, priority 0) when the two share a SIMD:
+  // the call's K4 work is off the critical path, the next K3 is on it (measured: step 37.1-38.7 -> 36.1-36.9 us, K3 beside the
+  // server 34.7 -> 33.7 us by rocprofv3).  Among K3's own waves nothing changes.
+#ifndef MH_K3_PRIO
+#define MH_K3_PRIO 3
 #endif
+  __builtin_amdgcn_s_setprio(MH_K3_PRIO);
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
   constexpr int SEGS = TPB / NENT;         // 18 / 5 point segments reduced in parallel
