@@ -540,7 +540,7 @@ void mh_icp_destroy(mh_icp * icp)
 {
   if (!icp) return;
   (void)mh_enter(icp->ctx);
-  if (icp->side_used) srv_stop(icp->ctx);
+  srv_stop(icp->ctx);  // (whoever's calls it is serving: the frees below may synchronise the device)
   (void)hipStreamSynchronize(icp->ctx->stream);
   if (icp->ctx->aux_stream && icp->side_used) (void)hipStreamSynchronize(icp->ctx->aux_stream);  // the server may still read a record
   for (int s2 = 0; s2 < icp->n_pending; ++s2) {  // calls never collected

@@ -177,3 +177,42 @@ def test_pipeline_left_alone_then_resumed(ctx, small_world, pause_s):
     f.destroy()
     g.destroy()
     gm.release()
+
+
+def test_two_factors_alternating_half_bursts_never_drain(ctx, small_world):
+    """Half-bursts alternate between two factors of one context and each wait collects ONE factor's calls while the other's are
+    in flight: the wait tells the component server to end behind everything posted so far (the other factor's calls among them)
+    and the next pipelined call starts a fresh one.  Results equal synchronous calls to the bit."""
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(small_world["map_xyz"])
+    cfg = capi.make_reg_config(**small_world["cfg"])
+    poses = _poses(small_world, 40)
+    pair = (capi.ICPFactor(ctx, gm, small_world["pts"], cfg), capi.ICPFactor(ctx, gm, small_world["pts"], cfg))
+    g = capi.ICPFactor(ctx, gm, small_world["pts"], cfg)
+    outs, cur = [], 0
+    for k in range(0, len(poses), 5):
+        f = pair[cur]
+        for R, t in poses[k:k + 5]:
+            f.reset()
+            outs.append(f.linearize_async(R, t))
+        cur ^= 1
+        pair[cur].wait()
+    pair[cur ^ 1].wait()
+    pair[cur].wait()   # nothing pending: a no-op
+    for o, (R, t) in zip(outs, poses):
+        g.reset()
+        want, got = g.linearize(R, t), o.as_dict()
+        for k in KEYS:
+            if k != "linearize_count":
+                assert np.array_equal(np.asarray(got[k], float), np.asarray(want[k], float), equal_nan=True), k
+    # a synchronous call and a destroy of one factor while the other has calls open
+    o2 = [pair[0].linearize_async(R, t) for R, t in poses[:4]]
+    want = g.linearize(*poses[7])
+    pair[1].destroy()
+    pair[0].wait()
+    assert np.isfinite(want["f"]) and all(np.isfinite(o.as_dict()["f"]) for o in o2)  # (warm calls of another history: they must complete)
+    pair[0].destroy()
+    g.destroy()
+    gm.release()
