@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
 INFLIGHT = 32
+INFLIGHT_ICP = 64  # calls of one unsharded factor in flight in the headline loop (the library's limit per factor, kMaxPending)
 
 
 def parse():
@@ -189,11 +190,11 @@ def main():
             torch.cuda.synchronize()
 
     def run_steps(k, collect=None, fs=None):
-        """k cold linearizes in total, dealt round-robin to the streams, <= INFLIGHT in flight each."""
+        """k cold linearizes in total, dealt round-robin to the streams, <= INFLIGHT_ICP in flight each."""
         fs = factors if fs is None else fs
         done = 0
         while done < k:
-            nb = min(INFLIGHT * len(fs), k - done)
+            nb = min(INFLIGHT_ICP * len(fs), k - done)
             outs = []
             for i in range(nb):
                 f = fs[i % len(fs)]
@@ -1069,7 +1070,7 @@ def main():
             "workload": f"configs[1]: OS0-128 {n_pts}-pt scan vs {stats['n_points']}-pt local map "
                         f"({stats['n_voxels']} voxels, {args.rooms} rooms), k=5 point-to-plane, ENWIDE params, "
                         f"cold linearize per step",
-            "mode": f"{args.streams} independent scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT} "
+            "mode": f"{args.streams} independent scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT_ICP} "
                     f"linearize calls in flight per stream, every result copied to the host",
             "streams": args.streams,
             "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",

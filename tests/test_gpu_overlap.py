@@ -216,3 +216,31 @@ def test_two_factors_alternating_half_bursts_never_drain(ctx, small_world):
     pair[0].destroy()
     g.destroy()
     gm.release()
+
+
+def test_sixty_four_calls_in_flight_and_the_sixty_fifth_refused(ctx, small_world):
+    """The library holds up to 64 calls of a factor (kMaxPending): all 64 agree with synchronous calls; one more is refused
+    (and leaves the 64 collectable)."""
+    from mimosa_amd import capi
+
+    gm = capi.VoxelMap(ctx)
+    gm.insert(small_world["map_xyz"])
+    cfg = capi.make_reg_config(**small_world["cfg"])
+    poses = _poses(small_world, 64)
+    f, g = capi.ICPFactor(ctx, gm, small_world["pts"], cfg), capi.ICPFactor(ctx, gm, small_world["pts"], cfg)
+    outs = []
+    for R, t in poses:
+        f.reset()
+        outs.append(f.linearize_async(R, t))
+    with pytest.raises(Exception, match="too many calls in flight"):
+        f.linearize_async(*poses[0])
+    f.wait()
+    for o, (R, t) in zip(outs, poses):
+        g.reset()
+        want, got = g.linearize(R, t), o.as_dict()
+        for k in KEYS:
+            if k != "linearize_count":
+                assert np.array_equal(np.asarray(got[k], float), np.asarray(want[k], float), equal_nan=True), k
+    f.destroy()
+    g.destroy()
+    gm.release()
