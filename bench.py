@@ -229,6 +229,14 @@ def main():
     event_every = max(1, min(args.event_every, args.steps // max(len(factors), 1)))
     for c in ctxs:
         c.set_profiling(event_every)
+    if dist is not None:
+        # Under torch.distributed the process's first collectives bring up RCCL's own HIP streams, and the first pipelined burst
+        # after that was seen to stall once for ~35 ms (tools/torchrun_probe.py: the second block of 64 calls took 37 ms, every
+        # other one 2.1-2.3 ms; HIP re-assigns hardware queues when new streams come into use).  Part of the setup, like the
+        # first linearize above: three rounds of (barrier + a short pipelined burst) before the W warmup steps.
+        for _ in range(3):
+            barrier()
+            run_steps(16)
     run_steps(args.warmup)
     outs = []
     elapsed = timed_block(args.steps, outs)  # THE timed region of the contract: exactly --steps steps
