@@ -157,6 +157,12 @@ def main():
     from mimosa_amd import capi, synth
 
     ctx = capi.Context(local_rank)  # raises if the HIP extension or the GPU is missing
+    if dist is not None and world > 1:
+        # Several ranks: RCCL and torch bring their own HIP streams into the process and a process has 4 hardware queues; the
+        # component server (a kernel that waits on the device for kernels of the compute stream) must never share a queue with
+        # that stream.  Not measurable on a one-GPU box, so the replica leg of a multi-rank run keeps every kernel on the
+        # context's one stream (`value` at N > 1 is the sharded factor, which has no server anyway).
+        ctx.set_overlap(False)
 
     room_clouds, pts, R, t = build_world(rank, args.rooms, args.rows)
     cfgd = synth.enwide_config()
@@ -230,13 +236,14 @@ def main():
     for c in ctxs:
         c.set_profiling(event_every)
     if dist is not None:
-        # Under torch.distributed the process's first collectives bring up RCCL's own HIP streams, and the first pipelined burst
-        # after that was seen to stall once for ~35 ms (tools/torchrun_probe.py: the second block of 64 calls took 37 ms, every
-        # other one 2.1-2.3 ms; HIP re-assigns hardware queues when new streams come into use).  Part of the setup, like the
-        # first linearize above: three rounds of (barrier + a short pipelined burst) before the W warmup steps.
-        for _ in range(3):
+        # Under torch.distributed ONE pipelined burst among the first few after the first collective stalls for 35-48 ms
+        # (tools/torchrun_probe.py, with a bare loop of library calls: the 2nd or 3rd block of 64 calls took 36 / 48 ms, every
+        # other one 2.1-2.4 ms; the same loop in a process without torch.distributed never does — a one-off of the process's
+        # RCCL / watchdog start-up, not of the path).  Part of the setup, like the first linearize above: eight rounds of
+        # (barrier + a 64-call burst) before the W warmup steps, so that it does not land in the timed block.
+        for _ in range(8):
             barrier()
-            run_steps(16)
+            run_steps(64)
     run_steps(args.warmup)
     outs = []
     elapsed = timed_block(args.steps, outs)  # THE timed region of the contract: exactly --steps steps

@@ -22,6 +22,8 @@ for xyz in room_clouds:
 f = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
 f.linearize(R, t)
 bt = torch.zeros(1, device="cuda")
+if os.environ.get("PROBE_PROF"):
+    ctx.set_profiling(int(os.environ["PROBE_PROF"]))  # HIP events around every n-th call, as bench.py's timed region has them
 rows = []
 for blk in range(8):
     ctx.synchronize(); dist.barrier(); torch.cuda.synchronize()
