@@ -1238,7 +1238,18 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   double * s_rows = reinterpret_cast<double *>(s_arena);                              // [TPB][ROWW]
   double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
 
+#ifdef MH_INTERLEAVE
+  // EXPERIMENT (tools/variant.sh): the waves of a workgroup take 64-point chunks that lie n_blocks / 8 chunks apart inside their
+  // XCD's range instead of 8 consecutive ones, so that a heavy stretch of the Morton curve is spread over the CUs of the XCD
+  // (same L2) instead of landing on one CU's eight waves.
+  const int qi = [&] {
+    constexpr int WPB = TPB / 64;
+    const int cpx = n_blocks >> 3, x = block_id & 7, j = block_id >> 3, wv = static_cast<int>(threadIdx.x >> 6);
+    return ((x * cpx * WPB) + wv * cpx + j) * 64 + static_cast<int>(threadIdx.x & 63u);
+  }();
+#else
   const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
+#endif
   // side-stream bookkeeping (IcpArgs::sig): the counter this call's stores may have to wait for is requested now and looked
   // at after the per-point section — its round trip is never waited for
   [[maybe_unused]] bool k4_ok = true;

@@ -22,6 +22,10 @@ L = ctx.L
 L.mh_icp_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 rooms = [xyz for _, _, xyz in synth.make_map_rooms(2, 5)]
 pts, aux = synth.make_scan(128)
+NPTS = int(os.environ.get("MH_TL_POINTS", "0"))  # e.g. 24576: the reference's real cloud size (256-thread workgroups)
+if NPTS:
+    pts = np.ascontiguousarray(pts[::5][:NPTS])
+WPB = 8 if len(pts) > 65536 else 4
 R, t = synth.query_pose()
 cfg = synth.enwide_config()
 m = capi.VoxelMap(ctx)
@@ -37,11 +41,11 @@ buf = np.zeros(8 * 16 * 4096, np.uint64)
 rc = L.mh_icp_timeline(f.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n))
 assert rc == 0, rc
 T = buf[: n.value].reshape(-1, 16).astype(np.int64)
-blk = np.arange(len(T)) // 8
+blk = np.arange(len(T)) // WPB
 live = T[:, 0] > 0
 T, blk = T[live], blk[live]
 k3_us = r["gpu_ms_linearize"] * 1e3
-print(f"waves {len(T)}  K3 by HIP events {k3_us:.1f} us  (ticks = s_memtime; per-XCD counters, so cross-wave times are per XCD)")
+print(f"points {len(pts)}  waves {len(T)}  K3 by HIP events {k3_us:.1f} us  (ticks = s_memtime; per-XCD counters, so cross-wave times are per XCD)")
 
 
 def stat(name, x):
