@@ -5,14 +5,14 @@ Metric (BASELINE.json): "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 
 Workload at N=1 = BASELINE.json configs[1]: Ouster OS0-128 131 072-pt scan vs a ~5 M-pt local map
 (10 synthetic rooms), k=5 point-to-plane, ENWIDE parameters.
 
-A "step" = one COLD ICPFactor::linearize of the whole scan (fresh data-association state: every
-point runs the voxel-map k-NN, plane fit, residual, Jacobian; the 6x6 Hessian + localizabilities
-come back to the host).  Scan and map are resident in HBM before the timed region.  Steps are
-enqueued back-to-back on the context stream (up to 32 in flight, every result still lands in host
-memory); the synchronous per-call latency is reported alongside.
+A "step" = one COLD ICPFactor::linearize of the whole scan (fresh data-association state: every point runs the
+voxel-map k-NN, plane fit, residual, Jacobian; the 6x6 Hessian + localizabilities come back to the host).  Scan and
+map are resident in HBM before the timed region.
 
-One JSON line on rank 0; see the task contract for the fields.  `roofline.achieved` uses the
-ALGORITHMIC gather-model bytes of SURVEY.md §8(d): B_pt = 384 + 16 * mean(C_q) bytes per point.
+This file holds the headline only: world, timed region (`run_steps`, `timed_block`), roofline, cpu_baseline and the
+JSON line.  Everything else the line reports is a side leg under tools/benchlegs/ (one module each, `run(E)`).
+`value` = the pipelined form (<= 64 calls of the factor in flight); `value_sync` = one synchronous call at a time,
+which is what SURVEY.md 8(d) defines and what the reference's callers do (geometric.cpp:194-196) — see `metric_form`.
 """
 from __future__ import annotations
 
@@ -24,17 +24,14 @@ import time
 
 import numpy as np
 
-# multi-process GPU work on this platform needs dmabuf IPC (RCCL / device-buffer sharing fail with hipIpcGetMemHandle: invalid
-# argument otherwise); the launch environment normally exports it already
+# multi-process GPU work on this platform needs dmabuf IPC; the launch environment normally exports it already
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from benchlegs.env import HBM_COPY_GBS, HBM_PEAK_GBS, INFLIGHT_ICP, Env  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-HBM_COPY_GBS = 6290.0
-INFLIGHT = 32
-INFLIGHT_ICP = 64  # calls of one unsharded factor in flight in the headline loop (the library's limit per factor, kMaxPending)
+N_SIMD, SHADER_GHZ = 1024, 2.4  # MI355X: 256 CUs x 4 SIMDs, peak engine clock (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -44,68 +41,23 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rooms", type=str, default="2x5", help="map size in rooms (2x5 ~ 5 M points)")
     ap.add_argument("--rows", type=int, default=128, help="scan rows (128 -> 131 072 points)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent scans in flight on separate HIP streams (contexts) sharing the map")
-    ap.add_argument("--concurrent-streams", type=int, default=4,
-                    help="size of the extra aggregate-throughput pass reported as value_concurrent (0/1 = skip)")
-    ap.add_argument("--profile-mode", action="store_true",
-                    help="only the warm-up and the timed region (what rocprofv3 should see): no latency, "
-                         "re-linearization, PCIe, concurrent or CPU-baseline legs")
-    ap.add_argument("--event-every", type=int, default=10,
-                    help="HIP events bracket the kernels of every n-th linearize call of the timed region "
-                         "(an event record costs ~4 us of stream time; 1 = every call)")
+    ap.add_argument("--streams", type=int, default=1, help="independent scans in flight on separate HIP streams sharing the map")
+    ap.add_argument("--concurrent-streams", type=int, default=4, help="size of the value_concurrent pass (0/1 = skip)")
+    ap.add_argument("--profile-mode", action="store_true", help="only the warm-up and the timed region (what rocprofv3 should see)")
+    ap.add_argument("--event-every", type=int, default=10, help="HIP events bracket the kernels of every n-th call of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-measure-traffic", action="store_true", help="skip the two self-profiling rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="skip the self-profiling rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--headline-only", action="store_true", help="skip every side leg (tools/benchlegs)")
     ap.add_argument("--cpu-iters", type=int, default=8)
-    ap.add_argument("--shard-timeout", type=float, default=240.0,
-                    help="seconds the sharded leg may take before the line is printed without it")
+    ap.add_argument("--shard-timeout", type=float, default=240.0, help="seconds the sharded leg may take before the line is printed without it")
     ap.add_argument("--shard-rooms", type=str, default="auto",
-                    help="map of the map-SHARDED leg that runs when --gpus > 1 (BASELINE configs[2]): rooms as AxB; auto = 10x10 "
-                         "(~50 M points) from 4 GPUs up, 4x5 below; none = skip the leg")
-    ap.add_argument("--hostile-rooms", type=str, default="2x5", help="rooms of the hostile second workload (mimosa_amd/synth_hostile.py); none = skip it and the moving-pose leg")
-    ap.add_argument("--leaf1-rooms", type=str, default="4x5", help="rooms of the leaf-1.0 / min-dist-0.2 workload (config/hornbill/params.yaml:86-95); none = skip it")
+                    help="map of the map-SHARDED leg (BASELINE configs[2]): rooms as AxB; auto = 10x10 from 4 GPUs up, 4x5 below; none = skip")
+    ap.add_argument("--hostile-rooms", type=str, default="2x5", help="rooms of the hostile second workload; none = skip it and the moving-pose leg")
+    ap.add_argument("--leaf1-rooms", type=str, default="4x5", help="rooms of the leaf-1.0 / min-dist-0.2 workload; none = skip it")
     ap.add_argument("--hostile-poses", type=int, default=5, help="past scans per room the hostile map is built from")
-    ap.add_argument("--sharded", action="store_true", help="(kept for old command lines: the map-sharded leg now runs by default, at --gpus 1 too)")
+    ap.add_argument("--sharded", action="store_true", help="(kept for old command lines: the map-sharded leg runs by default)")
     ap.add_argument("--shard-block-log2", type=int, default=3, help="shard blocks of 2^n voxels per axis (3: 4 m cubes at the 0.5 m leaf)")
     return ap.parse_args()
-
-
-def measure_traffic(args):
-    """(bytes per K3 launch, note) from two rocprofv3 --pmc passes of this script in --profile-mode, or (None, reason)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe:
-        return None, "rocprofv3 not found"
-    got = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="mh_pmc_", dir="/tmp")
-        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "40",
-               "--warmup", "5", "--profile-mode", "--no-measure-traffic", "--rooms", args.rooms, "--rows", str(args.rows)]
-        try:
-            # MH_OVERLAP=0: counter collection serialises the device's kernels, and the component server (a long-running kernel
-            # that waits for K3s of another stream) cannot run under that; K3 itself is the same code either way
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MH_OVERLAP="0"), timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            vals = []
-            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    kn = r.get("Kernel_Name", "")
-                    if "icp_linearize_kernel" in kn and "batch" not in kn and r.get("Counter_Name") == ctr:
-                        vals.append(float(r["Counter_Value"]))
-            if len(vals) < 10:
-                return None, f"the {ctr} pass produced {len(vals)} samples"
-            got[ctr] = float(np.mean(vals[5:]))   # the first launches include the map's first touch
-        except Exception as exc:  # noqa: BLE001
-            return None, f"the {ctr} pass failed: {type(exc).__name__}"
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    traffic = int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
-    note = (f"measured IN THIS RUN: two rocprofv3 --kernel-trace --pmc passes of this script (--profile-mode, 40 steps), FETCH_SIZE {got['FETCH_SIZE']:.0f} KB and "
-            f"WRITE_SIZE {got['WRITE_SIZE']:.0f} KB per launch; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
-    return traffic, note
 
 
 def build_world(rank: int, rooms: str, rows: int):
@@ -113,1416 +65,331 @@ def build_world(rank: int, rooms: str, rows: int):
 
     nx, ny = (int(v) for v in rooms.lower().split("x"))
     room_clouds = [xyz for _, _, xyz in synth.make_map_rooms(nx, ny)]
-    # every rank scans the same room geometry with its own range-noise seed (independent scans)
-    pts, aux = synth.make_scan(rows, seed=synth.BASE_SEED + 1 + rank)
+    pts, aux = synth.make_scan(rows, seed=synth.BASE_SEED + 1 + rank)  # every rank: the same room, its own range-noise seed
     R, t = synth.query_pose()
     return room_clouds, pts, R, t
 
 
-def main():
-    args = parse()
-    # The contract is ONE JSON line on stdout; RCCL prints a version banner there when a communicator comes up.  Everything
-    # else this process (and the libraries it loads) writes to fd 1 goes to stderr; the JSON line is written to the real stdout.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ:  # under torch.distributed.run
+def setup(args) -> Env:
+    """torch.distributed (when launched under it), context, map, factor(s), and the closures the legs share."""
+    E = Env(args=args, rank=int(os.environ.get("RANK", "0")), local_rank=int(os.environ.get("LOCAL_RANK", "0")),
+            world=int(os.environ.get("WORLD_SIZE", "1")), dist=None, _all_reduce=None, results={})
+    if E.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ:  # under torch.distributed.run
         import torch
         import torch.distributed as dist
 
-        # MH_BENCH_DRYRUN=1 (tests only): several ranks on ONE GPU over gloo, to exercise the multi-rank control flow of this
-        # script on a one-GPU box (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+        # MH_BENCH_DRYRUN=1 (tests only): several ranks on ONE GPU over gloo — control flow only, the numbers mean nothing
         dryrun = os.environ.get("MH_BENCH_DRYRUN") == "1"
         if dryrun:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if dryrun:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        _raw_all_reduce = dist.all_reduce
+            E.local_rank = 0
+        torch.cuda.set_device(E.local_rank)
+        dist.init_process_group("gloo") if dryrun else dist.init_process_group("nccl", device_id=torch.device("cuda", E.local_rank))
+        raw_all_reduce = dist.all_reduce
 
         def _all_reduce(t, op=dist.ReduceOp.SUM, **kw):  # gloo: device tensors go through the host
             if dist.get_backend() == "gloo" and t.is_cuda:
                 h = t.cpu()
-                _raw_all_reduce(h, op=op, **kw)
+                raw_all_reduce(h, op=op, **kw)
                 t.copy_(h)
                 return None
-            return _raw_all_reduce(t, op=op, **kw)
-
+            return raw_all_reduce(t, op=op, **kw)
+        E.dist, E._all_reduce = dist, _all_reduce
     from mimosa_amd import capi, synth
 
-    ctx = capi.Context(local_rank)  # raises if the HIP extension or the GPU is missing
-    if dist is not None and world > 1:
-        # Several ranks: RCCL and torch bring their own HIP streams into the process and a process has 4 hardware queues; the
-        # component server (a kernel that waits on the device for kernels of the compute stream) must never share a queue with
-        # that stream.  Not measurable on a one-GPU box, so the replica leg of a multi-rank run keeps every kernel on the
-        # context's one stream (`value` at N > 1 is the sharded factor, which has no server anyway).
-        ctx.set_overlap(False)
-
-    room_clouds, pts, R, t = build_world(rank, args.rooms, args.rows)
-    cfgd = synth.enwide_config()
+    E.capi, E.synth = capi, synth
+    E.ctx = capi.Context(E.local_rank)  # raises if the HIP extension or the GPU is missing: no fallback
+    E.overlap_note = "component server on (K4 of call i beside K3 of call i + 1)"
+    if E.dist is not None and E.world > 1:
+        # several ranks: RCCL and torch bring their own streams into the process's 4 hardware queues; the component server
+        # must never share one with the compute stream, which a one-GPU box cannot check — every kernel stays on ONE stream
+        E.ctx.set_overlap(False)
+        E.overlap_note = "component server OFF in multi-rank runs (K3 and K4 on one stream: ~5 us per step more than at N = 1)"
+    E.room_clouds, E.pts, E.R, E.t = build_world(E.rank, args.rooms, args.rows)
+    E.cfgd = synth.enwide_config()
     t0 = time.time()
-    gmap = capi.VoxelMap(ctx, leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
-                         max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
-                         lru_horizon=synth.ENWIDE_LRU_HORIZON)
-    for xyz in room_clouds:
-        gmap.insert(xyz)
-    factor = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
-    n_pts = len(pts)
-    first = factor.linearize(R, t)  # uploads the map, first cold pass
-    # additional independent scans (own range-noise seed) on their own HIP streams, same map
-    ctxs, factors = [ctx], [factor]
-    for sidx in range(1, args.streams):
-        c2 = capi.Context(local_rank)
-        p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + rank + 1000 * sidx)
-        f2 = capi.ICPFactor(c2, gmap, p2, capi.make_reg_config(**cfgd))
-        f2.linearize(R, t)
-        ctxs.append(c2)
-        factors.append(f2)
-    stats = gmap.stats()
-    setup_s = time.time() - t0
+    E.gmap = capi.VoxelMap(E.ctx, leaf=E.cfgd["target_ivox_map_leaf_size"], min_dist=E.cfgd["target_ivox_map_min_dist_in_voxel"],
+                           max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    for xyz in E.room_clouds:
+        E.gmap.insert(xyz)
+    E.factor = capi.ICPFactor(E.ctx, E.gmap, E.pts, capi.make_reg_config(**E.cfgd))
+    E.n_pts = len(E.pts)
+    E.first = E.factor.linearize(E.R, E.t)  # first cold pass
+    E.ctxs, E.factors = [E.ctx], [E.factor]
+    for sidx in range(1, args.streams):  # additional independent scans (own noise seed) on their own streams, same map
+        c2 = capi.Context(E.local_rank)
+        p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + E.rank + 1000 * sidx)
+        f2 = capi.ICPFactor(c2, E.gmap, p2, capi.make_reg_config(**E.cfgd))
+        f2.linearize(E.R, E.t)
+        E.ctxs.append(c2)
+        E.factors.append(f2)
+    E.stats = E.gmap.stats()
+    E.setup_s = time.time() - t0
 
     def barrier():
-        for c in ctxs:
+        for c in E.ctxs:
             c.synchronize()
-        if dist is not None:
+        if E.dist is not None:
             import torch
-            dist.barrier()
+            E.dist.barrier()
             torch.cuda.synchronize()
 
     def run_steps(k, collect=None, fs=None):
         """k cold linearizes in total, dealt round-robin to the streams, <= INFLIGHT_ICP in flight each."""
-        fs = factors if fs is None else fs
+        fs = E.factors if fs is None else fs
         done = 0
         while done < k:
             nb = min(INFLIGHT_ICP * len(fs), k - done)
             outs = []
             for i in range(nb):
                 f = fs[i % len(fs)]
-                f.reset()
-                outs.append(f.linearize_async(R, t))
+                f.reset()                                  # cold: fresh association state
+                outs.append(f.linearize_async(E.R, E.t))
             for f in fs:
-                f.wait()
+                f.wait()                                   # every result is on the host
             if collect is not None:
                 collect.extend(outs)
             done += nb
 
-    def timed_block(k, collect=None, fs=None, sync_extra=()):
-        """EXACTLY k steps bracketed by a barrier + device synchronisation on both sides; max over ranks; seconds."""
-        barrier()
-        for c in sync_extra:
-            c.synchronize()
-        t_start = time.perf_counter()
-        run_steps(k, collect, fs)
-        barrier()
-        for c in sync_extra:
-            c.synchronize()
-        el = time.perf_counter() - t_start
-        if dist is not None:
-            import torch
-            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-            _all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
+    import ctypes as C
+    E._R, E._g = np.ascontiguousarray(E.R, np.float64), np.ascontiguousarray([0.0, 0.0, -1.0], np.float64)
+    E._out = capi.IcpResult()
 
-    # ---- warmup, then the timed region (per-kernel HIP events on the launch stream are on) ----
-    # every n-th call of a factor is bracketed; with few steps (per stream) n shrinks so that the timed region still holds one
-    event_every = max(1, min(args.event_every, args.steps // max(len(factors), 1)))
-    for c in ctxs:
-        c.set_profiling(event_every)
-    if dist is not None:
-        # Under torch.distributed ONE pipelined burst among the first few after the first collective stalls for 35-48 ms
-        # (tools/torchrun_probe.py, with a bare loop of library calls: the 2nd or 3rd block of 64 calls took 36 / 48 ms, every
-        # other one 2.1-2.4 ms; the same loop in a process without torch.distributed never does — a one-off of the process's
-        # RCCL / watchdog start-up, not of the path).  Part of the setup, like the first linearize above: eight rounds of
-        # (barrier + a 64-call burst) before the W warmup steps, so that it does not land in the timed block.
+    def raw_linearize(tvec):  # the raw C-ABI call with pre-marshalled arguments: what a C++ caller pays
+        _t = np.ascontiguousarray(tvec, np.float64)
+        rc = E.ctx.L.mh_icp_linearize(E.factor.h, E._R.ctypes.data_as(C.c_void_p), _t.ctypes.data_as(C.c_void_p), None, None,
+                                      E._g.ctypes.data_as(C.c_void_p), C.byref(E._out))
+        assert rc == 0, rc
+    E.barrier, E.run_steps, E.raw_linearize = barrier, run_steps, raw_linearize
+    return E
+
+
+def timed_block(E, k, collect=None):
+    """EXACTLY k steps bracketed by a barrier + device synchronisation on both sides; max over ranks; seconds."""
+    E.barrier()
+    t_start = time.perf_counter()
+    E.run_steps(k, collect)
+    E.barrier()
+    el = time.perf_counter() - t_start
+    if E.dist is not None:
+        import torch
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        E._all_reduce(tt, op=E.dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
+
+
+def headline(E):
+    """Warm-up, THE timed region (exactly --steps steps) + four more blocks of the same size, kernel times by HIP events."""
+    args = E.args
+    event_every = max(1, min(args.event_every, args.steps // max(len(E.factors), 1)))
+    for c in E.ctxs:
+        c.set_profiling(event_every)  # every n-th call of a factor is bracketed by events on the launch stream
+    if E.dist is not None:
+        # under torch.distributed ONE pipelined burst among the first few after the first collective stalls for 35-48 ms
+        # (tools/torchrun_probe.py: a one-off of the process's RCCL / watchdog start-up): part of the setup, like the first linearize
         for _ in range(8):
-            barrier()
-            run_steps(64)
-    run_steps(args.warmup)
+            E.barrier()
+            E.run_steps(64)
+    E.run_steps(args.warmup)
     outs = []
-    elapsed = timed_block(args.steps, outs)  # THE timed region of the contract: exactly --steps steps
-    # ... and four more blocks of the same size: `value` / `ms_per_step` are the first block's, the spread over the five is
-    # reported next to them (median, p95), and the HIP events of all of them feed the kernel times (>= 8 bracketed launches
-    # whatever --steps is)
-    block_s = [elapsed]
+    block_s = [timed_block(E, args.steps, outs)]  # the timed region of the contract
     if not args.profile_mode:
         for _ in range(4):
-            block_s.append(timed_block(args.steps, outs))
-
-    # ---- several scans in flight: 4 contexts (one HIP stream each) sharing the map, in a process of their own ----
-    # HIP multiplexes a process's streams onto 4 hardware queues and two busy streams that share one serialise
-    # (profiles/r04_concurrency_bisect.md); this process's context holds a second stream (the component server's side
-    # stream), so four MORE contexts here would share queues (3.6-3.7 Gpts/s measured that way).  tools/conc_probe.py runs
-    # the same loop — cold linearizes dealt round-robin to the streams by one host thread, <= 32 in flight per stream — in a
-    # fresh process with one stream per context (MH_OVERLAP=0).
-    conc = None
-    if args.streams == 1 and args.concurrent_streams > 1 and not args.profile_mode and world == 1:
-        import subprocess
-        env = dict(os.environ, MH_OVERLAP="0")
-        here = os.path.dirname(os.path.abspath(__file__))
-        try:
-            pr = subprocess.run([sys.executable, os.path.join(here, "tools", "conc_probe.py"), "--streams", str(args.concurrent_streams),
-                                 "--steps", str(max(400, args.steps * 2))], env=env, capture_output=True, text=True, timeout=600)
-            line = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1]
-            pj = json.loads(line)
-            conc = {"streams": pj["streams"], "steps": pj["steps"], "value": pj["conc_mpts"], "ms_per_step": pj["conc_ms"],
-                    "single_stream_same_process_ms": pj["single_ms"], "one_host_thread_per_stream_mpts": pj["threads_mpts"],
-                    "note": "tools/conc_probe.py in a process of its own (best of 3 passes of this many steps): 4 contexts, one HIP stream each "
-                            "(MH_OVERLAP=0), sharing one map; see the comment in bench.py"}
-        except Exception as e:  # the figure is a side leg: say why it is missing
-            conc = {"error": f"{type(e).__name__}: {e}"}
-
+            block_s.append(timed_block(E, args.steps, outs))  # spread (median, p95) + more bracketed launches
     k3_ms = np.array([o.gpu_ms_linearize for o in outs if o.gpu_ms_linearize >= 0], dtype=np.float64)
     k4_ms = np.array([o.gpu_ms_localizability for o in outs if o.gpu_ms_localizability >= 0], dtype=np.float64)
     assert len(k3_ms) > 0, "no linearize call of the timed region was bracketed by HIP events"
     k4_timing = "HIP events around the K4 launches of the bracketed calls of the timed region"
-    if len(k4_ms) == 0:
-        # pipelined calls hand their component pass to the context's component server (no launch of its own to bracket):
-        # K4 is timed on synchronous calls, where it is a launch on the context's stream
-        for c in ctxs:
+    if len(k4_ms) == 0:  # pipelined calls hand K4 to the component server (no launch to bracket): timed on synchronous calls
+        for c in E.ctxs:
             c.set_profiling(1)
         k4s = []
         for _ in range(12):
-            factors[0].reset()
-            k4s.append(factors[0].linearize(R, t)["gpu_ms_localizability"])
+            E.factors[0].reset()
+            k4s.append(E.factors[0].linearize(E.R, E.t)["gpu_ms_localizability"])
         k4_ms = np.array([x for x in k4s[2:] if x >= 0], dtype=np.float64)
-        k4_timing = "HIP events around K4 in 10 synchronous calls after the timed region (in the timed region the component server does K4's work beside the next K3)"
-    last = outs[(len(outs) - 1) // len(factors) * len(factors)].as_dict()  # a result of stream 0
-    assert np.array_equal(last["H_ss"], first["H_ss"]), "cold linearize is not reproducible"
-
-    # synchronous per-call latency (result on the host before the next call), events off
-    for c in ctxs:
+        k4_timing = "HIP events around K4 in 10 synchronous calls after the timed region (pipelined calls: the component server does K4's work)"
+    last = outs[(len(outs) - 1) // len(E.factors) * len(E.factors)].as_dict()  # a result of stream 0
+    assert np.array_equal(last["H_ss"], E.first["H_ss"]), "cold linearize is not reproducible"
+    for c in E.ctxs:
         c.set_profiling(False)
+    return dict(elapsed=block_s[0], block_s=block_s, n_outs=len(outs), k3_ms=k3_ms, k4_ms=k4_ms, k4_timing=k4_timing, last=last, event_every=event_every)
+
+
+def roofline(E, H, small, back_to_back_ms):
+    """The dominant kernel (K3) against the roofs: SURVEY 8(d)'s gather model (the contract's `frac`), what the kernel really
+    requests (executed bytes), measured HBM traffic and VALU issue (self-profiling PMC passes), the compulsory bound."""
+    from benchlegs import traffic as tr
+
+    args, n, last = E.args, E.n_pts, H["last"]
+    k3_s = float(H["k3_ms"].mean()) * 1e-3
+    b_pt = 384.0 + 16.0 * float(last["mean_candidates"])  # SURVEY 8(d): source 16 + 19 hash slots x 16 + 16 C_q + state 64
+    achieved = n * b_pt / k3_s / 1e9
+    # what the kernel asks the memory system for, per point: source 16, block-table probe 16, nine 12-byte cell triples, 4 bytes
+    # per candidate scanned (packed 10-bit copy), 8 survivors x 16, association state 76 out, call record 52 out
+    ex_pt = 16 + 16 + 108 + 4.0 * float(last["mean_scanned"]) + 128 + 76 + 52
+    pmc, pmc_note = (None, "not measured (profile mode / multi-rank / --no-measure-traffic)")
+    if not args.profile_mode and E.world == 1 and E.rank == 0 and not args.no_measure_traffic:
+        pmc, pmc_note = tr.traffic(E)
+    traffic = pmc.get("traffic") if pmc else None
+    valu = pmc.get("SQ_INSTS_VALU") if pmc else None
+    valu_frac = (valu * 4.0 / (N_SIMD * k3_s * SHADER_GHZ * 1e9)) if valu else None
+    hbm_frac = traffic / k3_s / 1e9 / HBM_PEAK_GBS if traffic else None
+    comp_bytes, v_touched = tr.compulsory(E) if (not args.profile_mode and E.rank == 0) else (None, None)
+    bound = "hbm"
+    if valu_frac is not None and hbm_frac is not None and valu_frac > hbm_frac:
+        bound = "valu-issue"
+    return {
+        "bound": bound, "bound_note": "the larger of the two HARDWARE fractions measured in this run (hbm_measured_frac_of_peak, valu_issue_frac); "
+                                      "`frac` itself is SURVEY 8(d)'s gather model against the HBM peak, a work-equivalent figure",
+        "kernel": "icp_linearize_kernel<5,false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
+        "traffic": traffic, "traffic_note": pmc_note,
+        "hbm_measured_gbs": round(traffic / k3_s / 1e9, 1) if traffic else None,
+        "hbm_measured_frac_of_peak": round(hbm_frac, 4) if hbm_frac else None,
+        "executed_bytes_per_launch": int(n * ex_pt), "executed_bytes_per_point": round(ex_pt, 1),
+        "executed_frac_of_peak": round(n * ex_pt / k3_s / 1e9 / HBM_PEAK_GBS, 4),
+        "valu_insts_per_launch": int(valu) if valu else None, "valu_issue_frac": round(valu_frac, 4) if valu_frac else None,
+        "valu_issue_note": "SQ_INSTS_VALU x 4 issue cycles / (1024 SIMDs x kernel time x 2.4 GHz): a lower bound of the issue share (fp64 and "
+                           "packed instructions hold the pipe longer)",
+        "compulsory_bytes": comp_bytes, "voxels_touched": v_touched,
+        "frac_compulsory": round(comp_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 4) if comp_bytes else None,
+        "frac_note": "frac = gather-model bytes (no reuse credited, SURVEY.md 8(d)) / kernel time / 8 TB/s: NOT HBM bandwidth — the touched map "
+                     "lives in L2 / Infinity Cache, more than half of the model's candidates are pruned and the scanned ones are 4-byte words",
+        "small_cloud": small, "algorithmic_bytes_per_launch": int(n * b_pt), "bytes_per_point": round(b_pt, 1),
+        "mean_candidates_per_query": round(float(last["mean_candidates"]), 2),
+        "kernel_timing": f"HIP events on the launch stream around {len(H['k3_ms'])} of the {H['n_outs']} launches of the timed blocks "
+                         f"(every {H['event_every']}th call of each factor)",
+        "kernel_ms_avg": round(float(H["k3_ms"].mean()), 5), "kernel_ms_p95": round(float(np.percentile(H["k3_ms"], 95)), 5),
+        "localizability_kernel_ms_avg": round(float(H["k4_ms"].mean()), 5) if len(H["k4_ms"]) else None,
+        "localizability_kernel_timing": H["k4_timing"],
+        "frac_whole_step": round(n * b_pt / (H["elapsed"] / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 4),
+        "kernel_ms_back_to_back": back_to_back_ms,
+        "kernel_ms_back_to_back_note": "wall clock / steps of the pipelined pass with the component pass off (K3 launches back to back, no event "
+                                       "packets): the figure rocprofv3 reports; kernel_ms_avg (events) also contains the dispatch latency",
+    }
+
+
+def cpu_baseline(E, last):
+    """The oracle ("port") on the host cores, rank 0, N = 1 only: the checker timed beside the path, and the parity of this run."""
+    from oracle import ref_cpu
+    from tests.parity import rel  # (checker only)
+
+    args, cfgd, synth, n = E.args, E.cfgd, E.synth, E.n_pts
+    rmap = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
+                       max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+    for xyz in E.room_clouds:
+        rmap.insert(xyz)
+    rcfg = ref_cpu.make_config(**cfgd)
+    ncores = os.cpu_count() or 1
+    secs4, res4 = ref_cpu.time_cold(rmap, E.pts, rcfg, E.R, E.t, n_threads=4, iters=args.cpu_iters + 2)
+    sweep = {4: float(np.median(secs4[2:]))}  # thread sweep: the all-cores row is the BEST point of the curve
+    for nt in sorted({8, 16, 32, 64, ncores}):
+        if 4 < nt <= ncores:
+            secs_n, _ = ref_cpu.time_cold(rmap, E.pts, rcfg, E.R, E.t, n_threads=nt, iters=max(4, args.cpu_iters // 2) + 2)
+            sweep[nt] = float(np.median(secs_n[2:]))
+    best_nt = min(sweep, key=sweep.get)
+    base = {"value": round(n / sweep[4] / 1e6, 3), "unit": "Mpts/s", "cores": 4, "kind": "port",
+            "sample": f"the full workload ({n}-pt scan vs the same map), median of {args.cpu_iters} cold linearizes after 2 warm-ups, "
+                      "4 OpenMP threads as hard-coded in the reference (geometric_factor.hpp:261)",
+            "all_cores_value": round(n / sweep[best_nt] / 1e6, 3), "all_cores": ncores, "all_cores_threads_used": best_nt,
+            "thread_sweep_mpts_s": {str(k_): round(n / v_ / 1e6, 3) for k_, v_ in sorted(sweep.items())}}
+    parity = {"H_rel": rel(last["H_ss"], res4["H_ss"]), "b_rel": rel(last["b_s"], res4["b_s"]), "f_rel": abs(last["f"] - res4["f"]) / abs(res4["f"]),
+              "status_hist_equal": bool(np.array_equal(last["status_hist"], res4["status_hist"]))}
+    return base, parity
+
+
+def main():
+    args = parse()
+    # ONE JSON line on stdout: everything else this process and its libraries write to fd 1 (RCCL's banner) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    E = setup(args)
+    world, rank, n = E.world, E.rank, E.n_pts
+    H = headline(E)
     if args.profile_mode:
-        args.no_cpu_baseline, args.concurrent_streams = True, 0
+        args.no_cpu_baseline, args.concurrent_streams, args.headline_only = True, 0, True
     if world > 1:
-        args.no_cpu_baseline = True  # cpu_baseline and the oracle-timed legs are N=1, rank-0 figures
-    # Raw C-ABI calls with pre-marshalled arguments: what a C++ caller pays (capi's dict conversion adds ~20 us).
-    import ctypes as C
-    _R, _g = np.ascontiguousarray(R, np.float64), np.ascontiguousarray([0.0, 0.0, -1.0], np.float64)
-    _out = capi.IcpResult()
-
-    def raw_linearize(tvec):
-        _t = np.ascontiguousarray(tvec, np.float64)
-        rc = ctx.L.mh_icp_linearize(factor.h, _R.ctypes.data_as(C.c_void_p), _t.ctypes.data_as(C.c_void_p), None, None,
-                                    _g.ctypes.data_as(C.c_void_p), C.byref(_out))
-        assert rc == 0, rc
-
-    lat = []
-    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
-        factor.reset()
-        ctx.synchronize()
-        a = time.perf_counter()
-        raw_linearize(t)
-        lat.append(time.perf_counter() - a)
-    lat_ms = float(np.median(lat) * 1e3) if lat else float("nan")
-    lat_nc = []  # the same call with the component pass switched off (K3 alone publishes the result)
-    factor.set_components(False)
-    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
-        factor.reset()
-        ctx.synchronize()
-        a = time.perf_counter()
-        raw_linearize(t)
-        lat_nc.append(time.perf_counter() - a)
-    factor.set_components(True)
-    lat_nc_ms = float(np.median(lat_nc) * 1e3) if lat_nc else float("nan")
-
-    # The second caller of the path: GTSAM re-linearization (src/graph/manager.cpp:585-588).  The pose moved
-    # < min_dist/4, so every point takes the data-association cache branch (geometric_factor.hpp:308-317):
-    # no k-NN, cached plane, residual + Jacobian + reduction only.  Wall time with events off, kernel time in a
-    # second loop with events on.
-    relin_k3, relin_wall = [], []
-    if not args.profile_mode:
-        factor.reset()
-        factor.linearize(R, t)
-    for i in range(0 if args.profile_mode else 30):
-        dt = np.array([1e-3, -5e-4, 2e-4]) * ((i % 3) - 1)
-        ctx.synchronize()
-        a = time.perf_counter()
-        raw_linearize(t + dt)
-        relin_wall.append(time.perf_counter() - a)
-    ctx.set_profiling(1)
-    for i in range(0 if args.profile_mode else 30):
-        dt = np.array([1e-3, -5e-4, 2e-4]) * ((i % 3) - 1)
-        rr = factor.linearize(R, t + dt)
-        relin_k3.append(rr["gpu_ms_linearize"])
-        assert rr["n_knn"] == 0, "re-linearization leg ran k-NN"
-    ctx.set_profiling(False)
-
-    # The sliding window (src/graph/manager.cpp:585-588: smoother_->update + additional_update_iterations re-linearize
-    # every live ICPFactor): 5 factors of ~24 k points (the size the reference's down-sampler feeds the factor, SURVEY
-    # F7), one mh_icp_linearize_batch call (one K3 + one K4 launch) vs the same five one call at a time.
-    win_stats = None
-    if not args.profile_mode and world == 1:
-        nwin, per = 5, 24576
-        wf = [capi.ICPFactor(ctx, gmap, np.ascontiguousarray(pts[i::nwin][:per]), capi.make_reg_config(**cfgd)) for i in range(nwin)]
-        wR = [R for _ in range(nwin)]
-        wt = [t + np.array([0.002, -0.001, 0.0005]) * i for i in range(nwin)]
-        # raw C-ABI calls with pre-marshalled arguments (what a C++ caller pays; the Python binding's result -> dict
-        # conversion costs ~20 us per factor)
-        wRa = np.ascontiguousarray(np.stack(wR).reshape(nwin, 9))
-        wta = np.ascontiguousarray(np.stack(wt))
-        wga = np.ascontiguousarray(np.tile([0.0, 0.0, -1.0], (nwin, 1)))
-        whs = (C.c_void_p * nwin)(*[f.h for f in wf])
-        wout = (capi.IcpResult * nwin)()
-        vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
-        def _batch():
-            rc = ctx.L.mh_icp_linearize_batch(whs, nwin, vp(wRa), vp(wta), None, None, vp(wga), wout)
-            assert rc == 0, rc
-        def _one(i):
-            rc = ctx.L.mh_icp_linearize(wf[i].h, vp(wRa[i]), vp(wta[i]), None, None, vp(wga[i]), C.byref(wout[i]))
-            assert rc == 0, rc
-        def _one_by_one():
-            for i in range(nwin):
-                _one(i)
-        def _timed(fn, reps=40, cold=True):
-            ts_ = []
-            for _ in range(reps):
-                if cold:
-                    for f in wf:
-                        f.reset()
-                ctx.synchronize()
-                a = time.perf_counter()
-                fn()
-                ts_.append(time.perf_counter() - a)
-            return float(np.median(ts_) * 1e3)
-        _batch()
-        batch_cold = _timed(_batch)
-        single_cold = _timed(_one_by_one)
-        one_cold = _timed(lambda: _one(0))
-        _batch()
-        batch_relin = _timed(_batch, cold=False)
-        single_relin = _timed(_one_by_one, cold=False)
-        one_relin = _timed(lambda: _one(0), cold=False)
-        # the same window with the component pass switched off (mh_icp_set_components(icp, 0)): what the smoother's
-        # re-linearizations need — the reference never reads the components of those calls (geometric.cpp:205-214)
-        for f in wf:
-            f.set_components(False)
-        _batch()
-        nc_batch_cold = _timed(_batch)
-        nc_one_cold = _timed(lambda: _one(0))
-        _batch()
-        nc_batch_relin = _timed(_batch, cold=False)
-        nc_one_relin = _timed(lambda: _one(0), cold=False)
-        for f in wf:
-            f.set_components(True)
-        win_stats = {"factors": nwin, "points_per_factor": per,
-                     "batch_cold_ms": round(batch_cold, 4), "one_at_a_time_cold_ms": round(single_cold, 4),
-                     "single_factor_cold_ms": round(one_cold, 4),
-                     "batch_vs_single_factor": round(batch_cold / one_cold, 3),
-                     "batch_relinearize_ms": round(batch_relin, 4), "one_at_a_time_relinearize_ms": round(single_relin, 4),
-                     "single_factor_relinearize_ms": round(one_relin, 4),
-                     "batch_cold_mpts_s": round(nwin * per / batch_cold / 1e3, 1),
-                     "without_components": {"batch_cold_ms": round(nc_batch_cold, 4), "single_factor_cold_ms": round(nc_one_cold, 4),
-                                            "batch_relinearize_ms": round(nc_batch_relin, 4),
-                                            "single_factor_relinearize_ms": round(nc_one_relin, 4),
-                                            "batch_cold_mpts_s": round(nwin * per / nc_batch_cold / 1e3, 1),
-                                            "note": "K4 skipped: H, b, f, final localizabilities and degeneracy info bit-identical; "
-                                                    "component localizabilities / status histogram not produced"},
-                     "note": "median wall time of synchronous raw C-ABI calls (results on the host); cold = every point of "
-                             "every factor runs k-NN; relinearize = every point hits the data-association cache"}
-        for f in wf:
-            f.destroy()
-
-    # Photometric path (BASELINE configs[3], row f-2): 128 x 1024 Ouster intensity image — Photometric::preprocess
-    # (image formation, yaw table, proj_idx, filter chain, Sobel, mask), detectFeatures, and the NCC patch factor
-    # (60 features, 8 x 8 = 64-point patches as configs[3] words it; the reference default 5 x 5 alongside).
-    ph_stats = None
-    if not args.profile_mode and world == 1:
-        from mimosa_amd import synth_photo as sp
-        rel = lambda a_, b_: float(np.linalg.norm(np.asarray(a_) - np.asarray(b_)) / np.linalg.norm(np.asarray(b_)))
-        ph_stats = {}
-        for patch in (8, 5):
-            pcfg = sp.photo_config(patch=patch)
-            pf = [sp.make_frame(pcfg, k) for k in range(2)]
-            G = capi.Photo(ctx, pcfg)
-            def _pre(k):
-                return G.preprocess(pf[k]["raw"], pf[k]["deskewed"], pf[k]["unique_ns"], pf[k]["T_Le_Lt"])
-            _pre(0)
-            tp = []
-            _raw0 = np.ascontiguousarray(pf[0]["raw"])
-            _ns0 = np.ascontiguousarray(pf[0]["unique_ns"], np.uint32)
-            _T0 = np.ascontiguousarray(np.asarray(pf[0]["T_Le_Lt"], np.float64).reshape(len(_ns0), 12))
-            for _ in range(8):
-                _desk0 = np.array(pf[0]["deskewed"], copy=True)  # the call writes the corrected intensities back into it
-                ctx.synchronize()
-                a = time.perf_counter()   # raw C-ABI call: two 4 MiB host clouds in, corrected intensities out
-                ctx.check(ctx.L.mh_photo_preprocess(G.h, _raw0.ctypes.data_as(C.c_void_p), _desk0.ctypes.data_as(C.c_void_p), len(_desk0),
-                                                    _ns0.ctypes.data_as(C.c_void_p), _T0.ctypes.data_as(C.c_void_p), len(_ns0)))
-                tp.append(time.perf_counter() - a)
-            # detectFeatures changes the tracked set, so it is timed on fresh objects over the same frame: the first one
-            # warms the allocation cache (a cold call pays ~7 ms of hipMalloc), the median of the others is reported
-            td = []
-            for rep in range(4):
-                Gd = capi.Photo(ctx, pcfg)
-                Gd.preprocess(pf[0]["raw"], pf[0]["deskewed"], pf[0]["unique_ns"], pf[0]["T_Le_Lt"])
-                ctx.synchronize()
-                a = time.perf_counter()
-                Gd.detect(60, pf[0]["R_W_Be"], pf[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
-                td.append(time.perf_counter() - a)
-                Gd.destroy()
-            G.detect(60, pf[0]["R_W_Be"], pf[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
-            t_detect = float(np.median(td[1:]))
-            nfeat = len(G.features())
-            _pre(1)
-            GF = G.make_factor()
-            Rp = pf[1]["R_W_Be"] @ synth.so3_exp(np.array([0.002, -0.001, 0.003]))
-            tpp = pf[1]["t_W_Be"] + np.array([0.02, -0.01, 0.01])
-            ctx.set_profiling(1)
-            res = GF.linearize(Rp, tpp)
-            tl, kl = [], []
-            for _ in range(30):
-                res = GF.linearize(Rp, tpp)
-                kl.append(res["gpu_ms"])          # kernel time by HIP events (a timed call waits on the stream)
-            ctx.set_profiling(False)
-            for _ in range(30):                   # synchronous latency as a caller sees it: no events, the completion flag
-                ctx.synchronize()
-                a = time.perf_counter()
-                res = GF.linearize(Rp, tpp)
-                tl.append(time.perf_counter() - a)
-            # device-resident variant: raw + deskewed clouds already on the device (mh_scan), no 8 MB upload
-            npx = pcfg["rows"] * pcfg["cols"]
-            n_photo_pts = len(pf[0]["raw"])
-            alg_bytes = n_photo_pts * 64 + npx * (4 * 6 + 1 + 4 * 10) + npx * 8 * 5   # clouds in, images + proj_idx out, 5 filter passes
-            entry = {"features": nfeat, "points_per_feature": patch * patch,
-                     "preprocess_ms_host_buffers": round(float(np.median(tp)) * 1e3, 4),
-                     "detect_features_ms": round(t_detect * 1e3, 3),
-                     "factor_linearize_sync_ms": round(float(np.median(tl)) * 1e3, 4),
-                     "factor_kernel_ms": round(float(np.median(kl)), 5),
-                     "factor_status_hist": [int(v) for v in res["status_hist"]],
-                     "preprocess_algorithmic_bytes": int(alg_bytes)}
-            if not args.no_cpu_baseline:
-                from oracle import photo_ref as _pr
-                O = _pr.Photo(pcfg)
-                to = []
-                for _ in range(3):
-                    a = time.perf_counter()
-                    O.preprocess(pf[0]["raw"], pf[0]["deskewed"], pf[0]["unique_ns"], pf[0]["T_Le_Lt"])
-                    to.append(time.perf_counter() - a)
-                a = time.perf_counter()
-                O.detect(60, pf[0]["R_W_Be"], pf[0]["t_W_Be"], sp.BIAS_DIRECTIONS)
-                od = time.perf_counter() - a
-                O.preprocess(pf[1]["raw"], pf[1]["deskewed"], pf[1]["unique_ns"], pf[1]["T_Le_Lt"])
-                OF = O.make_factor()
-                ol = []
-                for _ in range(5):
-                    a = time.perf_counter()
-                    ro = OF.linearize(Rp, tpp)
-                    ol.append(time.perf_counter() - a)
-                entry["cpu_oracle"] = {"preprocess_ms": round(float(np.median(to)) * 1e3, 3), "detect_features_ms": round(od * 1e3, 3),
-                                       "factor_linearize_ms": round(float(np.median(ol)) * 1e3, 4), "cores": 1,
-                                       "note": "oracle/photo_ref.hpp, single thread (the reference's photometric code is sequential)"}
-                entry["parity_vs_oracle"] = {"H_rel": rel(res["H_bb"], ro["H_bb"]),
-                                             "status_hist_equal": bool(np.array_equal(res["status_hist"], ro["status_hist"]))}
-            GF.destroy()
-            G.destroy()
-            ph_stats[f"{patch}x{patch}"] = entry
-
-        # the device-resident form of preprocess (what the replay uses): raw + deskewed clouds are the mh_scan's, nothing is
-        # uploaded but the <= 1024 poses; raw C-ABI call timed, incl. the roofline view of the chain
+        args.no_cpu_baseline = True  # cpu_baseline and the oracle-timed legs are N = 1, rank-0 figures
+    from benchlegs import (concurrent, frontend, keyframe, latency, pcie, photometric, replay_leg, sharded, small_cloud, variants, window,
+                           worlds)
+    res = E.results
+    for leg in (() if args.headline_only else (concurrent, latency, window, photometric, keyframe, frontend, replay_leg, pcie, variants, small_cloud, worlds)):
         try:
-            from mimosa_amd import replay as _rp
-            rc1 = _rp.ReplayConfig(n_scans=1)
-            s1 = _rp.make_scans(rc1)[0]
-            scp = capi.Scan(ctx)
-            ctx.check(ctx.L.mh_scan_keep_raw(scp.h, 1))
-            G2 = capi.Photo(ctx, rc1.photo)
-            tr = []
-            for it in range(9):
-                scp.prepare_input(s1["raw"], capi.make_input_config())
-                Tq = np.ascontiguousarray(s1["frame"]["T_Le_Lt"][np.searchsorted(s1["frame"]["unique_ns"], scp.unique_ns())], np.float64)
-                scp.deskew(Tq.astype(np.float32))
-                ctx.synchronize()
-                a = time.perf_counter()
-                ctx.check(ctx.L.mh_photo_preprocess_scan(G2.h, scp.h, Tq.ctypes.data_as(C.c_void_p), len(Tq)))
-                if it:
-                    tr.append(time.perf_counter() - a)
-            t_res = float(np.median(tr))
-            ph_stats["resident"] = {"preprocess_scan_ms": round(t_res * 1e3, 4), "kernels": 13,
-                                    "roofline": {"bound": "hbm", "algorithmic_bytes": int(alg_bytes), "achieved_gbs": round(alg_bytes / t_res / 1e9, 1),
-                                                 "frac_of_peak": round(alg_bytes / t_res / 1e9 / HBM_PEAK_GBS, 4),
-                                                 "note": "13 dependent streaming passes over a 512 KiB image + two passes over a 4 MiB cloud: a "
-                                                         "launch-latency chain (each kernel 4-19 us), nowhere near the bandwidth roof"}}
-            G2.destroy()
-            scp.destroy()
-        except Exception as exc:  # noqa: BLE001
-            ph_stats["resident"] = {"error": f"{type(exc).__name__}: {exc}"}
-
-    # Keyframe map update (Geometric::updateMap, geometric.cpp:427-513): copy the map, insert the scan's geometric
-    # subset (every 4th point, world frame).  The map is maintained on the device: copy = device-to-device, insert =
-    # the batch over PCIe + the insert kernels (host buffer), or nothing over PCIe (resident scan, see sequence_replay).
-    kf_stats = None
-    if not args.profile_mode and world == 1:
-        sub = pts[::4]
-        xyz = synth.points_xyz(sub).astype(np.float64) @ R.T + t
-        xyz = np.ascontiguousarray(xyz.astype(np.float32))
-        tc, ti = [], []
-        for it in range(6):
-            ctx.synchronize()
-            a0 = time.perf_counter()
-            gmap2 = gmap.copy()
-            a1 = time.perf_counter()
-            gmap2.insert(xyz)
-            a2 = time.perf_counter()
-            s1 = gmap2.stats()
-            gmap2.release()
-            if it:
-                tc.append(a1 - a0)
-                ti.append(a2 - a1)
-        kf_stats = {"points": int(len(xyz)), "copy_ms": round(float(np.median(tc)) * 1e3, 3), "insert_ms": round(float(np.median(ti)) * 1e3, 3),
-                    "update_ms": round(float(np.median(tc) + np.median(ti)) * 1e3, 3), "bytes_uploaded_per_insert": int(len(xyz) * 12),
-                    "map_bytes": int(s1["device_bytes"]), "points_after": int(s1["n_points"]),
-                    "note": "host-buffer insert through the Python binding; the map (buckets, block tables, hash, LRU stamps) is built and kept on the device"}
-        if not args.no_cpu_baseline:
-            from oracle import ref_cpu as _rc
-            om = _rc.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
-                         mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-            for xyz_ in room_clouds:
-                om.insert(xyz_)
-            b0 = time.perf_counter()
-            om2 = om.copy()
-            b1 = time.perf_counter()
-            om2.insert(xyz)
-            b2 = time.perf_counter()
-            kf_stats["cpu_oracle"] = {"copy_ms": round((b1 - b0) * 1e3, 2), "insert_ms": round((b2 - b1) * 1e3, 2)}
-            assert om2.num_points == kf_stats["points_after"], "device and oracle maps disagree after the keyframe insert"
-
-    # Scan front end (rows a2-a5 / f-3): raw 128 x 1024 Ouster cloud -> prepareInput -> deskew -> body subset ->
-    # voxel down-sampler, on the device (one 4 MiB upload) vs the oracle's sequential CPU code on this host.
-    fe_stats = None
-    if not args.profile_mode and world == 1:
-        raw, raux = synth.make_raw_scan(args.rows, seed=synth.BASE_SEED + 1 + rank)
-        icfg = capi.make_input_config()
-        I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
-        sc = capi.Scan(ctx)
-        tg = {"prepare_input_ms": [], "deskew_ms": [], "preprocess_geometric_ms": [], "factor_create_ms": []}
-        for it in range(6):
-            ctx.synchronize()
-            a0 = time.perf_counter()
-            finfo = sc.prepare_input(raw, icfg)
-            a1 = time.perf_counter()
-            uns = sc.unique_ns()
-            Rt12 = raux["Rt12"][np.searchsorted(raux["unique_ns"], uns)]
-            a1b = time.perf_counter()
-            sc.deskew(Rt12)
-            a2 = time.perf_counter()
-            finfo = sc.preprocess_geometric(I3, z3, cfgd["source_voxel_grid_filter_leaf_size"], 20,
-                                            cfgd["source_voxel_grid_min_dist_in_voxel"])
-            a3 = time.perf_counter()
-            f3 = sc.make_factor(gmap, capi.make_reg_config(**cfgd))
-            a4 = time.perf_counter()
-            f3.destroy()
-            if it:  # first pass allocates
-                tg["prepare_input_ms"].append(a1 - a0)
-                tg["deskew_ms"].append(a2 - a1b)
-                tg["preprocess_geometric_ms"].append(a3 - a2)
-                tg["factor_create_ms"].append(a4 - a3)
-        fe_stats = {k: round(float(np.median(v)) * 1e3, 3) for k, v in tg.items()}
-        fe_stats.update({"raw_points": int(len(raw)), "points_full": finfo["n_full"], "geometric_subset": finfo["n_geometric"],
-                         "downsampled": finfo["n_downsampled"], "unique_timestamps": finfo["n_unique_ns"],
-                         "kernel_launches": {"prepare_input": 3, "deskew": 1, "preprocess_geometric": "7 + 1 memset"}})
-        # the same scan with the raw cloud already resident (mh_scan_prepare_input_device): the figure without the 4 MiB
-        # PCIe upload; and the dense variant (every point in the geometric subset) of the down-sampler
-        import ctypes as _C
-        _hip = _C.CDLL("libamdhip64.so")
-        d_raw = _C.c_void_p()
-        assert _hip.hipMalloc(_C.byref(d_raw), _C.c_size_t(raw.nbytes)) == 0
-        assert _hip.hipMemcpy(d_raw, _C.c_void_p(raw.ctypes.data), _C.c_size_t(raw.nbytes), 1) == 0
-        dense_cfg = capi.make_input_config(point_skip_divisor=1)
-        tr, td, tt = [], [], []
-        for it in range(8):
-            ctx.synchronize()
-            a0 = time.perf_counter()
-            sc.prepare_input_device(d_raw.value, len(raw), icfg)
-            a1 = time.perf_counter()
-            if it:
-                tr.append(a1 - a0)
-        for it in range(6):
-            sc.prepare_input_device(d_raw.value, len(raw), dense_cfg)
-            sc.deskew(Rt12)
-            ctx.synchronize()
-            a0 = time.perf_counter()
-            dinfo = sc.preprocess_geometric(I3, z3, cfgd["source_voxel_grid_filter_leaf_size"], 20,
-                                            cfgd["source_voxel_grid_min_dist_in_voxel"])
-            a1 = time.perf_counter()
-            if it:
-                td.append(a1 - a0)
-        fe_stats["prepare_input_resident_ms"] = round(float(np.median(tr)) * 1e3, 3)
-        fe_stats["resident_total_ms"] = round(fe_stats["prepare_input_resident_ms"] + fe_stats["deskew_ms"] + fe_stats["preprocess_geometric_ms"], 3)
-        fe_stats["dense_subset"] = {"geometric_subset": dinfo["n_geometric"], "downsampled": dinfo["n_downsampled"],
-                                    "preprocess_geometric_ms": round(float(np.median(td)) * 1e3, 3)}
-        sc.destroy()
-        _hip.hipFree(d_raw)
-        if not args.no_cpu_baseline:
-            from oracle import ref_cpu as _rc
-            ocfg = _rc.make_input_config()
-            tc = {"prepare_input_ms": [], "deskew_ms": [], "preprocess_geometric_ms": []}
-            for it in range(3):
-                b0 = time.perf_counter()
-                o = _rc.prepare_input(raw, ocfg)
-                b1 = time.perf_counter()
-                full = np.frombuffer(o["points_full"].tobytes(), dtype=synth.POINT_DTYPE).copy()
-                Rt12 = raux["Rt12"][np.searchsorted(raux["unique_ns"], o["unique_ns"])]
-                b1b = time.perf_counter()
-                desk = _rc.deskew(full, o["unique_ns"], Rt12)
-                b2 = time.perf_counter()
-                body = _rc.transform_f32(desk[o["geometric_idxs"].astype(np.int64)], I3, z3)
-                kept = _rc.downsample(body, cfgd["source_voxel_grid_filter_leaf_size"], 20,
-                                      cfgd["source_voxel_grid_min_dist_in_voxel"])
-                b3 = time.perf_counter()
-                tc["prepare_input_ms"].append(b1 - b0)
-                tc["deskew_ms"].append(b2 - b1b)
-                tc["preprocess_geometric_ms"].append(b3 - b2)
-            fe_stats["cpu_oracle"] = {k: round(float(np.median(v)) * 1e3, 3) for k, v in tc.items()}
-            fe_stats["cpu_oracle"]["note"] = "oracle/ref_cpu (sequential restatement, one core, incl. ctypes marshalling)"
-            assert len(kept) == fe_stats["downsampled"], "device and oracle down-samplers disagree"
-
-    # Sequence replay (row f-4, BASELINE configs[4]): 20 scans (128 x 1024, textured room, IMU-propagated deskew) — front end,
-    # photometric preprocess, ICP + photometric factors, a 5-scan fixed-lag window re-linearized 6 times per scan through
-    # mh_icp_linearize_batch, keyframe map updates, photometric feature bookkeeping — end to end through the C ABI.
-    rp_stats = None
-    if not args.profile_mode and world == 1:
-        from mimosa_amd import replay
-        rcfg = replay.ReplayConfig(n_scans=20, rows=args.rows)
-        rscans = replay.make_scans(rcfg)
-        rr = replay.run(rcfg, replay.HipBackend(ctx, rcfg), rscans)
-        rp_stats = {"scans": rcfg.n_scans, "scans_per_s": round(rr["scans_per_s"], 1), "keyframes": rr["n_keyframes"],
-                    "window": rcfg.window, "update_iterations": rcfg.update_iters, "photometric": True,
-                    "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rr["stage_s"].items()},
-                    "max_trans_err_mm": round(max(rr["trans_err"]) * 1e3, 2),
-                    "max_rot_err_mdeg": round(max(rr["rot_err_deg"]) * 1e3, 2),
-                    "photometric_features_tracked_min": int(min(rr["photo_valid"])) if rr["photo_valid"] else 0,
-                    "note": "errors vs ground truth from a 3 cm / 0.3 deg first guess, 1 cm range noise, noisy IMU; the harness "
-                            "(window assembly, 30 x 30 solve, IMU propagation) is Python / numpy on the host"}
-        # the same sequence through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls
-        try:
-            import tempfile
-            with tempfile.TemporaryDirectory() as td:
-                rn = replay.run_native(rcfg, rscans, td, repeats=2)
-            dpos = max(float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(rn["poses_est"], rr["poses_est"]))
-            rp_stats["native"] = {"scans_per_s": round(rn["scans_per_s"], 1), "keyframes": rn["n_keyframes"],
-                                  "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rn["stage_s"].items()},
-                                  "max_abs_translation_difference_to_the_python_harness_m": dpos,
-                                  "note": "replay_native (mimosa_amd/host/replay_main.cpp): the same loop in C++ over the host mirror, PIPELINED across "
-                                          "scans (the next cloud staged on a copy stream, the photometric map update on a worker thread beside the next "
-                                          "scan's geometric path); second pass over the sequence (allocations warm).  The per-stage times are the main "
-                                          "thread's (overlapped work is not in them)"}
-            with tempfile.TemporaryDirectory() as td:
-                rs = replay.run_native(rcfg, rscans, td, repeats=2, sequential=True)
-            rp_stats["native"]["sequential"] = {"scans_per_s": round(rs["scans_per_s"], 1),
-                                                "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rs["stage_s"].items()},
-                                                "trajectory_identical_to_pipelined": bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-                                                                                              for a, b in zip(rs["poses_est"], rn["poses_est"])))}
-            with tempfile.TemporaryDirectory() as td:
-                rm_ = replay.run_native(rcfg, rscans, td, repeats=2, through_manager=True)
-            rp_stats["native"]["through_lidar_manager"] = {"scans_per_s": round(rm_["scans_per_s"], 1),
-                                                           "note": "the same sequence through lidar::Manager::callback (host/mimosa_hip/manager.hpp): the reference's call order "
-                                                                   "incl. Geometric::getFactors' own first linearize with the component pass; the first cloud initialises"}
-        except Exception as exc:  # noqa: BLE001 - reported, the Python figure above stands
-            rp_stats["native"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if not args.no_cpu_baseline:
-            from oracle.replay_backend import OracleBackend
-            ccfg = replay.ReplayConfig(n_scans=3, rows=args.rows)
-            cr = replay.run(ccfg, OracleBackend(ccfg), rscans[:3])
-            rp_stats["cpu_oracle_scans_per_s"] = round(cr["scans_per_s"], 2)
-
-    # BASELINE configs[4] asks for scans/s "at 1 and 8 GPU": with more than one rank every GPU replays the sequence through
-    # replay_native on its own device at the same time (independent sequences, weak scaling; the host cores are shared)
-    if not args.profile_mode and world > 1:
-        import torch
-        my_rate = 0.0
-        err = None
-        try:
-            import tempfile
-            from mimosa_amd import replay
-            rcfg = replay.ReplayConfig(n_scans=20, rows=args.rows)
-            rscans = replay.make_scans(rcfg)
-            dist.barrier()
-            with tempfile.TemporaryDirectory() as td:
-                rn = replay.run_native(rcfg, rscans, td, repeats=2, visible_device=local_rank)
-            my_rate = float(rn["scans_per_s"])
-        except Exception as exc:  # noqa: BLE001 - a rank that failed contributes 0 and says why
-            err = f"{type(exc).__name__}: {exc}"
-        rates = torch.zeros(world, dtype=torch.float64, device="cuda")
-        rates[rank] = my_rate
-        _all_reduce(rates, op=dist.ReduceOp.SUM)
-        rl = [float(v) for v in rates.cpu()]
-        rp_stats = {"mode": "one replay per GPU through replay_native (C++ host mirror), all ranks at the same time; scans 20, window 5, "
-                            "6 update iterations, photometric on", "n_ranks": world,
-                    "scans_per_s_total": round(world * min(rl), 1) if min(rl) > 0 else 0.0,
-                    "scans_per_s_per_rank": [round(v, 1) for v in rl], "note": "total = ranks x slowest rank"}
-        if err:
-            rp_stats["error_rank0"] = err
-
-    # PCIe-inclusive figure: the boundary hands over HOST buffers, so a scan costs a factor creation
-    # (4 MiB upload + pack + Morton sort) before its first linearize.  Reported, never the headline.
-    cre = []
-    for _ in range(0 if args.profile_mode else 5):
-        ctx.synchronize()
-        a = time.perf_counter()
-        f2 = capi.ICPFactor(ctx, gmap, pts, capi.make_reg_config(**cfgd))
-        f2.linearize(R, t)
-        cre.append(time.perf_counter() - a)
-        f2.destroy()
-    create_plus_lin_ms = float(np.median(cre) * 1e3) if cre else float("nan")
-
-    # untimed-by-events pipelined pass (how much the event records cost)
-    barrier()
-    a = time.perf_counter()
-    if not args.profile_mode:
-        run_steps(args.steps)
-    barrier()
-    elapsed_noev = max(time.perf_counter() - a, 1e-9)
-    # the same pipelined pass with the component pass switched off: every step is K3 alone
-    for f in factors:
-        f.set_components(False)
-    barrier()
-    a = time.perf_counter()
-    if not args.profile_mode:
-        run_steps(args.steps)
-    barrier()
-    elapsed_nocomp = max(time.perf_counter() - a, 1e-9)
-    for f in factors:
-        f.set_components(True)
-
-    # Aggregate throughput with several independent scans in flight (own HIP streams, shared map): a single
-    # 131 072-point scan can only put 2 waves on a SIMD, concurrent scans fill the machine.  Measured at the start of the run
-    # (`conc`, below the timed region: measured in a process of its own).
-    total_pts = n_pts * args.steps * world
-    value = total_pts / elapsed / 1e6
-    mean_cq = float(last["mean_candidates"])
-    b_pt = 384.0 + 16.0 * mean_cq
-    k3_avg_s = float(k3_ms.mean()) * 1e-3
-    achieved_gbs = n_pts * b_pt / k3_avg_s / 1e9
-
-    # HBM traffic of the dominant kernel.  PMC counters cannot be collected inside this process, so the run profiles ITSELF:
-    # two separate `rocprofv3 --kernel-trace --pmc <one counter>` passes of this script in --profile-mode (the warm-up and the
-    # timed region only), FETCH_SIZE and WRITE_SIZE each in its own pass as MI355X_MICROARCH.md prescribes; bytes per launch =
-    # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950; uncalibrated for 16-byte
-    # scattered gathers, so the read side is an upper bound).  Without a profiler on the box the committed summary is used ONLY
-    # if it was taken from the kernel source of this tree (hash of icp_kernels.hip); a stale one is reported as null, loudly.
-    traffic, traffic_note = None, None
-    if not args.profile_mode and world == 1 and rank == 0 and not args.no_measure_traffic:
-        traffic, traffic_note = measure_traffic(args)
-    if traffic is None:
-        why = traffic_note
-        try:
-            import hashlib
-            pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-            src_hash = hashlib.sha256(open(os.path.join(ROOT, "mimosa_amd", "csrc", "icp_kernels.hip"), "rb").read()).hexdigest()[:16]
-            if pm.get("kernel_source_sha16") == src_hash:
-                traffic = int((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024)
-                traffic_note = "NOT measured in this run (" + str(why) + "); committed summary of the same kernel source: " + pm["source"] + " @ " + str(pm.get("commit"))
-            else:
-                traffic_note = ("NOT measured in this run (" + str(why) + ") and profiles/latest_pmc.json was taken from another version of icp_kernels.hip (" +
-                                str(pm.get("kernel_source_sha16")) + " != " + src_hash + "): no traffic figure")
-        except Exception as exc:  # noqa: BLE001
-            traffic_note = f"NOT measured in this run ({why}); no usable committed summary ({type(exc).__name__})"
-
-    # Compulsory lower bound of SURVEY.md §8(d): every touched voxel bucket read ONCE — N x 16 (source) + V_touched x 336
-    # (16-B slot + 320-B bucket) + N x 64 (state out); V_touched = distinct occupied voxels in the 19-neighbourhoods of
-    # all queries.  (Test-side numpy on the downloaded map; not in any timed region.)
-    comp_bytes, v_touched = None, None
-    if not args.profile_mode and rank == 0:
-        cloud = gmap.get_cloud()
-        leaf = cfgd["target_ivox_map_leaf_size"]
-        def _keys(c):
-            c = c.astype(np.int64) + (1 << 20)
-            return (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
-        vm = np.floor(cloud.astype(np.float64) * (1.0 / leaf)).astype(np.int64)
-        occ = np.unique(_keys(vm))
-        q = synth.points_xyz(pts).astype(np.float64) @ R.T + t
-        cq = np.floor(q * (1.0 / leaf)).astype(np.int64)
-        offs = np.array([(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1) if not (i and j and k)], np.int64)
-        touched = np.unique(np.concatenate([_keys(cq + o) for o in offs]))
-        v_touched = int(np.isin(touched, occ, assume_unique=True).sum())
-        comp_bytes = int(n_pts * 16 + v_touched * 336 + n_pts * 64)
-    # the cloud size the reference actually feeds the factor (SURVEY F7: 10-25 k points after the down-sampler)
-    small = None
-    if not args.profile_mode and world == 1:
-        ps = np.ascontiguousarray(pts[::5][:24576])
-        fs = capi.ICPFactor(ctx, gmap, ps, capi.make_reg_config(**cfgd))
-        ctx.set_profiling(1)
-        k3s, k4s, cqs = [], [], 0.0
-        for _ in range(30):
-            fs.reset()
-            rs = fs.linearize(R, t)
-            k3s.append(rs["gpu_ms_linearize"])
-            k4s.append(rs["gpu_ms_localizability"])
-            cqs = float(rs["mean_candidates"])
-        ctx.set_profiling(False)
-        sl = []
-        for _ in range(30):
-            fs.reset()
-            ctx.synchronize()
-            a = time.perf_counter()
-            rc = ctx.L.mh_icp_linearize(fs.h, _R.ctypes.data_as(C.c_void_p), np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), None, None,
-                                        _g.ctypes.data_as(C.c_void_p), C.byref(_out))
-            sl.append(time.perf_counter() - a)
-        bs = 384.0 + 16.0 * cqs
-        small = {"points": int(len(ps)), "kernel_ms_avg": round(float(np.mean(k3s[5:])), 5), "localizability_kernel_ms_avg": round(float(np.mean(k4s[5:])), 5),
-                 "sync_latency_ms": round(float(np.median(sl)) * 1e3, 4), "value_sync": round(len(ps) / float(np.median(sl)) / 1e6, 1),
-                 "achieved": round(len(ps) * bs / (float(np.mean(k3s[5:])) * 1e-3) / 1e9, 1),
-                 "frac": round(len(ps) * bs / (float(np.mean(k3s[5:])) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        fs.destroy()
-
-    # ---- second workloads (VERDICT r2 item 4): (a) a MOVING pose — S scans cast a step apart along a path, one factor each,
-    # cold linearizes round-robin, so the touched map region changes with every step instead of staying resident in L2 /
-    # MALL; (b) the HOSTILE world of mimosa_amd/synth_hostile.py — map = union of past ray-cast scans (1 / r^2 density,
-    # voxels at the 20-point cap next to sparse ones, clutter, thin structures), every RejectStatus branch populated.
-    def _round_robin(fs, poses, k):
-        """k cold linearizes dealt round-robin to the factors `fs` (all on `ctx`), <= INFLIGHT in flight each: seconds per step"""
-        def go(kk):
-            done = 0
-            while done < kk:
-                nb = min(INFLIGHT * len(fs), kk - done)
-                for i in range(nb):
-                    j = (done + i) % len(fs)
-                    fs[j].reset()
-                    fs[j].linearize_async(*poses[j])
-                for f in fs:
-                    f.wait()
-                done += nb
-        go(max(8, 2 * len(fs)))
-        ctx.synchronize()
-        a = time.perf_counter()
-        go(k)
-        ctx.synchronize()
-        return (time.perf_counter() - a) / k
-
-    moving, hostile = None, None
-    if not args.profile_mode and world == 1 and args.hostile_rooms != "none":
-        try:
-            from mimosa_amd import synth_hostile as sh
-            rcfg_ = capi.make_reg_config(**cfgd)
-            ksec = max(40, args.steps // 2)
-            # (a) grid world, moving pose: the sensor advances 0.6 m per scan
-            nmv = 8
-            mv_f, mv_p = [], []
-            for i in range(nmv):
-                loc = synth.SENSOR_LOCAL + np.array([0.6 * i, 0.25 * (i % 3), 0.0])
-                pi_, ai_ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 300 + i, sensor_local=loc, yaw=synth.SENSOR_YAW + 0.05 * i)
-                mv_f.append(capi.ICPFactor(ctx, gmap, pi_, rcfg_))
-                mv_p.append(synth.query_pose(ai_["R_W_L"], ai_["t_W_L"]))
-            same = _round_robin(mv_f[:1], mv_p[:1], ksec)
-            mv = _round_robin(mv_f, mv_p, ksec)
-            moving = {"workload": f"{nmv} scans cast 0.6 m apart along a path in the configs[1] map, one factor each, cold linearizes round-robin on one stream: "
-                                  "the touched map region changes every step",
-                      "value": round(n_pts / mv / 1e6, 2), "ms_per_step": round(mv * 1e3, 5),
-                      "same_pose_value": round(n_pts / same / 1e6, 2), "same_pose_ms_per_step": round(same * 1e3, 5), "unit": "Mpts/s"}
-            for f in mv_f:
-                f.destroy()
-            # (b) hostile world
-            hnx, hny = (int(v) for v in args.hostile_rooms.lower().split("x"))
-            t0h = time.time()
-            hmap = capi.VoxelMap(ctx, leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
-                                 max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-            past = []
-            for _, _, _, hits in sh.make_map_scans(hnx, hny, args.hostile_poses, workers=min(64, os.cpu_count() or 1)):
-                hmap.insert(hits)
-                past.append(hits)
-            hstats = hmap.stats()
-            fill = sh.voxel_fill_stats(hmap.get_cloud(), cfgd["target_ivox_map_leaf_size"], synth.MAX_PTS_PER_VOXEL)
-            hs_f, hs_p = [], []
-            for i in range(nmv):
-                hp_, ha_ = sh.make_query_scan(0.37 + 0.0095 * i, n_rows=args.rows)     # 0.6 m apart along the corridor
-                hs_f.append(capi.ICPFactor(ctx, hmap, hp_, rcfg_))
-                hs_p.append(synth.query_pose(ha_["R_W_L"], ha_["t_W_L"]))
-            hbuild = time.time() - t0h
-            hres = hs_f[0].linearize(*hs_p[0])
-            h_same = _round_robin(hs_f[:1], hs_p[:1], ksec)
-            h_mv = _round_robin(hs_f, hs_p, ksec)
-            hs_f[0].reset()
-            ctx.synchronize()
-            a = time.perf_counter()
-            hs_f[0].linearize(*hs_p[0])
-            h_sync = time.perf_counter() - a
-            hostile = {"workload": f"the {n_pts}-pt OS0-128 scan of a cluttered room vs a {hstats['n_points']}-pt map = the union of {len(past)} past ray-cast scans "
-                                   f"({hnx}x{hny} rooms x {args.hostile_poses} poses, one insert each): 1/r^2 density, saturated and sparse voxels, plates, poles",
-                       "value": round(n_pts / h_same / 1e6, 2), "ms_per_step": round(h_same * 1e3, 5), "unit": "Mpts/s",
-                       "moving_pose_value": round(n_pts / h_mv / 1e6, 2), "moving_pose_ms_per_step": round(h_mv * 1e3, 5),
-                       "sync_latency_ms": round(h_sync * 1e3, 4),
-                       "map_points": int(hstats["n_points"]), "map_voxels": int(hstats["n_voxels"]), "points_inserted": int(sum(len(h_) for h_ in past)),
-                       "voxel_fill": {k_: round(v_, 4) if isinstance(v_, float) else v_ for k_, v_ in fill.items()},
-                       "mean_candidates": round(float(hres["mean_candidates"]), 2), "mean_scanned_after_pruning": round(float(hres["mean_scanned"]), 2),
-                       "exact_fallback_queries": int(hres["n_exact_fallback"]), "status_hist": [int(v) for v in hres["status_hist"]],
-                       "world_build_s": round(hbuild, 1)}
-            try:
-                _h = np.asarray(sh.make_query_scan(0.37, n_rows=args.rows)[0])
-                _h = np.stack([_h["x"], _h["y"], _h["z"]], 1).astype(np.float64) if _h.dtype.names else np.asarray(_h, np.float64)[:, :3]
-                hq = _h @ np.asarray(hs_p[0][0], np.float64).T + np.asarray(hs_p[0][1], np.float64)
-                hostile["candidates_per_query"] = {k_: round(v_, 3) if isinstance(v_, float) else v_
-                                                   for k_, v_ in sh.candidate_stats(hmap.get_cloud(), hq, cfgd["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE).items()}
-            except Exception as e:  # noqa: BLE001
-                hostile["candidates_per_query"] = {"error": f"{type(e).__name__}: {e}"}
-            if not args.no_cpu_baseline:
-                from oracle import ref_cpu
-                hrm = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
-                                  mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-                for hits in past:
-                    hrm.insert(hits)
-                hq, _ = sh.make_query_scan(0.37, n_rows=args.rows)
-                secs_h, href = ref_cpu.time_cold(hrm, hq, ref_cpu.make_config(**cfgd), hs_p[0][0], hs_p[0][1], n_threads=4, iters=3)
-                hostile["parity_vs_oracle"] = {"H_rel": float(np.linalg.norm(hres["H_ss"] - href["H_ss"]) / np.linalg.norm(href["H_ss"])),
-                                               "f_rel": abs(hres["f"] - href["f"]) / abs(href["f"]),
-                                               "status_hist_equal": bool(np.array_equal(hres["status_hist"], href["status_hist"]))}
-                hostile["cpu_oracle_4_threads_mpts_s"] = round(n_pts / float(np.median(secs_h[1:])) / 1e6, 3)
-            for f in hs_f:
-                f.destroy()
-            hmap.release()
-        except Exception as exc:  # noqa: BLE001 - reported in the line
-            hostile = {"error": f"{type(exc).__name__}: {exc}"}
-
-    # The parameter block most shipped configurations use (config/hornbill/params.yaml:86-95; euroc, lapwing, magpie, parrot
-    # alike): 1 m leaf, 0.2 m minimum distance.  The same scan against a >= 5 M-point map built with that block — voxels AT the
-    # 20-point cap, ~190 candidates per query (up to 380): the regime the box pruning and the proof check were not tuned on.
-    leaf1 = None
-    if not args.profile_mode and world == 1 and args.leaf1_rooms != "none":
-        try:
-            from mimosa_amd import synth_hostile as sh1
-            hcfg = synth.hornbill_config()
-            lnx, lny = (int(v) for v in args.leaf1_rooms.lower().split("x"))
-            t0l = time.time()
-            lmap = capi.VoxelMap(ctx, leaf=hcfg["target_ivox_map_leaf_size"], min_dist=hcfg["target_ivox_map_min_dist_in_voxel"],
-                                 max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-            lrooms = [xyz for _, _, xyz in synth.make_hornbill_rooms(lnx, lny)]
-            for xyz in lrooms:
-                lmap.insert(xyz)
-            lstats = lmap.stats()
-            lbuild = time.time() - t0l
-            lf = capi.ICPFactor(ctx, lmap, pts, capi.make_reg_config(**hcfg))
-            lres = lf.linearize(R, t)
-            ctx.set_profiling(1)
-            lk3, lk4 = [], []
-            for _ in range(24):
-                lf.reset()
-                rr_ = lf.linearize(R, t)
-                lk3.append(rr_["gpu_ms_linearize"])
-                lk4.append(rr_["gpu_ms_localizability"])
-            ctx.set_profiling(False)
-            l_step = _round_robin([lf], [(R, t)], max(40, args.steps // 2))
-            lsync = []
-            for _ in range(20):
-                lf.reset()
-                ctx.synchronize()
-                a = time.perf_counter()
-                lf.linearize(R, t)
-                lsync.append(time.perf_counter() - a)
-            lcloud = lmap.get_cloud()
-            lfill = sh1.voxel_fill_stats(lcloud, hcfg["target_ivox_map_leaf_size"], synth.MAX_PTS_PER_VOXEL)
-            _p1 = np.asarray(pts)
-            _p1 = np.stack([_p1["x"], _p1["y"], _p1["z"]], 1).astype(np.float64)
-            lq = _p1 @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
-            lcq = sh1.candidate_stats(lcloud, lq, hcfg["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE)
-            lk3_s = float(np.mean(lk3[4:])) * 1e-3
-            l_bpt = 384.0 + 16.0 * float(lres["mean_candidates"])
-            leaf1 = {"workload": f"the {n_pts}-pt OS0-128 scan vs a {lstats['n_points']}-pt map built with config/hornbill/params.yaml:86-95 (leaf 1.0 m, min-dist 0.2 m; "
-                                 f"{lnx}x{lny} rooms, walls sampled every {synth.HORNBILL_GRID} m), k = 5, mode 19, cold linearize per step",
-                     "value": round(n_pts / l_step / 1e6, 2), "ms_per_step": round(l_step * 1e3, 5), "unit": "Mpts/s",
-                     "sync_latency_ms": round(float(np.median(lsync)) * 1e3, 4),
-                     "kernel_ms_avg": round(float(np.mean(lk3[4:])), 5), "localizability_kernel_ms_avg": round(float(np.mean(lk4[4:])), 5),
-                     "map_points": int(lstats["n_points"]), "map_voxels": int(lstats["n_voxels"]),
-                     "voxel_fill": {k_: round(v_, 4) if isinstance(v_, float) else v_ for k_, v_ in lfill.items()},
-                     "share_of_voxels_at_cap": round(float(lfill["share_at_cap"]), 4),
-                     "candidates_per_query": {k_: round(v_, 3) if isinstance(v_, float) else v_ for k_, v_ in lcq.items()},
-                     "mean_candidates": round(float(lres["mean_candidates"]), 2), "mean_scanned_after_pruning": round(float(lres["mean_scanned"]), 2),
-                     "exact_fallback_queries": int(lres["n_exact_fallback"]), "status_hist": [int(v) for v in lres["status_hist"]],
-                     "roofline": {"bound": "hbm", "bytes_per_point": round(l_bpt, 1), "achieved": round(n_pts * l_bpt / lk3_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(n_pts * l_bpt / lk3_s / 1e9 / HBM_PEAK_GBS, 4),
-                                  "note": "the same gather model as the headline (384 + 16 C_q bytes per point, no reuse credited): a work-equivalent figure, see roofline.frac_note"},
-                     "world_build_s": round(lbuild, 1)}
-            if not args.no_cpu_baseline:
-                from oracle import ref_cpu
-                lrm = ref_cpu.Map(leaf=hcfg["target_ivox_map_leaf_size"], min_dist=hcfg["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
-                                  mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-                for xyz in lrooms:
-                    lrm.insert(xyz)
-                secs_l, lref = ref_cpu.time_cold(lrm, pts, ref_cpu.make_config(**hcfg), R, t, n_threads=4, iters=3)
-                leaf1["parity_vs_oracle"] = {"H_rel": float(np.linalg.norm(lres["H_ss"] - lref["H_ss"]) / np.linalg.norm(lref["H_ss"])),
-                                             "f_rel": abs(lres["f"] - lref["f"]) / abs(lref["f"]),
-                                             "status_hist_equal": bool(np.array_equal(lres["status_hist"], lref["status_hist"]))}
-                leaf1["cpu_oracle_4_threads_mpts_s"] = round(n_pts / float(np.median(secs_l[1:])) / 1e6, 3)
-            lf.destroy()
-            lmap.release()
-        except Exception as exc:  # noqa: BLE001 - reported in the line
-            leaf1 = {"error": f"{type(exc).__name__}: {exc}"}
-
-    cand_stats = None
-    if rank == 0 and not args.profile_mode:
-        try:  # what the reference's k-NN scans per query on this world: the tail sets K3's slowest wave (DESIGN.md §3)
-            from mimosa_amd import synth_hostile as _sh
-            _p = np.asarray(pts)
-            _p = np.stack([_p["x"], _p["y"], _p["z"]], 1).astype(np.float64) if _p.dtype.names else np.asarray(_p, np.float64)[:, :3]
-            qw = _p @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
-            cand_stats = {k_: round(v_, 3) if isinstance(v_, float) else v_
-                          for k_, v_ in _sh.candidate_stats(gmap.get_cloud(), qw, cfgd["target_ivox_map_leaf_size"], synth.ENWIDE_NEIGHBOR_MODE).items()}
-        except Exception as e:  # noqa: BLE001 — a statistic, never the reason for a missing line
-            cand_stats = {"error": f"{type(e).__name__}: {e}"}
+            res.update(leg.run(E))
+        except Exception as exc:  # noqa: BLE001 - a side leg never costs the job its line
+            res[leg.__name__.split(".")[-1] + "_error"] = f"{type(exc).__name__}: {exc}"
+    last, hostile = H["last"], res.get("hostile_world")
+    elapsed, block_s = H["elapsed"], H["block_s"]
     line = {
         "metric": "ICP corr+residual Mpts/sec, 131k-pt scan vs 5M-pt map, 1/2/4/8 GPU",
-        "value": round(value, 3),
-        "unit": "Mpts/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
+        "value": round(n * args.steps * world / elapsed / 1e6, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "ms_per_step_median": round(float(np.median(block_s)) / args.steps * 1e3, 5),
         "ms_per_step_p95": round(float(np.percentile(block_s, 95)) / args.steps * 1e3, 5),
         "ms_per_step_blocks": [round(v / args.steps * 1e3, 5) for v in block_s],
-        "ms_per_step_note": f"value / ms_per_step = the first timed block of exactly {args.steps} steps; median / p95 over {len(block_s)} such blocks of this run",
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: OS0-128 {n_pts}-pt scan vs {stats['n_points']}-pt local map "
-                        f"({stats['n_voxels']} voxels, {args.rooms} rooms), k=5 point-to-plane, ENWIDE params, "
-                        f"cold linearize per step",
-            "mode": f"{args.streams} independent scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT_ICP} "
-                    f"linearize calls in flight per stream, every result copied to the host",
-            "streams": args.streams,
-            "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
-            "status_hist": [int(v) for v in last["status_hist"]],
-            "status_note": "index = RejectStatus (geometric_factor.hpp:35-46): 5 = Line, 8 = Valid.  A third of the points end as Line on this synthetic "
-                           "world (map points on a 0.16 m jittered grid: 5 neighbours often fall on one grid row); real scans will shift the valid fraction",
-            "exact_fallback_queries": int(last["n_exact_fallback"]),
-            "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2),
-            "valid_share": round(float(last["status_hist"][8]) / max(n_pts, 1), 4),
-            "candidates_per_query": cand_stats,
-            # the second, hostile world (every RejectStatus populated, 1/r^2 density, voxels at the cap) at full size in the same
-            # run: its throughput, valid share and candidate statistics next to the grid world's (all of it under "hostile_world")
+            "workload": f"configs[1]: OS0-128 {n}-pt scan vs {E.stats['n_points']}-pt local map ({E.stats['n_voxels']} voxels, {args.rooms} rooms), "
+                        "k=5 point-to-plane, ENWIDE params, cold linearize per step",
+            "mode": f"{args.streams} scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT_ICP} linearize calls in flight per "
+                    f"stream, every result copied to the host; {E.overlap_note}",
+            "streams": args.streams, "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
+            "status_hist": [int(v) for v in last["status_hist"]], "exact_fallback_queries": int(last["n_exact_fallback"]),
+            "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2), "valid_share": round(float(last["status_hist"][8]) / max(n, 1), 4),
+            "candidates_per_query": res.pop("candidates_per_query", None),
             "second_world": None if not isinstance(hostile, dict) or "error" in hostile else {
                 "workload": "hostile_world", "value": hostile.get("value"), "ms_per_step": hostile.get("ms_per_step"),
-                "valid_share": round(hostile["status_hist"][8] / max(n_pts, 1), 4), "status_hist": hostile["status_hist"],
-                "mean_candidates": hostile.get("mean_candidates"), "candidates_per_query": hostile.get("candidates_per_query"),
-                "H_rel_vs_oracle": (hostile.get("parity_vs_oracle") or {}).get("H_rel")},
+                "valid_share": round(hostile["status_hist"][8] / max(n, 1), 4), "status_hist": hostile["status_hist"],
+                "mean_candidates": hostile.get("mean_candidates"), "H_rel_vs_oracle": (hostile.get("parity_vs_oracle") or {}).get("H_rel")},
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "icp_linearize_kernel<5,false>",
-            "achieved": round(achieved_gbs, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-            "frac_of_measured_copy_peak": round(achieved_gbs / HBM_COPY_GBS, 4),
-            "traffic": traffic,
-            "traffic_note": traffic_note,
-            "hbm_measured_gbs": round(traffic / k3_avg_s / 1e9, 1) if traffic else None,
-            "hbm_measured_frac_of_peak": round(traffic / k3_avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-            "compulsory_bytes": comp_bytes,
-            "voxels_touched": v_touched,
-            "frac_compulsory": round(comp_bytes / k3_avg_s / 1e9 / HBM_PEAK_GBS, 4) if comp_bytes else None,
-            "frac_of_compulsory_at_measured_copy_peak": round(comp_bytes / (HBM_COPY_GBS * 1e9) / k3_avg_s, 4) if comp_bytes else None,
-            "frac_note": "frac = gather-model bytes (no reuse credited, SURVEY.md 8(d)) / kernel time / 8 TB/s: a work-equivalent figure, NOT "
-                         "HBM bandwidth — the touched map lives in L2 / Infinity Cache; hbm_measured_* is the PMC traffic, frac_compulsory the "
-                         "read-every-bucket-once bound.  The kernel is bound by dependent latency and L1 request rate, see DESIGN.md",
-            "small_cloud": small,
-            "algorithmic_bytes_per_launch": int(n_pts * b_pt),
-            "bytes_per_point": round(b_pt, 1),
-            "mean_candidates_per_query": round(mean_cq, 2),
-            "kernel_timing": f"HIP events on the launch stream around {len(k3_ms)} of the {len(outs)} launches of the timed "
-                             f"region (every {event_every}th call of each factor)",
-            "kernel_ms_avg": round(float(k3_ms.mean()), 5),
-            "kernel_ms_p95": round(float(np.percentile(k3_ms, 95)), 5),
-            "localizability_kernel_ms_avg": round(float(k4_ms.mean()), 5) if len(k4_ms) else None,
-            "localizability_kernel_timing": k4_timing,
-            "frac_whole_step": round(n_pts * b_pt / (elapsed / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 4),
-            "frac_whole_step_note": "the same gather-model bytes over ms_per_step (K3 + the component pass + launch gaps) instead of K3's own duration",
-            "kernel_ms_back_to_back": round(elapsed_nocomp / max(args.steps, 1) * 1e3, 5) if not args.profile_mode else None,
-            "kernel_ms_back_to_back_note": "wall clock / steps of the pipelined pass with the component pass off (K3 launches back to back, "
-                                           "no event packets): an upper bound of K3's duration, the figure rocprofv3 reports; "
-                                           "kernel_ms_avg (HIP events around single launches) also contains the dispatch latency",
-        },
-        "sync_latency_ms": round(lat_ms, 4),
-        "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
-        "sync_latency_without_components_ms": round(lat_nc_ms, 4),
-        "value_no_events": round(total_pts / elapsed_noev / 1e6, 2),
-        "value_without_components": round(total_pts / elapsed_nocomp / 1e6, 2),
-        "value_concurrent": conc,
-        "keyframe_map_update": kf_stats,
-        "scan_frontend": fe_stats,
-        "sequence_replay": rp_stats,
-        "relinearize_window": win_stats,
-        "moving_pose": moving,
-        "hostile_world": hostile,
-        "leaf1_world": leaf1,
-        "photometric": ph_stats,
-        "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
-                        "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
-                        "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,
-                        "value_sync": round(n_pts / float(np.median(relin_wall)) / 1e6, 1) if relin_wall else None},
-        "value_pcie_inclusive": round(n_pts / (create_plus_lin_ms * 1e-3) / 1e6, 2),
-        "create_plus_linearize_ms": round(create_plus_lin_ms, 4),
-        "setup_s": round(setup_s, 2),
+        "roofline": roofline(E, H, res.pop("small_cloud", None), res.pop("_kernel_ms_back_to_back", None)),
+        "setup_s": round(E.setup_s, 2),
     }
-
-    # ---- CPU baseline: the oracle ("port") on the host cores, rank 0, N=1 only ----
+    line.update(res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import ref_cpu
-
-        rmap = ref_cpu.Map(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"],
-                           max_pts=synth.MAX_PTS_PER_VOXEL, mode=synth.ENWIDE_NEIGHBOR_MODE,
-                           lru_horizon=synth.ENWIDE_LRU_HORIZON)
-        for xyz in room_clouds:
-            rmap.insert(xyz)
-        rcfg = ref_cpu.make_config(**cfgd)
-        ncores = os.cpu_count() or 1
-        secs4, res4 = ref_cpu.time_cold(rmap, pts, rcfg, R, t, n_threads=4, iters=args.cpu_iters + 2)
-        med4 = float(np.median(secs4[2:]))
-        # thread sweep: the all-cores row is the BEST point of the curve, with its thread count (round 3 reported the
-        # nproc-thread point alone, the worst one: fork / join of 256 threads around 30 ms of work)
-        sweep = {4: med4}
-        for nt in sorted({8, 16, 32, 64, ncores}):
-            if nt <= 4 or nt > ncores:
-                continue
-            secs_n, _ = ref_cpu.time_cold(rmap, pts, rcfg, R, t, n_threads=nt, iters=max(4, args.cpu_iters // 2) + 2)
-            sweep[nt] = float(np.median(secs_n[2:]))
-        best_nt = min(sweep, key=sweep.get)
-        med_all = sweep[best_nt]
-        from tests.parity import rel  # noqa: E402  (checker only)
-        line["cpu_baseline"] = {
-            "value": round(n_pts / med4 / 1e6, 3),
-            "unit": "Mpts/s",
-            "cores": 4,
-            "kind": "port",
-            "sample": f"the full workload ({n_pts}-pt scan vs the same map), median of {args.cpu_iters} cold "
-                      f"linearizes after 2 warm-ups, 4 OpenMP threads as hard-coded in the reference "
-                      f"(geometric_factor.hpp:261)",
-            "all_cores_value": round(n_pts / med_all / 1e6, 3),
-            "all_cores": ncores,
-            "all_cores_threads_used": best_nt,
-            "thread_sweep_mpts_s": {str(k_): round(n_pts / v_ / 1e6, 3) for k_, v_ in sorted(sweep.items())},
-            "all_cores_note": "best point of a thread sweep {4, 8, 16, 32, 64, nproc} of the same OpenMP loop (per-thread sums on their own cache "
-                              "lines); SURVEY 8(d)'s all-host-cores row",
-        }
-        line["parity_vs_oracle"] = {
-            "H_rel": rel(last["H_ss"], res4["H_ss"]), "b_rel": rel(last["b_s"], res4["b_s"]),
-            "f_rel": abs(last["f"] - res4["f"]) / abs(res4["f"]),
-            "status_hist_equal": bool(np.array_equal(last["status_hist"], res4["status_hist"])),
-        }
-
-    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node.  The NATIVE path
-    # (mimosa_amd/csrc/shard_api.hip, mh_shard_*): every rank stores the blocks it owns + a one-voxel halo, a linearize is one
-    # chain of enqueues — route kernels, ncclAllToAll of fixed-size segments over xGMI, append, K3, ncclAllReduce of the Hessian
-    # sums (+ K4 and a second all-reduce when the components are on), publish — and ONE wait.  Reported NEXT TO the replica
-    # figure (`value`); all ranks take part.  With one rank the leg also runs by default: the sharded factor without
-    # collectives (nothing to exchange: the call IS mh_icp_linearize) and the FULL protocol forced over RCCL.
-    sharded = None
-    if args.shard_rooms != "none" and not args.profile_mode:
-        # The leg runs under a deadline in a worker thread: a failure or a stuck collective in it must not cost the
-        # job its JSON line (the replica figure above is complete at this point).
-        import threading
-        box = {}
-        dry = os.environ.get("MH_BENCH_DRYRUN") == "1"
-
-        def _timed(fn, k, pre=None):
-            """k calls, barrier + device sync on both sides, max over ranks: seconds per call"""
-            def sync():
-                sctx.synchronize()
-                if dist is not None:
-                    dist.barrier()
-            for _ in range(3):
-                if pre:
-                    pre()
-                fn()
-            sync()
-            a = time.perf_counter()
-            for _ in range(k):
-                if pre:
-                    pre()
-                fn()
-            sync()
-            el = time.perf_counter() - a
-            if dist is not None and world > 1:
-                import torch
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-                _all_reduce(tt, op=dist.ReduceOp.MAX)
-                el = float(tt.item())
-            return el / k
-
-        def _native_leg(force, vmap, comm, spts, ksh):
-            f = capi.ShardedICPFactor(sctx, comm, vmap, np.array_split(spts, world)[rank], capi.make_reg_config(**cfgd), block_log2=args.shard_block_log2,
-                                      force_collectives=force)
-            a0 = time.perf_counter()
-            first_s = f.linearize(R, t)                                          # cold + routes every point to its owner
-            first_ms = (time.perf_counter() - a0) * 1e3
-            st0 = f.stats()
-            for _ in range(100):  # the scan was generated on the host just before: let the clocks come back up
-                f.linearize(R, t)
-            cold = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
-            warm = _timed(lambda: f.linearize(R, t), ksh)
-            f.set_components(False)
-            cold_nc = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
-            warm_nc = _timed(lambda: f.linearize(R, t), ksh)
-            kk = [0]
-            movers = []
-
-            def walk():  # a Gauss-Newton-sized pose step per call: points near block faces change owner
-                kk[0] += 1
-                f.linearize(R @ synth.so3_exp(np.array([0.0, 0.0, 0.0005 * kk[0]])), t + np.array([0.004, 0.002, 0.0]) * kk[0])
-                movers.append(f.stats()["last_max_movers"])
-            walk_nc = _timed(walk, ksh)
-            st = f.stats()
-            f.destroy()
-            return {"first_linearize_ms": round(first_ms, 4), "first_max_movers_per_destination": st0["last_max_movers"],
-                    "ms_per_cold_linearize": round(cold * 1e3, 4), "ms_per_warm_linearize": round(warm * 1e3, 4),
-                    "ms_per_cold_linearize_without_components": round(cold_nc * 1e3, 4), "ms_per_warm_linearize_without_components": round(warm_nc * 1e3, 4),
-                    "ms_per_walking_pose_linearize_without_components": round(walk_nc * 1e3, 4),
-                    "walking_pose_max_movers_per_destination": int(max(movers)) if movers else 0,
-                    "value": round(len(spts) / cold / 1e6, 2), "points_held": st["n_live"], "slots": st["n_slots"], "segment_records": st["segment_records"],
-                    "retries": st["retries_total"], "compactions": st["compactions_total"], "collectives_per_linearize": st["collectives_last"],
-                    "status_hist": [int(v) for v in first_s["status_hist"]]}
-
-        def _timed_total(fn_k, k):
-            """fn_k(k) issues k units of work (and waits for them); warm-up, then barrier + device sync on both sides, max over ranks: seconds per unit"""
-            def sync():
-                sctx.synchronize()
-                if dist is not None:
-                    dist.barrier()
-            fn_k(max(8, k // 4))
-            sync()
-            a = time.perf_counter()
-            fn_k(k)
-            sync()
-            el = time.perf_counter() - a
-            if dist is not None and world > 1:
-                import torch
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-                _all_reduce(tt, op=dist.ReduceOp.MAX)
-                el = float(tt.item())
-            return el / k
-
-        def _throughput_forms(force, vmap, comm, clouds, k, label):
-            """The throughput forms of the sharded factor (raw C-ABI calls, arguments marshalled once): ONE factor with <= 32 calls in
-            flight (mh_shard_icp_linearize_async / _wait), and a WINDOW of len(clouds) factors per protocol round
-            (mh_shard_icp_linearize_batch blocking; _batch_async with <= 32 rounds in flight).  Every call is a cold linearize
-            (mh_shard_icp_reset before it, stream-ordered); the points are already on their owners."""
-            import ctypes as C_
-            L = sctx.L
-            B = len(clouds)
-            rc_ = capi.make_reg_config(**cfgd)
-            fs = [capi.ShardedICPFactor(sctx, comm, vmap, np.array_split(cl, world)[rank], rc_, block_log2=args.shard_block_log2, force_collectives=force) for cl in clouds]
-            vp = lambda a_: a_.ctypes.data_as(C_.c_void_p)
-            R1, t1, g1 = np.ascontiguousarray(R, np.float64), np.ascontiguousarray(t, np.float64), np.ascontiguousarray([0.0, 0.0, -1.0], np.float64)
-            RB, tB, gB = np.ascontiguousarray(np.tile(R1.reshape(1, 9), (B, 1))), np.ascontiguousarray(np.tile(t1, (B, 1))), np.ascontiguousarray(np.tile(g1, (B, 1)))
-            hs = (C_.c_void_p * B)(*[f.h for f in fs])
-            first = capi.sharded_linearize_batch(fs, [R] * B, [t] * B)   # routes every point of every factor to its owner
-            out1 = (capi.IcpResult * INFLIGHT)()
-            outB = [(capi.IcpResult * B)() for _ in range(INFLIGHT)]
-            f0 = fs[0]
-
-            def single_sync(kk):
-                for _ in range(kk):
-                    sctx.check(L.mh_shard_icp_reset(f0.h))
-                    sctx.check(L.mh_shard_icp_linearize(f0.h, vp(R1), vp(t1), None, None, vp(g1), C_.byref(out1[0])))
-
-            def single_pipelined(kk):
-                done = 0
-                while done < kk:
-                    nb = min(INFLIGHT, kk - done)
-                    for i in range(nb):
-                        sctx.check(L.mh_shard_icp_reset(f0.h))
-                        sctx.check(L.mh_shard_icp_linearize_async(f0.h, vp(R1), vp(t1), None, None, vp(g1), C_.byref(out1[i])))
-                    sctx.check(L.mh_shard_icp_wait(f0.h))
-                    done += nb
-
-            def batch_blocking(kk):
-                for _ in range(kk):
-                    for f in fs:
-                        sctx.check(L.mh_shard_icp_reset(f.h))
-                    sctx.check(L.mh_shard_icp_linearize_batch(hs, B, vp(RB), vp(tB), None, None, vp(gB), outB[0]))
-
-            def batch_pipelined(kk):
-                done = 0
-                while done < kk:
-                    nb = min(INFLIGHT, kk - done)
-                    for i in range(nb):
-                        for f in fs:
-                            sctx.check(L.mh_shard_icp_reset(f.h))
-                        sctx.check(L.mh_shard_icp_linearize_batch_async(hs, B, vp(RB), vp(tB), None, None, vp(gB), outB[i]))
-                    sctx.check(L.mh_shard_icp_wait(f0.h))
-                    done += nb
-
-            single_sync(30)  # clocks up
-            npts_f = [len(cl) for cl in clouds]
-            res = {"what": label, "factors": B, "points_per_factor": npts_f[0] if len(set(npts_f)) == 1 else npts_f, "steps": k,
-                   "first_status_hist": [int(v) for v in first[0]["status_hist"]]}
-            ss = _timed_total(single_sync, k)
-            sp_ = _timed_total(single_pipelined, k)
-            bb = _timed_total(batch_blocking, k)
-            bp = _timed_total(batch_pipelined, k)
-            for f in fs:
-                f.set_components(False)
-            bb_nc = _timed_total(batch_blocking, k)
-            bp_nc = _timed_total(batch_pipelined, k)
-            tot = float(sum(npts_f))
-            res.update({"single_sync_ms": round(ss * 1e3, 4), "single_pipelined_ms": round(sp_ * 1e3, 4),
-                        "batch_blocking_ms_per_round": round(bb * 1e3, 4), "batch_pipelined_ms_per_round": round(bp * 1e3, 4),
-                        "batch_blocking_ms_per_round_without_components": round(bb_nc * 1e3, 4),
-                        "batch_pipelined_ms_per_round_without_components": round(bp_nc * 1e3, 4),
-                        "value_single_sync": round(npts_f[0] / ss / 1e6, 2), "value_single_pipelined": round(npts_f[0] / sp_ / 1e6, 2),
-                        "value_batch_blocking": round(tot / bb / 1e6, 2), "value_batch_pipelined": round(tot / bp / 1e6, 2),
-                        "value_batch_pipelined_without_components": round(tot / bp_nc / 1e6, 2), "unit": "Mpts/s",
-                        "retries": int(sum(f.stats()["retries_total"] for f in fs)), "collectives_per_round": fs[0].stats()["collectives_last"]})
-            for f in fs:
-                f.destroy()
-            return res
-
-        def _sharded_leg():
-            try:
-                if dist is not None:
-                    import torch
-                    torch.cuda.set_device(local_rank)
-                sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else ("4x5" if world > 1 else args.rooms))
-                snx, sny = (int(v) for v in sr.lower().split("x"))
-                spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
-                ksh = max(20, args.steps // 4)
-                mkw = dict(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
-                           mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
-                if dry and world > 1:
-                    # tests only: several ranks on ONE GPU — RCCL refuses that, so the caller-driven form of the protocol
-                    # (mimosa_amd/dist.py over gloo) stands in; the native path at world > 1 is covered by the in-process
-                    # transport in tests/test_gpu_shard_native.py
-                    import torch
-                    from mimosa_amd import dist as mdist
-                    lctx = mdist.context_on_torch_stream(local_rank)
-                    sh = mdist.ShardedICPDevice(dist.group.WORLD, lctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), torch.device("cuda", local_rank))
-                    sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), **mkw)
-                    sh.set_scan(np.array_split(spts, world)[rank])
-                    first_s = sh.linearize(R, t)
-                    nloc = torch.tensor([float(first_s["n_local"])], dtype=torch.float64, device="cuda")
-                    nmax = nloc.clone()
-                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
-                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
-                    box["result"] = {"n_ranks": world, "backend": "gloo (dry run, caller-driven protocol)", "scan_points_total": int(nloc[0].item()),
-                                     "scan_points_max_per_rank": int(nmax[0].item()), "status_hist": [int(v) for v in first_s["status_hist"]]}
-                    sh.close()
-                    return
-                # the communicator: rank 0 draws the ncclUniqueId, torch.distributed (already up for the replica leg) carries it
-                uid = capi.ShardComm.unique_id() if rank == 0 else None
-                if dist is not None and world > 1:
-                    obj = [uid]
-                    dist.broadcast_object_list(obj, src=0)
-                    uid = obj[0]
-                comm = capi.ShardComm.rccl(sctx, uid, world, rank)
-                t0s = time.time()
-                if world == 1 and sr == args.rooms:
-                    vmap, own_map = gmap, False                                    # one rank's shard IS the map
-                else:
-                    vmap, own_map = capi.VoxelMap(sctx, **mkw), True
-                    for _, _, xyz in synth.make_map_rooms(snx, sny):
-                        capi.map_insert_shard(sctx, vmap, xyz, world, rank, args.shard_block_log2)
-                build_s = time.time() - t0s
-                mstats = vmap.stats()
-                res = _native_leg(False, vmap, comm, spts, ksh)
-                # the throughput forms: a window of max(world, 2) whole scans (own noise seeds), one protocol round per step —
-                # at N ranks that is N scans' worth of points per round, i.e. the per-GPU work of the replica mode (weak scaling)
-                nwin_s = max(world, 2)
-                clouds = [spts] + [synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + 1000 * i)[0] for i in range(1, nwin_s)]
-                thr = _throughput_forms(False, vmap, comm, clouds, args.steps, f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
-                result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
-                                       f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
-                           "n_ranks": comm.world, "backend": comm.backend, "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
-                           "map_build_s": round(build_s, 2), **res, "throughput": thr}
-                if world == 1:
-                    result["full_protocol_forced"] = _native_leg(True, vmap, comm, spts, ksh)
-                    result["full_protocol_forced"]["throughput"] = _throughput_forms(True, vmap, comm, clouds, max(20, args.steps), "the same with the exchange protocol forced at one rank")
-                    # VERDICT r3 item 1's yardstick: the smoother window (5 factors x 24 576 points) through the sharded batch with the
-                    # protocol forced, against the unsharded mh_icp_linearize_batch of the same window (relinearize_window.batch_cold_ms)
-                    wcl = [np.ascontiguousarray(spts[i::5][:24576]) for i in range(5)]
-                    result["full_protocol_forced"]["window_5x24576"] = _throughput_forms(True, vmap, comm, wcl, max(20, args.steps), "5 factors x 24 576 points, protocol forced, one rank")
-                    if win_stats:
-                        result["full_protocol_forced"]["window_5x24576"]["unsharded_batch_cold_ms"] = win_stats["batch_cold_ms"]
-                        result["full_protocol_forced"]["window_5x24576"]["ratio_to_unsharded_batch"] = round(
-                            result["full_protocol_forced"]["window_5x24576"]["batch_blocking_ms_per_round"] / win_stats["batch_cold_ms"], 3)
-                    result["full_protocol_forced"]["note"] = ("one rank, every step of the exchange protocol executed anyway: route kernels, ncclAllToAll of the segments to itself, "
-                                                              "append, K3 on device-side counts, ncclAllReduce(s), publish")
-                    result["scan_points_total"] = result["scan_points_max_per_rank"] = res["points_held"]
-                    result["map_points_stored_total"] = result["map_points_max_per_rank"] = int(mstats["n_points"])
-                else:
-                    import torch
-                    nloc = torch.tensor([float(res["points_held"]), float(mstats["n_points"])], dtype=torch.float64, device="cuda")
-                    nmax = nloc.clone()
-                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
-                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
-                    result.update(scan_points_total=int(nloc[0].item()), scan_points_max_per_rank=int(nmax[0].item()),
-                                  map_points_stored_total=int(nloc[1].item()), map_points_max_per_rank=int(nmax[1].item()))
-                result["note"] = ("one scan is latency-bound when sharded (a few thousand points per rank behind one all-to-all and one or two all-reduces): "
-                                  "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode.  "
-                                  + ("No xGMI figure exists yet: a one-GPU box cannot run RCCL with more than one rank." if world == 1 else ""))
-                comm.destroy()
-                if own_map:
-                    vmap.release()
-                box["result"] = result
-            except Exception as exc:  # noqa: BLE001 - reported in the line
-                box["error"] = f"{type(exc).__name__}: {exc}"
-
-        sctx = capi.Context(local_rank)
-        th = threading.Thread(target=_sharded_leg, daemon=True)
-        th.start()
-        th.join(args.shard_timeout)
-        if th.is_alive():
-            sharded = {"error": f"no result within {args.shard_timeout} s (stuck collective?)", "n_ranks": world}
-            line["sharded"] = sharded
-            line["metric_form"] = "value = independent scan replicas (the map-sharded leg did not complete within its deadline)"
-            if rank == 0:
-                sys.stdout.flush()
-                os.write(real_stdout, (json.dumps(line) + "\n").encode())
-            os._exit(0)  # the worker may sit in a collective for ever: no clean-up is possible
-        sharded = box.get("result") or {"error": box.get("error", "unknown"), "n_ranks": world}
-        if "error" not in sharded:
-            sctx.close()
-    line["sharded"] = sharded
-    # ---- which figure is the metric.  north_star names the MAP-SHARDED factor as the multi-GPU design; with more than one rank
-    # `value` is therefore the sharded factor's throughput form — one protocol round of N scans per step (N ranks: the per-GPU
-    # work of the replica mode, weak scaling), rounds pipelined — and the replica figure (every rank holds the whole map, no
-    # collective) stands next to it as value_replica.  At one rank `value` is the unsharded configs[1] figure, as the contract
-    # says; the sharded forms of that rank (with the protocol forced) are reported under value_sharded.
-    thr_ = sharded.get("throughput") if isinstance(sharded, dict) else None
+        line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(E, last)
+    shd = None if args.headline_only else sharded.run(E, line, real_stdout)
+    line["sharded"] = shd
+    # ---- which figure is the metric.  SURVEY 8(d) defines it as N / the wall time of ONE cold linearize — value_sync, what the
+    # reference's callers do; `value` is the same work with calls pipelined.  With more than one rank `value` is the MAP-SHARDED
+    # factor's throughput form (north_star's multi-GPU design) and the replica figure stands next to it as value_replica.
+    thr_ = shd.get("throughput") if isinstance(shd, dict) else None
     if thr_:
-        forced_ = (sharded.get("full_protocol_forced") or {}).get("throughput") if world == 1 else None
-        src_ = forced_ or thr_
+        src_ = ((shd.get("full_protocol_forced") or {}).get("throughput") if world == 1 else None) or thr_
         line["value_sharded"] = {"single_sync": src_["value_single_sync"], "single_pipelined": src_["value_single_pipelined"],
                                  "batched_blocking": src_["value_batch_blocking"], "batched_pipelined": src_["value_batch_pipelined"],
                                  "batched_pipelined_without_components": src_["value_batch_pipelined_without_components"],
-                                 "factors_per_round": src_["factors"], "ms_per_round_pipelined": src_["batch_pipelined_ms_per_round"], "unit": "Mpts/s",
-                                 "what": src_["what"]}
+                                 "factors_per_round": src_["factors"], "ms_per_round_pipelined": src_["batch_pipelined_ms_per_round"],
+                                 "unit": "Mpts/s", "what": src_["what"]}
+        line["sharded_rccl"] = {"rccl_ranks": shd.get("n_ranks"), "rccl_version": shd.get("rccl_version"), "backend": shd.get("backend")}
+    form = ("value = <= 64 cold linearize calls of one factor in flight (results on the host, parity-checked); value_sync = one synchronous "
+            "mh_icp_linearize at a time = SURVEY 8(d)'s definition and the reference's call pattern (geometric.cpp:194-196)")
     if world > 1:
-        line["value_replica"] = line["value"]
-        line["ms_per_step_replica"] = line["ms_per_step"]
+        line["value_replica"], line["ms_per_step_replica"] = line["value"], line["ms_per_step"]
         if thr_:
-            line["value"] = thr_["value_batch_pipelined"]
-            line["ms_per_step"] = thr_["batch_pipelined_ms_per_round"]
-            line["steps"] = thr_["steps"]
-            line["metric_form"] = (f"value = the MAP-SHARDED factor (north_star's multi-GPU design): {thr_['factors']} scans of {n_pts} points per protocol round "
-                                   f"(one ncclAllToAll + ncclAllReduce(s) over xGMI per round), rounds pipelined, map hash-sharded over {world} GPUs; "
-                                   "value_replica = independent scan replicas, every rank holding the whole map (no collective)")
-            line["config"]["parallelism"] = f"1 process/GPU, map hash-sharded over {world} GPUs (RCCL all-to-all + all-reduce per round), {thr_['factors']} scans per round"
+            line["value"], line["ms_per_step"], line["steps"] = thr_["value_batch_pipelined"], thr_["batch_pipelined_ms_per_round"], thr_["steps"]
+            form = (f"value = the MAP-SHARDED factor: {thr_['factors']} scans of {n} points per protocol round (one ncclAllToAll + ncclAllReduce(s) "
+                    f"over xGMI per round), rounds pipelined, map hash-sharded over {world} GPUs; value_replica = independent scan replicas "
+                    f"({E.overlap_note})")
+            line["config"]["parallelism"] = f"1 process/GPU, map hash-sharded over {world} GPUs (RCCL all-to-all + all-reduce per round)"
         else:
-            line["metric_form"] = "value = independent scan replicas (the map-sharded leg did not complete: see sharded.error)"
-    else:
-        line["metric_form"] = "value = the unsharded configs[1] factor on one GPU; value_sharded = the sharded factor's forms at one rank with the exchange protocol forced"
-
+            form = "value = independent scan replicas (the map-sharded leg did not complete: see sharded.error); " + E.overlap_note
+    line["metric_form"] = form
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    if isinstance(sharded, dict) and "error" in sharded:
-        os._exit(0)  # a peer may still sit in a collective of the failed leg: tearing the process group down could wait on it for ever
-    for f in factors:
+    if isinstance(shd, dict) and "error" in shd:
+        os._exit(0)  # a peer may still sit in a collective of the failed leg: tearing the process group down could wait for ever
+    for f in E.factors:
         f.destroy()
-    gmap.release()
-    for c in ctxs[1:]:
+    E.gmap.release()
+    for c in E.ctxs[1:]:
         c.close()
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    E.ctx.close()
+    if E.dist is not None:
+        E.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -121,7 +121,7 @@ def _build_locked(force: bool, verbose: bool, timeline: bool) -> str:
             deps = None
         if force or _stale(o, deps if deps is not None else [s] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-DMH_BUILDING_LIBRARY", "-MMD", "-MF", d,
-                   "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] + (["-DMH_BALANCE"] if os.environ.get("MH_BALANCE") else []) if timeline else []), "-c", s, "-o", o]
+                   "-Wno-unused-parameter", *extra, *(["-DMH_TIMELINE"] if timeline else []), "-c", s, "-o", o]
             jobs.append((cmd, o))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:

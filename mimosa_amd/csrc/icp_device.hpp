@@ -41,11 +41,11 @@ struct DeviceResult
 // {lo, seq, hi, seq} into mapped pinned memory, each 8-byte half carrying the call's sequence number, so the host knows a
 // value has arrived by looking at the value itself — no system-scope fence, no completion flag behind the data, no
 // ordering between stores needed (the idea of NCCL's LL protocol).  Layout of one call's slot (LlSlot): the 28 / 91 Hessian
-// sums + 4 counters, the two eigenbases K4 projected on, and K4's per-workgroup rows of 16 (6 component sums + 9 histogram
-// counts, two 32-bit counts per word), which the HOST folds in workgroup order — K4 has no ticket / last-block fold any more.
+// sums + 4 counters, the two eigenbases K4 projected on, and K4's per-workgroup rows of 8 (6 component sums + 9 histogram
+// counts, 12 bits each in two words), which the HOST folds in workgroup order — K4 has no ticket / last-block fold any more.
 constexpr int kLlSums = 96;   // >= 91 + 4
 constexpr int kLlEig = 32;    // 18 used
-constexpr int kLlRow = 12;    // 11 used: 6 component sums, then the 9 histogram counts in pairs (lo | hi << 32)
+constexpr int kLlRow = 8;     // 6 component sums, then the 9 histogram counts 12 bits each: 0..4 in word 6, 5..8 in word 7 (128 B = two cache lines per row)
 constexpr int kLocChunks = 4; // consecutive chunks of TPB points per K4 workgroup (plain factors): a quarter of K3's workgroups => a quarter of the rows (8: 14 us instead of 10, measured)
 __host__ __device__ inline size_t ll_slot_words(int loc_grid_cap) { return static_cast<size_t>(kLlSums + kLlEig) + static_cast<size_t>(loc_grid_cap) * kLlRow; }
 
@@ -59,6 +59,7 @@ struct IcpArgs
   int use_huber;
   double R[9], t[3];  // delta pose  T_tgt^-1 * T_src
   double da_thresh, max_d2, plane_valid, sigma, huber;
+  double inv_sigma;  // 1 / sigma, divided on the host: the kernel whitens by multiplication
   double * q_da;
   double * mean;
   double * normal;
@@ -134,6 +135,7 @@ struct LocArgs
   unsigned int side = 0;
   int srv_blocks = 0;                // component server: workgroups this call's K4 would have had (= rows the host folds)
   int srv_class = 0;                 // ... and the class of its K3 launch (256 / 512 threads): chunks per workgroup
+  unsigned long long * dbg = nullptr;  // MH_TIMELINE diagnostic build only, else null: per-wave stamps of this pass (16 words per wave)
 };
 
 // The component server: ONE long-running kernel on the context's side stream does the K4 work of every pipelined call.

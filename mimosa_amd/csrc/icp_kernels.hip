@@ -157,6 +157,53 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
   return v;
 }
 
+// The same for a double: each step moves the two halves by DPP and adds in fp64 (lanes a step does not write add +0.0).  The
+// order of the additions is fixed by the lane pattern: deterministic.  (Six __shfl_xor rounds on doubles are 12 ds_bpermute
+// each — the LDS pipeline of the CU, shared by its waves: 2.1 us for K4's six sums, round 4.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_pull_f64(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// Six doubles / three words at once, step by step: six (three) independent chains for the scheduler to interleave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_step6_f64(double (&v)[6])
+{
+  double t[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) t[j] = dpp_pull_f64<CTRL, ROW_MASK>(v[j]);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) v[j] += t[j];
+}
+__device__ __forceinline__ void wave_sum6_f64_to_lane63(double (&v)[6])
+{
+  dpp_step6_f64<0xB1, 0xF>(v);
+  dpp_step6_f64<0x4E, 0xF>(v);
+  dpp_step6_f64<0x141, 0xF>(v);
+  dpp_step6_f64<0x140, 0xF>(v);
+  dpp_step6_f64<0x142, 0xA>(v);
+  dpp_step6_f64<0x143, 0xC>(v);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_step3_u32(uint32_t (&v)[3])
+{
+  uint32_t t[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) t[j] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v[j]), CTRL, ROW_MASK, 0xF, false));
+#pragma unroll
+  for (int j = 0; j < 3; ++j) v[j] += t[j];
+}
+__device__ __forceinline__ void wave_sum3_to_lane63(uint32_t (&v)[3])
+{
+  dpp_step3_u32<0xB1, 0xF>(v);
+  dpp_step3_u32<0x4E, 0xF>(v);
+  dpp_step3_u32<0x141, 0xF>(v);
+  dpp_step3_u32<0x140, 0xF>(v);
+  dpp_step3_u32<0x142, 0xA>(v);
+  dpp_step3_u32<0x143, 0xC>(v);
+}
 // Broadcast of one lane's value to the wave (l must be wave-uniform): v_readlane_b32 -> SGPR.
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, int l)
 {
@@ -178,6 +225,16 @@ __device__ __forceinline__ double lane_get(double v, int l)
   } while (0)
 #else
 #define MH_STAMP(ptr, i) do { } while (0)
+#endif
+// K4's waves: indexed by the factor's workgroup index (the component server runs several virtual workgroups per real one)
+#ifdef MH_TIMELINE
+#define MH_STAMP4(ptr, i)                                                                                          \
+  do {                                                                                                             \
+    if ((ptr) && (threadIdx.x & 63) == 0)                                                                          \
+      (ptr)[(static_cast<size_t>(block_id) * NW + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define MH_STAMP4(ptr, i) do { } while (0)
 #endif
 #ifdef MH_BALANCE  // slots 13-15 carry the lane-balance counters instead of the C2 sub-phase stamps
 #define MH_STAMP_C2(ptr, i) do { } while (0)
@@ -448,16 +505,29 @@ __host__ __device__ constexpr int share_words(int tpb) { return MH_SHARE ? kShar
 // budget) exceeds the exact k-th distance no non-survivor can belong to the answer; otherwise the wave re-runs
 // KnnResult::push for that lane over the scanned voxels (counted in n_exact_fallback).  Either way the selection is
 // bit-identical to the reference.
-template <int K, int NOFF, bool SHARE = false>
+// FAST (K3's k = 5 instantiation): the caller wants the k nearest POINTS, not their order — the exact tier ranks the survivors by
+// counting (28 independent comparisons of (distance, traversal rank) instead of 8 dependent insertions) and hands back the
+// survivors' coordinates with a membership mask: no sorted index list, no second load of the chosen points.  The SET is the
+// one KnnResult::push selects (same strict order, ties by traversal rank), dk the same k-th distance.
+template <int KK>
+struct KnnPoints
+{
+  float4 pt[KK];    // the survivors of the coarse tier (w unused)
+  uint32_t member;  // bit u: pt[u] is one of the k nearest
+};
+constexpr int knn_survivors(int K) { return K + 3 + (K > 5 ? 1 : 0); }  // 8 for k = 5, 12 for the generic k <= 8 path
+template <int K, int NOFF, bool SHARE = false, bool FAST = false>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
-                                              unsigned long long * dbg = nullptr, uint32_t * share = nullptr)
+                                              unsigned long long * dbg = nullptr, uint32_t * share = nullptr,
+                                              KnnPoints<knn_survivors(K)> * fast = nullptr)
 {
   (void)dbg;
   (void)share;
+  (void)fast;
   fell_back = false;
-  constexpr int KK = K + 3 + (K > 5 ? 1 : 0);  // survivors: 8 for k = 5, 12 for the generic k <= 8 path
+  constexpr int KK = knn_survivors(K);
   constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
   // ---- A. neighbourhood lookup ------------------------------------------------------------------
   // Block tables carry a one-voxel halo (voxel_map.hpp): all 27 neighbours of the centre voxel are in
@@ -849,6 +919,37 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       sc[u] = map.buckets[sidx[u]];
       srank[u] = (scan_lut[4 * b + 3] << 5) | (p & 31u);  // (traversal rank of the voxel, slot): the order push() sees
     }
+    if constexpr (FAST) {
+      // rank by counting: survivor u's position in the order (distance, traversal rank) = the number of survivors before it.
+      // An empty slot carries the largest double: it sorts behind every candidate, so no validity mask enters the comparisons.
+      double d[KK];
+      uint32_t rk[KK];
+#pragma unroll
+      for (int u = 0; u < KK; ++u) {
+        const double du = sq_dist3(static_cast<double>(sc[u].x) - q0, static_cast<double>(sc[u].y) - q1, static_cast<double>(sc[u].z) - q2);
+        d[u] = ck[u] != 0xFFFFFFFFu ? du : kDblMax;
+        rk[u] = 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int v = u + 1; v < KK; ++v) {
+          const bool lt = d[u] < d[v] || (d[u] == d[v] && srank[u] < srank[v]);  // u before v
+          rk[v] += lt ? 1u : 0u;
+          rk[u] += lt ? 0u : 1u;
+        }
+      uint32_t member = 0u;
+      double dkf = kDblMax;
+#pragma unroll
+      for (int u = 0; u < KK; ++u) {
+        const bool valid = ck[u] != 0xFFFFFFFFu;
+        member |= (valid && rk[u] < static_cast<uint32_t>(k)) ? (1u << u) : 0u;
+        dkf = (valid && rk[u] == static_cast<uint32_t>(k - 1)) ? d[u] : dkf;  // exists iff >= k candidates were found
+        fast->pt[u] = sc[u];
+      }
+      fast->member = member;
+      bd[K - 1] = dkf;  // (read back below as the k-th distance: K == k in this instantiation)
+    } else {
 #pragma unroll
     for (int u = 0; u < KK; ++u) {
       const uint32_t p = srank[u];
@@ -873,6 +974,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
           }
         }
       }
+    }
     }
   }
   MH_STAMP(dbg, 12);
@@ -975,6 +1077,16 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
         bi[i] = ei[i];
         if (i == k - 1) dk = ed[i];
       }
+      if constexpr (FAST) {  // this lane's points come from the exact pass: the first k slots of the hand-over
+        uint32_t member = 0u;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          if (i < k && ei[i] != 0xFFFFFFFFu) {
+            fast->pt[i] = map.buckets[ei[i]];
+            member |= 1u << i;
+          }
+        fast->member = member;
+      }
     }
   }
 #pragma unroll
@@ -1006,7 +1118,7 @@ __device__ __forceinline__ void null_vector3(const double a00, const double a01,
     nn = n2;
   }
   if (nn > 0.0) {
-    const double inv = 1.0 / sqrt(nn);
+    const double inv = mh_rsqrt(nn);
     v[0] = vx * inv;
     v[1] = vy * inv;
     v[2] = vz * inv;
@@ -1039,7 +1151,7 @@ __device__ __forceinline__ void plane_eigen(const double a00, const double a01, 
     const double p = ((x - c2) * x + c1) * x - c0;
     const double dp = (3.0 * x - 2.0 * c2) * x + c1;
     if (!(dp > 0.0)) break;
-    const double step = p / dp;
+    const double step = p * mh_rcp1(dp);  // (a Newton step need not be divided exactly: the fixed point is p(x) = 0 either way)
     x -= step;
     if (fabs(step) <= 1e-16 * fabs(x)) break;
   }
@@ -1063,7 +1175,7 @@ __device__ __forceinline__ void plane_eigen(const double a00, const double a01, 
         const double p = ((x - c2) * x + c1) * x - c0;
         const double dp = (3.0 * x - 2.0 * c2) * x + c1;
         if (!(dp > 0.0)) break;
-        const double step = p / dp;
+        const double step = p * mh_rcp1(dp);
         if (!(fabs(step) < 0.75 * prev)) break;  // steps halve while the pair is unresolved, then collapse; noise does neither
         x -= step;
         prev = fabs(step);
@@ -1215,19 +1327,16 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   __builtin_amdgcn_s_setprio(MH_K3_PRIO);
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
-  constexpr int SEGS = TPB / NENT;         // 18 / 5 point segments reduced in parallel
-  constexpr int PPS = (TPB + SEGS - 1) / SEGS;
   constexpr int EW = BINARY ? 96 : 32;
-  constexpr int ROWW = NV + 1;                  // +1 pad: rows land on distinct LDS banks
-  // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [reduce] rows, segment sums.
+  constexpr int ROWW = NV;                      // 7 / 13 doubles: an odd row stride spreads the lanes' rows over the LDS banks
+  // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [last block] fold scratch.  The waves' row tiles and partial
+  // sums (step 8) have memory of their own: a wave reduces its rows while the others are still in the k-NN arena.
   constexpr int kListWords = NOFF * TPB;
-  constexpr int kTileRows = SEGS * PPS;          // >= TPB; rows past the block's points are zero
-  constexpr int kRowWords = kTileRows * ROWW * 2;
-  constexpr int kSegWords = SEGS * NENT * 2;
   constexpr int kFoldWords = (TPB / EW) * EW * 2 + EW * 2;
-  constexpr int kReduceWords = kRowWords + (kSegWords > kFoldWords ? kSegWords : kFoldWords);
-  constexpr int kArenaWords = kListWords > kReduceWords ? kListWords : kReduceWords;
+  constexpr int kArenaWords = kListWords > kFoldWords ? kListWords : kFoldWords;
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
+  __shared__ double s_tile[TPB * ROWW];                               // [wave][64 rows][ROWW]
+  __shared__ double s_wsum[(TPB / 64) * (NENT <= 32 ? 2 : 1) * NENT];  // [wave][point segment][entry]
   __shared__ unsigned int s_cnt[4];  // n_knn, n_cand, exact-fallback count, candidates actually scanned
   __shared__ uint32_t s_scan[kScanLutWords];
   __shared__ uint32_t s_share[share_words(TPB)];  // work sharing of the neighbour scan (knn_query)
@@ -1235,8 +1344,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   constexpr bool kShare = MH_SHARE && K == 5;  // the fast path's top-8; the generic k <= 8 path keeps 12 survivors
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
-  double * s_rows = reinterpret_cast<double *>(s_arena);                              // [TPB][ROWW]
-  double * s_aux = reinterpret_cast<double *>(s_arena + kRowWords);                   // segment sums / fold scratch
+  double * s_aux = reinterpret_cast<double *>(s_arena);                               // fold scratch of the last block
 
 #ifdef MH_INTERLEAVE
   // EXPERIMENT (tools/variant.sh): the waves of a workgroup take 64-point chunks that lie n_blocks / 8 chunks apart inside their
@@ -1261,6 +1369,12 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     if (a.srv_posted && block_id == 0 && threadIdx.x == 0)  // announce the call to the component server (LocServerArgs)
       __hip_atomic_store(a.srv_posted, a.srv_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // the lane's source point is requested before the scan table is filled (a load of its own) and the barrier behind it: one
+  // memory round trip less on every wave's chain
+  const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
+  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
+  float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qi < n_pts) sp = a.src[qi];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
   if constexpr (kShare) {
     if (threadIdx.x == 0) s_share[0] = 0u;
@@ -1291,10 +1405,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
 #pragma unroll
   for (int j = 0; j < NV; ++j) row[j] = 0.0;
 
-  const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
-  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : a.n;
   if (qi < n_pts) {
-    const float4 sp = a.src[qi];
     const double px = sp.x, py = sp.y, pz = sp.z;
     // 1. q = R p + t (geometric_factor.hpp:276-277)
     const double q0 = (a.R[0] * px + (a.R[1] * py + a.R[2] * pz)) + a.t[0];
@@ -1328,7 +1439,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       }
     }
     const double ddx = q0 - qd0, ddy = q1 - qd1, ddz = q2 - qd2;
-    const bool update = !gone && sqrt(ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh;
+    // (q - q_da).norm() > threshold (:281), compared as squares: both sides are non-negative
+    const bool update = !gone && (ddx * ddx + (ddy * ddy + ddz * ddz)) > a.da_thresh * a.da_thresh;
 
     double mean[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
     bool go = false;
@@ -1342,7 +1454,11 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       double dk;
       bool fell_back;
       uint32_t n_scanned;
-      const uint32_t n_cand = knn_query<K, NOFF, kShare>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share);
+      constexpr bool kFast = K == 5;  // k == K: the nearest points as a set (knn_query, FAST)
+      constexpr int KS = knn_survivors(K);
+      [[maybe_unused]] KnnPoints<KS> sel;
+      const uint32_t n_cand = knn_query<K, NOFF, kShare, kFast>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share,
+                                                                kFast ? &sel : nullptr);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
       did_fall = fell_back;
@@ -1352,40 +1468,55 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         st = MH_CORRES_MAX_DIST;
       } else {
         // 4. estimatePlane (:176-229)
-        double X[K][3];
+        constexpr int NX = kFast ? KS : K;  // FAST: the survivors of the coarse tier, the k nearest marked in sel.member (the others count as zero)
+        double X[NX][3];
         double sx = 0, sy = 0, sz = 0;
+        if constexpr (kFast) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          X[j][0] = X[j][1] = X[j][2] = 0.0;
-          if (j < k) {
-            const float4 c = a.map.buckets[bi[j]];
-            X[j][0] = c.x;
-            X[j][1] = c.y;
-            X[j][2] = c.z;
+          for (int j = 0; j < NX; ++j) {
+            const bool m = (sel.member >> j) & 1u;
+            X[j][0] = m ? static_cast<double>(sel.pt[j].x) : 0.0;
+            X[j][1] = m ? static_cast<double>(sel.pt[j].y) : 0.0;
+            X[j][2] = m ? static_cast<double>(sel.pt[j].z) : 0.0;
             sx += X[j][0];
             sy += X[j][1];
             sz += X[j][2];
           }
+        } else {
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            X[j][0] = X[j][1] = X[j][2] = 0.0;
+            if (j < k) {
+              const float4 c = a.map.buckets[bi[j]];
+              X[j][0] = c.x;
+              X[j][1] = c.y;
+              X[j][2] = c.z;
+              sx += X[j][0];
+              sy += X[j][1];
+              sz += X[j][2];
+            }
+          }
         }
         MH_STAMP_C2(a.dbg, 13);
         const double kd = static_cast<double>(k);
-        mean[0] = sx / kd;
-        mean[1] = sy / kd;
-        mean[2] = sz / kd;
+        const double ikd = 1.0 / kd;  // (a compile-time constant in the k = 5 instantiation)
+        mean[0] = sx * ikd;
+        mean[1] = sy * ikd;
+        mean[2] = sz * ikd;
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          if (j < k) {
-            X[j][0] -= mean[0];
-            X[j][1] -= mean[1];
-            X[j][2] -= mean[2];
-            c00 += X[j][0] * X[j][0];
-            c01 += X[j][0] * X[j][1];
-            c02 += X[j][0] * X[j][2];
-            c11 += X[j][1] * X[j][1];
-            c12 += X[j][1] * X[j][2];
-            c22 += X[j][2] * X[j][2];
-          }
+        for (int j = 0; j < NX; ++j) {
+          const bool m = kFast ? (((sel.member >> j) & 1u) != 0u) : (j < k);
+          // a point that is not one of the k nearest stays at zero: it adds nothing to the covariance and passes the plane gate
+          X[j][0] = m ? X[j][0] - mean[0] : 0.0;
+          X[j][1] = m ? X[j][1] - mean[1] : 0.0;
+          X[j][2] = m ? X[j][2] - mean[2] : 0.0;
+          c00 += X[j][0] * X[j][0];
+          c01 += X[j][0] * X[j][1];
+          c02 += X[j][0] * X[j][2];
+          c11 += X[j][1] * X[j][1];
+          c12 += X[j][1] * X[j][2];
+          c22 += X[j][2] * X[j][2];
         }
         const double ikm1 = 1.0 / (kd - 1.0);
         // the mean is cached before the gates (:191)
@@ -1428,8 +1559,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
           a.normal[3 * qi + 2] = nrm[2];
           bool plane_ok = true;
 #pragma unroll
-          for (int j = 0; j < K; ++j) {
-            if (j < k) {
+          for (int j = 0; j < NX; ++j) {
+            if (kFast || j < k) {
               const double dj = X[j][0] * nrm[0] + (X[j][1] * nrm[1] + X[j][2] * nrm[2]);
               if (fabs(dj) > a.plane_valid) plane_ok = false;
             }
@@ -1469,17 +1600,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       // 5. residual + max-error gate (:319-328)
       double e = nrm[0] * (mean[0] - q0) + (nrm[1] * (mean[1] - q1) + nrm[2] * (mean[2] - q2));
       const double range = sqrt(px * px + (py * py + pz * pz));
-      const double s = 1.0 - 0.9 * fabs(e) / sqrt(range);
+      const double s = 1.0 - 0.9 * fabs(e) * mh_rsqrt(range);
       if (s < 0.9) {
         st = MH_MAX_ERROR;
       } else {
         // 6. Huber (:330-339)
         double sw = 1.0;
         if (a.use_huber) {
-          const double we = e / a.sigma;
-          if (fabs(we) > a.huber) sw = sqrt(a.huber / fabs(we));
+          const double we = e * a.inv_sigma;
+          if (fabs(we) > a.huber) sw = sqrt(mh_div(a.huber, fabs(we)));
         }
-        const double wgt = sw / a.sigma;
+        const double wgt = sw * a.inv_sigma;
         e *= wgt;
         // 7. Jacobian (:341-355): n_s = R^T n, J = [(n_s x p)^T, -n_s^T]
         const double ns0 = a.R[0] * nrm[0] + (a.R[3] * nrm[1] + a.R[6] * nrm[2]);
@@ -1529,9 +1660,76 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   }
 #endif
 
-  // 8. H += J^T J, b += J^T e, f += e^2 (:363-382) — LDS tile of rows (the k-NN arena is dead now),
-  //    then every thread owns one (entry, segment) pair of the upper triangle of sum v v^T.
+  // the call's record: what K4 reads of this point.  Side-stream calls write it through (K4 may run on another XCD, with no
+  // kernel boundary in between)
+  [[maybe_unused]] auto store_record = [&]() {
+    if constexpr (!SHARD) {
+      const size_t rn = static_cast<size_t>(a.rec_n);
+      int32_t * rst = reinterpret_cast<int32_t *>(a.rec + 6 * rn);
+      if (a.side) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          store_partial(&a.rec[static_cast<size_t>(c) * rn + qi], rec_jr[c]);
+          store_partial(&a.rec[static_cast<size_t>(3 + c) * rn + qi], rec_jt[c]);
+        }
+        __hip_atomic_store(&rst[qi], rec_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          a.rec[static_cast<size_t>(c) * rn + qi] = rec_jr[c];
+          a.rec[static_cast<size_t>(3 + c) * rn + qi] = rec_jt[c];
+        }
+        rst[qi] = rec_st;
+      }
+    }
+  };
+  // 8. H += J^T J, b += J^T e, f += e^2 (:363-382).  Every WAVE reduces its own 64 rows first, in its own time — a tile of rows in
+  //    LDS that only this wave touches (no workgroup barrier: the k-NN arena of the slower waves is still in use), every lane
+  //    owning one (entry, point-segment) of the upper triangle of sum v v^T — so that what is left behind the barrier, on the
+  //    critical path of the workgroup's slowest wave, is a sum of 8 (16) wave partials per entry.  (Rounds 1-4 built one tile per
+  //    workgroup behind the barrier: 4.8 k cycles = 2 us after the slowest wave of every workgroup.)
   MH_STAMP(a.dbg, 3);
+  {
+    constexpr int WSEG = NENT <= 32 ? 2 : 1;          // point segments per wave: lanes 0-31 / 32-63 (unary), all 64 points (binary)
+    constexpr int WPTS = 64 / WSEG;
+    const int lane = static_cast<int>(threadIdx.x & 63u), wv = static_cast<int>(threadIdx.x >> 6);
+    double * tile = s_tile + static_cast<size_t>(wv) * 64 * ROWW;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) tile[lane * ROWW + j] = row[j];
+    // the wave's own stores, then its own loads: ordered by the LDS queue; the fences keep the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int ROUNDS = (NENT * WSEG + 63) / 64;   // 1 (unary: 56 lanes busy), 2 (binary: 91 entries)
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int item = rd * 64 + lane;
+      const int ent = WSEG == 2 ? (lane & 31) : item, seg = WSEG == 2 ? (lane >> 5) : 0;
+      if (ent < NENT) {
+        int r = 0, rem = ent;  // ent -> (r, c), r <= c, row-major upper triangle
+        while (rem >= NV - r) {
+          rem -= NV - r;
+          ++r;
+        }
+        const int c = r + rem;
+        const double * pr = tile + seg * WPTS * ROWW;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent accumulators: a batch of LDS reads in flight together
+#pragma unroll
+        for (int p = 0; p < WPTS; p += 4) {
+          s0 += pr[(p + 0) * ROWW + r] * pr[(p + 0) * ROWW + c];
+          s1 += pr[(p + 1) * ROWW + r] * pr[(p + 1) * ROWW + c];
+          s2 += pr[(p + 2) * ROWW + r] * pr[(p + 2) * ROWW + c];
+          s3 += pr[(p + 3) * ROWW + r] * pr[(p + 3) * ROWW + c];
+        }
+        s_wsum[(wv * WSEG + seg) * NENT + ent] = (s0 + s1) + (s2 + s3);
+      }
+    }
+    // the call's record (what K4 reads of this point): a call whose pair of records nobody else can still be reading stores it
+    // here, in the wave's own time; one that may have to wait for an earlier call's K4 (k4_wait) stores it behind the check below
+    if constexpr (!SHARD) {
+      if (a.rec && !a.k4_wait && qi < a.n) store_record();
+    }
+  }
   if constexpr (!SHARD) {
     if (a.k4_wait && threadIdx.x < 64) {
       const bool all_ok = __all(static_cast<int>(k4_ok)) != 0;
@@ -1555,58 +1753,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       }
       __syncthreads();
     }
-    if (a.rec && qi < a.n) {
-      // the call's record: what K4 reads of this point.  Side-stream calls write it through (K4 may run on another XCD, with
-      // no kernel boundary in between)
-      const size_t rn = static_cast<size_t>(a.rec_n);
-      int32_t * rst = reinterpret_cast<int32_t *>(a.rec + 6 * rn);
-      if (a.side) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          store_partial(&a.rec[static_cast<size_t>(c) * rn + qi], rec_jr[c]);
-          store_partial(&a.rec[static_cast<size_t>(3 + c) * rn + qi], rec_jt[c]);
-        }
-        __hip_atomic_store(&rst[qi], rec_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          a.rec[static_cast<size_t>(c) * rn + qi] = rec_jr[c];
-          a.rec[static_cast<size_t>(3 + c) * rn + qi] = rec_jt[c];
-        }
-        rst[qi] = rec_st;
-      }
-    }
+    if (a.rec && a.k4_wait && qi < a.n) store_record();
   }
-#pragma unroll
-  for (int j = 0; j < NV; ++j) s_rows[threadIdx.x * ROWW + j] = row[j];
-  if (static_cast<int>(threadIdx.x) < (kTileRows - TPB) * ROWW) s_rows[TPB * ROWW + threadIdx.x] = 0.0;
-  __syncthreads();
-  {
-    const int ent = threadIdx.x % NENT, seg = threadIdx.x / NENT;
-    if (seg < SEGS) {
-      int r = 0, rem = ent;  // ent -> (r, c), r <= c, row-major upper triangle
-      while (rem >= NV - r) {
-        rem -= NV - r;
-        ++r;
-      }
-      const int c = r + rem;
-      // fixed trip count (the tile is padded with zero rows) and four independent accumulators: the LDS reads
-      // of a whole batch are in flight together instead of one dependent read -> FMA per point
-      const double * pr = s_rows + seg * PPS * ROWW;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int p = 0; p + 3 < PPS; p += 4) {
-        s0 += pr[(p + 0) * ROWW + r] * pr[(p + 0) * ROWW + c];
-        s1 += pr[(p + 1) * ROWW + r] * pr[(p + 1) * ROWW + c];
-        s2 += pr[(p + 2) * ROWW + r] * pr[(p + 2) * ROWW + c];
-        s3 += pr[(p + 3) * ROWW + r] * pr[(p + 3) * ROWW + c];
-      }
-#pragma unroll
-      for (int p = PPS - PPS % 4; p < PPS; ++p) s0 += pr[p * ROWW + r] * pr[p * ROWW + c];
-      s_aux[seg * NENT + ent] = (s0 + s1) + (s2 + s3);
-    }
-  }
-  __syncthreads();
   // A plain factor whose K4 follows (a.tail == 0) ends here: the row is an ordinary store, K4's workgroups fold the rows
   // themselves after the kernel boundary — no write-through, no ticket, no last-block fold (3 us of serial tail with 255
   // CUs idle in round 3).  Otherwise (no K4 behind it, or a map-sharded factor, whose sums feed an all-reduce): rows
@@ -1614,9 +1762,13 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   const bool fold_here = SHARD || a.tail != 0;
   const bool through = fold_here || (!SHARD && a.side);
   if (threadIdx.x < NENT) {
+    constexpr int NPART = (TPB / 64) * (NENT <= 32 ? 2 : 1);  // wave partials per entry, summed in index order: deterministic
+    double pv[NPART];
+#pragma unroll
+    for (int g = 0; g < NPART; ++g) pv[g] = s_wsum[g * NENT + threadIdx.x];  // all requested before the first is used
     double s = 0.0;
 #pragma unroll
-    for (int g = 0; g < SEGS; ++g) s += s_aux[g * NENT + threadIdx.x];
+    for (int g = 0; g < NPART; ++g) s += pv[g];
     double * dst = &a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x];
     if (through)
       store_partial(dst, s);
@@ -1757,7 +1909,14 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
 // (512 - 2 x 168 = 176 registers per lane are what K3 leaves of a SIMD's file)
 #define MH_LOC_VGPRS __attribute__((amdgpu_waves_per_eu(3, 8)))  // at most 168 registers per lane
 __host__ __device__ constexpr int loc_tpb(int tpb, bool shard) { return (!shard && tpb > 256) ? 256 : tpb; }
-__host__ __device__ constexpr int loc_ch(int tpb, bool shard) { return shard ? 1 : (tpb > 256 ? 2 * kLocChunks : kLocChunks); }
+// A K4 workgroup of a plain factor takes kLocChunks chunks of 256 points whatever K3's class was: 1024 points, i.e. 4 of K3's
+// workgroups of the 256-thread class or MH_LOC_BLOCKS_512 = 2 of the 512-thread class (round 4 took 4 = 2048 points per workgroup:
+// 64 workgroups for 131 072 points, a quarter of the CUs, each lane holding 8 chunks' record entries — the projection phase
+// alone was 1.4 us; 128 workgroups halve it and the host folds 128 rows of two cache lines instead of 64 of three).
+#ifndef MH_LOC_BLOCKS_512
+#define MH_LOC_BLOCKS_512 2
+#endif
+__host__ __device__ constexpr int loc_ch(int tpb, bool shard) { return shard ? 1 : (tpb > 256 ? 2 * MH_LOC_BLOCKS_512 : kLocChunks); }
 
 template <int TPB, bool SHARD, int CH>
 __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
@@ -1768,8 +1927,9 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   __shared__ bool s_last;
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  MH_STAMP4(a.dbg, 0);
   double v[6] = {0, 0, 0, 0, 0, 0};
-  unsigned int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long hpack = 0ull;
   // The pass is a handful of memory round trips long and nothing else, so everything that does not depend on the eigenbases
   // happens BEFORE they are known: the status / point / normal of ALL of this workgroup's chunks are requested up front (one
   // round trip, in flight while the Hessian rows are folded), and the unwhitened Jacobian directions of the Valid points
@@ -1795,49 +1955,11 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
       __syncthreads();
     }
   }
-  int st_c[CH];
-  double jr_c[CH][3], jt_c[CH][3];
-  [[maybe_unused]] float4 sp_c[CH];
-  [[maybe_unused]] double nx_c[CH], ny_c[CH], nz_c[CH];
-  // (eight chunks per workgroup: the second half is requested further down)
-  constexpr int CH0 = CH > kLocChunks ? CH / 2 : CH;
-  auto load_chunk = [&](const int ch) {
-    const int i = (block_id * CH + ch) * TPB + static_cast<int>(threadIdx.x);
-    const int i_ld = i < n_pts ? i : 0;
-    if constexpr (SHARD) {
-      st_c[ch] = n_pts > 0 ? a.status[i_ld] : -1;
-      sp_c[ch] = n_pts > 0 ? a.src[i_ld] : make_float4(0.f, 0.f, 0.f, 0.f);
-      nx_c[ch] = n_pts > 0 ? a.normal[3 * i_ld] : 0.0;
-      ny_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 1] : 0.0;
-      nz_c[ch] = n_pts > 0 ? a.normal[3 * i_ld + 2] : 0.0;
-    } else {
-      // plain factor: the call's record (K3 wrote the directions, zero unless Valid, and the status)
-      const size_t rn = static_cast<size_t>(a.rec_n);
-      const int32_t * rst = reinterpret_cast<const int32_t *>(a.rec + 6 * rn);
-      if (side) {  // written through by a kernel that may still be running on other XCDs: loads that see memory
-        st_c[ch] = n_pts > 0 ? __hip_atomic_load(&rst[i_ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          jr_c[ch][c] = n_pts > 0 ? load_partial(&a.rec[static_cast<size_t>(c) * rn + i_ld]) : 0.0;
-          jt_c[ch][c] = n_pts > 0 ? load_partial(&a.rec[static_cast<size_t>(3 + c) * rn + i_ld]) : 0.0;
-        }
-      } else {
-        st_c[ch] = n_pts > 0 ? rst[i_ld] : -1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          jr_c[ch][c] = n_pts > 0 ? a.rec[static_cast<size_t>(c) * rn + i_ld] : 0.0;
-          jt_c[ch][c] = n_pts > 0 ? a.rec[static_cast<size_t>(3 + c) * rn + i_ld] : 0.0;
-        }
-      }
-    }
-    if (i >= n_pts) st_c[ch] = -1;
-  };
-#pragma unroll
-  for (int ch = 0; ch < CH0; ++ch) load_chunk(ch);
-  // The Hessian sums the eigenbases come from.  Plain factor: K3 ended at its per-workgroup rows; EVERY workgroup of this
-  // kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed order of the old last-block
-  // fold — so every workgroup holds the same bits), workgroup 0 also publishes them.  Map-sharded factor: the all-reduced
-  // (global) sums are given.
+  // The Hessian sums the eigenbases come from — requested FIRST: the fold, the decompositions and everything behind them wait
+  // for these rows, the record entries further down only for the projections.  Plain factor: K3 ended at its per-workgroup
+  // rows; EVERY workgroup of this kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed
+  // order of the old last-block fold — so every workgroup holds the same bits), workgroup 0 also publishes them.
+  // Map-sharded factor: the all-reduced (global) sums are given.
   const double * sums = nullptr;
   double * s_h = s_seg + TPB;  // folded sums + counters (plain factors)
   if constexpr (SHARD) {
@@ -1858,6 +1980,54 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     }
     sums = s_h;
   }
+  MH_STAMP4(a.dbg, 1);
+  // The record entries (plain) / status, point and normal (map-sharded) of ALL of this workgroup's chunks: one round trip, in
+  // flight while two lanes of the workgroup decompose H_rr and H_tt.  One uniform branch around each chunk's loads (a select
+  // per loaded value made the compiler branch around every single load).
+  int st_c[CH];
+  double jr_c[CH][3], jt_c[CH][3];
+  [[maybe_unused]] float4 sp_c[CH];
+  [[maybe_unused]] double nx_c[CH], ny_c[CH], nz_c[CH];
+  auto load_chunk = [&](const int ch) {
+    const int i = (block_id * CH + ch) * TPB + static_cast<int>(threadIdx.x);
+    const int i_ld = i < n_pts ? i : 0;
+    st_c[ch] = -1;
+    jr_c[ch][0] = jr_c[ch][1] = jr_c[ch][2] = jt_c[ch][0] = jt_c[ch][1] = jt_c[ch][2] = 0.0;
+    if constexpr (SHARD) {
+      sp_c[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+      nx_c[ch] = ny_c[ch] = nz_c[ch] = 0.0;
+      if (n_pts > 0) {
+        st_c[ch] = a.status[i_ld];
+        sp_c[ch] = a.src[i_ld];
+        nx_c[ch] = a.normal[3 * i_ld];
+        ny_c[ch] = a.normal[3 * i_ld + 1];
+        nz_c[ch] = a.normal[3 * i_ld + 2];
+      }
+    } else if (n_pts > 0) {
+      // plain factor: the call's record (K3 wrote the directions, zero unless Valid, and the status)
+      const size_t rn = static_cast<size_t>(a.rec_n);
+      const int32_t * rst = reinterpret_cast<const int32_t *>(a.rec + 6 * rn);
+      if (side) {  // written through by a kernel that may still be running on other XCDs: loads that see memory
+        st_c[ch] = __hip_atomic_load(&rst[i_ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          jr_c[ch][c] = load_partial(&a.rec[static_cast<size_t>(c) * rn + i_ld]);
+          jt_c[ch][c] = load_partial(&a.rec[static_cast<size_t>(3 + c) * rn + i_ld]);
+        }
+      } else {
+        st_c[ch] = rst[i_ld];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          jr_c[ch][c] = a.rec[static_cast<size_t>(c) * rn + i_ld];
+          jt_c[ch][c] = a.rec[static_cast<size_t>(3 + c) * rn + i_ld];
+        }
+      }
+    }
+    if (i >= n_pts) st_c[ch] = -1;
+  };
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) load_chunk(ch);
+  MH_STAMP4(a.dbg, 2);
   // The two eigenbases: given (two-phase callers), or derived here — one lane per 3 x 3 block (computeLocalizability,
   // utils.hpp:308-313), every workgroup for itself, on the LAST two waves (the others go on to their points).
   __shared__ double s_E[18];
@@ -1875,10 +2045,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     compute_localizability(Hb, loc, E);
     for (int q = 0; q < 9; ++q) s_E[(o ? 9 : 0) + q] = E[q];
   }
-  // second half of the records (CH0 above): behind the eigen-decompositions in program order, so that their registers are
-  // not live inside them — the waves that decompose nothing get here at once, and their round trip hides behind the two that do
-#pragma unroll
-  for (int ch = CH0; ch < CH; ++ch) load_chunk(ch);
+  MH_STAMP4(a.dbg, 3);
   // Jacobian directions of this thread's points (independent of the eigenbases): map-sharded / two-phase callers work them
   // out here from the stored normals, plain factors loaded them above
   if constexpr (SHARD) {
@@ -1887,7 +2054,9 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
       loc_directions(a, nx_c[ch], ny_c[ch], nz_c[ch], static_cast<double>(sp_c[ch].x), static_cast<double>(sp_c[ch].y),
                      static_cast<double>(sp_c[ch].z), jr_c[ch], jt_c[ch]);
   }
+  MH_STAMP4(a.dbg, 4);
   __syncthreads();
+  MH_STAMP4(a.dbg, 5);
   double er[9], et[9];
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -1906,20 +2075,35 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
         v[3 + c] += rc >= 0.5 ? rc : 0.0;  // rot components
       }
     }
-#pragma unroll
-    for (int h = 0; h < 9; ++h) hist[h] += static_cast<unsigned int>(__popcll(__ballot(st == h)));
+    // status histogram (src/lidar/geometric.cpp:280-323): this lane's counts, 4 bits per status (<= 8 chunks per lane)
+    hpack += st >= 0 && st < 9 ? (1ull << (4 * st)) : 0ull;
   }
+  MH_STAMP4(a.dbg, 6);
+  // wave sums by DPP (wave_sum_f64_to_lane63); the nine counts travel three to a 32-bit word (<= 64 lanes x 8 chunks = 512 each)
+  // (all nine reductions in straight-line code, stores afterwards: a store under `lane == 63` between two of them is a branch
+  // the scheduler does not interleave across, and each reduction alone is six dependent steps on an otherwise idle SIMD)
+  wave_sum6_f64_to_lane63(v);
+  uint32_t hw[3];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double s = v[j];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) s_w[wv][j] = s;
+  for (int g = 0; g < 3; ++g) {
+    const uint32_t f0 = static_cast<uint32_t>(hpack >> (12 * g)) & 15u, f1 = static_cast<uint32_t>(hpack >> (12 * g + 4)) & 15u,
+                   f2 = static_cast<uint32_t>(hpack >> (12 * g + 8)) & 15u;
+    hw[g] = f0 | (f1 << 10) | (f2 << 20);
   }
+  wave_sum3_to_lane63(hw);
+  if (lane == 63) {
 #pragma unroll
-  for (int h = 0; h < 9; ++h)
-    if (lane == 0) s_w[wv][6 + h] = static_cast<double>(hist[h]);
+    for (int j = 0; j < 6; ++j) s_w[wv][j] = v[j];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      s_w[wv][6 + 3 * g + 0] = static_cast<double>(hw[g] & 1023u);
+      s_w[wv][6 + 3 * g + 1] = static_cast<double>((hw[g] >> 10) & 1023u);
+      s_w[wv][6 + 3 * g + 2] = static_cast<double>((hw[g] >> 20) & 1023u);
+    }
+  }
+  MH_STAMP4(a.dbg, 7);
   __syncthreads();
+  MH_STAMP4(a.dbg, 8);
   if constexpr (!SHARD) {
     // The workgroup's row of 15 goes to the host as flagged words and the HOST folds the rows (in workgroup order:
     // deterministic) — no partial-row store, ticket, fold or completion flag on the device.  Workgroup 0 adds what every
@@ -1929,14 +2113,15 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
       double s = 0.0;
       for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
       ll_store(ll_rows + threadIdx.x, s, a.seq);
-    } else if (threadIdx.x < 11) {  // histogram counts 2 (t - 6), 2 (t - 6) + 1 in one word
-      const int h0 = 2 * (static_cast<int>(threadIdx.x) - 6);
-      unsigned int c0 = 0u, c1 = 0u;
-      for (int w2 = 0; w2 < NW; ++w2) {
-        c0 += static_cast<unsigned int>(s_w[w2][6 + h0]);
-        if (h0 + 1 < 9) c1 += static_cast<unsigned int>(s_w[w2][6 + h0 + 1]);
+    } else if (threadIdx.x < 8) {  // histogram: counts 0..4 / 5..8, 12 bits each (a workgroup covers <= 2048 points), in one word
+      const int h0 = threadIdx.x == 6 ? 0 : 5, hn = threadIdx.x == 6 ? 5 : 4;
+      unsigned long long pk = 0ull;
+      for (int h = 0; h < hn; ++h) {
+        unsigned int c = 0u;
+        for (int w2 = 0; w2 < NW; ++w2) c += static_cast<unsigned int>(s_w[w2][6 + h0 + h]);
+        pk |= static_cast<unsigned long long>(c) << (12 * h);
       }
-      ll_rows[threadIdx.x] = make_uint4(c0, a.seq, c1, a.seq);
+      ll_rows[threadIdx.x] = make_uint4(static_cast<unsigned int>(pk), a.seq, static_cast<unsigned int>(pk >> 32), a.seq);
     }
     if (block_id == 0) {
       const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
@@ -1945,6 +2130,10 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     }
     (void)n_blocks;
     (void)s_last;
+#ifdef MH_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flagged words have left (acknowledged) by this stamp
+#endif
+    MH_STAMP4(a.dbg, 9);
     if (side && threadIdx.x == 0) __hip_atomic_store(&a.sig4[block_id], a.side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every value read was used before the barrier above
     return;
   } else {
@@ -1982,12 +2171,12 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
 }
 
 template <int TPB, bool SHARD>  // TPB: the class of the K3 launch (256 / 512 threads); this kernel runs loc_tpb(TPB, SHARD) threads
-__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) MH_LOC_VGPRS void icp_localizability_kernel(const LocArgs a)
+__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) void icp_localizability_kernel(const LocArgs a)
 {
   icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD)>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 template <int TPB>
-__global__ __launch_bounds__(loc_tpb(TPB, false)) MH_LOC_VGPRS void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
+__global__ __launch_bounds__(loc_tpb(TPB, false)) void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
 {
   const int b = static_cast<int>(blockIdx.x);
   const int f = batch_factor_of(start, n_factors, b);
@@ -1997,7 +2186,7 @@ __global__ __launch_bounds__(loc_tpb(TPB, false)) MH_LOC_VGPRS void icp_localiza
 }
 
 template <int TPB, bool SHARD>
-__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) MH_LOC_VGPRS void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
+__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) void icp_localizability_batch_inline_kernel(const BatchInline<LocArgs> blk)
 {
   (void)blk;
   const auto * p = (const BatchInline<LocArgs> *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2048,10 +2237,14 @@ __global__ __launch_bounds__(256) MH_LOC_VGPRS void icp_localizability_server_ke
     if (cmd == 2) break;
     const LocArgs a = load_uniform(&s.ring[j % static_cast<unsigned int>(s.ring_n)].a);
     for (int vb = static_cast<int>(blockIdx.x); vb < a.srv_blocks; vb += static_cast<int>(gridDim.x)) {
-      if (a.srv_class > 256)
-        icp_localizability_body<256, false, loc_ch(kThreads, false)>(a, vb, a.srv_blocks);
-      else
-        icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);
+      if constexpr (loc_ch(kThreads, false) == loc_ch(256, false)) {
+        icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);  // 1024 points per workgroup in either class
+      } else {
+        if (a.srv_class > 256)
+          icp_localizability_body<256, false, loc_ch(kThreads, false)>(a, vb, a.srv_blocks);
+        else
+          icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);
+      }
       __syncthreads();
     }
   }
@@ -2124,8 +2317,12 @@ int linearize_grid(int n)
 // K4's workgroups take kLocChunks consecutive chunks of a plain factor (the kernel's time does not depend on it — launch +
 // round trips — but the host folds a quarter of the rows), one chunk each of a map-sharded factor (its rows are folded on
 // the device as before).
-static int loc_chunks(bool shard) { return shard ? 1 : kLocChunks; }
-int localizability_grid(int n, bool shard) { return (linearize_grid(n) + loc_chunks(shard) - 1) / loc_chunks(shard); }
+static int loc_chunks(bool shard, int tpb) { return shard ? 1 : (tpb > 256 ? MH_LOC_BLOCKS_512 : kLocChunks); }  // in K3 workgroups
+int localizability_grid(int n, bool shard)
+{
+  const int c = loc_chunks(shard, linearize_tpb(n));
+  return (linearize_grid(n) + c - 1) / c;
+}
 
 template <int NOFF, int TPB, bool SHARD>
 static void launch_linearize_nt(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -2185,7 +2382,7 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
   const bool shard = a.n_dev != nullptr;
-  a.chunks_per_block = loc_chunks(shard);
+  a.chunks_per_block = loc_chunks(shard, linearize_tpb(a.n));
   const dim3 grid(localizability_grid(a.n, shard));
   if (linearize_tpb(a.n) == 256) {
     if (shard)
@@ -2204,7 +2401,7 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 // ---- batched launches: all factors share (k == 5 or not, binary, neighbour mode, TPB) ------------------------
 int batch_tpb(int max_n) { return linearize_tpb(max_n); }
 int batch_grid(int n, int tpb) { return (((n + tpb - 1) / tpb) + 7) & ~7; }
-int batch_loc_grid(int n, int tpb, bool shard) { return (batch_grid(n, tpb) + loc_chunks(shard) - 1) / loc_chunks(shard); }
+int batch_loc_grid(int n, int tpb, bool shard) { return (batch_grid(n, tpb) + loc_chunks(shard, tpb) - 1) / loc_chunks(shard, tpb); }
 
 template <int NOFF, int TPB>
 static void launch_linearize_batch_nt(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int k,

@@ -24,6 +24,44 @@ MH_HD double mh_rsqrt(double x)
 #endif
 }
 
+// Reciprocal without the IEEE division sequence (v_div_scale x 2, v_rcp_f64, 5 fma, v_div_fmas, v_div_fixup: ~11 dependent
+// instructions): the hardware estimate (v_rcp_f64, ~2^-23 relative) and Newton refinements y <- y + y (1 - x y), each of which
+// squares the error.  mh_rcp: two steps, <= 1 ulp-ish (2^-52 relative) for normal x; mh_rcp1: one step (~2^-46), for the
+// self-correcting Newton iterations of the eigen solvers, whose fixed point does not depend on how accurately the step is
+// divided.  x must be a normal, non-zero number (no scaling for denormal / huge operands: callers test for that).  On the
+// host these are plain divisions.
+MH_HD double mh_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+MH_HD double mh_rcp1(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, y, 1.0), y, y);
+#else
+  return 1.0 / x;
+#endif
+}
+// a / b to the last bit or two: the refined reciprocal, then one residual correction of the quotient
+MH_HD double mh_div(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = mh_rcp(b);
+  const double q = a * y;
+  return fma(fma(-b, q, a), y, q);
+#else
+  return a / b;
+#endif
+}
+
 // Symmetric 3x3 eigen-decomposition, cyclic Jacobi in fp64.  A row-major (only the upper triangle
 // is read); on return w[0] <= w[1] <= w[2] and V (row-major) holds the eigenvectors in COLUMNS.
 // Branch-light and register-resident: every lane runs the same fixed sweep schedule, rotations
@@ -106,16 +144,16 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
   const double mx = fmax(fmax(fabs(a00), fabs(a11)), fmax(fmax(fabs(a22), fabs(a01)), fmax(fabs(a02), fabs(a12))));
   bool ok = mx > 0.0 && mx < 1e300;
   if (ok) {
-    const double inv = 1.0 / mx;
+    const double inv = mh_rcp(mx);
     const double b00 = a00 * inv, b01 = a01 * inv, b02 = a02 * inv, b11 = a11 * inv, b12 = a12 * inv, b22 = a22 * inv;
     const double norm = b01 * b01 + b02 * b02 + b12 * b12;
-    const double q = (b00 + b11 + b22) / 3.0;
+    const double q = (b00 + b11 + b22) * (1.0 / 3.0);
     const double c00 = b00 - q, c11 = b11 - q, c22 = b22 - q;
-    const double p = sqrt((c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * norm) / 6.0);
+    const double p = sqrt((c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * norm) * (1.0 / 6.0));
     ok = p > 1e-8;  // (nearly) a multiple of the identity: let the sweeps decide
     double e0 = 0, e1 = 0, e2 = 0;
     if (ok) {
-      const double ip = 1.0 / p;
+      const double ip = mh_rcp(p);
       const double d00 = c00 * ip, d01 = b01 * ip, d02 = b02 * ip, d11 = c11 * ip, d12 = b12 * ip, d22 = c22 * ip;
       double half_det = 0.5 * (d00 * (d11 * d22 - d12 * d12) - d01 * (d01 * d22 - d12 * d02) + d02 * (d01 * d12 - d11 * d02));
       half_det = fmin(fmax(half_det, -1.0), 1.0);
@@ -127,12 +165,16 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
       // overshoot, g' >= 6, the root is simple for every half_det, and the error goes 0.27 -> 5e-2 -> 2e-3 -> 2e-6 -> 2e-12
       // -> round-off: six steps.  The other two from the deflated quadratic x^2 + r x + (r^2 - 3).  (Accuracy does not rest
       // on this: Rayleigh step + residual check below, Jacobi sweeps as the fallback.)
+      // Round 5: started on the chord sqrt 3 + (2 - sqrt 3) |half_det| instead (the root is 2 cos(acos(|half_det|) / 3): within
+      // 0.014 of the chord, below it; the first step lands above the root, the rest descend): 1.4e-2 -> 1.5e-4 -> 2e-8 -> round-off,
+      // four steps instead of six — every step is eight dependent fp64 operations on a single lane with the workgroup waiting.
       const double dd = 2.0 * half_det;
-      double br = half_det >= 0.0 ? 2.0 : -2.0;
+      double br = 1.7320508075688772 + 0.2679491924311228 * fabs(half_det);
+      br = half_det >= 0.0 ? br : -br;
 #pragma unroll
-      for (int it = 0; it < 6; ++it) {
+      for (int it = 0; it < 4; ++it) {
         const double b2 = br * br;
-        br -= ((b2 - 3.0) * br - dd) / (3.0 * b2 - 3.0);
+        br -= ((b2 - 3.0) * br - dd) * mh_rcp1(3.0 * b2 - 3.0);  // (g' >= 6 on the iterates: a plain reciprocal)
       }
       const double sq = sqrt(fmax(12.0 - 3.0 * br * br, 0.0));
       const double blo = 0.5 * (-br - sq), bhi = 0.5 * (-br + sq);
@@ -173,19 +215,33 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
         double cu, cw;  // v = cu U + cw W in the null space of [[m00, m01], [m01, m11]]
         if (am00 >= am11) {
           if (fmax(am00, am01) > 0.0) {
-            if (am00 >= am01) { const double t = m01 / m00; const double r = mh_rsqrt(1.0 + t * t); cu = t * r; cw = -r; }
-            else { const double t = m00 / m01; const double r = mh_rsqrt(1.0 + t * t); cu = r; cw = -t * r; }
+            if (am00 >= am01) { const double t = mh_div(m01, m00); const double r = mh_rsqrt(1.0 + t * t); cu = t * r; cw = -r; }
+            else { const double t = mh_div(m00, m01); const double r = mh_rsqrt(1.0 + t * t); cu = r; cw = -t * r; }
           } else { cu = 1.0; cw = 0.0; }
         } else {
           if (fmax(am11, am01) > 0.0) {
-            if (am11 >= am01) { const double t = m01 / m11; const double r = mh_rsqrt(1.0 + t * t); cu = -r; cw = t * r; }
-            else { const double t = m11 / m01; const double r = mh_rsqrt(1.0 + t * t); cu = -t * r; cw = r; }
+            if (am11 >= am01) { const double t = mh_div(m01, m11); const double r = mh_rsqrt(1.0 + t * t); cu = -r; cw = t * r; }
+            else { const double t = mh_div(m11, m01); const double r = mh_rsqrt(1.0 + t * t); cu = -t * r; cw = r; }
           } else { cu = 1.0; cw = 0.0; }
         }
         v[0] = cu * U[0] + cw * W[0]; v[1] = cu * U[1] + cw * W[1]; v[2] = cu * U[2] + cw * W[2];
       };
       double va[3], vb[3], vc[3];
-      if (half_det >= 0.0) {  // e2 stands alone (e0, e1 may be close)
+      // Fast path (round 5): all three eigenvectors as cross products of rows of b - e I — three INDEPENDENT chains the
+      // scheduler interleaves, a third of the dependent depth of first / second-in-the-complement / third-as-cross-product.
+      // Good whenever the eigenvalues are separated (the Hessian blocks of any scene with structure); accepted only if the
+      // vectors come out orthogonal, and verified like the others below.  Otherwise: Eberly's construction, as before.
+      bool fast = evec_first(e0, va);
+      fast = evec_first(e1, vb) && fast;
+      fast = evec_first(e2, vc) && fast;
+      {
+        const double dab = va[0] * vb[0] + va[1] * vb[1] + va[2] * vb[2], dac = va[0] * vc[0] + va[1] * vc[1] + va[2] * vc[2],
+                     dbc = vb[0] * vc[0] + vb[1] * vc[1] + vb[2] * vc[2];
+        fast = fast && fmax(fabs(dab), fmax(fabs(dac), fabs(dbc))) <= 1e-10;
+      }
+      if (fast) {
+        // (nothing to do: va, vb, vc stand)
+      } else if (half_det >= 0.0) {  // e2 stands alone (e0, e1 may be close)
         ok = evec_first(e2, vc);
         evec_second(vc, e1, vb);
         va[0] = vb[1] * vc[2] - vb[2] * vc[1]; va[1] = vb[2] * vc[0] - vb[0] * vc[2]; va[2] = vb[0] * vc[1] - vb[1] * vc[0];

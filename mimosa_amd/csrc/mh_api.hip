@@ -363,7 +363,7 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_ticket.reserve(4 * sizeof(unsigned int), ctx->stream, false));  // K3's ticket, K4's ticket, the point count of the two-phase forms
   MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
 #ifdef MH_TIMELINE
-  MH_HIP(ctx, icp->d_dbg.reserve(max_grid * 8 * 16 * sizeof(unsigned long long), ctx->stream, false));
+  MH_HIP(ctx, icp->d_dbg.reserve(2 * max_grid * 8 * 16 * sizeof(unsigned long long), ctx->stream, false));  // K3's waves, then K4's
   MH_HIP(ctx, hipMemsetAsync(icp->d_dbg.p, 0, icp->d_dbg.cap, ctx->stream));
 #endif
   MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_results), sizeof(mh::DeviceResult) * kMaxPending));
@@ -372,7 +372,12 @@ static int icp_alloc(mh_icp * icp)
   // one process-wide counter (next_call_seq), so nothing stale ever carries the number of a call of this factor
   // (row capacity in steps of 16 workgroups: factors of similar size — a scan's down-sampled cloud from one keyframe to the
   // next — ask the pinned cache for the SAME size and get a recycled block instead of a fresh hipHostMalloc)
-  icp->ll_words = mh::ll_slot_words((mh::localizability_grid(static_cast<int>(n)) + 15) & ~15);
+  {
+    // rows of K4's workgroups: the factor's own launch class, or the class of a window batch it may be linearized in
+    const int ni = static_cast<int>(n);
+    const int rows = std::max(mh::localizability_grid(ni), std::max(mh::batch_loc_grid(ni, 256), mh::batch_loc_grid(ni, 512)));
+    icp->ll_words = mh::ll_slot_words((rows + 15) & ~15);
+  }
   MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_ll), icp->ll_words * sizeof(uint4) * kMaxPending));
   MH_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&icp->d_h_ll), icp->h_ll, 0));
   return MH_OK;
@@ -586,7 +591,7 @@ int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_word
 {
   if (!icp || !out || !n_words) return MH_ERR_INVALID_ARG;
   mh_ctx * ctx = icp->ctx;
-  const size_t words = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 16;
+  const size_t words = 2 * static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 16;  // K3's half, then K4's
   *n_words = words;
   if (capacity_words < words) return MH_ERR_INVALID_ARG;
   MH_HIP(ctx, mh_enter(ctx));
@@ -712,6 +717,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   a.max_d2 = static_cast<double>(icp->cfg.max_corres_distance * icp->cfg.max_corres_distance);
   a.plane_valid = static_cast<double>(icp->cfg.plane_validity_distance);
   a.sigma = static_cast<double>(icp->cfg.lidar_point_noise_std_dev);
+  a.inv_sigma = 1.0 / a.sigma;
   a.huber = static_cast<double>(icp->cfg.huber_threshold);
   a.q_da = static_cast<double *>(icp->d_qda.p);
   a.mean = static_cast<double *>(icp->d_mean.p);
@@ -745,6 +751,9 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   l.sig = a.sig;
   l.sig4 = a.sig4;
   l.side = 0;
+#ifdef MH_TIMELINE
+  l.dbg = a.dbg ? a.dbg + static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * 8 * 16 : nullptr;
+#endif
 
   const int slot = icp->n_pending;
   PendingCall & pc = icp->pending[slot];
@@ -1035,13 +1044,12 @@ static bool collect_call(const mh_icp * icp, int slot, const PendingCall & pc, l
         if (!get(row + i, v)) return false;
         acc[i] += v;
       }
-      for (int i = 0; i < 5; ++i) {  // two 32-bit counts per word
+      for (int i = 0; i < 2; ++i) {  // counts 0..4 / 5..8, 12 bits each (icp_device.hpp: kLlRow)
         double raw;
         if (!get(row + 6 + i, raw)) return false;
         unsigned long long bits;
         std::memcpy(&bits, &raw, sizeof(bits));
-        hist[2 * i] += bits & 0xffffffffull;
-        hist[2 * i + 1] += bits >> 32;
+        for (int h = 0; h < (i == 0 ? 5 : 4); ++h) hist[5 * i + h] += (bits >> (12 * h)) & 0xfffull;
       }
     }
     for (int i = 0; i < 6; ++i) d.loc_comp[i] = acc[i];

@@ -166,6 +166,18 @@ struct ShardCall
   double carried[4] = {0, 0, 0, 0};  // k-NN counters of earlier attempts of this call (their points hit the cache in the repeat)
   int attempts = 0;
   unsigned long long round_index = 0;  // (repair list) the round the call overflowed in
+  bool cold = false;                   // the call was the first after mh_shard_icp_reset: a repeat of it starts from zero state again
+};
+// A segment-capacity decision read out of a completed round (complete_front).  Rounds complete at rank-local times (a rank
+// that needs an idle factor drains early), but the capacity sizes the NEXT round's exchange layout, which every rank must
+// agree on: the decision is parked here and takes effect at the next point all ranks reach with the same history
+// (apply_cap_updates: settle_rounds for the rounds it covers, run_repairs once everything has been completed).
+struct CapUpdate
+{
+  unsigned long long round_index;
+  mh_shard_icp * S;
+  uint32_t value;
+  bool grow_only;  // an overflow: never below the current capacity
 };
 struct ShardRound
 {
@@ -198,6 +210,8 @@ struct mh_shard_comm
   unsigned int seq = 0;
   unsigned long long n_rounds = 0;   // rounds enqueued so far
   std::vector<ShardCall> repairs;    // calls whose segments overflowed, waiting to be repeated (settle_rounds)
+  std::vector<CapUpdate> cap_updates;  // in round order (rounds complete in order)
+  bool repairing = false;              // run_repairs is on the stack: its own enqueues must not start another one
   std::vector<mh_shard_icp *> plain_pending;  // one rank, no protocol: the factors with mh_icp_linearize_async calls to collect
   std::vector<mh_shard_icp *> factors;        // every live factor of this communicator (a communicator destroyed first orphans them)
 
@@ -717,19 +731,20 @@ int complete_front(mh_shard_comm * comm)
       // of the factor that were enqueued BEHIND an overflowed one are repeated behind its repeat, whether they fitted or
       // not: the calls of a factor take effect — results, association cache — in the order they were made.
       if (overflow) {
-        S->seg_cap = std::max(S->seg_cap, std::min(S->seg_cap_max, pow2_at_least(max_movers)));
+        comm->cap_updates.push_back({r.index, S, std::min(S->seg_cap_max, pow2_at_least(max_movers)), true});
         S->stats.retries_total++;
         S->stats.retries_last++;
         S->replay = true;
       }
       ShardCall again = c;
-      for (int i = 0; i < 4; ++i) again.carried[i] = overflow ? c.carried[i] + p.ar[nent + i] : 0.0;
+      // (a cold call is repeated cold: every point is associated again, nothing of the failed attempt is carried over)
+      for (int i = 0; i < 4; ++i) again.carried[i] = (overflow && !c.cold) ? c.carried[i] + p.ar[nent + i] : 0.0;
       again.round_index = r.index;
       comm->repairs.push_back(again);
       continue;
     }
     // next call: room for four times what moved now (a pose step of centimetres moves a few points across block faces)
-    S->seg_cap = std::min(S->seg_cap_max, std::max<uint32_t>(256u, pow2_at_least(4u * max_movers)));
+    comm->cap_updates.push_back({r.index, S, std::min(S->seg_cap_max, std::max<uint32_t>(256u, pow2_at_least(4u * max_movers))), false});
     if (c.out) {
       mh::ShardPublish q = p;
       for (int i = 0; i < 4; ++i) q.ar[nent + i] += c.carried[i];
@@ -749,6 +764,20 @@ int complete_front(mh_shard_comm * comm)
   return rc_all;
 }
 
+// The parked capacity decisions of rounds up to `upto` take effect, in round order.  Only called where every rank has completed
+// exactly the same rounds <= upto (the decisions are read from all-reduced values, so the lists agree).
+void apply_cap_updates(mh_shard_comm * comm, unsigned long long upto)
+{
+  size_t done = 0;
+  for (const CapUpdate & u : comm->cap_updates) {
+    if (u.round_index > upto) break;
+    ++done;
+    if (!u.S) continue;  // the factor was destroyed meanwhile
+    u.S->seg_cap = u.grow_only ? std::max(u.S->seg_cap, u.value) : u.value;
+  }
+  comm->cap_updates.erase(comm->cap_updates.begin(), comm->cap_updates.begin() + static_cast<long>(done));
+}
+
 int drain_rounds(mh_shard_comm * comm)  // local: completes what is in flight, repeats nothing
 {
   int rc_all = MH_OK;
@@ -766,7 +795,14 @@ int enqueue_round(const RoundSpec * spec, size_t B);
 // reports the ORIGINAL call's linearize count and does not count as a linearize itself.
 int run_repairs(mh_shard_comm * comm)
 {
+  struct Busy
+  {
+    mh_shard_comm * c;
+    explicit Busy(mh_shard_comm * cc) : c(cc) { c->repairing = true; }
+    ~Busy() { c->repairing = false; }
+  } busy(comm);
   int rc_all = drain_rounds(comm);
+  apply_cap_updates(comm, ~0ull);  // every rank is here with everything completed: all parked decisions take effect
   std::vector<mh_shard_icp *> seen;
   struct Clear
   {
@@ -795,7 +831,11 @@ int run_repairs(mh_shard_comm * comm)
     const int saved_count = S->icp->linearize_count;
     const uint32_t retries_last = S->stats.retries_last;
     RoundSpec sp{S, c.R_src, c.t_src, c.has_tgt ? c.R_tgt : nullptr, c.has_tgt ? c.t_tgt : nullptr, c.g_unit, c.out};
+    // a reset that a later call may have announced meanwhile belongs to THAT call (still ahead): set aside over the repeat
+    const bool later_reset = S->cold_pending;
+    S->cold_pending = c.cold;
     int rc = enqueue_round(&sp, 1);
+    S->cold_pending = later_reset;
     if (rc != MH_OK) {
       rc_all = rc;
       continue;
@@ -809,6 +849,7 @@ int run_repairs(mh_shard_comm * comm)
     const size_t listed = comm->repairs.size();
     rc = drain_rounds(comm);  // a further overflow puts the call back on the list, with this attempt's counters added ...
     if (rc != MH_OK) rc_all = rc;
+    apply_cap_updates(comm, ~0ull);
     // ... and it is repeated at once, BEFORE the repeats of later calls: the calls of a factor end in the order they were made
     if (comm->repairs.size() > listed) std::rotate(comm->repairs.begin(), comm->repairs.begin() + static_cast<long>(listed), comm->repairs.end());
   }
@@ -827,9 +868,10 @@ int settle_rounds(mh_shard_comm * comm, unsigned long long upto)
     const int rc = complete_front(comm);
     if (rc != MH_OK) rc_all = rc;
   }
+  apply_cap_updates(comm, upto);
   bool due = false;
   for (const ShardCall & c : comm->repairs) due = due || c.round_index <= upto;
-  if (due) {
+  if (due && !comm->repairing) {  // (the repeats' own enqueues pass through here: the list is already being worked off)
     const int rc = run_repairs(comm);
     if (rc != MH_OK) rc_all = rc;
   }
@@ -992,6 +1034,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
     mh::LocArgs & l = la[f];
     a.n_dev = l.n_dev = &S->d_state->n_slots[S->cur ^ 1];
     a.cold = S->cold_pending ? 1 : 0;  // (K3 still reads the status words: tombstones and held-back movers are marked there)
+    round.calls[f].cold = S->cold_pending;
     S->cold_pending = false;
     a.host_result = nullptr;
     a.seq = 0;

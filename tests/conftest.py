@@ -56,3 +56,14 @@ def big_world():
     pts, aux = synth.make_scan(128)
     R, t = synth.query_pose()
     return dict(map_rooms=rooms, pts=pts, aux=aux, R=R, t=t, cfg=synth.enwide_config())
+
+
+@pytest.fixture(scope="session")
+def huge_world():
+    """BASELINE configs[2]: the 131 072-pt scan against the 10 x 10-room map (~50 M stored points, ~5.2 M voxels)."""
+    from mimosa_amd import synth
+
+    rooms = [xyz for _, _, xyz in synth.make_map_rooms(10, 10)]
+    pts, aux = synth.make_scan(128)
+    R, t = synth.query_pose()
+    return dict(map_rooms=rooms, pts=pts, aux=aux, R=R, t=t, cfg=synth.enwide_config())

@@ -5,6 +5,7 @@ import threading
 
 import numpy as np
 
+_ORACLE_MAPS = {}
 POSE_STEPS = [
     (np.zeros(3), np.array([0.004, 0.003, -0.002])),
     (np.array([0.0, 0.0, 0.012]), np.array([0.06, -0.05, 0.02])),
@@ -36,9 +37,15 @@ def default_case(cfg_over=None, binary=False):
 def oracle_results(case):
     """The unsharded oracle over the pose sequence: per pose (result, status, mean, normal)."""
     from oracle import ref_cpu
-    M = ref_cpu.Map()
-    for c in case["map_chunks"]:
-        M.insert(c)
+    key = id(case["map_chunks"])  # (the configs[2] map is ~50 M points: one oracle map per session-scoped world)
+    M = _ORACLE_MAPS.get(key)
+    if M is None:
+        M = ref_cpu.Map()
+        for c in case["map_chunks"]:
+            M.insert(c)
+        if sum(len(c) for c in case["map_chunks"]) > 10_000_000:
+            _ORACLE_MAPS.clear()
+            _ORACLE_MAPS[key] = M
     F = ref_cpu.ICP(M, case["scan"], ref_cpu.make_config(**case["cfg"]), binary=case["binary"]) if case["binary"] else ref_cpu.ICP(M, case["scan"], ref_cpu.make_config(**case["cfg"]))
     out = []
     for Rk, tk in case["poses"]:

@@ -47,3 +47,30 @@ def test_full_size_sharded_window_batch_pipelined_equals_the_oracle(big_world):
     """Two whole scans per protocol round over 8 ranks, every round of the pose sequence in flight before the one wait."""
     import shard_native_common as C
     C.run_local_world_batch(8, [_case(big_world), _case(big_world, seed_offset=1000)], pipelined=True, uneven=False)
+
+
+# ---- BASELINE configs[2]: the ~50 M-point map through the NATIVE sharded path -----------------------------------------------------
+def test_configs2_native_sharded_path_equals_the_oracle(huge_world):
+    """The 10 x 10-room map (~50 M points) hash-sharded over 8 ranks with mh_map_insert_shard (each rank stores its blocks + the
+    one-voxel halo: ~11 GB in all on the one GPU), the 131 072-point scan through mh_shard_icp_linearize: every rank's GLOBAL
+    result and the state of the points it holds against the ORACLE on the whole map — cold, after a pose step that re-associates
+    part of the cloud and moves points across shard-block faces, and once more at the same pose (all cache hits)."""
+    import shard_native_common as C
+    case = _case(huge_world)
+    assert len(case["scan"]) == 131072 and len(case["map_chunks"]) == 100
+    results, n_map = C.run_local_world(8, case=case)
+    assert n_map > 49_000_000
+    held = [r["stats"]["n_live"] for r in results]
+    stored = [r["map_points"] for r in results]
+    assert sum(held) == 131072
+    for r in results:
+        assert 0 < r["map_points"] < n_map and r["stats"]["collective"] == 1
+    print(f"configs[2], world 8: points held per rank {held}; stored map points per rank {stored} of {n_map} "
+          f"(total {sum(stored) / n_map:.2f}x, fullest {max(stored) / n_map:.1%})")
+
+
+def test_configs2_native_window_batch_async_equals_the_oracle(huge_world):
+    """The throughput form bench.py reports at N > 1 (mh_shard_icp_linearize_batch_async: two whole scans per protocol round, every
+    round of the pose sequence in flight before the one wait) on the configs[2] map over 8 ranks, against the oracle."""
+    import shard_native_common as C
+    C.run_local_world_batch(8, [_case(huge_world), _case(huge_world, seed_offset=1000)], pipelined=True, uneven=False)

@@ -1,0 +1,294 @@
+"""bench.py side leg (tools/benchlegs): BASELINE configs[2] — the map-sharded factor (native mh_shard_* path over RCCL), under a deadline"""
+import ctypes as C  # noqa: F401
+import json  # noqa: F401
+import os  # noqa: F401
+import sys  # noqa: F401
+import time  # noqa: F401
+
+import numpy as np  # noqa: F401
+
+from .env import HBM_COPY_GBS, HBM_PEAK_GBS, INFLIGHT, INFLIGHT_ICP, ROOT  # noqa: F401
+
+
+def run(E, line, real_stdout):
+    """Returns the `sharded` block.  If the leg hangs past its deadline the JSON line is printed WITHOUT it and the process ends here."""
+    args, rank, local_rank, world, dist = E.args, E.rank, E.local_rank, E.world, E.dist
+    ctx, ctxs, gmap, factor, factors = E.ctx, E.ctxs, E.gmap, E.factor, E.factors
+    pts, R, t, cfgd, n_pts, room_clouds = E.pts, E.R, E.t, E.cfgd, E.n_pts, E.room_clouds
+    capi, synth, barrier, run_steps, raw_linearize = E.capi, E.synth, E.barrier, E.run_steps, E.raw_linearize
+    _R, _g, _out, _all_reduce = E._R, E._g, E._out, E._all_reduce
+    win_stats = E.results.get("relinearize_window")
+    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node.  The NATIVE path
+    # (mimosa_amd/csrc/shard_api.hip, mh_shard_*): every rank stores the blocks it owns + a one-voxel halo, a linearize is one
+    # chain of enqueues — route kernels, ncclAllToAll of fixed-size segments over xGMI, append, K3, ncclAllReduce of the Hessian
+    # sums (+ K4 and a second all-reduce when the components are on), publish — and ONE wait.  Reported NEXT TO the replica
+    # figure (`value`); all ranks take part.  With one rank the leg also runs by default: the sharded factor without
+    # collectives (nothing to exchange: the call IS mh_icp_linearize) and the FULL protocol forced over RCCL.
+    sharded = None
+    if args.shard_rooms != "none" and not args.profile_mode:
+        # The leg runs under a deadline in a worker thread: a failure or a stuck collective in it must not cost the
+        # job its JSON line (the replica figure above is complete at this point).
+        import threading
+        box = {}
+        dry = os.environ.get("MH_BENCH_DRYRUN") == "1"
+
+        def _timed(fn, k, pre=None):
+            """k calls, barrier + device sync on both sides, max over ranks: seconds per call"""
+            def sync():
+                sctx.synchronize()
+                if dist is not None:
+                    dist.barrier()
+            for _ in range(3):
+                if pre:
+                    pre()
+                fn()
+            sync()
+            a = time.perf_counter()
+            for _ in range(k):
+                if pre:
+                    pre()
+                fn()
+            sync()
+            el = time.perf_counter() - a
+            if dist is not None and world > 1:
+                import torch
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                _all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return el / k
+
+        def _native_leg(force, vmap, comm, spts, ksh):
+            f = capi.ShardedICPFactor(sctx, comm, vmap, np.array_split(spts, world)[rank], capi.make_reg_config(**cfgd), block_log2=args.shard_block_log2,
+                                      force_collectives=force)
+            a0 = time.perf_counter()
+            first_s = f.linearize(R, t)                                          # cold + routes every point to its owner
+            first_ms = (time.perf_counter() - a0) * 1e3
+            st0 = f.stats()
+            for _ in range(100):  # the scan was generated on the host just before: let the clocks come back up
+                f.linearize(R, t)
+            cold = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
+            warm = _timed(lambda: f.linearize(R, t), ksh)
+            f.set_components(False)
+            cold_nc = _timed(lambda: f.linearize(R, t), ksh, pre=f.reset)
+            warm_nc = _timed(lambda: f.linearize(R, t), ksh)
+            kk = [0]
+            movers = []
+
+            def walk():  # a Gauss-Newton-sized pose step per call: points near block faces change owner
+                kk[0] += 1
+                f.linearize(R @ synth.so3_exp(np.array([0.0, 0.0, 0.0005 * kk[0]])), t + np.array([0.004, 0.002, 0.0]) * kk[0])
+                movers.append(f.stats()["last_max_movers"])
+            walk_nc = _timed(walk, ksh)
+            st = f.stats()
+            f.destroy()
+            return {"first_linearize_ms": round(first_ms, 4), "first_max_movers_per_destination": st0["last_max_movers"],
+                    "ms_per_cold_linearize": round(cold * 1e3, 4), "ms_per_warm_linearize": round(warm * 1e3, 4),
+                    "ms_per_cold_linearize_without_components": round(cold_nc * 1e3, 4), "ms_per_warm_linearize_without_components": round(warm_nc * 1e3, 4),
+                    "ms_per_walking_pose_linearize_without_components": round(walk_nc * 1e3, 4),
+                    "walking_pose_max_movers_per_destination": int(max(movers)) if movers else 0,
+                    "value": round(len(spts) / cold / 1e6, 2), "points_held": st["n_live"], "slots": st["n_slots"], "segment_records": st["segment_records"],
+                    "retries": st["retries_total"], "compactions": st["compactions_total"], "collectives_per_linearize": st["collectives_last"],
+                    "status_hist": [int(v) for v in first_s["status_hist"]]}
+
+        def _timed_total(fn_k, k):
+            """fn_k(k) issues k units of work (and waits for them); warm-up, then barrier + device sync on both sides, max over ranks: seconds per unit"""
+            def sync():
+                sctx.synchronize()
+                if dist is not None:
+                    dist.barrier()
+            fn_k(max(8, k // 4))
+            sync()
+            a = time.perf_counter()
+            fn_k(k)
+            sync()
+            el = time.perf_counter() - a
+            if dist is not None and world > 1:
+                import torch
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                _all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return el / k
+
+        def _throughput_forms(force, vmap, comm, clouds, k, label):
+            """The throughput forms of the sharded factor (raw C-ABI calls, arguments marshalled once): ONE factor with <= 32 calls in
+            flight (mh_shard_icp_linearize_async / _wait), and a WINDOW of len(clouds) factors per protocol round
+            (mh_shard_icp_linearize_batch blocking; _batch_async with <= 32 rounds in flight).  Every call is a cold linearize
+            (mh_shard_icp_reset before it, stream-ordered); the points are already on their owners."""
+            import ctypes as C_
+            L = sctx.L
+            B = len(clouds)
+            rc_ = capi.make_reg_config(**cfgd)
+            fs = [capi.ShardedICPFactor(sctx, comm, vmap, np.array_split(cl, world)[rank], rc_, block_log2=args.shard_block_log2, force_collectives=force) for cl in clouds]
+            vp = lambda a_: a_.ctypes.data_as(C_.c_void_p)
+            R1, t1, g1 = np.ascontiguousarray(R, np.float64), np.ascontiguousarray(t, np.float64), np.ascontiguousarray([0.0, 0.0, -1.0], np.float64)
+            RB, tB, gB = np.ascontiguousarray(np.tile(R1.reshape(1, 9), (B, 1))), np.ascontiguousarray(np.tile(t1, (B, 1))), np.ascontiguousarray(np.tile(g1, (B, 1)))
+            hs = (C_.c_void_p * B)(*[f.h for f in fs])
+            first = capi.sharded_linearize_batch(fs, [R] * B, [t] * B)   # routes every point of every factor to its owner
+            out1 = (capi.IcpResult * INFLIGHT)()
+            outB = [(capi.IcpResult * B)() for _ in range(INFLIGHT)]
+            f0 = fs[0]
+
+            def single_sync(kk):
+                for _ in range(kk):
+                    sctx.check(L.mh_shard_icp_reset(f0.h))
+                    sctx.check(L.mh_shard_icp_linearize(f0.h, vp(R1), vp(t1), None, None, vp(g1), C_.byref(out1[0])))
+
+            def single_pipelined(kk):
+                done = 0
+                while done < kk:
+                    nb = min(INFLIGHT, kk - done)
+                    for i in range(nb):
+                        sctx.check(L.mh_shard_icp_reset(f0.h))
+                        sctx.check(L.mh_shard_icp_linearize_async(f0.h, vp(R1), vp(t1), None, None, vp(g1), C_.byref(out1[i])))
+                    sctx.check(L.mh_shard_icp_wait(f0.h))
+                    done += nb
+
+            def batch_blocking(kk):
+                for _ in range(kk):
+                    for f in fs:
+                        sctx.check(L.mh_shard_icp_reset(f.h))
+                    sctx.check(L.mh_shard_icp_linearize_batch(hs, B, vp(RB), vp(tB), None, None, vp(gB), outB[0]))
+
+            def batch_pipelined(kk):
+                done = 0
+                while done < kk:
+                    nb = min(INFLIGHT, kk - done)
+                    for i in range(nb):
+                        for f in fs:
+                            sctx.check(L.mh_shard_icp_reset(f.h))
+                        sctx.check(L.mh_shard_icp_linearize_batch_async(hs, B, vp(RB), vp(tB), None, None, vp(gB), outB[i]))
+                    sctx.check(L.mh_shard_icp_wait(f0.h))
+                    done += nb
+
+            single_sync(30)  # clocks up
+            npts_f = [len(cl) for cl in clouds]
+            res = {"what": label, "factors": B, "points_per_factor": npts_f[0] if len(set(npts_f)) == 1 else npts_f, "steps": k,
+                   "first_status_hist": [int(v) for v in first[0]["status_hist"]]}
+            ss = _timed_total(single_sync, k)
+            sp_ = _timed_total(single_pipelined, k)
+            bb = _timed_total(batch_blocking, k)
+            bp = _timed_total(batch_pipelined, k)
+            for f in fs:
+                f.set_components(False)
+            bb_nc = _timed_total(batch_blocking, k)
+            bp_nc = _timed_total(batch_pipelined, k)
+            tot = float(sum(npts_f))
+            res.update({"single_sync_ms": round(ss * 1e3, 4), "single_pipelined_ms": round(sp_ * 1e3, 4),
+                        "batch_blocking_ms_per_round": round(bb * 1e3, 4), "batch_pipelined_ms_per_round": round(bp * 1e3, 4),
+                        "batch_blocking_ms_per_round_without_components": round(bb_nc * 1e3, 4),
+                        "batch_pipelined_ms_per_round_without_components": round(bp_nc * 1e3, 4),
+                        "value_single_sync": round(npts_f[0] / ss / 1e6, 2), "value_single_pipelined": round(npts_f[0] / sp_ / 1e6, 2),
+                        "value_batch_blocking": round(tot / bb / 1e6, 2), "value_batch_pipelined": round(tot / bp / 1e6, 2),
+                        "value_batch_pipelined_without_components": round(tot / bp_nc / 1e6, 2), "unit": "Mpts/s",
+                        "retries": int(sum(f.stats()["retries_total"] for f in fs)), "collectives_per_round": fs[0].stats()["collectives_last"]})
+            for f in fs:
+                f.destroy()
+            return res
+
+        def _sharded_leg():
+            try:
+                if dist is not None:
+                    import torch
+                    torch.cuda.set_device(local_rank)
+                sr = args.shard_rooms if args.shard_rooms != "auto" else ("10x10" if world >= 4 else ("4x5" if world > 1 else args.rooms))
+                snx, sny = (int(v) for v in sr.lower().split("x"))
+                spts, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1)     # ONE scan, split over the ranks
+                ksh = max(20, args.steps // 4)
+                mkw = dict(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
+                           mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
+                if dry and world > 1:
+                    # tests only: several ranks on ONE GPU — RCCL refuses that, so the caller-driven form of the protocol
+                    # (mimosa_amd/dist.py over gloo) stands in; the native path at world > 1 is covered by the in-process
+                    # transport in tests/test_gpu_shard_native.py
+                    import torch
+                    from mimosa_amd import dist as mdist
+                    lctx = mdist.context_on_torch_stream(local_rank)
+                    sh = mdist.ShardedICPDevice(dist.group.WORLD, lctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), torch.device("cuda", local_rank))
+                    sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), **mkw)
+                    sh.set_scan(np.array_split(spts, world)[rank])
+                    first_s = sh.linearize(R, t)
+                    nloc = torch.tensor([float(first_s["n_local"])], dtype=torch.float64, device="cuda")
+                    nmax = nloc.clone()
+                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
+                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
+                    box["result"] = {"n_ranks": world, "backend": "gloo (dry run, caller-driven protocol)", "scan_points_total": int(nloc[0].item()),
+                                     "scan_points_max_per_rank": int(nmax[0].item()), "status_hist": [int(v) for v in first_s["status_hist"]]}
+                    sh.close()
+                    return
+                # the communicator: rank 0 draws the ncclUniqueId, torch.distributed (already up for the replica leg) carries it
+                uid = capi.ShardComm.unique_id() if rank == 0 else None
+                if dist is not None and world > 1:
+                    obj = [uid]
+                    dist.broadcast_object_list(obj, src=0)
+                    uid = obj[0]
+                comm = capi.ShardComm.rccl(sctx, uid, world, rank)
+                t0s = time.time()
+                if world == 1 and sr == args.rooms:
+                    vmap, own_map = gmap, False                                    # one rank's shard IS the map
+                else:
+                    vmap, own_map = capi.VoxelMap(sctx, **mkw), True
+                    for _, _, xyz in synth.make_map_rooms(snx, sny):
+                        capi.map_insert_shard(sctx, vmap, xyz, world, rank, args.shard_block_log2)
+                build_s = time.time() - t0s
+                mstats = vmap.stats()
+                res = _native_leg(False, vmap, comm, spts, ksh)
+                # the throughput forms: a window of max(world, 2) whole scans (own noise seeds), one protocol round per step —
+                # at N ranks that is N scans' worth of points per round, i.e. the per-GPU work of the replica mode (weak scaling)
+                nwin_s = max(world, 2)
+                clouds = [spts] + [synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + 1000 * i)[0] for i in range(1, nwin_s)]
+                thr = _throughput_forms(False, vmap, comm, clouds, args.steps, f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
+                result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
+                                       f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
+                           "n_ranks": comm.world, "backend": comm.backend, "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
+                           "map_build_s": round(build_s, 2), **res, "throughput": thr}
+                if world == 1:
+                    result["full_protocol_forced"] = _native_leg(True, vmap, comm, spts, ksh)
+                    result["full_protocol_forced"]["throughput"] = _throughput_forms(True, vmap, comm, clouds, max(20, args.steps), "the same with the exchange protocol forced at one rank")
+                    # VERDICT r3 item 1's yardstick: the smoother window (5 factors x 24 576 points) through the sharded batch with the
+                    # protocol forced, against the unsharded mh_icp_linearize_batch of the same window (relinearize_window.batch_cold_ms)
+                    wcl = [np.ascontiguousarray(spts[i::5][:24576]) for i in range(5)]
+                    result["full_protocol_forced"]["window_5x24576"] = _throughput_forms(True, vmap, comm, wcl, max(20, args.steps), "5 factors x 24 576 points, protocol forced, one rank")
+                    if win_stats:
+                        result["full_protocol_forced"]["window_5x24576"]["unsharded_batch_cold_ms"] = win_stats["batch_cold_ms"]
+                        result["full_protocol_forced"]["window_5x24576"]["ratio_to_unsharded_batch"] = round(
+                            result["full_protocol_forced"]["window_5x24576"]["batch_blocking_ms_per_round"] / win_stats["batch_cold_ms"], 3)
+                    result["full_protocol_forced"]["note"] = ("one rank, every step of the exchange protocol executed anyway: route kernels, ncclAllToAll of the segments to itself, "
+                                                              "append, K3 on device-side counts, ncclAllReduce(s), publish")
+                    result["scan_points_total"] = result["scan_points_max_per_rank"] = res["points_held"]
+                    result["map_points_stored_total"] = result["map_points_max_per_rank"] = int(mstats["n_points"])
+                else:
+                    import torch
+                    nloc = torch.tensor([float(res["points_held"]), float(mstats["n_points"])], dtype=torch.float64, device="cuda")
+                    nmax = nloc.clone()
+                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
+                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
+                    result.update(scan_points_total=int(nloc[0].item()), scan_points_max_per_rank=int(nmax[0].item()),
+                                  map_points_stored_total=int(nloc[1].item()), map_points_max_per_rank=int(nmax[1].item()))
+                result["note"] = ("one scan is latency-bound when sharded (a few thousand points per rank behind one all-to-all and one or two all-reduces): "
+                                  "sharding is for maps that should not be replicated, the replica mode (`value`) is the throughput mode.  "
+                                  + ("No xGMI figure exists yet: a one-GPU box cannot run RCCL with more than one rank." if world == 1 else ""))
+                comm.destroy()
+                if own_map:
+                    vmap.release()
+                box["result"] = result
+            except Exception as exc:  # noqa: BLE001 - reported in the line
+                box["error"] = f"{type(exc).__name__}: {exc}"
+
+        sctx = capi.Context(local_rank)
+        th = threading.Thread(target=_sharded_leg, daemon=True)
+        th.start()
+        th.join(args.shard_timeout)
+        if th.is_alive():
+            sharded = {"error": f"no result within {args.shard_timeout} s (stuck collective?)", "n_ranks": world}
+            line["sharded"] = sharded
+            line["metric_form"] = "value = independent scan replicas (the map-sharded leg did not complete within its deadline)"
+            if rank == 0:
+                sys.stdout.flush()
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            os._exit(0)  # the worker may sit in a collective for ever: no clean-up is possible
+        sharded = box.get("result") or {"error": box.get("error", "unknown"), "n_ranks": world}
+        if "error" not in sharded:
+            sctx.close()
+    line["sharded"] = sharded
+
+    return sharded

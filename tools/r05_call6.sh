@@ -1,0 +1,10 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/c6
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_batch.py tests/test_gpu_configs1.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+tail -3 $O/pytest.log
+timeout 300 python tools/k3_time.py > $O/k3_time_new.json 2> $O/k3_time_new.err
+MH_JOBSTAMP=1 timeout 300 python tools/timeline.py > $O/timeline_131k.txt 2>&1
+MH_JOBSTAMP=1 MH_TL_POINTS=24576 timeout 300 python tools/timeline.py > $O/timeline_24k.txt 2>&1
+ls -la $O

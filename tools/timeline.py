@@ -37,10 +37,12 @@ for _ in range(5):
     f.reset()
     r = f.linearize(R, t)
 n = C.c_size_t()
-buf = np.zeros(8 * 16 * 4096, np.uint64)
+buf = np.zeros(2 * 8 * 16 * 4096, np.uint64)
 rc = L.mh_icp_timeline(f.h, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n))
 assert rc == 0, rc
-T = buf[: n.value].reshape(-1, 16).astype(np.int64)
+Tall = buf[: n.value].reshape(-1, 16).astype(np.int64)
+T = Tall[: len(Tall) // 2]    # K3's waves
+T4 = Tall[len(Tall) // 2:]    # K4's waves (4 per workgroup), stamps of icp_localizability_body
 blk = np.arange(len(T)) // WPB
 live = T[:, 0] > 0
 T, blk = T[live], blk[live]
@@ -62,29 +64,11 @@ stat("   B.3 neighbour scan (11->2)", T[:, 2] - T[:, 11])
 stat("   C.1 exact tier (2->12)", T[:, 12] - T[:, 2])
 stat("   C.2 proof+plane+residual+stores (12->3)", T[:, 3] - T[:, 12])
 stat("B: candidate scan (1->2)", T[:, 2] - T[:, 1])
-if os.environ.get("MH_BALANCE"):  # build with MH_BALANCE=1 python -m mimosa_amd.build --timeline --force
-  q_sum, steps = (T[:, 13] & 0xFFFF).astype(float), (T[:, 14] & 0xFFFF).astype(float)
-  sh = np.stack([(T[:, 13] >> s) & 0xFF for s in (16, 24, 32, 40, 48)], 1)      # share: posted, taken back, done by helpers, done for others, rounds
-  print("share: jobs posted", int(sh[:, 0].sum()), " taken back by their owner", int(sh[:, 1].sum()), " done by helpers", int(sh[:, 2].sum()),
-        " (claimed", int(sh[:, 3].sum()), ") waves that posted", int((sh[:, 0] > 0).sum()), " waves that helped", int((sh[:, 3] > 0).sum()),
-        " help rounds max", int(sh[:, 4].max()))
-  heavy = np.stack([(T[:, 14] >> s) & 0xFF for s in (16, 24, 32, 40)], 1)   # lanes with > 8 / 12 / 16 / 24 neighbour quads
-  print("lanes per wave with > 8 / 12 / 16 / 24 neighbour quads: mean", heavy.mean(0).round(2), " p95", np.percentile(heavy, 95, 0), " max", heavy.max(0))
-  for lo, hi in ((0, 12), (12, 16), (16, 20), (20, 24), (24, 28), (28, 40)):
-    sel = (steps > lo) & (steps <= hi)
-    if sel.any():
-      print(f"  waves with {lo:2d} < quad steps <= {hi:2d}: {int(sel.sum()):5d}   their lanes > 8 / 12 / 16 / 24: mean {heavy[sel].mean(0).round(1)}  max {heavy[sel].max(0)}")
-  print(f"scan lane balance: mean quads/lane (centre incl.) {q_sum.mean()/64:.2f}, mean neighbour quad steps per wave {steps.mean():.2f}, "
-        f"p95 {np.percentile(steps,95):.0f}, max {steps.max():.0f}")
-  i_sum, i_max = (T[:, 15] & 0xFFFFFFFF).astype(float), (T[:, 15] >> 32).astype(float)
-  print(f"ideal pruning (box nearer than the final k-th distance): mean neighbour quads/lane {i_sum.mean()/64:.2f}, "
-        f"mean per-wave max {i_max.mean():.2f}, p95 {np.percentile(i_max,95):.0f}, max {i_max.max():.0f}")
-else:
-  ok = T[:, 13] > 0
-  stat("   C.2a proof check + 5 bucket loads (12->13)", (T[:, 13] - T[:, 12])[ok])
-  stat("   C.2b mean + covariance (13->14)", (T[:, 14] - T[:, 13])[ok])
-  stat("   C.2c plane_eigen (14->15)", (T[:, 15] - T[:, 14])[ok])
-  stat("   C.2d gates + residual + Jacobian + stores (15->3)", (T[:, 3] - T[:, 15])[ok])
+ok = T[:, 13] > 0
+stat("   C.2a proof check + 5 bucket loads (12->13)", (T[:, 13] - T[:, 12])[ok])
+stat("   C.2b mean + covariance (13->14)", (T[:, 14] - T[:, 13])[ok])
+stat("   C.2c plane_eigen (14->15)", (T[:, 15] - T[:, 14])[ok])
+stat("   C.2d gates + residual + Jacobian + stores (15->3)", (T[:, 3] - T[:, 15])[ok])
 stat("C: plane/residual (2->3)", T[:, 3] - T[:, 2])
 stat("barrier wait (3->4)", T[:, 4] - T[:, 3])
 stat("D: block reduce+store (4->5)", T[:, 5] - T[:, 4])
@@ -119,3 +103,33 @@ work = T[:, 3] - T[:, 0]
 print(f"per-wave work before the barrier (0->3): mean {work.mean():.0f} p50 {np.percentile(work,50):.0f} p95 {np.percentile(work,95):.0f} p99 {np.percentile(work,99):.0f} max {work.max()}")
 bw = np.array([work[blk == b].max() for b in np.unique(blk)])
 print(f"per-block slowest wave: mean {bw.mean():.0f} p95 {np.percentile(bw,95):.0f} max {bw.max()}")
+
+# ---- K4 (icp_localizability_kernel): 0 entry, 1 K3's rows folded, 2 record entries requested, 3 eigenbases (the two lanes that
+# decompose) / nothing, 5 after the barrier (bases known), 6 projections + histogram done,
+# 7 wave sums in LDS, 8 after the barrier, 9 flagged words acknowledged
+blk4 = np.arange(len(T4)) // 4
+live4 = T4[:, 0] > 0
+T4, blk4 = T4[live4], blk4[live4]
+if len(T4):
+    print(f"K4 waves {len(T4)}  K4 by HIP events {r['gpu_ms_localizability'] * 1e3:.1f} us")
+    stat("K4 entry -> K3's rows folded (0->1)", T4[:, 1] - T4[:, 0])
+    stat("K4 record entries requested (1->2)", T4[:, 2] - T4[:, 1])
+    stat("K4 eigen lanes / pass-through (2->3)", T4[:, 3] - T4[:, 2])
+    stat("K4 barrier: bases known (3->5)", T4[:, 5] - T4[:, 3])
+    stat("K4 projections + histogram (5->6)", T4[:, 6] - T4[:, 5])
+    stat("K4 wave sums (6->7)", T4[:, 7] - T4[:, 6])
+    stat("K4 barrier (7->8)", T4[:, 8] - T4[:, 7])
+    stat("K4 flagged words out + ack (8->9)", T4[:, 9] - T4[:, 8])
+    stat("K4 wave total (0->9)", T4[:, 9] - T4[:, 0])
+    # same-XCD clocks: last K3 stamp of the XCD -> first / last K4 entry, K4 span
+    gaps, spans4, skew4 = [], [], []
+    for x in range(8):
+        s3, s4 = (blk % 8) == x, (blk4 % 8) == x
+        if not s3.any() or not s4.any():
+            continue
+        e3 = max(T[s3, 5].max(), T[s3, 7].max())
+        gaps.append(T4[s4, 0].min() - e3)
+        skew4.append(T4[s4, 0].max() - T4[s4, 0].min())
+        spans4.append(T4[s4, 9].max() - T4[s4, 0].min())
+    print("K3 last stamp -> first K4 entry per XCD (ticks):", gaps)
+    print("K4 entry skew per XCD:", skew4, " K4 span per XCD:", spans4)
