@@ -363,7 +363,8 @@ def main():
                                  "batched_pipelined_without_components": src_["value_batch_pipelined_without_components"],
                                  "factors_per_round": src_["factors"], "ms_per_round_pipelined": src_["batch_pipelined_ms_per_round"],
                                  "unit": "Mpts/s", "what": src_["what"]}
-        line["sharded_rccl"] = {"rccl_ranks": shd.get("n_ranks"), "rccl_version": shd.get("rccl_version"), "backend": shd.get("backend")}
+        line["sharded_rccl"] = {"rccl_ranks": shd.get("rccl_ranks"), "rccl_version": shd.get("rccl_version"), "backend": shd.get("backend"),
+                                "note": "rccl_ranks = ncclCommCount of the communicator the sharded leg ran on, rccl_version = ncclGetVersion"}
     form = ("value = <= 64 cold linearize calls of one factor in flight (results on the host, parity-checked); value_sync = one synchronous "
             "mh_icp_linearize at a time = SURVEY 8(d)'s definition and the reference's call pattern (geometric.cpp:194-196)")
     if world > 1:

@@ -27,12 +27,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 1
-#if defined(__GNUC__) && !defined(MH_BUILDING_LIBRARY)
-#define MH_DEPRECATED(msg) __attribute__((deprecated(msg)))
-#else
-#define MH_DEPRECATED(msg)
-#endif
+#define MH_ABI_VERSION 2  /* 2: the caller-driven sharding entry points, mh_map_fork and mh_map_sync are gone (round 5) */
 
 typedef enum mh_status {
   MH_OK = 0,
@@ -223,13 +218,9 @@ int mh_map_insert_from_scan(mh_map * map, const mh_scan * scan, const float R_W_
 /* Deep copy — IncrementalVoxelMapPCL copy ctor (incremental_voxel_map.hpp:33-42) used by Geometric::updateMap's
  * copy-then-insert (geometric.cpp:494): device to device, both maps stay writable. */
 int mh_map_copy(const mh_map * map, mh_map ** out);
-/* DEPRECATED (ABI version 1 only; removed with the next MH_ABI_VERSION): round-1 name of mh_map_copy — use mh_map_copy. */
-int mh_map_fork(mh_map * map, mh_map ** out) MH_DEPRECATED("use mh_map_copy");
 /* shared_ptr semantics: factors retain the map they were built with. */
 int mh_map_retain(mh_map * map);
 void mh_map_release(mh_map * map);
-/* DEPRECATED (ABI version 1 only; removed with the next MH_ABI_VERSION): a no-op since the device arrays ARE the map. */
-int mh_map_sync(mh_map * map) MH_DEPRECATED("no longer needed");
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out);
 /* IncrementalVoxelMapPCL::getCloud (incremental_voxel_map.cpp:34-38): all points in voxel order.
  * xyz may be NULL to query the size; returns the number of points through n_out. */
@@ -274,17 +265,6 @@ int mh_icp_wait(mh_icp * icp);
  * at most 64 per call.  R_tgt / t_tgt may be NULL when no factor is binary.  Blocks until every result is on the host. */
 int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out);
-/* Two-phase form for a factor whose map is sharded across GPUs (no reference counterpart; the
- * reference is single-process).  begin = everything of linearize up to the Hessian sums of THIS shard
- * (`partial`: H, b, f, counters; its localizability fields are shard-local and must be ignored);
- * the caller all-reduces H across shards, eigen-decomposes the 3x3 rot / trans blocks and hands the
- * GLOBAL eigenvectors (columns, row-major) to finish, which runs the component-localizability pass
- * (geometric_factor.hpp:434-457) over this shard's valid points; the caller sums those across shards. */
-int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3],
-                           const double * R_tgt, const double * t_tgt, const double g_unit[3],
-                           mh_icp_result * partial);
-int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9],
-                            double loc_trans_comp[3], double loc_rot_comp[3], int32_t status_hist[9]);
 /* getStatuses / getCorresMeansTarget / getCorresNormalsTarget (:48-50); any pointer may be NULL. */
 int mh_icp_get_state(const mh_icp * icp, int32_t * status, double * means, double * normals);
 /* Forget all data associations (== a freshly constructed factor): enqueued, no host sync. */
@@ -541,19 +521,14 @@ int mh_photo_factor_get_state(const mh_photo_factor * factor, int32_t * statuses
 size_t mh_photo_factor_size(const mh_photo_factor * factor);
 
 
-/* ---- map sharded across GPUs (BASELINE configs[2]) ------------------------------------------------
- * No reference counterpart: the reference is single-process.  One process per GPU; the map is partitioned into shard
- * blocks of 2^block_log2 voxels per axis owned by XORVector3iHash(block) mod world (the reference's hash,
- * include/mimosa/lidar/utils.hpp:228-238), every rank also stores the one-voxel halo of its blocks, and every source
- * point is linearized on the rank that owns the centre voxel of its CURRENT position — so the sharded factor equals the
- * unsharded ICPFactor::linearize (geometric_factor.hpp:231-562) point for point.  The exchange between ranks (the
- * all-to-all of migrating points, two small all-reduces) is the caller's, e.g. torch.distributed over RCCL / xGMI:
- * these entry points produce and consume plain DEVICE buffers and enqueue on the context stream without waiting.
- *
- * Per linearize:  mh_icp_shard_plan -> (all-to-all of the counts) -> mh_icp_shard_pack -> (all-to-all of 112-byte records)
- * -> mh_icp_shard_unpack -> mh_icp_linearize_begin_device -> (all-reduce 32 doubles) -> mh_icp_linearize_finish_device
- * -> (all-reduce 16 doubles) -> mh_icp_global_epilogue. */
-#define MH_SHARD_RECORD_BYTES 112
+/* ---- map sharded across GPUs (BASELINE configs[2]): what both the library's own exchange (below) and a
+ * framework that owns the stream need ------------------------------------------------------------------------------------
+ * No reference counterpart: the reference is single-process.  The map is partitioned into shard blocks of 2^block_log2 voxels
+ * per axis owned by XORVector3iHash(block) mod world (the reference's hash, include/mimosa/lidar/utils.hpp:228-238); every
+ * rank also stores the one-voxel halo of its blocks, so a query on the owner of its centre voxel finds all 1/7/19/27
+ * neighbour voxels locally.  (ABI version 1 also exported a caller-driven form of the exchange — mh_icp_shard_plan / _pack /
+ * _unpack, mh_icp_linearize_begin[_device] / _finish[_device], mh_icp_global_epilogue — with the collectives in the caller's
+ * hands; version 2 keeps ONE implementation, the native one below.) */
 /* A context on an existing HIP stream (not owned): kernels, the caller's collectives and its tensor ops are ordered by it. */
 int mh_init_on_stream(int device, void * hip_stream, mh_ctx ** out);
 /* This rank's share of IncrementalVoxelMapPCL::insert: of the batch (identical on every rank) the points of owned shard
@@ -562,28 +537,6 @@ int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride
 /* ICPFactor ctor (geometric_factor.hpp:119-142) from a cloud that is already on the device; the point order is kept. */
 int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg,
                               int is_binary, mh_icp ** out);
-/* Which local points belong to another rank at this pose (owner of the centre voxel of T_tgt^-1 T_src p)?
- * send_counts[world] receives how many leave for each rank.  Blocks until the counts are on the host. */
-int mh_icp_shard_plan(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt,
-                      int world, int rank, int block_log2, int64_t * send_counts);
-/* Writes the leaving points WITH their data-association state (q_da, mean, normal, status: the DA cache of
- * geometric_factor.hpp:279-317 travels with the point) to d_send — sum(send_counts) records of MH_SHARD_RECORD_BYTES,
- * grouped by destination rank — and removes them from the factor (the rest keeps its order). */
-int mh_icp_shard_pack(mh_icp * icp, void * d_send);
-/* Appends n_recv arriving records. */
-int mh_icp_shard_unpack(mh_icp * icp, const void * d_recv, size_t n_recv);
-/* Per-point state of the points this rank currently holds: origin = (first rank << 32 | index there). Any pointer may be NULL. */
-int mh_icp_shard_get_state(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals);
-/* linearize of THIS shard up to the raw Hessian sums: d_sums32 (device, 32 doubles) = 28 sums of [J(6), e][J(6), e]^T
- * (upper triangle, row-major) + n_knn, n_candidates, n_exact_fallback, n_scanned.  No epilogue is applied. */
-int mh_icp_linearize_begin_device(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32);
-/* Component localizabilities (geometric_factor.hpp:434-457) of this shard in the eigenbasis of the GLOBAL (all-reduced)
- * sums + status histogram: d_loc16 (device, 16 doubles) = trans xyz, rot xyz, 9 histogram counts, 0. */
-int mh_icp_linearize_finish_device(mh_icp * icp, const double * d_global_sums32, double * d_loc16);
-/* Host epilogue on the all-reduced values: localizabilities of the global H, Schur degeneracy info, 4-DoF projection and
- * the degeneracy branch (geometric_factor.hpp:405-428, 464-557) — applied once, to the global sums. */
-int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out);
-
 /* ---- native map-sharded factor: the exchange inside the library (RCCL over xGMI) ------------------------------------
  * No reference counterpart (the reference is single-process): what it must preserve is that the sharded factor equals
  * ICPFactor::linearize (include/mimosa/lidar/geometric_factor.hpp:231-562) point for point.  Same partition as above
@@ -619,6 +572,9 @@ void mh_shard_comm_destroy(mh_shard_comm * comm);
 int mh_shard_comm_world(const mh_shard_comm * comm);
 int mh_shard_comm_rank(const mh_shard_comm * comm);
 const char * mh_shard_comm_backend(const mh_shard_comm * comm); /* "rccl" | "local" */
+/* The communicator as the transport itself reports it: ranks_in_communicator = ncclCommCount (world for the local transport),
+ * rccl_version = ncclGetVersion (0 for the local transport).  Either pointer may be NULL. */
+int mh_shard_comm_info(const mh_shard_comm * comm, int * ranks_in_communicator, int * rccl_version);
 /* ICPFactor ctor (geometric_factor.hpp:119-142) for this rank's share of the scan (any split; the first linearize routes
  * every point to the owner of its centre voxel).  points: host buffer, or device buffer when points_on_device != 0.
  * shard_map: this rank's shard (mh_map_insert_shard with the same world / rank / block_log2).  Collective. */

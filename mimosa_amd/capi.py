@@ -20,17 +20,16 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 EXPORTS = [
     "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling", "mh_set_overlap",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
-    "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_fork", "mh_map_retain", "mh_map_release", "mh_map_sync", "mh_map_get_stats",
+    "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
     "mh_icp_create", "mh_icp_clone", "mh_icp_destroy", "mh_icp_linearize", "mh_icp_linearize_async",
-    "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_linearize_begin", "mh_icp_linearize_finish", "mh_icp_get_state", "mh_icp_reset", "mh_icp_set_components", "mh_icp_size",
+    "mh_icp_wait", "mh_icp_linearize_batch", "mh_icp_get_state", "mh_icp_reset", "mh_icp_set_components", "mh_icp_size",
     "mh_deskew", "mh_transform_f32",
     "mh_scan_create", "mh_scan_destroy", "mh_scan_prepare_input", "mh_scan_prepare_input_device", "mh_scan_prefetch", "mh_scan_prepare_input_prefetched", "mh_scan_prepare_input_layout", "mh_scan_get_unique_ns", "mh_scan_deskew",
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
-    "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", "mh_icp_shard_plan", "mh_icp_shard_pack", "mh_icp_shard_unpack",
-    "mh_icp_shard_get_state", "mh_icp_linearize_begin_device", "mh_icp_linearize_finish_device", "mh_icp_global_epilogue",
+    "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", 
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
-    "mh_shard_comm_backend", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
+    "mh_shard_comm_backend", "mh_shard_comm_info", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
     "mh_shard_icp_linearize_batch_async", "mh_shard_icp_wait", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
     "mh_shard_icp_stats", "mh_shard_icp_destroy", "mh_alloc_check_stats",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
@@ -337,11 +336,9 @@ def load(build_if_missing: bool = True):
     L.mh_map_insert_device.argtypes = [vp, vp, sz, sz, vp, vp]
     L.mh_map_insert_from_scan.argtypes = [vp, vp, vp, vp]
     L.mh_map_copy.argtypes = [vp, pvp]
-    L.mh_map_fork.argtypes = [vp, pvp]
     L.mh_map_retain.argtypes = [vp]
     L.mh_map_release.argtypes = [vp]
     L.mh_map_release.restype = None
-    L.mh_map_sync.argtypes = [vp]
     L.mh_map_get_stats.argtypes = [vp, C.POINTER(MapStats)]
     L.mh_map_get_cloud.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.mh_map_knn.argtypes = [vp, vp, sz, i32, vp, vp, vp]
@@ -353,8 +350,6 @@ def load(build_if_missing: bool = True):
     L.mh_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_icp_wait.argtypes = [vp]
     L.mh_icp_linearize_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
-    L.mh_icp_linearize_begin.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
-    L.mh_icp_linearize_finish.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mh_icp_get_state.argtypes = [vp, vp, vp, vp]
     L.mh_icp_reset.argtypes = [vp]
     L.mh_icp_set_components.argtypes = [vp, C.c_int]
@@ -380,13 +375,6 @@ def load(build_if_missing: bool = True):
     L.mh_init_on_stream.argtypes = [i32, vp, pvp]
     L.mh_map_insert_shard.argtypes = [vp, vp, sz, sz, i32, i32, i32]
     L.mh_icp_create_from_device.argtypes = [vp, vp, vp, sz, C.POINTER(RegConfig), i32, pvp]
-    L.mh_icp_shard_plan.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
-    L.mh_icp_shard_pack.argtypes = [vp, vp]
-    L.mh_icp_shard_unpack.argtypes = [vp, vp, sz]
-    L.mh_icp_shard_get_state.argtypes = [vp, vp, vp, vp, vp]
-    L.mh_icp_linearize_begin_device.argtypes = [vp, vp, vp, vp, vp]
-    L.mh_icp_linearize_finish_device.argtypes = [vp, vp, vp]
-    L.mh_icp_global_epilogue.argtypes = [vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_shard_unique_id.argtypes = [vp]
     L.mh_shard_comm_init_rccl.argtypes = [vp, vp, i32, i32, pvp]
     L.mh_shard_comm_init_local.argtypes = [i32, pvp]
@@ -396,6 +384,7 @@ def load(build_if_missing: bool = True):
     L.mh_shard_comm_rank.argtypes = [vp]
     L.mh_shard_comm_backend.argtypes = [vp]
     L.mh_shard_comm_backend.restype = C.c_char_p
+    L.mh_shard_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mh_shard_icp_create.argtypes = [vp, vp, vp, vp, sz, i32, C.POINTER(RegConfig), i32, C.POINTER(ShardConfig), pvp]
     L.mh_shard_icp_linearize.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
     L.mh_shard_icp_linearize_async.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(IcpResult)]
@@ -540,16 +529,6 @@ class VoxelMap:
         h = C.c_void_p()
         self.ctx.check(self.L.mh_map_copy(self.h, C.byref(h)))
         return VoxelMap(self.ctx, _h=h)
-
-    def fork(self):
-        """Copy-then-insert without the host copy: returns the writable successor, this map becomes read-only
-        (factors keep using it; knn / get_cloud / stats still work)."""
-        h = C.c_void_p()
-        self.ctx.check(self.L.mh_map_fork(self.h, C.byref(h)))
-        return VoxelMap(self.ctx, _h=h)
-
-    def sync(self):
-        self.ctx.check(self.L.mh_map_sync(self.h))
 
     def stats(self) -> dict:
         s = MapStats()
@@ -734,19 +713,6 @@ class ICPFactor:
         self.ctx.check(self.L.mh_icp_linearize(self.h, _p(R), _p(t), _p(Rt), _p(tt), _p(g), C.byref(out)))
         return out.as_dict()
 
-    def linearize_begin(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> dict:
-        out = IcpResult()
-        R, t, g = _f64(R), _f64(t), _f64(g_unit)
-        self.ctx.check(self.L.mh_icp_linearize_begin(self.h, _p(R), _p(t), None, None, _p(g), C.byref(out)))
-        return out.as_dict()
-
-    def linearize_finish(self, eigvec_rot, eigvec_trans):
-        er, et = _f64(eigvec_rot), _f64(eigvec_trans)
-        tc, rc = np.empty(3), np.empty(3)
-        hist = np.empty(9, np.int32)
-        self.ctx.check(self.L.mh_icp_linearize_finish(self.h, _p(er), _p(et), _p(tc), _p(rc), _p(hist)))
-        return tc, rc, hist
-
     def linearize_async(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> IcpResult:
         out = IcpResult()
         R, t, g = _f64(R), _f64(t), _f64(g_unit)
@@ -829,6 +795,11 @@ class ShardComm:
     @property
     def backend(self):
         return self.L.mh_shard_comm_backend(self.h).decode()
+
+    def info(self) -> dict:
+        n, v = C.c_int(0), C.c_int(0)
+        self.L.mh_shard_comm_info(self.h, C.byref(n), C.byref(v))
+        return {"ranks_in_communicator": n.value, "rccl_version": v.value}
 
     def destroy(self):
         if self.h:

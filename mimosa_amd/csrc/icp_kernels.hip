@@ -2368,8 +2368,10 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
   return hipGetLastError();
 }
 
+// One server workgroup per K4 workgroup of a 131 072-point call (128 of 1024 points each): with 64 every server workgroup ran two
+// of them back to back and the pipelined step went from 35.0 to 40.5 us (round 5, gpurun_out c10: 64 -> 128 = 3.20 -> 3.63 Gpts/s).
 #ifndef MH_SRV_GRID
-#define MH_SRV_GRID 64
+#define MH_SRV_GRID 128
 #endif
 int loc_server_grid() { return MH_SRV_GRID; }
 hipError_t launch_loc_server(const LocServerArgs & s, hipStream_t stream)

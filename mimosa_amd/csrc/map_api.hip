@@ -480,10 +480,6 @@ int mh_map_copy(const mh_map * src, mh_map ** out)
   });
 }
 
-/* Kept for callers of the round-1 interface: with the map maintained on the device a copy IS the cheap operation
- * (device-to-device, ~0.3 ms for a 5 M-point map), so fork == copy and both maps stay writable. */
-int mh_map_fork(mh_map * map, mh_map ** out) { return mh_map_copy(map, out); }
-
 int mh_map_retain(mh_map * map)
 {
   if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_retain: map is NULL");
@@ -499,12 +495,6 @@ void mh_map_release(mh_map * map)
     (void)hipStreamSynchronize(map->ctx->stream);  // the last factor is gone (each waited for its own stream): only the map's own work can be in flight
     map_free(map);
   }
-}
-
-int mh_map_sync(mh_map * map)
-{
-  if (!map) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_map_sync: map is NULL");
-  return MH_OK;  // the device arrays are the map: there is nothing to push
 }
 
 int mh_map_get_stats(const mh_map * map, mh_map_stats * out)

@@ -181,6 +181,23 @@ void finish_result(const mh_icp * icp, const mh::DeviceResult & d, const Pending
 }
 }  // namespace
 
+// MH_WAIT_TRACE=1 (diagnostic): where the host side of a synchronous call spends its time — enqueue (argument blocks + the two
+// launches), the wait for the first flagged word (kernels + dispatch + PCIe flight), the fold of K4's rows and the rest of the
+// slot, the epilogue.  Averages are printed to stderr at mh_shutdown.
+struct WaitTrace
+{
+  bool on = std::getenv("MH_WAIT_TRACE") != nullptr;
+  double enq = 0, k3launch = 0, first = 0, fold = 0, fin = 0;
+  long n = 0;
+  static double now()
+  {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return static_cast<double>(t.tv_sec) * 1e9 + static_cast<double>(t.tv_nsec);
+  }
+};
+static WaitTrace g_wt;
+
 extern "C" {
 
 int mh_abi_version(void) { return MH_ABI_VERSION; }
@@ -241,6 +258,13 @@ int mh_init(int device, mh_ctx ** out)
 void mh_shutdown(mh_ctx * ctx)
 {
   if (!ctx) return;
+  if (g_wt.on && g_wt.n) {
+    const double n = static_cast<double>(g_wt.n);
+    std::fprintf(stderr, "MH_WAIT_TRACE: %ld calls; per call: enqueue %.2f us (of which the K3 launch call %.2f), wait for the first word %.2f, "
+                         "fold of the slot %.2f, epilogue %.2f\n", g_wt.n, g_wt.enq / n * 1e-3, g_wt.k3launch / n * 1e-3, g_wt.first / n * 1e-3,
+                 (g_wt.fold - g_wt.first) / n * 1e-3, g_wt.fin / n * 1e-3);
+    g_wt = WaitTrace{};
+  }
   (void)mh_enter(ctx);
   srv_stop(ctx);
   if (ctx->stream) {
@@ -692,7 +716,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   int rec_b = 0;
   a.rec = nullptr;
   a.rec_n = 0;
-  if (icp->components && icp->shard_world == 0 && icp->n > 0) {
+  if (icp->components && icp->n > 0) {
     rec_b = icp->rec_parity;
     icp->rec_parity ^= 1;
     MH_HIP(ctx, icp->d_rec[rec_b].reserve(mh::loc_record_bytes(icp->n), ctx->stream, false));
@@ -915,7 +939,9 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
       a.srv_posted = ctx->d_srv_posted;
       a.srv_j = j + 1u;
     }
+    const double tl0 = g_wt.on ? WaitTrace::now() : 0.0;
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
+    if (g_wt.on) g_wt.k3launch += WaitTrace::now() - tl0;
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
     if (side) {
       // K3 is in the stream and will announce call j: from here on the bookkeeping must say so
@@ -1032,7 +1058,9 @@ static bool collect_call(const mh_icp * icp, int slot, const PendingCall & pc, l
       // landed: touch every cache line of the slot at once — the device wrote them over PCIe, each is a miss, and a dozen
       // misses in flight cost what one does
       double v0;
+      const double tw0 = g_wt.on ? WaitTrace::now() : 0.0;
       if (!get(rows, v0)) return false;
+      if (g_wt.on) g_wt.first += WaitTrace::now() - tw0;
       const char * lo = reinterpret_cast<const char *>(base);
       const char * hi = reinterpret_cast<const char *>(rows + static_cast<size_t>(pc.loc_blocks) * mh::kLlRow);
       for (const char * q = lo; q < hi; q += 64) __builtin_prefetch(q);
@@ -1073,6 +1101,7 @@ static bool collect_call(const mh_icp * icp, int slot, const PendingCall & pc, l
 
 static int mh_icp_wait_impl(mh_icp * icp)
 {
+  const double tw_enter = g_wt.on ? WaitTrace::now() : 0.0;
   if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_wait: icp is NULL");
   mh_ctx * ctx = icp->ctx;
   MH_HIP(ctx, mh_enter(ctx));
@@ -1118,7 +1147,14 @@ static int mh_icp_wait_impl(mh_icp * icp)
         return fail(ctx, MH_ERR_HIP, "mh_icp_wait: the stream drained without the call's results");
       }
     }
+    const double tf0 = g_wt.on ? WaitTrace::now() : 0.0;
     finish_result(icp, d, pc, pc.out);
+    if (g_wt.on) {
+      const double tf1 = WaitTrace::now();
+      g_wt.fin += tf1 - tf0;
+      g_wt.fold += tf0 - tw_enter;  // (wait for the first word included: subtracted when printed)
+      g_wt.n++;
+    }
     if (pc.ev[0]) {
       (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
       if (pc.ev[2])
@@ -1140,8 +1176,10 @@ int mh_icp_wait(mh_icp * icp)
 static int mh_icp_linearize_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
                      const double * t_tgt, const double g_unit[3], mh_icp_result * out)
 {
+  const double t0 = g_wt.on ? WaitTrace::now() : 0.0;
   const int rc = linearize_enqueue(icp, R_src, t_src, R_tgt, t_tgt, g_unit, out, icp && icp->n_pending == 0);
   if (rc != MH_OK) return rc;
+  if (g_wt.on) g_wt.enq += WaitTrace::now() - t0;
   return mh_icp_wait(icp);
 }
 int mh_icp_linearize(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
@@ -1314,78 +1352,6 @@ int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out)
 {
   return guarded((icps && n_factors && icps[0]) ? icps[0]->ctx : nullptr, "mh_icp_linearize_batch", [&]() -> int { return mh_icp_linearize_batch_impl(icps, n_factors, R_src, t_src, R_tgt, t_tgt, g_unit, out); });
-}
-
-// ---- two-phase form for map-sharded factors (mimosa_amd/dist.py): the Hessian sums of all shards are
-// all-reduced between the two phases and the component-localizability pass runs in the GLOBAL eigenbasis.
-static int mh_icp_linearize_begin_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
-                           const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
-{
-  if (!icp || !partial) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin: NULL argument");
-  if (icp->n_pending) return fail(icp->ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin: calls in flight");
-  const int rc = mh_icp_linearize(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial);
-  if (rc != MH_OK) return rc;
-  std::memcpy(icp->split_R, icp->pending[0].R, sizeof(icp->split_R));
-  icp->split_open = true;
-  return MH_OK;
-}
-int mh_icp_linearize_begin(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
-                           const double * t_tgt, const double g_unit[3], mh_icp_result * partial)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_begin", [&]() -> int { return mh_icp_linearize_begin_impl(icp, R_src, t_src, R_tgt, t_tgt, g_unit, partial); });
-}
-
-static int mh_icp_linearize_finish_impl(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
-                            double loc_rot_comp[3], int32_t status_hist[9])
-{
-  if (!icp || !eigvec_rot || !eigvec_trans || !loc_trans_comp || !loc_rot_comp)
-    return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (!icp->split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish: no mh_icp_linearize_begin before");
-  icp->split_open = false;
-  MH_HIP(ctx, mh_enter(ctx));
-  for (int i = 0; i < 3; ++i) loc_trans_comp[i] = loc_rot_comp[i] = 0.0;
-  if (status_hist) std::memset(status_hist, 0, 9 * sizeof(int32_t));
-  if (icp->n == 0) return MH_OK;
-  double e18[18];
-  std::memcpy(e18, eigvec_rot, 72);
-  std::memcpy(e18 + 9, eigvec_trans, 72);
-  MH_HIP(ctx, icp->d_eig.reserve(sizeof(e18), ctx->stream, false));
-  MH_HIP(ctx, hipMemcpyAsync(icp->d_eig.p, e18, sizeof(e18), hipMemcpyHostToDevice, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // e18 is a stack buffer
-  mh::LocArgs l;
-  l.host_result = icp->d_h_results;  // slot 0
-  l.seq = 0;
-  l.ll = nullptr;
-  l.k3_blocks = 0;
-  // the device-folding instantiation (the one the map-sharded factors use): it takes its point count from the device
-  MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), static_cast<int>(icp->n), 1, ctx->stream));
-  l.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
-  l.eig = static_cast<const double *>(icp->d_eig.p);
-  l.nv = icp->binary ? 13 : 7;
-  l.src = static_cast<const float4 *>(icp->d_src.p);
-  l.n = static_cast<int>(icp->n);
-  std::memcpy(l.R, icp->split_R, sizeof(l.R));
-  l.normal = static_cast<const double *>(icp->d_normal.p);
-  l.status = static_cast<const int32_t *>(icp->d_status.p);
-  l.partials = static_cast<double *>(icp->d_partials.p);
-  l.ticket = static_cast<unsigned int *>(icp->d_ticket.p) + 1;
-  l.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
-  MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const mh::DeviceResult & d = icp->h_results[0];
-  for (int i = 0; i < 3; ++i) {
-    loc_trans_comp[i] = d.loc_comp[i];
-    loc_rot_comp[i] = d.loc_comp[3 + i];
-  }
-  if (status_hist)
-    for (int i = 0; i < 9; ++i) status_hist[i] = static_cast<int32_t>(d.status_hist[i]);
-  return MH_OK;
-}
-int mh_icp_linearize_finish(mh_icp * icp, const double eigvec_rot[9], const double eigvec_trans[9], double loc_trans_comp[3],
-                            double loc_rot_comp[3], int32_t status_hist[9])
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_finish", [&]() -> int { return mh_icp_linearize_finish_impl(icp, eigvec_rot, eigvec_trans, loc_trans_comp, loc_rot_comp, status_hist); });
 }
 
 static int mh_icp_get_state_impl(const mh_icp * icp, int32_t * status, double * means, double * normals)
@@ -1924,37 +1890,7 @@ int mh_icp_create_from_scan(mh_ctx * ctx, mh_map * map, const mh_scan * s, const
 
 }  // extern "C"
 
-// ---- map-sharded factor (BASELINE configs[2]) ------------------------------------------------
-// No reference counterpart (the reference is single-process).  One process per GPU; the data path between ranks —
-// the all-to-all of migrating points and the two small all-reduces — is the caller's (torch.distributed over RCCL):
-// these entry points produce / consume plain device buffers.
-namespace
-{
-mh::ShardArrays shard_arrays(mh_icp * icp, bool alt)
-{
-  mh::ShardArrays a;
-  a.src = static_cast<float4 *>((alt ? icp->x_src : icp->d_src).p);
-  a.q_da = static_cast<double *>((alt ? icp->x_qda : icp->d_qda).p);
-  a.mean = static_cast<double *>((alt ? icp->x_mean : icp->d_mean).p);
-  a.normal = static_cast<double *>((alt ? icp->x_normal : icp->d_normal).p);
-  a.status = static_cast<int32_t *>((alt ? icp->x_status : icp->d_status).p);
-  a.origin = static_cast<unsigned long long *>((alt ? icp->x_origin : icp->d_origin).p);
-  return a;
-}
-int shard_reserve(mh_icp * icp, size_t n, bool alt, bool keep)
-{
-  mh_ctx * ctx = icp->ctx;
-  const size_t k = n ? n : 1;
-  MH_HIP(ctx, (alt ? icp->x_src : icp->d_src).reserve(k * sizeof(float4), ctx->stream, keep));
-  MH_HIP(ctx, (alt ? icp->x_qda : icp->d_qda).reserve(k * 3 * sizeof(double), ctx->stream, keep));
-  MH_HIP(ctx, (alt ? icp->x_mean : icp->d_mean).reserve(k * 3 * sizeof(double), ctx->stream, keep));
-  MH_HIP(ctx, (alt ? icp->x_normal : icp->d_normal).reserve(k * 3 * sizeof(double), ctx->stream, keep));
-  MH_HIP(ctx, (alt ? icp->x_status : icp->d_status).reserve(k * sizeof(int32_t), ctx->stream, keep));
-  MH_HIP(ctx, (alt ? icp->x_origin : icp->d_origin).reserve(k * sizeof(unsigned long long), ctx->stream, keep));
-  return MH_OK;
-}
-}  // namespace
-
+// ---- contexts on a caller's stream, factors over device-resident clouds (the native sharded path and frameworks that own the stream)
 extern "C" {
 
 static int mh_init_on_stream_impl(int device, void * hip_stream, mh_ctx ** out)
@@ -1984,241 +1920,6 @@ static int mh_icp_create_from_device_impl(mh_ctx * ctx, mh_map * map, const mh_p
 int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg, int is_binary, mh_icp ** out)
 {
   return guarded(ctx, "mh_icp_create_from_device", [&]() -> int { return mh_icp_create_from_device_impl(ctx, map, d_points, n, cfg, is_binary, out); });
-}
-
-static int mh_icp_shard_plan_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, int world,
-                                  int rank, int block_log2, int64_t * send_counts)
-{
-  if (!icp || !R_src || !t_src || !send_counts) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (world < 1 || world > 64 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 10)
-    return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: world in 1..64, 0 <= rank < world, block_log2 in 0..10");
-  if (icp->binary) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: unary factors only");
-  if (icp->ordered) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_plan: create the factor with mh_icp_create_from_device (caller's point order)");
-  if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_plan: calls in flight");
-  MH_HIP(ctx, mh_enter(ctx));
-  const size_t n = icp->n, k = n ? n : 1;
-  if (!icp->origin_ready) {
-    MH_HIP(ctx, icp->d_origin.reserve(k * sizeof(unsigned long long), ctx->stream, false));
-    MH_HIP(ctx, mh::launch_shard_origin(static_cast<unsigned long long *>(icp->d_origin.p), static_cast<uint32_t>(n), static_cast<uint32_t>(rank), ctx->stream));
-    icp->origin_ready = true;
-  }
-  for (DevBuf * b : {&icp->s_keys_a, &icp->s_keys_b, &icp->s_idx_a, &icp->s_idx_b}) MH_HIP(ctx, b->reserve(k * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, icp->s_counts.reserve(64 * sizeof(uint32_t), ctx->stream, false));
-  MH_HIP(ctx, icp->s_temp.reserve(mh::shard_temp_bytes(k), ctx->stream, false));
-  if (!icp->h_counts) MH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&icp->h_counts), 64 * sizeof(uint32_t), hipHostMallocDefault));
-  mh::ShardPose P;
-  pose_inverse_compose(R_src, t_src, R_tgt, t_tgt, P.R, P.t);
-  MH_HIP(ctx, mh::launch_shard_plan(P, static_cast<const float4 *>(icp->d_src.p), static_cast<uint32_t>(n), 1.0 / icp->map->cfg.leaf_size,
-                                    static_cast<uint32_t>(world), static_cast<uint32_t>(rank), block_log2, static_cast<uint32_t *>(icp->s_keys_a.p),
-                                    static_cast<uint32_t *>(icp->s_keys_b.p), static_cast<uint32_t *>(icp->s_idx_a.p),
-                                    static_cast<uint32_t *>(icp->s_idx_b.p), static_cast<uint32_t *>(icp->s_counts.p), icp->s_temp.p, icp->s_temp.cap,
-                                    ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(icp->h_counts, icp->s_counts.p, static_cast<size_t>(world) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  uint32_t movers = 0;
-  for (int r = 0; r < world; ++r) {
-    send_counts[r] = icp->h_counts[r];
-    movers += icp->h_counts[r];
-  }
-  icp->n_movers = movers;
-  icp->shard_world = world;
-  icp->shard_rank = rank;
-  icp->shard_log2 = block_log2;
-  icp->plan_open = true;
-  return MH_OK;
-}
-int mh_icp_shard_plan(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, int world, int rank,
-                      int block_log2, int64_t * send_counts)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_plan",
-                 [&]() -> int { return mh_icp_shard_plan_impl(icp, R_src, t_src, R_tgt, t_tgt, world, rank, block_log2, send_counts); });
-}
-
-static int mh_icp_shard_pack_impl(mh_icp * icp, void * d_send)
-{
-  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: icp is NULL");
-  mh_ctx * ctx = icp->ctx;
-  if (!icp->plan_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: no mh_icp_shard_plan before");
-  icp->plan_open = false;
-  if (icp->n_movers == 0) return MH_OK;  // nothing leaves: the arrays stay as they are
-  if (!d_send) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_pack: d_send is NULL");
-  MH_HIP(ctx, mh_enter(ctx));
-  const size_t n = icp->n;
-  int rc = shard_reserve(icp, n, true, false);
-  if (rc != MH_OK) return rc;
-  MH_HIP(ctx, mh::launch_shard_pack(shard_arrays(icp, false), shard_arrays(icp, true), static_cast<const uint32_t *>(icp->s_idx_b.p),
-                                    static_cast<uint32_t>(n), icp->n_movers, static_cast<mh::ShardRecord *>(d_send), ctx->stream));
-  std::swap(icp->d_src, icp->x_src);
-  std::swap(icp->d_qda, icp->x_qda);
-  std::swap(icp->d_mean, icp->x_mean);
-  std::swap(icp->d_normal, icp->x_normal);
-  std::swap(icp->d_status, icp->x_status);
-  std::swap(icp->d_origin, icp->x_origin);
-  icp->n = n - icp->n_movers;
-  icp->n_movers = 0;
-  icp->cold = false;  // the state arrays are explicit from now on (they were zero-initialised at creation)
-  return MH_OK;
-}
-int mh_icp_shard_pack(mh_icp * icp, void * d_send)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_pack", [&]() -> int { return mh_icp_shard_pack_impl(icp, d_send); });
-}
-
-static int mh_icp_shard_unpack_impl(mh_icp * icp, const void * d_recv, size_t n_recv)
-{
-  if (!icp || (!d_recv && n_recv)) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_unpack: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (!icp->origin_ready) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_unpack: no mh_icp_shard_plan before");
-  if (n_recv == 0) return MH_OK;
-  if (icp->n + n_recv > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_shard_unpack: cloud too large");
-  MH_HIP(ctx, mh_enter(ctx));
-  const int rc = shard_reserve(icp, icp->n + n_recv, false, true);
-  if (rc != MH_OK) return rc;
-  MH_HIP(ctx, mh::launch_shard_unpack(shard_arrays(icp, false), static_cast<uint32_t>(icp->n), static_cast<const mh::ShardRecord *>(d_recv),
-                                      static_cast<uint32_t>(n_recv), ctx->stream));
-  icp->n += n_recv;
-  icp->cold = false;
-  return MH_OK;
-}
-int mh_icp_shard_unpack(mh_icp * icp, const void * d_recv, size_t n_recv)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_unpack", [&]() -> int { return mh_icp_shard_unpack_impl(icp, d_recv, n_recv); });
-}
-
-static int mh_icp_shard_get_state_impl(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals)
-{
-  if (!icp) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_icp_shard_get_state: icp is NULL");
-  mh_ctx * ctx = icp->ctx;
-  MH_HIP(ctx, mh_enter(ctx));
-  const size_t n = icp->n;
-  if (n == 0) return MH_OK;
-  if (origin) {
-    if (!icp->origin_ready) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_shard_get_state: no mh_icp_shard_plan before");
-    MH_HIP(ctx, hipMemcpyAsync(origin, icp->d_origin.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  }
-  if (status) MH_HIP(ctx, hipMemcpyAsync(status, icp->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (means) MH_HIP(ctx, hipMemcpyAsync(means, icp->d_mean.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (normals) MH_HIP(ctx, hipMemcpyAsync(normals, icp->d_normal.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MH_OK;
-}
-int mh_icp_shard_get_state(mh_icp * icp, uint64_t * origin, int32_t * status, double * means, double * normals)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_shard_get_state", [&]() -> int { return mh_icp_shard_get_state_impl(icp, origin, status, means, normals); });
-}
-
-static int mh_icp_linearize_begin_device_impl(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32)
-{
-  if (!icp || !d_sums32) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin_device: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (icp->binary) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_icp_linearize_begin_device: unary factors only");
-  if (icp->n_pending) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_begin_device: calls in flight");
-  static mh_icp_result scratch;  // never read: the epilogue runs on the all-reduced sums
-  mh::IcpArgs a;
-  mh::LocArgs l;
-  bool timed = false;
-  LinearizeTxn txn(icp);
-  const int rc = linearize_prepare(icp, R_src, t_src, nullptr, nullptr, g_unit, &scratch, false, false, a, l, timed);
-  if (rc != MH_OK) return rc;
-  a.host_result = nullptr;  // results stay on the device: the device-folding instantiation (point count read from the device)
-  a.ll = nullptr;
-  if (a.n > 0) {
-    MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), a.n, 1, ctx->stream));
-    a.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
-  }
-  if (a.n > 0)
-    MH_HIP(ctx, mh::launch_linearize(a, false, ctx->stream));
-  else
-    MH_HIP(ctx, hipMemsetAsync(icp->d_result.p, 0, sizeof(mh::DeviceResult), ctx->stream));
-  MH_HIP(ctx, mh::launch_shard_pack_sums(static_cast<const mh::DeviceResult *>(icp->d_result.p), d_sums32, ctx->stream));
-  std::memcpy(icp->split_R, icp->pending[0].R, sizeof(icp->split_R));
-  icp->dev_split_open = true;
-  txn.commit();
-  return MH_OK;
-}
-int mh_icp_linearize_begin_device(mh_icp * icp, const double R_src[9], const double t_src[3], const double g_unit[3], double * d_sums32)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_begin_device",
-                 [&]() -> int { return mh_icp_linearize_begin_device_impl(icp, R_src, t_src, g_unit, d_sums32); });
-}
-
-static int mh_icp_linearize_finish_device_impl(mh_icp * icp, const double * d_global_sums32, double * d_loc16)
-{
-  if (!icp || !d_global_sums32 || !d_loc16) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (!icp->dev_split_open) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_finish_device: no mh_icp_linearize_begin_device before");
-  MH_HIP(ctx, mh_enter(ctx));
-  MH_HIP(ctx, icp->d_eig.reserve(18 * sizeof(double), ctx->stream, false));
-  MH_HIP(ctx, mh::launch_shard_eig(d_global_sums32, static_cast<double *>(icp->d_eig.p), ctx->stream));
-  if (icp->n > 0) {
-    mh::LocArgs l;
-    l.host_result = nullptr;
-    l.seq = 0;
-    l.ll = nullptr;
-    l.k3_blocks = 0;
-    MH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<unsigned int *>(icp->d_ticket.p) + 2), static_cast<int>(icp->n), 1, ctx->stream));
-    l.n_dev = static_cast<const uint32_t *>(icp->d_ticket.p) + 2;
-    l.eig = static_cast<const double *>(icp->d_eig.p);
-    l.nv = 7;
-    l.src = static_cast<const float4 *>(icp->d_src.p);
-    l.n = static_cast<int>(icp->n);
-    l.chunks_per_block = 1;
-    std::memcpy(l.R, icp->split_R, sizeof(l.R));
-    l.normal = static_cast<const double *>(icp->d_normal.p);
-    l.status = static_cast<const int32_t *>(icp->d_status.p);
-    l.partials = static_cast<double *>(icp->d_partials.p);
-    l.ticket = static_cast<unsigned int *>(icp->d_ticket.p) + 1;
-    l.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
-    MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
-  }
-  MH_HIP(ctx, mh::launch_shard_pack_loc(static_cast<const mh::DeviceResult *>(icp->d_result.p), d_loc16, ctx->stream));
-  return MH_OK;
-}
-int mh_icp_linearize_finish_device(mh_icp * icp, const double * d_global_sums32, double * d_loc16)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_linearize_finish_device",
-                 [&]() -> int { return mh_icp_linearize_finish_device_impl(icp, d_global_sums32, d_loc16); });
-}
-
-static int mh_icp_global_epilogue_impl(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out)
-{
-  if (!icp || !sums32 || !loc16 || !out) return fail(icp ? icp->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_icp_global_epilogue: NULL argument");
-  mh_ctx * ctx = icp->ctx;
-  if (!icp->dev_split_open || icp->n_pending != 1) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_global_epilogue: no open two-phase linearize");
-  icp->dev_split_open = false;
-  mh::DeviceResult d;
-  std::memset(&d, 0, sizeof(d));
-  for (int i = 0; i < 28; ++i) d.sums[i] = sums32[i];
-  d.n_knn = static_cast<unsigned long long>(sums32[28]);
-  d.n_cand = static_cast<unsigned long long>(sums32[29]);
-  d.n_fallback = static_cast<unsigned long long>(sums32[30]);
-  d.n_scanned = static_cast<unsigned long long>(sums32[31]);
-  for (int i = 0; i < 6; ++i) d.loc_comp[i] = loc16[i];
-  for (int i = 0; i < 9; ++i) d.status_hist[i] = static_cast<unsigned int>(loc16[6 + i]);
-  // localizabilities of the GLOBAL H (geometric_factor.hpp:405-411)
-  double Hr[9], Ht[9];
-  auto ent = [](int r, int c) {
-    if (r > c) std::swap(r, c);
-    return r * 7 - r * (r - 1) / 2 + (c - r);
-  };
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      Hr[3 * r + c] = sums32[ent(r, c)];
-      Ht[3 * r + c] = sums32[ent(3 + r, 3 + c)];
-    }
-  mh::compute_localizability(Hr, d.loc_rot_final, d.eig_rot);
-  mh::compute_localizability(Ht, d.loc_trans_final, d.eig_trans);
-  PendingCall pc = icp->pending[0];
-  pc.components = true;  // loc16 carries them: the two-phase form always runs the component pass
-  icp->n_pending = 0;
-  finish_result(icp, d, pc, out);  // Schur degeneracy info, 4-DoF projection, degeneracy quirk: once, on the global sums
-  out->gpu_ms_linearize = out->gpu_ms_localizability = -1.0f;
-  return MH_OK;
-}
-int mh_icp_global_epilogue(mh_icp * icp, const double sums32[32], const double loc16[16], mh_icp_result * out)
-{
-  return guarded(icp ? icp->ctx : nullptr, "mh_icp_global_epilogue", [&]() -> int { return mh_icp_global_epilogue_impl(icp, sums32, loc16, out); });
 }
 
 }  // extern "C"

@@ -633,8 +633,6 @@ struct mh_icp
   bool rec_side[2] = {false, false};
   bool side_used = false;
   bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
-  double split_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // delta rotation of an open mh_icp_linearize_begin
-  bool split_open = false;
   mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly (two-phase callers)
   mh::DeviceResult * d_h_results = nullptr;  // its device-side address
   uint4 * h_ll = nullptr;     // pinned, mapped ring of flagged-word slots (icp_device.hpp): what a plain call's kernels publish
@@ -657,8 +655,6 @@ struct mh_icp
   uint32_t * h_counts = nullptr;  // pinned
   bool origin_ready = false, plan_open = false;
   uint32_t n_movers = 0;
-  int shard_world = 0, shard_rank = 0, shard_log2 = 3;
-  bool dev_split_open = false;
 };
 
 // mh_api.hip internals used by shard_api.hip

@@ -67,6 +67,7 @@ struct RcclApi
   decltype(&ncclAllToAll) AllToAll = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;  // optional
   decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
   std::string err;
 };
@@ -100,6 +101,7 @@ RcclApi & rccl()
     MH_SYM(GetErrorString, "ncclGetErrorString")
     MH_SYM(GetVersion, "ncclGetVersion")
     api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(api.lib, "ncclCommGetAsyncError"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
 #undef MH_SYM
   });
   return api;
@@ -525,6 +527,20 @@ void mh_shard_comm_destroy(mh_shard_comm * comm)
 int mh_shard_comm_world(const mh_shard_comm * comm) { return comm ? comm->world : 0; }
 int mh_shard_comm_rank(const mh_shard_comm * comm) { return comm ? comm->rank : -1; }
 const char * mh_shard_comm_backend(const mh_shard_comm * comm) { return !comm ? "" : (comm->is_rccl ? "rccl" : "local"); }
+int mh_shard_comm_info(const mh_shard_comm * comm, int * ranks_in_communicator, int * rccl_version)
+{
+  if (!comm) return MH_ERR_INVALID_ARG;
+  int n = comm->world, v = 0;
+  if (comm->is_rccl) {
+    // what RCCL itself says about the communicator (not what the caller passed in): a driver can see that N ranks really joined
+    RcclApi & api = rccl();
+    if (api.CommCount && comm->nccl && api.CommCount(comm->nccl, &n) != ncclSuccess) n = -1;
+    if (api.GetVersion && api.GetVersion(&v) != ncclSuccess) v = 0;
+  }
+  if (ranks_in_communicator) *ranks_in_communicator = n;
+  if (rccl_version) *rccl_version = v;
+  return MH_OK;
+}
 
 void mh_shard_icp_destroy(mh_shard_icp * S)
 {

@@ -1,8 +1,8 @@
-"""Multi-GPU layer for the geometric factor (BASELINE configs[2]): the map sharded by spatial hash
-across the GPUs of a node, every source point linearized on the rank that owns the centre voxel of its CURRENT position,
-partial Hessians combined with two small all-reduces.  One process per GPU; torch.distributed carries the exchange
-(backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU tests).  Plumbing, not arithmetic: the kernels are behind the
-C ABI (mh_map_insert_shard, mh_icp_shard_*, mh_icp_linearize_begin_device / _finish_device, mh_icp_global_epilogue).
+"""Test harness (NOT product code): a host-staged, backend-agnostic restatement of the map-sharding protocol of SURVEY.md 8(e) over
+torch.distributed — what the CPU suite runs at world size 2 over gloo with the oracle standing in for the device backend
+(tests/test_dist_cpu.py).  The product's multi-GPU path is the NATIVE one behind the C ABI (mh_map_insert_shard + mh_shard_*,
+mimosa_amd/csrc/shard_api.hip: RCCL inside the library); until round 5 this file lived in the package next to a device form that
+drove caller-side collectives through C entry points which ABI version 2 no longer has.
 
 Partition.  Voxels are grouped into shard blocks of 8 x 8 x 8 voxels (4 m cubes at the 0.5 m leaf); block b is owned by
 rank  XORVector3iHash(b) mod P  (the reference's hash, include/mimosa/lidar/utils.hpp:228-238).  Besides the voxels of its
@@ -12,17 +12,10 @@ subsequence in the original order, so a voxel has identical contents on every ra
 of its centre voxel therefore finds all 1/7/19/27 neighbour voxels locally, bit-identically.
 
 Per linearize (the pose changes between Gauss-Newton iterations, so does the owner of points near block borders):
-  plan     owner of every local point at the new pose (kernel) -> counts          C0  all_to_all of the counts (P int64)
-  migrate  points that changed owner leave WITH their data-association state      C1  all_to_all(v) of 112-byte records
-           (q_da, mean, normal, status: geometric_factor.hpp:279-317's cache), the rest is compacted; arrivals appended
+  plan     owner of every local point at the new pose -> counts                   C0  all_to_all of the counts (P int64)
+  migrate  points that changed owner leave WITH their data-association state      C1  all_to_all(v) of the records
   K3       local linearize up to the raw Hessian sums                             C3a all_reduce(SUM) of 32 doubles
   K4       component localizabilities in the eigenbasis of the GLOBAL H           C3b all_reduce(SUM) of 16 doubles
-  epilogue degeneracy info / 4-DoF / degeneracy projection once, on the global sums (host, 48 doubles)
-
-Two implementations of the same protocol:
-  ShardedICPDevice  the product path: device tensors end to end, HIP kernels through the C ABI
-  ShardedICP        host-staged, backend-agnostic (a factory for maps / factors is injected): what the CPU suite runs over
-                    gloo with the oracle standing in for the device backend
 """
 from __future__ import annotations
 
@@ -111,119 +104,6 @@ def all_reduce_sum(dist, comm, t):
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=comm)
     return t
-
-
-class ShardedICPDevice:
-    """One rank's view of a map-sharded scan-to-map factor; everything between the calls stays on the device."""
-
-    def __init__(self, comm, ctx, leaf: float, reg_cfg, device):
-        import torch
-        import torch.distributed as dist
-        from . import capi
-        self.torch, self.dist, self.comm, self.capi = torch, dist, comm, capi
-        self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
-        self.ctx, self.L, self.leaf, self.reg, self.device = ctx, ctx.L, leaf, reg_cfg, device
-        self.map = None
-        self.fh = None
-        self.sums = torch.zeros(32, dtype=torch.float64, device=device)
-        self.loc = torch.zeros(16, dtype=torch.float64, device=device)
-        self.n_migrated = 0
-
-    def build_map(self, insert_batches, **map_kw):
-        """insert_batches: iterable of float32 (n,3) arrays, identical on every rank (one iVox insert call each)."""
-        self.map = self.capi.VoxelMap(self.ctx, **map_kw)
-        for xyz in insert_batches:
-            xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
-            self.ctx.check(self.L.mh_map_insert_shard(self.map.h, xyz.ctypes.data_as(C.c_void_p), len(xyz), 3, self.world, self.rank,
-                                                      SHARD_BLOCK_LOG2))
-        return self.map
-
-    def set_scan(self, my_points):
-        """This rank's slice of the scan (POINT_DTYPE records): uploaded once, routed by the first linearize."""
-        pts = np.ascontiguousarray(my_points)
-        t = self.torch.from_numpy(pts.view(np.uint8).reshape(-1, 32).copy()).to(self.device)
-        self.torch.cuda.current_stream(self.device).synchronize()
-        h = C.c_void_p()
-        self.ctx.check(self.L.mh_icp_create_from_device(self.ctx.h, self.map.h, C.c_void_p(t.data_ptr()), len(pts), C.byref(self.reg), 0, C.byref(h)))
-        self.ctx.synchronize()
-        if self.fh is not None:
-            self.L.mh_icp_destroy(self.fh)
-        self.fh = h
-
-    def linearize(self, R, t, g_unit=(0.0, 0.0, -1.0)) -> dict:
-        capi, L, torch = self.capi, self.L, self.torch
-        R, tv, g = capi._f64(R), capi._f64(t), capi._f64(g_unit)
-        p = capi._p
-        sc = np.zeros(self.world, np.int64)
-        self.ctx.check(L.mh_icp_shard_plan(self.fh, p(R), p(tv), None, None, self.world, self.rank, SHARD_BLOCK_LOG2, p(sc)))
-        rc, moving = exchange_counts(self.dist, self.comm, sc, self.device)                             # C0
-        send = torch.empty((int(sc.sum()), RECORD_BYTES), dtype=torch.uint8, device=self.device)
-        self.ctx.check(L.mh_icp_shard_pack(self.fh, C.c_void_p(send.data_ptr()) if len(send) else None))
-        if moving:  # a global fact: every rank enters the record exchange or none does
-            self._sync_for_torch()
-            recv = all_to_all_rows(self.dist, self.comm, send, sc, rc)                                   # C1
-            self._sync_from_torch()
-            self.ctx.check(L.mh_icp_shard_unpack(self.fh, C.c_void_p(recv.data_ptr()) if len(recv) else None, len(recv)))
-            self._keep = recv
-        self.n_migrated = int(rc.sum())
-        self.ctx.check(L.mh_icp_linearize_begin_device(self.fh, p(R), p(tv), p(g), C.c_void_p(self.sums.data_ptr())))
-        self._sync_for_torch()
-        all_reduce_sum(self.dist, self.comm, self.sums)                                                 # C3a
-        self._sync_from_torch()
-        self.ctx.check(L.mh_icp_linearize_finish_device(self.fh, C.c_void_p(self.sums.data_ptr()), C.c_void_p(self.loc.data_ptr())))
-        self._sync_for_torch()
-        all_reduce_sum(self.dist, self.comm, self.loc)                                                  # C3b
-        host = torch.cat([self.sums, self.loc]).cpu().numpy()
-        out = capi.IcpResult()
-        s32, l16 = np.ascontiguousarray(host[:32]), np.ascontiguousarray(host[32:])
-        self.ctx.check(L.mh_icp_global_epilogue(self.fh, p(s32), p(l16), C.byref(out)))
-        d = out.as_dict()
-        d["n_local"] = int(L.mh_icp_size(self.fh))
-        d["n_migrated_in"] = self.n_migrated
-        return d
-
-    # the context runs on torch's current stream when created with on_torch_stream(); otherwise order explicitly
-    def _sync_for_torch(self):
-        if not getattr(self.ctx, "on_torch_stream", False):
-            self.ctx.synchronize()
-
-    def _sync_from_torch(self):
-        if not getattr(self.ctx, "on_torch_stream", False):
-            self.torch.cuda.current_stream(self.device).synchronize()
-
-    def state(self):
-        """(origin, status, mean, normal) of the points this rank holds now."""
-        n = int(self.L.mh_icp_size(self.fh))
-        origin, st = np.empty(n, np.uint64), np.empty(n, np.int32)
-        mean, nrm = np.empty((n, 3)), np.empty((n, 3))
-        p = self.capi._p
-        self.ctx.check(self.L.mh_icp_shard_get_state(self.fh, p(origin), p(st), p(mean), p(nrm)))
-        return origin, st, mean, nrm
-
-    def close(self):
-        if self.fh is not None:
-            self.L.mh_icp_destroy(self.fh)
-            self.fh = None
-        if self.map is not None:
-            self.map.release()
-            self.map = None
-
-
-def context_on_torch_stream(device_index: int):
-    """A libmimosa_hip context bound to torch's current HIP stream: kernels launched through the C ABI, torch tensor ops and
-    the collectives torch enqueues are then ordered by that one stream (no host synchronisation between them)."""
-    import torch
-    from . import capi
-    L = capi.load()
-    h = C.c_void_p()
-    stream = torch.cuda.current_stream(device_index).cuda_stream
-    rc = L.mh_init_on_stream(device_index, C.c_void_p(stream), C.byref(h))
-    if rc != capi.MH_OK:
-        raise capi.MhError(rc, (L.mh_last_error(None) or b"").decode())
-    ctx = capi.Context.__new__(capi.Context)
-    ctx.L, ctx.h, ctx.device, ctx._children, ctx._closing = L, h, device_index, 0, False
-    ctx.on_torch_stream = True
-    return ctx
 
 
 class ShardedICP:

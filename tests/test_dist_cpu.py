@@ -1,4 +1,4 @@
-"""CPU suite, world_size 2 over gloo: the map-sharding layer (mimosa_amd/dist.py) — spatial-hash
+"""CPU suite, world_size 2 over gloo: the map-sharding protocol as restated in tests/dist_harness.py — spatial-hash
 partition with a one-voxel halo, all-to-all routing of the scan, all-reduce of the partial Hessians —
 reproduces the unsharded result.  The CPU oracle stands in for the per-rank device backend here (it is
 the checker; on GPUs the same layer drives mimosa_amd.capi)."""
@@ -39,7 +39,8 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from mimosa_amd import dist as mdist, synth
+    import dist_harness as mdist
+    from mimosa_amd import synth
     from oracle import ref_cpu
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -72,7 +73,8 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_partition_properties():
-    from mimosa_amd import dist as mdist, synth
+    import dist_harness as mdist
+    from mimosa_amd import synth
     m = synth.make_room(4321, 0, 0, room=np.array([20.0, 14.0, 3.0]))
     masks = [mdist.shard_insert_mask(m, 0.5, 4, r) for r in range(4)]
     assert np.all(np.sum(masks, axis=0) >= 1)          # every point lives somewhere

@@ -94,9 +94,9 @@ def test_configs1_workgroup_size_boundary(ctx, big_world, maps, n):
     gf.destroy()
 
 
-def test_fork_of_a_big_map_keeps_the_source_queryable(ctx, big_world, maps):
-    """mh_map_fork on a map with far more than 512 blocks (the source handle's hash mask must be the one of the
-    table its device mirror holds): factors and k-NN on the SOURCE keep their answers after the fork."""
+def test_copy_of_a_big_map_keeps_the_source_queryable(ctx, big_world, maps):
+    """mh_map_copy of a map with far more than 512 blocks (the source handle's hash mask must be the one of the
+    table its device mirror holds): factors and k-NN on the SOURCE keep their answers after the copy."""
     from mimosa_amd import capi
     from oracle import ref_cpu
 
@@ -109,7 +109,7 @@ def test_fork_of_a_big_map_keeps_the_source_queryable(ctx, big_world, maps):
     before = f_old.linearize(w["R"], w["t"])
     q = np.concatenate([xyz[:300] for xyz in w["map_rooms"][:4]]).astype(np.float64) + 0.04
     _, sq0, found0 = gm.knn(q, 5)
-    g2 = gm.fork()
+    g2 = gm.copy()
     extra = (w["map_rooms"][0][:4000] + np.float32(0.09))
     g2.insert(extra)
     f_old.reset()

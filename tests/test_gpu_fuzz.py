@@ -276,7 +276,7 @@ def test_non_finite_and_far_inputs_do_not_fault(ctx, small_world):
 
 @pytest.mark.parametrize("seed", list(range(6)) + _EXTRA(600))
 def test_random_map_generations_with_live_factors(ctx, seed):
-    """Geometric::updateMap's pattern under random schedules: copy (or fork) -> insert -> occasional LRU purge, while factors
+    """Geometric::updateMap's pattern under random schedules: copy -> insert -> occasional LRU purge, while factors
     built on EARLIER generations stay alive, are re-linearized, cloned and destroyed in random order, and old generations are
     released as soon as the caller lets go of them.  Every factor must keep seeing exactly the generation it was built on
     (the oracle does the same steps with deep copies)."""
@@ -299,9 +299,9 @@ def test_random_map_generations_with_live_factors(ctx, seed):
         if op == 0:      # a factor on the current generation
             sub = np.ascontiguousarray(pts[rng.permutation(len(pts))[: int(rng.choice([64, 500, len(pts)]))]])
             live.append((capi.ICPFactor(ctx, gm, sub, rc), ref_cpu.ICP(rm, sub, rrc)))
-        # the next generation: copy or fork, then insert — the old handle is released right away (factors keep it alive)
-        use_fork = bool(rng.integers(0, 2))
-        new_g = gm.fork() if use_fork else gm.copy()
+        # the next generation: copy, then insert — the old handle is released right away (factors keep it alive)
+        rng.integers(0, 2)  # (the draw the fork / copy choice of ABI version 1 made: keeps the schedules what they were)
+        new_g = gm.copy()
         new_r = rm.copy()
         gm.release()
         gm, rm = new_g, new_r

@@ -226,36 +226,6 @@ def test_async_pipeline_matches_sync(ctx, small_world):
         assert np.array_equal(a["H_ss"], b["H_ss"]) and np.array_equal(a["status_hist"], b["status_hist"])
 
 
-def test_two_phase_linearize_matches_single_call(ctx, small_world):
-    """mh_icp_linearize_begin / _finish (the map-sharded form) with the factor's own eigenvectors
-    reproduces the one-call result; with other eigenvectors it follows geometric_factor.hpp:434-457."""
-    gm, rm, gf, rf = _mk(ctx, small_world)
-    R, t = small_world["R"], small_world["t"]
-    one = gf.linearize(R, t)
-    gf.reset()
-    part = gf.linearize_begin(R, t)
-    assert np.array_equal(part["H_ss"], one["H_ss"]) and np.array_equal(part["status_hist"], one["status_hist"])
-    tc, rc, hist = gf.linearize_finish(one["eigvec_rot"], one["eigvec_trans"])
-    assert np.array_equal(hist, one["status_hist"])
-    assert rel(tc, one["loc_trans_comp"]) <= 1e-12 and rel(rc, one["loc_rot_comp"]) <= 1e-12
-    # arbitrary orthonormal bases: compare with the oracle-side formula on the oracle's per-point state
-    rng = np.random.default_rng(2)
-    Er, Et = np.linalg.qr(rng.normal(size=(3, 3)))[0], np.linalg.qr(rng.normal(size=(3, 3)))[0]
-    gf.reset()
-    gf.linearize_begin(R, t)
-    tc, rc, _ = gf.linearize_finish(Er, Et)
-    rf.linearize(R, t)
-    st, mean, nrm, _ = rf.state()
-    P = np.stack([small_world["pts"]["x"], small_world["pts"]["y"], small_world["pts"]["z"]], 1).astype(np.float64)
-    v = st == 8
-    ns = nrm[v] @ R  # R^T n per row
-    Lrot = np.cross(ns, P[v])
-    Lrot /= np.linalg.norm(Lrot, axis=1, keepdims=True)
-    a = np.abs(-ns @ Et); a[a < 0.5] = 0
-    b = np.abs(Lrot @ Er); b[b < 0.5] = 0
-    assert rel(tc, a.sum(0)) <= 1e-10 and rel(rc, b.sum(0)) <= 1e-10
-
-
 @pytest.mark.parametrize("n", [1, 63, 511, 513, 1000])
 def test_ragged_cloud_sizes(ctx, small_world, n):
     """Cloud sizes around the 512-thread workgroup / 64-lane wave boundaries."""
@@ -378,9 +348,9 @@ def test_keyframe_update_copy_then_insert_on_the_device(ctx, small_world):
     assert_result_parity(gf.linearize(small_world["R"], small_world["t"]), rf.linearize(small_world["R"], small_world["t"]))
 
 
-def test_fork_is_a_copy_and_both_maps_stay_writable(ctx, small_world):
-    """mh_map_fork (round-1 name) == mh_map_copy now: a factor built on the source keeps its answers while the fork
-    grows, and the source accepts inserts of its own afterwards."""
+def test_copy_keeps_both_maps_writable(ctx, small_world):
+    """mh_map_copy (Geometric::updateMap's copy-then-insert, geometric.cpp:494): a factor built on the source keeps its answers
+    while the copy grows, and the source accepts inserts of its own afterwards."""
     from mimosa_amd import capi
     from oracle import ref_cpu
 
@@ -393,7 +363,7 @@ def test_fork_is_a_copy_and_both_maps_stay_writable(ctx, small_world):
     f_old = capi.ICPFactor(ctx, gm, w["pts"], cfg)
     r_old = f_old.linearize(w["R"], w["t"])
     cloud_before = gm.get_cloud()
-    g2, rm2 = gm.fork(), rm.copy()
+    g2, rm2 = gm.copy(), rm.copy()
     g2.insert(w["map_xyz"][half:])
     rm2.insert(w["map_xyz"][half:])
     assert np.array_equal(g2.get_cloud(), rm2.export()[2]) and g2.stats()["n_points"] == rm2.num_points

@@ -197,23 +197,10 @@ def run(E, line, real_stdout):
                 mkw = dict(leaf=cfgd["target_ivox_map_leaf_size"], min_dist=cfgd["target_ivox_map_min_dist_in_voxel"], max_pts=synth.MAX_PTS_PER_VOXEL,
                            mode=synth.ENWIDE_NEIGHBOR_MODE, lru_horizon=synth.ENWIDE_LRU_HORIZON)
                 if dry and world > 1:
-                    # tests only: several ranks on ONE GPU — RCCL refuses that, so the caller-driven form of the protocol
-                    # (mimosa_amd/dist.py over gloo) stands in; the native path at world > 1 is covered by the in-process
-                    # transport in tests/test_gpu_shard_native.py
-                    import torch
-                    from mimosa_amd import dist as mdist
-                    lctx = mdist.context_on_torch_stream(local_rank)
-                    sh = mdist.ShardedICPDevice(dist.group.WORLD, lctx, cfgd["target_ivox_map_leaf_size"], capi.make_reg_config(**cfgd), torch.device("cuda", local_rank))
-                    sh.build_map((xyz for _, _, xyz in synth.make_map_rooms(snx, sny)), **mkw)
-                    sh.set_scan(np.array_split(spts, world)[rank])
-                    first_s = sh.linearize(R, t)
-                    nloc = torch.tensor([float(first_s["n_local"])], dtype=torch.float64, device="cuda")
-                    nmax = nloc.clone()
-                    _all_reduce(nloc, op=dist.ReduceOp.SUM)
-                    _all_reduce(nmax, op=dist.ReduceOp.MAX)
-                    box["result"] = {"n_ranks": world, "backend": "gloo (dry run, caller-driven protocol)", "scan_points_total": int(nloc[0].item()),
-                                     "scan_points_max_per_rank": int(nmax[0].item()), "status_hist": [int(v) for v in first_s["status_hist"]]}
-                    sh.close()
+                    # tests only: several ranks on ONE GPU — RCCL refuses two ranks on one device, and the native path is the only
+                    # sharded path (ABI version 2); its world > 1 form is covered by the in-process transport in
+                    # tests/test_gpu_shard_native.py / test_gpu_shard_fullsize.py
+                    box["result"] = {"n_ranks": world, "skipped": "dry run: several ranks on one device (RCCL cannot form the communicator)"}
                     return
                 # the communicator: rank 0 draws the ncclUniqueId, torch.distributed (already up for the replica leg) carries it
                 uid = capi.ShardComm.unique_id() if rank == 0 else None
@@ -239,7 +226,8 @@ def run(E, line, real_stdout):
                 thr = _throughput_forms(False, vmap, comm, clouds, args.steps, f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
                 result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
                                        f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
-                           "n_ranks": comm.world, "backend": comm.backend, "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
+                           "n_ranks": comm.world, "backend": comm.backend, "rccl_ranks": comm.info()["ranks_in_communicator"],
+                           "rccl_version": comm.info()["rccl_version"], "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
                            "map_build_s": round(build_s, 2), **res, "throughput": thr}
                 if world == 1:
                     result["full_protocol_forced"] = _native_leg(True, vmap, comm, spts, ksh)
