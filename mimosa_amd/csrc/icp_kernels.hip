@@ -36,6 +36,9 @@
 #ifndef MH_PIPE
 #define MH_PIPE 4  // quads in flight per lane in the neighbour scan (knn_query)
 #endif
+#ifndef MH_PIPE_SMALL
+#define MH_PIPE_SMALL 4  // the same for the 256-thread workgroup class (6 and 8 measured in round 5: 21.6 / 21.7 / 21.4 us at 24 576 points — no effect)
+#endif
 // Work sharing inside a workgroup (knn_query, "share") — an EXPERIMENT, compiled out by default: a lane that still has
 // MH_SHARE_MIN_VOX neighbour voxels to enter after MH_SHARE_TRIP trips of the scan posts MH_SHARE_HELPERS of every
 // (MH_SHARE_HELPERS + 1) of them as jobs in LDS; waves of the same workgroup whose own scans are over claim and scan them.
@@ -441,14 +444,14 @@ __device__ __forceinline__ void box_dists(const float qg0, const float qg1, cons
 
 // One trip of the neighbour scan: the kPipe quads in flight are merged into the top-KK, each stage is refilled from the
 // cursor first.  Returns the number of live quads this lane consumed.
-template <int KK, int NOFF>
-__device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage (&stage)[MH_PIPE], uint32_t (&ck)[KK], const KeyConsts & kc,
+template <int KK, int NOFF, int PIPE>
+__device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage (&stage)[PIPE], uint32_t (&ck)[KK], const KeyConsts & kc,
                                               const uint32_t * list, int lds_stride, const float4 * lut4, const uint4 * qbuckets,
                                               const float cx0, const float cy1, const float cz2, uint32_t & n_scanned)
 {
   uint32_t live_quads = 0u;
 #pragma unroll
-  for (int u = 0; u < MH_PIPE; ++u) {
+  for (int u = 0; u < PIPE; ++u) {
     const ScanStage st = stage[u];
     stage[u] = cur.advance(list, lds_stride, lut4, qbuckets);  // refill this stage
     n_scanned += st.vcnt;
@@ -516,7 +519,7 @@ struct KnnPoints
   uint32_t member;  // bit u: pt[u] is one of the k nearest
 };
 constexpr int knn_survivors(int K) { return K + 3 + (K > 5 ? 1 : 0); }  // 8 for k = 5, 12 for the generic k <= 8 path
-template <int K, int NOFF, bool SHARE = false, bool FAST = false>
+template <int K, int NOFF, bool SHARE = false, bool FAST = false, int PIPE = MH_PIPE>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
@@ -657,7 +660,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint32_t extra_scanned = 0u;  // share: scan positions a helper entered for this lane
   uint32_t donated = 0u;        // share: scan positions posted as jobs and not (yet) taken back
   {
-    constexpr int kPipe = MH_PIPE;
+    constexpr int kPipe = PIPE;
     const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
     const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
     const uint32_t lane_ = threadIdx.x & 63u;
@@ -777,7 +780,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
       ++trips;
       myq +=
 #endif
-        scan_trip<KK, NOFF>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
+        scan_trip<KK, NOFF, kPipe>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
     }
     rem = cur.rem;
 #ifdef MH_FAKE_MID_BARRIER  // tuning experiment only (hangs unless every wave of the block gets here): what a block-wide
@@ -825,7 +828,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
             hc.rem &= keep;
             h_alive &= keep;
           }
-          scan_trip<KK, NOFF>(hc, stage, hk, kc, hlist, lds_stride, lut4, map.qbuckets, hx0, hy1, hz2, h_scanned);
+          scan_trip<KK, NOFF, kPipe>(hc, stage, hk, kc, hlist, lds_stride, lut4, map.qbuckets, hx0, hy1, hz2, h_scanned);
         }
         if (hj) {
 #pragma unroll
@@ -1457,7 +1460,10 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       constexpr bool kFast = K == 5;  // k == K: the nearest points as a set (knn_query, FAST)
       constexpr int KS = knn_survivors(K);
       [[maybe_unused]] KnnPoints<KS> sel;
-      const uint32_t n_cand = knn_query<K, NOFF, kShare, kFast>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share,
+      // quads in flight per lane: the 256-thread class (clouds of up to 65 536 points: at most one wave per SIMD, the scan waits
+      // on memory, registers are plentiful) runs a deeper pipeline than the 512-thread class (two waves per SIMD: VALU-bound)
+      constexpr int kPipeK3 = TPB <= 256 ? MH_PIPE_SMALL : MH_PIPE;
+      const uint32_t n_cand = knn_query<K, NOFF, kShare, kFast, kPipeK3>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share,
                                                                 kFast ? &sel : nullptr);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
@@ -2307,6 +2313,8 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 #ifndef MH_TPB_SPLIT
 #define MH_TPB_SPLIT 65536  // clouds up to this many points run 256-thread workgroups, larger ones 512
 #endif
+// (round 5, timing-only variants: 128- and 64-thread workgroups for the small class change nothing — K3 at 24 576 points 21.5 /
+// 21.2 / 21.2 us by rocprofv3 for 256 / 128 / 64 threads: the kernel is one wave's dependent chain wherever its neighbours run)
 static int linearize_tpb(int n) { return n <= MH_TPB_SPLIT ? 256 : kThreads; }
 int linearize_class(int n) { return linearize_tpb(n); }
 int linearize_grid(int n)
