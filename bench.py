@@ -154,10 +154,14 @@ def setup(args) -> Env:
     E._R, E._g = np.ascontiguousarray(E.R, np.float64), np.ascontiguousarray([0.0, 0.0, -1.0], np.float64)
     E._out = capi.IcpResult()
 
-    def raw_linearize(tvec):  # the raw C-ABI call with pre-marshalled arguments: what a C++ caller pays
-        _t = np.ascontiguousarray(tvec, np.float64)
-        rc = E.ctx.L.mh_icp_linearize(E.factor.h, E._R.ctypes.data_as(C.c_void_p), _t.ctypes.data_as(C.c_void_p), None, None,
-                                      E._g.ctypes.data_as(C.c_void_p), C.byref(E._out))
+    E._t = np.array(E.t, np.float64)  # written in place by raw_set_t: the argument tuple below is marshalled ONCE
+    _lin, _raw = E.ctx.L.mh_icp_linearize, (E.factor.h, E._R.ctypes.data_as(C.c_void_p), E._t.ctypes.data_as(C.c_void_p), None, None,
+                                            E._g.ctypes.data_as(C.c_void_p), C.byref(E._out))
+
+    def raw_linearize(tvec=None):  # the raw C-ABI call, nothing but the foreign call inside: what a C++ caller pays
+        if tvec is not None:
+            E._t[:] = tvec
+        rc = _lin(*_raw)
         assert rc == 0, rc
     E.barrier, E.run_steps, E.raw_linearize = barrier, run_steps, raw_linearize
     return E

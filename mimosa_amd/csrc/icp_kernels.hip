@@ -233,7 +233,7 @@ __device__ __forceinline__ double lane_get(double v, int l)
 #ifdef MH_TIMELINE
 #define MH_STAMP4(ptr, i)                                                                                          \
   do {                                                                                                             \
-    if ((ptr) && (threadIdx.x & 63) == 0)                                                                          \
+    if ((ptr) && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < static_cast<unsigned int>(NW))                    \
       (ptr)[(static_cast<size_t>(block_id) * NW + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime();  \
   } while (0)
 #else
@@ -1915,6 +1915,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
 // (512 - 2 x 168 = 176 registers per lane are what K3 leaves of a SIMD's file)
 #define MH_LOC_VGPRS __attribute__((amdgpu_waves_per_eu(3, 8)))  // at most 168 registers per lane
 __host__ __device__ constexpr int loc_tpb(int tpb, bool shard) { return (!shard && tpb > 256) ? 256 : tpb; }
+__host__ __device__ constexpr int loc_threads(int tpb, bool shard) { return loc_tpb(tpb, shard) + (shard ? 0 : 64); }  // + the decomposition wave (XW)
 // A K4 workgroup of a plain factor takes kLocChunks chunks of 256 points whatever K3's class was: 1024 points, i.e. 4 of K3's
 // workgroups of the 256-thread class or MH_LOC_BLOCKS_512 = 2 of the 512-thread class (round 4 took 4 = 2048 points per workgroup:
 // 64 workgroups for 131 072 points, a quarter of the CUs, each lane holding 8 chunks' record entries — the projection phase
@@ -1924,10 +1925,16 @@ __host__ __device__ constexpr int loc_tpb(int tpb, bool shard) { return (!shard 
 #endif
 __host__ __device__ constexpr int loc_ch(int tpb, bool shard) { return shard ? 1 : (tpb > 256 ? 2 * MH_LOC_BLOCKS_512 : kLocChunks); }
 
-template <int TPB, bool SHARD, int CH>
+// XW: the workgroup has one wave MORE than TPB / 64 (the synchronous launch of a plain factor): that wave holds no points — it
+// takes part in the fold's barriers and then decomposes H_rr and H_tt on two of its lanes AT ONCE (one SIMD pass for both), while
+// the four point waves issue their 28 loads each; with the decompositions on lanes of two point waves those loads (1.7 k cycles
+// of issue on a wave that has a SIMD to itself) sat in front of the 5 k-cycle decompositions on the kernel's critical path.  The
+// bases are the same bits whichever lane works them out, so the component server's body (no extra wave) agrees to the bit.
+template <int TPB, bool SHARD, int CH, bool XW = false>
 __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
 {
   constexpr int NW = TPB / 64;
+  const bool worker = !XW || threadIdx.x < static_cast<unsigned int>(TPB);  // (wave-uniform)
   __shared__ double s_w[NW][16];
   __shared__ double s_seg[TPB + 96 + 96];  // fold scratch: (TPB / EW) * EW segment sums + EW totals, EW = 32 or 96
   __shared__ bool s_last;
@@ -1942,7 +1949,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   // (geometric_factor.hpp:343-352) are worked out while two lanes of the workgroup decompose H_rr and H_tt.
   // (a plain factor without a record: its component pass is switched off but a batch runs K4 for every member — nothing to
   // read, the host reports NaN for it)
-  const int n_pts = SHARD ? static_cast<int>(*a.n_dev) : (a.rec ? a.n : 0);
+  const int n_pts = !worker ? 0 : (SHARD ? static_cast<int>(*a.n_dev) : (a.rec ? a.n : 0));
   bool side = false;
   if constexpr (!SHARD) {
     side = a.side != 0;
@@ -2039,8 +2046,8 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   __shared__ double s_E[18];
   if (a.eig) {
     if (threadIdx.x < 18) s_E[threadIdx.x] = a.eig[threadIdx.x];
-  } else if (threadIdx.x == TPB - 64 || threadIdx.x == TPB - 128) {
-    const int NV = a.nv, o = threadIdx.x == TPB - 64 ? 3 : 0;
+  } else if (XW ? (threadIdx.x == TPB || threadIdx.x == TPB + 1) : (threadIdx.x == TPB - 64 || threadIdx.x == TPB - 128)) {
+    const int NV = a.nv, o = (XW ? threadIdx.x == TPB + 1 : threadIdx.x == TPB - 64) ? 3 : 0;
     double Hb[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
@@ -2048,7 +2055,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
         Hb[3 * r + c] = sums[rr * NV - rr * (rr - 1) / 2 + (cc - rr)];
       }
     double loc[3], E[9];
-    compute_localizability(Hb, loc, E);
+    if (!sym_eigvec3_fast(Hb, E)) compute_localizability(Hb, loc, E);  // (the vectors only, verified; the full solver behind it)
     for (int q = 0; q < 9; ++q) s_E[(o ? 9 : 0) + q] = E[q];
   }
   MH_STAMP4(a.dbg, 3);
@@ -2097,7 +2104,7 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     hw[g] = f0 | (f1 << 10) | (f2 << 20);
   }
   wave_sum3_to_lane63(hw);
-  if (lane == 63) {
+  if (lane == 63 && worker) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) s_w[wv][j] = v[j];
 #pragma unroll
@@ -2176,10 +2183,10 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   }
 }
 
-template <int TPB, bool SHARD>  // TPB: the class of the K3 launch (256 / 512 threads); this kernel runs loc_tpb(TPB, SHARD) threads
-__global__ __launch_bounds__(loc_tpb(TPB, SHARD)) void icp_localizability_kernel(const LocArgs a)
+template <int TPB, bool SHARD>  // TPB: the class of the K3 launch (256 / 512 threads); this kernel runs loc_threads(TPB, SHARD) threads
+__global__ __launch_bounds__(loc_threads(TPB, SHARD)) void icp_localizability_kernel(const LocArgs a)
 {
-  icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD)>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD), !SHARD>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 template <int TPB>
 __global__ __launch_bounds__(loc_tpb(TPB, false)) void icp_localizability_batch_kernel(const LocArgs * args, const int * start, int n_factors)
@@ -2398,12 +2405,12 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
     if (shard)
       hipLaunchKernelGGL((icp_localizability_kernel<256, true>), grid, dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_localizability_kernel<256, false>), grid, dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((icp_localizability_kernel<256, false>), grid, dim3(loc_threads(256, false)), 0, stream, a);
   } else {
     if (shard)
       hipLaunchKernelGGL((icp_localizability_kernel<kThreads, true>), grid, dim3(kThreads), 0, stream, a);
     else
-      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, false>), grid, dim3(loc_tpb(kThreads, false)), 0, stream, a);
+      hipLaunchKernelGGL((icp_localizability_kernel<kThreads, false>), grid, dim3(loc_threads(kThreads, false)), 0, stream, a);
   }
   return hipGetLastError();
 }

@@ -272,6 +272,70 @@ MH_HD void sym_eigen3(const double A[9], double w[3], double V[9])
   if (!ok) sym_eigen3_jacobi(A, w, V);
 }
 
+// Eigenvectors ONLY (columns of V, eigenvalues ascending), for K4's projections: the decomposition sits on the critical path of
+// the component pass (one lane per 3 x 3 block, a workgroup waiting), and K4 never looks at the eigenvalues (the host derives the
+// localizabilities from the sums itself).  Works on D = (A - q I) / p (trace 0, |D|_F^2 = 6: no separate scaling), eigenvalues as in
+// sym_eigen3, all three eigenvectors as cross products of rows of D - beta I; accepted only if they are orthogonal to 1e-10 and
+// |D v - beta v| <= 2e-13 — otherwise false, and the caller runs sym_eigen3 (Eberly's construction, Jacobi behind it).
+MH_HD bool sym_eigvec3_fast(const double A[9], double V[9])
+{
+  const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
+  const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+  const double c00 = a00 - q, c11 = a11 - q, c22 = a22 - q;
+  const double p2 = (c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12)) * (1.0 / 6.0);
+  if (!(p2 > 1e-280) || !(p2 < 1e280)) return false;  // (also NaN, and a multiple of the identity)
+  const double ip = mh_rsqrt(p2);
+  if (!(p2 * ip * ip > 0.999999)) return false;
+  const double d00 = c00 * ip, d01 = a01 * ip, d02 = a02 * ip, d11 = c11 * ip, d12 = a12 * ip, d22 = c22 * ip;
+  double half_det = 0.5 * (d00 * (d11 * d22 - d12 * d12) - d01 * (d01 * d22 - d12 * d02) + d02 * (d01 * d12 - d11 * d02));
+  half_det = fmin(fmax(half_det, -1.0), 1.0);
+  const double dd = 2.0 * half_det;
+  double br = 1.7320508075688772 + 0.2679491924311228 * fabs(half_det);
+  br = half_det >= 0.0 ? br : -br;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int it = 0; it < 4; ++it) {
+    const double b2 = br * br;
+    br -= ((b2 - 3.0) * br - dd) * mh_rcp1(3.0 * b2 - 3.0);
+  }
+  const double sq = sqrt(fmax(12.0 - 3.0 * br * br, 0.0));
+  const double blo = 0.5 * (-br - sq), bhi = 0.5 * (-br + sq);
+  const double beta[3] = {half_det >= 0.0 ? blo : br, half_det >= 0.0 ? bhi : blo, half_det >= 0.0 ? br : bhi};
+  double v[3][3];
+  bool ok = true;
+  double worst = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 3; ++k) {
+    const double m00 = d00 - beta[k], m11 = d11 - beta[k], m22 = d22 - beta[k];
+    const double x0 = d01 * d12 - d02 * m11, y0 = d02 * d01 - m00 * d12, z0 = m00 * m11 - d01 * d01;
+    const double x1 = d01 * m22 - d02 * d12, y1 = d02 * d02 - m00 * m22, z1 = m00 * d12 - d01 * d02;
+    const double x2 = m11 * m22 - d12 * d12, y2 = d12 * d02 - d01 * m22, z2 = d01 * d12 - m11 * d02;
+    const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    ok = ok && nn > 0.0;
+    const double r = nn > 0.0 ? mh_rsqrt(nn) : 0.0;
+    vx *= r; vy *= r; vz *= r;
+    v[k][0] = vx; v[k][1] = vy; v[k][2] = vz;
+    const double r0 = m00 * vx + d01 * vy + d02 * vz, r1 = d01 * vx + m11 * vy + d12 * vz, r2 = d02 * vx + d12 * vy + m22 * vz;
+    worst = fmax(worst, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
+  }
+  const double dab = v[0][0] * v[1][0] + v[0][1] * v[1][1] + v[0][2] * v[1][2], dac = v[0][0] * v[2][0] + v[0][1] * v[2][1] + v[0][2] * v[2][2],
+               dbc = v[1][0] * v[2][0] + v[1][1] * v[2][1] + v[1][2] * v[2][2];
+  ok = ok && worst <= 2e-13 && fmax(fabs(dab), fmax(fabs(dac), fabs(dbc))) <= 1e-10;
+  if (!ok) return false;
+  for (int k = 0; k < 3; ++k) {
+    V[k] = v[k][0];
+    V[3 + k] = v[k][1];
+    V[6 + k] = v[k][2];
+  }
+  return true;
+}
+
 // computeLocalizability, include/mimosa/utils.hpp:308-313: sqrt(eigenvalues) ascending + eigenvectors
 MH_HD void compute_localizability(const double JtJ[9], double loc[3], double E[9])
 {

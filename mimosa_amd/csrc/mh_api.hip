@@ -266,6 +266,7 @@ void mh_shutdown(mh_ctx * ctx)
     g_wt = WaitTrace{};
   }
   (void)mh_enter(ctx);
+  mhi::shard_ctx_gone(ctx);
   srv_stop(ctx);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);

@@ -667,4 +667,6 @@ int icp_create(mh_ctx * ctx, mh_map * map, const mh_point32 * source, const mh_p
 // argument blocks of one linearize call in pending slot n_pending (claimed); no launch
 int prepare(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt, const double * t_tgt, const double g_unit[3],
             mh_icp_result * out, bool want_flag, mh::IcpArgs & a, mh::LocArgs & l);
+// shard_api.hip: called by mh_shutdown(ctx) so that communicators whose rounds ran on ctx let go of it
+void shard_ctx_gone(mh_ctx * ctx);
 }  // namespace mhi

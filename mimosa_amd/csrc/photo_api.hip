@@ -79,7 +79,11 @@ struct mh_photo
   mh::PhotoModel model{};
   DevBuf d_alt, d_shift, d_hp, d_lp, d_static;
   // per-frame scratch
-  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather;
+  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather, d_stamps;
+  // frame stamps of the four-launch preprocess (photo_scatter_stamp_kernel): zeroed when (re)allocated, seq counts the frames
+  void * stamps_zeroed_at = nullptr;
+  size_t stamps_zeroed_bytes = 0;
+  uint32_t frame_seq = 0;
   // pinned, mapped: [0] the preprocess kernels' counters (project() errors of a frame), [1] the factor kernels' — a factor
   // linearize between mh_photo_preprocess_scan_begin and _commit must not erase or mix into the frame's count
   mh::PhotoCounters * h_counters = nullptr;
@@ -135,7 +139,7 @@ void photo_release(mh_photo * p)
   if (p->next_ev) (void)hipEventDestroy(p->next_ev);
   if (p->scan_ev) (void)hipEventDestroy(p->scan_ev);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
-                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather})
+                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather, &p->d_stamps})
     b->release();
   if (p->h_counters) (void)hipHostFree(p->h_counters);
   if (p->h_int_out) (void)hipHostFree(p->h_int_out);
@@ -314,9 +318,13 @@ int upload_pinned(mh_ctx * ctx, DevBuf & b, const void * pinned_src, size_t byte
 }
 
 // The device part of preprocess on points already resident (d_raw / frame->d_points), then the pose table.
+// scan_cloud: the points are a scan's resident deskewed cloud — the frame's copy (frame->d_points) is still to be made;
+// scan_writeback: the corrected intensities also go straight into scan_cloud (a committing mh_photo_preprocess_scan).
+// *folded says whether both were done inside the chain's launches (else the caller copies first / writes back afterwards).
 int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, size_t n, const uint32_t * unique_ns,
-                      const double * T_Le_Lt, size_t n_groups)
+                      const double * T_Le_Lt, size_t n_groups, mh_point32 * scan_cloud = nullptr, bool scan_writeback = false, bool * folded = nullptr)
 {
+  if (folded) *folded = false;
   mh_ctx * ctx = ph->ctx;
   const mh::PhotoModel & m = ph->model;
   const int rows = m.rows, cols = m.cols, npx = rows * cols;
@@ -357,17 +365,10 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   fr->n_points = n;
   auto * desk = static_cast<mh_point32 *>(fr->d_points.p);
   float * img_raw = static_cast<float *>(ph->d_img_raw.p);
-  MH_HIP(ctx, mh::launch_photo_clear(npx, static_cast<int>(n), img_raw, static_cast<float *>(fr->d_range.p),
-                                     static_cast<uint8_t *>(ph->d_mask_raw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
-                                     static_cast<int32_t *>(fr->d_idx.p), static_cast<int32_t *>(fr->d_proj.p),
-                                     static_cast<float *>(ph->d_int_out.p), pose_src, fr->d_pose_ns.p, pose_bytes, ctx->stream));
   ph->h_counters->project_throw = ph->h_counters->pose_missing = 0;
   const int ni = static_cast<int>(n);
-  MH_HIP(ctx, mh::launch_photo_scatter(m, d_raw, desk, ni, static_cast<float *>(fr->d_yaw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
-                                       img_raw, static_cast<float *>(fr->d_range.p), static_cast<uint8_t *>(ph->d_mask_raw.p),
-                                       static_cast<int32_t *>(fr->d_idx.p), ctx->stream));
   // behind the scatter: the image chain (photometric.cpp:246-320), the mask erosion, the yaw table and the projection index in
-  // THREE multi-job launches (photo_kernels.hip, "Round 4": 13 launches -> 5), or the single-stage kernels when a filter is
+  // the scatter + THREE multi-job launches (photo_kernels.hip, "Round 4": 13 launches -> 5; round 5: no reset launch, 4), or the single-stage kernels when a filter is
   // larger than the tiles were sized for (and with MH_PHOTO_UNFUSED=1, diagnostic)
   const mh_photo_config & c = ph->cfg;
   const float scale = static_cast<float>(static_cast<double>(c.intensity_scale)), gamma = c.intensity_gamma;
@@ -385,12 +386,12 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   pc.intensity_out = static_cast<float *>(ph->d_int_out.p);
   pc.hp = static_cast<const float *>(ph->d_hp.p);
   pc.lp = static_cast<const float *>(ph->d_lp.p);
-  pc.mask_raw = static_cast<const uint8_t *>(ph->d_mask_raw.p);
   pc.static_mask = ph->static_mask.empty() ? nullptr : static_cast<const uint8_t *>(ph->d_static.p);
   pc.mask_out = static_cast<uint8_t *>(fr->d_mask.p);
   pc.yaw = static_cast<float *>(fr->d_yaw.p);
-  pc.yaw_valid = static_cast<const uint8_t *>(ph->d_yaw_valid.p);
   pc.desk_points = desk;
+  pc.desk_src = nullptr;
+  pc.desk_writeback = nullptr;
   pc.proj = static_cast<int32_t *>(fr->d_proj.p);
   pc.counters = ph->d_counters;
   pc.rows = rows;
@@ -408,9 +409,39 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   pc.gamma = gamma;
   static const bool unfused = std::getenv("MH_PHOTO_UNFUSED") != nullptr;
   if (!unfused && mh::photo_stages_fit(pc)) {
+    // four launches, no reset: the marks are frame stamps (zero when allocated, so no frame ever carries the number 0)
+    const size_t sb = static_cast<size_t>(npx) * 2 * sizeof(uint32_t);
+    MH_HIP(ctx, ph->d_stamps.reserve(sb, ctx->stream, false));
+    if (ph->d_stamps.p != ph->stamps_zeroed_at || ph->stamps_zeroed_bytes < sb || ph->frame_seq == 0xFFFFFFFFu) {
+      MH_HIP(ctx, hipMemsetAsync(ph->d_stamps.p, 0, sb, ctx->stream));
+      ph->stamps_zeroed_at = ph->d_stamps.p;
+      ph->stamps_zeroed_bytes = sb;
+      ph->frame_seq = 0;
+    }
+    pc.stamps = static_cast<uint32_t *>(ph->d_stamps.p);
+    pc.seq = ++ph->frame_seq;
+    pc.raw_points = d_raw;
+    pc.raw_w = img_raw;
+    pc.range = static_cast<float *>(fr->d_range.p);
+    pc.idx_w = static_cast<int32_t *>(fr->d_idx.p);
+    pc.copy_src = pose_src;
+    pc.copy_dst = fr->d_pose_ns.p;
+    pc.copy_bytes = pose_bytes;
+    pc.desk_src = scan_cloud;
+    pc.desk_writeback = scan_writeback ? scan_cloud : nullptr;
     MH_HIP(ctx, mh::launch_photo_stages(pc, m, ctx->stream));
+    if (folded) *folded = true;
     return MH_OK;
   }
+  if (scan_cloud && n) MH_HIP(ctx, mh::launch_copy16(scan_cloud, fr->d_points.p, n * sizeof(mh_point32), ctx->stream));
+  // the single-stage kernels (a filter larger than the stage tiles, or MH_PHOTO_UNFUSED=1): reset, scatter, one launch per stage
+  MH_HIP(ctx, mh::launch_photo_clear(npx, static_cast<int>(n), img_raw, static_cast<float *>(fr->d_range.p),
+                                     static_cast<uint8_t *>(ph->d_mask_raw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
+                                     static_cast<int32_t *>(fr->d_idx.p), static_cast<int32_t *>(fr->d_proj.p),
+                                     static_cast<float *>(ph->d_int_out.p), pose_src, fr->d_pose_ns.p, pose_bytes, ctx->stream));
+  MH_HIP(ctx, mh::launch_photo_scatter(m, d_raw, desk, ni, static_cast<float *>(fr->d_yaw.p), static_cast<uint8_t *>(ph->d_yaw_valid.p),
+                                       img_raw, static_cast<float *>(fr->d_range.p), static_cast<uint8_t *>(ph->d_mask_raw.p),
+                                       static_cast<int32_t *>(fr->d_idx.p), ctx->stream));
   MH_HIP(ctx, mh::launch_photo_yaw_fill(m, static_cast<float *>(fr->d_yaw.p), static_cast<const uint8_t *>(ph->d_yaw_valid.p), ctx->stream));
   MH_HIP(ctx, mh::launch_photo_project(m, desk, ni, static_cast<const float *>(fr->d_yaw.p), static_cast<int32_t *>(fr->d_proj.p),
                                        ph->d_counters, ctx->stream));
@@ -943,11 +974,13 @@ int mh_photo_preprocess(mh_photo * photo, const mh_point32 * points_raw, mh_poin
 }
 
 // corrected intensities into the scan's resident cloud (:307-314), ordered before whatever the scan's own stream does next
-static int photo_writeback_scan(mh_photo * photo, PhotoFrame * fr, mh_scan * scan)
+// (already_written: the chain's last launch did it — only the ordering against the scan's stream is left)
+static int photo_writeback_scan(mh_photo * photo, PhotoFrame * fr, mh_scan * scan, bool already_written = false)
 {
   mh_ctx * ctx = photo->ctx;
   if (!scan->c.n_full) return MH_OK;
-  MH_HIP(ctx, mh::launch_photo_sobel_writeback(static_cast<const float *>(fr->d_intensity.p), static_cast<float *>(fr->d_dx.p),
+  if (!already_written)
+    MH_HIP(ctx, mh::launch_photo_sobel_writeback(static_cast<const float *>(fr->d_intensity.p), static_cast<float *>(fr->d_dx.p),
                                                static_cast<float *>(fr->d_dy.p), static_cast<const int32_t *>(fr->d_idx.p),
                                                static_cast<mh_point32 *>(scan->d_full.p), nullptr, photo->cfg.rows, photo->cfg.cols, ctx->stream));
   if (scan->ctx != ctx) {
@@ -980,10 +1013,9 @@ static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double 
     PhotoFrame * fr = new PhotoFrame;
     fr->ctx = ctx;
     hipError_t e = fr->d_points.reserve((n ? n : 1) * sizeof(mh_point32), ctx->stream, false);
-    if (e == hipSuccess && n) e = mh::launch_copy16(scan->d_full.p, fr->d_points.p, n * sizeof(mh_point32), ctx->stream);
     if (e != hipSuccess) {
       frame_release(fr);
-      return hip_fail(ctx, e, "mh_photo_preprocess_scan: frame copy");
+      return hip_fail(ctx, e, "mh_photo_preprocess_scan: frame cloud");
     }
     std::vector<uint32_t> uns(n_groups);
     if (n_groups && scan->n_unique_cached == n_groups) {  // the host copy that came back with mh_scan_prepare_input's counters
@@ -992,7 +1024,11 @@ static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double 
       if (n_groups) MH_HIP(ctx, hipMemcpyAsync(uns.data(), scan->d_unique.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
       MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    int rc = preprocess_device(photo, fr, static_cast<const mh_point32 *>(scan->d_full_raw.p), n, uns.data(), T_Le_Lt, n_groups);
+    // the frame's copy of the cloud is made by the chain's first launch, and a committing call's write-back of the corrected
+    // intensities into the scan by its last (six launches -> four)
+    bool folded = false;
+    int rc = preprocess_device(photo, fr, static_cast<const mh_point32 *>(scan->d_full_raw.p), n, uns.data(), T_Le_Lt, n_groups,
+                               static_cast<mh_point32 *>(scan->d_full.p), commit, &folded);
     if (rc != MH_OK) {
       frame_release(fr);
       return rc;
@@ -1006,7 +1042,7 @@ static int photo_preprocess_scan(mh_photo * photo, mh_scan * scan, const double 
       photo->next_scan = scan;
       return MH_OK;
     }
-    rc = photo_writeback_scan(photo, fr, scan);
+    rc = photo_writeback_scan(photo, fr, scan, folded);
     if (rc != MH_OK) {
       frame_release(fr);
       return rc;

@@ -87,7 +87,8 @@ hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, i
                               int k, hipStream_t stream);
 // detectFeatures' per-pixel part (:524-540): gradient magnitude image
 // Photometric::preprocess behind the scatter — the image chain (photometric.cpp:246-320), the mask erosion (:349-371), the
-// yaw-table fill (:135-199) and the projection index (:218-244) — in three multi-job launches (photo_kernels.hip, "Round 4")
+// yaw-table fill (:135-199) and the projection index (:218-244) — the scatter and three multi-job launches, four in all
+// (photo_kernels.hip, "Round 4" and photo_scatter_stamp_kernel)
 struct PhotoChain
 {
   const float * raw;
@@ -97,15 +98,28 @@ struct PhotoChain
   float * dx;
   float * dy;
   const int32_t * idx;
-  float * intensity_out;
+  float * intensity_out;  // n_pts floats: NaN = the point owns no pixel
   const float * hp;
   const float * lp;
-  const uint8_t * mask_raw;
   const uint8_t * static_mask;
   uint8_t * mask_out;
   float * yaw;
-  const uint8_t * yaw_valid;
-  const mh_point32 * desk_points;
+  const mh_point32 * raw_points;   // the scan as it came (yaw angles)
+  const mh_point32 * desk_points;  // deskewed (image fill, projection): the frame's cloud
+  const mh_point32 * desk_src;     // where the deskewed points are read from when the frame's cloud is still to be filled (the
+                                   // scatter copies them over), or nullptr / == desk_points
+  mh_point32 * desk_writeback;     // a cloud that also receives the corrected intensities (:307-314), or nullptr
+  // no frame-reset launch: per-pixel frame stamps (2 x rows x cols words: [raw point landed | deskewed point in range landed],
+  // zero when allocated; a pixel is marked when its word equals seq != 0), and the arrays the scatter fills
+  uint32_t * stamps;
+  uint32_t seq;
+  float * raw_w;
+  float * range;
+  int32_t * idx_w;
+  // the frame's pose table, copied by a job of stage A: copy_bytes (a multiple of 16) from a mapped pinned block
+  const void * copy_src;
+  void * copy_dst;
+  size_t copy_bytes;
   int32_t * proj;
   PhotoCounters * counters;
   int rows, cols, n_pts, n_hp, n_lp, remove_lines, filter_brightness, bw, bh, do_gauss, erode_k;

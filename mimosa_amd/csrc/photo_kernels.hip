@@ -15,6 +15,7 @@
 // per feature, one lane per patch point, with wave shuffles for the NCC sums and the 28 / 91 Hessian sums.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "photo_device.hpp"
@@ -106,13 +107,58 @@ __global__ __launch_bounds__(kT) void photo_scatter_kernel(const PhotoModel m, c
   }
 }
 
+// Round 5: scatter WITHOUT a reset launch ahead of it.  A pixel's "a raw point landed here" / "a deskewed point in range landed
+// here" marks are 32-bit frame stamps (stamp[px] == seq) instead of bytes that have to be zeroed first; the consumers of the
+// next launch (stage A) read through the stamps, and one of its jobs writes the reset values (intensity / range 0, idx -1)
+// into the pixels no point claimed, so everything behind stage A sees the arrays the reset launch used to leave.  The
+// projection index's "empty" fill and the corrected-intensity NaNs do not depend on the scatter: second and third job here.
+// desk_copy: the frame's own copy of the deskewed cloud when the points are read out of a scan's resident cloud (the copy launch
+// that used to precede the chain); nullptr when desk already is the frame's.
+__global__ __launch_bounds__(kT) void photo_scatter_stamp_kernel(const PhotoModel m, const mh_point32 * raw, const mh_point32 * desk, mh_point32 * desk_copy,
+                                                                  int n, float * yaw, uint32_t * ystamp, uint32_t * pstamp, uint32_t seq, float * intensity,
+                                                                  float * range, int32_t * idx, float * int_out, int32_t * proj, int n_point_blocks)
+{
+  const int npx = m.rows * m.cols;
+  if (static_cast<int>(blockIdx.x) >= n_point_blocks) {
+    const int nb = static_cast<int>(gridDim.x) - n_point_blocks;
+    for (int k = (static_cast<int>(blockIdx.x) - n_point_blocks) * kT + static_cast<int>(threadIdx.x); k < npx * kPhotoDup; k += nb * kT) proj[k] = kProjEmpty;
+    return;
+  }
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  int_out[i] = __uint_as_float(0xFFFFFFFFu);  // NaN = "this point owns no pixel" (stage C overwrites the owners')
+  {
+    const mh_point32 p = raw[i];
+    if (p.idx < static_cast<uint32_t>(npx)) {
+      int u, v;
+      idx_to_pixel(m, p.idx, u, v);
+      yaw[v * m.cols + u] = static_cast<float>(atan2(static_cast<double>(p.y), static_cast<double>(p.x)));  // :127
+      ystamp[v * m.cols + u] = seq;
+    }
+  }
+  {
+    const mh_point32 p = desk[i];
+    if (desk_copy) desk_copy[i] = p;
+    if (p.range < m.range_min || p.range > m.range_max) return;  // :209
+    if (p.idx >= static_cast<uint32_t>(npx)) return;
+    int u, v;
+    idx_to_pixel(m, p.idx, u, v);
+    const int px = v * m.cols + u;
+    intensity[px] = p.intensity;
+    range[px] = p.range;
+    idx[px] = i;
+    pstamp[px] = seq;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // preprocess stage 2: one workgroup per image row
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxCols = 4096;
 constexpr int kYawLdsWords = 3 * kMaxCols + 2 * 1024;  // s_yaw, s_prev, s_next, s_clast, s_cfirst (<= 1024 threads)
 // row v of the yaw table; `lds`: kYawLdsWords words; any workgroup size up to 1024
-__device__ __forceinline__ void yaw_fill_row(const PhotoModel & m, float * yaw, const uint8_t * yaw_valid, const int v, uint32_t * lds)
+__device__ __forceinline__ void yaw_fill_row(const PhotoModel & m, float * yaw, const uint8_t * yaw_valid, const int v, uint32_t * lds,
+                                             const uint32_t * stamp = nullptr, const uint32_t seq = 0)
 {
   float * s_yaw = reinterpret_cast<float *>(lds);
   int * s_prev = reinterpret_cast<int *>(lds + kMaxCols);
@@ -123,16 +169,18 @@ __device__ __forceinline__ void yaw_fill_row(const PhotoModel & m, float * yaw, 
   const int cols = m.cols;
   float * yr = yaw + static_cast<size_t>(v) * cols;
   const uint8_t * vr = yaw_valid + static_cast<size_t>(v) * cols;
+  const uint32_t * sr = stamp ? stamp + static_cast<size_t>(v) * cols : nullptr;
+  auto valid = [&](int u) { return sr ? sr[u] == seq : vr[u] != 0; };
   const int per = (cols + nthr - 1) / nthr, c0 = min(cols, static_cast<int>(threadIdx.x) * per), c1 = min(cols, c0 + per);
   int last = -1, first = -1;
   for (int u = c0; u < c1; ++u) {
-    const bool ok = vr[u] != 0;
+    const bool ok = valid(u);
     s_yaw[u] = ok ? yr[u] : 0.f;
     last = ok ? u : last;
     s_prev[u] = last;  // chunk-local
   }
   for (int u = c1 - 1; u >= c0; --u) {
-    first = vr[u] ? u : first;
+    first = valid(u) ? u : first;
     s_next[u] = first;
   }
   s_clast[threadIdx.x] = last;
@@ -143,7 +191,7 @@ __device__ __forceinline__ void yaw_fill_row(const PhotoModel & m, float * yaw, 
   for (int t = threadIdx.x + 1; t < nthr && carry_next < 0; ++t) carry_next = s_cfirst[t];
   const double kPi = 3.14159265358979323846;
   for (int u = c0; u < c1; ++u) {
-    if (vr[u]) continue;
+    if (valid(u)) continue;
     const int pv = s_prev[u] >= 0 ? s_prev[u] : carry_prev, nx = s_next[u] >= 0 ? s_next[u] : carry_next;
     float out;
     if (pv < 0 && nx < 0) {  // :148-155 no valid column in this row
@@ -280,19 +328,25 @@ __global__ __launch_bounds__(kT) void photo_proj_finalize_kernel(int n_pixels, i
 constexpr int kVT_R = 16, kVT_C = 64;  // 8 x 16 = 128 workgroups for a 128 x 1024 image
 constexpr int kVfirLdsWords = (kVT_R + kPhotoMaxTaps - 1) * kVT_C + kPhotoMaxTaps;
 __device__ __forceinline__ void vfir_tile(const float * in, float * out, int rows, int cols, const float * taps, int n_taps, float scale, float gamma,
-                                          const int bx, const int by, uint32_t * pool)
+                                          const int bx, const int by, uint32_t * pool, const uint32_t * stamp = nullptr, const uint32_t seq = 0)
 {
+  const int nthr = static_cast<int>(blockDim.x);
   float * s_tile = reinterpret_cast<float *>(pool);
   float * s_taps = s_tile + (kVT_R + kPhotoMaxTaps - 1) * kVT_C;
   const int a = n_taps / 2, r0 = by * kVT_R, c0 = bx * kVT_C, th = kVT_R + n_taps - 1;
-  for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
-  for (int e = threadIdx.x; e < th * kVT_C; e += kT) {
+  for (int t = threadIdx.x; t < n_taps; t += nthr) s_taps[t] = taps[t];
+  for (int e = threadIdx.x; e < th * kVT_C; e += nthr) {
     const int ty = e / kVT_C, tx = e % kVT_C;
     const int y = reflect101(r0 + ty - a, rows), x = c0 + tx;
-    s_tile[e] = x < cols ? prep(in[static_cast<size_t>(y) * cols + x], scale, gamma) : 0.f;
+    float v = 0.f;
+    if (x < cols) {
+      const size_t px = static_cast<size_t>(y) * cols + x;
+      v = prep((!stamp || stamp[px] == seq) ? in[px] : 0.f, scale, gamma);  // an unclaimed pixel holds the reset value 0
+    }
+    s_tile[e] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kVT_R * kVT_C; e += kT) {
+  for (int e = threadIdx.x; e < kVT_R * kVT_C; e += nthr) {
     const int ty = e / kVT_C, tx = e % kVT_C;
     if (r0 + ty >= rows || c0 + tx >= cols) continue;
     float s = 0.f;
@@ -316,14 +370,15 @@ __device__ __forceinline__ void hfir_sub_tile(const float * hp, const float * ra
   float * s_tile = reinterpret_cast<float *>(pool);
   float * s_taps = s_tile + kHT_R * (kHT_C + kPhotoMaxTaps - 1);
   const int a = n_taps / 2, r0 = by * kHT_R, c0 = bx * kHT_C, tw = kHT_C + n_taps - 1;
-  for (int t = threadIdx.x; t < n_taps; t += kT) s_taps[t] = taps[t];
-  for (int e = threadIdx.x; e < kHT_R * tw; e += kT) {
+  const int nthr = static_cast<int>(blockDim.x);
+  for (int t = threadIdx.x; t < n_taps; t += nthr) s_taps[t] = taps[t];
+  for (int e = threadIdx.x; e < kHT_R * tw; e += nthr) {
     const int ty = e / tw, tx = e % tw;
     const int y = r0 + ty, x = reflect101(c0 + tx - a, cols);
     s_tile[e] = y < rows ? hp[static_cast<size_t>(y) * cols + x] : 0.f;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kHT_R * kHT_C; e += kT) {
+  for (int e = threadIdx.x; e < kHT_R * kHT_C; e += nthr) {
     const int ty = e / kHT_C, tx = e % kHT_C;
     if (r0 + ty >= rows || c0 + tx >= cols) continue;
     float s = 0.f;
@@ -427,31 +482,32 @@ __global__ __launch_bounds__(kT) void photo_sobel_writeback_kernel(const float *
 constexpr int kET_R = 16, kET_C = 64, kEMaxK = 33;
 constexpr int kErodeLdsWords = ((kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1) + (kET_R + kEMaxK - 1) * kET_C + 3) / 4;
 __device__ __forceinline__ void erode_tile(const uint8_t * in, const uint8_t * static_mask, int margin, uint8_t * out, int rows, int cols, int k,
-                                           const int bx, const int by, uint32_t * pool)
+                                           const int bx, const int by, uint32_t * pool, const uint32_t * stamp = nullptr, const uint32_t seq = 0)
 {
+  const int nthr = static_cast<int>(blockDim.x);
   uint8_t * s_raw = reinterpret_cast<uint8_t *>(pool);
   uint8_t * s_row = s_raw + (kET_R + kEMaxK - 1) * (kET_C + kEMaxK - 1);
   const int a = k / 2, r0 = by * kET_R, c0 = bx * kET_C, tw = kET_C + k - 1, th = kET_R + k - 1;
-  for (int e = threadIdx.x; e < th * tw; e += kT) {
+  for (int e = threadIdx.x; e < th * tw; e += nthr) {
     const int ty = e / tw, tx = e % tw;
     const int y = r0 + ty - a, x = c0 + tx - a;
     uint8_t v = 255;  // outside the image: never lowers the minimum
     if (y >= 0 && y < rows && x >= 0 && x < cols) {
-      v = in[static_cast<size_t>(y) * cols + x];
+      v = stamp ? (stamp[static_cast<size_t>(y) * cols + x] == seq ? 1 : 0) : in[static_cast<size_t>(y) * cols + x];
       if (static_mask && static_mask[static_cast<size_t>(y) * cols + x] == 0) v = 0;
       if (margin >= 0 && !(y >= margin && y < rows - margin && x >= margin && x < cols - margin)) v = 0;
     }
     s_raw[e] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < th * kET_C; e += kT) {
+  for (int e = threadIdx.x; e < th * kET_C; e += nthr) {
     const int ty = e / kET_C, tx = e % kET_C;
     uint8_t mn = 255;
     for (int j = 0; j < k; ++j) mn = min(mn, s_raw[ty * tw + tx + j]);
     s_row[e] = mn;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kET_R * kET_C; e += kT) {
+  for (int e = threadIdx.x; e < kET_R * kET_C; e += nthr) {
     const int ty = e / kET_C, tx = e % kET_C;
     if (r0 + ty >= rows || c0 + tx >= cols) continue;
     uint8_t mn = 255;
@@ -588,39 +644,64 @@ struct PhotoStageArgs  // one argument block for the three multi-job launches
   float * intensity_out;
   const float * hp;
   const float * lp;
-  const uint8_t * mask_raw;
   const uint8_t * static_mask;
   uint8_t * mask_out;
   float * yaw;
-  const uint8_t * yaw_valid;
   const mh_point32 * desk;
   int32_t * proj;
   PhotoCounters * counters;
   int rows, cols, n_pts, n_hp, n_lp, remove_lines, filter_brightness, bw, bh, do_gauss, erode_k;
   float scale, gamma;
   int n_job0, n_job1;  // workgroups of the launch's first / second job (the rest run the third)
+  // round 5 (no reset launch): frame stamps [yaw | pixel] of rows x cols words each, the frame's sequence number, the arrays
+  // stage A's fix-up job completes, and the frame's pose table (mapped pinned block -> device, n_copy16 x 16 bytes)
+  const uint32_t * stamps;
+  uint32_t seq;
+  float * raw_w;
+  float * range;
+  int32_t * idx_w;
+  const uint4 * copy_src;
+  uint4 * copy_dst;
+  int n_copy16, n_job2, n_job3;
+  mh_point32 * desk_writeback;  // stage C: the corrected intensities also go into this cloud (a scan's resident one), or nullptr
 };
+// Workgroups of the three stage launches: 1024 threads.  The tiles are the ones of the 256-thread single-stage kernels; a
+// tile's phases are loops over its elements in steps of the workgroup size, so four times the threads means a quarter of the
+// dependent iterations per thread and sixteen waves per CU to hide the LDS and memory latency behind (the chain is
+// latency-bound: 512 KiB images).
+constexpr int kTS = 1024;
 constexpr int kStageALds = kYawLdsWords > kVfirLdsWords ? kYawLdsWords : kVfirLdsWords;
-__global__ __launch_bounds__(kT) void photo_stage_a_kernel(const PhotoStageArgs a, const PhotoModel m)
+__global__ __launch_bounds__(kTS) void photo_stage_a_kernel(const PhotoStageArgs a, const PhotoModel m)
 {
   __shared__ uint32_t s_pool[kStageALds > kErodeLdsWords ? kStageALds : kErodeLdsWords];
-  const int b = static_cast<int>(blockIdx.x);
+  const int b = static_cast<int>(blockIdx.x), npx = a.rows * a.cols;
+  const uint32_t * ystamp = a.stamps, * pstamp = a.stamps + npx;
   if (b < a.n_job0) {  // vertical high-pass tiles (or the plain intensity scaling when removeLines is off)
     if (a.remove_lines) {
       const int gx = (a.cols + kVT_C - 1) / kVT_C;
-      vfir_tile(a.raw, a.ta, a.rows, a.cols, a.hp, a.n_hp, a.scale, a.gamma, b % gx, b / gx, s_pool);
+      vfir_tile(a.raw, a.ta, a.rows, a.cols, a.hp, a.n_hp, a.scale, a.gamma, b % gx, b / gx, s_pool, pstamp, a.seq);
     } else {
-      const int i = b * kT + static_cast<int>(threadIdx.x);
-      if (i < a.rows * a.cols) a.tb[i] = prep(a.raw[i], a.scale, a.gamma);
+      const int i = b * kTS + static_cast<int>(threadIdx.x);
+      if (i < npx) a.tb[i] = prep(pstamp[i] == a.seq ? a.raw[i] : 0.f, a.scale, a.gamma);
     }
   } else if (b < a.n_job0 + a.n_job1) {  // mask erosion tiles
     const int t = b - a.n_job0, gx = (a.cols + kET_C - 1) / kET_C;
-    erode_tile(a.mask_raw, a.static_mask, -1, a.mask_out, a.rows, a.cols, a.erode_k, t % gx, t / gx, s_pool);
-  } else {  // yaw-table rows
-    yaw_fill_row(m, a.yaw, a.yaw_valid, b - a.n_job0 - a.n_job1, s_pool);
+    erode_tile(nullptr, a.static_mask, -1, a.mask_out, a.rows, a.cols, a.erode_k, t % gx, t / gx, s_pool, pstamp, a.seq);
+  } else if (b < a.n_job0 + a.n_job1 + a.n_job2) {  // yaw-table rows
+    yaw_fill_row(m, a.yaw, nullptr, b - a.n_job0 - a.n_job1, s_pool, ystamp, a.seq);
+  } else if (b < a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3) {  // the reset values of the pixels no point claimed
+    const int i = (b - a.n_job0 - a.n_job1 - a.n_job2) * kTS + static_cast<int>(threadIdx.x);
+    if (i < npx && pstamp[i] != a.seq) {
+      a.raw_w[i] = 0.f;
+      a.range[i] = 0.f;
+      a.idx_w[i] = -1;
+    }
+  } else {  // the frame's pose table from its mapped pinned block (read by the factors, not by this chain)
+    const int nb = static_cast<int>(gridDim.x) - (a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3);
+    for (int k = (b - (static_cast<int>(gridDim.x) - nb)) * kTS + static_cast<int>(threadIdx.x); k < a.n_copy16; k += nb * kTS) a.copy_dst[k] = a.copy_src[k];
   }
 }
-__global__ __launch_bounds__(kT) void photo_stage_b_kernel(const PhotoStageArgs a, const PhotoModel m)
+__global__ __launch_bounds__(kTS) void photo_stage_b_kernel(const PhotoStageArgs a, const PhotoModel m)
 {
   __shared__ uint32_t s_pool[kHfirLdsWords];
   const int b = static_cast<int>(blockIdx.x);
@@ -628,18 +709,18 @@ __global__ __launch_bounds__(kT) void photo_stage_b_kernel(const PhotoStageArgs 
     const int gx = (a.cols + kHT_C - 1) / kHT_C;
     hfir_sub_tile(a.ta, a.raw, a.tb, a.rows, a.cols, a.lp, a.n_lp, a.scale, a.gamma, b % gx, b / gx, s_pool);
   } else {
-    project_point(m, a.desk, a.n_pts, a.yaw, a.proj, a.counters, (b - a.n_job0) * kT + static_cast<int>(threadIdx.x));
+    project_point(m, a.desk, a.n_pts, a.yaw, a.proj, a.counters, (b - a.n_job0) * kTS + static_cast<int>(threadIdx.x));
   }
 }
-__global__ __launch_bounds__(kT) void photo_stage_c_kernel(const PhotoStageArgs a)
+__global__ __launch_bounds__(kTS) void photo_stage_c_kernel(const PhotoStageArgs a)
 {
   __shared__ __attribute__((aligned(8))) uint32_t s_pool[kBgsLdsWords];
   const int b = static_cast<int>(blockIdx.x);
   if (b < a.n_job0) {
     const int gx = (a.cols + kFT_C - 1) / kFT_C;
-    bgs_tile(a.tb, a.fin, a.dx, a.dy, a.idx, nullptr, a.intensity_out, a.rows, a.cols, a.filter_brightness, a.bw, a.bh, a.do_gauss, b % gx, b / gx, s_pool);
+    bgs_tile(a.tb, a.fin, a.dx, a.dy, a.idx, a.desk_writeback, a.intensity_out, a.rows, a.cols, a.filter_brightness, a.bw, a.bh, a.do_gauss, b % gx, b / gx, s_pool);
   } else {
-    proj_finalize_px(a.rows * a.cols, a.proj, (b - a.n_job0) * kT + static_cast<int>(threadIdx.x));
+    proj_finalize_px(a.rows * a.cols, a.proj, (b - a.n_job0) * kTS + static_cast<int>(threadIdx.x));
   }
 }
 
@@ -1147,11 +1228,9 @@ hipError_t launch_photo_stages(const PhotoChain & c, const PhotoModel & m, hipSt
   a.intensity_out = c.intensity_out;
   a.hp = c.hp;
   a.lp = c.lp;
-  a.mask_raw = c.mask_raw;
   a.static_mask = c.static_mask;
   a.mask_out = c.mask_out;
   a.yaw = c.yaw;
-  a.yaw_valid = c.yaw_valid;
   a.desk = c.desk_points;
   a.proj = c.proj;
   a.counters = c.counters;
@@ -1168,20 +1247,40 @@ hipError_t launch_photo_stages(const PhotoChain & c, const PhotoModel & m, hipSt
   a.erode_k = c.erode_k;
   a.scale = c.scale;
   a.gamma = c.gamma;
+  a.stamps = c.stamps;
+  a.seq = c.seq;
+  a.raw_w = c.raw_w;
+  a.range = c.range;
+  a.idx_w = c.idx_w;
+  a.copy_src = static_cast<const uint4 *>(c.copy_src);
+  a.copy_dst = static_cast<uint4 *>(c.copy_dst);
+  a.n_copy16 = static_cast<int>(c.copy_bytes / 16);
+  a.desk_writeback = c.desk_writeback;
   const int npx = c.rows * c.cols;
   auto tiles = [&](int tr, int tc) { return ((c.cols + tc - 1) / tc) * ((c.rows + tr - 1) / tr); };
-  // A: vertical FIR (or scaling) | erosion | yaw rows
-  a.n_job0 = c.remove_lines ? tiles(kVT_R, kVT_C) : (npx + kT - 1) / kT;
+  // the launch ahead of the stages: scatter | projection-index reset (no frame-reset launch: see photo_scatter_stamp_kernel)
+  {
+    const int npb = (c.n_pts + kT - 1) / kT, nproj = (npx * kPhotoDup + 8 * kT - 1) / (8 * kT);
+    const bool copy = c.desk_src && c.desk_src != c.desk_points;
+    hipLaunchKernelGGL(photo_scatter_stamp_kernel, dim3(npb + nproj), dim3(kT), 0, stream, m, c.raw_points, copy ? c.desk_src : c.desk_points,
+                       copy ? const_cast<mh_point32 *>(c.desk_points) : nullptr, c.n_pts, c.yaw, c.stamps, c.stamps + npx, c.seq, c.raw_w, c.range, c.idx_w,
+                       c.intensity_out, c.proj, npb);
+  }
+  // A: vertical FIR (or scaling) | erosion | yaw rows | reset values of unclaimed pixels | pose-table copy
+  a.n_job0 = c.remove_lines ? tiles(kVT_R, kVT_C) : (npx + kTS - 1) / kTS;
   a.n_job1 = tiles(kET_R, kET_C);
-  hipLaunchKernelGGL(photo_stage_a_kernel, dim3(a.n_job0 + a.n_job1 + m.rows), dim3(kT), 0, stream, a, m);
+  a.n_job2 = m.rows;
+  a.n_job3 = (npx + kTS - 1) / kTS;
+  const int ncopy = a.n_copy16 ? std::min(4, (a.n_copy16 + kTS - 1) / kTS) : 0;
+  hipLaunchKernelGGL(photo_stage_a_kernel, dim3(a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3 + ncopy), dim3(kTS), 0, stream, a, m);
   // B: horizontal FIR + subtract | projection
   a.n_job0 = c.remove_lines ? tiles(kHT_R, kHT_C) : 0;
-  a.n_job1 = (c.n_pts + kT - 1) / kT;
-  if (a.n_job0 + a.n_job1 > 0) hipLaunchKernelGGL(photo_stage_b_kernel, dim3(a.n_job0 + a.n_job1), dim3(kT), 0, stream, a, m);
+  a.n_job1 = (c.n_pts + kTS - 1) / kTS;
+  if (a.n_job0 + a.n_job1 > 0) hipLaunchKernelGGL(photo_stage_b_kernel, dim3(a.n_job0 + a.n_job1), dim3(kTS), 0, stream, a, m);
   // C: brightness + Gaussian + Sobel + write-back | projection-index finalise
   a.n_job0 = tiles(kFT_R, kFT_C);
-  a.n_job1 = (npx + kT - 1) / kT;
-  hipLaunchKernelGGL(photo_stage_c_kernel, dim3(a.n_job0 + a.n_job1), dim3(kT), 0, stream, a);
+  a.n_job1 = (npx + kTS - 1) / kTS;
+  hipLaunchKernelGGL(photo_stage_c_kernel, dim3(a.n_job0 + a.n_job1), dim3(kTS), 0, stream, a);
   return hipGetLastError();
 }
 

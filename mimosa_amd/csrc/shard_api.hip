@@ -423,6 +423,58 @@ void global_result(mh_shard_icp * S, const mh::ShardPublish & p, const PendingCa
 }
 }  // namespace
 
+// Every live communicator, so that a context that goes away first (mh_shutdown) can take back what the communicator holds on it.
+static std::mutex g_comm_mu;
+static std::vector<mh_shard_comm *> g_comms;
+
+static void comm_register(mh_shard_comm * c)
+{
+  std::lock_guard<std::mutex> g(g_comm_mu);
+  g_comms.push_back(c);
+}
+
+// Detach a communicator from the context its rounds run on: rounds nobody waited for are dropped (their factors can
+// only be destroyed afterwards), the exchange buffers and the publish ring go back once the stream has drained.
+static void comm_release_ctx(mh_shard_comm * comm)
+{
+  if (!comm->ws_ctx) return;
+  (void)mh_enter(comm->ws_ctx);
+  (void)hipStreamSynchronize(comm->ws_ctx->stream);
+  for (ShardRound & r : comm->rounds)
+    for (ShardCall & c : r.calls)
+      if (c.S) {
+        c.S->inflight = 0;
+        c.S->broken = true;
+        c.S->comm = nullptr;
+      }
+  comm->rounds.clear();
+  comm->cap_updates.clear();
+  for (DevBuf * b : {&comm->ws_send, &comm->ws_recv, &comm->ws_ar, &comm->ws_loc}) b->release(true);
+  if (comm->h_ring) AllocCache::free_pinned(comm->h_ring, sizeof(mh::ShardPublish) * comm->ring_width * kShardRing);
+  comm->h_ring = comm->d_h_ring = nullptr;
+  comm->ring_width = 0;
+  comm->ws_ctx = nullptr;
+}
+
+namespace mhi
+{
+// mh_shutdown(ctx), before the stream goes: communicators whose rounds ran on ctx let go of it (a later
+// mh_shard_comm_destroy must not touch a dead context; a later mh_shard_icp_create may bind a new one)
+void shard_ctx_gone(mh_ctx * ctx)
+{
+  std::lock_guard<std::mutex> g(g_comm_mu);
+  for (mh_shard_comm * c : g_comms)
+    if (c->ws_ctx == ctx) {
+      for (mh_shard_icp * S : c->factors)
+        if (S->ctx == ctx) {  // the factors of that context are unusable from here on
+          S->broken = true;
+          S->inflight = 0;
+        }
+      comm_release_ctx(c);
+    }
+}
+}  // namespace mhi
+
 extern "C" {
 
 int mh_shard_unique_id(void * id128)
@@ -463,6 +515,7 @@ int mh_shard_comm_init_rccl(mh_ctx * ctx, const void * id128, int world, int ran
       delete c;
       return fail(ctx, MH_ERR_HIP, msg);
     }
+    comm_register(c);
     *out = c;
     return MH_OK;
   });
@@ -483,6 +536,7 @@ int mh_shard_comm_init_local(int world, mh_shard_comm ** out_array)
       c->world = world;
       c->rank = r;
       c->grp = g;
+      comm_register(c);
       out_array[r] = c;
     }
     return MH_OK;
@@ -492,19 +546,11 @@ int mh_shard_comm_init_local(int world, mh_shard_comm ** out_array)
 void mh_shard_comm_destroy(mh_shard_comm * comm)
 {
   if (!comm) return;
-  if (comm->ws_ctx) {  // rounds nobody waited for are dropped; the exchange buffers go back once the stream has drained
-    (void)mh_enter(comm->ws_ctx);
-    (void)hipStreamSynchronize(comm->ws_ctx->stream);
-    for (ShardRound & r : comm->rounds)
-      for (ShardCall & c : r.calls)
-        if (c.S) {
-          c.S->inflight = 0;
-          c.S->broken = true;
-          c.S->comm = nullptr;
-        }
-    for (DevBuf * b : {&comm->ws_send, &comm->ws_recv, &comm->ws_ar, &comm->ws_loc}) b->release(true);
-    if (comm->h_ring) AllocCache::free_pinned(comm->h_ring, sizeof(mh::ShardPublish) * comm->ring_width * kShardRing);
+  {
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    g_comms.erase(std::remove(g_comms.begin(), g_comms.end(), comm), g_comms.end());
   }
+  comm_release_ctx(comm);
   for (mh_shard_icp * S : comm->factors) {  // factors that outlive their communicator can only be destroyed
     S->comm = nullptr;
     S->broken = true;

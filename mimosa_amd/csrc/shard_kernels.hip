@@ -25,13 +25,20 @@ namespace
 constexpr int kT = 256;
 int grid_for(uint32_t n) { return static_cast<int>(max(1u, min((n + kT - 1) / kT, 8192u))); }
 
-// XORVector3iHash (include/mimosa/lidar/utils.hpp:228-238): size_t products of the coordinates with three 64-bit primes
+// Owner of a block: rank = (bx + A[P] by + B[P] bz) mod P — a lattice colouring of the block grid (tools/lattice_table.py has
+// the rule the two tables come from and prints them).  Neighbouring blocks never share a rank and a sheet of blocks (a wall, a
+// floor) spreads over all ranks as evenly as a static function can, so the few blocks next to the sensor that hold most of a
+// scan's points do too: on the configs[1] world the fullest of 8 ranks gets 1.30 x its fair share of the queries, against the
+// 1.65 x of the XOR hash of the block coordinates that rounds 3-4 used (neighbouring heavy blocks met on one rank at random).
+// Results do not depend on the owner function; the storage balance stays within 2 percent.
+__constant__ uint8_t kOwnerA[kShardMaxWorld + 1] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 3, 3, 5, 7, 5, 6, 5, 4, 7, 5, 6, 6, 5, 5, 5, 5, 5, 6, 6, 6, 5, 5, 7, 6, 7, 5, 7, 6, 7, 8, 7, 6, 7, 7, 9, 8, 8, 7, 7, 10, 10, 7, 7, 8, 7, 8, 8, 8, 8};
+__constant__ uint8_t kOwnerB[kShardMaxWorld + 1] = {0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 5, 6, 4, 5, 7, 8, 8, 8, 8, 10, 9, 7, 11, 8, 12, 11, 12, 6, 7, 14, 13, 10, 6, 7, 11, 16, 15, 6, 12, 7, 13, 17, 10, 14, 18, 11, 11, 14, 23, 22, 16, 12, 21, 8, 9, 13, 11, 11, 17, 14, 19};
 __device__ __forceinline__ uint32_t owner_of_block(int bx, int by, int bz, uint32_t world)
 {
-  const unsigned long long h = (static_cast<unsigned long long>(static_cast<long long>(bx)) * 9132043225175502913ull) ^
-                               (static_cast<unsigned long long>(static_cast<long long>(by)) * 7277549399757405689ull) ^
-                               (static_cast<unsigned long long>(static_cast<long long>(bz)) * 6673468629021231217ull);
-  return static_cast<uint32_t>(h % world);
+  const int w = static_cast<int>(world);  // the terms are reduced first: no overflow for any block coordinate
+  int r = (bx % w + static_cast<int>(kOwnerA[world]) * (by % w) + static_cast<int>(kOwnerB[world]) * (bz % w)) % w;
+  r = r < 0 ? r + w : r;
+  return static_cast<uint32_t>(r);
 }
 
 __global__ __launch_bounds__(kT) void shard_filter_kernel(const float * xyz, uint32_t n, uint32_t stride, double inv_leaf, uint32_t world,

@@ -6,7 +6,7 @@
 #include "../../mimosa_amd/csrc/math3.hpp"
 int main() {
   std::mt19937_64 rng(3); std::normal_distribution<double> N(0,1); std::uniform_real_distribution<double> U(0,1);
-  double worst_w=0, worst_v=0; long fallback_like=0, cases=0;
+  double worst_w=0, worst_v=0, worst_f=0, worst_o=0; long fast_ok=0, cases=0;
   for (int rep=0; rep<400000; ++rep) {
     // random PSD with controlled spectrum
     double Q[9]; { double a=N(rng),b=N(rng),c=N(rng),d=N(rng); double n=std::sqrt(a*a+b*b+c*c+d*d); a/=n;b/=n;c/=n;d/=n;
@@ -24,7 +24,17 @@ int main() {
       double r=0; for(int i=0;i<3;++i){double av=0;for(int j=0;j<3;++j)av+=A[3*i+j]*V[3*j+k]; r=std::fmax(r,std::fabs(av-w[k]*V[3*i+k]));}
       worst_v=std::fmax(worst_v,r/sc);}
     ++cases;
+    // the eigenvector-only solver of K4 (sym_eigvec3_fast): whatever it ACCEPTS must be the ascending eigenvectors, orthonormal
+    double Vf[9];
+    if (mh::sym_eigvec3_fast(A, Vf)) {
+      ++fast_ok;
+      for (int k = 0; k < 3; ++k) {
+        double r = 0; for (int i = 0; i < 3; ++i) { double av = 0; for (int j = 0; j < 3; ++j) av += A[3*i+j] * Vf[3*j+k]; r = std::fmax(r, std::fabs(av - wj[k] * Vf[3*i+k])); }
+        worst_f = std::fmax(worst_f, r / sc);
+      }
+      for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) { double d = 0; for (int i = 0; i < 3; ++i) d += Vf[3*i+a] * Vf[3*i+b]; worst_o = std::fmax(worst_o, std::fabs(d - (a == b))); }
+    }
   }
-  std::printf("cases %ld worst |dw|/|A| %.3e worst residual/|A| %.3e\n",cases,worst_w,worst_v);
-  return (worst_w<1e-12&&worst_v<1e-12)?0:1;
+  std::printf("cases %ld worst |dw|/|A| %.3e worst residual/|A| %.3e; fast vectors accepted %ld, worst residual %.3e, worst |V^T V - I| %.3e\n",cases,worst_w,worst_v,fast_ok,worst_f,worst_o);
+  return (worst_w<1e-12&&worst_v<1e-12&&worst_f<1e-11&&worst_o<1e-9&&fast_ok>cases/10)?0:1;
 }

@@ -24,8 +24,9 @@ import ctypes as C
 import numpy as np
 
 SHARD_BLOCK_LOG2 = 3
-_P1, _P2, _P3 = np.uint64(9132043225175502913), np.uint64(7277549399757405689), np.uint64(6673468629021231217)
 RECORD_BYTES = 112
+OWNER_A = [0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 3, 3, 5, 7, 5, 6, 5, 4, 7, 5, 6, 6, 5, 5, 5, 5, 5, 6, 6, 6, 5, 5, 7, 6, 7, 5, 7, 6, 7, 8, 7, 6, 7, 7, 9, 8, 8, 7, 7, 10, 10, 7, 7, 8, 7, 8, 8, 8, 8]
+OWNER_B = [0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 5, 6, 4, 5, 7, 8, 8, 8, 8, 10, 9, 7, 11, 8, 12, 11, 12, 6, 7, 14, 13, 10, 6, 7, 11, 16, 15, 6, 12, 7, 13, 17, 10, 14, 18, 11, 11, 14, 23, 22, 16, 12, 21, 8, 9, 13, 11, 11, 17, 14, 19]
 
 
 def voxel_coords(xyz, leaf: float) -> np.ndarray:
@@ -36,10 +37,10 @@ def voxel_coords(xyz, leaf: float) -> np.ndarray:
 
 
 def owner_of_block(b: np.ndarray, world: int) -> np.ndarray:
-    b = np.asarray(b, dtype=np.int64).astype(np.uint64)  # two's complement, like the size_t casts
-    with np.errstate(over="ignore"):
-        h = (b[..., 0] * _P1) ^ (b[..., 1] * _P2) ^ (b[..., 2] * _P3)
-    return (h % np.uint64(world)).astype(np.int64)
+    """The library's owner function (mimosa_amd/csrc/shard_kernels.hip owner_of_block): a lattice colouring of the block grid,
+    rank = (bx + A[world] by + B[world] bz) mod world, tables from tools/lattice_table.py."""
+    b = np.asarray(b, dtype=np.int64)
+    return np.mod(b[..., 0] + OWNER_A[world] * b[..., 1] + OWNER_B[world] * b[..., 2], world).astype(np.int64)
 
 
 def owner_of_voxel(v: np.ndarray, world: int) -> np.ndarray:

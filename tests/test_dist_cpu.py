@@ -83,11 +83,20 @@ def test_partition_properties():
         assert np.all(masks[r][own == r])              # owners hold their own voxels
         assert masks[r].sum() > (own == r).sum()       # ...plus a halo
     assert len(set(own.tolist())) == 4
-    # negative coordinates hash like the reference's size_t arithmetic
-    b = np.array([[-1, 2, -3]])
-    with np.errstate(over="ignore"):
-        h = (np.uint64(-1 & 0xFFFFFFFFFFFFFFFF) * mdist._P1) ^ (np.uint64(2) * mdist._P2) ^ (np.uint64(-3 & 0xFFFFFFFFFFFFFFFF) * mdist._P3)
-    assert mdist.owner_of_block(b, 7)[0] == int(h % np.uint64(7))
+    # the lattice colouring: neighbouring blocks never share a rank (world > 1), negative coordinates wrap like positive ones,
+    # and the tables are the ones tools/lattice_table.py's rule gives (spot checks: the full search takes a quarter of a minute)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lattice_table as lt
+    assert mdist.OWNER_A == lt.TABLE_A and mdist.OWNER_B == lt.TABLE_B
+    for P in (2, 3, 8, 12):
+        assert lt.pick(P) == (lt.TABLE_A[P], lt.TABLE_B[P])
+    for world in (2, 3, 5, 8, 64):
+        b = np.array([[-9, 2, -3], [7, 7, 7], [0, 0, 0]])
+        o = mdist.owner_of_block(b, world)
+        assert np.all((o >= 0) & (o < world))
+        for d in ([1, 0, 0], [0, 1, 0], [0, 0, 1]):
+            assert np.all(mdist.owner_of_block(b + np.array(d), world) != o)
+        assert np.array_equal(mdist.owner_of_block(b + world * np.array([3, -5, 7]), world), o)
 
 
 def test_sharded_equals_unsharded_world2(tmp_path):

@@ -147,6 +147,35 @@ def test_native_world1_is_the_plain_factor(ctx, small_world):
     comm.destroy()
 
 
+def test_context_shut_down_before_its_communicator(small_world):
+    """mh_shutdown(ctx) while a communicator still holds exchange buffers and a publish ring on ctx: the communicator lets go
+    of the context there (shard_ctx_gone), so mh_shard_comm_destroy afterwards touches nothing of the dead context — and the
+    same communicator bound to a NEW context in between gives the same results."""
+    from mimosa_amd import capi
+    w = small_world
+    rc = capi.make_reg_config(**w["cfg"])
+
+    def one_life(comm, pipelined_tail):
+        c = capi.Context(0)
+        vmap = capi.VoxelMap(c)
+        capi.map_insert_shard(c, vmap, w["map_xyz"], 1, 0)
+        f = capi.ShardedICPFactor(c, comm, vmap, w["pts"], rc, force_collectives=True)
+        out = f.linearize(w["R"], w["t"])
+        if pipelined_tail:
+            f.linearize_async(w["R"], w["t"])  # a round nobody waits for: dropped with the factor
+        f.destroy()
+        vmap.release()
+        c.close()  # the communicator is still alive and was bound to c
+        assert c.h is None
+        return out
+
+    comm = capi.ShardComm.local(1)[0]
+    a = one_life(comm, True)
+    b = one_life(comm, False)
+    assert np.array_equal(a["H_ss"], b["H_ss"]) and np.array_equal(a["b_s"], b["b_s"]) and a["f"] == b["f"]
+    comm.destroy()  # after both contexts are gone
+
+
 def test_native_world1_over_rccl_full_protocol():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_native_rccl_worker.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

@@ -17,12 +17,13 @@ def _raw_sync_ms(E, f, R, t, reps=20):
     """Median wall time (ms) of synchronous raw C-ABI mh_icp_linearize calls of factor f, association state reset before each."""
     Rm, tv = np.ascontiguousarray(R, np.float64), np.ascontiguousarray(t, np.float64)
     out, ts = E.capi.IcpResult(), []
+    lin, raw = E.ctx.L.mh_icp_linearize, (f.h, Rm.ctypes.data_as(C.c_void_p), tv.ctypes.data_as(C.c_void_p), None, None,
+                                          E._g.ctypes.data_as(C.c_void_p), C.byref(out))
     for i in range(reps + 3):
         f.reset()
         E.ctx.synchronize()
         a = time.perf_counter()
-        rc = E.ctx.L.mh_icp_linearize(f.h, Rm.ctypes.data_as(C.c_void_p), tv.ctypes.data_as(C.c_void_p), None, None,
-                                      E._g.ctypes.data_as(C.c_void_p), C.byref(out))
+        rc = lin(*raw)
         b = time.perf_counter()
         assert rc == 0, rc
         if i >= 3:

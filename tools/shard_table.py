@@ -10,6 +10,7 @@ has the same per-room geometry, its totals scale by 10) —
 CPU only (numpy); prints a markdown table and one JSON line."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from mimosa_amd import synth
 
@@ -17,11 +18,18 @@ P1, P2, P3 = np.uint64(9132043225175502913), np.uint64(7277549399757405689), np.
 LEAF = 0.5
 
 
-def owner(v, log2, world):
+def owner_hash(v, log2, world):
+    """Rounds 3-4: XOR hash of the block coordinates (kept for the comparison column)."""
     b = (v >> log2).astype(np.int64).astype(np.uint64)
     with np.errstate(over="ignore"):
         h = (b[..., 0] * P1) ^ (b[..., 1] * P2) ^ (b[..., 2] * P3)
     return (h % np.uint64(world)).astype(np.int16)
+
+
+def owner(v, log2, world):
+    """The library's owner function (shard_kernels.hip owner_of_block): the lattice colouring of tools/lattice_table.py."""
+    import lattice_table
+    return lattice_table.owner_of_block(np.asarray(v, np.int64) >> log2, world)
 
 
 def vox(xyz):
@@ -68,7 +76,9 @@ def main():
                 owners_touched[np.arange(len(c0)), ow] = True
             owners_touched[np.arange(len(c0)), o0] = False
             n_foreign = owners_touched.sum(1)
-            rec = dict(block=B, world=world, stored_total_over_map=float(stored.sum() / n_map), stored_max_over_map=float(stored.max() / n_map),
+            qc, qh = np.bincount(o0, minlength=world), np.bincount(owner_hash(vox(q0), log2, world), minlength=world)
+            rec = dict(block=B, world=world, query_imbalance=float(qc.max() / qc.mean()), query_imbalance_xor_hash=float(qh.max() / qh.mean()),
+                       queries_min_max=[int(qc.min()), int(qc.max())], stored_total_over_map=float(stored.sum() / n_map), stored_max_over_map=float(stored.max() / n_map),
                        fair_share=1.0 / world, boundary_query_fraction=float((n_foreign > 0).mean()), foreign_owners_per_query=float(n_foreign.mean()),
                        query_exchange_bytes_per_linearize=int(n_foreign.sum() * (16 + 80)), steps=[])
             for name, w, d in steps:
@@ -86,11 +96,12 @@ def main():
             out.append(rec)
             s = rec["steps"]
             rows.append(f"| {B} | {world} | {rec['stored_total_over_map']:.2f}x | {rec['stored_max_over_map'] * 100:.1f} % ({100.0 / world:.1f} %) | "
+                        f"{rec['query_imbalance']:.2f} x ({rec['query_imbalance_xor_hash']:.2f} x) | "
                         f"{rec['boundary_query_fraction'] * 100:.0f} % / {rec['foreign_owners_per_query']:.2f} | {rec['query_exchange_bytes_per_linearize'] / 1e6:.1f} MB | "
                         + " | ".join(f"{x['migrated_fraction'] * 100:.2f} % / {x['max_movers_per_pair']} / {x['all_to_all_bytes_per_rank'] / 1e3:.0f} KB" for x in s) + " |")
-    print("| B (voxels) | P | stored total / map | fullest rank (fair share) | boundary queries / foreign owners per query | query-exchange traffic per linearize | "
+    print("| B (voxels) | P | stored total / map | fullest rank (fair share) | queries on the fullest rank / fair share (XOR hash of rounds 3-4) | boundary queries / foreign owners per query | query-exchange traffic per linearize | "
           + " | ".join(f"step {n}: migrated / max per pair / all-to-all per rank" for n, _, _ in steps) + " |")
-    print("|---|---|---|---|---|---|" + "---|" * len(steps))
+    print("|---|---|---|---|---|---|---|" + "---|" * len(steps))
     print("\n".join(rows))
     print(json.dumps(out))
 
