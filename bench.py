@@ -188,12 +188,13 @@ def headline(E):
     event_every = max(1, min(args.event_every, args.steps // max(len(E.factors), 1)))
     for c in E.ctxs:
         c.set_profiling(event_every)  # every n-th call of a factor is bracketed by events on the launch stream
-    if E.dist is not None:
-        # under torch.distributed ONE pipelined burst among the first few after the first collective stalls for 35-48 ms
-        # (tools/torchrun_probe.py: a one-off of the process's RCCL / watchdog start-up): part of the setup, like the first linearize
-        for _ in range(8):
-            E.barrier()
-            E.run_steps(64)
+    # CPython's cyclic garbage collector out of the timed region: with torch imported a full (generation-2) collection walks
+    # ~170 000 objects and takes 35-58 ms on the calling thread — the "one-off stall under torch.distributed" of rounds 4-5
+    # (tools/torchrun_stall.py logs it through gc.callbacks: block 3, call 47, 44 ms; none after gc.freeze()).  Everything alive
+    # after the setup moves to the permanent generation; the young collections of the loop's own garbage (~45 us) stay.
+    import gc
+    gc.collect()
+    gc.freeze()
     E.run_steps(args.warmup)
     outs = []
     block_s = [timed_block(E, args.steps, outs)]  # the timed region of the contract

@@ -149,5 +149,17 @@ def build_replay_native(force: bool = False) -> str:
     return exe
 
 
+def build_sync_caller(force: bool = False) -> str:
+    """tools/micro/sync_caller.c (plain C, links nothing): times synchronous mh_icp_linearize calls from C for bench.py's latency
+    leg and tools/sync_probe.py.  Measurement harness, never loaded by the product path."""
+    src = os.path.join(os.path.dirname(HERE), "tools", "micro", "sync_caller.c")
+    out = os.path.join(LIBDIR, "libmh_sync_caller.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    with _BuildLock():
+        if force or _stale(out, [src]):
+            _run_to(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", src, "-o", out], out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

@@ -139,7 +139,7 @@ __device__ __forceinline__ double sq_dist3(double dx, double dy, double dz)
 // of a voxel-ordered down-sampled cloud) are spatial neighbours that read the same buckets: they now
 // share one 4 MiB L2 instead of pulling the same lines into all eight.  The grid is padded to a
 // multiple of 8; chunks past the cloud simply find qi >= n.  Placement is a speed matter only.
-__device__ __forceinline__ int xcd_chunk(int b, int n_blocks)
+[[maybe_unused]] __device__ __forceinline__ int xcd_chunk(int b, int n_blocks)
 {
   const int cpx = n_blocks >> 3;  // launchers round the grid up to a multiple of 8
   return (b & 7) * cpx + (b >> 3);
@@ -1349,10 +1349,15 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
   double * s_aux = reinterpret_cast<double *>(s_arena);                               // fold scratch of the last block
 
-#ifdef MH_INTERLEAVE
-  // EXPERIMENT (tools/variant.sh): the waves of a workgroup take 64-point chunks that lie n_blocks / 8 chunks apart inside their
-  // XCD's range instead of 8 consecutive ones, so that a heavy stretch of the Morton curve is spread over the CUs of the XCD
-  // (same L2) instead of landing on one CU's eight waves.
+  // Which 64 points a wave takes.  A workgroup's waves take 64-point chunks that lie n_blocks / 8 chunks apart inside their XCD's
+  // stretch of the (Morton-ordered) cloud instead of consecutive ones: the cost of a chunk varies slowly along the curve (a
+  // dense corner is several thousand points long), there are exactly as many workgroups as CUs, and the kernel ends with its
+  // slowest workgroup — eight consecutive chunks put a heavy stretch on ONE CU's eight waves, eight strided ones give every CU
+  // a sample of its XCD's whole stretch (same L2 as before).  rocprofv3, cold calls on the configs[1] world: 32.2 -> 29.2 us at
+  // 131 072 points, 21.3 -> 20.9 us at 24 576 (gpurun c19; -DMH_NO_INTERLEAVE restores the consecutive chunks).
+#if defined(MH_INTERLEAVE_GLOBAL)  // (experiment: strided over the whole cloud — every XCD's L2 then sees the whole touched map)
+  const int qi = (static_cast<int>(threadIdx.x >> 6) * n_blocks + block_id) * 64 + static_cast<int>(threadIdx.x & 63u);
+#elif !defined(MH_NO_INTERLEAVE)
   const int qi = [&] {
     constexpr int WPB = TPB / 64;
     const int cpx = n_blocks >> 3, x = block_id & 7, j = block_id >> 3, wv = static_cast<int>(threadIdx.x >> 6);
@@ -1968,32 +1973,6 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
       __syncthreads();
     }
   }
-  // The Hessian sums the eigenbases come from — requested FIRST: the fold, the decompositions and everything behind them wait
-  // for these rows, the record entries further down only for the projections.  Plain factor: K3 ended at its per-workgroup
-  // rows; EVERY workgroup of this kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed
-  // order of the old last-block fold — so every workgroup holds the same bits), workgroup 0 also publishes them.
-  // Map-sharded factor: the all-reduced (global) sums are given.
-  const double * sums = nullptr;
-  double * s_h = s_seg + TPB;  // folded sums + counters (plain factors)
-  if constexpr (SHARD) {
-    sums = a.sums ? a.sums : a.result->sums;
-  } else {
-    const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
-    constexpr int FB = 32;  // rows in flight per thread: 256 rows over 8 segments in one round trip
-    if (a.nv == 7) {
-      if (side)
-        fold_rows<32, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-      else
-        fold_rows<32, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-    } else {
-      if (side)
-        fold_rows<96, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-      else
-        fold_rows<96, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-    }
-    sums = s_h;
-  }
-  MH_STAMP4(a.dbg, 1);
   // The record entries (plain) / status, point and normal (map-sharded) of ALL of this workgroup's chunks: one round trip, in
   // flight while two lanes of the workgroup decompose H_rr and H_tt.  One uniform branch around each chunk's loads (a select
   // per loaded value made the compiler branch around every single load).
@@ -2038,8 +2017,37 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     }
     if (i >= n_pts) st_c[ch] = -1;
   };
+  auto load_all = [&]() {  // (behind the fold: requested inside the rows' round trip they delay the rows — K4 6.4 -> 7.3 us, gpurun c21)
+    MH_STAMP4(a.dbg, 1);
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch) load_chunk(ch);
+    for (int ch = 0; ch < CH; ++ch) load_chunk(ch);
+  };
+  // The Hessian sums the eigenbases come from — requested FIRST: the fold, the decompositions and everything behind them wait
+  // for these rows, the record entries further down only for the projections.  Plain factor: K3 ended at its per-workgroup
+  // rows; EVERY workgroup of this kernel folds them for itself (k3_blocks rows of <= 95 doubles, one round trip, the fixed
+  // order of the old last-block fold — so every workgroup holds the same bits), workgroup 0 also publishes them.
+  // Map-sharded factor: the all-reduced (global) sums are given.
+  const double * sums = nullptr;
+  double * s_h = s_seg + TPB;  // folded sums + counters (plain factors)
+  if constexpr (SHARD) {
+    sums = a.sums ? a.sums : a.result->sums;
+  } else {
+    const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
+    constexpr int FB = 32;  // rows in flight per thread: 256 rows over 8 segments in one round trip
+    if (a.nv == 7) {
+      if (side)
+        fold_rows<32, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+      else
+        fold_rows<32, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    } else {
+      if (side)
+        fold_rows<96, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+      else
+        fold_rows<96, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    }
+    sums = s_h;
+  }
+  load_all();
   MH_STAMP4(a.dbg, 2);
   // The two eigenbases: given (two-phase callers), or derived here — one lane per 3 x 3 block (computeLocalizability,
   // utils.hpp:308-313), every workgroup for itself, on the LAST two waves (the others go on to their points).

@@ -22,25 +22,21 @@ def run(E):
     # synchronous per-call latency (result on the host before the next call), events off
     for c in ctxs:
         c.set_profiling(False)
-    E._t[:] = t
-    lat = []
-    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
-        factor.reset()
-        ctx.synchronize()
-        a = time.perf_counter()
-        raw_linearize()
-        lat.append(time.perf_counter() - a)
-    lat_ms = float(np.median(lat) * 1e3) if lat else float("nan")
-    lat_nc = []  # the same call with the component pass switched off (K3 alone publishes the result)
-    factor.set_components(False)
-    for _ in range(0 if args.profile_mode else min(50, max(10, args.steps // 4))):
-        factor.reset()
-        ctx.synchronize()
-        a = time.perf_counter()
-        raw_linearize()
-        lat_nc.append(time.perf_counter() - a)
+    from .env import c_sync_ns
+    n_lat = 0 if args.profile_mode else min(50, max(10, args.steps // 4))
+    lat = c_sync_ns(ctx, factor.h, R, t, _g, _out, n_lat + 3)[3:] if n_lat else []
+    lat_ms = float(np.median(lat) * 1e-6) if len(lat) else float("nan")
+    factor.set_components(False)  # the same call with the component pass switched off (K3 alone publishes the result)
+    lat_nc = c_sync_ns(ctx, factor.h, R, t, _g, _out, n_lat + 3)[3:] if n_lat else []
     factor.set_components(True)
-    lat_nc_ms = float(np.median(lat_nc) * 1e3) if lat_nc else float("nan")
+    lat_nc_ms = float(np.median(lat_nc) * 1e-6) if len(lat_nc) else float("nan")
+    lat_py = []  # the same call through ctypes, arguments marshalled once: what the Python binding's caller pays at best
+    for _ in range(n_lat):
+        factor.reset()
+        ctx.synchronize()
+        a = time.perf_counter()
+        raw_linearize()
+        lat_py.append(time.perf_counter() - a)
     # The second caller of the path: GTSAM re-linearization (src/graph/manager.cpp:585-588).  The pose moved
     # < min_dist/4, so every point takes the data-association cache branch (geometric_factor.hpp:308-317):
     # no k-NN, cached plane, residual + Jacobian + reduction only.  Wall time with events off, kernel time in a
@@ -69,8 +65,9 @@ def run(E):
         "value_sync": round(n_pts / (lat_ms * 1e-3) / 1e6, 2),
         "sync_latency_without_components_ms": round(lat_nc_ms, 4),
         "value_sync_without_components": round(n_pts / (lat_nc_ms * 1e-3) / 1e6, 2),
-        "sync_latency_note": "median wall time of raw C-ABI mh_icp_linearize calls (pre-marshalled arguments, association state reset and the "
-                             "stream drained before each): what ICPFactor::linearize costs its caller",
+        "sync_latency_note": "median wall time of mh_icp_linearize calls made from C (tools/micro/sync_caller.c: clock_gettime around the call, "
+                             "association state reset and the stream drained before each): what ICPFactor::linearize costs its C++ caller",
+        "sync_latency_through_ctypes_ms": round(float(np.median(lat_py)) * 1e3, 4) if lat_py else None,
         "relinearize": {"what": "warm ICPFactor::linearize (all points hit the data-association cache, no k-NN)",
                         "kernel_ms": round(float(np.median(relin_k3)), 5) if relin_k3 else None,
                         "sync_latency_ms": round(float(np.median(relin_wall) * 1e3), 4) if relin_wall else None,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Synchronous mh_icp_linearize latency, raw C-ABI calls (prebuilt ctypes arguments, perf_counter_ns around the foreign call):
+"""Synchronous mh_icp_linearize latency, calls made from C (tools/micro/sync_caller.c: clock_gettime around the foreign call):
 with and without the component pass, at 131 072 and 24 576 points on the configs[1] world.
 Prints one JSON line.  Under `rocprofv3 --hip-trace --kernel-trace` the same calls give the API / kernel breakdown."""
 import ctypes as C
@@ -13,6 +13,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from mimosa_amd import capi, synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from benchlegs.env import c_sync_ns  # noqa: E402
 
 N = int(os.environ.get("SYNC_PROBE_CALLS", "200"))
 room_clouds, pts, R, t = bench.build_world(0, "2x5", 128)
@@ -30,25 +32,10 @@ for mode, env in (("two_launch", {}),):
         f = capi.ICPFactor(ctx, gmap, cloud, rc)
         res = capi.IcpResult()
         Rc, tc, gc = np.ascontiguousarray(R, np.float64), np.ascontiguousarray(t, np.float64), np.array([0.0, 0.0, -1.0])
-        args = (f.h, Rc.ctypes.data_as(C.c_void_p), tc.ctypes.data_as(C.c_void_p), None, None, gc.ctypes.data_as(C.c_void_p), C.byref(res))
-        lin, rst = ctx.L.mh_icp_linearize, ctx.L.mh_icp_reset
         for comp in (1, 0):
             f.set_components(bool(comp))
-            cold, warm = [], []
-            for i in range(N + 20):
-                rst(f.h)
-                ctx.synchronize()
-                a = time.perf_counter_ns()
-                lin(*args)
-                b = time.perf_counter_ns()
-                if i >= 20:
-                    cold.append(b - a)
-            for i in range(N // 2):
-                ctx.synchronize()
-                a = time.perf_counter_ns()
-                lin(*args)
-                b = time.perf_counter_ns()
-                warm.append(b - a)
+            cold = c_sync_ns(ctx, f.h, Rc, tc, gc, res, N + 20, reset=True)[20:]
+            warm = c_sync_ns(ctx, f.h, Rc, tc, gc, res, N // 2, reset=False)
             q = lambda v, p: round(float(np.percentile(v, p)) / 1e3, 2)
             out[f"{mode}.{name}.{'comp' if comp else 'nocomp'}"] = {"cold_p10": q(cold, 10), "cold_p50": q(cold, 50), "cold_p90": q(cold, 90), "warm_p50": q(warm, 50)}
         out[f"{mode}.{name}.H00"] = float(res.as_dict()["H_ss"][0][0])
