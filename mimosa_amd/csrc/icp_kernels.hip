@@ -36,6 +36,9 @@
 #ifndef MH_PIPE
 #define MH_PIPE 4  // quads in flight per lane in the neighbour scan (knn_query)
 #endif
+#ifndef MH_XCD_PIECES
+#define MH_XCD_PIECES 2  // pieces of the Morton curve an XCD's chunks come from (icp_linearize_body: which chunk a wave takes)
+#endif
 #ifndef MH_PIPE_SMALL
 #define MH_PIPE_SMALL 4  // the same for the 256-thread workgroup class (6 and 8 measured in round 5: 21.6 / 21.7 / 21.4 us at 24 576 points — no effect)
 #endif
@@ -1361,7 +1364,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   const int qi = [&] {
     constexpr int WPB = TPB / 64;
     const int cpx = n_blocks >> 3, x = block_id & 7, j = block_id >> 3, wv = static_cast<int>(threadIdx.x >> 6);
+#if MH_XCD_PIECES > 1
+    // An XCD's chunks come from MH_XCD_PIECES (2) separate pieces of the curve, the odd piece in mirrored XCD order, so that a heavy
+    // eighth of the cloud is shared by two XCDs instead of ending the kernel on one: the same number of points and two compact
+    // regions per L2 (29.3-29.7 -> 29.0 us at 131 072 points, 21.3 -> 20.8 us at 24 576; four pieces: 31.3 us — gpurun c26).
+    constexpr int P = MH_XCD_PIECES;
+    static_assert(WPB % P == 0, "pieces must divide the waves of a workgroup");
+    const int S = cpx * (WPB / P), p = wv / (WPB / P), o = (wv % (WPB / P)) * cpx + j;
+    return ((p * 8 + ((p & 1) ? 7 - x : x)) * S + o) * 64 + static_cast<int>(threadIdx.x & 63u);
+#else
     return ((x * cpx * WPB) + wv * cpx + j) * 64 + static_cast<int>(threadIdx.x & 63u);
+#endif
   }();
 #else
   const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;

@@ -44,6 +44,12 @@ def run(E):
             dpos = max(float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(rn["poses_est"], rr["poses_est"]))
             rp_stats["native"] = {"scans_per_s": round(rn["scans_per_s"], 1), "keyframes": rn["n_keyframes"],
                                   "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rn["stage_s"].items()},
+                                  "factor_create_split_ms_per_scan": {k: round(rn["detail_s"][k] / rcfg.n_scans * 1e3, 3)
+                                                                      for k in ("icp_create", "photo_wait", "photo_factor") if k in rn.get("detail_s", {})},
+                                  "factor_create_note": "factor_create = ICPFactor construction (icp_create) + in the pipelined loop the wait for the worker "
+                                                        "thread's Photometric::updateMap of the previous scan, the preprocess commit and the candidate prefetch "
+                                                        "(photo_wait) + Photometric::getFactors (photo_factor): the pipelined loop moves the photometric tail of "
+                                                        "scan k - 1 behind the geometric front of scan k, so what it has not hidden shows up HERE, not in update_map",
                                   "max_abs_translation_difference_to_the_python_harness_m": dpos,
                                   "note": "replay_native (mimosa_amd/host/replay_main.cpp): the same loop in C++ over the host mirror, PIPELINED across "
                                           "scans (the next cloud staged on a copy stream, the photometric map update on a worker thread beside the next "
@@ -53,6 +59,8 @@ def run(E):
                 rs = replay.run_native(rcfg, rscans, td, repeats=2, sequential=True)
             rp_stats["native"]["sequential"] = {"scans_per_s": round(rs["scans_per_s"], 1),
                                                 "stage_ms_per_scan": {k: round(v / rcfg.n_scans * 1e3, 3) for k, v in rs["stage_s"].items()},
+                                                "factor_create_split_ms_per_scan": {k: round(rs["detail_s"][k] / rcfg.n_scans * 1e3, 3)
+                                                                                    for k in ("icp_create", "photo_wait", "photo_factor") if k in rs.get("detail_s", {})},
                                                 "trajectory_identical_to_pipelined": bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
                                                                                               for a, b in zip(rs["poses_est"], rn["poses_est"])))}
             with tempfile.TemporaryDirectory() as td:
