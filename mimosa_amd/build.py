@@ -31,7 +31,7 @@ SOURCES = [
     ("photo_kernels.hip", ["-ffp-contract=off"]),
     ("photo_api.hip", []),
 ]
-HEADERS = ["icp_device.hpp", "scan_device.hpp", "math3.hpp", "voxel_map.hpp", "voxel_group.hpp", "mh_internal.hpp", "photo_device.hpp", "map_device.hpp", "shard_device.hpp", "exact_sort.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
+HEADERS = ["icp_device.hpp", "wave_dpp.hpp", "scan_device.hpp", "math3.hpp", "voxel_map.hpp", "voxel_group.hpp", "mh_internal.hpp", "photo_device.hpp", "map_device.hpp", "shard_device.hpp", "exact_sort.hpp", os.path.join("..", "..", "include", "mimosa_hip.h")]
 
 
 def _hipcc() -> str:

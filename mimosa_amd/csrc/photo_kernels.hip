@@ -17,8 +17,10 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "photo_device.hpp"
+#include "wave_dpp.hpp"
 
 namespace mh
 {
@@ -741,12 +743,11 @@ __global__ __launch_bounds__(kT) void photo_grad_kernel(const float * dx, const 
 // ------------------------------------------------------------------------------------------------
 // PhotometricFactor::linearize — one wave per feature, lane = patch point
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+// wave-wide sums: DPP (wave_dpp.hpp), every lane gets the total.  (Round 5: the 43 butterflies of __shfl_xor on doubles of a
+// unary feature — 516 ds_bpermute — were a third of the kernel's 30 us: 29.8 -> 19.4 us.  Also tried on top, and taken out
+// again: the altitude table in LDS, the yaw window of project() requested at once and searched in registers, the pose index
+// by interpolation guess — 22.0 us: the chain is the fp64 atan2 / asin / sqrt of the two projections, not its table probes.)
+__device__ __forceinline__ double wave_sum(double v) { return wave_allsum_f64(v); }
 
 __device__ __forceinline__ double bilinear(const float * img, int cols, double x, double y)  // photometric_utils.cpp:368-388
 {
@@ -987,22 +988,23 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
   }
   const double wgt = sw / a.sigma;
   double row[13];
+  auto psi_rows = [&](const double (&D)[6], const int at) {  // six columns at a time: two 6-wide sums instead of twelve single ones
+    double cm[6], dc[6], pd[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double cm = wave_sum(Db[k]) / md;
-    const double dc = act ? Db[k] - cm : 0.0;
-    const double pd = wave_sum(psi * dc);
-    row[k] = act ? ((dc - psi * pd) / sigma) * wgt : 0.0;
-  }
-  const int NV = a.binary ? 13 : 7;
-  if (a.binary) {
+    for (int k = 0; k < 6; ++k) cm[k] = D[k];
+    wave_allsum_f64<6>(cm);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double cm = wave_sum(Da[k]) / md;
-      const double dc = act ? Da[k] - cm : 0.0;
-      const double pd = wave_sum(psi * dc);
-      row[6 + k] = act ? ((dc - psi * pd) / sigma) * wgt : 0.0;
+      dc[k] = act ? D[k] - cm[k] / md : 0.0;
+      pd[k] = psi * dc[k];
     }
+    wave_allsum_f64<6>(pd);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[at + k] = act ? ((dc[k] - psi * pd[k]) / sigma) * wgt : 0.0;
+  };
+  psi_rows(Db, 0);
+  if (a.binary) {
+    psi_rows(Da, 6);
     row[12] = e0 * wgt;
   } else {
     row[6] = e0 * wgt;
@@ -1014,15 +1016,35 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
     for (int k = 0; k < 6; ++k) ro[1 + k] = row[k];
     ro[7] = 1.0;
   }
-  // per-feature sums of v v^T (upper triangle), v = [J_b (, J_a), e]
+  // per-feature sums of v v^T (upper triangle), v = [J_b (, J_a), e]: 28 / 91 products, seven sums at a time
   double * part = a.partials + static_cast<size_t>(f) * kPhotoPartial;
-  int ent = 0;
-  for (int r = 0; r < NV; ++r)
-    for (int c = r; c < NV; ++c) {
-      const double s = wave_sum(row[r] * row[c]);
-      if (lane == 0) part[ent] = s;
-      ++ent;
+  auto triangle = [&](auto nv_tag) {
+    constexpr int NV = decltype(nv_tag)::value, NE = NV * (NV + 1) / 2;
+    static_assert(NE % 7 == 0, "28 and 91 are multiples of 7");
+    double prod[NE];
+    int ent = 0;
+#pragma unroll
+    for (int r = 0; r < NV; ++r)
+#pragma unroll
+      for (int c = r; c < NV; ++c) prod[ent++] = row[r] * row[c];
+#pragma unroll
+    for (int b = 0; b < NE / 7; ++b) {
+      double v[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) v[j] = prod[7 * b + j];
+      wave_allsum_f64<7>(v);
+      if (lane < 7) {
+        double s = v[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) s = lane == j ? v[j] : s;
+        part[7 * b + lane] = s;
+      }
     }
+  };
+  if (a.binary)
+    triangle(std::integral_constant<int, 13>{});
+  else
+    triangle(std::integral_constant<int, 7>{});
 }
 
 __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(const PhotoLinArgs a)

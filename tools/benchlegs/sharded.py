@@ -18,7 +18,7 @@ def run(E, line, real_stdout):
     capi, synth, barrier, run_steps, raw_linearize = E.capi, E.synth, E.barrier, E.run_steps, E.raw_linearize
     _R, _g, _out, _all_reduce = E._R, E._g, E._out, E._all_reduce
     win_stats = E.results.get("relinearize_window")
-    # ---- BASELINE configs[2]: the same scan against a map hash-sharded over the GPUs of the node.  The NATIVE path
+    # ---- BASELINE configs[2]: the same scan against a map block-sharded (lattice owner function) over the GPUs of the node.  The NATIVE path
     # (mimosa_amd/csrc/shard_api.hip, mh_shard_*): every rank stores the blocks it owns + a one-voxel halo, a linearize is one
     # chain of enqueues — route kernels, ncclAllToAll of fixed-size segments over xGMI, append, K3, ncclAllReduce of the Hessian
     # sums (+ K4 and a second all-reduce when the components are on), publish — and ONE wait.  Reported NEXT TO the replica
@@ -224,7 +224,7 @@ def run(E, line, real_stdout):
                 nwin_s = max(world, 2)
                 clouds = [spts] + [synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + 1000 * i)[0] for i in range(1, nwin_s)]
                 thr = _throughput_forms(False, vmap, comm, clouds, args.steps, f"{nwin_s} scans of {len(spts)} points per protocol round, map sharded over {world} rank(s)")
-                result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map hash-sharded over {world} rank(s) "
+                result = {"workload": f"configs[2]: the {len(spts)}-pt scan vs a {sr}-room map block-sharded (lattice owner function) over {world} rank(s) "
                                        f"(shard blocks of {1 << args.shard_block_log2}^3 voxels + one-voxel halo); value = cold linearize (association state reset, points already routed)",
                            "n_ranks": comm.world, "backend": comm.backend, "rccl_ranks": comm.info()["ranks_in_communicator"],
                            "rccl_version": comm.info()["rccl_version"], "steps": ksh, "unit": "Mpts/s", "block_log2": args.shard_block_log2,
