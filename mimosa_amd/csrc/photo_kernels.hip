@@ -224,9 +224,11 @@ __global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, 
 // project() with the yaw table (photometric_utils.cpp:80-198).  Returns 1 ok, 0 = false, -1 = the reference throws.
 // PCL's DEG2RAD / RAD2DEG macro constants (see oracle/photo_ref.hpp).
 // ------------------------------------------------------------------------------------------------
+// alt: the beam-altitude table (m.alt), or a copy of it in LDS (the factor kernel: the seven probes of the search are dependent loads)
 __device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * yaw, double px, double py, double pz, double & ux,
-                                           double & uy)
+                                           double & uy, const float * alt = nullptr)
 {
+  if (!alt) alt = m.alt;
   const double L = sqrt(px * px + py * py) - static_cast<double>(m.beam_offset_m);
   const double R = sqrt(L * L + pz * pz);
   const double phi = atan2(py, px);
@@ -240,14 +242,14 @@ __device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * y
   int lo = 0, hi = m.rows;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (static_cast<double>(m.alt[mid]) > th_deg)
+    if (static_cast<double>(alt[mid]) > th_deg)
       lo = mid + 1;
     else
       hi = mid;
   }
   int g = lo - 1;
   g = g < 0 ? 0 : (g > m.rows - 2 ? m.rows - 2 : g);
-  const float ag = m.alt[g], as = m.alt[g + 1];
+  const float ag = alt[g], as = alt[g + 1];
   uy = static_cast<double>(g) + (static_cast<double>(ag) - th_deg) / static_cast<double>(ag - as);
   const int approx_y = static_cast<int>(round(uy));
   if (approx_y < 0 || approx_y >= m.rows) return 0;
@@ -744,9 +746,9 @@ __global__ __launch_bounds__(kT) void photo_grad_kernel(const float * dx, const 
 // PhotometricFactor::linearize — one wave per feature, lane = patch point
 // ------------------------------------------------------------------------------------------------
 // wave-wide sums: DPP (wave_dpp.hpp), every lane gets the total.  (Round 5: the 43 butterflies of __shfl_xor on doubles of a
-// unary feature — 516 ds_bpermute — were a third of the kernel's 30 us: 29.8 -> 19.4 us.  Also tried on top, and taken out
-// again: the altitude table in LDS, the yaw window of project() requested at once and searched in registers, the pose index
-// by interpolation guess — 22.0 us: the chain is the fp64 atan2 / asin / sqrt of the two projections, not its table probes.)
+// unary feature — 516 ds_bpermute — were a third of the kernel's 30 us: 29.8 -> 19.4-20.1 us.  On top, same box (gpurun c31):
+// the altitude table in LDS 19.1, the pose index by interpolation guess 18.8 (both kept); the yaw window of project() requested
+// at once and searched in registers 21.6 (eleven loads and forty selects cost more than four dependent probes: not kept).)
 __device__ __forceinline__ double wave_sum(double v) { return wave_allsum_f64(v); }
 
 __device__ __forceinline__ double bilinear(const float * img, int cols, double x, double y)  // photometric_utils.cpp:368-388
@@ -781,7 +783,7 @@ __device__ __forceinline__ void mat3_vec(const double * R, double x, double y, d
 
 constexpr int kFeatPerBlock = 4;
 // one wave = one feature; returns as soon as the feature's status is known
-__device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
+__device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a, const float * s_alt)
 {
   const int lane = threadIdx.x & 63, f = blockIdx.x * kFeatPerBlock + (threadIdx.x >> 6);
   if (f >= a.n_features) return;  // whole waves
@@ -809,7 +811,7 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
     bz += a.dLe_t[2];
     // projectUndistorted (photometric_utils.cpp:287-366)
     double kx, ky;
-    int r = project_yaw(m, fr.yaw, bx, by, bz, kx, ky);
+    int r = project_yaw(m, fr.yaw, bx, by, bz, kx, ky, s_alt);
     bool ok = r > 0;
     if (r < 0) threw = 1;
     int dist_idx = -1;
@@ -849,7 +851,24 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
     if (ok) {
       // T_Le_Lt = interpolated_map_T_Le_Lt.at(points_deskewed[distortion_idx].t)
       const uint32_t ns = fr.points[dist_idx].t;
+      // lower bound of ns in the sorted timestamps.  The columns fire at a constant rate, so the index is guessed by linear
+      // interpolation between the first and the last timestamp and verified (one round trip instead of ten dependent ones);
+      // whatever the guess misses goes through the binary search.
       int lo = 0, hi = fr.n_poses;
+      if (fr.n_poses > 1) {
+        const uint32_t t0 = fr.pose_ns[0], t1 = fr.pose_ns[fr.n_poses - 1];
+        if (ns >= t0 && ns <= t1 && t1 > t0) {
+          const int gq = static_cast<int>((static_cast<double>(ns - t0) / static_cast<double>(t1 - t0)) * static_cast<double>(fr.n_poses - 1) + 0.5);
+          const int gl = gq > 0 ? gq - 1 : 0, gh = gq + 1 < fr.n_poses ? gq + 1 : fr.n_poses - 1;
+          const uint32_t a0 = fr.pose_ns[gl], a1 = fr.pose_ns[gq], a2 = fr.pose_ns[gh];  // three neighbours, requested together
+          if (a1 == ns && (gq == 0 || a0 < ns))
+            lo = hi = gq;  // the first entry equal to ns
+          else if (a0 == ns && (gl == 0 || fr.pose_ns[gl - 1] < ns))
+            lo = hi = gl;
+          else if (a2 == ns && a1 < ns)
+            lo = hi = gh;
+        }
+      }
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (fr.pose_ns[mid] < ns)
@@ -870,7 +889,7 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
         lx = (TR[0] * bx + (TR[3] * by + TR[6] * bz)) + itx;
         ly = (TR[1] * bx + (TR[4] * by + TR[7] * bz)) + ity;
         lz = (TR[2] * bx + (TR[5] * by + TR[8] * bz)) + itz;
-        r = project_yaw(m, fr.yaw, lx, ly, lz, ux, uy);
+        r = project_yaw(m, fr.yaw, lx, ly, lz, ux, uy, s_alt);
         if (r < 0) threw = 1;
         ok = r > 0;
       }
@@ -1047,9 +1066,16 @@ __device__ __forceinline__ void photo_linearize_feature(const PhotoLinArgs & a)
     triangle(std::integral_constant<int, 7>{});
 }
 
+constexpr int kAltLds = 512;  // beam altitudes kept in LDS by the factor kernel (taller sensors read the table in memory)
 __global__ __launch_bounds__(64 * kFeatPerBlock) void photo_linearize_kernel(const PhotoLinArgs a)
 {
-  photo_linearize_feature(a);
+  __shared__ float s_alt[kAltLds];
+  const bool alt_lds = a.model.rows <= kAltLds;
+  if (alt_lds) {
+    for (int i = threadIdx.x; i < a.model.rows; i += 64 * kFeatPerBlock) s_alt[i] = a.model.alt[i];
+    __syncthreads();
+  }
+  photo_linearize_feature(a, alt_lds ? s_alt : nullptr);
   // Completion number for a host that spins on the mapped block instead of paying a stream synchronisation (as K4 does
   // for the ICP factor): every block makes its host writes visible (system-scope fence), takes a ticket, the last one
   // re-arms the ticket and publishes.
