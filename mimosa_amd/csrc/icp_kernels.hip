@@ -61,6 +61,7 @@
 #endif
 #include "map_device.hpp"
 #include "math3.hpp"
+#include "wave_dpp.hpp"
 
 namespace mh
 {
@@ -148,68 +149,17 @@ __device__ __forceinline__ double sq_dist3(double dx, double dy, double dz)
   return (b & 7) * cpx + (b >> 3);
 }
 
-// Wave-wide sum by DPP (all 64 lanes must be active); the total lands in lane 63.  Two quad permutes, two
-// row mirrors, then row_bcast15 / row_bcast31 carry the 16-lane row sums across rows.  (Leaving this to
-// atomicAdd on LDS makes the compiler aggregate with a 64-trip scalar v_readlane loop per counter:
-// ~450 dependent SALU instructions each, 11 k of the wave's 71 k cycles in round 1.)
-__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
+// Wave-wide sums by DPP (wave_dpp.hpp; all 64 lanes must be active): the total lands in lane 63.
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t x)
 {
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140, 0xF, 0xF, false));  // row_mirror
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
-  return v;
+  uint32_t v[1] = {x};
+  wave_sum_to_lane63_u32<1>(v);
+  return v[0];
 }
-
-// The same for a double: each step moves the two halves by DPP and adds in fp64 (lanes a step does not write add +0.0).  The
-// order of the additions is fixed by the lane pattern: deterministic.  (Six __shfl_xor rounds on doubles are 12 ds_bpermute
-// each — the LDS pipeline of the CU, shared by its waves: 2.1 us for K4's six sums, round 4.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_pull_f64(double v)
-{
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-// Six doubles / three words at once, step by step: six (three) independent chains for the scheduler to interleave.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dpp_step6_f64(double (&v)[6])
-{
-  double t[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) t[j] = dpp_pull_f64<CTRL, ROW_MASK>(v[j]);
-#pragma unroll
-  for (int j = 0; j < 6; ++j) v[j] += t[j];
-}
-__device__ __forceinline__ void wave_sum6_f64_to_lane63(double (&v)[6])
-{
-  dpp_step6_f64<0xB1, 0xF>(v);
-  dpp_step6_f64<0x4E, 0xF>(v);
-  dpp_step6_f64<0x141, 0xF>(v);
-  dpp_step6_f64<0x140, 0xF>(v);
-  dpp_step6_f64<0x142, 0xA>(v);
-  dpp_step6_f64<0x143, 0xC>(v);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dpp_step3_u32(uint32_t (&v)[3])
-{
-  uint32_t t[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) t[j] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v[j]), CTRL, ROW_MASK, 0xF, false));
-#pragma unroll
-  for (int j = 0; j < 3; ++j) v[j] += t[j];
-}
-__device__ __forceinline__ void wave_sum3_to_lane63(uint32_t (&v)[3])
-{
-  dpp_step3_u32<0xB1, 0xF>(v);
-  dpp_step3_u32<0x4E, 0xF>(v);
-  dpp_step3_u32<0x141, 0xF>(v);
-  dpp_step3_u32<0x140, 0xF>(v);
-  dpp_step3_u32<0x142, 0xA>(v);
-  dpp_step3_u32<0x143, 0xC>(v);
-}
+// (six __shfl_xor rounds on doubles are 12 ds_bpermute each — the LDS pipeline of the CU, shared by its waves: 2.1 us for K4's
+// six sums, round 4)
+__device__ __forceinline__ void wave_sum6_f64_to_lane63(double (&v)[6]) { wave_sum_to_lane63_f64<6>(v); }
+__device__ __forceinline__ void wave_sum3_to_lane63(uint32_t (&v)[3]) { wave_sum_to_lane63_u32<3>(v); }
 // Broadcast of one lane's value to the wave (l must be wave-uniform): v_readlane_b32 -> SGPR.
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, int l)
 {
