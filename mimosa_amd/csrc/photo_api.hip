@@ -79,7 +79,7 @@ struct mh_photo
   mh::PhotoModel model{};
   DevBuf d_alt, d_shift, d_hp, d_lp, d_static;
   // per-frame scratch
-  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather, d_stamps;
+  DevBuf d_raw_pts, d_img_raw, d_tmp_a, d_tmp_b, d_mask_raw, d_yaw_valid, d_int_out, d_grad, d_detmask, d_xyz, d_cand, d_gather, d_stamps, d_proj_pre;
   // frame stamps of the four-launch preprocess (photo_scatter_stamp_kernel): zeroed when (re)allocated, seq counts the frames
   void * stamps_zeroed_at = nullptr;
   size_t stamps_zeroed_bytes = 0;
@@ -139,7 +139,7 @@ void photo_release(mh_photo * p)
   if (p->next_ev) (void)hipEventDestroy(p->next_ev);
   if (p->scan_ev) (void)hipEventDestroy(p->scan_ev);
   for (DevBuf * b : {&p->d_alt, &p->d_shift, &p->d_hp, &p->d_lp, &p->d_static, &p->d_raw_pts, &p->d_img_raw, &p->d_tmp_a, &p->d_tmp_b,
-                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather, &p->d_stamps})
+                     &p->d_mask_raw, &p->d_yaw_valid, &p->d_int_out, &p->d_grad, &p->d_detmask, &p->d_xyz, &p->d_cand, &p->d_gather, &p->d_stamps, &p->d_proj_pre})
     b->release();
   if (p->h_counters) (void)hipHostFree(p->h_counters);
   if (p->h_int_out) (void)hipHostFree(p->h_int_out);
@@ -392,6 +392,7 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
   pc.desk_points = desk;
   pc.desk_src = nullptr;
   pc.desk_writeback = nullptr;
+  pc.proj_pre = nullptr;
   pc.proj = static_cast<int32_t *>(fr->d_proj.p);
   pc.counters = ph->d_counters;
   pc.rows = rows;
@@ -418,6 +419,8 @@ int preprocess_device(mh_photo * ph, PhotoFrame * fr, const mh_point32 * d_raw, 
       ph->stamps_zeroed_bytes = sb;
       ph->frame_seq = 0;
     }
+    MH_HIP(ctx, ph->d_proj_pre.reserve((n ? n : 1) * mh::kPhotoProjPreBytes, ctx->stream, false));
+    pc.proj_pre = ph->d_proj_pre.p;
     pc.stamps = static_cast<uint32_t *>(ph->d_stamps.p);
     pc.seq = ++ph->frame_seq;
     pc.raw_points = d_raw;

@@ -89,6 +89,7 @@ hipError_t launch_photo_erode(const uint8_t * in, const uint8_t * static_mask, i
 // Photometric::preprocess behind the scatter — the image chain (photometric.cpp:246-320), the mask erosion (:349-371), the
 // yaw-table fill (:135-199) and the projection index (:218-244) — the scatter and three multi-job launches, four in all
 // (photo_kernels.hip, "Round 4" and photo_scatter_stamp_kernel)
+constexpr size_t kPhotoProjPreBytes = 32;
 struct PhotoChain
 {
   const float * raw;
@@ -116,6 +117,7 @@ struct PhotoChain
   float * raw_w;
   float * range;
   int32_t * idx_w;
+  void * proj_pre;  // n_pts x kPhotoProjPreBytes of scratch: the projection's front (stage A) hands its findings to the back (stage B)
   // the frame's pose table, copied by a job of stage A: copy_bytes (a multiple of 16) from a mapped pinned block
   const void * copy_src;
   void * copy_dst;

@@ -224,14 +224,18 @@ __global__ __launch_bounds__(kT) void photo_yaw_fill_kernel(const PhotoModel m, 
 // project() with the yaw table (photometric_utils.cpp:80-198).  Returns 1 ok, 0 = false, -1 = the reference throws.
 // PCL's DEG2RAD / RAD2DEG macro constants (see oracle/photo_ref.hpp).
 // ------------------------------------------------------------------------------------------------
+// In two parts: the FRONT needs no yaw table (the fp64 square roots, atan2, asin and the altitude search: most of the arithmetic),
+// the BACK is the column search in the table's row.  project_yaw = front, then back; the preprocess chain runs the front of every
+// point in stage A's launch, beside the jobs that build the yaw table, and the back in stage B's (same operations, same order).
 // alt: the beam-altitude table (m.alt), or a copy of it in LDS (the factor kernel: the seven probes of the search are dependent loads)
-__device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * yaw, double px, double py, double pz, double & ux,
-                                           double & uy, const float * alt = nullptr)
+// front: -1 = the reference throws, 0 = false, 2 = go on with (phi, ux, uy)
+__device__ __forceinline__ int project_yaw_front(const PhotoModel & m, double px, double py, double pz, double & phi, double & ux, double & uy,
+                                                 const float * alt = nullptr)
 {
   if (!alt) alt = m.alt;
   const double L = sqrt(px * px + py * py) - static_cast<double>(m.beam_offset_m);
   const double R = sqrt(L * L + pz * pz);
-  const double phi = atan2(py, px);
+  phi = atan2(py, px);
   const double theta = asin(pz / R);
   ux = m.fx * phi + m.cx;
   if (ux < 0 || ux >= static_cast<double>(m.cols)) return -1;
@@ -253,6 +257,11 @@ __device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * y
   uy = static_cast<double>(g) + (static_cast<double>(ag) - th_deg) / static_cast<double>(ag - as);
   const int approx_y = static_cast<int>(round(uy));
   if (approx_y < 0 || approx_y >= m.rows) return 0;
+  return 2;
+}
+__device__ __forceinline__ int project_yaw_back(const PhotoModel & m, const float * yaw, const double phi, double & ux, const double uy)
+{
+  const int approx_y = static_cast<int>(round(uy));
   const float * row = yaw + static_cast<size_t>(approx_y) * m.cols;
   int il = static_cast<int>(ux) - 5, ir = static_cast<int>(ux) + 5;
   il = il < 0 ? 0 : il;
@@ -273,6 +282,13 @@ __device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * y
   ux = static_cast<double>(il) + (static_cast<double>(yl) - phi) / static_cast<double>(yl - yr);
   return (ux >= 0 && ux <= m.cols - 1 && uy >= 0 && uy <= m.rows - 1) ? 1 : 0;
 }
+__device__ __forceinline__ int project_yaw(const PhotoModel & m, const float * yaw, double px, double py, double pz, double & ux,
+                                           double & uy, const float * alt = nullptr)
+{
+  double phi;
+  const int r = project_yaw_front(m, px, py, pz, phi, ux, uy, alt);
+  return r == 2 ? project_yaw_back(m, yaw, phi, ux, uy) : r;
+}
 
 // preprocess stage 3: project + proj_idx.  Slots 1..9 of a pixel hold its 9 smallest point indices in ascending
 // order, kept by a carry chain of atomicMin (the displaced larger value moves on to the next slot); the reference
@@ -288,6 +304,45 @@ __device__ __forceinline__ void project_point(const PhotoModel & m, const mh_poi
   if (r < 0) atomicAdd(&counters->project_throw, 1u);
   if (r <= 0) return;
   const int u = static_cast<int>(round(ux)), v = static_cast<int>(round(uy));
+  if (u < 0 || v < 0) return;
+  int32_t * slot = proj + (static_cast<size_t>(v) * m.cols + u) * kPhotoDup;
+  int cur = i;
+#pragma unroll 1
+  for (int s = 1; s < kPhotoDup && cur != kProjEmpty; ++s) {
+    const int old = atomicMin(&slot[s], cur);
+    cur = max(old, cur);
+  }
+}
+// The same in the chain's two launches: what the front found out about point i travels in a 32-byte record.
+struct ProjPre
+{
+  double phi, ux, uy;
+  int32_t code;  // project_yaw_front's result; 0 also for a point outside the range gate
+  int32_t pad;
+};
+static_assert(sizeof(ProjPre) == kPhotoProjPreBytes, "photo_api.hip sizes the scratch by kPhotoProjPreBytes");
+__device__ __forceinline__ void project_point_front(const PhotoModel & m, const mh_point32 * desk, int n, ProjPre * pre, const int i)
+{
+  if (i >= n) return;
+  const mh_point32 p = desk[i];
+  ProjPre r;
+  r.phi = r.ux = r.uy = 0.0;
+  r.pad = 0;
+  r.code = 0;
+  if (!(p.range < m.range_min || p.range > m.range_max))
+    r.code = project_yaw_front(m, static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z), r.phi, r.ux, r.uy);
+  pre[i] = r;
+}
+__device__ __forceinline__ void project_point_back(const PhotoModel & m, int n, const float * yaw, int32_t * proj, PhotoCounters * counters,
+                                                   const ProjPre * pre, const int i)
+{
+  if (i >= n) return;
+  const ProjPre q = pre[i];
+  if (q.code < 0) atomicAdd(&counters->project_throw, 1u);
+  if (q.code != 2) return;
+  double ux = q.ux;
+  if (project_yaw_back(m, yaw, q.phi, ux, q.uy) <= 0) return;
+  const int u = static_cast<int>(round(ux)), v = static_cast<int>(round(q.uy));
   if (u < 0 || v < 0) return;
   int32_t * slot = proj + (static_cast<size_t>(v) * m.cols + u) * kPhotoDup;
   int cur = i;
@@ -666,7 +721,8 @@ struct PhotoStageArgs  // one argument block for the three multi-job launches
   int32_t * idx_w;
   const uint4 * copy_src;
   uint4 * copy_dst;
-  int n_copy16, n_job2, n_job3;
+  int n_copy16, n_job2, n_job3, n_job4;
+  ProjPre * pre;  // per-point records of the projection's front (stage A) for its back (stage B)
   mh_point32 * desk_writeback;  // stage C: the corrected intensities also go into this cloud (a scan's resident one), or nullptr
 };
 // Workgroups of the three stage launches: 1024 threads.  The tiles are the ones of the 256-thread single-stage kernels; a
@@ -700,8 +756,10 @@ __global__ __launch_bounds__(kTS) void photo_stage_a_kernel(const PhotoStageArgs
       a.range[i] = 0.f;
       a.idx_w[i] = -1;
     }
+  } else if (b < a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3 + a.n_job4) {  // the projection's front: everything that needs no yaw table
+    project_point_front(m, a.desk, a.n_pts, a.pre, (b - a.n_job0 - a.n_job1 - a.n_job2 - a.n_job3) * kTS + static_cast<int>(threadIdx.x));
   } else {  // the frame's pose table from its mapped pinned block (read by the factors, not by this chain)
-    const int nb = static_cast<int>(gridDim.x) - (a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3);
+    const int nb = static_cast<int>(gridDim.x) - (a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3 + a.n_job4);
     for (int k = (b - (static_cast<int>(gridDim.x) - nb)) * kTS + static_cast<int>(threadIdx.x); k < a.n_copy16; k += nb * kTS) a.copy_dst[k] = a.copy_src[k];
   }
 }
@@ -713,7 +771,7 @@ __global__ __launch_bounds__(kTS) void photo_stage_b_kernel(const PhotoStageArgs
     const int gx = (a.cols + kHT_C - 1) / kHT_C;
     hfir_sub_tile(a.ta, a.raw, a.tb, a.rows, a.cols, a.lp, a.n_lp, a.scale, a.gamma, b % gx, b / gx, s_pool);
   } else {
-    project_point(m, a.desk, a.n_pts, a.yaw, a.proj, a.counters, (b - a.n_job0) * kTS + static_cast<int>(threadIdx.x));
+    project_point_back(m, a.n_pts, a.yaw, a.proj, a.counters, a.pre, (b - a.n_job0) * kTS + static_cast<int>(threadIdx.x));
   }
 }
 __global__ __launch_bounds__(kTS) void photo_stage_c_kernel(const PhotoStageArgs a)
@@ -1314,14 +1372,16 @@ hipError_t launch_photo_stages(const PhotoChain & c, const PhotoModel & m, hipSt
                        copy ? const_cast<mh_point32 *>(c.desk_points) : nullptr, c.n_pts, c.yaw, c.stamps, c.stamps + npx, c.seq, c.raw_w, c.range, c.idx_w,
                        c.intensity_out, c.proj, npb);
   }
-  // A: vertical FIR (or scaling) | erosion | yaw rows | reset values of unclaimed pixels | pose-table copy
+  // A: vertical FIR (or scaling) | erosion | yaw rows | reset values of unclaimed pixels | the projection's front | pose-table copy
   a.n_job0 = c.remove_lines ? tiles(kVT_R, kVT_C) : (npx + kTS - 1) / kTS;
   a.n_job1 = tiles(kET_R, kET_C);
   a.n_job2 = m.rows;
   a.n_job3 = (npx + kTS - 1) / kTS;
+  a.n_job4 = (c.n_pts + kTS - 1) / kTS;
+  a.pre = static_cast<ProjPre *>(c.proj_pre);
   const int ncopy = a.n_copy16 ? std::min(4, (a.n_copy16 + kTS - 1) / kTS) : 0;
-  hipLaunchKernelGGL(photo_stage_a_kernel, dim3(a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3 + ncopy), dim3(kTS), 0, stream, a, m);
-  // B: horizontal FIR + subtract | projection
+  hipLaunchKernelGGL(photo_stage_a_kernel, dim3(a.n_job0 + a.n_job1 + a.n_job2 + a.n_job3 + a.n_job4 + ncopy), dim3(kTS), 0, stream, a, m);
+  // B: horizontal FIR + subtract | the projection's back
   a.n_job0 = c.remove_lines ? tiles(kHT_R, kHT_C) : 0;
   a.n_job1 = (c.n_pts + kTS - 1) / kTS;
   if (a.n_job0 + a.n_job1 > 0) hipLaunchKernelGGL(photo_stage_b_kernel, dim3(a.n_job0 + a.n_job1), dim3(kTS), 0, stream, a, m);
