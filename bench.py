@@ -9,10 +9,12 @@ A "step" = one COLD ICPFactor::linearize of the whole scan (fresh data-associati
 voxel-map k-NN, plane fit, residual, Jacobian; the 6x6 Hessian + localizabilities come back to the host).  Scan and
 map are resident in HBM before the timed region.
 
-This file holds the headline only: world, timed region (`run_steps`, `timed_block`), roofline, cpu_baseline and the
+This file holds the headline only: world, timed region (`run_steps_sync`, `timed_block`), roofline, cpu_baseline and the
 JSON line.  Everything else the line reports is a side leg under tools/benchlegs/ (one module each, `run(E)`).
-`value` = the pipelined form (<= 64 calls of the factor in flight); `value_sync` = one synchronous call at a time,
-which is what SURVEY.md 8(d) defines and what the reference's callers do (geometric.cpp:194-196) — see `metric_form`.
+`value` = N / the wall time of ONE synchronous cold linearize — SURVEY.md 8(d)'s definition and what the reference's callers
+do (geometric.cpp:194-196; GTSAM re-linearizes one factor at a time): the timed region is --steps such calls made back to back
+from C through the raw C ABI (tools/micro/sync_caller.c).  `value_pipelined` = the same work with <= 64 calls of the factor in
+flight (mh_icp_linearize_async), a form no caller of the reference produces — see `metric_form`.
 """
 from __future__ import annotations
 
@@ -29,7 +31,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from benchlegs.env import HBM_COPY_GBS, HBM_PEAK_GBS, INFLIGHT_ICP, Env  # noqa: E402
+from benchlegs.env import HBM_COPY_GBS, HBM_PEAK_GBS, INFLIGHT_ICP, Env, c_sync_steps  # noqa: E402
 
 N_SIMD, SHADER_GHZ = 1024, 2.4  # MI355X: 256 CUs x 4 SIMDs, peak engine clock (MI355X_MICROARCH.md)
 
@@ -41,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rooms", type=str, default="2x5", help="map size in rooms (2x5 ~ 5 M points)")
     ap.add_argument("--rows", type=int, default=128, help="scan rows (128 -> 131 072 points)")
-    ap.add_argument("--streams", type=int, default=1, help="independent scans in flight on separate HIP streams sharing the map")
+    ap.add_argument("--streams", type=int, default=1, help="(kept for old command lines; the headline is one synchronous call at a time)")
     ap.add_argument("--concurrent-streams", type=int, default=4, help="size of the value_concurrent pass (0/1 = skip)")
     ap.add_argument("--profile-mode", action="store_true", help="only the warm-up and the timed region (what rocprofv3 should see)")
     ap.add_argument("--event-every", type=int, default=10, help="HIP events bracket the kernels of every n-th call of the timed region")
@@ -98,12 +100,6 @@ def setup(args) -> Env:
 
     E.capi, E.synth = capi, synth
     E.ctx = capi.Context(E.local_rank)  # raises if the HIP extension or the GPU is missing: no fallback
-    E.overlap_note = "component server on (K4 of call i beside K3 of call i + 1)"
-    if E.dist is not None and E.world > 1:
-        # several ranks: RCCL and torch bring their own streams into the process's 4 hardware queues; the component server
-        # must never share one with the compute stream, which a one-GPU box cannot check — every kernel stays on ONE stream
-        E.ctx.set_overlap(False)
-        E.overlap_note = "component server OFF in multi-rank runs (K3 and K4 on one stream: ~5 us per step more than at N = 1)"
     E.room_clouds, E.pts, E.R, E.t = build_world(E.rank, args.rooms, args.rows)
     E.cfgd = synth.enwide_config()
     t0 = time.time()
@@ -115,13 +111,6 @@ def setup(args) -> Env:
     E.n_pts = len(E.pts)
     E.first = E.factor.linearize(E.R, E.t)  # first cold pass
     E.ctxs, E.factors = [E.ctx], [E.factor]
-    for sidx in range(1, args.streams):  # additional independent scans (own noise seed) on their own streams, same map
-        c2 = capi.Context(E.local_rank)
-        p2, _ = synth.make_scan(args.rows, seed=synth.BASE_SEED + 1 + E.rank + 1000 * sidx)
-        f2 = capi.ICPFactor(c2, E.gmap, p2, capi.make_reg_config(**E.cfgd))
-        f2.linearize(E.R, E.t)
-        E.ctxs.append(c2)
-        E.factors.append(f2)
     E.stats = E.gmap.stats()
     E.setup_s = time.time() - t0
 
@@ -133,8 +122,16 @@ def setup(args) -> Env:
             E.dist.barrier()
             torch.cuda.synchronize()
 
+    def run_steps_sync(k, collect=None):
+        """k cold SYNCHRONOUS linearizes, one at a time, made from C through the raw C ABI (tools/micro/sync_caller.c): every
+        call returns with its result on the host before the next one is made."""
+        outs = (capi.IcpResult * k)()
+        c_sync_steps(E.ctx, E.factor.h, E.R, E.t, [0.0, 0.0, -1.0], outs)
+        if collect is not None:
+            collect.extend(outs)
+
     def run_steps(k, collect=None, fs=None):
-        """k cold linearizes in total, dealt round-robin to the streams, <= INFLIGHT_ICP in flight each."""
+        """(side legs) k cold linearizes PIPELINED: <= INFLIGHT_ICP calls of the factor in flight, results collected per burst."""
         fs = E.factors if fs is None else fs
         done = 0
         while done < k:
@@ -163,7 +160,7 @@ def setup(args) -> Env:
             E._t[:] = tvec
         rc = _lin(*_raw)
         assert rc == 0, rc
-    E.barrier, E.run_steps, E.raw_linearize = barrier, run_steps, raw_linearize
+    E.barrier, E.run_steps, E.run_steps_sync, E.raw_linearize = barrier, run_steps, run_steps_sync, raw_linearize
     return E
 
 
@@ -171,7 +168,7 @@ def timed_block(E, k, collect=None):
     """EXACTLY k steps bracketed by a barrier + device synchronisation on both sides; max over ranks; seconds."""
     E.barrier()
     t_start = time.perf_counter()
-    E.run_steps(k, collect)
+    E.run_steps_sync(k, collect)
     E.barrier()
     el = time.perf_counter() - t_start
     if E.dist is not None:
@@ -201,8 +198,8 @@ def headline(E):
         # (gpurun c28: 0.046-0.054 ms per step in the first block of 20 against 0.038-0.040 in the others)
         for _ in range(4):
             E.barrier()
-            E.run_steps(16)
-    E.run_steps(args.warmup)
+            E.run_steps_sync(16)
+    E.run_steps_sync(args.warmup)
     outs = []
     block_s = [timed_block(E, args.steps, outs)]  # the timed region of the contract
     if not args.profile_mode:
@@ -212,16 +209,7 @@ def headline(E):
     k4_ms = np.array([o.gpu_ms_localizability for o in outs if o.gpu_ms_localizability >= 0], dtype=np.float64)
     assert len(k3_ms) > 0, "no linearize call of the timed region was bracketed by HIP events"
     k4_timing = "HIP events around the K4 launches of the bracketed calls of the timed region"
-    if len(k4_ms) == 0:  # pipelined calls hand K4 to the component server (no launch to bracket): timed on synchronous calls
-        for c in E.ctxs:
-            c.set_profiling(1)
-        k4s = []
-        for _ in range(12):
-            E.factors[0].reset()
-            k4s.append(E.factors[0].linearize(E.R, E.t)["gpu_ms_localizability"])
-        k4_ms = np.array([x for x in k4s[2:] if x >= 0], dtype=np.float64)
-        k4_timing = "HIP events around K4 in 10 synchronous calls after the timed region (pipelined calls: the component server does K4's work)"
-    last = outs[(len(outs) - 1) // len(E.factors) * len(E.factors)].as_dict()  # a result of stream 0
+    last = outs[-1].as_dict()
     assert np.array_equal(last["H_ss"], E.first["H_ss"]), "cold linearize is not reproducible"
     for c in E.ctxs:
         c.set_profiling(False)
@@ -345,9 +333,9 @@ def main():
         "config": {
             "workload": f"configs[1]: OS0-128 {n}-pt scan vs {E.stats['n_points']}-pt local map ({E.stats['n_voxels']} voxels, {args.rooms} rooms), "
                         "k=5 point-to-plane, ENWIDE params, cold linearize per step",
-            "mode": f"{args.streams} scan(s) on {args.streams} HIP stream(s) sharing one map, <= {INFLIGHT_ICP} linearize calls in flight per "
-                    f"stream, every result copied to the host; {E.overlap_note}",
-            "streams": args.streams, "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
+            "mode": "one synchronous mh_icp_linearize at a time on one HIP stream (K3 then K4), made from C through the raw C ABI; every call "
+                    "returns with the 6x6 Hessian, b, f, localizabilities and status histogram on the host",
+            "parallelism": "1 process/GPU, independent scan replicas (no data-path collective)" if world > 1 else "single GPU",
             "status_hist": [int(v) for v in last["status_hist"]], "exact_fallback_queries": int(last["n_exact_fallback"]),
             "mean_scanned_after_pruning": round(float(last["mean_scanned"]), 2), "valid_share": round(float(last["status_hist"][8]) / max(n, 1), 4),
             "candidates_per_query": res.pop("candidates_per_query", None),
@@ -364,9 +352,9 @@ def main():
         line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(E, last)
     shd = None if args.headline_only else sharded.run(E, line, real_stdout)
     line["sharded"] = shd
-    # ---- which figure is the metric.  SURVEY 8(d) defines it as N / the wall time of ONE cold linearize — value_sync, what the
-    # reference's callers do; `value` is the same work with calls pipelined.  With more than one rank `value` is the MAP-SHARDED
-    # factor's throughput form (north_star's multi-GPU design) and the replica figure stands next to it as value_replica.
+    # ---- which figure is the metric.  SURVEY 8(d) defines it as N / the wall time of ONE cold linearize — what the reference's
+    # callers do, and what `value` is.  With more than one rank `value` is the MAP-SHARDED factor (north_star's multi-GPU
+    # design), one synchronous protocol round at a time, and the replica figure stands next to it as value_replica.
     thr_ = shd.get("throughput") if isinstance(shd, dict) else None
     if thr_:
         src_ = ((shd.get("full_protocol_forced") or {}).get("throughput") if world == 1 else None) or thr_
@@ -377,18 +365,18 @@ def main():
                                  "unit": "Mpts/s", "what": src_["what"]}
         line["sharded_rccl"] = {"rccl_ranks": shd.get("rccl_ranks"), "rccl_version": shd.get("rccl_version"), "backend": shd.get("backend"),
                                 "note": "rccl_ranks = ncclCommCount of the communicator the sharded leg ran on, rccl_version = ncclGetVersion"}
-    form = ("value = <= 64 cold linearize calls of one factor in flight (results on the host, parity-checked); value_sync = one synchronous "
-            "mh_icp_linearize at a time = SURVEY 8(d)'s definition and the reference's call pattern (geometric.cpp:194-196)")
+    form = ("value = N / wall time of ONE synchronous cold mh_icp_linearize (SURVEY 8(d)'s definition, the reference's call pattern: "
+            "geometric.cpp:194-196), --steps such calls back to back from C; value_pipelined = <= 64 calls of the factor in flight")
     if world > 1:
         line["value_replica"], line["ms_per_step_replica"] = line["value"], line["ms_per_step"]
         if thr_:
-            line["value"], line["ms_per_step"], line["steps"] = thr_["value_batch_pipelined"], thr_["batch_pipelined_ms_per_round"], thr_["steps"]
+            line["value"], line["ms_per_step"], line["steps"] = thr_["value_batch_blocking"], thr_["batch_blocking_ms_per_round"], thr_["steps"]
             form = (f"value = the MAP-SHARDED factor: {thr_['factors']} scans of {n} points per protocol round (one ncclAllToAll + ncclAllReduce(s) "
-                    f"over xGMI per round), rounds pipelined, map hash-sharded over {world} GPUs; value_replica = independent scan replicas "
-                    f"({E.overlap_note})")
+                    f"over xGMI per round), one SYNCHRONOUS round at a time (mh_shard_icp_linearize_batch), map hash-sharded over {world} GPUs; "
+                    "value_sharded.batched_pipelined = rounds pipelined; value_replica = independent scan replicas, one synchronous call at a time each")
             line["config"]["parallelism"] = f"1 process/GPU, map hash-sharded over {world} GPUs (RCCL all-to-all + all-reduce per round)"
         else:
-            form = "value = independent scan replicas (the map-sharded leg did not complete: see sharded.error); " + E.overlap_note
+            form = "value = independent scan replicas, one synchronous call at a time each (the map-sharded leg did not complete: see sharded.error)"
     line["metric_form"] = form
     if rank == 0:
         sys.stdout.flush()

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 2  /* 2: the caller-driven sharding entry points, mh_map_fork and mh_map_sync are gone (round 5) */
+#define MH_ABI_VERSION 3  /* 3: mh_set_overlap is gone with the component server (round 6); 2: the caller-driven sharding entry points,
+                           * mh_map_fork and mh_map_sync went (round 5) */
 
 typedef enum mh_status {
   MH_OK = 0,
@@ -180,17 +181,6 @@ const char * mh_last_error(const mh_ctx * ctx);
  * bracket the kernels of every n-th linearize call of a factor (each event record costs ~4 us of stream time,
  * so a throughput measurement samples).  Untimed calls report gpu_ms_* = -1. */
 int mh_set_profiling(mh_ctx * ctx, int every);
-/* mh_icp_linearize_async pipelining: 1 (default) = the component pass (K4) of a pipelined call is done by a component
- * server, one long-running kernel on a side stream of the context that K3 signals through flag words in device memory (no
- * dispatch, event or barrier packet per call), so the context's stream goes from one call's K3 straight into the next
- * call's — K4 reads only what K3 recorded for that call, so consecutive calls of ONE factor overlap as well.  Only the first
- * context of a process gets a side stream (MH_SIDE_CONTEXTS raises that), and only calls that follow another call still in
- * flight use it; the server ends at the next mh_icp_wait / mh_synchronize / destroy, and by itself after ~4 s without
- * work.  A caller that synchronises the DEVICE (hipDeviceSynchronize) with pipelined calls open must call mh_icp_wait or
- * mh_synchronize first.  0 = every kernel on the context's stream (what several contexts sharing the device want: a
- * process has 4 hardware queues).  Results are identical either way, bit for bit.
- * The reference has no counterpart: GTSAM calls ICPFactor::linearize (geometric_factor.hpp:231) one factor after the other. */
-int mh_set_overlap(mh_ctx * ctx, int on);
 /* hipStream_t of the context, for callers that want to order their own work / events on it. */
 void * mh_stream(mh_ctx * ctx);
 int mh_synchronize(mh_ctx * ctx);
@@ -524,11 +514,16 @@ size_t mh_photo_factor_size(const mh_photo_factor * factor);
 /* ---- map sharded across GPUs (BASELINE configs[2]): what both the library's own exchange (below) and a
  * framework that owns the stream need ------------------------------------------------------------------------------------
  * No reference counterpart: the reference is single-process.  The map is partitioned into shard blocks of 2^block_log2 voxels
- * per axis owned by XORVector3iHash(block) mod world (the reference's hash, include/mimosa/lidar/utils.hpp:228-238); every
- * rank also stores the one-voxel halo of its blocks, so a query on the owner of its centre voxel finds all 1/7/19/27
- * neighbour voxels locally.  (ABI version 1 also exported a caller-driven form of the exchange — mh_icp_shard_plan / _pack /
+ * per axis; block (bx, by, bz) = voxel coordinates >> block_log2 is owned by rank (bx + A[world] by + B[world] bz) mod world, a
+ * lattice colouring of the block grid (neighbouring blocks never share a rank; tools/lattice_table.py derives the two tables;
+ * rounds 3-4 used the reference's XORVector3iHash, include/mimosa/lidar/utils.hpp:228-238, which put neighbouring heavy blocks
+ * on one rank at random).  A caller that partitions points itself asks mh_shard_owner_of_block instead of re-implementing the
+ * rule.  Every rank also stores the one-voxel halo of its blocks, so a query on the owner of its centre voxel finds all
+ * 1/7/19/27 neighbour voxels locally.  (ABI version 1 also exported a caller-driven form of the exchange — mh_icp_shard_plan / _pack /
  * _unpack, mh_icp_linearize_begin[_device] / _finish[_device], mh_icp_global_epilogue — with the collectives in the caller's
  * hands; version 2 keeps ONE implementation, the native one below.) */
+/* The owner function: rank (0 .. world - 1) of shard block (bx, by, bz); -1 if world is outside 1 .. 64. */
+int mh_shard_owner_of_block(int bx, int by, int bz, int world);
 /* A context on an existing HIP stream (not owned): kernels, the caller's collectives and its tensor ops are ordered by it. */
 int mh_init_on_stream(int device, void * hip_stream, mh_ctx ** out);
 /* This rank's share of IncrementalVoxelMapPCL::insert: of the batch (identical on every rank) the points of owned shard
@@ -540,7 +535,7 @@ int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_p
 /* ---- native map-sharded factor: the exchange inside the library (RCCL over xGMI) ------------------------------------
  * No reference counterpart (the reference is single-process): what it must preserve is that the sharded factor equals
  * ICPFactor::linearize (include/mimosa/lidar/geometric_factor.hpp:231-562) point for point.  Same partition as above
- * (shard blocks by XORVector3iHash, include/mimosa/lidar/utils.hpp:228-238; one-voxel halo stored by mh_map_insert_shard).
+ * (shard blocks by the lattice owner function, mh_shard_owner_of_block; one-voxel halo stored by mh_map_insert_shard).
  * One process per GPU; a linearize is ONE chain of enqueues — route kernels, ncclAllToAll of fixed-size per-peer segments
  * [count | records], append, K3, ncclAllReduce of the Hessian sums, (K4 + ncclAllReduce when the components are on), publish —
  * and one wait at its end: no count ever crosses the host, the factor's slot count lives on the device.  A segment that

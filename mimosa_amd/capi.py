@@ -18,7 +18,7 @@ MH_OK, MH_ERR_INVALID_ARG, MH_ERR_HIP, MH_ERR_NO_DEVICE, MH_ERR_OOM, MH_ERR_UNSU
 
 # every symbol include/mimosa_hip.h declares
 EXPORTS = [
-    "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling", "mh_set_overlap",
+    "mh_abi_version", "mh_init", "mh_shutdown", "mh_last_error", "mh_set_profiling",
     "mh_stream", "mh_synchronize", "mh_timer_begin", "mh_timer_end",
     "mh_map_create", "mh_map_insert", "mh_map_insert_device", "mh_map_insert_from_scan", "mh_map_copy", "mh_map_retain", "mh_map_release", "mh_map_get_stats",
     "mh_map_get_cloud", "mh_map_knn",
@@ -29,7 +29,7 @@ EXPORTS = [
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", 
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
-    "mh_shard_comm_backend", "mh_shard_comm_info", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
+    "mh_shard_comm_backend", "mh_shard_comm_info", "mh_shard_owner_of_block", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
     "mh_shard_icp_linearize_batch_async", "mh_shard_icp_wait", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
     "mh_shard_icp_stats", "mh_shard_icp_destroy", "mh_alloc_check_stats",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
@@ -319,13 +319,14 @@ def load(build_if_missing: bool = True):
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     pvp = C.POINTER(C.c_void_p)
     L.mh_abi_version.restype = i32
+    L.mh_shard_owner_of_block.argtypes = [i32, i32, i32, i32]
+    L.mh_shard_owner_of_block.restype = i32
     L.mh_init.argtypes = [i32, pvp]
     L.mh_shutdown.argtypes = [vp]
     L.mh_shutdown.restype = None
     L.mh_last_error.argtypes = [vp]
     L.mh_last_error.restype = C.c_char_p
     L.mh_set_profiling.argtypes = [vp, i32]
-    L.mh_set_overlap.argtypes = [vp, i32]
     L.mh_stream.argtypes = [vp]
     L.mh_stream.restype = vp
     L.mh_synchronize.argtypes = [vp]
@@ -459,10 +460,6 @@ class Context:
     def set_profiling(self, every):
         """0/False = off, n = HIP events around the kernels of every n-th linearize call (True = every call)."""
         self.check(self.L.mh_set_profiling(self.h, int(every)))
-
-    def set_overlap(self, on):
-        """K4 of pipelined linearize calls on a side stream of the context (default on); off = one stream per context."""
-        self.check(self.L.mh_set_overlap(self.h, int(bool(on))))
 
     def synchronize(self):
         self.check(self.L.mh_synchronize(self.h))

@@ -79,31 +79,11 @@ struct IcpArgs
   // kShardSkip (points that left for another rank, or could not be sent yet) are passed over untouched
   const uint32_t * n_dev = nullptr;    // null: n is exact
   double * shard_out = nullptr;        // non-null: the last block also writes the NENT sums + 4 counters here (all-reduce input)
-  // plain factors whose K4 follows: what K4 needs of every point, written HERE into a per-call record (6 arrays of rec_n
+  // plain factors whose K4 follows: what K4 needs of every point, written HERE into the factor's record (6 arrays of rec_n
   // doubles: the unwhitened, normalised Jacobian directions jr[3], jt[3] — zero unless the point is Valid — then rec_n
-  // status words).  K4 reads nothing of the factor's association state any more, so K4 of one call may run beside K3 of the
-  // next call of the same factor (the host alternates two records and two sets of partial rows: mh_api.hip)
+  // status words).  K4 follows on the same stream and reads nothing of the factor's association state.
   double * rec = nullptr;
   int rec_n = 0;
-  // Side-stream calls (mh_api.hip: the K4 work is done by a kernel of ANOTHER stream, with no dependency packet between the
-  // streams — an event record + wait costs more stream time than the overlap buys): the kernels meet through flag words in
-  // device memory, one per workgroup, holding the ordinal of the factor's last side-stream call that workgroup has finished
-  // (compared modulo 2^32).  No atomics and no shared counter: 64 workgroups polling ONE word that 256 others bump with
-  // atomics kept that word so busy that K3 took 38-41 us instead of 32 (measured).
-  //   side != 0 (= the call's ordinal): record and rows are written through, then the workgroup stores `side` to sig[its index],
-  //     which the K4 work of this call polls.
-  //   k4_wait: the record / rows this call overwrites were last read by the K4 work of side-stream call k4_need — before storing
-  //     them the workgroup makes sure sig4[0 .. k4_blocks) have all reached it (they have, two calls later; the check is what
-  //     makes it certain).
-  unsigned int * sig = nullptr;
-  unsigned int * sig4 = nullptr;
-  unsigned int k4_need = 0;
-  int k4_blocks = 0;
-  int k4_wait = 0;
-  unsigned int side = 0;
-  // side-stream calls: workgroup 0 announces the call to the context's component server (LocServerArgs) by storing srv_j here
-  unsigned int * srv_posted = nullptr;
-  unsigned int srv_j = 0;
 };
 __host__ __device__ inline size_t loc_record_bytes(size_t n) { return n * (6 * sizeof(double) + sizeof(int32_t)); }
 constexpr int32_t kShardSkip = 0x100;  // status flag bit: not this rank's point in this call
@@ -130,39 +110,8 @@ struct LocArgs
   double * shard_out = nullptr;      // non-null: the last block also writes 6 component sums + 9 histogram counts here (16 doubles)
   const double * rec = nullptr;      // plain factors: the call's record written by K3 (IcpArgs::rec); src / normal / status are not read
   int rec_n = 0;
-  const unsigned int * sig = nullptr;  // side-stream calls (IcpArgs::sig): wait for sig[0 .. k3_blocks) to reach `side`, ...
-  unsigned int * sig4 = nullptr;       // ... sign off with sig4[workgroup] = side
-  unsigned int side = 0;
-  int srv_blocks = 0;                // component server: workgroups this call's K4 would have had (= rows the host folds)
-  int srv_class = 0;                 // ... and the class of its K3 launch (256 / 512 threads): chunks per workgroup
   unsigned long long * dbg = nullptr;  // MH_TIMELINE diagnostic build only, else null: per-wave stamps of this pass (16 words per wave)
 };
-
-// The component server: ONE long-running kernel on the context's side stream does the K4 work of every pipelined call.
-// Why not a K4 launch per call on that stream: every kernel dispatch starts with a cache acquire, and a dispatch that begins in
-// the middle of the next call's K3 costs that K3 7-9 us (measured: K3 31.8 -> 38.7-41 us with a K4 dispatch per call on a second
-// stream; a K3-only loop goes from 32.4 to 45.9 us per step when another stream issues small kernels at the same rate:
-// tools/interfere_probe.py) — more than the overlap buys.  The server is dispatched once per burst of calls:
-//   host    writes call j's LocArgs into ring[j % ring_n] (mapped pinned memory), then launches K3 with srv_posted / srv_j = j + 1
-//   K3      workgroup 0 stores srv_j to *posted when it starts; every workgroup signs off on the factor's sig[0] when it ends
-//   server  every workgroup, for j = first, first + 1, ...: waits for *posted >= j + 1, reads the slot, does the call's
-//           workgroups w, w + grid, ... exactly as K4 would (waiting for sig[0], publishing flagged words, signing off on sig[1])
-//   stop    the host stores N = calls posted so far to *stop (mapped pinned) when it wants the stream to drain (a wait, a
-//           synchronise, a destroy): the server ends once it has done calls < N and finds call N not posted
-struct alignas(256) LocServerSlot
-{
-  LocArgs a;
-};
-struct LocServerArgs
-{
-  const LocServerSlot * ring;   // mapped pinned (device address)
-  int ring_n;
-  unsigned int first;           // index of the first call this launch serves
-  unsigned int * posted;        // device word: calls announced by their K3 so far
-  const unsigned int * stop;    // mapped pinned word: 0 = keep serving
-};
-int loc_server_grid();
-hipError_t launch_loc_server(const LocServerArgs & s, hipStream_t stream);
 
 int linearize_grid(int n);
 int linearize_class(int n);  // threads per workgroup of the K3 launch for n points (256 / 512)

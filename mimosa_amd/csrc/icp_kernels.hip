@@ -42,23 +42,6 @@
 #ifndef MH_PIPE_SMALL
 #define MH_PIPE_SMALL 4  // the same for the 256-thread workgroup class (6 and 8 measured in round 5: 21.6 / 21.7 / 21.4 us at 24 576 points — no effect)
 #endif
-// Work sharing inside a workgroup (knn_query, "share") — an EXPERIMENT, compiled out by default: a lane that still has
-// MH_SHARE_MIN_VOX neighbour voxels to enter after MH_SHARE_TRIP trips of the scan posts MH_SHARE_HELPERS of every
-// (MH_SHARE_HELPERS + 1) of them as jobs in LDS; waves of the same workgroup whose own scans are over claim and scan them.
-// Correct (the GPU parity suites pass with -DMH_SHARE=1) and 4 us SLOWER on configs[1] (42.0 vs 38.0 us; DESIGN.md §3,
-// "Round 3, second attempt"): kept so that the measurement can be repeated (tools/variant.sh share -DMH_SHARE=1).
-#ifndef MH_SHARE
-#define MH_SHARE 0
-#endif
-#ifndef MH_SHARE_TRIP
-#define MH_SHARE_TRIP 4
-#endif
-#ifndef MH_SHARE_MIN_VOX
-#define MH_SHARE_MIN_VOX 3
-#endif
-#ifndef MH_SHARE_HELPERS
-#define MH_SHARE_HELPERS 3
-#endif
 #include "map_device.hpp"
 #include "math3.hpp"
 #include "wave_dpp.hpp"
@@ -182,7 +165,7 @@ __device__ __forceinline__ double lane_get(double v, int l)
 #else
 #define MH_STAMP(ptr, i) do { } while (0)
 #endif
-// K4's waves: indexed by the factor's workgroup index (the component server runs several virtual workgroups per real one)
+// K4's waves: indexed by the factor's workgroup index
 #ifdef MH_TIMELINE
 #define MH_STAMP4(ptr, i)                                                                                          \
   do {                                                                                                             \
@@ -192,11 +175,7 @@ __device__ __forceinline__ double lane_get(double v, int l)
 #else
 #define MH_STAMP4(ptr, i) do { } while (0)
 #endif
-#ifdef MH_BALANCE  // slots 13-15 carry the lane-balance counters instead of the C2 sub-phase stamps
-#define MH_STAMP_C2(ptr, i) do { } while (0)
-#else
 #define MH_STAMP_C2(ptr, i) MH_STAMP(ptr, i)
-#endif
 
 // 32-bit literals used per candidate, held in VGPRs: (a & lit) | lit needs two instructions with literal operands
 // (one literal per VOP3), one v_and_or_b32 with register operands.
@@ -328,21 +307,6 @@ struct ScanCursor
     ScanStage st;
     st.ofs = lut4[o_cur];
     uint32_t qidx = (e >> 5) * (kBucketStride / 4) + min(qd, static_cast<uint32_t>(kBucketStride / 4 - 1));
-#ifdef MH_DEAD_COALESCE
-    {
-      // a dead stage (this lane has no quad left while others of the wave still scan) loads quad 0 of voxel 0: every dead lane
-      // the SAME 16 bytes, one L1 transaction for all of them instead of one each.  Opaque to the compiler (a select on the
-      // index makes it sink the LDS read of `e` into a branch).
-      const uint32_t lm = 0u - static_cast<uint32_t>(qd < nq_cur);
-      asm volatile("v_and_b32 %0, %0, %1" : "+v"(qidx) : "v"(lm));
-    }
-#endif
-#ifdef MH_FAKE_SCAN_ADDR  // tuning experiment only (wrong results): every scan load reads quad 0 — the scan without its scattered line fills
-    {
-      uint32_t zero = 0u;
-      asm volatile("v_and_b32 %0, %0, %1" : "+v"(qidx) : "v"(zero));
-    }
-#endif
     st.quad = qbuckets[qidx];
     // valid slots: the voxel's count minus the slots before this quad, clamped to 0..4 — a quad index at or past the
     // voxel's last (an exhausted cursor keeps counting) gives 0 by itself: no liveness select
@@ -362,7 +326,7 @@ template <int K, int KK, int NOFF>
 __device__ __forceinline__ uint32_t prune_keep_mask(const uint32_t (&ck)[KK], const float (&boxd)[NOFF], int k, float err_g,
                                                     uint32_t kth_given = 0xFFFFFFFFu)
 {
-  uint32_t kth = kth_given;  // a k-th key proven elsewhere (the owner of a shared job at the time it posted it)
+  uint32_t kth = kth_given;  // a k-th key proven elsewhere (the other lanes of the query's lane group)
 #pragma unroll
   for (int i = 0; i < K; ++i)
     if (i == k - 1) kth = min(kth, ck[i]);
@@ -414,33 +378,6 @@ __device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage 
   return live_quads;
 }
 
-// ---- work sharing inside a workgroup ("share") ---------------------------------------------------------------------
-// LDS: word 0 = job slots handed out so far; from word 4 on, kShareJobWords per job:
-//   [0] state: 0 free, 1 posted, 2 claimed, 3 done
-//   posted:  [1..3] qg (f32 bits), [4] the owner's k-th key when it posted, [5] mask of the scan positions to enter,
-//            [6..9] quads per voxel (the owner's qc0 / qc1), [10] the owner's thread index (its LDS list column)
-//   done:    [1..KK] the job's sorted top-KK keys (KK <= 8), [9] candidates scanned, [10] scan positions entered
-// Every job is resolved by exactly one party: a helper's compare-and-swap 1 -> 2, or the owner's own (it takes back what
-// nobody claimed once its own share is done).  A helper never waits; an owner waits only for jobs a helper holds: no cycle.
-constexpr int kShareJobWords = 12;
-constexpr int kShareHdrWords = 4;
-__host__ __device__ constexpr int share_jobs(int tpb) { return tpb / 2; }
-__host__ __device__ constexpr int share_words(int tpb) { return MH_SHARE ? kShareHdrWords + share_jobs(tpb) * kShareJobWords : 4; }
-
-[[maybe_unused]] __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t * p)
-{
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-[[maybe_unused]] __device__ __forceinline__ void lds_store_release(uint32_t * p, uint32_t v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-[[maybe_unused]] __device__ __forceinline__ bool lds_claim(uint32_t * p)  // 1 -> 2
-{
-  uint32_t expect = 1u;
-  return __hip_atomic_compare_exchange_strong(p, &expect, 2u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found), dk = squared
 // distance of the k-th.  `list` is this lane's column of an LDS array [NOFF][stride] (cell words in scan order),
@@ -472,15 +409,13 @@ struct KnnPoints
   uint32_t member;  // bit u: pt[u] is one of the k nearest
 };
 constexpr int knn_survivors(int K) { return K + 3 + (K > 5 ? 1 : 0); }  // 8 for k = 5, 12 for the generic k <= 8 path
-template <int K, int NOFF, bool SHARE = false, bool FAST = false, int PIPE = MH_PIPE>
+template <int K, int NOFF, bool FAST = false, int PIPE = MH_PIPE>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
-                                              unsigned long long * dbg = nullptr, uint32_t * share = nullptr,
-                                              KnnPoints<knn_survivors(K)> * fast = nullptr)
+                                              unsigned long long * dbg = nullptr, KnnPoints<knn_survivors(K)> * fast = nullptr)
 {
   (void)dbg;
-  (void)share;
   (void)fast;
   fell_back = false;
   constexpr int KK = knn_survivors(K);
@@ -591,13 +526,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   box_dists<NOFF>(qg0, qg1, qg2, boxd);
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
   rem &= prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
-#ifdef MH_FAKE_SCAN_MASK  // tuning experiment only (wrong results): what the kernel would take if a lane scanned a subset of its voxels
-  rem &= MH_FAKE_SCAN_MASK;
-#endif
   uint32_t alive = rem;  // neighbour voxels never pruned: alive & ~rem (after the scan) = the voxels scanned
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-  const uint32_t amask_unpruned = amask & ~1u;
-#endif
 
   MH_STAMP(dbg, 11);
   // ---- B2. remaining voxels: flattened, software-pipelined coarse scan over QUADS of candidates ---
@@ -606,17 +535,10 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // wave loops while any lane still has a live quad in flight; after the first and second trip the
   // tightened bound prunes the voxels not entered yet (what matters for lanes whose centre voxel held
   // fewer than k points: their first bound is infinite).
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-  unsigned long long share_stats = 0ull;  // per wave: jobs posted | taken back | done by helpers | done for others | help rounds
-  uint32_t st_posted = 0u, st_back = 0u, st_helped = 0u, st_rounds = 0u;
-#endif
-  uint32_t extra_scanned = 0u;  // share: scan positions a helper entered for this lane
-  uint32_t donated = 0u;        // share: scan positions posted as jobs and not (yet) taken back
   {
     constexpr int kPipe = PIPE;
     const float4 * lut4 = reinterpret_cast<const float4 *>(scan_lut);
     const float cx0 = 0.5f - qg0, cy1 = 8192.0f - 0.5f + qg1, cz2 = 0.5f - qg2;
-    const uint32_t lane_ = threadIdx.x & 63u;
     ScanCursor<NOFF> cur;
     cur.rem = rem;
     cur.qc0 = qc0;
@@ -624,223 +546,16 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     ScanStage stage[kPipe];
 #pragma unroll
     for (int u = 0; u < kPipe; ++u) stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-    uint32_t trips = 0, myq = 0;
-#endif
-    constexpr int HS = MH_SHARE_HELPERS;
-    uint32_t job_base = 0u, job_pending = 0u, job_await = 0u;  // this lane's jobs: first slot, not resolved yet, held by a helper
     for (int trip = 0;; ++trip) {
-      if (!__any(static_cast<int>(stage[0].vcnt))) {  // a dead stage 0 means dead stages 1..3
-        if (SHARE && __any(static_cast<int>(job_pending))) {
-          // this wave's own shares are done: every lane takes back the first of its jobs that nobody has claimed
-          bool took = false;
-          const uint32_t keep_now = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
-          alive &= keep_now;
-#pragma unroll
-          for (int p = 0; p < HS; ++p) {
-            if (!took && ((job_pending >> p) & 1u)) {
-              job_pending &= ~(1u << p);
-              uint32_t * rec = share + kShareHdrWords + (job_base + static_cast<uint32_t>(p)) * kShareJobWords;
-              if (lds_claim(rec)) {
-                const uint32_t part = rec[5];
-                cur.rem |= part & keep_now;  // the bound has tightened since the job was posted
-                donated &= ~part;
-                took = true;
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-                ++st_back;
-#endif
-              } else {
-                job_await |= 1u << p;
-              }
-            }
-          }
-          if (__any(took)) {
-#pragma unroll
-            for (int u = 0; u < kPipe; ++u) stage[u] = cur.advance(list, lds_stride, lut4, map.qbuckets);
-            continue;
-          }
-        }
-        break;
-      }
-#ifdef MH_FAKE_TRIP_CAP  // tuning experiment only (wrong results): what the kernel would take if no wave ran more trips than this
-      if (trip >= MH_FAKE_TRIP_CAP) break;
-#endif
-      if constexpr (SHARE) {
-        if (trip == MH_SHARE_TRIP) {
-          // lanes with many voxels still to enter keep every (HS+1)-th of them and post the others as HS jobs
-          const int jobs_max = share_jobs(lds_stride);
-          const bool want = __popc(cur.rem) >= MH_SHARE_MIN_VOX;
-          const uint64_t wm = __ballot(want);
-          if (wm) {
-            const int leader = __builtin_ctzll(wm);
-            uint32_t base = 0u;
-            if (static_cast<int>(lane_) == leader)
-              base = __hip_atomic_fetch_add(share, static_cast<uint32_t>(__popcll(wm)) * HS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            base = lane_get(base, leader) + static_cast<uint32_t>(__popcll(wm & ((1ull << lane_) - 1ull))) * HS;
-            if (want && base + HS <= static_cast<uint32_t>(jobs_max)) {
-              uint32_t part[HS + 1];
-#pragma unroll
-              for (int p = 0; p <= HS; ++p) part[p] = 0u;
-              uint32_t cnt = 0u;
-#pragma unroll
-              for (int b = 1; b < NOFF; ++b) {
-                const uint32_t bit = cur.rem & (1u << b);
-#pragma unroll
-                for (int p = 0; p <= HS; ++p) part[p] |= (cnt == static_cast<uint32_t>(p)) ? bit : 0u;
-                cnt = bit ? (cnt == HS ? 0u : cnt + 1u) : cnt;
-              }
-              uint32_t kth = 0xFFFFFFFFu;
-#pragma unroll
-              for (int i = 0; i < K; ++i)
-                if (i == k - 1) kth = ck[i];
-#pragma unroll
-              for (int p = 1; p <= HS; ++p) {
-                uint32_t * rec = share + kShareHdrWords + (base + static_cast<uint32_t>(p - 1)) * kShareJobWords;
-                rec[1] = __float_as_uint(qg0);
-                rec[2] = __float_as_uint(qg1);
-                rec[3] = __float_as_uint(qg2);
-                rec[4] = kth;
-                rec[5] = part[p];
-                rec[6] = static_cast<uint32_t>(qc0);
-                rec[7] = static_cast<uint32_t>(qc0 >> 32);
-                rec[8] = static_cast<uint32_t>(qc1);
-                rec[9] = static_cast<uint32_t>(qc1 >> 32);
-                rec[10] = threadIdx.x;
-                donated |= part[p];
-              }
-#pragma unroll
-              for (int p = 1; p <= HS; ++p)
-                lds_store_release(share + kShareHdrWords + (base + static_cast<uint32_t>(p - 1)) * kShareJobWords, part[p] ? 1u : 3u);
-              // (an empty part is "done" at once: its record reads as a result nobody wrote — handled at the merge)
-              cur.rem = part[0];
-              job_base = base;
-              job_pending = 0u;
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-              st_posted = HS;
-#endif
-#pragma unroll
-              for (int p = 1; p <= HS; ++p) job_pending |= part[p] ? (1u << (p - 1)) : 0u;
-            }
-          }
-        }
-      }
+      if (!__any(static_cast<int>(stage[0].vcnt))) break;  // a dead stage 0 means dead stages 1..3
       if (MH_PRUNE_TRIPS) {
         const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
         cur.rem &= keep;
         alive &= keep;
       }
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-      ++trips;
-      myq +=
-#endif
-        scan_trip<KK, NOFF, kPipe>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
+      scan_trip<KK, NOFF, kPipe>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
     }
     rem = cur.rem;
-#ifdef MH_FAKE_MID_BARRIER  // tuning experiment only (hangs unless every wave of the block gets here): what a block-wide
-    __builtin_amdgcn_s_barrier();  // exchange point between the scan and the plane fit would cost by aligning the waves
-#endif
-    if constexpr (SHARE) {
-      // ---- help: claim posted jobs of this workgroup and scan them (own scan state stays in registers) ----
-      const int jobs_max = share_jobs(lds_stride);
-      for (;;) {
-        const uint32_t n_posted = min(lane_get(lds_load_acquire(share), static_cast<int>(__builtin_ctzll(__ballot(1)))), static_cast<uint32_t>(jobs_max));
-        if (n_posted == 0u) break;
-        int jc = -1;
-        for (uint32_t j = lane_; j < n_posted && jc < 0; j += 64u) {
-          uint32_t * rec = share + kShareHdrWords + j * kShareJobWords;
-          if (lds_load_acquire(rec) == 1u && lds_claim(rec)) jc = static_cast<int>(j);
-        }
-        if (!__any(jc >= 0)) break;
-        const bool hj = jc >= 0;
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-        st_helped += hj ? 1u : 0u;
-        ++st_rounds;
-#endif
-        uint32_t * rec = share + kShareHdrWords + static_cast<uint32_t>(hj ? jc : 0) * kShareJobWords;
-        const float h0 = __uint_as_float(rec[1]), h1 = __uint_as_float(rec[2]), h2 = __uint_as_float(rec[3]);
-        const uint32_t kth_owner = hj ? rec[4] : 0xFFFFFFFFu;
-        const uint32_t * hlist = hj ? (list - threadIdx.x + rec[10]) : list;
-        ScanCursor<NOFF> hc;
-        hc.rem = hj ? rec[5] : 0u;
-        hc.qc0 = static_cast<uint64_t>(rec[6]) | (static_cast<uint64_t>(rec[7]) << 32);
-        hc.qc1 = static_cast<uint64_t>(rec[8]) | (static_cast<uint64_t>(rec[9]) << 32);
-        float hbox[NOFF];
-        box_dists<NOFF>(h0, h1, h2, hbox);
-        uint32_t hk[KK];
-#pragma unroll
-        for (int i = 0; i < KK; ++i) hk[i] = 0xFFFFFFFFu;
-        hc.rem &= prune_keep_mask<K, KK, NOFF>(hk, hbox, k, kErrG, kth_owner);
-        uint32_t h_alive = hc.rem, h_scanned = 0u;
-        const float hx0 = 0.5f - h0, hy1 = 8192.0f - 0.5f + h1, hz2 = 0.5f - h2;
-#pragma unroll
-        for (int u = 0; u < kPipe; ++u) stage[u] = hc.advance(hlist, lds_stride, lut4, map.qbuckets);
-        for (int trip = 0;; ++trip) {
-          if (!__any(static_cast<int>(stage[0].vcnt))) break;
-          if (MH_PRUNE_TRIPS) {
-            const uint32_t keep = prune_keep_mask<K, KK, NOFF>(hk, hbox, k, kErrG, kth_owner);
-            hc.rem &= keep;
-            h_alive &= keep;
-          }
-          scan_trip<KK, NOFF, kPipe>(hc, stage, hk, kc, hlist, lds_stride, lut4, map.qbuckets, hx0, hy1, hz2, h_scanned);
-        }
-        if (hj) {
-#pragma unroll
-          for (int i = 0; i < KK; ++i)
-            if (i < 8) rec[1 + i] = hk[i];
-          rec[9] = h_scanned;
-          rec[10] = h_alive & ~hc.rem;
-          lds_store_release(rec, 3u);
-        }
-      }
-      // ---- collect the jobs helpers did for this lane ----
-#pragma unroll
-      for (int p = 0; p < HS; ++p) {
-        if ((job_await >> p) & 1u) {
-          uint32_t * rec = share + kShareHdrWords + (job_base + static_cast<uint32_t>(p)) * kShareJobWords;
-          while (lds_load_acquire(rec) != 3u) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            uint32_t t = rec[1 + c];
-#pragma unroll
-            for (int i = 0; i < KK - 1; ++i) {
-              const uint32_t lo = min(ck[i], t);
-              t = max(ck[i], t);
-              ck[i] = lo;
-            }
-            ck[KK - 1] = min(ck[KK - 1], t);
-          }
-          n_scanned += rec[9];
-          extra_scanned |= rec[10];
-          donated &= ~rec[10];
-        }
-      }
-    }
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-    {
-      uint32_t a_ = st_posted, b_ = st_back, c_ = static_cast<uint32_t>(__popc(job_await)), d_ = st_helped;
-      for (int d = 32; d > 0; d >>= 1) {
-        a_ += __shfl_xor(a_, d);
-        b_ += __shfl_xor(b_, d);
-        c_ += __shfl_xor(c_, d);
-        d_ += __shfl_xor(d_, d);
-      }
-      share_stats = (static_cast<unsigned long long>(min(a_, 255u)) << 16) | (static_cast<unsigned long long>(min(b_, 255u)) << 24) |
-                    (static_cast<unsigned long long>(min(c_, 255u)) << 32) | (static_cast<unsigned long long>(min(d_, 255u)) << 40) |
-                    (static_cast<unsigned long long>(min(st_rounds, 255u)) << 48);
-    }
-    if (dbg && (threadIdx.x & 63) == 0) {
-      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
-      w_[14] = 4u * trips;  // quad steps the wave executed
-    }
-    {  // lanes of this wave that scanned more than 8 / 12 / 16 / 24 neighbour quads (8 bits each above bit 16)
-      const unsigned long long h = (static_cast<unsigned long long>(__popcll(__ballot(myq > 8u))) << 16) |
-                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 12u))) << 24) |
-                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 16u))) << 32) |
-                                   (static_cast<unsigned long long>(__popcll(__ballot(myq > 24u))) << 40);
-      if (dbg && (threadIdx.x & 63) == 0)
-        dbg[(static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + 14] |= h;
-    }
-#endif
   }
   // (Measured, round 1: capping the per-lane scan at 16 quads and letting the 64 lanes scan the leftover
   // voxels together, one candidate per lane, was 2x SLOWER — each (lane, voxel) step is a dependent LDS ->
@@ -849,9 +564,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   const uint64_t act = __ballot(1);
   const uint32_t nact = static_cast<uint32_t>(__popcll(act));
   const uint32_t rank = static_cast<uint32_t>(__popcll(act & ((1ull << lane) - 1ull)));
-  // centre + every neighbour voxel the cursor entered (+ what helpers entered for this lane; what was handed to a helper
-  // and pruned by it was never entered)
-  const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem & ~donated) | extra_scanned;
+  // centre + every neighbour voxel the cursor entered
+  const uint32_t scanned_mask = (amask & 1u) | (alive & ~rem);
   MH_STAMP(dbg, 2);
 
   // ---- exact tier: re-rank the survivors in fp64 by (distance, traversal rank) -------------------
@@ -938,26 +652,6 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 #pragma unroll
   for (int i = 0; i < K; ++i)
     if (i == k - 1) dk = bd[i];
-#if defined(MH_TIMELINE) && defined(MH_BALANCE)
-  if (dbg) {  // ideal pruning: quads in neighbour voxels whose box is nearer than the FINAL k-th distance (slot 15)
-    const float dkg = dk < kDblMax ? static_cast<float>(dk / (g_d * g_d)) : 3.0e38f;
-    uint32_t iq = 0;
-#pragma unroll
-    for (int b = 1; b < NOFF; ++b)
-      if (((amask_unpruned >> b) & 1u) && boxd[b] <= dkg) iq += ((cell[b] & 31u) + 3u) >> 2;
-    uint32_t sq = iq, mq = iq, sn = (n_scanned + 3u) >> 2;
-    for (int d = 32; d > 0; d >>= 1) {
-      sq += __shfl_xor(sq, d);
-      sn += __shfl_xor(sn, d);
-      mq = max(mq, static_cast<uint32_t>(__shfl_xor(mq, d)));
-    }
-    if ((threadIdx.x & 63) == 0) {
-      unsigned long long * w_ = dbg + (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
-      w_[13] = sn | share_stats;  // ~quads scanned by the wave's lanes (centre included); share counters above bit 16
-      w_[15] = static_cast<unsigned long long>(sq) | (static_cast<unsigned long long>(mq) << 32);
-    }
-  }
-#endif
   // ---- proof check (only meaningful when there ARE non-survivors: the KK-th slot is filled) ------
   bool need_exact = false;
   if (ck[KK - 1] != 0xFFFFFFFFu && dk < kDblMax) {
@@ -1198,7 +892,7 @@ __device__ __forceinline__ void fold_rows(const double * partials, int n_blocks,
                                           double * s_out)
 {  // PLAIN: the rows were written by an EARLIER kernel (plain stores, visible at the kernel boundary): ordinary cached loads
   // The segmentation — and with it the order of the additions — is that of a 256-thread workgroup whatever TPB is: the same
-  // rows fold to the same bits in K3's own last block, in a 512-thread K4 and in the 256-thread K4 of a side-stream call.
+  // rows fold to the same bits in K3's own last block, in a single call's K4 and in a window batch's.
   constexpr int NSEG = (TPB < 256 ? TPB : 256) / EW;
   const int ent = threadIdx.x % EW, seg = threadIdx.x / EW;
   if (seg < NSEG && ent < n_ent) {
@@ -1274,13 +968,6 @@ __device__ __forceinline__ void loc_directions(const A & a, const double nx, con
 template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
 __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
-  // K3's waves issue ahead of the component server's (icp_localizability_server_kernel, priority 0) when the two share a SIMD:
-  // the call's K4 work is off the critical path, the next K3 is on it (measured: step 37.1-38.7 -> 36.1-36.9 us, K3 beside the
-  // server 34.7 -> 33.7 us by rocprofv3).  Among K3's own waves nothing changes.
-#ifndef MH_K3_PRIO
-#define MH_K3_PRIO 3
-#endif
-  __builtin_amdgcn_s_setprio(MH_K3_PRIO);
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
   constexpr int EW = BINARY ? 96 : 32;
@@ -1295,9 +982,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   __shared__ double s_wsum[(TPB / 64) * (NENT <= 32 ? 2 : 1) * NENT];  // [wave][point segment][entry]
   __shared__ unsigned int s_cnt[4];  // n_knn, n_cand, exact-fallback count, candidates actually scanned
   __shared__ uint32_t s_scan[kScanLutWords];
-  __shared__ uint32_t s_share[share_words(TPB)];  // work sharing of the neighbour scan (knn_query)
   __shared__ bool s_last;
-  constexpr bool kShare = MH_SHARE && K == 5;  // the fast path's top-8; the generic k <= 8 path keeps 12 survivors
 
   uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
   double * s_aux = reinterpret_cast<double *>(s_arena);                               // fold scratch of the last block
@@ -1329,17 +1014,6 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
 #else
   const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
 #endif
-  // side-stream bookkeeping (IcpArgs::sig): the counter this call's stores may have to wait for is requested now and looked
-  // at after the per-point section — its round trip is never waited for
-  [[maybe_unused]] bool k4_ok = true;
-  __shared__ int s_hold;
-  if constexpr (!SHARD) {
-    if (a.k4_wait && threadIdx.x < 64)
-      for (int b = static_cast<int>(threadIdx.x); b < a.k4_blocks; b += 64)
-        k4_ok = k4_ok && static_cast<int>(__hip_atomic_load(&a.sig4[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.k4_need) >= 0;
-    if (a.srv_posted && block_id == 0 && threadIdx.x == 0)  // announce the call to the component server (LocServerArgs)
-      __hip_atomic_store(a.srv_posted, a.srv_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   // the lane's source point is requested before the scan table is filled (a load of its own) and the barrier behind it: one
   // memory round trip less on every wave's chain
   const int k = (K == 5) ? 5 : a.k;  // compile-time in the fast instantiation: no `j < k` branches
@@ -1347,10 +1021,6 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
   if (qi < n_pts) sp = a.src[qi];
   if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
-  if constexpr (kShare) {
-    if (threadIdx.x == 0) s_share[0] = 0u;
-    if (static_cast<int>(threadIdx.x) < share_jobs(TPB)) s_share[kShareHdrWords + threadIdx.x * kShareJobWords] = 0u;
-  }
   fill_scan_lut<NOFF>(s_scan);
   __syncthreads();
 
@@ -1365,10 +1035,6 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   if (rep > 0) {
     __syncthreads();
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
-    if constexpr (kShare) {
-      if (threadIdx.x == 0) s_share[0] = 0u;
-      if (static_cast<int>(threadIdx.x) < share_jobs(TPB)) s_share[kShareHdrWords + threadIdx.x * kShareJobWords] = 0u;
-    }
     __syncthreads();
   }
 #endif
@@ -1431,8 +1097,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       // quads in flight per lane: the 256-thread class (clouds of up to 65 536 points: at most one wave per SIMD, the scan waits
       // on memory, registers are plentiful) runs a deeper pipeline than the 512-thread class (two waves per SIMD: VALU-bound)
       constexpr int kPipeK3 = TPB <= 256 ? MH_PIPE_SMALL : MH_PIPE;
-      const uint32_t n_cand = knn_query<K, NOFF, kShare, kFast, kPipeK3>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg, s_share,
-                                                                kFast ? &sel : nullptr);
+      const uint32_t n_cand = knn_query<K, NOFF, kFast, kPipeK3>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg,
+                                                                        kFast ? &sel : nullptr);
       cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
       did_knn = true;
       did_fall = fell_back;
@@ -1499,16 +1165,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         a.mean[3 * qi + 2] = mean[2];
         double w[3], v0[3];
         MH_STAMP_C2(a.dbg, 14);
-#ifdef MH_FAKE_NO_EIGEN  // timing-only bound experiment (wrong results): the plane fit without its eigen-decomposition
-        w[0] = c00 * ikm1 * 1e-3;
-        w[1] = c11 * ikm1;
-        w[2] = c22 * ikm1 + w[1];
-        v0[0] = 0.0;
-        v0[1] = 0.0;
-        v0[2] = 1.0;
-#else
         plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
-#endif
         MH_STAMP_C2(a.dbg, 15);
         if (!(w[0] == w[0]) || !(w[2] == w[2])) {
           st = MH_EIGEN_SOLVER_FAIL;  // NaN input: Eigen would report NoConvergence (:197)
@@ -1634,27 +1291,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   }
 #endif
 
-  // the call's record: what K4 reads of this point.  Side-stream calls write it through (K4 may run on another XCD, with no
-  // kernel boundary in between)
+  // the call's record: what K4 reads of this point (the kernel boundary makes it visible)
   [[maybe_unused]] auto store_record = [&]() {
     if constexpr (!SHARD) {
       const size_t rn = static_cast<size_t>(a.rec_n);
       int32_t * rst = reinterpret_cast<int32_t *>(a.rec + 6 * rn);
-      if (a.side) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          store_partial(&a.rec[static_cast<size_t>(c) * rn + qi], rec_jr[c]);
-          store_partial(&a.rec[static_cast<size_t>(3 + c) * rn + qi], rec_jt[c]);
-        }
-        __hip_atomic_store(&rst[qi], rec_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          a.rec[static_cast<size_t>(c) * rn + qi] = rec_jr[c];
-          a.rec[static_cast<size_t>(3 + c) * rn + qi] = rec_jt[c];
-        }
-        rst[qi] = rec_st;
+      for (int c = 0; c < 3; ++c) {
+        a.rec[static_cast<size_t>(c) * rn + qi] = rec_jr[c];
+        a.rec[static_cast<size_t>(3 + c) * rn + qi] = rec_jt[c];
       }
+      rst[qi] = rec_st;
     }
   };
   // 8. H += J^T J, b += J^T e, f += e^2 (:363-382).  Every WAVE reduces its own 64 rows first, in its own time — a tile of rows in
@@ -1698,43 +1345,19 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         s_wsum[(wv * WSEG + seg) * NENT + ent] = (s0 + s1) + (s2 + s3);
       }
     }
-    // the call's record (what K4 reads of this point): a call whose pair of records nobody else can still be reading stores it
-    // here, in the wave's own time; one that may have to wait for an earlier call's K4 (k4_wait) stores it behind the check below
+    // the call's record (what K4 reads of this point), in the wave's own time
     if constexpr (!SHARD) {
-      if (a.rec && !a.k4_wait && qi < a.n) store_record();
-    }
-  }
-  if constexpr (!SHARD) {
-    if (a.k4_wait && threadIdx.x < 64) {
-      const bool all_ok = __all(static_cast<int>(k4_ok)) != 0;
-      if (threadIdx.x == 0) s_hold = all_ok ? 0 : 1;
+      if (a.rec && qi < a.n) store_record();
     }
   }
   __syncthreads();
   MH_STAMP(a.dbg, 4);
-  if constexpr (!SHARD) {
-    if (a.k4_wait && s_hold) {  // (not seen in practice: the K4 in question ended a whole K3 ago)
-      if (threadIdx.x < 64) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        for (;;) {
-          bool ok = true;
-          for (int b = static_cast<int>(threadIdx.x); b < a.k4_blocks; b += 64)
-            ok = ok && static_cast<int>(__hip_atomic_load(&a.sig4[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.k4_need) >= 0;
-          if (__all(static_cast<int>(ok))) break;
-          if (__builtin_readcyclecounter() - t0 > 8000000000ull) break;  // (the server gave up: that call is lost anyway)
-          __builtin_amdgcn_s_sleep(32);
-        }
-      }
-      __syncthreads();
-    }
-    if (a.rec && a.k4_wait && qi < a.n) store_record();
-  }
   // A plain factor whose K4 follows (a.tail == 0) ends here: the row is an ordinary store, K4's workgroups fold the rows
   // themselves after the kernel boundary — no write-through, no ticket, no last-block fold (3 us of serial tail with 255
   // CUs idle in round 3).  Otherwise (no K4 behind it, or a map-sharded factor, whose sums feed an all-reduce): rows
   // write-through, ticket, fold by the last block.
   const bool fold_here = SHARD || a.tail != 0;
-  const bool through = fold_here || (!SHARD && a.side);
+  const bool through = fold_here;
   if (threadIdx.x < NENT) {
     constexpr int NPART = (TPB / 64) * (NENT <= 32 ? 2 : 1);  // wave partials per entry, summed in index order: deterministic
     double pv[NPART];
@@ -1759,18 +1382,8 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     else
       *dst = c;
   }
-  if constexpr (!SHARD) {
-    if (a.side) {  // sign off: this workgroup's record entries and row are in memory
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&a.sig[block_id], a.side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 
   MH_STAMP(a.dbg, 5);
-#ifdef MH_FAKE_NO_TAIL  // timing-only bound experiment (wrong results): no ticket, no fold by the last block
-  return;
-#endif
   if (!fold_here) return;
   if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   MH_STAMP(a.dbg, 6);
@@ -1874,14 +1487,8 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
 // normal instead of storing two more per-point vectors.  6 sums by wave shuffles, 9 counts by
 // ballot/popcount; per-block row of 15 -> same ticket + fold as K3.
 // ------------------------------------------------------------------------------------------------
-// A plain factor's K4 runs 256-thread workgroups whatever K3 ran (a 512-thread K3 class gets twice the chunks per workgroup:
-// the same 2048 points, the same grid): a K4 launched on the side stream (LocArgs::side) sits on its CUs while the next
-// call's K3 starts, and it must FIT beside a K3 workgroup — K3 holds 2 waves x 168 VGPRs of every SIMD's 512, a 512-thread K4
-// workgroup (2 waves x 128) does not fit next to that and K3 then runs on the CUs K4 left free, in two rounds (measured:
-// 52.9 us per step instead of 48.1); one wave per SIMD does.  Synchronous calls run the same configuration, so the two
-// forms agree to the bit.
-// (512 - 2 x 168 = 176 registers per lane are what K3 leaves of a SIMD's file)
-#define MH_LOC_VGPRS __attribute__((amdgpu_waves_per_eu(3, 8)))  // at most 168 registers per lane
+// A plain factor's K4 runs 256 point-carrying threads per workgroup whatever K3 ran (the batched body shares the shape, so a
+// factor's rows fold — and its sums add — in the same order in a single call and in a window batch: the two agree to the bit).
 __host__ __device__ constexpr int loc_tpb(int tpb, bool shard) { return (!shard && tpb > 256) ? 256 : tpb; }
 __host__ __device__ constexpr int loc_threads(int tpb, bool shard) { return loc_tpb(tpb, shard) + (shard ? 0 : 64); }  // + the decomposition wave (XW)
 // A K4 workgroup of a plain factor takes kLocChunks chunks of 256 points whatever K3's class was: 1024 points, i.e. 4 of K3's
@@ -1897,7 +1504,7 @@ __host__ __device__ constexpr int loc_ch(int tpb, bool shard) { return shard ? 1
 // takes part in the fold's barriers and then decomposes H_rr and H_tt on two of its lanes AT ONCE (one SIMD pass for both), while
 // the four point waves issue their 28 loads each; with the decompositions on lanes of two point waves those loads (1.7 k cycles
 // of issue on a wave that has a SIMD to itself) sat in front of the 5 k-cycle decompositions on the kernel's critical path.  The
-// bases are the same bits whichever lane works them out, so the component server's body (no extra wave) agrees to the bit.
+// bases are the same bits whichever lane works them out, so the batched body (no extra wave) agrees to the bit.
 template <int TPB, bool SHARD, int CH, bool XW = false>
 __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const int block_id, const int n_blocks)
 {
@@ -1918,24 +1525,6 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   // (a plain factor without a record: its component pass is switched off but a batch runs K4 for every member — nothing to
   // read, the host reports NaN for it)
   const int n_pts = !worker ? 0 : (SHARD ? static_cast<int>(*a.n_dev) : (a.rec ? a.n : 0));
-  bool side = false;
-  if constexpr (!SHARD) {
-    side = a.side != 0;
-    if (side) {
-      // this kernel was launched on the context's side stream with nothing between it and the K3 whose record it reads: wait
-      // until every workgroup of that K3 has signed off (LocArgs::sig).  The waves not polling sit at the barrier.
-      if (threadIdx.x < 64) {
-        for (;;) {
-          bool ok = true;
-          for (int b = static_cast<int>(threadIdx.x); b < a.k3_blocks; b += 64)
-            ok = ok && static_cast<int>(__hip_atomic_load(&a.sig[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.side) >= 0;
-          if (__all(static_cast<int>(ok))) break;
-          __builtin_amdgcn_s_sleep(100);  // ~2.7 us between looks
-        }
-      }
-      __syncthreads();
-    }
-  }
   // The record entries (plain) / status, point and normal (map-sharded) of ALL of this workgroup's chunks: one round trip, in
   // flight while two lanes of the workgroup decompose H_rr and H_tt.  One uniform branch around each chunk's loads (a select
   // per loaded value made the compiler branch around every single load).
@@ -1962,20 +1551,11 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
       // plain factor: the call's record (K3 wrote the directions, zero unless Valid, and the status)
       const size_t rn = static_cast<size_t>(a.rec_n);
       const int32_t * rst = reinterpret_cast<const int32_t *>(a.rec + 6 * rn);
-      if (side) {  // written through by a kernel that may still be running on other XCDs: loads that see memory
-        st_c[ch] = __hip_atomic_load(&rst[i_ld], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st_c[ch] = rst[i_ld];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          jr_c[ch][c] = load_partial(&a.rec[static_cast<size_t>(c) * rn + i_ld]);
-          jt_c[ch][c] = load_partial(&a.rec[static_cast<size_t>(3 + c) * rn + i_ld]);
-        }
-      } else {
-        st_c[ch] = rst[i_ld];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          jr_c[ch][c] = a.rec[static_cast<size_t>(c) * rn + i_ld];
-          jt_c[ch][c] = a.rec[static_cast<size_t>(3 + c) * rn + i_ld];
-        }
+      for (int c = 0; c < 3; ++c) {
+        jr_c[ch][c] = a.rec[static_cast<size_t>(c) * rn + i_ld];
+        jt_c[ch][c] = a.rec[static_cast<size_t>(3 + c) * rn + i_ld];
       }
     }
     if (i >= n_pts) st_c[ch] = -1;
@@ -1997,17 +1577,10 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
   } else {
     const int n_ent = a.nv * (a.nv + 1) / 2 + 4;
     constexpr int FB = 32;  // rows in flight per thread: 256 rows over 8 segments in one round trip
-    if (a.nv == 7) {
-      if (side)
-        fold_rows<32, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-      else
-        fold_rows<32, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-    } else {
-      if (side)
-        fold_rows<96, TPB, false, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-      else
-        fold_rows<96, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
-    }
+    if (a.nv == 7)
+      fold_rows<32, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
+    else
+      fold_rows<96, TPB, true, FB>(a.partials, a.k3_blocks, n_ent, s_seg, s_h);
     sums = s_h;
   }
   load_all();
@@ -2118,7 +1691,6 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flagged words have left (acknowledged) by this stamp
 #endif
     MH_STAMP4(a.dbg, 9);
-    if (side && threadIdx.x == 0) __hip_atomic_store(&a.sig4[block_id], a.side, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every value read was used before the barrier above
     return;
   } else {
   if (threadIdx.x < 15) {
@@ -2126,9 +1698,6 @@ __device__ __forceinline__ void icp_localizability_body(const LocArgs & a, const
     for (int w2 = 0; w2 < NW; ++w2) s += s_w[w2][threadIdx.x];
     store_partial(&a.partials[static_cast<size_t>(block_id) * kPartialStride + threadIdx.x], s);
   }
-#ifdef MH_FAKE_K4_NO_TAIL  // timing-only bound experiment (wrong results): no ticket, no fold by the last block
-  return;
-#endif
   if (!arrive_is_last(a.ticket, static_cast<unsigned int>(n_blocks), &s_last)) return;
   double * s_sum = s_seg + (TPB / 32) * 32;
   fold_rows<32, TPB>(a.partials, n_blocks, 15, s_seg, s_sum);
@@ -2179,59 +1748,6 @@ __global__ __launch_bounds__(loc_tpb(TPB, SHARD)) void icp_localizability_batch_
   const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
   const LocArgs a = load_uniform(p->a + f);
   icp_localizability_body<loc_tpb(TPB, SHARD), SHARD, loc_ch(TPB, SHARD)>(a, b - s0, s1 - s0);
-}
-
-// The component server (icp_device.hpp: LocServerArgs): K4's body in a loop over the calls the context's K3s announce.
-__global__ __launch_bounds__(256) MH_LOC_VGPRS void icp_localizability_server_kernel(const LocServerArgs s)
-{
-  __shared__ int s_cmd;
-#ifdef MH_SRV_PRIO
-  __builtin_amdgcn_s_setprio(MH_SRV_PRIO);
-#endif
-  for (unsigned int j = s.first;; ++j) {
-    if (threadIdx.x == 0) {
-      int cmd = 0;
-      const unsigned long long t0 = __builtin_readcyclecounter();
-      for (unsigned int it = 1u;; ++it) {
-        const unsigned int p = __hip_atomic_load(s.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (static_cast<int>(p - (j + 1u)) >= 0) {
-          cmd = 1;
-          break;
-        }
-        if ((it & 7u) == 0u) {  // (a read of host memory: every eighth round)
-          const unsigned int st = __hip_atomic_load(s.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (st != 0u && static_cast<int>(j - st) >= 0) {
-            cmd = 2;
-            break;
-          }
-          // nothing to serve and no word from the host for ~4 s of shader clock: give up rather than hold the device for ever
-          // (a host that died, a stream layout this kernel must not be used with); the host sees its calls unanswered
-          if (__builtin_readcyclecounter() - t0 > 8000000000ull) {
-            cmd = 2;
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(60);
-      }
-      s_cmd = cmd;
-    }
-    __syncthreads();
-    const int cmd = s_cmd;
-    __syncthreads();
-    if (cmd == 2) break;
-    const LocArgs a = load_uniform(&s.ring[j % static_cast<unsigned int>(s.ring_n)].a);
-    for (int vb = static_cast<int>(blockIdx.x); vb < a.srv_blocks; vb += static_cast<int>(gridDim.x)) {
-      if constexpr (loc_ch(kThreads, false) == loc_ch(256, false)) {
-        icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);  // 1024 points per workgroup in either class
-      } else {
-        if (a.srv_class > 256)
-          icp_localizability_body<256, false, loc_ch(kThreads, false)>(a, vb, a.srv_blocks);
-        else
-          icp_localizability_body<256, false, loc_ch(256, false)>(a, vb, a.srv_blocks);
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2351,18 +1867,6 @@ hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
     launch_linearize_n<19>(a, binary, stream);
   else
     launch_linearize_n<27>(a, binary, stream);
-  return hipGetLastError();
-}
-
-// One server workgroup per K4 workgroup of a 131 072-point call (128 of 1024 points each): with 64 every server workgroup ran two
-// of them back to back and the pipelined step went from 35.0 to 40.5 us (round 5, gpurun_out c10: 64 -> 128 = 3.20 -> 3.63 Gpts/s).
-#ifndef MH_SRV_GRID
-#define MH_SRV_GRID 128
-#endif
-int loc_server_grid() { return MH_SRV_GRID; }
-hipError_t launch_loc_server(const LocServerArgs & s, hipStream_t stream)
-{
-  hipLaunchKernelGGL(icp_localizability_server_kernel, dim3(loc_server_grid()), dim3(256), 0, stream, s);
   return hipGetLastError();
 }
 

@@ -204,10 +204,6 @@ int mh_abi_version(void) { return MH_ABI_VERSION; }
 
 const char * mh_last_error(const mh_ctx * ctx) { return ctx ? ctx->err.c_str() : g_mh_err.c_str(); }
 
-extern std::atomic<int> g_side_granted;  // contexts holding a side stream (side_slot below)
-static void srv_stop(mh_ctx * ctx);
-static int srv_prepare(mh_ctx * ctx);
-static bool side_slot(mh_ctx * ctx);
 static int mh_init_impl(int device, mh_ctx ** out)
 {
   if (!out) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_init: out is NULL");
@@ -229,24 +225,9 @@ static int mh_init_impl(int device, mh_ctx ** out)
   if (!ctx) return fail(nullptr, MH_ERR_OOM, "mh_init: host allocation failed");
   ctx->device = device;
   MH_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  if (const char * ov = std::getenv("MH_OVERLAP")) ctx->overlap = std::atoi(ov) ? 1 : 0;  // diagnostics: MH_OVERLAP=0
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[0]));
   MH_HIP(nullptr, hipEventCreate(&ctx->timer[1]));
   AllocCache::context_created(device);
-  // The side stream of the process's first contexts is opened — and used once — NOW, right behind the compute stream: HIP
-  // assigns hardware queues (4 per process) in the order streams come into use, and the component server must not land on the
-  // queue of the compute stream it waits for (a fifth stream opened later did: every K3 then sat behind the waiting server
-  // until the next mh_icp_wait told it to stop — 70-90 us per step, measured).
-  if (ctx->overlap && side_slot(ctx)) {
-    const int rc = srv_prepare(ctx);
-    if (rc == MH_ERR_UNSUPPORTED) {
-      ctx->side_granted = -1;
-      g_side_granted.fetch_sub(1, std::memory_order_relaxed);
-    } else if (rc != MH_OK) {
-      mh_shutdown(ctx);
-      return rc;
-    }
-  }
   *out = ctx;
   return MH_OK;
 }
@@ -267,7 +248,6 @@ void mh_shutdown(mh_ctx * ctx)
   }
   (void)mh_enter(ctx);
   mhi::shard_ctx_gone(ctx);
-  srv_stop(ctx);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -281,13 +261,6 @@ void mh_shutdown(mh_ctx * ctx)
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
   }
-  if (ctx->aux_stream) {
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->aux_stream);
-  }
-  if (ctx->h_srv) (void)hipHostFree(ctx->h_srv);
-  if (ctx->d_srv_posted) (void)hipFree(ctx->d_srv_posted);
-  if (ctx->side_granted > 0) g_side_granted.fetch_sub(1, std::memory_order_relaxed);
   const int dev = ctx->device;
   delete ctx;
   AllocCache::context_destroyed(dev);  // the device's last context: its cached blocks (and, with no context left anywhere, the pinned ones) go back
@@ -306,36 +279,11 @@ int mh_set_profiling(mh_ctx * ctx, int on)
 
 void * mh_stream(mh_ctx * ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 
-static int mh_set_overlap_impl(mh_ctx * ctx, int on)
-{
-  if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_set_overlap: ctx is NULL");
-  MH_HIP(ctx, mh_enter(ctx));
-  if (!on && ctx->aux_stream) {
-    // give the side stream's hardware queue back: what a caller about to run several contexts side by side wants
-    srv_stop(ctx);
-    MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
-    MH_HIP(ctx, hipStreamDestroy(ctx->aux_stream));
-    ctx->aux_stream = nullptr;
-  }
-  ctx->overlap = on ? 1 : 0;
-  if (on && ctx->side_granted > 0 && !ctx->aux_stream) {
-    const int rc = srv_prepare(ctx);  // opens the stream again and takes its hardware queue now
-    if (rc != MH_OK) return rc;
-  }
-  return MH_OK;
-}
-int mh_set_overlap(mh_ctx * ctx, int on)
-{
-  return guarded(ctx, "mh_set_overlap", [&]() -> int { return mh_set_overlap_impl(ctx, on); });
-}
-
 static int mh_synchronize_impl(mh_ctx * ctx)
 {
   if (!ctx) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_synchronize: ctx is NULL");
   MH_HIP(ctx, mh_enter(ctx));
-  srv_stop(ctx);
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->aux_stream) MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
   return MH_OK;
 }
 int mh_synchronize(mh_ctx * ctx)
@@ -570,17 +518,8 @@ void mh_icp_destroy(mh_icp * icp)
 {
   if (!icp) return;
   (void)mh_enter(icp->ctx);
-  srv_stop(icp->ctx);  // (whoever's calls it is serving: the frees below may synchronise the device)
   (void)hipStreamSynchronize(icp->ctx->stream);
-  if (icp->ctx->aux_stream && icp->side_used) (void)hipStreamSynchronize(icp->ctx->aux_stream);  // the server may still read a record
-  for (int s2 = 0; s2 < icp->n_pending; ++s2) {  // calls never collected
-    PendingCall & pc = icp->pending[s2];
-    if (pc.srv_index >= 0) icp->ctx->srv_open.erase(static_cast<unsigned int>(pc.srv_index));
-    if (pc.counted && icp->ctx->calls_open > 0) icp->ctx->calls_open--;
-  }
-  icp->d_rec[0].release(true);
-  icp->d_rec[1].release(true);
-  icp->d_sig.release(true);
+  icp->d_rec.release(true);
   icp->d_src.release(true);
   icp->d_qda.release(true);
   icp->d_mean.release(true);
@@ -656,17 +595,16 @@ struct LinearizeTxn
 {
   mh_icp * icp;
   bool cold = true, committed = false;
-  int count = 0, pending = 0, rec_parity = 0;
+  int count = 0, pending = 0;
   explicit LinearizeTxn(mh_icp * i) : icp(i)
   {
     if (icp) {
       cold = icp->cold;
       count = icp->linearize_count;
       pending = icp->n_pending;
-      rec_parity = icp->rec_parity;
     }
   }
-  LinearizeTxn(LinearizeTxn && o) noexcept : icp(o.icp), cold(o.cold), committed(o.committed), count(o.count), pending(o.pending), rec_parity(o.rec_parity) { o.icp = nullptr; }
+  LinearizeTxn(LinearizeTxn && o) noexcept : icp(o.icp), cold(o.cold), committed(o.committed), count(o.count), pending(o.pending) { o.icp = nullptr; }
   LinearizeTxn(const LinearizeTxn &) = delete;
   LinearizeTxn & operator=(const LinearizeTxn &) = delete;
   void commit() { committed = true; }
@@ -676,7 +614,6 @@ struct LinearizeTxn
       icp->cold = cold;
       icp->linearize_count = count;
       icp->n_pending = pending;
-      icp->rec_parity = rec_parity;
     }
   }
 };
@@ -711,25 +648,15 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   }
 
   const size_t row_doubles = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * mh::kPartialStride;
-  MH_HIP(ctx, icp->d_partials.reserve(2 * row_doubles * sizeof(double), ctx->stream, false));
-  // The record K3 writes for K4 and the set of partial rows alternate with the calls (mh_internal.hpp).  If the K4 that last read
-  // this call's pair ran on the side stream, the compute stream queues behind it before anything overwrites the pair.
-  int rec_b = 0;
+  MH_HIP(ctx, icp->d_partials.reserve(row_doubles * sizeof(double), ctx->stream, false));
+  // the record K3 writes for K4 (mh_internal.hpp): K4 follows on the same stream, one record serves every call
   a.rec = nullptr;
   a.rec_n = 0;
   if (icp->components && icp->n > 0) {
-    rec_b = icp->rec_parity;
-    icp->rec_parity ^= 1;
-    MH_HIP(ctx, icp->d_rec[rec_b].reserve(mh::loc_record_bytes(icp->n), ctx->stream, false));
-    a.rec = static_cast<double *>(icp->d_rec[rec_b].p);
+    MH_HIP(ctx, icp->d_rec.reserve(mh::loc_record_bytes(icp->n), ctx->stream, false));
+    a.rec = static_cast<double *>(icp->d_rec.p);
     a.rec_n = static_cast<int>(icp->n);
   }
-  a.sig = static_cast<unsigned int *>(icp->d_sig.p);
-  a.sig4 = a.sig ? a.sig + icp->sig_k3_cap : nullptr;
-  a.k4_wait = icp->rec_side[rec_b] ? 1 : 0;  // the pair was last read by side-stream K4 work: the kernel checks it has finished
-  a.k4_need = icp->rec_need[rec_b];
-  a.k4_blocks = icp->rec_blocks[rec_b];
-  a.side = 0;
   a.map = map_view(icp->map);
   a.src = static_cast<const float4 *>(icp->d_src.p);
   a.n = static_cast<int>(icp->n);
@@ -748,7 +675,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   a.mean = static_cast<double *>(icp->d_mean.p);
   a.normal = static_cast<double *>(icp->d_normal.p);
   a.status = static_cast<int32_t *>(icp->d_status.p);
-  a.partials = static_cast<double *>(icp->d_partials.p) + static_cast<size_t>(rec_b) * row_doubles;
+  a.partials = static_cast<double *>(icp->d_partials.p);
   a.ticket = static_cast<unsigned int *>(icp->d_ticket.p);
   a.result = static_cast<mh::DeviceResult *>(icp->d_result.p);
   a.host_result = nullptr;  // set below once the slot is known
@@ -773,9 +700,6 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   l.result = a.result;
   l.rec = a.rec;
   l.rec_n = a.rec_n;
-  l.sig = a.sig;
-  l.sig4 = a.sig4;
-  l.side = 0;
 #ifdef MH_TIMELINE
   l.dbg = a.dbg ? a.dbg + static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * 8 * 16 : nullptr;
 #endif
@@ -798,9 +722,6 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   pc.seq_has_basis = false;  // set by the callers whose K4 publishes the eigenbases it projected on
   pc.loc_blocks = 0;
   pc.launched_k4 = false;
-  pc.rec_b = rec_b;
-  pc.srv_index = -1;
-  pc.counted = false;
   a.seq = 0;
   a.tail = 1;
   a.ll = l.ll = nullptr;
@@ -815,62 +736,6 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   icp->n_pending++;
   icp->cold = false;
   return MH_OK;
-}
-
-// ---- the component server of a context (icp_device.hpp: LocServerArgs) ----------------------------------------------------
-constexpr std::chrono::milliseconds kSrvIdleRestart{500};  // see linearize_enqueue
-static unsigned int * srv_stop_word(mh_ctx * ctx)
-{
-  return reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->h_srv) + sizeof(mh::LocServerSlot) * kSrvRing);
-}
-// Tell a running server to end once it has served every call posted so far.  Everything that waits for the side stream, or for
-// results, calls this first: the server would otherwise sit there for ever.
-static void srv_stop(mh_ctx * ctx)
-{
-  if (!ctx->srv_running) return;
-  __atomic_store_n(srv_stop_word(ctx), ctx->srv_posted, __ATOMIC_RELEASE);  // (srv_posted >= 1 while a server runs: never the "keep serving" 0)
-  ctx->srv_running = false;
-}
-static int srv_prepare(mh_ctx * ctx)
-{
-  if (ctx->h_srv && ctx->aux_stream) return MH_OK;
-  if (!ctx->aux_stream) {
-    // The server waits ON THE DEVICE for kernels of the compute stream, so the two streams must never share a hardware queue
-    // (HIP multiplexes a process's streams onto 4 of them: a K3 queued behind the waiting server would never run).  Streams of
-    // another priority come from another pool of queues.
-    int least = 0, greatest = 0;
-    MH_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (greatest == least) return fail(ctx, MH_ERR_UNSUPPORTED, "side stream: the device has one stream priority only");
-    MH_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, greatest));
-  }
-  if (!ctx->h_srv) {
-    const size_t bytes = sizeof(mh::LocServerSlot) * kSrvRing + 256;
-    MH_HIP(ctx, hipHostMalloc(&ctx->h_srv, bytes, hipHostMallocMapped));
-    std::memset(ctx->h_srv, 0, bytes);
-    MH_HIP(ctx, hipHostGetDevicePointer(&ctx->d_h_srv, ctx->h_srv, 0));
-    MH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_srv_posted), 256));
-    ctx->srv_posted = 0;
-  }
-  // (no call is in flight at the server when this runs: the counter of announced calls restarts with the host's)
-  ctx->srv_posted = 0;
-  ctx->srv_open.clear();
-  MH_HIP(ctx, hipMemsetAsync(ctx->d_srv_posted, 0, 256, ctx->aux_stream));  // (the side stream's first use: its hardware queue is taken here)
-  MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));                        // zero before any kernel can look
-  return MH_OK;
-}
-
-// A side stream is for a process with ONE busy context: the server waiting on the device occupies wave slots, and a process has
-// 4 hardware queues.  The first context of the process gets one (MH_SIDE_CONTEXTS raises that); the others keep one stream.
-std::atomic<int> g_side_granted{0};
-static bool side_slot(mh_ctx * ctx)
-{
-  if (ctx->side_granted == 0) {
-    static const int limit = std::getenv("MH_SIDE_CONTEXTS") ? std::atoi(std::getenv("MH_SIDE_CONTEXTS")) : 1;
-    const bool ok = g_side_granted.fetch_add(1, std::memory_order_relaxed) < limit;
-    if (!ok) g_side_granted.fetch_sub(1, std::memory_order_relaxed);
-    ctx->side_granted = ok ? 1 : -1;
-  }
-  return ctx->side_granted > 0;
 }
 
 static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t_src[3], const double * R_tgt,
@@ -888,101 +753,21 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
   if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[0], ctx->stream));
   if (a.n > 0) {
     a.tail = pc.components ? 0 : 1;  // K4 follows and folds K3's rows itself / K3 is the whole call: its last block folds and publishes
-    // A pipelined call with the component pass: K4 goes to the context's side stream and the compute stream is free for the next
-    // call's K3 at once (K4 reads only this call's record, partial rows and its own host slot).  Nothing is enqueued between
-    // the streams — an event record + wait costs the compute stream more than the overlap buys (measured: 50.6 us per step
-    // against 48.4 without the side stream) — K4 is simply launched and polls a device counter its K3 signs off on
-    // (icp_device.hpp: IcpArgs::sig); the side stream runs its K4s in order, so only one of them ever waits on the device.
-    // A synchronous call keeps K4 on the compute stream.  A pipelined call timed by events goes to the server like the others
-    // (its K3 is bracketed, its component pass has no launch of its own to bracket: gpu_ms_localizability = -1).
-    // Only a caller that pipelines goes to the server — a call that follows another one still in flight on this context, or the
-    // first call after a wait that collected several: a lone call gains nothing from it.
-    if (ctx->calls_open > 0) ctx->pipelined = true;
-    // The server ends by itself after ~3.3 s (8e9 shader cycles) without work, unseen by the host.  A caller that left its
-    // pipeline alone for a while therefore gets a fresh one: the old server is told to end (it has, or does so now, after
-    // everything posted so far) and the launch further down waits for the side stream to drain before it clears the stop word.
-    // The host-side limit is far below the device's, so no call is ever announced to a server that has already gone.
-    if (ctx->srv_running && std::chrono::steady_clock::now() - ctx->srv_last_post > kSrvIdleRestart) srv_stop(ctx);
-    bool side = ctx->overlap && !want_flag && pc.components && a.rec != nullptr && ctx->pipelined && side_slot(ctx);
-    // (a ring slot is free once the call that used it has been collected)
-    if (side && !ctx->srv_open.empty() && ctx->srv_posted - *ctx->srv_open.begin() >= static_cast<unsigned int>(kSrvRing) - 1u) side = false;
-    if (side) {
-      const int rc2 = srv_prepare(ctx);
-      if (rc2 == MH_ERR_UNSUPPORTED) {
-        ctx->side_granted = -1;
-        side = false;
-      } else if (rc2 != MH_OK) {
-        return rc2;
-      }
-    }
-    if (side) {
-      if (!icp->sig_ready) {
-        // the counters must read zero before a kernel of the OTHER stream can look at them: once per factor
-        icp->sig_k3_cap = (l.k3_blocks + 63) & ~63;
-        const size_t words = static_cast<size_t>(icp->sig_k3_cap) + static_cast<size_t>((pc.loc_blocks + 63) & ~63);
-        MH_HIP(ctx, icp->d_sig.reserve(words * sizeof(unsigned int), ctx->stream, false));
-        MH_HIP(ctx, hipMemsetAsync(icp->d_sig.p, 0, words * sizeof(unsigned int), ctx->stream));
-        MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        icp->sig_ready = true;
-        a.sig = static_cast<unsigned int *>(icp->d_sig.p);
-        a.sig4 = a.sig + icp->sig_k3_cap;
-        l.sig = a.sig;
-        l.sig4 = a.sig4;
-      }
-      const unsigned int j = ctx->srv_posted;
-      a.side = l.side = icp->side_calls + 1u;
-      if (a.side == 0u) a.side = l.side = 1u;  // (0 means "not a side-stream call")
-      l.srv_blocks = pc.loc_blocks;
-      l.srv_class = mh::linearize_class(a.n);
-      l.chunks_per_block = 0;
-      static_cast<mh::LocServerSlot *>(ctx->h_srv)[j % kSrvRing].a = l;  // the call's K4 arguments, where the server reads them
-      std::atomic_thread_fence(std::memory_order_release);
-      a.srv_posted = ctx->d_srv_posted;
-      a.srv_j = j + 1u;
-    }
+    // K3, then K4 on the context's stream, for synchronous and pipelined callers alike (mh_icp_linearize_async only skips the
+    // wait).  Rounds 4-5 ran the K4 work of pipelined calls on a long-running "component server" kernel of a side stream: it
+    // bought 6 us per step for a caller with <= 64 calls of ONE factor in flight — a pattern no caller of the reference has
+    // (GTSAM linearizes one factor at a time, the smoother window goes through mh_icp_linearize_batch) — and cost a ring,
+    // sign-off words, write-through records, a restart rule and a hazard with device-wide synchronisations: removed in round 6.
     const double tl0 = g_wt.on ? WaitTrace::now() : 0.0;
     MH_HIP(ctx, mh::launch_linearize(a, icp->binary, ctx->stream));
     if (g_wt.on) g_wt.k3launch += WaitTrace::now() - tl0;
     if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
-    if (side) {
-      // K3 is in the stream and will announce call j: from here on the bookkeeping must say so
-      const unsigned int j = ctx->srv_posted++;
-      ctx->srv_last_post = std::chrono::steady_clock::now();
-      icp->side_calls = a.side;
-      icp->rec_need[pc.rec_b] = a.side;
-      icp->rec_blocks[pc.rec_b] = pc.loc_blocks;
-      icp->rec_side[pc.rec_b] = true;
-      icp->side_used = true;
-      pc.srv_index = static_cast<long long>(j);
-      ctx->srv_open.insert(j);
-      pc.seq_has_basis = true;
-      pc.launched_k4 = true;
-      if (!ctx->srv_running) {
-        mh::LocServerArgs sa;
-        sa.ring = static_cast<const mh::LocServerSlot *>(ctx->d_h_srv);
-        sa.ring_n = kSrvRing;
-        sa.first = j;
-        sa.posted = ctx->d_srv_posted;
-        sa.stop = reinterpret_cast<const unsigned int *>(static_cast<const char *>(ctx->d_h_srv) + sizeof(mh::LocServerSlot) * kSrvRing);
-        // the previous server, told to stop, must have gone before the stop word is cleared for this one (it has, as a rule: the
-        // wait that stopped it collected what it published)
-        if (hipStreamQuery(ctx->aux_stream) != hipSuccess) MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
-        __atomic_store_n(srv_stop_word(ctx), 0u, __ATOMIC_RELEASE);
-        MH_HIP(ctx, mh::launch_loc_server(sa, ctx->aux_stream));
-        ctx->srv_running = true;
-      }
-    } else if (pc.components) {
+    if (pc.components) {
       MH_HIP(ctx, mh::launch_localizability(l, ctx->stream));
-      icp->rec_side[pc.rec_b] = false;  // ordered by the compute stream itself
       pc.seq_has_basis = true;
       pc.launched_k4 = true;
     }
-    if (timed) {
-      if (pc.srv_index >= 0)
-        pc.ev[2] = nullptr;  // served: nothing of K4 is on this stream
-      else
-        MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
-    }
+    if (timed) MH_HIP(ctx, hipEventRecord(pc.ev[2], ctx->stream));
   } else {
     if (timed) {
       MH_HIP(ctx, hipEventRecord(pc.ev[1], ctx->stream));
@@ -991,8 +776,6 @@ static int linearize_enqueue(mh_icp * icp, const double R_src[9], const double t
     // nothing was launched (pc.seq == 0): the result of an empty cloud is all zero, assembled on the host
   }
   txn.commit();
-  ctx->calls_open++;
-  pc.counted = true;
   return MH_OK;
 }
 
@@ -1108,39 +891,16 @@ static int mh_icp_wait_impl(mh_icp * icp)
   MH_HIP(ctx, mh_enter(ctx));
   // Every value a call produces arrives in mapped pinned memory tagged with the call's sequence number: the host polls the
   // values themselves instead of paying the runtime's stream-synchronisation latency (or a device-side completion flag
-  // behind a system-scope fence).  Calls timed by HIP events, and anything that does not show up within the spin budget,
-  // fall back to the stream.
-  srv_stop(ctx);  // a component server ends once it has served what was posted (the calls collected below among them)
-  struct Closer  // however this returns, the calls leave the context's books
-  {
-    mh_icp * icp;
-    int n;
-    ~Closer()
-    {
-      for (int s = 0; s < n; ++s) {
-        PendingCall & pc = icp->pending[s];
-        if (pc.srv_index >= 0) icp->ctx->srv_open.erase(static_cast<unsigned int>(pc.srv_index));
-        pc.srv_index = -1;
-        if (pc.counted && icp->ctx->calls_open > 0) icp->ctx->calls_open--;
-        pc.counted = false;
-      }
-      if (n == 1 && icp->ctx->calls_open == 0) icp->ctx->pipelined = false;  // one call, then its wait: not a pipeline
-    }
-  } closer{icp, icp->n_pending};
+  // behind a system-scope fence).  Anything that does not show up within the spin budget falls back to the stream.  A call
+  // bracketed by HIP events is collected the same way; its last event — recorded behind K4, whose words have arrived — is
+  // waited for alone (hipEventSynchronize on an event that has completed or is about to), not the whole stream.
   bool synced = false;
-  for (int s = 0; s < icp->n_pending; ++s)
-    if (icp->pending[s].ev[0] && !synced) {
-      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->aux_stream) MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
-      synced = true;
-    }
   for (int s = 0; s < icp->n_pending; ++s) {
     const PendingCall & pc = icp->pending[s];
     mh::DeviceResult d;
     if (!collect_call(icp, s, pc, synced ? 0L : 20000000L, d)) {  // 20 ms
       if (!synced) {
         MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->aux_stream) MH_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
         synced = true;
       }
       if (!collect_call(icp, s, pc, 2000000L, d)) {
@@ -1157,11 +917,9 @@ static int mh_icp_wait_impl(mh_icp * icp)
       g_wt.n++;
     }
     if (pc.ev[0]) {
+      if (!synced) (void)hipEventSynchronize(pc.ev[2]);
       (void)hipEventElapsedTime(&pc.out->gpu_ms_linearize, pc.ev[0], pc.ev[1]);
-      if (pc.ev[2])
-        (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
-      else
-        pc.out->gpu_ms_localizability = -1.0f;  // done by the component server: no launch to bracket
+      (void)hipEventElapsedTime(&pc.out->gpu_ms_localizability, pc.ev[1], pc.ev[2]);
     } else {
       pc.out->gpu_ms_linearize = pc.out->gpu_ms_localizability = -1.0f;  // this call was not timed
     }

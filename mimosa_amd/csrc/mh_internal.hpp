@@ -44,23 +44,7 @@ struct mh_ctx
   size_t d_scratch_cap = 0;
   hipStream_t copy_stream = nullptr;  // mh_scan_prefetch: uploads beside the compute stream (created on first use: an HSA queue costs ~1 ms)
   std::mutex copy_mu;
-  // mh_icp_linearize_async: K4 (64 workgroups, a few round trips long) runs on this side stream behind an event, so that the
-  // compute stream goes from K3 of one call straight into K3 of the next (created on first use; mh_set_overlap switches it off)
-  hipStream_t aux_stream = nullptr;
-  int overlap = 1;
-  int side_granted = 0;  // 0 not asked yet, 1 this context may use a side stream, -1 refused (mh_api.hip: side_slot)
-  // the component server on the side stream (icp_device.hpp: LocServerArgs)
-  void * h_srv = nullptr;            // mapped pinned: kSrvRing slots, then the stop word
-  void * d_h_srv = nullptr;          // ... its device address
-  unsigned int * d_srv_posted = nullptr;
-  unsigned int srv_posted = 0;       // calls handed to the server so far (= index of the next one)
-  bool srv_running = false;
-  std::chrono::steady_clock::time_point srv_last_post{};  // host time of the last call handed to the server (mh_api.hip: kSrvIdleRestart)
-  int calls_open = 0;                // linearize calls enqueued on this context and not collected yet
-  bool pipelined = false;            // the caller has had several calls in flight (and has not gone back to one at a time)
-  std::set<unsigned int> srv_open;   // calls posted and not yet collected by their factor's wait (ring slots in use)
 };
-constexpr int kSrvRing = 256;
 
 // The stream of the context the calling thread is working for (set by mh_enter at every entry point): what the allocation
 // cache orders its hand-overs by.
@@ -604,9 +588,6 @@ struct PendingCall
   unsigned int seq;  // what the call's last kernel publishes to the host slot when it is complete (0: nothing was launched)
   bool components;   // K4 ran for this call: loc_*_comp / status_hist are meaningful
   bool seq_has_basis = false;  // ... and wrote the eigenbases it projected on into the call's result slot
-  int rec_b = 0;               // plain factors: which of the factor's two records / sets of partial rows the call uses
-  long long srv_index = -1;    // the call's index at the context's component server (-1: its K4 was a launch of its own)
-  bool counted = false;        // the call is in the context's calls_open
   int loc_blocks = 0;          // plain factors: K4's workgroups of this call = rows of flagged words the host folds
   bool launched_k4 = false;    // plain factors: the call's sums come from K4's workgroup 0 (else from K3's last block)
   hipEvent_t ev[3];
@@ -620,18 +601,9 @@ struct mh_icp
   mh_reg_config cfg;
   bool binary;
   DevBuf d_src, d_qda, d_mean, d_normal, d_status, d_partials, d_ticket, d_result, d_dbg, d_perm, d_eig;
-  // plain factors: what K4 reads of a call is a record K3 wrote for it (icp_device.hpp: IcpArgs::rec) and K3's partial rows —
-  // two of each, alternating with the calls, so K4 of call i (side stream) and K3 of call i + 1 (compute stream) touch
-  // different memory.  The streams meet through two device counters (d_sig; IcpArgs::sig): sig_k3 / sig_k4 are what they will
-  // read once everything enqueued so far has run, rec_need[b] is the sig_k4 value behind the side-stream K4 that last read pair b
-  DevBuf d_rec[2], d_sig;
-  int rec_parity = 0;
-  bool sig_ready = false;
-  unsigned int side_calls = 0, rec_need[2] = {0, 0};  // ordinal of the factor's last side-stream call; ... of the one that last read pair b
-  int rec_blocks[2] = {0, 0};                         // ... and how many workgroups its K4 work had
-  int sig_k3_cap = 0;                                 // flag words of K3's workgroups in d_sig (K4's follow)
-  bool rec_side[2] = {false, false};
-  bool side_used = false;
+  // plain factors: what K4 reads of a call is the record K3 wrote for it (icp_device.hpp: IcpArgs::rec) and K3's partial rows;
+  // K4 follows its K3 on the context's stream, so one of each serves every call of the factor
+  DevBuf d_rec;
   bool ordered = false;  // d_src / per-point state are in Morton order, d_perm maps back
   mh::DeviceResult * h_results = nullptr;    // pinned, mapped ring: the device writes results here directly (two-phase callers)
   mh::DeviceResult * d_h_results = nullptr;  // its device-side address

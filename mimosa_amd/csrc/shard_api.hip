@@ -294,6 +294,8 @@ struct mh_shard_icp
   uint32_t seg_cap = 0, seg_cap_max = 0;
   uint64_t n_total = 0;
   bool broken = false;  // a collective call failed half way (records sent, slots tombstoned): the factor's state is not to be trusted
+  bool ctx_gone = false;  // mh_shutdown of the factor's context ran first (shard_ctx_gone): ctx and icp are null, the handle can only be destroyed
+  int last_linearize_count = 0;  // ... what mh_shard_icp_stats still reports then
   mh_shard_stats stats{};
 };
 
@@ -456,24 +458,58 @@ static void comm_release_ctx(mh_shard_comm * comm)
   comm->ws_ctx = nullptr;
 }
 
+// Everything of a factor that lives on its context: device buffers, the inner plain factor.  The context must still be alive.
+static void shard_release_device(mh_shard_icp * S)
+{
+  for (DevBuf * b : {&S->d_dest, &S->d_hist, &S->d_ar, &S->d_flags, &S->d_pos, &S->d_temp}) b->release(true);
+  if (S->d_state) AllocCache::free(S->d_state, true);
+  S->d_state = nullptr;
+  if (S->icp) {
+    S->last_linearize_count = S->icp->linearize_count;
+    mh_icp_destroy(S->icp);
+  }
+  S->icp = nullptr;
+}
+
 namespace mhi
 {
 // mh_shutdown(ctx), before the stream goes: communicators whose rounds ran on ctx let go of it (a later
-// mh_shard_comm_destroy must not touch a dead context; a later mh_shard_icp_create may bind a new one)
+// mh_shard_comm_destroy must not touch a dead context; a later mh_shard_icp_create may bind a new one), and the sharded
+// factors of ctx give their device memory back NOW, while the context is alive — afterwards such a handle holds no pointer
+// into the dead context (ctx, icp null; ctx_gone set): every entry point refuses it and mh_shard_icp_destroy just deletes it.
 void shard_ctx_gone(mh_ctx * ctx)
 {
   std::lock_guard<std::mutex> g(g_comm_mu);
-  for (mh_shard_comm * c : g_comms)
-    if (c->ws_ctx == ctx) {
-      for (mh_shard_icp * S : c->factors)
-        if (S->ctx == ctx) {  // the factors of that context are unusable from here on
-          S->broken = true;
-          S->inflight = 0;
-        }
-      comm_release_ctx(c);
-    }
+  for (mh_shard_comm * c : g_comms) {
+    bool any = c->ws_ctx == ctx;
+    for (mh_shard_icp * S : c->factors) any = any || S->ctx == ctx;
+    if (!any) continue;
+    if (c->ws_ctx == ctx) comm_release_ctx(c);  // (synchronises the stream; drops the rounds)
+    for (mh_shard_icp * S : c->factors)
+      if (S->ctx == ctx) {
+        S->broken = true;
+        S->inflight = 0;
+        for (ShardCall & q : c->repairs)
+          if (q.S == S) q.S = nullptr;
+        for (CapUpdate & u : c->cap_updates)
+          if (u.S == S) u.S = nullptr;
+        auto & pend = c->plain_pending;
+        pend.erase(std::remove(pend.begin(), pend.end(), S), pend.end());
+        (void)mh_enter(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        shard_release_device(S);
+        S->ctx = nullptr;
+        S->ctx_gone = true;
+      }
+  }
 }
 }  // namespace mhi
+
+// every entry point but destroy: a factor whose context was shut down first
+#define MH_SHARD_ALIVE(S, who)                                                                                                      \
+  do {                                                                                                                              \
+    if ((S) && (S)->ctx_gone) return fail(nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": the factor's context was shut down; the handle can only be destroyed"); \
+  } while (0)
 
 extern "C" {
 
@@ -605,12 +641,13 @@ void mh_shard_icp_destroy(mh_shard_icp * S)
         if (c.S == S) c.S = nullptr;
     for (ShardCall & c : S->comm->repairs)
       if (c.S == S) c.S = nullptr;
+    // capacity decisions parked for this factor (complete_front) must not be applied to freed memory later
+    for (CapUpdate & u : S->comm->cap_updates)
+      if (u.S == S) u.S = nullptr;
     auto & pend = S->comm->plain_pending;
     pend.erase(std::remove(pend.begin(), pend.end(), S), pend.end());
   }
-  for (DevBuf * b : {&S->d_dest, &S->d_hist, &S->d_ar, &S->d_flags, &S->d_pos, &S->d_temp}) b->release(true);
-  if (S->d_state) AllocCache::free(S->d_state, true);
-  if (S->icp) mh_icp_destroy(S->icp);
+  if (S->ctx) shard_release_device(S);  // (a factor whose context went first gave everything back in shard_ctx_gone)
   delete S;
 }
 
@@ -1223,6 +1260,7 @@ int check_round(mh_shard_icp * const * Ss, size_t B, const double * R_src, const
   if (B > static_cast<size_t>(kMaxBatch)) return fail(nullptr, MH_ERR_UNSUPPORTED, std::string(who) + ": at most 64 factors per call");
   for (size_t f = 0; f < B; ++f)
     if (!Ss[f]) return fail(nullptr, MH_ERR_INVALID_ARG, std::string(who) + ": NULL factor");
+  for (size_t f = 0; f < B; ++f) MH_SHARD_ALIVE(Ss[f], who);
   mh_ctx * ctx = Ss[0]->ctx;
   for (size_t f = 0; f < B; ++f)
     if (!Ss[f]->comm) return fail(ctx, MH_ERR_INVALID_ARG, std::string(who) + ": the factor's communicator was destroyed");
@@ -1334,6 +1372,7 @@ int mh_shard_icp_wait(mh_shard_icp * S)
 {
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_wait", [&]() -> int {
     if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_wait: NULL argument");
+    MH_SHARD_ALIVE(S, "mh_shard_icp_wait");
     if (!S->comm) return fail(S->ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_wait: the factor's communicator was destroyed");
     if (!S->collective) {  // every factor of the communicator with enqueued calls, like the rounds of the collective form
       int rc_all = mh_icp_wait(S->icp);
@@ -1354,6 +1393,7 @@ int mh_shard_icp_reset(mh_shard_icp * S)
 {
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_reset", [&]() -> int {
     if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_reset: NULL argument");
+    MH_SHARD_ALIVE(S, "mh_shard_icp_reset");
     if (!S->collective) return mh_icp_reset(S->icp);
     mh_ctx * ctx = S->ctx;
     MH_HIP(ctx, mh_enter(ctx));
@@ -1370,12 +1410,14 @@ int mh_shard_icp_reset(mh_shard_icp * S)
 int mh_shard_icp_set_components(mh_shard_icp * S, int enabled)
 {
   if (!S) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_set_components: NULL argument");
+  MH_SHARD_ALIVE(S, "mh_shard_icp_set_components");
   return mh_icp_set_components(S->icp, enabled);
 }
 
 static int shard_icp_get_state_impl(mh_shard_icp * S, uint64_t * origin, int32_t * status, double * means, double * normals, size_t capacity, size_t * n_out)
 {
   if (!S || !n_out) return fail(S ? S->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_get_state: NULL argument");
+  MH_SHARD_ALIVE(S, "mh_shard_icp_get_state");
   mh_ctx * ctx = S->ctx;
   mh_icp * icp = S->icp;
   if (S->collective && S->inflight) return fail(ctx, MH_ERR_INVALID_ARG, "mh_shard_icp_get_state: calls in flight (mh_shard_icp_wait first)");
@@ -1417,6 +1459,15 @@ int mh_shard_icp_get_state(mh_shard_icp * S, uint64_t * origin, int32_t * status
   return guarded(S ? S->ctx : nullptr, "mh_shard_icp_get_state", [&]() -> int { return shard_icp_get_state_impl(S, origin, status, means, normals, capacity, n_out); });
 }
 
+int mh_shard_owner_of_block(int bx, int by, int bz, int world)
+{
+  // the host twin of shard_kernels.hip's owner_of_block (same tables, same arithmetic)
+  static const uint8_t A[mh::kShardMaxWorld + 1] = MH_SHARD_OWNER_A, B[mh::kShardMaxWorld + 1] = MH_SHARD_OWNER_B;
+  if (world < 1 || world > mh::kShardMaxWorld) return -1;
+  int r = (bx % world + static_cast<int>(A[world]) * (by % world) + static_cast<int>(B[world]) * (bz % world)) % world;
+  return r < 0 ? r + world : r;
+}
+
 int mh_shard_icp_stats(const mh_shard_icp * S, mh_shard_stats * out)
 {
   if (!S || !out) return fail(nullptr, MH_ERR_INVALID_ARG, "mh_shard_icp_stats: NULL argument");
@@ -1429,7 +1480,7 @@ int mh_shard_icp_stats(const mh_shard_icp * S, mh_shard_stats * out)
   out->world = S->comm ? S->comm->world : S->stats.world;
   out->rank = S->comm ? S->comm->rank : S->stats.rank;
   out->collective = S->collective ? 1 : 0;
-  out->linearize_count = S->icp->linearize_count;
+  out->linearize_count = S->icp ? S->icp->linearize_count : S->last_linearize_count;
   return MH_OK;
 }
 

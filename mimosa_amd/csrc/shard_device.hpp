@@ -44,6 +44,11 @@ static_assert(sizeof(ShardRecord) == 112, "ShardRecord layout");
 // device (ping-pong entries: the kernels of call c read [c & 1] and write [(c + 1) & 1]).
 constexpr unsigned long long kShardTomb = ~0ull;
 constexpr int kShardMaxWorld = 64;
+// The owner function's two tables (index = world size; tools/lattice_table.py derives and prints them): rank of block
+// (bx, by, bz) = (bx + A[P] by + B[P] bz) mod P.  One initialiser for the device copy (shard_kernels.hip) and the host twin
+// (mh_shard_owner_of_block, shard_api.hip).
+#define MH_SHARD_OWNER_A {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 3, 3, 5, 7, 5, 6, 5, 4, 7, 5, 6, 6, 5, 5, 5, 5, 5, 6, 6, 6, 5, 5, 7, 6, 7, 5, 7, 6, 7, 8, 7, 6, 7, 7, 9, 8, 8, 7, 7, 10, 10, 7, 7, 8, 7, 8, 8, 8, 8}
+#define MH_SHARD_OWNER_B {0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 5, 6, 4, 5, 7, 8, 8, 8, 8, 10, 9, 7, 11, 8, 12, 11, 12, 6, 7, 14, 13, 10, 6, 7, 11, 16, 15, 6, 12, 7, 13, 17, 10, 14, 18, 11, 11, 14, 23, 22, 16, 12, 21, 8, 9, 13, 11, 11, 17, 14, 19}
 constexpr int kShardSums = 104;                          // all-reduce vector: 95 sums / counters of a binary factor, padded
 constexpr int kShardArLen = kShardSums + kShardMaxWorld;  // ... + one slot per rank (each rank fills its own): max movers per destination
 struct ShardState

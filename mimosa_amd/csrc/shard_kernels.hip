@@ -3,8 +3,8 @@
 // The reference is single-process (no counterpart); what these kernels must preserve is that the SHARDED result equals
 // the unsharded ICPFactor::linearize (include/mimosa/lidar/geometric_factor.hpp:231-562) bit for bit per point.
 //
-// Partition: shard blocks of 2^log2 voxels per axis, owner = XORVector3iHash(block) mod world (the reference's hash,
-// include/mimosa/lidar/utils.hpp:228-238).  Every rank also stores the one-voxel halo of its blocks, so the 1/7/19/27
+// Partition: shard blocks of 2^log2 voxels per axis, owner = a lattice colouring of the block grid (owner_of_block below;
+// mh_shard_owner_of_block is its host twin).  Every rank also stores the one-voxel halo of its blocks, so the 1/7/19/27
 // neighbourhood of a query in an owned block is complete locally.
 //   shard_filter   which points of an insert batch this rank keeps (owned blocks + halo), order preserved
 //   route / append / compact_slots / publish: the native protocol's stages (further down, shard_device.hpp)
@@ -31,8 +31,8 @@ int grid_for(uint32_t n) { return static_cast<int>(max(1u, min((n + kT - 1) / kT
 // scan's points do too: on the configs[1] world the fullest of 8 ranks gets 1.30 x its fair share of the queries, against the
 // 1.65 x of the XOR hash of the block coordinates that rounds 3-4 used (neighbouring heavy blocks met on one rank at random).
 // Results do not depend on the owner function; the storage balance stays within 2 percent.
-__constant__ uint8_t kOwnerA[kShardMaxWorld + 1] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 3, 3, 5, 7, 5, 6, 5, 4, 7, 5, 6, 6, 5, 5, 5, 5, 5, 6, 6, 6, 5, 5, 7, 6, 7, 5, 7, 6, 7, 8, 7, 6, 7, 7, 9, 8, 8, 7, 7, 10, 10, 7, 7, 8, 7, 8, 8, 8, 8};
-__constant__ uint8_t kOwnerB[kShardMaxWorld + 1] = {0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 5, 6, 4, 5, 7, 8, 8, 8, 8, 10, 9, 7, 11, 8, 12, 11, 12, 6, 7, 14, 13, 10, 6, 7, 11, 16, 15, 6, 12, 7, 13, 17, 10, 14, 18, 11, 11, 14, 23, 22, 16, 12, 21, 8, 9, 13, 11, 11, 17, 14, 19};
+__constant__ uint8_t kOwnerA[kShardMaxWorld + 1] = MH_SHARD_OWNER_A;
+__constant__ uint8_t kOwnerB[kShardMaxWorld + 1] = MH_SHARD_OWNER_B;
 __device__ __forceinline__ uint32_t owner_of_block(int bx, int by, int bz, uint32_t world)
 {
   const int w = static_cast<int>(world);  // the terms are reduced first: no overflow for any block coordinate

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_header_symbol():
     missing = [f for f in header_functions() if not hasattr(L, f)]
     assert not missing, missing
     assert sorted(capi.EXPORTS) == header_functions()  # the Python binding list mirrors the header
-    assert L.mh_abi_version() == 2
+    assert L.mh_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

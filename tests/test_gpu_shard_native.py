@@ -176,6 +176,65 @@ def test_context_shut_down_before_its_communicator(small_world):
     comm.destroy()  # after both contexts are gone
 
 
+def test_factor_destroyed_behind_a_drain_with_its_capacity_update_parked(small_world):
+    """factor A has a round in flight; a window batch of two OTHER factors is wider than the publish ring, so
+    its enqueue drains the rounds — A's round completes and its segment-capacity decision is PARKED in the communicator.  A is
+    destroyed without a wait (the API allows it); the next settle must not apply the parked decision to freed memory."""
+    from mimosa_amd import capi
+    w = small_world
+    rc = capi.make_reg_config(**w["cfg"])
+    c = capi.Context(0)
+    comm = capi.ShardComm.local(1)[0]
+    vmap = capi.VoxelMap(c)
+    capi.map_insert_shard(c, vmap, w["map_xyz"], 1, 0)
+    ref = capi.ShardedICPFactor(c, comm, vmap, w["pts"], rc, force_collectives=True)
+    want = ref.linearize(w["R"], w["t"])
+    for rep in range(6):
+        a = capi.ShardedICPFactor(c, comm, vmap, w["pts"], rc, force_collectives=True)
+        b1 = capi.ShardedICPFactor(c, comm, vmap, w["pts"], rc, force_collectives=True)
+        b2 = capi.ShardedICPFactor(c, comm, vmap, w["pts"][: len(w["pts"]) // 2], rc, force_collectives=True)
+        a.linearize_async(w["R"], w["t"])                       # ring width 1: a round in flight
+        outs = capi.sharded_linearize_batch_async([b1, b2], [w["R"]] * 2, [w["t"]] * 2)   # B = 2 > ring width: drains, parks A's update
+        a.destroy()                                             # ... which now points at a destroyed factor
+        junk = [np.zeros(1 << 16) for _ in range(8)]            # (churn the host heap over the freed handle)
+        b1.wait()                                               # settle_rounds -> apply_cap_updates
+        got = outs.results()[0]
+        assert np.array_equal(got["H_ss"], want["H_ss"]) and got["f"] == want["f"]
+        del junk
+        b1.destroy()
+        b2.destroy()
+    ref.destroy()
+    vmap.release()
+    comm.destroy()
+    c.close()
+
+
+def test_sharded_factor_outlives_its_context(small_world):
+    """mh_shutdown(ctx) with a sharded factor of ctx still alive.  The factor gives its device memory back in
+    the shutdown (while the context exists); afterwards every entry point refuses the handle and destroy only deletes it."""
+    from mimosa_amd import capi
+    w = small_world
+    rc = capi.make_reg_config(**w["cfg"])
+    for collective in (True, False):
+        c = capi.Context(0)
+        comm = capi.ShardComm.local(1)[0]
+        vmap = capi.VoxelMap(c)
+        capi.map_insert_shard(c, vmap, w["map_xyz"], 1, 0)
+        f = capi.ShardedICPFactor(c, comm, vmap, w["pts"], rc, force_collectives=collective)
+        f.linearize(w["R"], w["t"])
+        f.linearize_async(w["R"], w["t"])   # in flight at the shutdown
+        vmap.release()
+        c.close()
+        with pytest.raises(Exception, match="context was shut down"):
+            f.reset()
+        with pytest.raises(Exception, match="context was shut down"):
+            f.linearize(w["R"], w["t"])
+        st = f.stats()
+        assert st["linearize_count"] >= 1
+        f.destroy()
+        comm.destroy()
+
+
 def test_native_world1_over_rccl_full_protocol():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_native_rccl_worker.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

@@ -21,14 +21,13 @@ def run(E):
     _R, _g, _out, _all_reduce = E._R, E._g, E._out, E._all_reduce
     # ---- several scans in flight: 4 contexts (one HIP stream each) sharing the map, in a process of their own ----
     # HIP multiplexes a process's streams onto 4 hardware queues and two busy streams that share one serialise
-    # (profiles/r04_concurrency_bisect.md); this process's context holds a second stream (the component server's side
-    # stream), so four MORE contexts here would share queues (3.6-3.7 Gpts/s measured that way).  tools/conc_probe.py runs
-    # the same loop — cold linearizes dealt round-robin to the streams by one host thread, <= 32 in flight per stream — in a
-    # fresh process with one stream per context (MH_OVERLAP=0).
+    # (profiles/r04_concurrency_bisect.md); this process already holds contexts of its own, so four MORE here would share
+    # queues.  tools/conc_probe.py runs the same loop — cold linearizes dealt round-robin to the streams by one host thread,
+    # <= 32 in flight per stream — in a fresh process with one stream per context.
     conc = None
     if args.streams == 1 and args.concurrent_streams > 1 and not args.profile_mode and world == 1:
         import subprocess
-        env = dict(os.environ, MH_OVERLAP="0")
+        env = dict(os.environ)
         here = ROOT
         try:
             pr = subprocess.run([sys.executable, os.path.join(here, "tools", "conc_probe.py"), "--streams", str(args.concurrent_streams),
@@ -37,8 +36,8 @@ def run(E):
             pj = json.loads(line)
             conc = {"streams": pj["streams"], "steps": pj["steps"], "value": pj["conc_mpts"], "ms_per_step": pj["conc_ms"],
                     "single_stream_same_process_ms": pj["single_ms"], "one_host_thread_per_stream_mpts": pj["threads_mpts"],
-                    "note": "tools/conc_probe.py in a process of its own (best of 3 passes of this many steps): 4 contexts, one HIP stream each "
-                            "(MH_OVERLAP=0), sharing one map; see the comment in bench.py"}
+                    "note": "tools/conc_probe.py in a process of its own (best of 3 passes of this many steps): 4 contexts, one HIP stream each, "
+                            "sharing one map"}
         except Exception as e:  # the figure is a side leg: say why it is missing
             conc = {"error": f"{type(e).__name__}: {e}"}
 

@@ -35,3 +35,23 @@ def c_sync_ns(ctx, factor_h, R, t, g, out, n, reset=True):
                               tv.ctypes.data_as(vp), gv.ctypes.data_as(vp), C.byref(out), n, 1 if reset else 0, ns.ctypes.data_as(vp))
     assert rc == 0, rc
     return ns
+
+
+def c_sync_steps(ctx, factor_h, R, t, g, outs):
+    """len(outs) cold synchronous mh_icp_linearize calls made FROM C back to back (tools/micro/sync_caller.c:
+    mh_sync_caller_steps: reset + linearize per step, result i in outs[i]); `outs` = a ctypes array of capi.IcpResult."""
+    import ctypes as C
+
+    import numpy as np
+
+    from mimosa_amd import build as hb
+    H = C.CDLL(hb.build_sync_caller())
+    vp = C.c_void_p
+    H.mh_sync_caller_steps.argtypes = [vp] * 7 + [C.c_size_t, C.c_int]
+    fn = lambda f: C.cast(f, vp)
+    L = ctx.L
+    Rm, tv, gv = (np.ascontiguousarray(x, np.float64) for x in (R, t, g))
+    n = len(outs)
+    rc = H.mh_sync_caller_steps(fn(L.mh_icp_linearize), fn(L.mh_icp_reset), factor_h, Rm.ctypes.data_as(vp), tv.ctypes.data_as(vp),
+                                gv.ctypes.data_as(vp), C.cast(outs, vp), C.sizeof(outs) // max(n, 1), n)
+    assert rc == 0, rc

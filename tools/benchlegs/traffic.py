@@ -26,9 +26,7 @@ def measure_traffic(args):
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--steps", "40", "--warmup", "5", "--profile-mode", "--no-measure-traffic", "--rooms", args.rooms, "--rows", str(args.rows)]
         try:
-            # MH_OVERLAP=0: counter collection serialises the device's kernels, and the component server (a long-running kernel
-            # that waits for K3s of another stream) cannot run under that; K3 itself is the same code either way
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MH_OVERLAP="0"), timeout=240, stdout=subprocess.DEVNULL,
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):

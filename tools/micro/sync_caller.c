@@ -34,3 +34,17 @@ int mh_sync_caller_run(void * lin, void * rst, void * syn, void * ctx, void * ic
   }
   return 0;
 }
+
+/* The timed region of bench.py: n COLD synchronous calls back to back — mh_icp_reset, then mh_icp_linearize, whose return means
+ * the result is on the host (in out + i * out_stride; stride 0 = one slot) — with nothing between them: what a C++ caller that
+ * linearizes one factor at a time pays per step (geometric.cpp:194-196).  Returns the first non-zero status. */
+int mh_sync_caller_steps(void * lin, void * rst, void * icp, const double * R, const double * t, const double * g, char * out,
+                         size_t out_stride, int n)
+{
+  for (int i = 0; i < n; ++i) {
+    int rc = ((reset_fn)rst)(icp);
+    if (!rc) rc = ((lin_fn)lin)(icp, R, t, NULL, NULL, g, out + (size_t)i * out_stride);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -9,11 +9,6 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 200 --warmup 20 --profile-mode --no-measure-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
-# the same with every kernel on the context's stream (no component server): K3 and K4 without each other's company
-MH_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_plain -- $CMD > $OUT/stats_plain.log 2>&1
-# Counter collection serialises the device's kernels; the component server (a long-running kernel waiting for K3s of another
-# stream) cannot run under that, so the PMC passes run with MH_OVERLAP=0 (K3 is the same code either way).
-export MH_OVERLAP=0
 i=0
 for pass in \
   "FETCH_SIZE" \
@@ -69,5 +64,4 @@ PY
 cat $OUT/stats/*/*_kernel_stats.csv | cut -c1-200
 # gpurun merges at most 64 MiB back: keep the summaries, the logs and the stats table, drop the raw per-dispatch tables
 mkdir -p $OUT/keep && cp $OUT/stats/*/*_kernel_stats.csv $OUT/keep/kernel_stats.csv 2>/dev/null
-cp $OUT/stats_plain/*/*_kernel_stats.csv $OUT/keep/kernel_stats_plain.csv 2>/dev/null
-rm -rf $OUT/pmc_*/ $OUT/stats $OUT/stats_plain
+rm -rf $OUT/pmc_*/ $OUT/stats
