@@ -60,6 +60,7 @@ struct IcpArgs
   double R[9], t[3];  // delta pose  T_tgt^-1 * T_src
   double da_thresh, max_d2, plane_valid, sigma, huber;
   double inv_sigma;  // 1 / sigma, divided on the host: the kernel whitens by multiplication
+  double inv_huber;  // 1 / huber, likewise (the Huber weight is one reciprocal square root of |we| / huber)
   double * q_da;
   double * mean;
   double * normal;

@@ -424,7 +424,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // Block tables carry a one-voxel halo (voxel_map.hpp): all 27 neighbours of the centre voxel are in
   // the table of ITS block.  One hash probe, then nine 12-byte loads (the z-triple of each (dx, dy)
   // column) — 11 per-lane L1 transactions with the source point instead of 28.
-  const int cx = fast_floor(q0 * map.inv_leaf), cy = fast_floor(q1 * map.inv_leaf), cz = fast_floor(q2 * map.inv_leaf);
+  const double u0 = q0 * map.inv_leaf, u1 = q1 * map.inv_leaf, u2 = q2 * map.inv_leaf;  // voxel units
+  const int cx = fast_floor(u0), cy = fast_floor(u1), cz = fast_floor(u2);
   constexpr int m = kBlockDim - 1;
   const int bx = cx >> kBlockLog2, by = cy >> kBlockLog2, bz = cz >> kBlockLog2;
   int blk_id;
@@ -475,8 +476,9 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   uint64_t qc0 = 0, qc1 = 0;  // quads per voxel, 3 bits each: scan positions 0..20 | 21..26
 #pragma unroll
   for (int o = 0; o < NOFF; ++o) {
-    list[o * lds_stride] = cell[o] != kEmptyCell ? cell[o] : 0u;  // empty = (voxel 0, count 0): always a mapped index
-    const uint32_t c = cell[o] != kEmptyCell ? (cell[o] & 31u) : 0u;
+    static_assert(kEmptyCell == 0u, "an empty cell reads as (voxel 0, count 0): a mapped index and no candidates, without a select");
+    list[o * lds_stride] = cell[o];
+    const uint32_t c = cell[o] & 31u;
     amask |= (c ? 1u : 0u) << o;
     total_ref += c;
     const uint64_t nq = (c + 3u) >> 2;
@@ -491,12 +493,13 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // packed 3 x 10-bit copy of the buckets: ONE 16-byte load brings four candidates (the kernel is bound
   // by per-lane L1 requests, not bytes).  A decoded coordinate is the middle of its quantisation cell:
   // |error| <= 0.5 g per axis, so |r_coarse - r| <= 0.87 g + f32 round-off; kErrG covers it.
+  // q inside its voxel, in grid units: frac(q * inv_leaf) * 1024 — the expression the map's packed copy was quantised with
+  // (map_kernels.hip), no division.
   constexpr float kErrG = 0.9f;
-  const double leaf_d = 1.0 / map.inv_leaf;
-  const double g_d = leaf_d / static_cast<double>(1 << kQuantBits);
-  const float qg0 = static_cast<float>((q0 - static_cast<double>(cx) * leaf_d) / g_d);
-  const float qg1 = static_cast<float>((q1 - static_cast<double>(cy) * leaf_d) / g_d);
-  const float qg2 = static_cast<float>((q2 - static_cast<double>(cz) * leaf_d) / g_d);
+  constexpr double kQ_d = static_cast<double>(1 << kQuantBits);
+  const float qg0 = static_cast<float>((u0 - static_cast<double>(cx)) * kQ_d);
+  const float qg1 = static_cast<float>((u1 - static_cast<double>(cy)) * kQ_d);
+  const float qg2 = static_cast<float>((u2 - static_cast<double>(cz)) * kQ_d);
   uint32_t ck[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
@@ -592,31 +595,58 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     if constexpr (FAST) {
       // rank by counting: survivor u's position in the order (distance, traversal rank) = the number of survivors before it.
       // An empty slot carries the largest double: it sorts behind every candidate, so no validity mask enters the comparisons.
-      double d[KK];
+      // A squared distance is a non-negative double, so its BIT PATTERN orders like its value: one 64-bit integer compare
+      // per pair.  Exact ties are broken by the traversal rank only where it matters — a tie across the boundary of the answer
+      // (the k-th and the (k+1)-th distance equal) — in a second, wave-uniform pass that almost no wave takes: a tie inside
+      // the answer or outside it changes neither the set nor the k-th distance.
+      unsigned long long d[KK];
       uint32_t rk[KK];
 #pragma unroll
       for (int u = 0; u < KK; ++u) {
         const double du = sq_dist3(static_cast<double>(sc[u].x) - q0, static_cast<double>(sc[u].y) - q1, static_cast<double>(sc[u].z) - q2);
-        d[u] = ck[u] != 0xFFFFFFFFu ? du : kDblMax;
+        d[u] = static_cast<unsigned long long>(__double_as_longlong(ck[u] != 0xFFFFFFFFu ? du : kDblMax));
         rk[u] = 0u;
       }
 #pragma unroll
       for (int u = 0; u < KK; ++u)
 #pragma unroll
         for (int v = u + 1; v < KK; ++v) {
-          const bool lt = d[u] < d[v] || (d[u] == d[v] && srank[u] < srank[v]);  // u before v
+          const bool lt = d[u] < d[v];  // u before v
           rk[v] += lt ? 1u : 0u;
           rk[u] += lt ? 0u : 1u;
         }
+      unsigned long long dk_bits = static_cast<unsigned long long>(__double_as_longlong(kDblMax)), dn_bits = ~0ull;
+#pragma unroll
+      for (int u = 0; u < KK; ++u) {
+        dk_bits = rk[u] == static_cast<uint32_t>(k - 1) ? d[u] : dk_bits;  // the k-th of the order (kDblMax: fewer than k candidates)
+        dn_bits = rk[u] == static_cast<uint32_t>(k) ? d[u] : dn_bits;      // the (k+1)-th
+      }
       uint32_t member = 0u;
-      double dkf = kDblMax;
 #pragma unroll
       for (int u = 0; u < KK; ++u) {
         const bool valid = ck[u] != 0xFFFFFFFFu;
         member |= (valid && rk[u] < static_cast<uint32_t>(k)) ? (1u << u) : 0u;
-        dkf = (valid && rk[u] == static_cast<uint32_t>(k - 1)) ? d[u] : dkf;  // exists iff >= k candidates were found
         fast->pt[u] = sc[u];
       }
+      if (__any(static_cast<int>(dk_bits == dn_bits && dk_bits != static_cast<unsigned long long>(__double_as_longlong(kDblMax))))) {
+        // an exact tie across the boundary somewhere in this wave: the full order (distance, traversal rank) for everybody
+        uint32_t rt[KK];
+#pragma unroll
+        for (int u = 0; u < KK; ++u) rt[u] = 0u;
+#pragma unroll
+        for (int u = 0; u < KK; ++u)
+#pragma unroll
+          for (int v = u + 1; v < KK; ++v) {
+            const bool lt = d[u] < d[v] || (d[u] == d[v] && srank[u] < srank[v]);
+            rt[v] += lt ? 1u : 0u;
+            rt[u] += lt ? 0u : 1u;
+          }
+        uint32_t mt = 0u;
+#pragma unroll
+        for (int u = 0; u < KK; ++u) mt |= (ck[u] != 0xFFFFFFFFu && rt[u] < static_cast<uint32_t>(k)) ? (1u << u) : 0u;
+        member = mt;
+      }
+      const double dkf = __longlong_as_double(static_cast<long long>(dk_bits));  // (the same value whichever tied survivor holds rank k - 1)
       fast->member = member;
       bd[K - 1] = dkf;  // (read back below as the k-th distance: K == k in this instantiation)
     } else {
@@ -657,10 +687,13 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   if (ck[KK - 1] != 0xFFFFFFFFu && dk < kDblMax) {
     // Scanned non-survivors have coarse keys >= ck[KK-1]; clearing the payload bits only lowers the
     // bound; |r_coarse - r| <= kErrG grid units.  (Pruned voxels are farther than the k-th distance
-    // by construction.)
-    const double c8 = static_cast<double>(__uint_as_float(ck[KK - 1] & ~0x3FFu));  // grid units^2
-    const double r_lo = (sqrt(c8) * (1.0 - 1e-6) - static_cast<double>(kErrG)) * g_d;  // metres
-    need_exact = !(r_lo > 0.0 && dk < r_lo * r_lo);
+    // by construction.)  Evaluated in f32 grid units with the roundings on the safe side: a lane flagged without need only
+    // takes the exact pass, which returns the same answer.
+    const float c8 = __uint_as_float(ck[KK - 1] & ~0x3FFu);                       // grid units^2, a lower bound of every non-survivor's key
+    const float r_lo = sqrtf(c8) * (1.0f - 2e-6f) - kErrG;                         // grid units
+    const double inv_g = map.inv_leaf * kQ_d;                                      // grid units per metre
+    const float dk_g = static_cast<float>(dk * (inv_g * inv_g)) * (1.0f + 3e-7f);  // the exact k-th distance, rounded up
+    need_exact = !(r_lo > 0.0f && dk_g < r_lo * r_lo * (1.0f - 3e-7f));
   }
   // ---- exact fallback, wave-cooperative: KnnResult::push verbatim for lane L — the scanned voxels in
   // traversal (offset-generation) order, slots in order, strict '<' so the earlier candidate wins ties —
@@ -941,7 +974,7 @@ __device__ __forceinline__ void loc_directions(const A & a, const double nx, con
   double r0 = ns1 * pz - ns2 * py, r1 = ns2 * px - ns0 * pz, r2 = ns0 * py - ns1 * px;
   const double nr2 = r0 * r0 + (r1 * r1 + r2 * r2);
   if (nr2 > 0.0) {
-    const double inv = 1.0 / sqrt(nr2);
+    const double inv = mh_rsqrt(nr2);
     r0 *= inv;
     r1 *= inv;
     r2 *= inv;
@@ -1110,14 +1143,17 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         // 4. estimatePlane (:176-229)
         constexpr int NX = kFast ? KS : K;  // FAST: the survivors of the coarse tier, the k nearest marked in sel.member (the others count as zero)
         double X[NX][3];
+        [[maybe_unused]] double dm[NX];  // FAST: 1.0 for a member, 0.0 otherwise (the two differ in the high word only: one select)
         double sx = 0, sy = 0, sz = 0;
         if constexpr (kFast) {
 #pragma unroll
           for (int j = 0; j < NX; ++j) {
             const bool m = (sel.member >> j) & 1u;
-            X[j][0] = m ? static_cast<double>(sel.pt[j].x) : 0.0;
-            X[j][1] = m ? static_cast<double>(sel.pt[j].y) : 0.0;
-            X[j][2] = m ? static_cast<double>(sel.pt[j].z) : 0.0;
+            // the select on the f32 value (one instruction), then the conversion: a point that is not one of the k nearest is 0
+            X[j][0] = static_cast<double>(m ? sel.pt[j].x : 0.0f);
+            X[j][1] = static_cast<double>(m ? sel.pt[j].y : 0.0f);
+            X[j][2] = static_cast<double>(m ? sel.pt[j].z : 0.0f);
+            dm[j] = __hiloint2double(m ? 0x3FF00000 : 0, 0);
             sx += X[j][0];
             sy += X[j][1];
             sz += X[j][2];
@@ -1146,11 +1182,18 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-          const bool m = kFast ? (((sel.member >> j) & 1u) != 0u) : (j < k);
           // a point that is not one of the k nearest stays at zero: it adds nothing to the covariance and passes the plane gate
-          X[j][0] = m ? X[j][0] - mean[0] : 0.0;
-          X[j][1] = m ? X[j][1] - mean[1] : 0.0;
-          X[j][2] = m ? X[j][2] - mean[2] : 0.0;
+          if constexpr (kFast) {
+            // X - dm * mean: the same rounding as X - mean for a member (dm = 1), exactly 0 otherwise (X = 0, dm = 0)
+            X[j][0] = fma(-dm[j], mean[0], X[j][0]);
+            X[j][1] = fma(-dm[j], mean[1], X[j][1]);
+            X[j][2] = fma(-dm[j], mean[2], X[j][2]);
+          } else {
+            const bool m = j < k;
+            X[j][0] = m ? X[j][0] - mean[0] : 0.0;
+            X[j][1] = m ? X[j][1] - mean[1] : 0.0;
+            X[j][2] = m ? X[j][2] - mean[2] : 0.0;
+          }
           c00 += X[j][0] * X[j][0];
           c01 += X[j][0] * X[j][1];
           c02 += X[j][0] * X[j][2];
@@ -1230,16 +1273,19 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     if (go) {
       // 5. residual + max-error gate (:319-328)
       double e = nrm[0] * (mean[0] - q0) + (nrm[1] * (mean[1] - q1) + nrm[2] * (mean[2] - q2));
-      const double range = sqrt(px * px + (py * py + pz * pz));
-      const double s = 1.0 - 0.9 * fabs(e) * mh_rsqrt(range);
-      if (s < 0.9) {
+      // s = 1 - 0.9 |e| / sqrt(range) < 0.9 (:322-326)  <=>  9 |e| > sqrt(range)  <=>  (81 e^2)^2 > range^2 = |p|^2: the gate
+      // needs the comparison only, and that form has no square root in it (rounding differs from the reference's expression in
+      // the last bits of the threshold, as every other gate's does)
+      const double r2 = px * px + (py * py + pz * pz);
+      const double e81 = 81.0 * (e * e);
+      if (e81 * e81 > r2) {
         st = MH_MAX_ERROR;
       } else {
         // 6. Huber (:330-339)
         double sw = 1.0;
         if (a.use_huber) {
           const double we = e * a.inv_sigma;
-          if (fabs(we) > a.huber) sw = sqrt(mh_div(a.huber, fabs(we)));
+          if (fabs(we) > a.huber) sw = mh_rsqrt(fabs(we) * a.inv_huber);  // sqrt(huber / |we|) (:334-336)
         }
         const double wgt = sw * a.inv_sigma;
         e *= wgt;

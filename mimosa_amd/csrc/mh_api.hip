@@ -671,6 +671,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   a.sigma = static_cast<double>(icp->cfg.lidar_point_noise_std_dev);
   a.inv_sigma = 1.0 / a.sigma;
   a.huber = static_cast<double>(icp->cfg.huber_threshold);
+  a.inv_huber = 1.0 / a.huber;
   a.q_da = static_cast<double *>(icp->d_qda.p);
   a.mean = static_cast<double *>(icp->d_mean.p);
   a.normal = static_cast<double *>(icp->d_normal.p);

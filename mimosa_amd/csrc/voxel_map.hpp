@@ -16,7 +16,7 @@
 //                                          tier reads 4 candidates per 16-byte load; selection is
 //                                          always re-decided on the exact float4 copy
 //   cells   : uint32[n_blocks * 216]       4x4x4-voxel blocks stored WITH A ONE-VOXEL HALO (6x6x6 words,
-//                                          z fastest); entry = voxel_id << 5 | count, ~0u = empty
+//                                          z fastest); entry = voxel_id << 5 | count (count >= 1), 0 = empty
 //   table   : int4[capacity]               open-addressing hash of BLOCK coords -> block id: {key lo, key hi, id, -},
 //                                          key = 3 x 21-bit packed block coordinate, all-ones = empty
 //
@@ -40,7 +40,7 @@ constexpr int kBlockDim = 1 << kBlockLog2;
 constexpr int kHaloDim = kBlockDim + 2;                // block + one-voxel halo
 constexpr int kCellsPerBlock = kHaloDim * kHaloDim * kHaloDim;  // 216 words per block table
 constexpr int kBucketStride = 20;                   // FlatContainer max_num_points_in_cell
-constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
+constexpr uint32_t kEmptyCell = 0u;  // a stored word is voxel_id << 5 | count with count >= 1: never 0.  Read as (voxel 0, count 0) by K3: no select
 constexpr int kQuantBits = 10;                     // coarse copy: leaf / 1024 resolution
 
 struct Int4

@@ -224,7 +224,8 @@ def test_sharded_factor_outlives_its_context(small_world):
         f.linearize(w["R"], w["t"])
         f.linearize_async(w["R"], w["t"])   # in flight at the shutdown
         vmap.release()
-        c.close()
+        c.L.mh_shutdown(c.h)   # the raw call: the Python binding would defer the shutdown until the factor is gone
+        c.h = None
         with pytest.raises(Exception, match="context was shut down"):
             f.reset()
         with pytest.raises(Exception, match="context was shut down"):
