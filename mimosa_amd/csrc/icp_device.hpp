@@ -98,6 +98,7 @@ struct LocArgs
   const float4 * src;
   int n;
   int chunks_per_block;  // set by the launcher
+  int k;                 // num_corres_points (with n: the launch class of the single-call launcher)
   int k3_blocks;         // plain factors: K3's workgroups of this factor = rows in `partials` that every K4 workgroup folds for itself
   uint4 * ll;            // plain factors: the call's slot in mapped pinned memory
   double R[9];
@@ -114,16 +115,17 @@ struct LocArgs
   unsigned long long * dbg = nullptr;  // MH_TIMELINE diagnostic build only, else null: per-wave stamps of this pass (16 words per wave)
 };
 
-int linearize_grid(int n);
-int linearize_class(int n);  // threads per workgroup of the K3 launch for n points (256 / 512)
-int localizability_grid(int n, bool shard = false);
+// The launch class of a factor = points per K3 workgroup (icp_kernels.hip, "Launchers"): 512 / 256 (one lane per point), 128 / 64
+// (2 / 4 lanes per point: small clouds of plain k = 5 factors).  total: the points of the whole window batch the factor is
+// linearized in (0 = a call of its own).
+int linearize_class(int n, int k, bool shard, long long total = 0);
+int class_grid(int n, int ppw);                       // K3 workgroups of an n-point factor in that class (a multiple of 8)
+int class_loc_grid(int n, int ppw, bool shard = false);  // K4 workgroups
+int linearize_grid_max(int n);                        // the largest K3 grid any class gives n points (buffer sizing)
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream);
 hipError_t launch_localizability(const LocArgs & a, hipStream_t stream);
 // Batched form: d_args / d_start live in device-visible memory (n_factors argument blocks, n_factors + 1 grid
-// prefix entries); every factor's grid is batch_grid(n, tpb) with one tpb = batch_tpb(max n) for the whole batch.
-int batch_tpb(int max_n);
-int batch_grid(int n, int tpb);
-int batch_loc_grid(int n, int tpb, bool shard = false);
+// prefix entries); every factor's grid is class_grid(n, ppw) with one class for the launch group.
 hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb, int k,
                                   int n_off, bool binary, hipStream_t stream);
 hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,

@@ -28,6 +28,8 @@
 // reductions and in the exact fallback, not in the scan.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "icp_device.hpp"
 
 #ifndef MH_PRUNE_TRIPS
@@ -378,6 +380,78 @@ __device__ __forceinline__ uint32_t scan_trip(ScanCursor<NOFF> & cur, ScanStage 
   return live_quads;
 }
 
+// ---- several lanes per query (the small-cloud classes of K3) -------------------------------------------------------------
+// QL = 2 or 4 ADJACENT lanes of a wave serve one query: they look the neighbourhood up together (the same addresses: one
+// transaction), share the quads of the centre voxel and the neighbour voxels left by the pruning among themselves, each keeps a
+// sorted top-KK of what it scanned, and the lists are merged through DPP quad permutes — every lane of the group ends with the
+// top-KK of the union, sorted, exactly the list one lane scanning everything would hold (the coarse keys are unique per
+// candidate: distance bits | scan position | slot).  For clouds that leave most of the machine without a wave the scan is a
+// fraction of one wave's dependent chain instead of all of it.
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_pull(uint32_t v)
+{
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+// own sorted top-8 + the partner's (lane ^ 1: CTRL 0xB1, lane ^ 2: CTRL 0x4E) -> the sorted top-8 of both, in both lanes:
+// min(a[i], b[7 - i]) are the 8 smallest of the 16 as a bitonic sequence; three compare-exchange stages sort it.
+template <int CTRL>
+__device__ __forceinline__ void quad_merge8(uint32_t (&ck)[8])
+{
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = quad_pull<CTRL>(ck[7 - i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ck[i] = min(ck[i], o[i]);
+  cmp_exch(ck[0], ck[4]); cmp_exch(ck[1], ck[5]); cmp_exch(ck[2], ck[6]); cmp_exch(ck[3], ck[7]);
+  cmp_exch(ck[0], ck[2]); cmp_exch(ck[1], ck[3]); cmp_exch(ck[4], ck[6]); cmp_exch(ck[5], ck[7]);
+  cmp_exch(ck[0], ck[1]); cmp_exch(ck[2], ck[3]); cmp_exch(ck[4], ck[5]); cmp_exch(ck[6], ck[7]);
+}
+template <int QL>
+__device__ __forceinline__ void group_merge8(uint32_t (&ck)[8])
+{
+  if constexpr (QL >= 2) quad_merge8<0xB1>(ck);
+  if constexpr (QL >= 4) quad_merge8<0x4E>(ck);
+}
+template <int QL>
+__device__ __forceinline__ uint32_t group_min(uint32_t v)
+{
+  if constexpr (QL >= 2) v = min(v, quad_pull<0xB1>(v));
+  if constexpr (QL >= 4) v = min(v, quad_pull<0x4E>(v));
+  return v;
+}
+template <int QL>
+__device__ __forceinline__ uint32_t group_or(uint32_t v)
+{
+  if constexpr (QL >= 2) v |= quad_pull<0xB1>(v);
+  if constexpr (QL >= 4) v |= quad_pull<0x4E>(v);
+  return v;
+}
+// The set bits of x dealt round-robin: lane `sub` of the group keeps the bits whose index among the set bits is = sub (mod QL).
+// Inclusive prefix parity by five shift-xor steps: bit i of y = parity of popcount(x & (2 << i) - 1).
+__device__ __forceinline__ uint32_t prefix_parity(uint32_t x)
+{
+  uint32_t y = x;
+  y ^= y << 1;
+  y ^= y << 2;
+  y ^= y << 4;
+  y ^= y << 8;
+  y ^= y << 16;
+  return y;
+}
+template <int QL>
+__device__ __forceinline__ uint32_t deal_bits(uint32_t x, uint32_t sub)
+{
+  if constexpr (QL == 1) return x;
+  // first, third, ... set bit: odd inclusive count
+  const uint32_t odd = x & prefix_parity(x);
+  uint32_t m = (sub & 1u) ? (x & ~odd) : odd;
+  if constexpr (QL == 4) {
+    const uint32_t odd2 = m & prefix_parity(m);
+    m = (sub & 2u) ? (m & ~odd2) : odd2;
+  }
+  return m;
+}
+
 // k-NN of q over the neighbour voxels of its centre voxel (IncrementalVoxelMapPCL::knn_search).
 // bi[0..k-1] = bucket indices of the k nearest in ascending order (0xFFFFFFFF where not found), dk = squared
 // distance of the k-th.  `list` is this lane's column of an LDS array [NOFF][stride] (cell words in scan order),
@@ -409,7 +483,10 @@ struct KnnPoints
   uint32_t member;  // bit u: pt[u] is one of the k nearest
 };
 constexpr int knn_survivors(int K) { return K + 3 + (K > 5 ? 1 : 0); }  // 8 for k = 5, 12 for the generic k <= 8 path
-template <int K, int NOFF, bool FAST = false, int PIPE = MH_PIPE>
+// QL > 1 (FAST only): QL adjacent lanes call with the SAME query and the same `list` column; `n_scanned` is then the calling
+// lane's own share (the caller sums the lanes), the return value and every result are the same in all lanes of the group, and the
+// exact fallback is run for the group's first lane only (the others' results are the caller's to ignore).
+template <int K, int NOFF, bool FAST = false, int PIPE = MH_PIPE, int QL = 1>
 __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double q0, const double q1, const double q2,
                                               int k, uint32_t * list, int lds_stride, const uint32_t * scan_lut,
                                               uint32_t (&bi)[K], double & dk, bool & fell_back, uint32_t & n_scanned,
@@ -417,6 +494,8 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 {
   (void)dbg;
   (void)fast;
+  static_assert(QL == 1 || (FAST && knn_survivors(K) == 8), "several lanes per query: the k = 5 fast path's top-8 only");
+  [[maybe_unused]] const uint32_t sub = QL > 1 ? (threadIdx.x & static_cast<uint32_t>(QL - 1)) : 0u;
   fell_back = false;
   constexpr int KK = knn_survivors(K);
   constexpr int row = NOFF == 7 ? 1 : (NOFF == 19 ? 2 : 3);
@@ -508,18 +587,39 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
 
   // ---- B1. centre voxel first: it supplies the pruning bound -------------------------------------
   n_scanned = 0;
-  if (amask & 1u) {
+  if constexpr (QL == 1) {
+    if (amask & 1u) {
+      const uint32_t cc = cell[0] & 31u;
+      const uint4 * b = map.qbuckets + static_cast<size_t>(cell[0] >> 5) * (kBucketStride / 4);
+      n_scanned += cc;
+      const float ofx = 0.5f - qg0, ofy = 0.5f - qg1, ofz = 0.5f - qg2;  // centre voxel: offset (0,0,0)
+      uint4 qw[kBucketStride / 4];
+#pragma unroll
+      for (int u = 0; u < kBucketStride / 4; ++u) qw[u] = b[static_cast<uint32_t>(4 * u) < cc ? u : 0];  // all issued together
+#pragma unroll
+      for (int u = 0; u < kBucketStride / 4; ++u) {
+        if (static_cast<uint32_t>(4 * u) < cc) merge_quad<KK>(ck, kc, qw[u], ofx, 8192.0f - ofy, ofz, static_cast<uint32_t>(4 * u), min(cc - static_cast<uint32_t>(4 * u), 4u));
+      }
+    }
+  } else {
+    // the centre voxel's quads dealt to the group: lane `sub` takes quads sub, sub + QL, ... — every lane runs the same
+    // ceil(5 / QL) merges (a quad past the voxel's last has no valid slot), then the lists are merged: every lane holds the
+    // centre voxel's top-8 and with it the first pruning bound.  (An empty centre voxel reads quad 0 of voxel 0: mapped.)
     const uint32_t cc = cell[0] & 31u;
     const uint4 * b = map.qbuckets + static_cast<size_t>(cell[0] >> 5) * (kBucketStride / 4);
-    n_scanned += cc;
-    const float ofx = 0.5f - qg0, ofy = 0.5f - qg1, ofz = 0.5f - qg2;  // centre voxel: offset (0,0,0)
-    uint4 qw[kBucketStride / 4];
+    const float ofx = 0.5f - qg0, ofy = 0.5f - qg1, ofz = 0.5f - qg2;
+    constexpr int NJ = (kBucketStride / 4 + QL - 1) / QL;
+    uint4 qw[NJ];
 #pragma unroll
-    for (int u = 0; u < kBucketStride / 4; ++u) qw[u] = b[static_cast<uint32_t>(4 * u) < cc ? u : 0];  // all issued together
+    for (int j = 0; j < NJ; ++j) qw[j] = b[min(static_cast<uint32_t>(j * QL) + sub, static_cast<uint32_t>(kBucketStride / 4 - 1))];
 #pragma unroll
-    for (int u = 0; u < kBucketStride / 4; ++u) {
-      if (static_cast<uint32_t>(4 * u) < cc) merge_quad<KK>(ck, kc, qw[u], ofx, 8192.0f - ofy, ofz, static_cast<uint32_t>(4 * u), min(cc - static_cast<uint32_t>(4 * u), 4u));
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t u4 = 4u * (static_cast<uint32_t>(j * QL) + sub);
+      const uint32_t vc = static_cast<uint32_t>(min(max(static_cast<int>(cc) - static_cast<int>(u4), 0), 4));
+      n_scanned += vc;
+      merge_quad<KK>(ck, kc, qw[j], ofx, 8192.0f - ofy, ofz, min(u4, 28u), vc);
     }
+    group_merge8<QL>(ck);
   }
   MH_STAMP(dbg, 10);
   // ---- prune: a neighbour voxel whose BOX is farther from q than a proven upper bound of the current
@@ -529,6 +629,20 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   box_dists<NOFF>(qg0, qg1, qg2, boxd);
   uint32_t rem = amask & ~1u;  // neighbour voxels the cursor has not entered yet
   rem &= prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
+  // several lanes per query: the voxels that are left are dealt round-robin in scan order (faces, edges, corners: every lane
+  // gets near and far ones); the group's first lane goes on with the centre voxel's list, the others start empty and prune
+  // with the bound it proves (kth_group) until their own is tighter
+  [[maybe_unused]] uint32_t kth_group = 0xFFFFFFFFu;
+  if constexpr (QL > 1) {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (i == k - 1) kth_group = ck[i];
+    rem = deal_bits<QL>(rem, sub);
+    if (sub != 0u) {
+#pragma unroll
+      for (int i = 0; i < KK; ++i) ck[i] = 0xFFFFFFFFu;
+    }
+  }
   uint32_t alive = rem;  // neighbour voxels never pruned: alive & ~rem (after the scan) = the voxels scanned
 
   MH_STAMP(dbg, 11);
@@ -552,13 +666,26 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     for (int trip = 0;; ++trip) {
       if (!__any(static_cast<int>(stage[0].vcnt))) break;  // a dead stage 0 means dead stages 1..3
       if (MH_PRUNE_TRIPS) {
-        const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG);
+        if constexpr (QL > 1) {
+          // the tightest k-th key any lane of the group has proven (each is an upper bound of the answer's k-th distance)
+          uint32_t mine = kth_group;
+#pragma unroll
+          for (int i = 0; i < K; ++i)
+            if (i == k - 1) mine = min(mine, ck[i]);
+          kth_group = group_min<QL>(mine);
+        }
+        const uint32_t keep = prune_keep_mask<K, KK, NOFF>(ck, boxd, k, kErrG, kth_group);
         cur.rem &= keep;
         alive &= keep;
       }
       scan_trip<KK, NOFF, kPipe>(cur, stage, ck, kc, list, lds_stride, lut4, map.qbuckets, cx0, cy1, cz2, n_scanned);
     }
     rem = cur.rem;
+  }
+  if constexpr (QL > 1) {
+    group_merge8<QL>(ck);                                  // every lane: the sorted top-8 of everything the group scanned
+    alive = group_or<QL>(alive & ~rem);                    // ... and the neighbour voxels the group entered
+    rem = 0u;
   }
   // (Measured, round 1: capping the per-lane scan at 16 quads and letting the 64 lanes scan the leftover
   // voxels together, one candidate per lane, was 2x SLOWER — each (lane, voxel) step is a dependent LDS ->
@@ -699,6 +826,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
   // traversal (offset-generation) order, slots in order, strict '<' so the earlier candidate wins ties —
   // with the 64 lanes computing one fp64 distance each and L inserting the few that beat its k-th.
   // (Pruned voxels are provably farther than the k-th distance, so skipping them changes nothing.)
+  if constexpr (QL > 1) need_exact = need_exact && sub == 0u;  // one lane of the group answers for the query
   fell_back = need_exact;
   uint64_t fb = __ballot(need_exact);
   while (fb) {
@@ -706,7 +834,7 @@ __device__ __forceinline__ uint32_t knn_query(const MapView & map, const double 
     fb &= fb - 1ull;
     const uint32_t mL = lane_get(scanned_mask, L);
     const double y0 = lane_get(q0, L), y1 = lane_get(q1, L), y2 = lane_get(q2, L);
-    const int dl = L - static_cast<int>(lane);
+    const int dl = QL > 1 ? L / QL - static_cast<int>(lane) / QL : L - static_cast<int>(lane);  // lane L's list column from this lane's
     double ed[K];
     uint32_t ei[K];
 #pragma unroll
@@ -998,16 +1126,22 @@ __device__ __forceinline__ void loc_directions(const A & a, const double nx, con
 // SHARD: the launch of a map-sharded factor (shard_api.hip) — the slot count is read from the device, slots whose status
 // carries kShardSkip are passed over, the last block also writes its sums into the all-reduce vector.  The plain factor's
 // instantiation carries none of it (round 3 had it in the one kernel: +1 us on every unsharded launch).
-template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
+// QL: lanes per query (1; 2 or 4 for small clouds of plain k = 5 factors — "several lanes per query" above): the workgroup's
+// TPB threads then serve TPB / QL consecutive points, the group's first lane owns the point (stores, row, counters), and the
+// per-point results are bit-identical to the QL = 1 classes'.
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD, int QL = 1>
 __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int block_id, const int n_blocks)
 {
+  static_assert(QL == 1 || (!SHARD && K == 5), "several lanes per query: plain k = 5 factors only");
+  constexpr int PPW = TPB / QL;  // points per workgroup
+  [[maybe_unused]] const bool lead = QL == 1 || (threadIdx.x & static_cast<unsigned int>(QL - 1)) == 0u;
   constexpr int NV = BINARY ? 13 : 7;           // row vector v = [J_s(6) (, J_t(6)), e]
   constexpr int NENT = NV * (NV + 1) / 2;       // upper triangle of v v^T: 28 / 91 sums
   constexpr int EW = BINARY ? 96 : 32;
   constexpr int ROWW = NV;                      // 7 / 13 doubles: an odd row stride spreads the lanes' rows over the LDS banks
   // One LDS arena, reused: [k-NN] per-lane neighbour cell words; [last block] fold scratch.  The waves' row tiles and partial
   // sums (step 8) have memory of their own: a wave reduces its rows while the others are still in the k-NN arena.
-  constexpr int kListWords = NOFF * TPB;
+  constexpr int kListWords = NOFF * PPW;
   constexpr int kFoldWords = (TPB / EW) * EW * 2 + EW * 2;
   constexpr int kArenaWords = kListWords > kFoldWords ? kListWords : kFoldWords;
   __shared__ __attribute__((aligned(16))) uint32_t s_arena[kArenaWords];
@@ -1017,7 +1151,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   __shared__ uint32_t s_scan[kScanLutWords];
   __shared__ bool s_last;
 
-  uint32_t * s_list = s_arena + threadIdx.x;                                          // [NOFF][TPB]
+  uint32_t * s_list = s_arena + threadIdx.x / QL;                                     // [NOFF][PPW]: one column per point
   double * s_aux = reinterpret_cast<double *>(s_arena);                               // fold scratch of the last block
 
   // Which 64 points a wave takes.  A workgroup's waves take 64-point chunks that lie n_blocks / 8 chunks apart inside their XCD's
@@ -1026,10 +1160,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   // slowest workgroup — eight consecutive chunks put a heavy stretch on ONE CU's eight waves, eight strided ones give every CU
   // a sample of its XCD's whole stretch (same L2 as before).  rocprofv3, cold calls on the configs[1] world: 32.2 -> 29.2 us at
   // 131 072 points, 21.3 -> 20.9 us at 24 576 (gpurun c19; -DMH_NO_INTERLEAVE restores the consecutive chunks).
-#if defined(MH_INTERLEAVE_GLOBAL)  // (experiment: strided over the whole cloud — every XCD's L2 then sees the whole touched map)
-  const int qi = (static_cast<int>(threadIdx.x >> 6) * n_blocks + block_id) * 64 + static_cast<int>(threadIdx.x & 63u);
-#elif !defined(MH_NO_INTERLEAVE)
+#if !defined(MH_NO_INTERLEAVE)
   const int qi = [&] {
+    if constexpr (QL > 1) return xcd_chunk(block_id, n_blocks) * PPW + static_cast<int>(threadIdx.x) / QL;  // (every wave has a SIMD to itself)
     constexpr int WPB = TPB / 64;
     const int cpx = n_blocks >> 3, x = block_id & 7, j = block_id >> 3, wv = static_cast<int>(threadIdx.x >> 6);
 #if MH_XCD_PIECES > 1
@@ -1045,7 +1178,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
 #endif
   }();
 #else
-  const int qi = xcd_chunk(block_id, n_blocks) * TPB + threadIdx.x;
+  const int qi = xcd_chunk(block_id, n_blocks) * PPW + static_cast<int>(threadIdx.x) / QL;
 #endif
   // the lane's source point is requested before the scan table is filled (a load of its own) and the barrier behind it: one
   // memory round trip less on every wave's chain
@@ -1116,9 +1249,11 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     bool go = false;
     if (update) {
       st = MH_UNPROCESSED;
-      a.q_da[3 * qi + 0] = q0;
-      a.q_da[3 * qi + 1] = q1;
-      a.q_da[3 * qi + 2] = q2;
+      if (lead) {
+        a.q_da[3 * qi + 0] = q0;
+        a.q_da[3 * qi + 1] = q1;
+        a.q_da[3 * qi + 2] = q2;
+      }
       // 3. k-NN (:292-302)
       uint32_t bi[K];
       double dk;
@@ -1130,10 +1265,10 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       // quads in flight per lane: the 256-thread class (clouds of up to 65 536 points: at most one wave per SIMD, the scan waits
       // on memory, registers are plentiful) runs a deeper pipeline than the 512-thread class (two waves per SIMD: VALU-bound)
       constexpr int kPipeK3 = TPB <= 256 ? MH_PIPE_SMALL : MH_PIPE;
-      const uint32_t n_cand = knn_query<K, NOFF, kFast, kPipeK3>(a.map, q0, q1, q2, k, s_list, TPB, s_scan, bi, dk, fell_back, n_scanned, a.dbg,
-                                                                        kFast ? &sel : nullptr);
-      cnt_pack = n_cand | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits
-      did_knn = true;
+      const uint32_t n_cand = knn_query<K, NOFF, kFast, kPipeK3, QL>(a.map, q0, q1, q2, k, s_list, PPW, s_scan, bi, dk, fell_back, n_scanned, a.dbg,
+                                                                            kFast ? &sel : nullptr);
+      cnt_pack = (lead ? n_cand : 0u) | (n_scanned << 16);  // each <= 27 x 20 = 540: the 64-lane sums fit 16 bits (several lanes per query: every lane its own share of the scan)
+      did_knn = lead;
       did_fall = fell_back;
       if (!(dk < kDblMax)) {
         st = MH_INSUFFICIENT_CORRES_POINTS;  // found != k
@@ -1203,9 +1338,11 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         }
         const double ikm1 = 1.0 / (kd - 1.0);
         // the mean is cached before the gates (:191)
-        a.mean[3 * qi + 0] = mean[0];
-        a.mean[3 * qi + 1] = mean[1];
-        a.mean[3 * qi + 2] = mean[2];
+        if (lead) {
+          a.mean[3 * qi + 0] = mean[0];
+          a.mean[3 * qi + 1] = mean[1];
+          a.mean[3 * qi + 2] = mean[2];
+        }
         double w[3], v0[3];
         MH_STAMP_C2(a.dbg, 14);
         plane_eigen(c00 * ikm1, c01 * ikm1, c02 * ikm1, c11 * ikm1, c12 * ikm1, c22 * ikm1, w, v0);
@@ -1228,9 +1365,11 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
             nrm[1] = -nrm[1];
             nrm[2] = -nrm[2];
           }
-          a.normal[3 * qi + 0] = nrm[0];
-          a.normal[3 * qi + 1] = nrm[1];
-          a.normal[3 * qi + 2] = nrm[2];
+          if (lead) {
+            a.normal[3 * qi + 0] = nrm[0];
+            a.normal[3 * qi + 1] = nrm[1];
+            a.normal[3 * qi + 2] = nrm[2];
+          }
           bool plane_ok = true;
 #pragma unroll
           for (int j = 0; j < NX; ++j) {
@@ -1245,7 +1384,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
             st = MH_CORRES_PLANE_INVALID;
         }
       }
-      if (a.cold) {
+      if (a.cold && lead) {
         // a fresh factor has zero mean / normal wherever this pass did not write them
         if (st == MH_INSUFFICIENT_CORRES_POINTS || st == MH_CORRES_MAX_DIST)
           a.mean[3 * qi + 0] = a.mean[3 * qi + 1] = a.mean[3 * qi + 2] = 0.0;
@@ -1262,7 +1401,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         nrm[1] = a.normal[3 * qi + 1];
         nrm[2] = a.normal[3 * qi + 2];
         go = true;
-      } else if (a.cold) {
+      } else if (a.cold && lead) {
         // lazily materialise the zero state of a fresh factor for points that never associate
         a.q_da[3 * qi + 0] = a.q_da[3 * qi + 1] = a.q_da[3 * qi + 2] = 0.0;
         a.mean[3 * qi + 0] = a.mean[3 * qi + 1] = a.mean[3 * qi + 2] = 0.0;
@@ -1270,7 +1409,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
       }
     }
 
-    if (go) {
+    if (go && lead) {
       // 5. residual + max-error gate (:319-328)
       double e = nrm[0] * (mean[0] - q0) + (nrm[1] * (mean[1] - q1) + nrm[2] * (mean[2] - q2));
       // s = 1 - 0.9 |e| / sqrt(range) < 0.9 (:322-326)  <=>  9 |e| > sqrt(range)  <=>  (81 e^2)^2 > range^2 = |p|^2: the gate
@@ -1312,9 +1451,9 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
         st = MH_VALID;
       }
     }
-    if (!gone) a.status[qi] = st;
+    if (!gone && lead) a.status[qi] = st;
     if constexpr (!SHARD) {
-      if (a.rec) {
+      if (a.rec && lead) {
         if (st == MH_VALID) loc_directions(a, nrm[0], nrm[1], nrm[2], px, py, pz, rec_jr, rec_jt);
         rec_st = st;
       }
@@ -1393,7 +1532,7 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
     }
     // the call's record (what K4 reads of this point), in the wave's own time
     if constexpr (!SHARD) {
-      if (a.rec && qi < a.n) store_record();
+      if (a.rec && qi < a.n && lead) store_record();
     }
   }
   __syncthreads();
@@ -1459,10 +1598,10 @@ __device__ __forceinline__ void icp_linearize_body(const IcpArgs & a, const int 
   MH_STAMP(a.dbg, 7);
 }
 
-template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD, int QL = 1>
 __global__ __launch_bounds__(TPB) void icp_linearize_kernel(const IcpArgs a)
 {
-  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD, QL>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 
 // A kernel-argument block read from memory into SGPRs: lane i of the wave loads dword i (one or two coalesced
@@ -1515,7 +1654,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_kernel(const IcpArgs 
 
 // The same with the argument blocks inside the kernel-argument segment.  They are read through the segment pointer:
 // indexing the by-value parameter itself with a runtime index makes the compiler copy the whole struct to scratch.
-template <int K, bool BINARY, int NOFF, int TPB, bool SHARD>
+template <int K, bool BINARY, int NOFF, int TPB, bool SHARD, int QL = 1>
 __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const BatchInline<IcpArgs> blk)
 {
   (void)blk;
@@ -1524,7 +1663,7 @@ __global__ __launch_bounds__(TPB) void icp_linearize_batch_inline_kernel(const B
   const int f = batch_factor_of(p->start, p->n, b);
   const int s0 = __builtin_amdgcn_readfirstlane(p->start[f]), s1 = __builtin_amdgcn_readfirstlane(p->start[f + 1]);
   const IcpArgs a = load_uniform(p->a + f);
-  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD>(a, b - s0, s1 - s0);
+  icp_linearize_body<K, BINARY, NOFF, TPB, SHARD, QL>(a, b - s0, s1 - s0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1849,60 +1988,95 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-// Threads per workgroup for an n-point cloud (see icp_linearize_kernel).
-#ifndef MH_TPB_SPLIT
-#define MH_TPB_SPLIT 65536  // clouds up to this many points run 256-thread workgroups, larger ones 512
+// The launch CLASS of a factor = the points one K3 workgroup serves:
+//   512   512 threads, one lane per point     clouds above 65 536 points (one workgroup per CU at 131 072)
+//   256   256 threads, one lane per point     up to 65 536 points, map-sharded factors, the generic k != 5 path
+//   128   256 threads, 2 lanes per point      plain k = 5 factors of up to kQl2Max points
+//    64   256 threads, 4 lanes per point      ... of up to kQl4Max points
+// The down-sampled clouds the reference feeds the factor are 10-25 k points (config/enwide/params.yaml:79-80, geometric.cpp:170-172):
+// at one lane per point they put a wave on 160-400 of the machine's 1024 SIMDs and the kernel is as long as that wave's dependent
+// chain; with several lanes per point the scan — the longest link of the chain — is split across lanes that would have had
+// nothing to do.  Per-point results are identical in every class; the order in which the rows are summed differs with the
+// class (last digits of H, like the 256 / 512 classes before).  A window batch picks its class from the batch's TOTAL: above
+// 65 536 points the machine is full at one lane per point and the lane groups' redundant lookups and plane fits would cost more
+// than the shorter chain returns.
+#ifndef MH_QL2_MAX
+#define MH_QL2_MAX 32768
 #endif
-// (round 5, timing-only variants: 128- and 64-thread workgroups for the small class change nothing — K3 at 24 576 points 21.5 /
-// 21.2 / 21.2 us by rocprofv3 for 256 / 128 / 64 threads: the kernel is one wave's dependent chain wherever its neighbours run)
-static int linearize_tpb(int n) { return n <= MH_TPB_SPLIT ? 256 : kThreads; }
-int linearize_class(int n) { return linearize_tpb(n); }
-int linearize_grid(int n)
+#ifndef MH_QL4_MAX
+#define MH_QL4_MAX 0  // (measured, round 6: 19.6 us at 24 576 points against 16.1 with 2 lanes and 19.0 with 1 — a third and fourth lane add waves that share SIMDs and repeat the lookup and the plane fit; the class stays built for the measurement, off by default)
+#endif
+static int env_or(const char * name, int dflt)
 {
-  const int tpb = linearize_tpb(n);
-  return (((n + tpb - 1) / tpb) + 7) & ~7;
+  const char * e = std::getenv(name);
+  return (e && *e) ? std::atoi(e) : dflt;
 }
-// K4's workgroups take kLocChunks consecutive chunks of a plain factor (the kernel's time does not depend on it — launch +
-// round trips — but the host folds a quarter of the rows), one chunk each of a map-sharded factor (its rows are folded on
-// the device as before).
-static int loc_chunks(bool shard, int tpb) { return shard ? 1 : (tpb > 256 ? MH_LOC_BLOCKS_512 : kLocChunks); }  // in K3 workgroups
-int localizability_grid(int n, bool shard)
+int linearize_class(int n, int k, bool shard, long long total)
 {
-  const int c = loc_chunks(shard, linearize_tpb(n));
-  return (linearize_grid(n) + c - 1) / c;
+  static const int ql2_max = env_or("MH_QL2_MAX", MH_QL2_MAX), ql4_max = env_or("MH_QL4_MAX", MH_QL4_MAX);  // (tuning: tools/k3_time.py)
+  const long long tot = total > 0 ? total : n;
+  if (!shard && k == 5 && tot <= 65536) {
+    if (n <= ql4_max) return 64;
+    if (n <= ql2_max) return 128;
+  }
+  return n <= 65536 ? 256 : kThreads;
+}
+int class_grid(int n, int ppw) { return (((n + ppw - 1) / ppw) + 7) & ~7; }
+int linearize_grid_max(int n) { return class_grid(n, 64); }
+// K4's workgroups take 1024 points of a plain factor whatever K3's class was (the kernel's time does not depend on it — launch +
+// round trips — but the host folds fewer rows), one K3 workgroup's points each of a map-sharded factor (its rows are folded on
+// the device as before).
+static int loc_chunks(bool shard, int ppw) { return shard ? 1 : (kLocChunks * 256) / ppw; }  // in K3 workgroups
+int class_loc_grid(int n, int ppw, bool shard)
+{
+  const int c = loc_chunks(shard, ppw);
+  return (class_grid(n, ppw) + c - 1) / c;
 }
 
-template <int NOFF, int TPB, bool SHARD>
-static void launch_linearize_nt(const IcpArgs & a, bool binary, hipStream_t stream)
+template <int K, bool BINARY, int NOFF, bool SHARD>
+static void launch_linearize_k(const IcpArgs & a, int ppw, hipStream_t stream)
 {
-  const dim3 grid(linearize_grid(a.n)), block(TPB);
-  if (a.k == 5) {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<5, true, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((icp_linearize_kernel<5, false, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
-  } else {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_kernel<8, true, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((icp_linearize_kernel<8, false, NOFF, TPB, SHARD>), grid, block, 0, stream, a);
+  const dim3 grid(class_grid(a.n, ppw));
+  if (ppw == 512) {
+    hipLaunchKernelGGL((icp_linearize_kernel<K, BINARY, NOFF, kThreads, SHARD>), grid, dim3(kThreads), 0, stream, a);
+    return;
   }
+  if constexpr (K == 5 && !SHARD) {
+    if (ppw == 128) {
+      hipLaunchKernelGGL((icp_linearize_kernel<K, BINARY, NOFF, 256, SHARD, 2>), grid, dim3(256), 0, stream, a);
+      return;
+    }
+    if (ppw == 64) {
+      hipLaunchKernelGGL((icp_linearize_kernel<K, BINARY, NOFF, 256, SHARD, 4>), grid, dim3(256), 0, stream, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((icp_linearize_kernel<K, BINARY, NOFF, 256, SHARD>), grid, dim3(256), 0, stream, a);
 }
 template <int NOFF>
 static void launch_linearize_n(const IcpArgs & a, bool binary, hipStream_t stream)
 {
   const bool shard = a.n_dev != nullptr;  // a map-sharded factor's launch (shard_api.hip): the SHARD instantiation
-  if (linearize_tpb(a.n) == 256) {
-    if (shard)
-      launch_linearize_nt<NOFF, 256, true>(a, binary, stream);
+  const int ppw = linearize_class(a.n, a.k, shard);
+#define MH_K3_GO(KK, BIN)                                       \
+  do {                                                          \
+    if (shard)                                                  \
+      launch_linearize_k<KK, BIN, NOFF, true>(a, ppw, stream);  \
+    else                                                        \
+      launch_linearize_k<KK, BIN, NOFF, false>(a, ppw, stream); \
+  } while (0)
+  if (a.k == 5) {
+    if (binary)
+      MH_K3_GO(5, true);
     else
-      launch_linearize_nt<NOFF, 256, false>(a, binary, stream);
+      MH_K3_GO(5, false);
   } else {
-    if (shard)
-      launch_linearize_nt<NOFF, kThreads, true>(a, binary, stream);
+    if (binary)
+      MH_K3_GO(8, true);
     else
-      launch_linearize_nt<NOFF, kThreads, false>(a, binary, stream);
+      MH_K3_GO(8, false);
   }
+#undef MH_K3_GO
 }
 
 hipError_t launch_linearize(const IcpArgs & a, bool binary, hipStream_t stream)
@@ -1920,9 +2094,10 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
 {
   LocArgs a = a0;
   const bool shard = a.n_dev != nullptr;
-  a.chunks_per_block = loc_chunks(shard, linearize_tpb(a.n));
-  const dim3 grid(localizability_grid(a.n, shard));
-  if (linearize_tpb(a.n) == 256) {
+  const int ppw = linearize_class(a.n, a.k, shard);
+  a.chunks_per_block = loc_chunks(shard, ppw);
+  const dim3 grid(class_loc_grid(a.n, ppw, shard));
+  if (ppw <= 256) {
     if (shard)
       hipLaunchKernelGGL((icp_localizability_kernel<256, true>), grid, dim3(256), 0, stream, a);
     else
@@ -1936,11 +2111,7 @@ hipError_t launch_localizability(const LocArgs & a0, hipStream_t stream)
   return hipGetLastError();
 }
 
-// ---- batched launches: all factors share (k == 5 or not, binary, neighbour mode, TPB) ------------------------
-int batch_tpb(int max_n) { return linearize_tpb(max_n); }
-int batch_grid(int n, int tpb) { return (((n + tpb - 1) / tpb) + 7) & ~7; }
-int batch_loc_grid(int n, int tpb, bool shard) { return (batch_grid(n, tpb) + loc_chunks(shard, tpb) - 1) / loc_chunks(shard, tpb); }
-
+// ---- batched launches: all factors share (k == 5 or not, binary, neighbour mode, class) -----------------------
 template <int NOFF, int TPB>
 static void launch_linearize_batch_nt(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int k,
                                       bool binary, hipStream_t stream)
@@ -1959,16 +2130,18 @@ static void launch_linearize_batch_nt(const IcpArgs * d_args, const int * d_star
   }
 }
 
-hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb, int k,
+// (windows of more than kBatchInline factors: the one-lane-per-point classes only — batch_class never hands them another)
+hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, int n_factors, int total_grid, int ppw, int k,
                                   int n_off, bool binary, hipStream_t stream)
 {
 #define MH_BATCH_TPB(NOFF)                                                                                  \
   do {                                                                                                      \
-    if (tpb == 256)                                                                                         \
+    if (ppw == 256)                                                                                         \
       launch_linearize_batch_nt<NOFF, 256>(d_args, d_start, n_factors, total_grid, k, binary, stream);      \
     else                                                                                                    \
       launch_linearize_batch_nt<NOFF, kThreads>(d_args, d_start, n_factors, total_grid, k, binary, stream); \
   } while (0)
+  if (ppw != 256 && ppw != kThreads) return hipErrorInvalidValue;
   if (n_off <= 7)
     MH_BATCH_TPB(7);
   else if (n_off == 19)
@@ -1979,10 +2152,10 @@ hipError_t launch_linearize_batch(const IcpArgs * d_args, const int * d_start, i
   return hipGetLastError();
 }
 
-hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int tpb,
+hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_start, int n_factors, int total_grid, int ppw,
                                        hipStream_t stream)
 {
-  if (tpb == 256)
+  if (ppw <= 256)
     hipLaunchKernelGGL(icp_localizability_batch_kernel<256>, dim3(total_grid), dim3(256), 0, stream, d_args, d_start, n_factors);
   else
     hipLaunchKernelGGL(icp_localizability_batch_kernel<kThreads>, dim3(total_grid), dim3(loc_tpb(kThreads, false)), 0, stream, d_args, d_start,
@@ -1991,54 +2164,66 @@ hipError_t launch_localizability_batch(const LocArgs * d_args, const int * d_sta
 }
 
 // The inline form also serves the map-sharded factors' batch (shard_api.hip): shard = every argument block carries n_dev.
-template <int NOFF, int TPB, bool SHARD>
-static void launch_linearize_batch_inline_nt(const BatchInline<IcpArgs> & blk, int total_grid, int k, bool binary, hipStream_t stream)
+template <int K, bool BINARY, int NOFF, bool SHARD>
+static void launch_linearize_batch_inline_k(const BatchInline<IcpArgs> & blk, int total_grid, int ppw, hipStream_t stream)
 {
-  const dim3 grid(total_grid), block(TPB);
-  if (k == 5) {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, true, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
-    else
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<5, false, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
-  } else {
-    if (binary)
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, true, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
-    else
-      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<8, false, NOFF, TPB, SHARD>), grid, block, 0, stream, blk);
+  const dim3 grid(total_grid);
+  if (ppw == 512) {
+    hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<K, BINARY, NOFF, kThreads, SHARD>), grid, dim3(kThreads), 0, stream, blk);
+    return;
   }
+  if constexpr (K == 5 && !SHARD) {
+    if (ppw == 128) {
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<K, BINARY, NOFF, 256, SHARD, 2>), grid, dim3(256), 0, stream, blk);
+      return;
+    }
+    if (ppw == 64) {
+      hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<K, BINARY, NOFF, 256, SHARD, 4>), grid, dim3(256), 0, stream, blk);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((icp_linearize_batch_inline_kernel<K, BINARY, NOFF, 256, SHARD>), grid, dim3(256), 0, stream, blk);
 }
 
-hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int tpb, int k, int n_off, bool binary,
+hipError_t launch_linearize_batch_inline(const BatchInline<IcpArgs> & blk, int total_grid, int ppw, int k, int n_off, bool binary,
                                          hipStream_t stream, bool shard)
 {
-#define MH_BATCH_TPB(NOFF)                                                                                  \
-  do {                                                                                                      \
-    if (tpb == 256) {                                                                                       \
-      if (shard)                                                                                            \
-        launch_linearize_batch_inline_nt<NOFF, 256, true>(blk, total_grid, k, binary, stream);              \
-      else                                                                                                  \
-        launch_linearize_batch_inline_nt<NOFF, 256, false>(blk, total_grid, k, binary, stream);             \
-    } else {                                                                                                \
-      if (shard)                                                                                            \
-        launch_linearize_batch_inline_nt<NOFF, kThreads, true>(blk, total_grid, k, binary, stream);         \
-      else                                                                                                  \
-        launch_linearize_batch_inline_nt<NOFF, kThreads, false>(blk, total_grid, k, binary, stream);        \
-    }                                                                                                       \
+#define MH_BATCH_GO(KK, BIN, NOFF)                                                             \
+  do {                                                                                         \
+    if (shard)                                                                                 \
+      launch_linearize_batch_inline_k<KK, BIN, NOFF, true>(blk, total_grid, ppw, stream);      \
+    else                                                                                       \
+      launch_linearize_batch_inline_k<KK, BIN, NOFF, false>(blk, total_grid, ppw, stream);     \
+  } while (0)
+#define MH_BATCH_KB(NOFF)          \
+  do {                             \
+    if (k == 5) {                  \
+      if (binary)                  \
+        MH_BATCH_GO(5, true, NOFF);  \
+      else                         \
+        MH_BATCH_GO(5, false, NOFF); \
+    } else {                       \
+      if (binary)                  \
+        MH_BATCH_GO(8, true, NOFF);  \
+      else                         \
+        MH_BATCH_GO(8, false, NOFF); \
+    }                              \
   } while (0)
   if (n_off <= 7)
-    MH_BATCH_TPB(7);
+    MH_BATCH_KB(7);
   else if (n_off == 19)
-    MH_BATCH_TPB(19);
+    MH_BATCH_KB(19);
   else
-    MH_BATCH_TPB(27);
-#undef MH_BATCH_TPB
+    MH_BATCH_KB(27);
+#undef MH_BATCH_KB
+#undef MH_BATCH_GO
   return hipGetLastError();
 }
 
-hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int tpb, hipStream_t stream, bool shard)
+hipError_t launch_localizability_batch_inline(const BatchInline<LocArgs> & blk, int total_grid, int ppw, hipStream_t stream, bool shard)
 {
   const dim3 grid(total_grid);
-  if (tpb == 256) {
+  if (ppw <= 256) {
     if (shard)
       hipLaunchKernelGGL((icp_localizability_batch_inline_kernel<256, true>), grid, dim3(256), 0, stream, blk);
     else

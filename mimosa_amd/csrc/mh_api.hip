@@ -331,7 +331,7 @@ static int icp_alloc(mh_icp * icp)
   MH_HIP(ctx, icp->d_mean.reserve(n * 3 * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, icp->d_normal.reserve(n * 3 * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, icp->d_status.reserve(n * sizeof(int32_t), ctx->stream, false));
-  const size_t max_grid = static_cast<size_t>(mh::linearize_grid(static_cast<int>(n)));
+  const size_t max_grid = static_cast<size_t>(mh::linearize_grid_max(static_cast<int>(n)));
   MH_HIP(ctx, icp->d_partials.reserve(max_grid * mh::kPartialStride * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, icp->d_ticket.reserve(4 * sizeof(unsigned int), ctx->stream, false));  // K3's ticket, K4's ticket, the point count of the two-phase forms
   MH_HIP(ctx, icp->d_result.reserve(sizeof(mh::DeviceResult), ctx->stream, false));
@@ -348,7 +348,8 @@ static int icp_alloc(mh_icp * icp)
   {
     // rows of K4's workgroups: the factor's own launch class, or the class of a window batch it may be linearized in
     const int ni = static_cast<int>(n);
-    const int rows = std::max(mh::localizability_grid(ni), std::max(mh::batch_loc_grid(ni, 256), mh::batch_loc_grid(ni, 512)));
+    int rows = 0;
+    for (int ppw : {64, 128, 256, 512}) rows = std::max(rows, mh::class_loc_grid(ni, ppw));
     icp->ll_words = mh::ll_slot_words((rows + 15) & ~15);
   }
   MH_HIP(ctx, AllocCache::alloc_pinned(reinterpret_cast<void **>(&icp->h_ll), icp->ll_words * sizeof(uint4) * kMaxPending));
@@ -555,7 +556,7 @@ int mh_icp_timeline(mh_icp * icp, unsigned long long * out, size_t capacity_word
 {
   if (!icp || !out || !n_words) return MH_ERR_INVALID_ARG;
   mh_ctx * ctx = icp->ctx;
-  const size_t words = 2 * static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n))) * 8 * 16;  // K3's half, then K4's
+  const size_t words = 2 * static_cast<size_t>(mh::linearize_grid_max(static_cast<int>(icp->n))) * 8 * 16;  // K3's half, then K4's
   *n_words = words;
   if (capacity_words < words) return MH_ERR_INVALID_ARG;
   MH_HIP(ctx, mh_enter(ctx));
@@ -647,7 +648,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
     icp->events_ready = true;
   }
 
-  const size_t row_doubles = static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * mh::kPartialStride;
+  const size_t row_doubles = static_cast<size_t>(mh::linearize_grid_max(static_cast<int>(icp->n ? icp->n : 1))) * mh::kPartialStride;
   MH_HIP(ctx, icp->d_partials.reserve(row_doubles * sizeof(double), ctx->stream, false));
   // the record K3 writes for K4 (mh_internal.hpp): K4 follows on the same stream, one record serves every call
   a.rec = nullptr;
@@ -692,6 +693,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   l.eig = nullptr;
   l.nv = icp->binary ? 13 : 7;
   l.n = a.n;
+  l.k = a.k;
   l.chunks_per_block = 1;
   std::memcpy(l.R, a.R, sizeof(l.R));
   l.normal = a.normal;
@@ -702,7 +704,7 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   l.rec = a.rec;
   l.rec_n = a.rec_n;
 #ifdef MH_TIMELINE
-  l.dbg = a.dbg ? a.dbg + static_cast<size_t>(mh::linearize_grid(static_cast<int>(icp->n ? icp->n : 1))) * 8 * 16 : nullptr;
+  l.dbg = a.dbg ? a.dbg + static_cast<size_t>(mh::linearize_grid_max(static_cast<int>(icp->n ? icp->n : 1))) * 8 * 16 : nullptr;
 #endif
 
   const int slot = icp->n_pending;
@@ -726,13 +728,14 @@ static int linearize_prepare(mh_icp * icp, const double R_src[9], const double t
   a.seq = 0;
   a.tail = 1;
   a.ll = l.ll = nullptr;
-  l.k3_blocks = mh::linearize_grid(a.n);
+  const int ppw = mh::linearize_class(a.n, a.k, false);  // (a call of its own; a window batch and the sharded path set their own)
+  l.k3_blocks = mh::class_grid(a.n, ppw);
   (void)want_flag;  // every call is collected through its flagged words now: no completion flag to ask for
   if (a.n > 0) {
     // plain factors publish flagged words into the call's slot; the two-phase and sharded callers overwrite what they need
     pc.seq = a.seq = l.seq = next_call_seq();
     a.ll = l.ll = icp->d_h_ll + static_cast<size_t>(slot) * icp->ll_words;
-    pc.loc_blocks = mh::localizability_grid(a.n);
+    pc.loc_blocks = mh::class_loc_grid(a.n, ppw);
   }
   icp->n_pending++;
   icp->cold = false;
@@ -983,10 +986,15 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     int first = 0, grid = 0, grid4 = 0;
   };
   std::vector<Group> groups;
+  long long total_points = 0;  // the class of a small cloud depends on how full the machine is: the whole window's points
+  for (size_t f = 0; f < n_factors; ++f) total_points += static_cast<long long>(icps[f]->n);
+  // (more factors than ride in the kernel-argument segment: the staged launch form has the one-lane-per-point classes only)
+  if (n_factors > static_cast<size_t>(mh::kBatchInline)) total_points = std::max<long long>(total_points, 65537);
   for (size_t f = 0; f < n_factors; ++f) {
     const mh_icp * c = icps[f];
     if (c->n == 0) continue;
-    const int tpb = mh::batch_tpb(static_cast<int>(c->n)), k = c->cfg.num_corres_points == 5 ? 5 : 8, n_off = c->map->n_off;
+    const int k = c->cfg.num_corres_points == 5 ? 5 : 8, n_off = c->map->n_off;
+    const int tpb = mh::linearize_class(static_cast<int>(c->n), static_cast<int>(c->cfg.num_corres_points), false, total_points);
     Group * g = nullptr;
     for (Group & q : groups)
       if (q.tpb == tpb && q.k == k && q.n_off == n_off && q.binary == c->binary) g = &q;
@@ -1042,11 +1050,11 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
       const int slot = g.first + static_cast<int>(i);
       start[i] = acc;
       start4[i] = acc4;
-      acc += mh::batch_grid(h_a[slot].n, g.tpb);
-      acc4 += mh::batch_loc_grid(h_a[slot].n, g.tpb);
-      h_l[slot].k3_blocks = mh::batch_grid(h_a[slot].n, g.tpb);
+      acc += mh::class_grid(h_a[slot].n, g.tpb);
+      acc4 += mh::class_loc_grid(h_a[slot].n, g.tpb);
+      h_l[slot].k3_blocks = mh::class_grid(h_a[slot].n, g.tpb);
       h_l[slot].chunks_per_block = mh::kLocChunks;
-      icps[g.members[i]]->pending[0].loc_blocks = mh::batch_loc_grid(h_a[slot].n, g.tpb);
+      icps[g.members[i]]->pending[0].loc_blocks = mh::class_loc_grid(h_a[slot].n, g.tpb);
     }
     start[g.members.size()] = acc;
     start4[g.members.size()] = acc4;

@@ -726,7 +726,7 @@ static int shard_icp_create_impl(mh_ctx * ctx, mh_shard_comm * comm, mh_map * ma
   MH_HIP(ctx, S->d_dest.reserve(slots_rounded, ctx->stream, false));
   MH_HIP(ctx, S->d_hist.reserve((slots_rounded / 256 + 1) * comm->world * sizeof(uint32_t), ctx->stream, false));
   // partial rows for the largest grid a call can use
-  MH_HIP(ctx, icp->d_partials.reserve(static_cast<size_t>(mh::linearize_grid(static_cast<int>(S->slot_capacity))) * mh::kPartialStride * sizeof(double), ctx->stream, false));
+  MH_HIP(ctx, icp->d_partials.reserve(static_cast<size_t>(mh::linearize_grid_max(static_cast<int>(S->slot_capacity))) * mh::kPartialStride * sizeof(double), ctx->stream, false));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   S->n_slots = S->n_live = S->slots_bound = static_cast<uint32_t>(n_local);
   *out = S;
@@ -1156,7 +1156,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
   if (B > 1) {
     for (size_t f = 0; f < B; ++f) {
       const mh_icp * icp = spec[f].S->icp;
-      const int tpb = mh::batch_tpb(ia[f].n), k = icp->cfg.num_corres_points == 5 ? 5 : 8, n_off = icp->map->n_off;
+      const int tpb = mh::linearize_class(ia[f].n, ia[f].k, true), k = icp->cfg.num_corres_points == 5 ? 5 : 8, n_off = icp->map->n_off;
       Group * g = nullptr;
       for (Group & q : groups)
         if (q.tpb == tpb && q.k == k && q.n_off == n_off && q.binary == icp->binary && static_cast<int>(q.members.size()) < mh::kBatchInline) g = &q;
@@ -1178,7 +1178,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
       for (size_t i = 0; i < g.members.size(); ++i) {
         blk.a[i] = ia[g.members[i]];
         blk.start[i] = acc;
-        acc += mh::batch_grid(ia[g.members[i]].n, g.tpb);
+        acc += mh::class_grid(ia[g.members[i]].n, g.tpb);
       }
       blk.start[g.members.size()] = acc;
       blk.n = static_cast<int>(g.members.size());
@@ -1200,7 +1200,7 @@ int enqueue_round(const RoundSpec * spec, size_t B)
         for (size_t i = 0; i < g.members.size(); ++i) {
           blk.a[i] = la[g.members[i]];
           blk.start[i] = acc;
-          acc += mh::batch_grid(ia[g.members[i]].n, g.tpb);
+          acc += mh::class_grid(ia[g.members[i]].n, g.tpb);
         }
         blk.start[g.members.size()] = acc;
         blk.n = static_cast<int>(g.members.size());

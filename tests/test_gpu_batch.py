@@ -36,6 +36,20 @@ def _same(a, b):
         assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
 
 
+def _same_up_to_summation_order(a, b):
+    """A window batch picks K3's launch class from the batch's TOTAL (several lanes per point only while the machine is not full),
+    a call of its own from the factor's size: when the two differ the per-point results are identical but the rows are summed
+    in another order — last digits of the sums."""
+    from parity import eigvec_equal_mod_sign, rel
+    for k in ("status_hist", "n_knn", "mean_candidates", "linearize_count"):
+        assert np.array_equal(np.asarray(a[k], float), np.asarray(b[k], float), equal_nan=True), k
+    for k in ("H_ss", "b_s", "loc_trans_final", "loc_rot_final", "loc_trans_comp", "loc_rot_comp"):
+        assert rel(a[k], b[k]) <= 1e-12, k
+    assert abs(a["f"] - b["f"]) <= 1e-12 * abs(b["f"])
+    for k in ("eigvec_rot", "eigvec_trans"):
+        assert eigvec_equal_mod_sign(a[k], b[k], tol=1e-9), k
+
+
 def test_batch_equals_separate_calls_and_oracle(ctx, room_world):
     from mimosa_amd import capi
 
@@ -111,7 +125,8 @@ def test_batch_mixed_block_size(ctx, room_world):
     Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
     got = capi.linearize_batch(fa, Rs, ts)
     for i in range(2):
-        _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+        # (78 536 points in the window: the 9 000-point member runs one lane per point here and two on its own)
+        (_same if i == 0 else _same_up_to_summation_order)(got[i], fb[i].linearize(Rs[i], ts[i]))
         assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
     for f in fa + fb:
         f.destroy()
@@ -128,7 +143,11 @@ def test_batch_larger_than_the_inline_window(ctx, small_world):
     Rs, ts = [p[0] for p in poses], [p[1] for p in poses]
     got = capi.linearize_batch(fa, Rs, ts)
     for i in range(n):
-        _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+        # (the staged launch form runs one lane per point; a 431-point factor on its own runs several: the same points, the
+        # same per-point results — the state below — summed in another order)
+        _same_up_to_summation_order(got[i], fb[i].linearize(Rs[i], ts[i]))
+        for x, y in zip(fa[i].state(), fb[i].state()):
+            assert np.array_equal(x, y, equal_nan=True)
     got8 = capi.linearize_batch(fa[:8], Rs[:8], ts[:8])          # exactly the inline capacity, re-linearization
     for i in range(8):
         _same(got8[i], fb[i].linearize(Rs[i], ts[i]))
