@@ -37,9 +37,10 @@ def c_sync_ns(ctx, factor_h, R, t, g, out, n, reset=True):
     return ns
 
 
-def c_sync_steps(ctx, factor_h, R, t, g, outs):
-    """len(outs) cold synchronous mh_icp_linearize calls made FROM C back to back (tools/micro/sync_caller.c:
-    mh_sync_caller_steps: reset + linearize per step, result i in outs[i]); `outs` = a ctypes array of capi.IcpResult."""
+def make_sync_stepper(ctx, factor_h, R, t, g):
+    """A closure run(outs): len(outs) cold synchronous mh_icp_linearize calls made FROM C back to back (tools/micro/sync_caller.c:
+    mh_sync_caller_steps: reset + linearize per step, result i in outs[i]); `outs` = a ctypes array of capi.IcpResult.
+    Everything that is not the calls — loading the harness, marshalling the arguments — happens here, once."""
     import ctypes as C
 
     import numpy as np
@@ -48,10 +49,14 @@ def c_sync_steps(ctx, factor_h, R, t, g, outs):
     H = C.CDLL(hb.build_sync_caller())
     vp = C.c_void_p
     H.mh_sync_caller_steps.argtypes = [vp] * 7 + [C.c_size_t, C.c_int]
-    fn = lambda f: C.cast(f, vp)
     L = ctx.L
+    lin, rst = C.cast(L.mh_icp_linearize, vp), C.cast(L.mh_icp_reset, vp)
     Rm, tv, gv = (np.ascontiguousarray(x, np.float64) for x in (R, t, g))
-    n = len(outs)
-    rc = H.mh_sync_caller_steps(fn(L.mh_icp_linearize), fn(L.mh_icp_reset), factor_h, Rm.ctypes.data_as(vp), tv.ctypes.data_as(vp),
-                                gv.ctypes.data_as(vp), C.cast(outs, vp), C.sizeof(outs) // max(n, 1), n)
-    assert rc == 0, rc
+    pR, pt, pg = Rm.ctypes.data_as(vp), tv.ctypes.data_as(vp), gv.ctypes.data_as(vp)
+    fn = H.mh_sync_caller_steps
+
+    def run(outs, _keep=(Rm, tv, gv)):
+        n = len(outs)
+        rc = fn(lin, rst, factor_h, pR, pt, pg, C.cast(outs, vp), C.sizeof(outs) // max(n, 1), n)
+        assert rc == 0, rc
+    return run

@@ -29,8 +29,9 @@ for name, cloud in (("131k", pts), ("24k", np.ascontiguousarray(pts[::5][:24576]
         f.reset()
         ctx.synchronize()
         a = time.perf_counter()
-        f.linearize(R, t)
+        r = f.linearize(R, t)
         ts.append(time.perf_counter() - a)
-    out[name] = {"calls": N, "sync_us_python_binding_p50": round(float(np.median(ts[10:])) * 1e6, 1)}
+    out[name] = {"calls": N, "sync_us_python_binding_p50": round(float(np.median(ts[10:])) * 1e6, 1), "mean_scanned": round(float(r["mean_scanned"]), 2),
+                 "exact_fallback": int(r["n_exact_fallback"])}
     f.destroy()
 print(json.dumps(out))
