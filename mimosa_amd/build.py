@@ -153,7 +153,7 @@ def build_replay_native(force: bool = False) -> str:
     exe = os.path.join(LIBDIR, "replay_native")
     host = os.path.join(HERE, "host")
     src = os.path.join(host, "replay_main.cpp")
-    deps = [src, lib] + [os.path.join(host, "mimosa_hip", h) for h in ("replay.hpp", "manager.hpp", "binio.hpp", "photometric.hpp", "lidar.hpp", "types.hpp")]
+    deps = [src, lib] + [os.path.join(host, "mimosa_hip", h) for h in ("replay.hpp", "sharded_replay.hpp", "sharded.hpp", "manager.hpp", "binio.hpp", "photometric.hpp", "lidar.hpp", "types.hpp")]
     deps += [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(host, "gtsam_sig")) for f in fs]
     with _BuildLock():
         if force or _stale(exe, deps):

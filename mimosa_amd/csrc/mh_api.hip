@@ -189,6 +189,8 @@ struct WaitTrace
   bool on = std::getenv("MH_WAIT_TRACE") != nullptr;
   double enq = 0, k3launch = 0, first = 0, fold = 0, fin = 0;
   long n = 0;
+  double b_prep = 0, b_launch = 0, b_wait = 0;  // window batches: argument blocks, the launches, collecting every factor
+  long b_n = 0;
   static double now()
   {
     timespec t;
@@ -244,6 +246,9 @@ void mh_shutdown(mh_ctx * ctx)
     std::fprintf(stderr, "MH_WAIT_TRACE: %ld calls; per call: enqueue %.2f us (of which the K3 launch call %.2f), wait for the first word %.2f, "
                          "fold of the slot %.2f, epilogue %.2f\n", g_wt.n, g_wt.enq / n * 1e-3, g_wt.k3launch / n * 1e-3, g_wt.first / n * 1e-3,
                  (g_wt.fold - g_wt.first) / n * 1e-3, g_wt.fin / n * 1e-3);
+    if (g_wt.b_n)
+      std::fprintf(stderr, "MH_WAIT_TRACE: %ld window batches; per batch: argument blocks %.2f us, launches %.2f, collecting the factors %.2f\n", g_wt.b_n,
+                   g_wt.b_prep / g_wt.b_n * 1e-3, g_wt.b_launch / g_wt.b_n * 1e-3, g_wt.b_wait / g_wt.b_n * 1e-3);
     g_wt = WaitTrace{};
   }
   (void)mh_enter(ctx);
@@ -974,6 +979,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
       if (icps[g] == c) return fail(ctx, MH_ERR_INVALID_ARG, "mh_icp_linearize_batch: the same factor twice");
   }
   MH_HIP(ctx, mh_enter(ctx));
+  const double tb0 = g_wt.on ? WaitTrace::now() : 0.0;
   // Launch groups: the factors that share a kernel instantiation — workgroup size (256 threads up to 65 536 points, 512
   // above: so every factor reduces in exactly the order of a separate call), k == 5 or the generic k <= 8 path, neighbour
   // mode, unary / binary.  One K3b (+ one K4b) launch per non-empty group; a window of like factors — the usual case — is
@@ -1062,6 +1068,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
     g.grid4 = acc4;
     inline_args = inline_args && static_cast<int>(g.members.size()) <= mh::kBatchInline;
   }
+  const double tb1 = g_wt.on ? WaitTrace::now() : 0.0;
   if (!groups.empty()) {
     if (inline_args) {
       // small window: the argument blocks ride in the kernel-argument segment, nothing is copied before the launches
@@ -1109,10 +1116,18 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
         if (icps[f]->components) icps[f]->pending[0].seq_has_basis = true;  // ... and K4b published the bases it used
       }
   for (LinearizeTxn & t : txns) t.commit();
+  const double tb2 = g_wt.on ? WaitTrace::now() : 0.0;
   int rc_all = MH_OK;
   for (size_t f = 0; f < n_factors; ++f) {
     const int rc = mh_icp_wait(icps[f]);
     if (rc != MH_OK) rc_all = rc;
+  }
+  static long b_seen = 0;
+  if (g_wt.on && ++b_seen > 10) {  // (the first launches of a kernel instantiation load its code object: not the steady state)
+    g_wt.b_prep += tb1 - tb0;
+    g_wt.b_launch += tb2 - tb1;
+    g_wt.b_wait += WaitTrace::now() - tb2;
+    g_wt.b_n++;
   }
   return rc_all;
 }

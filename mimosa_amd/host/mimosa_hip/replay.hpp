@@ -300,18 +300,21 @@ private:
 // additional_update_iterations do, src/graph/manager.cpp:585-588), the photometric factor on the newest pose, between
 // factors from the IMU propagation, a prior on the oldest pose.  Shared by FixedLagReplay and by the graph-manager stand-in
 // that lidar::Manager is driven with (ManagerReplay below).
-class WindowSmoother
+// FactorT: lidar::ICPFactor, or lidar::ShardedICPFactor (sharded.hpp) — the same surface: a static linearizeBatch over the
+// window's factors returning one HessianFactor each, identical on every rank in the sharded case.
+template <class FactorT>
+class WindowSmootherT
 {
 public:
   struct Live
   {
     size_t k;
     RT T;
-    ICPFactor::Ptr f;
+    typename FactorT::Ptr f;
     bool has_Z;
     RT Z;
   };
-  WindowSmoother(int window, int update_iters, double between_sigma_rot, double between_sigma_trans)
+  WindowSmootherT(int window, int update_iters, double between_sigma_rot, double between_sigma_trans)
   : window_(window), update_iters_(update_iters)
   {
     const double wr = 1.0 / (between_sigma_rot * between_sigma_rot), wt = 1.0 / (between_sigma_trans * between_sigma_trans);
@@ -342,7 +345,7 @@ public:
       const size_t nW = win.size(), dim = 6 * nW;
       std::vector<double> fs;
       for (int it = 0; it < cfg_.update_iters; ++it) {
-        std::vector<ICPFactor::Ptr> factors(nW);
+        std::vector<typename FactorT::Ptr> factors(nW);
         Values v;
         v.insert(G(0), Unit3(0.0, 0.0, -1.0));  // the gravity direction ICPFactor::linearize reads (geometric_factor.hpp:257)
         for (size_t i = 0; i < nW; ++i) {
@@ -350,7 +353,7 @@ public:
           v.insert(X(win[i].k), toPose3(win[i].T));
         }
         if (pf) pf->linearizeAsync(v);  // queued ahead of the window: one wait for both
-        const auto lin = ICPFactor::linearizeBatch(factors, v);
+        const auto lin = FactorT::linearizeBatch(factors, v);
         std::vector<double> A(dim * dim, 0.0), g(dim, 0.0);
         double cost = 0.0;
         for (size_t i = 0; i < nW; ++i) {
@@ -435,15 +438,41 @@ private:
   bool pushed_ = false;
 };
 
-class FixedLagReplay
+using WindowSmoother = WindowSmootherT<ICPFactor>;
+
+// The geometric side of the replay loop — what Geometric owns in the reference (src/lidar/geometric.cpp): the map, the factor
+// of a scan (getFactors, :185-226) and the keyframe's copy-then-insert (updateMap, :483-495).  PlainGeometric: one GPU holds
+// the map.  ShardedGeometric (sharded_replay.hpp): the map sharded over the ranks of a communicator.
+class PlainGeometric
 {
 public:
-  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000) : ctx_(ctx), cfg_(cfg), scan_(ctx), scan_b_(ctx)
+  using Factor = ICPFactor;
+  PlainGeometric(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon)
   {
-    map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx_, cfg_.reg.target_ivox_map_leaf_size);
+    map_ = std::make_shared<IncrementalVoxelMapPCL>(ctx, cfg.reg.target_ivox_map_leaf_size);
     map_->set_lru_horizon(lru_horizon);
-    map_->set_neighbor_voxel_mode(cfg_.neighbor_voxel_mode);
-    map_->set_min_dist_in_cell(cfg_.reg.target_ivox_map_min_dist_in_voxel);
+    map_->set_neighbor_voxel_mode(cfg.neighbor_voxel_mode);
+    map_->set_min_dist_in_cell(cfg.reg.target_ivox_map_min_dist_in_voxel);
+  }
+  void seed(const float * xyz, size_t n) { map_->insert(xyz, n); }
+  Factor::Ptr makeFactor(const Key Xk, ScanFrontEnd & scan, const lidar::RegistrationConfig & reg) { return std::make_shared<ICPFactor>(Xk, map_, scan, reg); }
+  void keyframe(ScanFrontEnd & scan, const Pose3 & T_W_Be)
+  {
+    map_ = map_->fork();  // copy-then-insert (geometric.cpp:494-495): live factors keep the map they were built on
+    map_->insertBodyCloud(scan.underlying(), T_W_Be);
+  }
+
+private:
+  IncrementalVoxelMapPCL::Ptr map_;
+};
+
+template <class Geo>
+class FixedLagReplayT
+{
+public:
+  // geo: the geometric back end (its map lives on ctx)
+  FixedLagReplayT(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, std::unique_ptr<Geo> geo) : ctx_(ctx), cfg_(cfg), scan_(ctx), scan_b_(ctx), geo_(std::move(geo))
+  {
     if (cfg_.photometric) {
       // its own context = its own HIP stream: the patch factor (60 waves, a 27 us latency chain) and the window's ICP batch
       // (a few hundred waves) are independent work of one smoother iteration and run side by side instead of one behind
@@ -454,7 +483,7 @@ public:
       scan_b_.keepRaw(true);
     }
   }
-  void seedMap(const float * xyz, size_t n) { map_->insert(xyz, n); }
+  void seedMap(const float * xyz, size_t n) { geo_->seed(xyz, n); }
 
   // state0: the state at the first IMU sample of the first sweep (the caller's first guess)
   Result run(const std::vector<ScanInput> & scans, const State & state0)
@@ -462,8 +491,9 @@ public:
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     Result res;
-    using Live = WindowSmoother::Live;
-    WindowSmoother smoother(cfg_.window, cfg_.update_iters, cfg_.between_sigma_rot, cfg_.between_sigma_trans);
+    using Smoother = WindowSmootherT<typename Geo::Factor>;
+    using Live = typename Smoother::Live;
+    Smoother smoother(cfg_.window, cfg_.update_iters, cfg_.between_sigma_rot, cfg_.between_sigma_trans);
     std::deque<Live> & win = smoother.win;
     std::vector<RT> kf_poses;
     State prev = state0;
@@ -546,7 +576,7 @@ public:
       Live lv;
       lv.k = k;
       lv.T = pred.T;
-      lv.f = std::make_shared<ICPFactor>(Xk, map_, scan_, cfg_.reg);
+      lv.f = geo_->makeFactor(Xk, scan_, cfg_.reg);
       lv.f->computeComponents(false);  // the loop below only takes H, b, f
       const auto b1 = clk::now();
       res.detail[4] += secs(a3, b1);
@@ -593,8 +623,7 @@ public:
         is_kf = best > cfg_.keyframe_trans_thresh || ypr > cfg_.keyframe_rot_thresh_deg * 0.017453293;
       }
       if (is_kf) {
-        map_ = map_->fork();  // copy-then-insert (geometric.cpp:494-495): live factors keep the map they were built on
-        map_->insertBodyCloud(scan_.underlying(), toPose3(T));
+        geo_->keyframe(scan_, toPose3(T));
         kf_poses.push_back(T);
         ++res.n_keyframes;
       }
@@ -648,9 +677,18 @@ private:
   std::shared_ptr<lidar::Context> ctx_;
   Config cfg_;
   ScanFrontEnd scan_, scan_b_;  // double-buffered: scan k + 1 is staged into the one scan k is not using
-  IncrementalVoxelMapPCL::Ptr map_;
+  std::unique_ptr<Geo> geo_;
   std::shared_ptr<lidar::Context> photo_ctx_;  // declared before photo_: destroyed after it
   std::unique_ptr<Photometric> photo_;
+};
+
+class FixedLagReplay : public FixedLagReplayT<PlainGeometric>
+{
+public:
+  FixedLagReplay(const std::shared_ptr<lidar::Context> & ctx, const Config & cfg, size_t lru_horizon = 1000)
+  : FixedLagReplayT<PlainGeometric>(ctx, cfg, std::unique_ptr<PlainGeometric>(new PlainGeometric(ctx, cfg, lru_horizon)))
+  {
+  }
 };
 
 // ---- the same sequence through lidar::Manager::callback (manager.hpp) -------------------------------------------------

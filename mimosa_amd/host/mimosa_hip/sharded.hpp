@@ -210,11 +210,20 @@ public:
       comm_->context()->check(mh_map_insert_shard(map_->underlying(), &cloud[0].x, cloud.size(), sizeof(Point) / sizeof(float), comm_->world(), comm_->rank(), block_log2_),
                               "mh_map_insert_shard");
   }
+  // Successor for copy-then-insert (Geometric::updateMap, geometric.cpp:494-495): a device-to-device copy of THIS rank's shard;
+  // this object stays valid and unchanged for the factors that hold it.  Every rank forks at the same keyframes.
+  Ptr fork() const
+  {
+    Ptr next(new ShardedVoxelMap(comm_, block_log2_));
+    next->map_ = map_->fork();
+    return next;
+  }
   const IncrementalVoxelMapPCL::Ptr & map() const { return map_; }
   const ShardCommunicator::Ptr & communicator() const { return comm_; }
   int blockLog2() const { return block_log2_; }
 
 private:
+  ShardedVoxelMap(const ShardCommunicator::Ptr & comm, int block_log2) : comm_(comm), block_log2_(block_log2) {}
   ShardCommunicator::Ptr comm_;
   int block_log2_;
   IncrementalVoxelMapPCL::Ptr map_;

@@ -1,11 +1,17 @@
 // Native sequence replay: drives mimosa_hip::replay::FixedLagReplay (host/mimosa_hip/replay.hpp) on an input file written
 // by mimosa_amd/replay.py:write_native_input and prints one JSON object (estimated poses, per-stage seconds, scans/s).
-//   replay_native <input.bin> [repeats]      (repeats > 1: the whole sequence again, timing of the last pass is reported)
+//   replay_native <input.bin> [repeats] [manager | sequential | sharded <world> | sharded-rccl]
+//     repeats > 1: the whole sequence again, timing of the last pass is reported
+//     sharded <world>: the map sharded over <world> ranks INSIDE this process (one host thread and one context each, in-process
+//       transport: what a one-GPU box can run); sharded-rccl: this process is one rank of a torch.distributed.run-style launch
+//       (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT), RCCL over xGMI.  The JSON carries rank 0's trajectory and
+//       `max_rank_deviation_m`, the largest difference between any rank's positions and rank 0's (in-process form).
 #include <cstdio>
 #include <cstring>
 
 #include "mimosa_hip/binio.hpp"
 #include "mimosa_hip/replay.hpp"
+#include "mimosa_hip/sharded_replay.hpp"
 
 using namespace mimosa_hip;
 using binio::read_vec;
@@ -19,6 +25,9 @@ int main(int argc, char ** argv)
   const int repeats = argc > 2 ? std::atoi(argv[2]) : 1;
   const bool through_manager = argc > 3 && std::string(argv[3]) == "manager";  // the same sequence through lidar::Manager::callback
   const bool sequential = argc > 3 && std::string(argv[3]) == "sequential";   // FixedLagReplay without the cross-scan overlap
+  const bool sharded_local = argc > 4 && std::string(argv[3]) == "sharded";
+  const bool sharded_rccl = argc > 3 && std::string(argv[3]) == "sharded-rccl";
+  const int world = sharded_local ? std::atoi(argv[4]) : 1;
   try {
     std::ifstream f(argv[1], std::ios::binary);
     if (!f) throw std::runtime_error("cannot open the input file");
@@ -63,10 +72,49 @@ int main(int argc, char ** argv)
     for (int i = 0; i < 9; ++i) st0.T.R[i] = s0[i];
     for (int i = 0; i < 3; ++i) st0.T.t[i] = s0[9 + i];
     st0.vel = {s0[12], s0[13], s0[14]};
-    auto ctx = std::make_shared<lidar::Context>(0);
+    const char * lr = std::getenv("LOCAL_RANK");
+    auto ctx = std::make_shared<lidar::Context>(sharded_rccl && lr ? std::atoi(lr) : 0);
     replay::Result r;
+    double max_dev = 0.0;
+    int n_ranks = 1;
     for (int rep = 0; rep < repeats; ++rep) {
-      if (through_manager) {
+      if (sharded_local) {
+        // `world` ranks = host threads of this process, one context each on the one device
+        if (world < 1 || world > 64) throw std::runtime_error("sharded: world in 1..64");
+        n_ranks = world;
+        std::vector<std::shared_ptr<lidar::Context>> ctxs{ctx};
+        for (int q = 1; q < world; ++q) ctxs.push_back(std::make_shared<lidar::Context>(0));
+        const auto comms = lidar::ShardCommunicator::local(ctxs);
+        std::vector<replay::Result> rr(static_cast<size_t>(world));
+        std::vector<std::string> err(static_cast<size_t>(world));
+        std::vector<std::thread> th;
+        for (int q = 0; q < world; ++q)
+          th.emplace_back([&, q] {
+            try {
+              replay::ShardedFixedLagReplay run(comms[static_cast<size_t>(q)], cfg, static_cast<size_t>(I[4]), 3, world == 1);
+              run.seedMap(seed.data(), seed.size() / 3);
+              rr[static_cast<size_t>(q)] = run.run(scans, st0);
+            } catch (const std::exception & e) {
+              err[static_cast<size_t>(q)] = e.what();
+            }
+          });
+        for (auto & t : th) t.join();
+        for (int q = 0; q < world; ++q)
+          if (!err[static_cast<size_t>(q)].empty()) throw std::runtime_error("rank " + std::to_string(q) + ": " + err[static_cast<size_t>(q)]);
+        r = rr[0];
+        max_dev = 0.0;
+        for (int q = 1; q < world; ++q) {
+          r.seconds = std::max(r.seconds, rr[static_cast<size_t>(q)].seconds);
+          for (size_t k = 0; k < r.poses.size(); ++k)
+            for (int i = 0; i < 3; ++i) max_dev = std::max(max_dev, std::fabs(rr[static_cast<size_t>(q)].poses[k].t[i] - r.poses[k].t[i]));
+        }
+      } else if (sharded_rccl) {
+        const auto comm = lidar::ShardCommunicator::rcclFromEnv(ctx);
+        n_ranks = comm->world();
+        replay::ShardedFixedLagReplay run(comm, cfg, static_cast<size_t>(I[4]), 3, comm->world() == 1);
+        run.seedMap(seed.data(), seed.size() / 3);
+        r = run.run(scans, st0);
+      } else if (through_manager) {
         replay::ManagerReplay run(ctx, cfg, static_cast<size_t>(I[4]));
         r = run.run(scans, st0, seed.data(), seed.size() / 3);
       } else {
@@ -75,8 +123,8 @@ int main(int argc, char ** argv)
         r = run.run(scans, st0);
       }
     }
-    std::printf("{\"scans\": %zu, \"seconds\": %.9f, \"scans_per_s\": %.3f, \"n_keyframes\": %d,\n", scans.size(), r.seconds,
-                static_cast<double>(scans.size()) / r.seconds, r.n_keyframes);
+    std::printf("{\"scans\": %zu, \"seconds\": %.9f, \"scans_per_s\": %.3f, \"n_keyframes\": %d, \"n_ranks\": %d, \"max_rank_deviation_m\": %.3e,\n", scans.size(),
+                r.seconds, static_cast<double>(scans.size()) / r.seconds, r.n_keyframes, n_ranks, max_dev);
     std::printf("\"stage_s\": {\"front_end\": %.9f, \"imu\": %.9f, \"factor_create\": %.9f, \"optimise\": %.9f, \"update_map\": %.9f},\n",
                 r.stage[0], r.stage[1], r.stage[2], r.stage[3], r.stage[4]);
     {

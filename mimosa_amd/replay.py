@@ -296,11 +296,15 @@ def write_native_input(path, cfg: ReplayConfig, scans, rng_seed=7, mode=synth.EN
             w([sc["header_ts"]], np.float64)
 
 
-def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible_device=None, through_manager=False, sequential=False):
+def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible_device=None, through_manager=False, sequential=False,
+               sharded_world=0, sharded_rccl=False, timeout=900):
     """The same replay through the C++ host mirror (host/mimosa_hip/replay.hpp): no Python between the library calls.
     visible_device: run the driver with HIP_VISIBLE_DEVICES set to it (one replay per GPU of a node).
     through_manager: every scan goes through lidar::Manager::callback (host/mimosa_hip/manager.hpp: the reference's method
-    names and call order, the first cloud initialises instead of being registered) instead of FixedLagReplay's own loop."""
+    names and call order, the first cloud initialises instead of being registered) instead of FixedLagReplay's own loop.
+    sharded_world = W > 0: the map sharded over W ranks inside the driver process (host/mimosa_hip/sharded_replay.hpp, one host
+    thread per rank, in-process transport); sharded_rccl: the driver is one rank of the launch this process belongs to (RANK /
+    WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment), RCCL inside the library."""
     import json
     import os
     import subprocess
@@ -312,7 +316,12 @@ def run_native(cfg: ReplayConfig, scans, workdir, repeats=1, rng_seed=7, visible
     env = dict(os.environ)
     if visible_device is not None:
         env["HIP_VISIBLE_DEVICES"] = str(visible_device)
-    out = subprocess.run([exe, path, str(repeats)] + (["manager"] if through_manager else (["sequential"] if sequential else [])), capture_output=True, text=True, timeout=900, env=env)
+    mode = ["manager"] if through_manager else (["sequential"] if sequential else [])
+    if sharded_world:
+        mode = ["sharded", str(sharded_world)]
+    if sharded_rccl:
+        mode = ["sharded-rccl"]
+    out = subprocess.run([exe, path, str(repeats)] + mode, capture_output=True, text=True, timeout=timeout, env=env)
     os.remove(path)
     if out.returncode != 0:
         raise RuntimeError("replay_native failed: " + out.stderr[-2000:])

@@ -118,6 +118,38 @@ def test_pipelined_native_replay_is_the_sequential_one_bit_for_bit(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_replay_equals_the_unsharded_one(tmp_path, world):
+    """BASELINE configs[4] with the map SHARDED (host/mimosa_hip/sharded_replay.hpp): a 20-scan sequence, every rank (a host
+    thread with its own context, in-process transport) runs the replay loop on its shard of the map — mh_map_insert_shard of the
+    seed and of every keyframe's cloud, a ShardedICPFactor per scan, every smoother iteration ONE protocol round over the live
+    window (mh_shard_icp_linearize_batch).  Every rank's trajectory is rank 0's, and rank 0's is the unsharded replay's up to
+    the order in which the shards' rows are summed."""
+    import dataclasses
+    cfg = dataclasses.replace(small_cfg(20), photometric=False)
+    scans = replay.make_scans(cfg)
+    plain = replay.run_native(cfg, scans, str(tmp_path))
+    shard = replay.run_native(cfg, scans, str(tmp_path), sharded_world=world)
+    assert shard["n_ranks"] == world and shard["max_rank_deviation_m"] <= 1e-9
+    assert shard["n_keyframes"] == plain["n_keyframes"] >= 3
+    for (Ra, ta), (Rb, tb) in zip(shard["poses_est"], plain["poses_est"]):
+        assert np.max(np.abs(ta - tb)) <= 1e-9 and np.max(np.abs(Ra - Rb)) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_sharded_replay_with_the_photometric_path_replicated(tmp_path):
+    """The same with the photometric factor on: every rank builds its own frame and features (the scan is replicated, only the
+    map is sharded); 2 ranks, 6 scans."""
+    cfg = small_cfg(6)
+    scans = replay.make_scans(cfg)
+    plain = replay.run_native(cfg, scans, str(tmp_path))
+    shard = replay.run_native(cfg, scans, str(tmp_path), sharded_world=2)
+    assert shard["max_rank_deviation_m"] <= 1e-9 and shard["photo_valid"] == plain["photo_valid"]
+    for (Ra, ta), (Rb, tb) in zip(shard["poses_est"], plain["poses_est"]):
+        assert np.max(np.abs(ta - tb)) <= 1e-8 and np.max(np.abs(Ra - Rb)) <= 1e-8
+
+
+@pytest.mark.gpu
 def test_native_replay_through_the_manager_mirror(ctx, tmp_path):
     """The sequence through lidar::Manager::callback (host/mimosa_hip/manager.hpp: callback -> prepareInput -> declare ->
     deskewPoints -> preprocess -> getFactors -> define -> postDefineUpdate, the reference's call order, with stand-ins behind the

@@ -68,6 +68,17 @@ def run(E):
             rp_stats["native"]["through_lidar_manager"] = {"scans_per_s": round(rm_["scans_per_s"], 1),
                                                            "note": "the same sequence through lidar::Manager::callback (host/mimosa_hip/manager.hpp): the reference's call order "
                                                                    "incl. Geometric::getFactors' own first linearize with the component pass; the first cloud initialises"}
+            # the map SHARDED over 2 ranks inside one process (host/mimosa_hip/sharded_replay.hpp; in-process transport: what a one-GPU box
+            # can run — the rate says what the protocol costs on one device, not what 2 GPUs give)
+            import dataclasses
+            gcfg = dataclasses.replace(rcfg, photometric=False)
+            with tempfile.TemporaryDirectory() as td:
+                g1 = replay.run_native(gcfg, rscans, td, repeats=2)
+                g2 = replay.run_native(gcfg, rscans, td, repeats=2, sharded_world=2)
+            rp_stats["native"]["map_sharded_in_process"] = {
+                "n_ranks": 2, "photometric": False, "scans_per_s": round(g2["scans_per_s"], 1), "unsharded_scans_per_s": round(g1["scans_per_s"], 1),
+                "max_rank_deviation_m": g2["max_rank_deviation_m"],
+                "max_abs_translation_difference_to_unsharded_m": max(float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(g2["poses_est"], g1["poses_est"]))}
         except Exception as exc:  # noqa: BLE001 - reported, the Python figure above stands
             rp_stats["native"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
@@ -103,5 +114,28 @@ def run(E):
                     "scans_per_s_per_rank": [round(v, 1) for v in rl], "note": "total = ranks x slowest rank"}
         if err:
             rp_stats["error_rank0"] = err
+        # ... and ONE sequence with the map sharded over the ranks (host/mimosa_hip/sharded_replay.hpp over RCCL: every smoother
+        # iteration one ncclAllToAll + ncclAllReduce round over the live window, every keyframe an mh_map_insert_shard per rank)
+        sh_rate, sh_err = 0.0, None
+        if os.environ.get("MH_BENCH_DRYRUN") == "1":
+            sh_err = "dry run: several ranks on one device (RCCL cannot form the communicator)"
+        else:
+            try:
+                import dataclasses
+                gcfg = dataclasses.replace(rcfg, photometric=False)
+                dist.barrier()
+                with tempfile.TemporaryDirectory() as td:
+                    rs_ = replay.run_native(gcfg, rscans, td, repeats=2, sharded_rccl=True, timeout=150)
+                sh_rate = float(rs_["scans_per_s"])
+            except Exception as exc:  # noqa: BLE001
+                sh_err = f"{type(exc).__name__}: {exc}"[:300]
+        srates = torch.zeros(world, dtype=torch.float64, device="cuda")
+        srates[rank] = sh_rate
+        _all_reduce(srates, op=dist.ReduceOp.SUM)
+        sl = [float(v) for v in srates.cpu()]
+        rp_stats["map_sharded"] = {"mode": "ONE sequence, the map sharded over the ranks (RCCL inside the library), geometric path, window 5, 6 update iterations",
+                                   "scans_per_s": round(min(sl), 1) if min(sl) > 0 else 0.0, "scans_per_s_per_rank": [round(v, 1) for v in sl]}
+        if sh_err:
+            rp_stats["map_sharded"]["error_rank0"] = sh_err
 
     return {"sequence_replay": rp_stats}

@@ -37,3 +37,7 @@ for rep in range(30):
         for i, f in enumerate(fs):
             f.linearize(Rs[i], ts[i])
 print("done")
+for f in fs:
+    f.destroy()
+gm.release()
+ctx.close()  # (MH_WAIT_TRACE=1 prints the host side's shares at the shutdown)
