@@ -81,3 +81,18 @@ def test_fast_eigen3_matches_jacobi(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "eigen3_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_no_wrong_result_branches_in_the_product_kernels():
+    """Timing-only experiment branches that return wrong results (MH_FAKE_*) live as a patch under tools/variants/, applied to
+    a COPY of the source by tools/variant.sh — never as #ifdef branches of the product kernels; and the patch still applies."""
+    import glob
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "mimosa_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*")):
+        assert "MH_FAKE" not in open(f, errors="replace").read(), f
+    patch = os.path.join(ROOT, "tools", "variants", "fake_bounds.patch")
+    if shutil.which("patch"):
+        r = subprocess.run(["patch", "--dry-run", "-s", os.path.join(csrc, "icp_kernels.hip"), patch], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
