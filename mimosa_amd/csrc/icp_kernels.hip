@@ -2003,8 +2003,8 @@ __global__ __launch_bounds__(kThreads) void map_knn_kernel(const MapView map, co
 // chain; with several lanes per point the scan — the longest link of the chain — is split across lanes that would have had
 // nothing to do.  Per-point results are identical in every class; the order in which the rows are summed differs with the
 // class (last digits of H, like the 256 / 512 classes before).  A window batch picks its class from the batch's TOTAL: above
-// 65 536 points the machine is full at one lane per point and the lane groups' redundant lookups and plane fits would cost more
-// than the shorter chain returns.
+// 32 768 points two lanes per point would put more than one wave on a SIMD, and then the lane groups' redundant lookups and
+// plane fits cost more than the shorter chain returns (the machine is issue-bound, not latency-bound, from there on).
 #ifndef MH_QL2_MAX
 #define MH_QL2_MAX 32768
 #endif
@@ -2019,10 +2019,10 @@ static int env_or(const char * name, int dflt)
 int linearize_class(int n, int k, bool shard, long long total)
 {
   static const int ql2_max = env_or("MH_QL2_MAX", MH_QL2_MAX), ql4_max = env_or("MH_QL4_MAX", MH_QL4_MAX);  // (tuning: tools/k3_time.py)
-  const long long tot = total > 0 ? total : n;
-  if (!shard && k == 5 && tot <= 65536) {
-    if (n <= ql4_max) return 64;
-    if (n <= ql2_max) return 128;
+  const long long tot = total > 0 ? total : n;  // what decides is how many waves the LAUNCH puts on the machine's 1024 SIMDs
+  if (!shard && k == 5) {
+    if (tot <= ql4_max) return 64;
+    if (tot <= ql2_max) return 128;
   }
   return n <= 65536 ? 256 : kThreads;
 }

@@ -995,7 +995,7 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
   long long total_points = 0;  // the class of a small cloud depends on how full the machine is: the whole window's points
   for (size_t f = 0; f < n_factors; ++f) total_points += static_cast<long long>(icps[f]->n);
   // (more factors than ride in the kernel-argument segment: the staged launch form has the one-lane-per-point classes only)
-  if (n_factors > static_cast<size_t>(mh::kBatchInline)) total_points = std::max<long long>(total_points, 65537);
+  if (n_factors > static_cast<size_t>(mh::kBatchInline)) total_points = std::max<long long>(total_points, 1ll << 30);
   for (size_t f = 0; f < n_factors; ++f) {
     const mh_icp * c = icps[f];
     if (c->n == 0) continue;

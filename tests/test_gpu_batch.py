@@ -58,7 +58,8 @@ def test_batch_equals_separate_calls_and_oracle(ctx, room_world):
     got = capi.linearize_batch(fa, Rs, ts)                       # cold: every point of every factor runs k-NN
     for i in range(5):
         one = fb[i].linearize(Rs[i], ts[i])
-        _same(got[i], one)
+        # (5 x 13 107 points: the window runs one lane per point, a 13 107-point factor on its own two — same per-point results)
+        _same_up_to_summation_order(got[i], one)
         assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
         assert_state_parity(fa[i].state(), fr[i].state())
         assert np.array_equal(fa[i].state()[0], fb[i].state()[0])
@@ -67,7 +68,9 @@ def test_batch_equals_separate_calls_and_oracle(ctx, room_world):
         ts = [t + np.array([0.012, -0.009, 0.003]) for t in ts]
         got = capi.linearize_batch(fa, Rs, ts)
         for i in range(5):
-            _same(got[i], fb[i].linearize(Rs[i], ts[i]))
+            _same_up_to_summation_order(got[i], fb[i].linearize(Rs[i], ts[i]))
+            for x, y in zip(fa[i].state(), fb[i].state()):
+                assert np.array_equal(x, y, equal_nan=True)
             assert_result_parity(got[i], fr[i].linearize(Rs[i], ts[i]))
     for f in fa + fb:
         f.destroy()
