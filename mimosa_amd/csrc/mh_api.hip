@@ -995,12 +995,13 @@ static int mh_icp_linearize_batch_impl(mh_icp * const * icps, size_t n_factors, 
   long long total_points = 0;  // the class of a small cloud depends on how full the machine is: the whole window's points
   for (size_t f = 0; f < n_factors; ++f) total_points += static_cast<long long>(icps[f]->n);
   // (more factors than ride in the kernel-argument segment: the staged launch form has the one-lane-per-point classes only)
-  if (n_factors > static_cast<size_t>(mh::kBatchInline)) total_points = std::max<long long>(total_points, 1ll << 30);
+  const bool maybe_staged = n_factors > static_cast<size_t>(mh::kBatchInline);
   for (size_t f = 0; f < n_factors; ++f) {
     const mh_icp * c = icps[f];
     if (c->n == 0) continue;
     const int k = c->cfg.num_corres_points == 5 ? 5 : 8, n_off = c->map->n_off;
-    const int tpb = mh::linearize_class(static_cast<int>(c->n), static_cast<int>(c->cfg.num_corres_points), false, total_points);
+    int tpb = mh::linearize_class(static_cast<int>(c->n), static_cast<int>(c->cfg.num_corres_points), false, total_points);
+    if (maybe_staged && tpb < 256) tpb = 256;
     Group * g = nullptr;
     for (Group & q : groups)
       if (q.tpb == tpb && q.k == k && q.n_off == n_off && q.binary == c->binary) g = &q;
