@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="(kept for old command lines; the headline is one synchronous call at a time)")
     ap.add_argument("--concurrent-streams", type=int, default=4, help="size of the value_concurrent pass (0/1 = skip)")
     ap.add_argument("--profile-mode", action="store_true", help="only the warm-up and the timed region (what rocprofv3 should see)")
-    ap.add_argument("--event-every", type=int, default=10, help="HIP events bracket the kernels of every n-th call of the timed region")
+    ap.add_argument("--event-every", type=int, default=20, help="HIP events bracket the kernels of every n-th call of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-measure-traffic", action="store_true", help="skip the self-profiling rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--headline-only", action="store_true", help="skip every side leg (tools/benchlegs)")
