@@ -248,10 +248,13 @@ int mh_icp_wait(mh_icp * icp);
 /* Every live ICPFactor of the sliding window re-linearized in ONE pass: what graph::Manager::defineNoLock's
  * smoother_->update() + additional_update_iterations (src/graph/manager.cpp:585-588) make GTSAM do one factor at
  * a time.  icps[f] is linearized at (R_src + 9 f, t_src + 3 f[, R_tgt + 9 f, t_tgt + 3 f], g_unit + 3 f) into out[f];
- * results are bit-identical to n_factors separate mh_icp_linearize calls.  Factors that share a kernel instantiation —
- * workgroup size (clouds of up to 65 536 points / larger ones), num_corres_points == 5 or not, the map's neighbour mode,
- * unary / binary — form one launch group: one K3 launch and one K4 launch per group, so a window of like factors (the usual
- * case) is one launch pair and any mix is accepted.  All factors must belong to one context and have no call in flight;
+ * the per-point results (status, cached mean / normal of every point) are bit-identical to n_factors separate
+ * mh_icp_linearize calls, and so are the sums when the factor runs the same LAUNCH CLASS in both — the class follows the
+ * points of the whole launch (two lanes per point for k = 5 launches of up to 32 768 points, one lane up to 65 536, the
+ * 512-thread class above); where the window's total moves a factor to another class its rows are added in another order
+ * (H, b, f agree to ~1e-13 relative).  Factors that share a kernel instantiation — launch class, num_corres_points == 5 or
+ * not, the map's neighbour mode, unary / binary — form one launch group: one K3 launch and one K4 launch per group, so a
+ * window of like factors (the usual case) is one launch pair and any mix is accepted.  All factors must belong to one context and have no call in flight;
  * at most 64 per call.  R_tgt / t_tgt may be NULL when no factor is binary.  Blocks until every result is on the host. */
 int mh_icp_linearize_batch(mh_icp * const * icps, size_t n_factors, const double * R_src, const double * t_src,
                            const double * R_tgt, const double * t_tgt, const double * g_unit, mh_icp_result * out);
