@@ -4,8 +4,8 @@
 // (estimatePlane), src/lidar/incremental_voxel_map.cpp:26-32 -> gtsam_points::iVox::knn_search.
 // SURVEY.md Appendix A is the arithmetic spec; kernels K3 / K4 of SURVEY.md §2.3.
 //
-//   K3  icp_linearize_kernel   one thread per source point, 512-thread workgroups (one per CU at
-//       131 072 points), fused:
+//   K3  icp_linearize_kernel   one thread per source point (two for small clouds), 512-thread workgroups (one per CU at
+//       131 072 points; 256 threads below 65 536), fused:
 //         pose transform (fp64) -> data-association cache test
 //         A. neighbourhood lookup: one block-table probe + nine 12-byte loads from the block's halo'd cell
 //            table; cell words to a per-lane LDS column, quad counts packed in registers
@@ -15,17 +15,19 @@
 //         C. exact tier: the 8 survivors re-ranked in fp64 in the reference's operation order, proof check,
 //            wave-cooperative KnnResult::push for the rare lane the proof does not cover; mean / covariance /
 //            Newton cubic eigen / plane gates -> residual, Huber weight, Jacobian row
-//         D. LDS tile of rows -> every thread owns one (entry, point-segment) of the 28 (unary) or
-//            91 (binary) sums of v v^T -> per-block partial row (write-through) -> ticket -> the
-//            last-arriving block folds all rows in a fixed order and eigen-decomposes H_rr, H_tt.
+//         D. every wave: LDS tile of its rows -> a lane owns one (entry, point-segment) of the 28 (unary) or 91 (binary)
+//            sums of v v^T -> per-block partial row.  K4 follows and folds the rows; without K4 (components off) or for
+//            a map-sharded factor: rows written through -> ticket -> the last-arriving block folds them in a fixed order.
 //   K4  icp_localizability_kernel   second pass: component localizabilities in that eigenbasis
 //       (geometric_factor.hpp:434-457) + status histogram (src/lidar/geometric.cpp:280-323).
 //
 // Gather / scan / reduce work bound by VALU issue and the memory system at 2 waves per SIMD, not a dense
-// contraction: no MFMA.  Measured on MI355X (round 1): cooperating sub-groups of 2/4/8 lanes per query with
-// shuffle-min merges were 1.4x/2.5x/4.9x SLOWER than one lane per query, and finishing the heaviest lanes'
-// voxels with the whole wave was 2x slower, so the wave-level cooperation lives in the
-// reductions and in the exact fallback, not in the scan.
+// contraction: no MFMA.  At 131 072 points, where every SIMD has its two waves, one lane per query is the fastest form
+// (round 1: cooperating sub-groups of 2/4/8 lanes per query with shuffle-min merges were 1.4x/2.5x/4.9x SLOWER, and
+// finishing the heaviest lanes' voxels with the whole wave was 2x slower): there the wave-level
+// cooperation lives in the reductions and in the exact fallback, not in the scan.  Launches of up to 32 768 points —
+// the clouds the reference feeds the factor — leave most SIMDs without a wave and run TWO adjacent lanes per query
+// ("several lanes per query" below: DPP quad merges of the lanes' top-8 lists; round 6).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
