@@ -353,6 +353,10 @@ int mh_scan_preprocess_geometric(mh_scan * scan, const float R_B_L[9], const flo
                                  int max_points_per_voxel, double min_dist_in_voxel, mh_scan_info * info);
 /* Copies a stage's cloud to the host.  which: 0 points_full_, 1 Be_cloud_, 2 sm_Be_cloud_ds_. */
 int mh_scan_get_points(const mh_scan * scan, int which, mh_point32 * out, size_t capacity, size_t * n_out);
+/* The DEVICE address of a stage's cloud (which as above; valid until the scan object is prepared again or destroyed) for callers
+ * that hand it on without a copy — mh_shard_icp_create(points_on_device = 1) on a rank's share of sm_Be_cloud_ds_,
+ * mh_map_insert_device.  No reference counterpart (the reference's clouds are host members of Manager / Geometric). */
+int mh_scan_device_points(const mh_scan * scan, int which, const mh_point32 ** d_points, size_t * n_out);
 /* geometric_point_idxs_ (indices into points_full_) / the indices into Be_cloud_ that the down-sampler kept. */
 int mh_scan_get_indices(const mh_scan * scan, int which, uint32_t * out, size_t capacity, size_t * n_out);
 /* ICPFactor ctor (geometric_factor.hpp:119-142) with sm_Be_cloud_ds_ taken from the device. */
@@ -532,6 +536,9 @@ int mh_init_on_stream(int device, void * hip_stream, mh_ctx ** out);
 /* This rank's share of IncrementalVoxelMapPCL::insert: of the batch (identical on every rank) the points of owned shard
  * blocks plus their one-voxel halo are inserted, in the original order. */
 int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride_floats, int world, int rank, int block_log2);
+/* The same for the resident scan's Be_cloud_ with Geometric::updateMap's f32 world transform (geometric.cpp:483-495) applied
+ * first: mh_map_insert_from_scan for ONE RANK's shard — transform, shard filter and insert on the device, nothing crosses PCIe. */
+int mh_map_insert_shard_from_scan(mh_map * map, const mh_scan * scan, const float R_W_Be[9], const float t_W_Be[3], int world, int rank, int block_log2);
 /* ICPFactor ctor (geometric_factor.hpp:119-142) from a cloud that is already on the device; the point order is kept. */
 int mh_icp_create_from_device(mh_ctx * ctx, mh_map * map, const mh_point32 * d_points, size_t n, const mh_reg_config * cfg,
                               int is_binary, mh_icp ** out);

@@ -29,7 +29,7 @@ EXPORTS = [
     "mh_scan_preprocess_geometric", "mh_scan_get_points", "mh_scan_get_indices", "mh_icp_create_from_scan",
     "mh_init_on_stream", "mh_map_insert_shard", "mh_icp_create_from_device", 
     "mh_shard_unique_id", "mh_shard_comm_init_rccl", "mh_shard_comm_init_local", "mh_shard_comm_destroy", "mh_shard_comm_world", "mh_shard_comm_rank",
-    "mh_shard_comm_backend", "mh_shard_comm_info", "mh_shard_owner_of_block", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
+    "mh_shard_comm_backend", "mh_shard_comm_info", "mh_shard_owner_of_block", "mh_map_insert_shard_from_scan", "mh_scan_device_points", "mh_shard_icp_create", "mh_shard_icp_linearize", "mh_shard_icp_linearize_async", "mh_shard_icp_linearize_batch",
     "mh_shard_icp_linearize_batch_async", "mh_shard_icp_wait", "mh_shard_icp_reset", "mh_shard_icp_set_components", "mh_shard_icp_get_state",
     "mh_shard_icp_stats", "mh_shard_icp_destroy", "mh_alloc_check_stats",
     "mh_photo_create", "mh_photo_destroy", "mh_photo_preprocess", "mh_scan_keep_raw", "mh_photo_preprocess_scan", "mh_photo_preprocess_scan_begin", "mh_photo_preprocess_commit", "mh_photo_detect_prefetch", "mh_photo_get_image",
@@ -375,6 +375,8 @@ def load(build_if_missing: bool = True):
     L.mh_icp_create_from_scan.argtypes = [vp, vp, vp, C.POINTER(RegConfig), i32, pvp]
     L.mh_init_on_stream.argtypes = [i32, vp, pvp]
     L.mh_map_insert_shard.argtypes = [vp, vp, sz, sz, i32, i32, i32]
+    L.mh_map_insert_shard_from_scan.argtypes = [vp, vp, vp, vp, i32, i32, i32]
+    L.mh_scan_device_points.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
     L.mh_icp_create_from_device.argtypes = [vp, vp, vp, sz, C.POINTER(RegConfig), i32, pvp]
     L.mh_shard_unique_id.argtypes = [vp]
     L.mh_shard_comm_init_rccl.argtypes = [vp, vp, i32, i32, pvp]
@@ -923,6 +925,13 @@ def alloc_check_stats():
     if load().mh_alloc_check_stats(C.byref(a), C.byref(b)) != 0:
         return None
     return int(a.value), int(b.value)
+
+
+def map_insert_shard_from_scan(ctx: Context, vmap: VoxelMap, scan, R_W_Be, t_W_Be, world: int, rank: int, block_log2: int = 3):
+    """mh_map_insert_shard_from_scan: one rank's share of Geometric::updateMap's insert of the resident scan's Be_cloud_, on the device."""
+    R = np.ascontiguousarray(R_W_Be, np.float32)
+    t = np.ascontiguousarray(t_W_Be, np.float32)
+    ctx.check(ctx.L.mh_map_insert_shard_from_scan(vmap.h, scan.h, _p(R), _p(t), world, rank, block_log2))
 
 
 def map_insert_shard(ctx: Context, vmap: VoxelMap, xyz, world: int, rank: int, block_log2: int = 3):

@@ -408,6 +408,49 @@ int mh_map_insert_shard(mh_map * map, const float * xyz, size_t n, size_t stride
   });
 }
 
+// This rank's share of Geometric::updateMap's insert of a device-resident scan: the f32 world transform of the body cloud
+// (mh_transform_f32's kernel, the arithmetic of geometric.cpp:483-490), the shard filter and the greedy insert, all on the
+// device — what mh_scan_get_points + mh_transform_f32 + mh_map_insert_shard do through the host, without the three copies.
+int mh_map_insert_shard_from_scan(mh_map * map, const mh_scan * scan, const float R_W_Be[9], const float t_W_Be[3], int world, int rank, int block_log2)
+{
+  if (!map || !scan || !R_W_Be || !t_W_Be) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert_shard_from_scan: NULL argument");
+  mh_ctx * ctx = map->ctx;
+  return guarded(ctx, "mh_map_insert_shard_from_scan", [&]() -> int {
+    if (!scan->preprocessed) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard_from_scan: no mh_scan_preprocess_geometric before");
+    if (scan->ctx->device != ctx->device) return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard_from_scan: scan lives on another device");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || block_log2 < 0 || block_log2 > 10)
+      return fail(ctx, MH_ERR_INVALID_ARG, "mh_map_insert_shard_from_scan: world in 1..64, 0 <= rank < world, block_log2 in 0..10");
+    MH_HIP(ctx, mh_enter(ctx));
+    const size_t n = scan->n_body;
+    size_t kept = 0;
+    if (n) {
+      if (n > 0x3fffffffu) return fail(ctx, MH_ERR_UNSUPPORTED, "mh_map_insert_shard_from_scan: batch too large");
+      float rt[12];
+      std::memcpy(rt, R_W_Be, 9 * sizeof(float));
+      std::memcpy(rt + 9, t_W_Be, 3 * sizeof(float));
+      MH_HIP(ctx, map->s_rt.reserve(sizeof(rt), ctx->stream, false));
+      MH_HIP(ctx, hipMemcpyAsync(map->s_rt.p, rt, sizeof(rt), hipMemcpyHostToDevice, ctx->stream));
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rt is a stack buffer
+      // a copy of the body cloud (the scan keeps its own), transformed in place; the filter reads xyz at the records' stride
+      MH_HIP(ctx, map->s_in.reserve(n * sizeof(mh_point32), ctx->stream, false));
+      MH_HIP(ctx, hipMemcpyAsync(map->s_in.p, scan->d_body.p, n * sizeof(mh_point32), hipMemcpyDeviceToDevice, ctx->stream));
+      MH_HIP(ctx, mh::launch_transform(static_cast<mh_point32 *>(map->s_in.p), static_cast<int>(n), static_cast<const float *>(map->s_rt.p), ctx->stream));
+      MH_HIP(ctx, map->s_flags.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, map->s_pos.reserve(n * sizeof(uint32_t), ctx->stream, false));
+      MH_HIP(ctx, map->s_temp.reserve(mh::shard_temp_bytes(n) > mh::map_temp_bytes(n) ? mh::shard_temp_bytes(n) : mh::map_temp_bytes(n), ctx->stream, false));
+      MH_HIP(ctx, map->s_shard.reserve(n * 3 * sizeof(float), ctx->stream, false));
+      MH_HIP(ctx, mh::launch_shard_filter(static_cast<const float *>(map->s_in.p), static_cast<uint32_t>(n), static_cast<uint32_t>(sizeof(mh_point32) / sizeof(float)),
+                                          map->inv_leaf, static_cast<uint32_t>(world), static_cast<uint32_t>(rank), block_log2,
+                                          static_cast<uint32_t *>(map->s_flags.p), static_cast<uint32_t *>(map->s_pos.p), static_cast<float *>(map->s_shard.p),
+                                          &map->d_state->n_keep, map->s_temp.p, map->s_temp.cap, ctx->stream));
+      const int rc = fetch_state(map);
+      if (rc != MH_OK) return rc;
+      kept = map->h_state->n_keep;
+    }
+    return insert_device(map, static_cast<const float *>(map->s_shard.p), kept, 3, nullptr);
+  });
+}
+
 int mh_map_insert_device(mh_map * map, const void * d_points, size_t n, size_t stride_floats, const float * R, const float * t)
 {
   if (!map || (!d_points && n)) return fail(map ? map->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_map_insert_device: NULL argument");

@@ -1634,6 +1634,17 @@ int mh_scan_get_points(const mh_scan * s, int which, mh_point32 * out, size_t ca
   return guarded(s ? s->ctx : nullptr, "mh_scan_get_points", [&]() -> int { return mh_scan_get_points_impl(s, which, out, capacity, n_out); });
 }
 
+int mh_scan_device_points(const mh_scan * s, int which, const mh_point32 ** d_points, size_t * n_out)
+{
+  if (!s || !d_points || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_device_points: NULL argument");
+  if (!s->prepared || (which != 0 && !s->preprocessed) || which < 0 || which > 2)
+    return fail(s->ctx, MH_ERR_INVALID_ARG, "mh_scan_device_points: that stage has not run");
+  const DevBuf & b = which == 0 ? s->d_full : (which == 1 ? s->d_body : s->d_ds);
+  *d_points = static_cast<const mh_point32 *>(b.p);
+  *n_out = which == 0 ? s->c.n_full : (which == 1 ? s->n_body : s->c.n_downsampled);
+  return MH_OK;
+}
+
 static int mh_scan_get_indices_impl(const mh_scan * s, int which, uint32_t * out, size_t capacity, size_t * n_out)
 {
   if (!s || !n_out) return fail(s ? s->ctx : nullptr, MH_ERR_INVALID_ARG, "mh_scan_get_indices: NULL argument");

@@ -210,6 +210,14 @@ public:
       comm_->context()->check(mh_map_insert_shard(map_->underlying(), &cloud[0].x, cloud.size(), sizeof(Point) / sizeof(float), comm_->world(), comm_->rank(), block_log2_),
                               "mh_map_insert_shard");
   }
+  // Geometric::updateMap's insert (geometric.cpp:483-495) of a device-resident scan's Be_cloud_: f32 world transform, shard
+  // filter and greedy insert on the GPU — this rank's part of IncrementalVoxelMapPCL::insertBodyCloud
+  void insertBodyCloud(mh_scan * scan, const Pose3 & T_W_Be)
+  {
+    float Rt[12];
+    toFloat12(T_W_Be, Rt);
+    comm_->context()->check(mh_map_insert_shard_from_scan(map_->underlying(), scan, Rt, Rt + 9, comm_->world(), comm_->rank(), block_log2_), "mh_map_insert_shard_from_scan");
+  }
   // Successor for copy-then-insert (Geometric::updateMap, geometric.cpp:494-495): a device-to-device copy of THIS rank's shard;
   // this object stays valid and unchanged for the factors that hold it.  Every rank forks at the same keyframes.
   Ptr fork() const
@@ -240,6 +248,13 @@ public:
   : NonlinearFactor(KeyVector{key_source}), is_binary_(false), impl_(std::make_shared<Impl>(shard))
   {
     create(cloud_share, config, force_collectives);
+  }
+  // unary, the rank's share already on the device (a slice of a resident scan's sm_Be_cloud_ds_: mh_scan_device_points)
+  ShardedICPFactor(const Key key_source, const ShardedVoxelMap::Ptr & shard, const mh_point32 * d_share, size_t n_share, const RegistrationConfig & config,
+                   bool force_collectives = false)
+  : NonlinearFactor(KeyVector{key_source}), is_binary_(false), impl_(std::make_shared<Impl>(shard))
+  {
+    create(d_share, n_share, true, config, force_collectives);
   }
   // binary (:131-142)
   ShardedICPFactor(const Key key_source, const Key key_target, const ShardedVoxelMap::Ptr & shard, const PointCloud & cloud_share,
@@ -351,12 +366,13 @@ private:
     mh_icp_result last;
   };
   ShardedICPFactor(const ShardedICPFactor & o) : NonlinearFactor(KeyVector(o.keys())), is_binary_(o.is_binary_), impl_(o.impl_) {}
-  void create(const PointCloud & cloud, const RegistrationConfig & config, bool force)
+  void create(const PointCloud & cloud, const RegistrationConfig & config, bool force) { create(cloud.data(), cloud.size(), false, config, force); }
+  void create(const mh_point32 * points, size_t n, bool on_device, const RegistrationConfig & config, bool force)
   {
     mh_shard_config sc{};
     sc.block_log2 = impl_->shard->blockLog2();
     sc.force_collectives = force ? 1 : 0;
-    ctx().check(mh_shard_icp_create(ctx().get(), impl_->shard->communicator()->underlying(), impl_->shard->map()->underlying(), cloud.data(), cloud.size(), 0, &config,
+    ctx().check(mh_shard_icp_create(ctx().get(), impl_->shard->communicator()->underlying(), impl_->shard->map()->underlying(), points, n, on_device ? 1 : 0, &config,
                                     is_binary_ ? 1 : 0, &sc, &impl_->icp),
                 "mh_shard_icp_create");
   }

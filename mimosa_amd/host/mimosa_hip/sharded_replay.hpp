@@ -33,24 +33,23 @@ public:
     shard_ = std::make_shared<lidar::ShardedVoxelMap>(comm, g, block_log2);
   }
   void seed(const float * xyz, size_t n) { shard_->insert(xyz, n); }
-  // this rank's share of sm_Be_cloud_ds_ (any split does: the first linearize routes every point to the owner of its voxel)
+  // this rank's share of sm_Be_cloud_ds_ (any split does: the first linearize routes every point to the owner of its voxel),
+  // taken where the front end left it — on the device
   Factor::Ptr makeFactor(const Key Xk, lidar::ScanFrontEnd & scan, const lidar::RegistrationConfig & reg)
   {
-    const lidar::PointCloud ds = scan.download(2);
+    const mh_point32 * d_ds = nullptr;
+    size_t n = 0;
+    comm_->context()->check(mh_scan_device_points(scan.underlying(), 2, &d_ds, &n), "mh_scan_device_points");
     const size_t w = static_cast<size_t>(comm_->world()), r = static_cast<size_t>(comm_->rank());
-    const lidar::PointCloud share(ds.begin() + static_cast<std::ptrdiff_t>(ds.size() * r / w), ds.begin() + static_cast<std::ptrdiff_t>(ds.size() * (r + 1) / w));
-    return std::make_shared<Factor>(Xk, shard_, share, reg, force_);
+    const size_t lo = n * r / w, hi = n * (r + 1) / w;
+    return std::make_shared<Factor>(Xk, shard_, d_ds + lo, hi - lo, reg, force_);
   }
-  // Geometric::updateMap's insert (geometric.cpp:483-495): Be_cloud_ into the world frame in f32, then this rank's part of it
+  // Geometric::updateMap's insert (geometric.cpp:483-495): copy-then-insert of this rank's shard, the scan's Be_cloud_ transformed,
+  // filtered and inserted on the device
   void keyframe(lidar::ScanFrontEnd & scan, const Pose3 & T_W_Be)
   {
     shard_ = shard_->fork();
-    lidar::PointCloud W = scan.download(1);
-    float Rt[12];
-    toFloat12(T_W_Be, Rt);
-    const auto & ctx = comm_->context();
-    if (!W.empty()) ctx->check(mh_transform_f32(ctx->get(), W.data(), W.size(), Rt, Rt + 9), "mh_transform_f32");
-    shard_->insert(W);
+    shard_->insertBodyCloud(scan.underlying(), T_W_Be);
   }
 
 private:

@@ -138,3 +138,40 @@ def test_insert_from_resident_scan(ctx, small_world):
     for g in (ga, gb):
         g.release()
     sc.destroy()
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_insert_shard_from_resident_scan(ctx, small_world, world):
+    """mh_map_insert_shard_from_scan — one rank's share of Geometric::updateMap's insert, transform + shard filter + insert on the
+    device — == the host route (download Be_cloud_, mh_transform_f32, mh_map_insert_shard), rank by rank; and the ranks' shards
+    together hold the unsharded map's points."""
+    from mimosa_amd import capi, synth
+
+    raw, aux = synth.make_raw_scan(16, n_cols=64, room=(6.0, 5.0, 3.0), sensor_local=np.array([2.3, 2.6, 1.2]))
+    sc = capi.Scan(ctx)
+    sc.prepare_input(raw, capi.make_input_config())
+    sc.deskew(aux["Rt12"][np.searchsorted(aux["unique_ns"], sc.unique_ns())])
+    sc.preprocess_geometric(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+    body = sc.points(capi.Scan.BODY)
+    R, t = aux["R_W_L"], aux["t_W_L"]
+    W = ctx.transform_f32(body, R.astype(np.float32), t.astype(np.float32))
+    Wx = np.stack([W["x"], W["y"], W["z"]], 1)
+    whole = capi.VoxelMap(ctx)
+    whole.insert(small_world["map_xyz"])
+    whole.insert(Wx)
+    want = {tuple(p) for p in whole.get_cloud()}
+    seen = set()
+    for rank in range(world):
+        ga, gb = capi.VoxelMap(ctx), capi.VoxelMap(ctx)
+        for g in (ga, gb):
+            capi.map_insert_shard(ctx, g, small_world["map_xyz"], world, rank, 2)
+        capi.map_insert_shard_from_scan(ctx, ga, sc, R, t, world, rank, 2)
+        capi.map_insert_shard(ctx, gb, Wx, world, rank, 2)
+        ca, cb = ga.get_cloud(), gb.get_cloud()
+        assert np.array_equal(ca, cb), rank
+        seen |= {tuple(p) for p in ca}
+        ga.release()
+        gb.release()
+    assert seen == want          # owned blocks + halos cover the map; nothing a rank holds is foreign to it
+    whole.release()
+    sc.destroy()
