@@ -73,8 +73,8 @@ int ensure_blocks(mh_map * m, size_t n, size_t n_initialised)
     MH_HIP(ctx, m->d_cells.reserve(cap * mh::kCellsPerBlock * sizeof(uint32_t), ctx->stream, true));
     m->block_cap = cap;
   }
+  static_assert(mh::kEmptyCell == 0u, "the byte pattern of the fill below");
   if (n > n_initialised)
-    static_assert(mh::kEmptyCell == 0u, "the byte pattern of the fill below");
     MH_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(m->d_cells.p) + n_initialised * mh::kCellsPerBlock, 0x00,
                                (n - n_initialised) * mh::kCellsPerBlock * sizeof(uint32_t), ctx->stream));
   return MH_OK;
